@@ -1,0 +1,138 @@
+! TEST INFRASTRUCTURE (oracle/_ref recipe) -- not part of the product path.
+!
+! Interposers that let the *unmodified* reference objects (compiled from the
+! sources where they lie under /root/reference, never copied) record every
+! DISORT call that `program sbdart` makes.  build_ref.sh renames the reference
+! definitions with llvm-objcopy
+!     disort_   -> disort_ref_     (disort.o)
+!     depthscl_ -> depthscl_ref_   (taugas.o)
+!     filter_   -> filter_ref_     (spectra.o)
+! and links these same-named wrappers in their place, so drt.o's call sites
+! (drt.f:531-533 depthscl, drt.f:461 filter, drt.f:541-546 DISORT) land here.
+!
+! Record layout: see sbdart_amd/records.py (the single definition of the
+! "SBDREC1" stream format).  Inputs are written BEFORE the reference call
+! because DISORT mutates SSALB/DTAUC/PMOM(0,:)/NUMU/UMU/NTAU/NSTR
+! (disort.f:486, 4944, 2544, 2655-2669, 2526, 2650).
+
+module sbd_capture_state
+  implicit none
+  integer, parameter :: dp = selected_real_kind(10)
+  integer :: rec_unit = -1
+  integer :: cur_kd = 0, cur_nk = 0, cur_iwl = 0
+  real(dp) :: cur_wl = 0, cur_wt = 0, cur_ff = 1, last_wl = -1
+contains
+  subroutine capture_open()
+    character(len=1024) :: path
+    integer :: n, stat
+    if (rec_unit >= 0) return
+    call get_environment_variable('SBD_CAPTURE_FILE', path, n, stat)
+    if (stat /= 0 .or. n <= 0) then
+      path = 'disort_capture.sbdrec'
+      n = len_trim(path)
+    end if
+    rec_unit = 77
+    open(rec_unit, file=path(1:n), access='stream', form='unformatted', &
+         status='replace')
+    ! header: magic, nrec (-1 = until EOF), has_out
+    write(rec_unit) 'SBDREC1'//char(0), -1, 1
+  end subroutine
+end module sbd_capture_state
+
+subroutine depthscl(kdist, kd, nk, ib, nz, wl, dtaur, dtaua, &
+     waer, dtauc, wcld, spowder, gwk, dtauk, dtaugc, wt, dtau, wreal, idb)
+  use sbd_capture_state
+  implicit none
+  integer :: kdist, kd, nk, ib, nz, idb
+  real(dp) :: wl, dtaur(*), dtaua(*), waer(*), dtauc(*), wcld(*), &
+       gwk(*), dtauk(65,*), dtaugc(*), wt, dtau(*), wreal(*)
+  logical :: spowder
+  external depthscl_ref
+  call depthscl_ref(kdist, kd, nk, ib, nz, wl, dtaur, dtaua, &
+       waer, dtauc, wcld, spowder, gwk, dtauk, dtaugc, wt, dtau, wreal, idb)
+  cur_kd = kd
+  cur_nk = nk
+  cur_wt = wt
+  if (wl /= last_wl) then
+    cur_iwl = cur_iwl + 1
+    last_wl = wl
+  end if
+  cur_wl = wl
+end subroutine depthscl
+
+function filter(w)
+  use sbd_capture_state
+  implicit none
+  real(dp) :: w, filter
+  real(dp), external :: filter_ref
+  filter = filter_ref(w)
+  cur_ff = filter
+end function filter
+
+subroutine disort(nlyr, dtauc, ssalb, corint, nmom, pmom, temper, &
+     wvnmlo, wvnmhi, usrtau, ntau, utau, nstr, usrang, numu, umu, &
+     nphi, phi, ibcnd, fbeam, umu0, phi0, fisot, lamber, albedo, &
+     btemp, ttemp, temis, plank, onlyfl, accur, prnt, header, &
+     maxcly, maxulv, maxumu, maxphi, maxmom, rfldir, rfldn, flup, &
+     dfdt, uavg, uu, albmed, trnmed)
+  use sbd_capture_state
+  implicit none
+  character header*127
+  logical :: lamber, onlyfl, plank, usrang, usrtau, corint
+  integer :: ibcnd, maxcly, maxmom, maxphi, maxulv, maxumu, nlyr, &
+       nmom, nphi, nstr, ntau, numu
+  real(dp) :: accur, albedo, btemp, fbeam, fisot, phi0, temis, ttemp, &
+       umu0, wvnmhi, wvnmlo
+  logical :: prnt(5)
+  real(dp) :: albmed(maxumu), dfdt(maxulv), dtauc(maxcly), flup(maxulv), &
+       phi(maxphi), pmom(0:maxmom, maxcly), rfldir(maxulv), rfldn(maxulv), &
+       ssalb(maxcly), temper(0:maxcly), trnmed(maxumu), uavg(maxulv), &
+       umu(maxumu), utau(maxulv), uu(maxumu, maxulv, maxphi)
+  external disort_ref
+  integer :: flags, lc, k, j, lu, iu, numu_in, nphi_in
+  integer :: hdr(12), ohdr(4)
+  real(dp) :: sc(16)
+
+  call capture_open()
+
+  flags = 0
+  if (plank)  flags = flags + 1
+  if (onlyfl) flags = flags + 2
+  if (lamber) flags = flags + 4
+  if (usrang) flags = flags + 8
+  numu_in = 0
+  nphi_in = 0
+  if (usrang) numu_in = numu
+  if (.not. onlyfl) nphi_in = nphi
+  hdr = 0
+  hdr(1) = nlyr;  hdr(2) = nstr;  hdr(3) = nmom;  hdr(4) = numu_in
+  hdr(5) = nphi_in; hdr(6) = flags; hdr(7) = cur_kd; hdr(8) = cur_nk
+  hdr(9) = cur_iwl; hdr(10) = ibcnd
+  sc = 0
+  sc(1) = cur_wl;  sc(2) = cur_wt;  sc(3) = cur_ff
+  sc(4) = wvnmlo;  sc(5) = wvnmhi;  sc(6) = fbeam;  sc(7) = umu0
+  sc(8) = phi0;    sc(9) = albedo;  sc(10) = btemp; sc(11) = ttemp
+  sc(12) = temis;  sc(13) = fisot;  sc(14) = accur
+  write(rec_unit) hdr, sc
+  write(rec_unit) (dtauc(lc), lc=1,nlyr), (ssalb(lc), lc=1,nlyr), &
+       (temper(lc), lc=0,nlyr), ((pmom(k,lc), k=0,nmom), lc=1,nlyr), &
+       (umu(iu), iu=1,numu_in), (phi(j), j=1,nphi_in)
+
+  call disort_ref(nlyr, dtauc, ssalb, corint, nmom, pmom, temper, &
+       wvnmlo, wvnmhi, usrtau, ntau, utau, nstr, usrang, numu, umu, &
+       nphi, phi, ibcnd, fbeam, umu0, phi0, fisot, lamber, albedo, &
+       btemp, ttemp, temis, plank, onlyfl, accur, prnt, header, &
+       maxcly, maxulv, maxumu, maxphi, maxmom, rfldir, rfldn, flup, &
+       dfdt, uavg, uu, albmed, trnmed)
+
+  ohdr = 0
+  ohdr(1) = nstr; ohdr(2) = nlyr + 1; ohdr(3) = numu_in
+  write(rec_unit) ohdr
+  write(rec_unit) (rfldir(lu), lu=1,nlyr+1), (rfldn(lu), lu=1,nlyr+1), &
+       (flup(lu), lu=1,nlyr+1), (dfdt(lu), lu=1,nlyr+1), &
+       (uavg(lu), lu=1,nlyr+1)
+  if (.not. onlyfl) then
+    write(rec_unit) (((uu(iu,lu,j), iu=1,numu_in), lu=1,nlyr+1), j=1,nphi_in)
+  end if
+  flush(rec_unit)
+end subroutine disort
