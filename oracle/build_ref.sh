@@ -10,6 +10,8 @@
 #                                (symbol renames by llvm-objcopy -- no source edits)
 #   oracle/_ref/disort_ref_cli   reference DISORT behind a record-file CLI
 #                                (oracle/ref/sbd_ref_cli.f90)
+#   oracle/_ref/ref_units_cli    single reference routines (QGAUSN, PLKAVG, ASYMTX,
+#                                LEPOLY, SGBCO/SGBSL) behind a CLI (oracle/ref/sbd_ref_units.f90)
 #
 # Compiler: amdflang (flang, ROCm 7.2); gfortran is not in the image.  The
 # flang runtime is linked statically, so the binaries run on the GPU box.
@@ -46,4 +48,7 @@ done
 # --- reference DISORT behind a CLI (BDREF stubbed: Lambertian only) ---
 "$FC" $FFLAGS -c "$HERE/ref/sbd_ref_cli.f90" -o sbd_ref_cli.o
 "$FC" $FFLAGS -o "$OUT/disort_ref_cli" sbd_ref_cli.o disort.o disutil.o params.o
+# --- individual reference routines behind a CLI (unit pinning) ---
+"$FC" $FFLAGS -c "$HERE/ref/sbd_ref_units.f90" -o sbd_ref_units.o
+"$FC" $FFLAGS -o "$OUT/ref_units_cli" sbd_ref_units.o disort.o disutil.o params.o
 echo "built: $(ls "$OUT" | grep -v obj | tr '\n' ' ')"

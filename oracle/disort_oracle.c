@@ -1,0 +1,1750 @@
+/*
+ * TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  See disort_oracle.h.
+ *
+ * Plain-C fp64 restatement of the DISORT solve the reference performs for one
+ * (wavelength, k-term) work item.  Every function cites the reference
+ * file:line it follows.  Layouts are compact (no MXCMU/MXCLY padding, no
+ * ZEROAL of max-dim work arrays) and the routine is stateless; numerics follow
+ * the reference statement by statement, including its fp32-widened constants
+ * (every un-suffixed Fortran real literal is rounded to fp32, then widened).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (oracle/Makefile).
+ */
+#include "disort_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- column-major, 1-based accessors (Fortran order) ------------------ */
+#define F2(a, ld, i, j) (a)[((size_t)(j) - 1) * (size_t)(ld) + ((size_t)(i) - 1)]
+
+static inline double f32(float x) { return (double)x; }
+static inline double dsign(double a, double b) { return (b >= 0.0) ? fabs(a) : -fabs(a); }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+/* disort.f:441  PI = 2.*ASIN(1.0): single-precision intrinsic, widened */
+double sbdo_pi(void) { return (double)(2.0f * asinf(1.0f)); }
+/* disort.f:442-448  DITHER = 10*R1MACH(4), x10 when < 1e-10; R1MACH(4)=2^-52 */
+double sbdo_dither(void) { return 10.0 * (10.0 * DBL_EPSILON); }
+
+/* ======================================================================
+ * BLAS-1 / LINPACK (disutil.f:426-2102).  The solve path (SGxFA + SGxSL,
+ * JOB=0) is reduction-free, so only the pivot rule and column order matter.
+ * ==================================================================== */
+
+/* disutil.f:2018-2076 ISAMAX: first index of max |x| (strict <) */
+static int isamax(int n, const double *sx)
+{
+    if (n <= 0) return 0;
+    if (n == 1) return 1;
+    double smax = 0.0;
+    int idx = 0; /* reference leaves 0 when all entries are 0 or NaN */
+    for (int i = 1; i <= n; ++i) {
+        double xmag = fabs(sx[i - 1]);
+        if (smax < xmag) { smax = xmag; idx = i; }
+    }
+    return idx;
+}
+/* disutil.f:1672-1758 SAXPY (unit stride; element-wise, order-free) */
+static void saxpy(int n, double sa, const double *sx, double *sy)
+{
+    if (n <= 0 || sa == 0.0) return;
+    for (int i = 0; i < n; ++i) sy[i] = sy[i] + sa * sx[i];
+}
+/* disutil.f:1847 SSCAL */
+static void sscal(int n, double sa, double *sx)
+{
+    for (int i = 0; i < n; ++i) sx[i] = sa * sx[i];
+}
+/* disutil.f:1611 SASUM, 1760 SDOT -- used only by the RCOND estimate */
+static double sasum(int n, const double *sx)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += fabs(sx[i]);
+    return s;
+}
+static double sdot(int n, const double *sx, const double *sy)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += sx[i] * sy[i];
+    return s;
+}
+
+/* disutil.f:771-918 SGBFA */
+void sbdo_sgbfa(double *abd, int lda, int n, int ml, int mu, int *ipvt, int *info)
+{
+#define ABD(i, j) F2(abd, lda, i, j)
+    int m = ml + mu + 1;
+    *info = 0;
+    int j0 = mu + 2, j1 = imin(n, m) - 1;
+    for (int jz = j0; jz <= j1; ++jz) {
+        int i0 = m + 1 - jz;
+        for (int i = i0; i <= ml; ++i) ABD(i, jz) = 0.0;
+    }
+    int jz = j1, ju = 0;
+    for (int k = 1; k <= n - 1; ++k) {
+        int kp1 = k + 1;
+        jz = jz + 1;
+        if (jz <= n)
+            for (int i = 1; i <= ml; ++i) ABD(i, jz) = 0.0;
+        int lm = imin(ml, n - k);
+        int l = isamax(lm + 1, &ABD(m, k)) + m - 1;
+        ipvt[k - 1] = l + k - m;
+        if (ABD(l, k) == 0.0) {
+            *info = k;
+        } else {
+            if (l != m) { double t = ABD(l, k); ABD(l, k) = ABD(m, k); ABD(m, k) = t; }
+            double t = -1.0 / ABD(m, k);
+            sscal(lm, t, &ABD(m + 1, k));
+            ju = imin(imax(ju, mu + ipvt[k - 1]), n);
+            int mm = m;
+            for (int j = kp1; j <= ju; ++j) {
+                l = l - 1;
+                mm = mm - 1;
+                t = ABD(l, j);
+                if (l != mm) { ABD(l, j) = ABD(mm, j); ABD(mm, j) = t; }
+                saxpy(lm, t, &ABD(m + 1, k), &ABD(mm + 1, j));
+            }
+        }
+    }
+    ipvt[n - 1] = n;
+    if (ABD(m, n) == 0.0) *info = n;
+#undef ABD
+}
+
+/* disutil.f:920-1092 SGBSL, JOB=0 */
+void sbdo_sgbsl(const double *abd, int lda, int n, int ml, int mu, const int *ipvt, double *b)
+{
+#define ABD(i, j) F2(abd, lda, i, j)
+    int m = mu + ml + 1, nm1 = n - 1;
+    if (ml != 0) {
+        for (int k = 1; k <= nm1; ++k) {
+            int lm = imin(ml, n - k);
+            int l = ipvt[k - 1];
+            double t = b[l - 1];
+            if (l != k) { b[l - 1] = b[k - 1]; b[k - 1] = t; }
+            saxpy(lm, t, &ABD(m + 1, k), &b[k]);
+        }
+    }
+    for (int kb = 1; kb <= n; ++kb) {
+        int k = n + 1 - kb;
+        b[k - 1] = b[k - 1] / ABD(m, k);
+        int lm = imin(k, m) - 1;
+        int la = m - lm, lb = k - lm;
+        double t = -b[k - 1];
+        saxpy(lm, t, &ABD(la, k), &b[lb - 1]);
+    }
+#undef ABD
+}
+
+/* disutil.f:426-769 SGBCO: factor + 1-norm reciprocal condition estimate */
+double sbdo_sgbco(double *abd, int lda, int n, int ml, int mu, int *ipvt, double *z)
+{
+#define ABD(i, j) F2(abd, lda, i, j)
+    double anorm = 0.0;
+    int l = ml + 1, is = l + mu, info;
+    for (int j = 1; j <= n; ++j) {
+        double s = sasum(l, &ABD(is, j));
+        if (s > anorm) anorm = s;
+        if (is > ml + 1) is = is - 1;
+        if (j <= mu) l = l + 1;
+        if (j >= n - ml) l = l - 1;
+    }
+    sbdo_sgbfa(abd, lda, n, ml, mu, ipvt, &info);
+
+    double ek = 1.0, s, sm, t, wk, wkm, ynorm;
+    for (int j = 0; j < n; ++j) z[j] = 0.0;
+    int m = ml + mu + 1, ju = 0;
+    for (int k = 1; k <= n; ++k) {
+        if (z[k - 1] != 0.0) ek = dsign(ek, -z[k - 1]);
+        if (fabs(ek - z[k - 1]) > fabs(ABD(m, k))) {
+            s = fabs(ABD(m, k)) / fabs(ek - z[k - 1]);
+            sscal(n, s, z);
+            ek = s * ek;
+        }
+        wk = ek - z[k - 1];
+        wkm = -ek - z[k - 1];
+        s = fabs(wk);
+        sm = fabs(wkm);
+        if (ABD(m, k) != 0.0) { wk = wk / ABD(m, k); wkm = wkm / ABD(m, k); }
+        else { wk = 1.0; wkm = 1.0; }
+        int kp1 = k + 1;
+        ju = imin(imax(ju, mu + ipvt[k - 1]), n);
+        int mm = m;
+        if (kp1 <= ju) {
+            for (int j = kp1; j <= ju; ++j) {
+                mm = mm - 1;
+                sm = sm + fabs(z[j - 1] + wkm * ABD(mm, j));
+                z[j - 1] = z[j - 1] + wk * ABD(mm, j);
+                s = s + fabs(z[j - 1]);
+            }
+            if (s < sm) {
+                t = wkm - wk;
+                wk = wkm;
+                mm = m;
+                for (int j = kp1; j <= ju; ++j) { mm = mm - 1; z[j - 1] = z[j - 1] + t * ABD(mm, j); }
+            }
+        }
+        z[k - 1] = wk;
+    }
+    s = 1.0 / sasum(n, z);
+    sscal(n, s, z);
+    for (int kb = 1; kb <= n; ++kb) {
+        int k = n + 1 - kb;
+        int lm = imin(ml, n - k);
+        if (k < n) z[k - 1] = z[k - 1] + sdot(lm, &ABD(m + 1, k), &z[k]);
+        if (fabs(z[k - 1]) > 1.0) { s = 1.0 / fabs(z[k - 1]); sscal(n, s, z); }
+        int lp = ipvt[k - 1];
+        t = z[lp - 1]; z[lp - 1] = z[k - 1]; z[k - 1] = t;
+    }
+    s = 1.0 / sasum(n, z);
+    sscal(n, s, z);
+    ynorm = 1.0;
+    for (int k = 1; k <= n; ++k) {
+        int lp = ipvt[k - 1];
+        t = z[lp - 1]; z[lp - 1] = z[k - 1]; z[k - 1] = t;
+        int lm = imin(ml, n - k);
+        if (k < n) saxpy(lm, t, &ABD(m + 1, k), &z[k]);
+        if (fabs(z[k - 1]) > 1.0) { s = 1.0 / fabs(z[k - 1]); sscal(n, s, z); ynorm = s * ynorm; }
+    }
+    s = 1.0 / sasum(n, z);
+    sscal(n, s, z);
+    ynorm = s * ynorm;
+    for (int kb = 1; kb <= n; ++kb) {
+        int k = n + 1 - kb;
+        if (fabs(z[k - 1]) > fabs(ABD(m, k))) {
+            s = fabs(ABD(m, k)) / fabs(z[k - 1]);
+            sscal(n, s, z);
+            ynorm = s * ynorm;
+        }
+        if (ABD(m, k) != 0.0) z[k - 1] = z[k - 1] / ABD(m, k);
+        if (ABD(m, k) == 0.0) z[k - 1] = 1.0;
+        int lm = imin(k, m) - 1;
+        int la = m - lm, lz = k - lm;
+        t = -z[k - 1];
+        saxpy(lm, t, &ABD(la, k), &z[lz - 1]);
+    }
+    s = 1.0 / sasum(n, z);
+    sscal(n, s, z);
+    ynorm = s * ynorm;
+    return (anorm != 0.0) ? ynorm / anorm : 0.0;
+#undef ABD
+}
+
+/* disutil.f:1355-1464 SGEFA */
+void sbdo_sgefa(double *a, int lda, int n, int *ipvt, int *info)
+{
+#define A(i, j) F2(a, lda, i, j)
+    *info = 0;
+    for (int k = 1; k <= n - 1; ++k) {
+        int kp1 = k + 1;
+        int l = isamax(n - k + 1, &A(k, k)) + k - 1;
+        ipvt[k - 1] = l;
+        if (A(l, k) == 0.0) { *info = k; continue; }
+        if (l != k) { double t = A(l, k); A(l, k) = A(k, k); A(k, k) = t; }
+        double t = -1.0 / A(k, k);
+        sscal(n - k, t, &A(k + 1, k));
+        for (int j = kp1; j <= n; ++j) {
+            t = A(l, j);
+            if (l != k) { A(l, j) = A(k, j); A(k, j) = t; }
+            saxpy(n - k, t, &A(k + 1, k), &A(k + 1, j));
+        }
+    }
+    ipvt[n - 1] = n;
+    if (A(n, n) == 0.0) *info = n;
+#undef A
+}
+
+/* disutil.f:1466-1609 SGESL, JOB=0 */
+void sbdo_sgesl(const double *a, int lda, int n, const int *ipvt, double *b)
+{
+#define A(i, j) F2(a, lda, i, j)
+    for (int k = 1; k <= n - 1; ++k) {
+        int l = ipvt[k - 1];
+        double t = b[l - 1];
+        if (l != k) { b[l - 1] = b[k - 1]; b[k - 1] = t; }
+        saxpy(n - k, t, &A(k + 1, k), &b[k]);
+    }
+    for (int kb = 1; kb <= n; ++kb) {
+        int k = n + 1 - kb;
+        b[k - 1] = b[k - 1] / A(k, k);
+        double t = -b[k - 1];
+        saxpy(k - 1, t, &A(1, k), &b[0]);
+    }
+#undef A
+}
+
+/* disutil.f:1094-1353 SGECO */
+double sbdo_sgeco(double *a, int lda, int n, int *ipvt, double *z)
+{
+#define A(i, j) F2(a, lda, i, j)
+    double anorm = 0.0;
+    int info;
+    for (int j = 1; j <= n; ++j) {
+        double s = sasum(n, &A(1, j));
+        if (s > anorm) anorm = s;
+    }
+    sbdo_sgefa(a, lda, n, ipvt, &info);
+    double ek = 1.0, s, sm, t, wk, wkm, ynorm;
+    for (int j = 0; j < n; ++j) z[j] = 0.0;
+    for (int k = 1; k <= n; ++k) {
+        if (z[k - 1] != 0.0) ek = dsign(ek, -z[k - 1]);
+        if (fabs(ek - z[k - 1]) > fabs(A(k, k))) {
+            s = fabs(A(k, k)) / fabs(ek - z[k - 1]);
+            sscal(n, s, z);
+            ek = s * ek;
+        }
+        wk = ek - z[k - 1];
+        wkm = -ek - z[k - 1];
+        s = fabs(wk);
+        sm = fabs(wkm);
+        if (A(k, k) != 0.0) { wk = wk / A(k, k); wkm = wkm / A(k, k); }
+        else { wk = 1.0; wkm = 1.0; }
+        int kp1 = k + 1;
+        if (kp1 <= n) {
+            for (int j = kp1; j <= n; ++j) {
+                sm = sm + fabs(z[j - 1] + wkm * A(k, j));
+                z[j - 1] = z[j - 1] + wk * A(k, j);
+                s = s + fabs(z[j - 1]);
+            }
+            if (s < sm) {
+                t = wkm - wk;
+                wk = wkm;
+                for (int j = kp1; j <= n; ++j) z[j - 1] = z[j - 1] + t * A(k, j);
+            }
+        }
+        z[k - 1] = wk;
+    }
+    s = 1.0 / sasum(n, z);
+    sscal(n, s, z);
+    for (int kb = 1; kb <= n; ++kb) {
+        int k = n + 1 - kb;
+        if (k < n) z[k - 1] = z[k - 1] + sdot(n - k, &A(k + 1, k), &z[k]);
+        if (fabs(z[k - 1]) > 1.0) { s = 1.0 / fabs(z[k - 1]); sscal(n, s, z); }
+        int l = ipvt[k - 1];
+        t = z[l - 1]; z[l - 1] = z[k - 1]; z[k - 1] = t;
+    }
+    s = 1.0 / sasum(n, z);
+    sscal(n, s, z);
+    ynorm = 1.0;
+    for (int k = 1; k <= n; ++k) {
+        int l = ipvt[k - 1];
+        t = z[l - 1]; z[l - 1] = z[k - 1]; z[k - 1] = t;
+        if (k < n) saxpy(n - k, t, &A(k + 1, k), &z[k]);
+        if (fabs(z[k - 1]) > 1.0) { s = 1.0 / fabs(z[k - 1]); sscal(n, s, z); ynorm = s * ynorm; }
+    }
+    s = 1.0 / sasum(n, z);
+    sscal(n, s, z);
+    ynorm = s * ynorm;
+    for (int kb = 1; kb <= n; ++kb) {
+        int k = n + 1 - kb;
+        if (fabs(z[k - 1]) > fabs(A(k, k))) {
+            s = fabs(A(k, k)) / fabs(z[k - 1]);
+            sscal(n, s, z);
+            ynorm = s * ynorm;
+        }
+        if (A(k, k) != 0.0) z[k - 1] = z[k - 1] / A(k, k);
+        if (A(k, k) == 0.0) z[k - 1] = 1.0;
+        t = -z[k - 1];
+        saxpy(k - 1, t, &A(1, k), &z[0]);
+    }
+    s = 1.0 / sasum(n, z);
+    sscal(n, s, z);
+    ynorm = s * ynorm;
+    return (anorm != 0.0) ? ynorm / anorm : 0.0;
+#undef A
+}
+
+/* ======================================================================
+ * QGAUSN  (disort.f:5984-6157)
+ * ==================================================================== */
+void sbdo_qgausn(int m, double *gmu, double *gwt)
+{
+    const double pi = sbdo_pi();           /* disort.f:6069 */
+    const double tol = 10.0 * DBL_EPSILON; /* disort.f:6070 */
+    if (m == 1) { gmu[0] = 0.5; gwt[0] = 1.0; return; }
+    double en = (double)m;
+    int np1 = m + 1;
+    double nnp1 = (double)(m * np1);
+    /* CONA = FLOAT(M-1)/(8*M**3): single-precision quotient, widened */
+    double cona = (double)((float)(m - 1) / (float)(8 * m * m * m));
+    int lim = m / 2;
+    for (int k = 1; k <= lim; ++k) {
+        double t = (double)(4 * k - 1) * pi / (double)(4 * m + 2);
+        double x = cos(t + cona / tan(t));
+        double p = 0.0, pm1, pm2, ppr, p2pri, xi, tmp;
+        for (;;) {
+            pm2 = 1.0;
+            pm1 = x;
+            for (int nn = 2; nn <= m; ++nn) {
+                p = ((double)(2 * nn - 1) * x * pm1 - (double)(nn - 1) * pm2) / (double)nn;
+                pm2 = pm1;
+                pm1 = p;
+            }
+            tmp = 1.0 / (1.0 - x * x);
+            ppr = en * (pm2 - x * p) * tmp;
+            p2pri = (2.0 * x * ppr - nnp1 * p) * tmp;
+            xi = x - (p / ppr) * (1.0 + (p / ppr) * p2pri / (2.0 * ppr));
+            if (fabs(xi - x) > tol) { x = xi; continue; }
+            break;
+        }
+        gmu[k - 1] = -x;
+        { double ep = en * pm2; gwt[k - 1] = 2.0 / (tmp * (ep * ep)); }
+        gmu[np1 - k - 1] = -gmu[k - 1];
+        gwt[np1 - k - 1] = gwt[k - 1];
+    }
+    if (m % 2 != 0) {
+        gmu[lim] = 0.0;
+        double prod = 1.0;
+        for (int k = 3; k <= m; k += 2) prod = prod * (double)k / (double)(k - 1);
+        gwt[lim] = 2.0 / (prod * prod);
+    }
+    for (int k = 0; k < m; ++k) {
+        gmu[k] = 0.5 * gmu[k] + 0.5;
+        gwt[k] = 0.5 * gwt[k];
+    }
+}
+
+/* SQT(k) = SQRT(FLOAT(k)): a single-precision square root (disort.f:452-454) */
+static inline double sqt(int k) { return (double)sqrtf((float)k); }
+
+/* ======================================================================
+ * LEPOLY (disort.f:5286-5408).  ylm is YLM(0:maxmu, nmu) column-major:
+ * ylm[i*(maxmu+1) + l].  For m>0 the caller must have run m-1 before.
+ * ==================================================================== */
+void sbdo_lepoly(int nmu, int m, int maxmu, int twonm1, const double *mu, double *ylm)
+{
+#define YLM(l, i) ylm[(size_t)((i) - 1) * (size_t)(maxmu + 1) + (size_t)(l)]
+    if (m == 0) {
+        for (int i = 1; i <= nmu; ++i) { YLM(0, i) = 1.0; YLM(1, i) = mu[i - 1]; }
+        for (int l = 2; l <= twonm1; ++l)
+            for (int i = 1; i <= nmu; ++i)
+                YLM(l, i) = ((double)(2 * l - 1) * mu[i - 1] * YLM(l - 1, i)
+                             - (double)(l - 1) * YLM(l - 2, i)) / (double)l;
+    } else {
+        for (int i = 1; i <= nmu; ++i) {
+            YLM(m, i) = -sqt(2 * m - 1) / sqt(2 * m) * sqrt(1.0 - mu[i - 1] * mu[i - 1]) * YLM(m - 1, i);
+            YLM(m + 1, i) = sqt(2 * m + 1) * mu[i - 1] * YLM(m, i);
+        }
+        for (int l = m + 2; l <= twonm1; ++l) {
+            double tmp1 = sqt(l - m) * sqt(l + m);
+            double tmp2 = sqt(l - m - 1) * sqt(l + m - 1);
+            for (int i = 1; i <= nmu; ++i)
+                YLM(l, i) = ((double)(2 * l - 1) * mu[i - 1] * YLM(l - 1, i) - tmp2 * YLM(l - 2, i)) / tmp1;
+        }
+    }
+#undef YLM
+}
+
+/* ======================================================================
+ * PLKAVG (disort.f:5410-5671)
+ * ==================================================================== */
+static double plkf(double x) { return x * x * x / (exp(x) - 1.0); }
+
+double sbdo_plkavg(double wnumlo, double wnumhi, double t, int *warn)
+{
+    const double a1 = f32(1.0f / 3.0f), a2 = f32(-1.0f / 8.0f), a3 = f32(1.0f / 60.0f),
+                 a4 = f32(-1.0f / 5040.0f), a5 = f32(1.0f / 272160.0f),
+                 a6 = f32(-1.0f / 13305600.0f);
+    const double c2 = f32(1.438786f), sigma = f32(5.67032e-8f), vcut = 1.5;
+    const double vcp[7] = { 10.25, f32(5.7f), f32(3.9f), f32(2.9f), f32(2.3f), f32(1.9f), 0.0 };
+    const double pi = sbdo_pi();
+    const double vmax = log(DBL_MAX), epsil = DBL_EPSILON;
+    const double sigdpi = sigma / pi;
+    const double conc = 15.0 / (pi * pi * pi * pi);
+    double d[2] = { 0, 0 }, p[2] = { 0, 0 }, v[2];
+
+    if (t < f32(1.0e-4f)) return 0.0;
+    v[0] = c2 * wnumlo / t;
+    v[1] = c2 * wnumhi / t;
+
+    if (v[0] > epsil && v[1] < vmax && (wnumhi - wnumlo) / wnumhi < f32(1.0e-2f)) {
+        /* Simpson rule iterated to convergence (disort.f:5566-5600) */
+        double hh = v[1] - v[0], oldval = 0.0, val = 0.0;
+        double val0 = plkf(v[0]) + plkf(v[1]);
+        int conv = 0;
+        for (int n = 1; n <= 10; ++n) {
+            double del = hh / (double)(2 * n);
+            val = val0;
+            for (int k = 1; k <= 2 * n - 1; ++k)
+                val = val + (double)(2 * (1 + k % 2)) * plkf(v[0] + (double)k * del);
+            val = del / 3.0 * val;
+            if (fabs((val - oldval) / val) <= f32(1.0e-6f)) { conv = 1; break; }
+            oldval = val;
+        }
+        if (!conv && warn) *warn |= 1; /* errmsg(9) */
+        return sigdpi * (t * t * t * t) * conc * val;
+    }
+
+    int smallv = 0;
+    for (int i = 0; i < 2; ++i) {
+        if (v[i] < vcut) {
+            smallv = smallv + 1;
+            double vsq = v[i] * v[i];
+            p[i] = conc * vsq * v[i] * (a1 + v[i] * (a2 + v[i] * (a3 + vsq * (a4 + vsq * (a5 + vsq * a6)))));
+        } else {
+            int mmax = 0;
+            do { mmax = mmax + 1; } while (v[i] < vcp[mmax - 1]);
+            double ex = exp(-v[i]), exm = 1.0;
+            d[i] = 0.0;
+            for (int m = 1; m <= mmax; ++m) {
+                double mv = (double)m * v[i];
+                exm = ex * exm;
+                d[i] = d[i] + exm * (6.0 + mv * (6.0 + mv * (3.0 + mv))) / (double)(m * m * m * m);
+            }
+            d[i] = conc * d[i];
+        }
+    }
+    double r;
+    if (smallv == 2) r = p[1] - p[0];
+    else if (smallv == 1) r = 1.0 - p[0] - d[1];
+    else r = d[0] - d[1];
+    r = sigdpi * (t * t * t * t) * r;
+    if (r == 0.0 && warn) *warn |= 2; /* errmsg(10) */
+    return r;
+}
+
+/* ======================================================================
+ * ASYMTX (disort.f:873-1656): real nonsymmetric eigenproblem with real
+ * spectrum -- balance, Householder->Hessenberg, shifted double QR, back-
+ * substitution.  Returns IER (0 ok; >0: EVAL(IER) failed to converge).
+ * aa is (ia x m), evec is (ievec x m), column-major; wk holds 2*m doubles.
+ * ==================================================================== */
+int sbdo_asymtx(double *aa, double *evec, double *eval, int m, int ia, int ievec, double *wk)
+{
+#define AA(i, j) F2(aa, ia, i, j)
+#define EV(i, j) F2(evec, ievec, i, j)
+#define WK(i) wk[(i) - 1]
+    const double c1 = 0.4375, c2 = 0.5, c3 = 0.75, c4 = 0.95, c5 = 16.0, c6 = 256.0;
+    const double tol = DBL_EPSILON;
+    double p = 0.0, q = 0.0, r = 0.0;
+    double col, discri, f, g, h, repl, rnorm, row, s, scale, sgn, t, uu, vv, w, x, y, z;
+    int i, in, j, k, ka, kkk, l, lb = 0, lll, n, n1, n2;
+
+    if (m == 1) { eval[0] = AA(1, 1); EV(1, 1) = 1.0; return 0; }
+    if (m == 2) { /* disort.f:989-1023 */
+        discri = (AA(1, 1) - AA(2, 2)) * (AA(1, 1) - AA(2, 2)) + 4.0 * AA(1, 2) * AA(2, 1);
+        if (discri < 0.0) return -1; /* fatal "complex evals in 2x2 case" */
+        sgn = 1.0;
+        if (AA(1, 1) < AA(2, 2)) sgn = -1.0;
+        eval[0] = 0.5 * (AA(1, 1) + AA(2, 2) + sgn * sqrt(discri));
+        eval[1] = 0.5 * (AA(1, 1) + AA(2, 2) - sgn * sqrt(discri));
+        EV(1, 1) = 1.0;
+        EV(2, 2) = 1.0;
+        if (AA(1, 1) == AA(2, 2) && (AA(2, 1) == 0.0 || AA(1, 2) == 0.0)) {
+            rnorm = fabs(AA(1, 1)) + fabs(AA(1, 2)) + fabs(AA(2, 1)) + fabs(AA(2, 2));
+            w = tol * rnorm;
+            EV(2, 1) = AA(2, 1) / w;
+            EV(1, 2) = -AA(1, 2) / w;
+        } else {
+            EV(2, 1) = AA(2, 1) / (eval[0] - AA(2, 2));
+            EV(1, 2) = AA(1, 2) / (eval[1] - AA(1, 1));
+        }
+        return 0;
+    }
+
+    for (i = 1; i <= m; ++i) {
+        eval[i - 1] = 0.0;
+        for (j = 1; j <= m; ++j) EV(i, j) = 0.0;
+        EV(i, i) = 1.0;
+    }
+    /* balance: isolate eigenvalues, push rows down (disort.f:1043-1092) */
+    rnorm = 0.0;
+    l = 1;
+    k = m;
+L30:
+    kkk = k;
+    for (j = kkk; j >= 1; --j) {
+        row = 0.0;
+        for (i = 1; i <= k; ++i)
+            if (i != j) row = row + fabs(AA(j, i));
+        if (row == 0.0) {
+            WK(k) = (double)j;
+            if (j != k) {
+                for (i = 1; i <= k; ++i) { repl = AA(i, j); AA(i, j) = AA(i, k); AA(i, k) = repl; }
+                for (i = l; i <= m; ++i) { repl = AA(j, i); AA(j, i) = AA(k, i); AA(k, i) = repl; }
+            }
+            k = k - 1;
+            goto L30;
+        }
+    }
+    /* columns isolating an eigenvalue, push left (disort.f:1095-1135) */
+L80:
+    lll = l;
+    for (j = lll; j <= k; ++j) {
+        col = 0.0;
+        for (i = l; i <= k; ++i)
+            if (i != j) col = col + fabs(AA(i, j));
+        if (col == 0.0) {
+            WK(l) = (double)j;
+            if (j != l) {
+                for (i = 1; i <= k; ++i) { repl = AA(i, j); AA(i, j) = AA(i, l); AA(i, l) = repl; }
+                for (i = l; i <= m; ++i) { repl = AA(j, i); AA(j, i) = AA(l, i); AA(l, i) = repl; }
+            }
+            l = l + 1;
+            goto L80;
+        }
+    }
+    /* balance the submatrix in rows l..k (disort.f:1138-1188) */
+    for (i = l; i <= k; ++i) WK(i) = 1.0;
+    for (;;) {
+        int noconv = 0;
+        for (i = l; i <= k; ++i) {
+            col = 0.0;
+            row = 0.0;
+            for (j = l; j <= k; ++j)
+                if (j != i) { col = col + fabs(AA(j, i)); row = row + fabs(AA(i, j)); }
+            f = 1.0;
+            g = row / c5;
+            h = col + row;
+            while (col < g) { f = f * c5; col = col * c6; }
+            g = row * c5;
+            while (col >= g) { f = f / c5; col = col / c6; }
+            if ((col + row) / f < c4 * h) {
+                WK(i) = WK(i) * f;
+                noconv = 1;
+                for (j = l; j <= m; ++j) AA(i, j) = AA(i, j) / f;
+                for (j = 1; j <= k; ++j) AA(j, i) = AA(j, i) * f;
+            }
+        }
+        if (!noconv) break;
+    }
+    /* Hessenberg reduction + accumulation (disort.f:1191-1286) */
+    if (!(k - 1 < l + 1)) {
+        for (n = l + 1; n <= k - 1; ++n) {
+            h = 0.0;
+            WK(n + m) = 0.0;
+            scale = 0.0;
+            for (i = n; i <= k; ++i) scale = scale + fabs(AA(i, n - 1));
+            if (scale != 0.0) {
+                for (i = k; i >= n; --i) {
+                    WK(i + m) = AA(i, n - 1) / scale;
+                    h = h + WK(i + m) * WK(i + m);
+                }
+                g = -dsign(sqrt(h), WK(n + m));
+                h = h - WK(n + m) * g;
+                WK(n + m) = WK(n + m) - g;
+                for (j = n; j <= m; ++j) {
+                    f = 0.0;
+                    for (i = k; i >= n; --i) f = f + WK(i + m) * AA(i, j);
+                    for (i = n; i <= k; ++i) AA(i, j) = AA(i, j) - WK(i + m) * f / h;
+                }
+                for (i = 1; i <= k; ++i) {
+                    f = 0.0;
+                    for (j = k; j >= n; --j) f = f + WK(j + m) * AA(i, j);
+                    for (j = n; j <= k; ++j) AA(i, j) = AA(i, j) - WK(j + m) * f / h;
+                }
+                WK(n + m) = scale * WK(n + m);
+                AA(n, n - 1) = scale * g;
+            }
+        }
+        for (n = k - 2; n >= l; --n) {
+            f = AA(n + 1, n);
+            if (f != 0.0) {
+                f = f * WK(n + 1 + m);
+                for (i = n + 2; i <= k; ++i) WK(i + m) = AA(i, n);
+                if (n + 1 <= k) {
+                    for (j = 1; j <= m; ++j) {
+                        g = 0.0;
+                        for (i = n + 1; i <= k; ++i) g = g + WK(i + m) * EV(i, j);
+                        g = g / f;
+                        for (i = n + 1; i <= k; ++i) EV(i, j) = EV(i, j) + g * WK(i + m);
+                    }
+                }
+            }
+        }
+    }
+    /* disort.f:1289-1300 */
+    n = 1;
+    for (i = 1; i <= m; ++i) {
+        for (j = n; j <= m; ++j) rnorm = rnorm + fabs(AA(i, j));
+        n = i;
+        if (i < l || i > k) eval[i - 1] = AA(i, i);
+    }
+    n = k;
+    t = 0.0;
+    /* search for next eigenvalues (disort.f:1305-1546) */
+L380:
+    if (n < l) goto L530;
+    in = 0;
+    n1 = n - 1;
+    n2 = n - 2;
+L390:
+    for (i = l; i <= n; ++i) {
+        lb = n + l - i;
+        if (lb == l) break;
+        s = fabs(AA(lb - 1, lb - 1)) + fabs(AA(lb, lb));
+        if (s == 0.0) s = rnorm;
+        if (fabs(AA(lb, lb - 1)) <= tol * s) break;
+    }
+    x = AA(n, n);
+    if (lb == n) { /* one eigenvalue found */
+        AA(n, n) = x + t;
+        eval[n - 1] = AA(n, n);
+        n = n1;
+        goto L380;
+    }
+    y = AA(n1, n1);
+    w = AA(n, n1) * AA(n1, n);
+    if (lb == n1) { /* two eigenvalues found */
+        p = (y - x) * c2;
+        q = p * p + w;
+        z = sqrt(fabs(q));
+        AA(n, n) = x + t;
+        x = AA(n, n);
+        AA(n1, n1) = y + t;
+        z = p + dsign(z, p);
+        eval[n1 - 1] = x + z;
+        eval[n - 1] = eval[n1 - 1];
+        if (z != 0.0) eval[n - 1] = x - w / z;
+        x = AA(n, n1);
+        r = sqrt(x * x + z * z);
+        p = x / r;
+        q = z / r;
+        for (j = n1; j <= m; ++j) {
+            z = AA(n1, j);
+            AA(n1, j) = q * z + p * AA(n, j);
+            AA(n, j) = q * AA(n, j) - p * z;
+        }
+        for (i = 1; i <= n; ++i) {
+            z = AA(i, n1);
+            AA(i, n1) = q * z + p * AA(i, n);
+            AA(i, n) = q * AA(i, n) - p * z;
+        }
+        for (i = l; i <= k; ++i) {
+            z = EV(i, n1);
+            EV(i, n1) = q * z + p * EV(i, n);
+            EV(i, n) = q * EV(i, n) - p * z;
+        }
+        n = n2;
+        goto L380;
+    }
+    if (in == 30) return n; /* no convergence: IER = n */
+    if (in == 10 || in == 20) { /* exceptional shift */
+        t = t + x;
+        for (i = l; i <= n; ++i) AA(i, i) = AA(i, i) - x;
+        s = fabs(AA(n, n1)) + fabs(AA(n1, n2));
+        x = c3 * s;
+        y = x;
+        w = -c1 * (s * s);
+    }
+    in = in + 1;
+    /* two consecutive small sub-diagonal elements */
+    for (j = lb; j <= n2; ++j) {
+        i = n2 + lb - j;
+        z = AA(i, i);
+        r = x - z;
+        s = y - z;
+        p = (r * s - w) / AA(i + 1, i) + AA(i, i + 1);
+        q = AA(i + 1, i + 1) - z - r - s;
+        r = AA(i + 2, i + 1);
+        s = fabs(p) + fabs(q) + fabs(r);
+        p = p / s;
+        q = q / s;
+        r = r / s;
+        if (i == lb) break;
+        uu = fabs(AA(i, i - 1)) * (fabs(q) + fabs(r));
+        vv = fabs(p) * (fabs(AA(i - 1, i - 1)) + fabs(z) + fabs(AA(i + 1, i + 1)));
+        if (uu <= tol * vv) break;
+    }
+    AA(i + 2, i) = 0.0;
+    for (j = i + 3; j <= n; ++j) { AA(j, j - 2) = 0.0; AA(j, j - 3) = 0.0; }
+    /* double QR step, rows i..n */
+    for (ka = i; ka <= n1; ++ka) {
+        int notlas = (ka != n1);
+        if (ka == i) {
+            s = dsign(sqrt(p * p + q * q + r * r), p);
+            if (lb != i) AA(ka, ka - 1) = -AA(ka, ka - 1);
+        } else {
+            p = AA(ka, ka - 1);
+            q = AA(ka + 1, ka - 1);
+            r = 0.0;
+            if (notlas) r = AA(ka + 2, ka - 1);
+            x = fabs(p) + fabs(q) + fabs(r);
+            if (x == 0.0) continue;
+            p = p / x;
+            q = q / x;
+            r = r / x;
+            s = dsign(sqrt(p * p + q * q + r * r), p);
+            AA(ka, ka - 1) = -s * x;
+        }
+        p = p + s;
+        x = p / s;
+        y = q / s;
+        z = r / s;
+        q = q / p;
+        r = r / p;
+        for (j = ka; j <= m; ++j) { /* row modification */
+            p = AA(ka, j) + q * AA(ka + 1, j);
+            if (notlas) { p = p + r * AA(ka + 2, j); AA(ka + 2, j) = AA(ka + 2, j) - p * z; }
+            AA(ka + 1, j) = AA(ka + 1, j) - p * y;
+            AA(ka, j) = AA(ka, j) - p * x;
+        }
+        for (int ii = 1; ii <= imin(n, ka + 3); ++ii) { /* column modification */
+            p = x * AA(ii, ka) + y * AA(ii, ka + 1);
+            if (notlas) { p = p + z * AA(ii, ka + 2); AA(ii, ka + 2) = AA(ii, ka + 2) - p * r; }
+            AA(ii, ka + 1) = AA(ii, ka + 1) - p * q;
+            AA(ii, ka) = AA(ii, ka) - p;
+        }
+        for (int ii = l; ii <= k; ++ii) { /* accumulate */
+            p = x * EV(ii, ka) + y * EV(ii, ka + 1);
+            if (notlas) { p = p + z * EV(ii, ka + 2); EV(ii, ka + 2) = EV(ii, ka + 2) - p * r; }
+            EV(ii, ka + 1) = EV(ii, ka + 1) - p * q;
+            EV(ii, ka) = EV(ii, ka) - p;
+        }
+    }
+    goto L390;
+
+L530: /* back-substitute (disort.f:1549-1615) */
+    if (rnorm != 0.0) {
+        for (n = m; n >= 1; --n) {
+            n2 = n;
+            AA(n, n) = 1.0;
+            for (i = n - 1; i >= 1; --i) {
+                w = AA(i, i) - eval[n - 1];
+                if (w == 0.0) w = tol * rnorm;
+                r = AA(i, n);
+                for (j = n2; j <= n - 1; ++j) r = r + AA(i, j) * AA(j, n);
+                AA(i, n) = -r / w;
+                n2 = i;
+            }
+        }
+        for (i = 1; i <= m; ++i)
+            if (i < l || i > k)
+                for (j = i; j <= m; ++j) EV(i, j) = AA(i, j);
+        if (k != 0) {
+            for (j = m; j >= l; --j)
+                for (i = l; i <= k; ++i) {
+                    z = 0.0;
+                    for (n = l; n <= imin(j, k); ++n) z = z + EV(i, n) * AA(n, j);
+                    EV(i, j) = z;
+                }
+        }
+    }
+    for (i = l; i <= k; ++i)
+        for (j = 1; j <= m; ++j) EV(i, j) = EV(i, j) * WK(i);
+    for (i = l - 1; i >= 1; --i) {
+        j = (int)WK(i);
+        if (i != j)
+            for (n = 1; n <= m; ++n) { repl = EV(i, n); EV(i, n) = EV(j, n); EV(j, n) = repl; }
+    }
+    for (i = k + 1; i <= m; ++i) {
+        j = (int)WK(i);
+        if (i != j)
+            for (n = 1; n <= m; ++n) { repl = EV(i, n); EV(i, n) = EV(j, n); EV(j, n) = repl; }
+    }
+    return 0;
+#undef AA
+#undef EV
+#undef WK
+}
+
+/* ======================================================================
+ * RATIO (disort.f:6159-6266)
+ * ==================================================================== */
+static double ratio_(double a, double b)
+{
+    const double tiny = DBL_MIN, huge = DBL_MAX;
+    const double powmax = log10(huge), powmin = log10(tiny);
+    double r;
+    if (a == 0.0) return (b == 0.0) ? 1.0 : 0.0;
+    if (b == 0.0) return dsign(huge, a);
+    double absa = fabs(a), absb = fabs(b);
+    double powa = log10(absa), powb = log10(absb);
+    if (absa < tiny && absb < tiny) r = 1.0;
+    else if (powa - powb >= powmax) r = huge;
+    else if (powa - powb <= powmin) r = tiny;
+    else r = absa / absb;
+    if ((a > 0.0 && b < 0.0) || (a < 0.0 && b > 0.0)) r = -r;
+    return r;
+}
+
+/* ======================================================================
+ * The solve.  Work arrays in one arena, compact dims:
+ *   n = NSTR, nn = n/2, L = NLYR, ld = n (leading dim of stream matrices)
+ * ==================================================================== */
+typedef struct {
+    int n, nn, L, numu, ncut, lyrcut;
+    double *cmu, *cwt;                 /* [n] */
+    double *gl;                        /* GL(0:n, L): gl[(lc-1)*(n+1)+k] */
+    double *tauc, *taucpr, *expbea;    /* [0:L] */
+    double *dtaucp, *oprim, *flyr;     /* [L] */
+    double *pkag, *xr0, *xr1;
+    double *ylm0, *ylmc, *ylmu;        /* YLM0(0:n), YLMC(0:n,n), YLMU(0:n,numu) */
+    double *gc, *kk, *ll, *zz, *zplk0, *zplk1; /* GC(n,n,L), KK(n,L) ... */
+    double *gu, *zbeam, *z0u, *z1u;    /* GU(numu,n,L), ZBEAM(numu,L) ... */
+    double *bdr, *bem, *rmu, *emu;     /* BDR(nn,0:nn) BEM(nn) RMU(numu,0:nn) EMU(numu) */
+} work_t;
+
+#define GL(k, lc) w->gl[(size_t)((lc) - 1) * (size_t)(n + 1) + (size_t)(k)]
+#define YLMC(l, iq) w->ylmc[(size_t)((iq) - 1) * (size_t)(n + 1) + (size_t)(l)]
+#define YLMU(l, iu) w->ylmu[(size_t)((iu) - 1) * (size_t)(n + 1) + (size_t)(l)]
+#define YLM0(l) w->ylm0[(l)]
+#define GC(i, j, lc) w->gc[((size_t)((lc) - 1) * n + (size_t)((j) - 1)) * n + (size_t)((i) - 1)]
+#define KK(i, lc) w->kk[(size_t)((lc) - 1) * n + (size_t)((i) - 1)]
+#define LL(i, lc) w->ll[(size_t)((lc) - 1) * n + (size_t)((i) - 1)]
+#define ZZ(i, lc) w->zz[(size_t)((lc) - 1) * n + (size_t)((i) - 1)]
+#define ZPLK0(i, lc) w->zplk0[(size_t)((lc) - 1) * n + (size_t)((i) - 1)]
+#define ZPLK1(i, lc) w->zplk1[(size_t)((lc) - 1) * n + (size_t)((i) - 1)]
+#define GU(iu, iq, lc) w->gu[((size_t)((lc) - 1) * n + (size_t)((iq) - 1)) * numu + (size_t)((iu) - 1)]
+#define ZBEAM(iu, lc) w->zbeam[(size_t)((lc) - 1) * numu + (size_t)((iu) - 1)]
+#define Z0U(iu, lc) w->z0u[(size_t)((lc) - 1) * numu + (size_t)((iu) - 1)]
+#define Z1U(iu, lc) w->z1u[(size_t)((lc) - 1) * numu + (size_t)((iu) - 1)]
+#define BDR(iq, jq) w->bdr[(size_t)(jq) * nn + (size_t)((iq) - 1)]
+#define RMU(iu, iq) w->rmu[(size_t)(iq) * numu + (size_t)((iu) - 1)]
+#define CMU(i) w->cmu[(i) - 1]
+#define CWT(i) w->cwt[(i) - 1]
+
+/* SOLEIG (disort.f:3099-3320).  cc, evecc are (n x n); amb, apb, array are
+ * (nn x nn); eval [nn]; wkd [n]. Returns IER from ASYMTX. */
+static int soleig(work_t *w, int lc, int mazim, double *amb, double *apb, double *array,
+                  double *cc, double *evecc, double *eval, double *wkd)
+{
+    const int n = w->n, nn = w->nn;
+#define CC(i, j) F2(cc, n, i, j)
+#define EVECC(i, j) F2(evecc, n, i, j)
+#define AMB(i, j) F2(amb, nn, i, j)
+#define APB(i, j) F2(apb, nn, i, j)
+#define ARRAY(i, j) F2(array, nn, i, j)
+    for (int iq = 1; iq <= nn; ++iq) {
+        for (int jq = 1; jq <= n; ++jq) {
+            double sum = 0.0;
+            for (int l = mazim; l <= n - 1; ++l) sum = sum + GL(l, lc) * YLMC(l, iq) * YLMC(l, jq);
+            CC(iq, jq) = 0.5 * sum * CWT(jq);
+        }
+        for (int jq = 1; jq <= nn; ++jq) {
+            CC(iq + nn, jq) = CC(iq, jq + nn);
+            CC(iq + nn, jq + nn) = CC(iq, jq);
+            double alpha = CC(iq, jq) / CMU(iq);
+            double beta = CC(iq, jq + nn) / CMU(iq);
+            AMB(iq, jq) = alpha - beta;
+            APB(iq, jq) = alpha + beta;
+        }
+        AMB(iq, iq) = AMB(iq, iq) - 1.0 / CMU(iq);
+        APB(iq, iq) = APB(iq, iq) - 1.0 / CMU(iq);
+    }
+    for (int iq = 1; iq <= nn; ++iq)
+        for (int jq = 1; jq <= nn; ++jq) {
+            double sum = 0.0;
+            for (int kq = 1; kq <= nn; ++kq) sum = sum + APB(iq, kq) * AMB(kq, jq);
+            ARRAY(iq, jq) = sum;
+        }
+    int ier = sbdo_asymtx(array, evecc, eval, nn, nn, n, wkd);
+    if (ier != 0) return ier;
+    for (int iq = 1; iq <= nn; ++iq) {
+        eval[iq - 1] = sqrt(fabs(eval[iq - 1]));
+        KK(iq + nn, lc) = eval[iq - 1];
+        KK(nn + 1 - iq, lc) = -eval[iq - 1];
+    }
+    for (int jq = 1; jq <= nn; ++jq)
+        for (int iq = 1; iq <= nn; ++iq) {
+            double sum = 0.0;
+            for (int kq = 1; kq <= nn; ++kq) sum = sum + AMB(iq, kq) * EVECC(kq, jq);
+            APB(iq, jq) = sum / eval[jq - 1];
+        }
+    for (int jq = 1; jq <= nn; ++jq)
+        for (int iq = 1; iq <= nn; ++iq) {
+            double gpplgm = APB(iq, jq);
+            double gpmigm = EVECC(iq, jq);
+            EVECC(iq, jq) = 0.5 * (gpplgm + gpmigm);
+            EVECC(iq + nn, jq) = 0.5 * (gpplgm - gpmigm);
+            gpplgm = -gpplgm;
+            EVECC(iq, jq + nn) = 0.5 * (gpplgm + gpmigm);
+            EVECC(iq + nn, jq + nn) = 0.5 * (gpplgm - gpmigm);
+            GC(iq + nn, jq + nn, lc) = EVECC(iq, jq);
+            GC(nn + 1 - iq, jq + nn, lc) = EVECC(iq + nn, jq);
+            GC(iq + nn, nn + 1 - jq, lc) = EVECC(iq, jq + nn);
+            GC(nn + 1 - iq, nn + 1 - jq, lc) = EVECC(iq + nn, jq + nn);
+        }
+    return 0;
+#undef AMB
+#undef APB
+#undef ARRAY
+}
+
+/* UPBEAM (disort.f:4130-4245): zj returned in CMU order, ZZ(.,lc) reordered */
+static int upbeam(work_t *w, int lc, int mazim, double delm0, double fbeam, double pi,
+                  double umu0, const double *cc, double *array, int *ipvt, double *wk, double *zj)
+{
+    const int n = w->n, nn = w->nn;
+#define ARR(i, j) F2(array, n, i, j)
+    for (int iq = 1; iq <= n; ++iq) {
+        for (int jq = 1; jq <= n; ++jq) ARR(iq, jq) = -CC(iq, jq);
+        ARR(iq, iq) = 1.0 + CMU(iq) / umu0 + ARR(iq, iq);
+        double sum = 0.0;
+        for (int k = mazim; k <= n - 1; ++k) sum = sum + GL(k, lc) * YLMC(k, iq) * YLM0(k);
+        zj[iq - 1] = (2.0 - delm0) * fbeam * sum / (4.0 * pi);
+    }
+    double rcond = sbdo_sgeco(array, n, n, ipvt, wk);
+    int warn = (1.0 + rcond == 1.0);
+    sbdo_sgesl(array, n, n, ipvt, zj);
+    for (int iq = 1; iq <= nn; ++iq) {
+        ZZ(iq + nn, lc) = zj[iq - 1];
+        ZZ(nn + 1 - iq, lc) = zj[iq + nn - 1];
+    }
+    return warn;
+}
+
+/* UPISOT (disort.f:4247-4353): z0, z1 returned in CMU order */
+static int upisot(work_t *w, int lc, const double *cc, double *array, int *ipvt, double *wk,
+                  double *z0, double *z1)
+{
+    const int n = w->n, nn = w->nn;
+    const double oprim = w->oprim[lc - 1], xr0 = w->xr0[lc - 1], xr1 = w->xr1[lc - 1];
+    for (int iq = 1; iq <= n; ++iq) {
+        for (int jq = 1; jq <= n; ++jq) ARR(iq, jq) = -CC(iq, jq);
+        ARR(iq, iq) = 1.0 + ARR(iq, iq);
+        z1[iq - 1] = (1.0 - oprim) * xr1;
+    }
+    double rcond = sbdo_sgeco(array, n, n, ipvt, wk);
+    int warn = (1.0 + rcond == 1.0);
+    sbdo_sgesl(array, n, n, ipvt, z1);
+    for (int iq = 1; iq <= n; ++iq) z0[iq - 1] = (1.0 - oprim) * xr0 + CMU(iq) * z1[iq - 1];
+    sbdo_sgesl(array, n, n, ipvt, z0);
+    for (int iq = 1; iq <= nn; ++iq) {
+        ZPLK0(iq + nn, lc) = z0[iq - 1];
+        ZPLK1(iq + nn, lc) = z1[iq - 1];
+        ZPLK0(nn + 1 - iq, lc) = z0[iq + nn - 1];
+        ZPLK1(nn + 1 - iq, lc) = z1[iq + nn - 1];
+    }
+    return warn;
+#undef ARR
+}
+
+/* TERPEV (disort.f:3920-3978) */
+static void terpev(work_t *w, int lc, int mazim, const double *evecc, double *wk)
+{
+    const int n = w->n, nn = w->nn, numu = w->numu;
+    for (int iq = 1; iq <= n; ++iq) {
+        for (int l = mazim; l <= n - 1; ++l) {
+            double sum = 0.0;
+            for (int jq = 1; jq <= n; ++jq) sum = sum + CWT(jq) * YLMC(l, jq) * EVECC(jq, iq);
+            wk[l] = 0.5 * GL(l, lc) * sum;
+        }
+        for (int iu = 1; iu <= numu; ++iu) {
+            double sum = 0.0;
+            for (int l = mazim; l <= n - 1; ++l) sum = sum + wk[l] * YLMU(l, iu);
+            if (iq <= nn) GU(iu, iq + nn, lc) = sum;
+            if (iq > nn) GU(iu, n + 1 - iq, lc) = sum;
+        }
+    }
+}
+
+/* TERPSO (disort.f:3980-4128) */
+static void terpso(work_t *w, int lc, int mazim, double delm0, double fbeam, int plank, double pi,
+                   const double *z0, const double *z1, const double *zj, double *psi0, double *psi1)
+{
+    const int n = w->n, numu = w->numu;
+    const double oprim = w->oprim[lc - 1], xr0 = w->xr0[lc - 1], xr1 = w->xr1[lc - 1];
+    if (fbeam > 0.0) {
+        for (int iq = mazim; iq <= n - 1; ++iq) {
+            double psum = 0.0;
+            for (int jq = 1; jq <= n; ++jq) psum = psum + CWT(jq) * YLMC(iq, jq) * zj[jq - 1];
+            psi0[iq] = 0.5 * GL(iq, lc) * psum;
+        }
+        double fact = (2.0 - delm0) * fbeam / (4.0 * pi);
+        for (int iu = 1; iu <= numu; ++iu) {
+            double sum = 0.0;
+            for (int iq = mazim; iq <= n - 1; ++iq)
+                sum = sum + YLMU(iq, iu) * (psi0[iq] + fact * GL(iq, lc) * YLM0(iq));
+            ZBEAM(iu, lc) = sum;
+        }
+    }
+    if (plank && mazim == 0) {
+        for (int iq = mazim; iq <= n - 1; ++iq) {
+            double psum0 = 0.0, psum1 = 0.0;
+            for (int jq = 1; jq <= n; ++jq) {
+                psum0 = psum0 + CWT(jq) * YLMC(iq, jq) * z0[jq - 1];
+                psum1 = psum1 + CWT(jq) * YLMC(iq, jq) * z1[jq - 1];
+            }
+            psi0[iq] = 0.5 * GL(iq, lc) * psum0;
+            psi1[iq] = 0.5 * GL(iq, lc) * psum1;
+        }
+        for (int iu = 1; iu <= numu; ++iu) {
+            double sum0 = 0.0, sum1 = 0.0;
+            for (int iq = mazim; iq <= n - 1; ++iq) {
+                sum0 = sum0 + YLMU(iq, iu) * psi0[iq];
+                sum1 = sum1 + YLMU(iq, iu) * psi1[iq];
+            }
+            Z0U(iu, lc) = sum0 + (1.0 - oprim) * xr0;
+            Z1U(iu, lc) = sum1 + (1.0 - oprim) * xr1;
+        }
+    }
+}
+#undef CC
+#undef EVECC
+
+/* SETMTX (disort.f:2702-2994): cband is (lda x ncol) LINPACK band storage */
+static void setmtx(work_t *w, double *cband, int lda, double delm0, int lamber, double *wk, int *ncol_out)
+{
+    const int n = w->n, nn = w->nn, ncut = w->ncut;
+#define CB(i, j) F2(cband, lda, i, j)
+    memset(cband, 0, sizeof(double) * (size_t)lda * (size_t)(n * ncut));
+    int ncd = 3 * nn - 1;
+    int nshift = (3 * ncd + 1) - 2 * n + 1;
+    int ncol = 0, jcol, irow;
+    for (int lc = 1; lc <= ncut; ++lc) {
+        for (int iq = 1; iq <= nn; ++iq) wk[iq - 1] = exp(KK(iq, lc) * w->dtaucp[lc - 1]);
+        jcol = 0;
+        for (int iq = 1; iq <= nn; ++iq) {
+            ncol = ncol + 1;
+            irow = nshift - jcol;
+            for (int jq = 1; jq <= n; ++jq) {
+                CB(irow + n, ncol) = GC(jq, iq, lc);
+                CB(irow, ncol) = -GC(jq, iq, lc) * wk[iq - 1];
+                irow = irow + 1;
+            }
+            jcol = jcol + 1;
+        }
+        for (int iq = nn + 1; iq <= n; ++iq) {
+            ncol = ncol + 1;
+            irow = nshift - jcol;
+            for (int jq = 1; jq <= n; ++jq) {
+                CB(irow + n, ncol) = GC(jq, iq, lc) * wk[n + 1 - iq - 1];
+                CB(irow, ncol) = -GC(jq, iq, lc);
+                irow = irow + 1;
+            }
+            jcol = jcol + 1;
+        }
+    }
+    /* top boundary */
+    jcol = 0;
+    for (int iq = 1; iq <= nn; ++iq) {
+        double expa = exp(KK(iq, 1) * w->taucpr[1]);
+        irow = nshift - jcol + nn;
+        for (int jq = nn; jq >= 1; --jq) { CB(irow, jcol + 1) = GC(jq, iq, 1) * expa; irow = irow + 1; }
+        jcol = jcol + 1;
+    }
+    for (int iq = nn + 1; iq <= n; ++iq) {
+        irow = nshift - jcol + nn;
+        for (int jq = nn; jq >= 1; --jq) { CB(irow, jcol + 1) = GC(jq, iq, 1); irow = irow + 1; }
+        jcol = jcol + 1;
+    }
+    /* bottom boundary; wk still holds exp(KK*DTAUCP) of layer ncut */
+    int nncol = ncol - n;
+    jcol = 0;
+    for (int iq = 1; iq <= nn; ++iq) {
+        nncol = nncol + 1;
+        irow = nshift - jcol + n;
+        for (int jq = nn + 1; jq <= n; ++jq) {
+            if (w->lyrcut || (lamber && delm0 == 0.0)) {
+                CB(irow, nncol) = GC(jq, iq, ncut);
+            } else {
+                double sum = 0.0;
+                for (int k = 1; k <= nn; ++k)
+                    sum = sum + CWT(k) * CMU(k) * BDR(jq - nn, k) * GC(nn + 1 - k, iq, ncut);
+                CB(irow, nncol) = GC(jq, iq, ncut) - (1.0 + delm0) * sum;
+            }
+            irow = irow + 1;
+        }
+        jcol = jcol + 1;
+    }
+    for (int iq = nn + 1; iq <= n; ++iq) {
+        nncol = nncol + 1;
+        irow = nshift - jcol + n;
+        double expa = wk[n + 1 - iq - 1];
+        for (int jq = nn + 1; jq <= n; ++jq) {
+            if (w->lyrcut || (lamber && delm0 == 0.0)) {
+                CB(irow, nncol) = GC(jq, iq, ncut) * expa;
+            } else {
+                double sum = 0.0;
+                for (int k = 1; k <= nn; ++k)
+                    sum = sum + CWT(k) * CMU(k) * BDR(jq - nn, k) * GC(nn + 1 - k, iq, ncut);
+                CB(irow, nncol) = (GC(jq, iq, ncut) - (1.0 + delm0) * sum) * expa;
+            }
+            irow = irow + 1;
+        }
+        jcol = jcol + 1;
+    }
+    *ncol_out = ncol;
+#undef CB
+}
+
+/* SOLVE0 (disort.f:3322-3637) */
+static int solve0(work_t *w, double *b, double *cband, int lda, int ncol, int mazim, double fbeam,
+                  double fisot, int lamber, double pi, double bplank, double tplank, double umu0,
+                  int *ipvt, double *z)
+{
+    const int n = w->n, nn = w->nn, ncut = w->ncut, lyrcut = w->lyrcut;
+    const double *expbea = w->expbea, *taucpr = w->taucpr;
+    for (int i = 0; i < ncol; ++i) b[i] = 0.0;
+#define B(i) b[(i) - 1]
+    if (mazim > 0 && fbeam > 0.0) {
+        if (lyrcut || lamber) {
+            for (int iq = 1; iq <= nn; ++iq) {
+                B(iq) = -ZZ(nn + 1 - iq, 1);
+                B(ncol - nn + iq) = -ZZ(iq + nn, ncut) * expbea[ncut];
+            }
+        } else {
+            for (int iq = 1; iq <= nn; ++iq) {
+                B(iq) = -ZZ(nn + 1 - iq, 1);
+                double sum = 0.0;
+                for (int jq = 1; jq <= nn; ++jq)
+                    sum = sum + CWT(jq) * CMU(jq) * BDR(iq, jq) * ZZ(nn + 1 - jq, ncut) * expbea[ncut];
+                B(ncol - nn + iq) = sum;
+                if (fbeam > 0.0)
+                    B(ncol - nn + iq) = sum + (BDR(iq, 0) * umu0 * fbeam / pi - ZZ(iq + nn, ncut)) * expbea[ncut];
+            }
+        }
+        int it = nn;
+        for (int lc = 1; lc <= ncut - 1; ++lc)
+            for (int iq = 1; iq <= n; ++iq) {
+                it = it + 1;
+                B(it) = (ZZ(iq, lc + 1) - ZZ(iq, lc)) * expbea[lc];
+            }
+    } else if (fbeam == 0.0) {
+        for (int iq = 1; iq <= nn; ++iq) B(iq) = -ZPLK0(nn + 1 - iq, 1) + fisot + tplank;
+        if (lyrcut) {
+            for (int iq = 1; iq <= nn; ++iq)
+                B(ncol - nn + iq) = -ZPLK0(iq + nn, ncut) - ZPLK1(iq + nn, ncut) * taucpr[ncut];
+        } else {
+            for (int iq = 1; iq <= nn; ++iq) {
+                double sum = 0.0;
+                for (int jq = 1; jq <= nn; ++jq)
+                    sum = sum + CWT(jq) * CMU(jq) * BDR(iq, jq) *
+                                    (ZPLK0(nn + 1 - jq, ncut) + ZPLK1(nn + 1 - jq, ncut) * taucpr[ncut]);
+                B(ncol - nn + iq) = 2.0 * sum + w->bem[iq - 1] * bplank - ZPLK0(iq + nn, ncut)
+                                    - ZPLK1(iq + nn, ncut) * taucpr[ncut];
+            }
+        }
+        int it = nn;
+        for (int lc = 1; lc <= ncut - 1; ++lc)
+            for (int iq = 1; iq <= n; ++iq) {
+                it = it + 1;
+                B(it) = ZPLK0(iq, lc + 1) - ZPLK0(iq, lc) + (ZPLK1(iq, lc + 1) - ZPLK1(iq, lc)) * taucpr[lc];
+            }
+    } else {
+        for (int iq = 1; iq <= nn; ++iq)
+            B(iq) = -ZZ(nn + 1 - iq, 1) - ZPLK0(nn + 1 - iq, 1) + fisot + tplank;
+        if (lyrcut) {
+            for (int iq = 1; iq <= nn; ++iq)
+                B(ncol - nn + iq) = -ZZ(iq + nn, ncut) * expbea[ncut] - ZPLK0(iq + nn, ncut)
+                                    - ZPLK1(iq + nn, ncut) * taucpr[ncut];
+        } else {
+            for (int iq = 1; iq <= nn; ++iq) {
+                double sum = 0.0;
+                for (int jq = 1; jq <= nn; ++jq)
+                    sum = sum + CWT(jq) * CMU(jq) * BDR(iq, jq) *
+                                    (ZZ(nn + 1 - jq, ncut) * expbea[ncut] + ZPLK0(nn + 1 - jq, ncut)
+                                     + ZPLK1(nn + 1 - jq, ncut) * taucpr[ncut]);
+                B(ncol - nn + iq) = 2.0 * sum
+                                    + (BDR(iq, 0) * umu0 * fbeam / pi - ZZ(iq + nn, ncut)) * expbea[ncut]
+                                    + w->bem[iq - 1] * bplank - ZPLK0(iq + nn, ncut)
+                                    - ZPLK1(iq + nn, ncut) * taucpr[ncut];
+            }
+        }
+        int it = nn;
+        for (int lc = 1; lc <= ncut - 1; ++lc)
+            for (int iq = 1; iq <= n; ++iq) {
+                it = it + 1;
+                B(it) = (ZZ(iq, lc + 1) - ZZ(iq, lc)) * expbea[lc] + ZPLK0(iq, lc + 1) - ZPLK0(iq, lc)
+                        + (ZPLK1(iq, lc + 1) - ZPLK1(iq, lc)) * taucpr[lc];
+            }
+    }
+    int ncd = 3 * nn - 1;
+    double rcond = sbdo_sgbco(cband, lda, ncol, ncd, ncd, ipvt, z);
+    int warn = (1.0 + rcond == 1.0);
+    sbdo_sgbsl(cband, lda, ncol, ncd, ncd, ipvt, b);
+    for (int lc = 1; lc <= ncut; ++lc) {
+        int ipnt = lc * n - nn;
+        for (int iq = 1; iq <= nn; ++iq) {
+            LL(nn + 1 - iq, lc) = B(ipnt + 1 - iq);
+            LL(iq + nn, lc) = B(iq + ipnt);
+        }
+    }
+    return warn;
+#undef B
+}
+
+/* FLUXES (disort.f:1780-2042).  Output arrays are pre-zeroed by the caller
+ * (ZEROAL, disort.f:502-521). */
+static void fluxes(work_t *w, int ntau, const int *layru, const double *utau, const double *utaupr,
+                   const double *ssalb, double fbeam, double umu0, double pi, sbdo_out *out)
+{
+    const int n = w->n, nn = w->nn, ncut = w->ncut;
+    const double *taucpr = w->taucpr;
+    double fact = 0.0; /* DATA FACT/0.0/ */
+    for (int lu = 1; lu <= ntau; ++lu) {
+        int lyu = layru[lu - 1];
+        double fldir = 0.0, fldn = 0.0, dirint;
+        if (w->lyrcut && lyu > ncut) continue;
+        if (fbeam > 0.0) {
+            fact = exp(-utaupr[lu - 1] / umu0);
+            dirint = fbeam * fact;
+            fldir = umu0 * (fbeam * fact);
+            out->rfldir[lu - 1] = umu0 * fbeam * exp(-utau[lu - 1] / umu0);
+        } else {
+            dirint = 0.0;
+            fldir = 0.0;
+            out->rfldir[lu - 1] = 0.0;
+        }
+        for (int iq = 1; iq <= n; ++iq) {
+            double zint = 0.0;
+            for (int jq = 1; jq <= nn; ++jq)
+                zint = zint + GC(iq, jq, lyu) * LL(jq, lyu) * exp(-KK(jq, lyu) * (utaupr[lu - 1] - taucpr[lyu]));
+            for (int jq = nn + 1; jq <= n; ++jq)
+                zint = zint + GC(iq, jq, lyu) * LL(jq, lyu) * exp(-KK(jq, lyu) * (utaupr[lu - 1] - taucpr[lyu - 1]));
+            double u0c = zint;
+            if (fbeam > 0.0) u0c = zint + ZZ(iq, lyu) * fact;
+            u0c = u0c + ZPLK0(iq, lyu) + ZPLK1(iq, lyu) * utaupr[lu - 1];
+            if (out->u0c) out->u0c[(size_t)(lu - 1) * n + (iq - 1)] = u0c;
+            if (iq <= nn) {
+                out->uavg[lu - 1] = out->uavg[lu - 1] + CWT(nn + 1 - iq) * u0c;
+                fldn = fldn + CWT(nn + 1 - iq) * CMU(nn + 1 - iq) * u0c;
+            } else {
+                out->uavg[lu - 1] = out->uavg[lu - 1] + CWT(iq - nn) * u0c;
+                out->flup[lu - 1] = out->flup[lu - 1] + CWT(iq - nn) * CMU(iq - nn) * u0c;
+            }
+        }
+        out->flup[lu - 1] = 2.0 * pi * out->flup[lu - 1];
+        fldn = 2.0 * pi * fldn;
+        double fdntot = fldn + fldir;
+        out->rfldn[lu - 1] = fdntot - out->rfldir[lu - 1];
+        out->uavg[lu - 1] = (2.0 * pi * out->uavg[lu - 1] + dirint) / (4.0 * pi);
+        double plsorc = w->xr0[lyu - 1] + w->xr1[lyu - 1] * utaupr[lu - 1];
+        out->dfdt[lu - 1] = (1.0 - ssalb[lyu - 1]) * 4.0 * pi * (out->uavg[lu - 1] - plsorc);
+    }
+}
+
+/* USRINT (disort.f:4355-4793).  uum is UUM(numu, ntau), pre-zeroed. */
+static void usrint(work_t *w, int ntau, const int *layru, const double *utaupr, const double *umu,
+                   int mazim, double delm0, double fbeam, double fisot, int lamber, int plank,
+                   double pi, double bplank, double tplank, double umu0, double *wk, double *uum)
+{
+    const int n = w->n, nn = w->nn, numu = w->numu, ncut = w->ncut, nlyr = w->L;
+    const double *taucpr = w->taucpr, *dtaucp = w->dtaucp, *expbea = w->expbea;
+    const double lh = f32(0.0001f), eps6 = f32(1.0e-6f);
+    double exp0 = 0.0, exp1 = 0.0, exp2 = 0.0; /* DATA-initialised, SAVEd in the reference */
+    for (int lc = 1; lc <= ncut; ++lc)
+        for (int iq = 1; iq <= n; ++iq)
+            for (int iu = 1; iu <= numu; ++iu) GU(iu, iq, lc) = GU(iu, iq, lc) * LL(iq, lc);
+    for (int lu = 1; lu <= ntau; ++lu) {
+        if (fbeam > 0.0) exp0 = exp(-utaupr[lu - 1] / umu0);
+        int lyu = layru[lu - 1];
+        for (int iu = 1; iu <= numu; ++iu) {
+            if (w->lyrcut && lyu > ncut) continue;
+            const double um = umu[iu - 1];
+            int negumu = (um < 0.0);
+            int lyrstr, lyrend;
+            double sgn, denom, expn, dtau;
+            if (negumu) { lyrstr = 1; lyrend = lyu - 1; sgn = -1.0; }
+            else { lyrstr = lyu + 1; lyrend = ncut; sgn = 1.0; }
+            double palint = 0.0, plkint = 0.0;
+            for (int lc = lyrstr; lc <= lyrend; ++lc) {
+                dtau = dtaucp[lc - 1];
+                exp1 = exp((utaupr[lu - 1] - taucpr[lc - 1]) / um);
+                exp2 = exp((utaupr[lu - 1] - taucpr[lc]) / um);
+                if (plank && mazim == 0) {
+                    double f0n = sgn * (exp1 - exp2);
+                    double f1n = sgn * ((taucpr[lc - 1] + um) * exp1 - (taucpr[lc] + um) * exp2);
+                    plkint = plkint + Z0U(iu, lc) * f0n + Z1U(iu, lc) * f1n;
+                }
+                if (fbeam > 0.0) {
+                    denom = 1.0 + um / umu0;
+                    if (fabs(denom) < lh) expn = (dtau / umu0) * exp0;
+                    else expn = (exp1 * expbea[lc - 1] - exp2 * expbea[lc]) * sgn / denom;
+                    palint = palint + ZBEAM(iu, lc) * expn;
+                }
+                for (int iq = 1; iq <= nn; ++iq) { /* KK negative */
+                    wk[iq - 1] = exp(KK(iq, lc) * dtau);
+                    denom = 1.0 + um * KK(iq, lc);
+                    if (fabs(denom) < lh) expn = dtau / um * exp2;
+                    else expn = sgn * (exp1 * wk[iq - 1] - exp2) / denom;
+                    palint = palint + GU(iu, iq, lc) * expn;
+                }
+                for (int iq = nn + 1; iq <= n; ++iq) { /* KK positive */
+                    denom = 1.0 + um * KK(iq, lc);
+                    if (fabs(denom) < lh) expn = -dtau / um * exp1;
+                    else expn = sgn * (exp1 - exp2 * wk[n + 1 - iq - 1]) / denom;
+                    palint = palint + GU(iu, iq, lc) * expn;
+                }
+            }
+            /* contribution from the user level to the next computational level */
+            double dtau1 = utaupr[lu - 1] - taucpr[lyu - 1];
+            double dtau2 = utaupr[lu - 1] - taucpr[lyu];
+            int skip = (fabs(dtau1) < eps6 && negumu) || (fabs(dtau2) < eps6 && !negumu);
+            if (!skip) {
+                if (negumu) exp1 = exp(dtau1 / um);
+                if (!negumu) exp2 = exp(dtau2 / um);
+                if (fbeam > 0.0) {
+                    denom = 1.0 + um / umu0;
+                    if (fabs(denom) < lh) expn = (dtau1 / umu0) * exp0;
+                    else if (negumu) expn = (exp0 - expbea[lyu - 1] * exp1) / denom;
+                    else expn = (exp0 - expbea[lyu] * exp2) / denom;
+                    palint = palint + ZBEAM(iu, lyu) * expn;
+                }
+                dtau = dtaucp[lyu - 1];
+                for (int iq = 1; iq <= nn; ++iq) {
+                    denom = 1.0 + um * KK(iq, lyu);
+                    if (fabs(denom) < lh) expn = -dtau2 / um * exp2;
+                    else if (negumu) expn = (exp(-KK(iq, lyu) * dtau2) - exp(KK(iq, lyu) * dtau) * exp1) / denom;
+                    else expn = (exp(-KK(iq, lyu) * dtau2) - exp2) / denom;
+                    palint = palint + GU(iu, iq, lyu) * expn;
+                }
+                for (int iq = nn + 1; iq <= n; ++iq) {
+                    denom = 1.0 + um * KK(iq, lyu);
+                    if (fabs(denom) < lh) expn = -dtau1 / um * exp1;
+                    else if (negumu) expn = (exp(-KK(iq, lyu) * dtau1) - exp1) / denom;
+                    else expn = (exp(-KK(iq, lyu) * dtau1) - exp(-KK(iq, lyu) * dtau) * exp2) / denom;
+                    palint = palint + GU(iu, iq, lyu) * expn;
+                }
+                if (plank && mazim == 0) {
+                    double fact;
+                    if (negumu) { expn = exp1; fact = taucpr[lyu - 1] + um; }
+                    else { expn = exp2; fact = taucpr[lyu] + um; }
+                    double f0n = 1.0 - expn;
+                    double f1n = utaupr[lu - 1] + um - fact * expn;
+                    plkint = plkint + Z0U(iu, lyu) * f0n + Z1U(iu, lyu) * f1n;
+                }
+            }
+            /* intensity components attenuated at both boundaries */
+            double bndint = 0.0;
+            if (negumu && mazim == 0) {
+                bndint = (fisot + tplank) * exp(utaupr[lu - 1] / um);
+            } else if (!negumu) {
+                if (!(w->lyrcut || (lamber && mazim > 0))) {
+                    for (int jq = nn + 1; jq <= n; ++jq) wk[jq - 1] = exp(-KK(jq, nlyr) * dtaucp[nlyr - 1]);
+                    double bnddfu = 0.0;
+                    for (int iq = nn; iq >= 1; --iq) {
+                        double dfuint = 0.0;
+                        for (int jq = 1; jq <= nn; ++jq) dfuint = dfuint + GC(iq, jq, nlyr) * LL(jq, nlyr);
+                        for (int jq = nn + 1; jq <= n; ++jq)
+                            dfuint = dfuint + GC(iq, jq, nlyr) * LL(jq, nlyr) * wk[jq - 1];
+                        if (fbeam > 0.0) dfuint = dfuint + ZZ(iq, nlyr) * expbea[nlyr];
+                        dfuint = dfuint + delm0 * (ZPLK0(iq, nlyr) + ZPLK1(iq, nlyr) * taucpr[nlyr]);
+                        bnddfu = bnddfu + (1.0 + delm0) * RMU(iu, nn + 1 - iq) * CMU(nn + 1 - iq)
+                                              * CWT(nn + 1 - iq) * dfuint;
+                    }
+                    double bnddir = 0.0;
+                    if (fbeam > 0.0) bnddir = umu0 * fbeam / pi * RMU(iu, 0) * expbea[nlyr];
+                    bndint = (bnddfu + bnddir + delm0 * w->emu[iu - 1] * bplank)
+                             * exp((utaupr[lu - 1] - taucpr[nlyr]) / um);
+                }
+            }
+            F2(uum, numu, iu, lu) = palint + plkint + bndint;
+        }
+    }
+}
+
+static double *carve(double **p, size_t nelem)
+{
+    double *r = *p;
+    *p += nelem;
+    return r;
+}
+
+int sbdo_disort(const sbdo_in *in, sbdo_out *out)
+{
+    const int n0 = in->nstr;
+    const int L = in->nlyr;
+    const double pi = sbdo_pi();
+    const double dither = sbdo_dither();
+    const double rpd = pi / 180.0;
+    int status = 0;
+
+    out->status = 0;
+    out->nstr_out = n0;
+    /* ---- CHEKIN subset (disort.f:4864-5176): fatal input errors ---- */
+    if (n0 < 4 || (n0 % 2) != 0 || L < 1) { out->status = SBDO_ERR_INPUT; return out->status; }
+    const int n = n0, nn = n / 2;
+    int numu = (in->usrang && !in->onlyfl) ? in->numu : 0;
+    const int nphi = in->onlyfl ? 0 : in->nphi;
+    const int ntau = in->usrtau ? in->ntau : L + 1;
+    out->ntau = ntau;
+
+    for (int lu = 0; lu < ntau; ++lu) {
+        out->rfldir[lu] = out->rfldn[lu] = out->flup[lu] = out->dfdt[lu] = out->uavg[lu] = 0.0;
+    }
+    if (out->uu && !in->onlyfl)
+        for (size_t i = 0; i < (size_t)nphi * ntau * (size_t)in->numu; ++i) out->uu[i] = 0.0;
+    if (out->u0c)
+        for (size_t i = 0; i < (size_t)ntau * n; ++i) out->u0c[i] = 0.0;
+
+    /* local copies of the arrays DISORT mutates */
+    double *dtauc = (double *)malloc(sizeof(double) * (size_t)(2 * L));
+    double *ssalb = dtauc + L;
+    double *tauc = (double *)calloc((size_t)(L + 1), sizeof(double));
+    double *utau = (double *)calloc((size_t)(ntau + 1), sizeof(double));
+    for (int lc = 0; lc < L; ++lc) { dtauc[lc] = in->dtauc[lc]; ssalb[lc] = in->ssalb[lc]; }
+    /* disort.f:482-489 */
+    for (int lc = 1; lc <= L; ++lc) {
+        if (ssalb[lc - 1] == 1.0) ssalb[lc - 1] = 1.0 - dither;
+        tauc[lc] = tauc[lc - 1] + dtauc[lc - 1];
+    }
+    int inperr = 0;
+    double yessct = 0.0;
+    for (int lc = 0; lc < L; ++lc) {
+        if (dtauc[lc] < 0.0) dtauc[lc] = 0.0; /* disort.f:4944 */
+        if (ssalb[lc] < 0.0 || ssalb[lc] > 1.0) inperr = 1;
+        yessct += ssalb[lc];
+        if (in->plank) {
+            if (lc == 0 && in->temper[0] < 0.0) inperr = 1;
+            if (in->temper[lc + 1] < 0.0) inperr = 1;
+        }
+    }
+    if (in->nmom < 0 || (yessct > 0.0 && in->nmom < n)) inperr = 1;
+    for (int lc = 0; lc < L; ++lc)
+        for (int k = 0; k <= in->nmom; ++k) {
+            double pm = in->pmom[(size_t)lc * (in->nmom + 1) + k];
+            if (pm < -1.0 || pm > 1.0) inperr = 1;
+        }
+    if (in->usrtau) {
+        for (int lu = 0; lu < ntau; ++lu) {
+            utau[lu] = in->utau[lu];
+            if (fabs(utau[lu] - tauc[L]) <= f32(1.0e-4f)) utau[lu] = tauc[L];
+            if (utau[lu] < 0.0 || utau[lu] > tauc[L]) inperr = 1;
+        }
+    }
+    if (in->usrang) {
+        if (in->numu < 0 || (!in->onlyfl && in->numu == 0)) inperr = 1;
+        for (int iu = 0; iu < in->numu; ++iu) {
+            if (in->umu[iu] < -1.0 || in->umu[iu] > 1.0 || in->umu[iu] == 0.0) inperr = 1;
+            if (iu > 0 && in->umu[iu] < in->umu[iu - 1]) inperr = 1;
+        }
+    } else if (!in->onlyfl) {
+        inperr = 1; /* CMPINT path (intensities at quadrature angles) is never used by SBDART */
+    }
+    if (!in->onlyfl) {
+        if (in->nphi <= 0) inperr = 1;
+        for (int j = 0; j < in->nphi; ++j)
+            if (in->phi[j] < 0.0 || in->phi[j] > 360.0) inperr = 1;
+    }
+    if (in->fbeam < 0.0) inperr = 1;
+    if (in->fbeam > 0.0 && (in->umu0 <= 0.0 || in->umu0 > 1.0)) inperr = 1;
+    if (in->fbeam > 0.0 && (in->phi0 < 0.0 || in->phi0 > 360.0)) inperr = 1;
+    if (in->fisot < 0.0) inperr = 1;
+    if (!in->lamber) inperr = 1; /* BRDF surfaces: out of scope */
+    if (in->albedo < 0.0 || in->albedo > 1.0) inperr = 1;
+    if (in->plank) {
+        if (in->wvnmlo < 0.0 || in->wvnmhi <= in->wvnmlo) inperr = 1;
+        if (in->temis < 0.0 || in->temis > 1.0) inperr = 1;
+        if (in->btemp < 0.0 || in->ttemp < 0.0) inperr = 1;
+    }
+    if (inperr) {
+        free(dtauc); free(tauc); free(utau);
+        out->status = SBDO_ERR_INPUT;
+        return out->status;
+    }
+
+    /* ---- arena ---- */
+    const int lda = 9 * nn - 2;
+    size_t need = 0;
+    need += 2 * (size_t)n;                                   /* cmu cwt */
+    need += (size_t)(n + 1) * L;                             /* gl */
+    need += 2 * (size_t)(L + 1) + 3 * (size_t)L;             /* taucpr expbea dtaucp oprim flyr */
+    need += (size_t)(L + 1) + 2 * (size_t)L;                 /* pkag xr0 xr1 */
+    need += (size_t)(n + 1) * (1 + n + (numu > 0 ? numu : 1));
+    need += (size_t)n * n * L + 5 * (size_t)n * L;           /* gc kk ll zz zplk0 zplk1 */
+    need += (size_t)(numu > 0 ? numu : 1) * ((size_t)n * L + 3 * (size_t)L);
+    need += (size_t)nn * (nn + 1) + nn + (size_t)(numu > 0 ? numu : 1) * (nn + 2);
+    need += 2 * (size_t)nn * nn + 4 * (size_t)n * n + nn + 8 * (size_t)n + 2 * (size_t)(n + 1);
+    need += (size_t)lda * n * L + 2 * (size_t)n * L;         /* cband b z */
+    need += 2 * (size_t)(ntau + 1) + (size_t)(numu > 0 ? numu : 1) * ntau + (size_t)nphi + 16;
+    double *arena = (double *)calloc(need, sizeof(double));
+    int *ipvt = (int *)calloc((size_t)n * L + n, sizeof(int));
+    int *layru = (int *)calloc((size_t)ntau + 1, sizeof(int));
+    double *pa = arena;
+    work_t W, *w = &W;
+    memset(w, 0, sizeof(W));
+    w->n = n; w->nn = nn; w->L = L; w->numu = numu;
+    w->cmu = carve(&pa, n); w->cwt = carve(&pa, n);
+    w->gl = carve(&pa, (size_t)(n + 1) * L);
+    w->tauc = tauc;
+    w->taucpr = carve(&pa, L + 1); w->expbea = carve(&pa, L + 1);
+    w->dtaucp = carve(&pa, L); w->oprim = carve(&pa, L); w->flyr = carve(&pa, L);
+    w->pkag = carve(&pa, L + 1); w->xr0 = carve(&pa, L); w->xr1 = carve(&pa, L);
+    w->ylm0 = carve(&pa, n + 1); w->ylmc = carve(&pa, (size_t)(n + 1) * n);
+    w->ylmu = carve(&pa, (size_t)(n + 1) * (numu > 0 ? numu : 1));
+    w->gc = carve(&pa, (size_t)n * n * L);
+    w->kk = carve(&pa, (size_t)n * L); w->ll = carve(&pa, (size_t)n * L);
+    w->zz = carve(&pa, (size_t)n * L);
+    w->zplk0 = carve(&pa, (size_t)n * L); w->zplk1 = carve(&pa, (size_t)n * L);
+    w->gu = carve(&pa, (size_t)(numu > 0 ? numu : 1) * n * L);
+    w->zbeam = carve(&pa, (size_t)(numu > 0 ? numu : 1) * L);
+    w->z0u = carve(&pa, (size_t)(numu > 0 ? numu : 1) * L);
+    w->z1u = carve(&pa, (size_t)(numu > 0 ? numu : 1) * L);
+    w->bdr = carve(&pa, (size_t)nn * (nn + 1)); w->bem = carve(&pa, nn);
+    w->rmu = carve(&pa, (size_t)(numu > 0 ? numu : 1) * (nn + 1));
+    w->emu = carve(&pa, (numu > 0 ? numu : 1));
+    double *amb = carve(&pa, (size_t)nn * nn), *apb = carve(&pa, (size_t)nn * nn);
+    double *array = carve(&pa, (size_t)n * n), *cc = carve(&pa, (size_t)n * n);
+    double *evecc = carve(&pa, (size_t)n * n), *eval = carve(&pa, nn);
+    double *wk = carve(&pa, n + 1), *wkd = carve(&pa, 2 * n), *zj = carve(&pa, n);
+    double *z0 = carve(&pa, n), *z1 = carve(&pa, n), *psi0 = carve(&pa, n + 1), *psi1 = carve(&pa, n + 1);
+    double *cband = carve(&pa, (size_t)lda * n * L);
+    double *b = carve(&pa, (size_t)n * L), *zwork = carve(&pa, (size_t)n * L);
+    double *utaupr = carve(&pa, ntau + 1);
+    double *uum = carve(&pa, (size_t)(numu > 0 ? numu : 1) * ntau);
+    double *phirad = carve(&pa, nphi + 1);
+    double *pmomn = carve(&pa, 1); /* scratch */
+    (void)pmomn;
+
+    /* ---- SETDIS (disort.f:2454-2700) ---- */
+    const double abscut = 10.0;
+    if (!in->usrtau)
+        for (int lc = 0; lc <= L; ++lc) utau[lc] = tauc[lc];
+    w->expbea[0] = 1.0;
+    w->taucpr[0] = 0.0;
+    double abstau = 0.0;
+    int ncut = L;
+    yessct = 0.0;
+    for (int lc = 1; lc <= L; ++lc) {
+        const double *pm = in->pmom + (size_t)(lc - 1) * (in->nmom + 1);
+        yessct = yessct + ssalb[lc - 1];
+        if (abstau < abscut) ncut = lc;
+        abstau = abstau + (1.0 - ssalb[lc - 1]) * dtauc[lc - 1];
+        double f = (n <= in->nmom) ? pm[n] : 0.0;
+        w->oprim[lc - 1] = ssalb[lc - 1] * (1.0 - f) / (1.0 - f * ssalb[lc - 1]);
+        w->dtaucp[lc - 1] = (1.0 - f * ssalb[lc - 1]) * dtauc[lc - 1];
+        w->taucpr[lc] = w->taucpr[lc - 1] + w->dtaucp[lc - 1];
+        for (int k = 0; k <= n - 1; ++k) {
+            double pk = (k == 0) ? 1.0 : ((k <= in->nmom) ? pm[k] : 0.0); /* PMOM(0,LC)=1 */
+            GL(k, lc) = (double)(2 * k + 1) * w->oprim[lc - 1] * (pk - f) / (1.0 - f);
+        }
+        w->flyr[lc - 1] = f;
+        w->expbea[lc] = 0.0;
+        if (in->fbeam > 0.0) w->expbea[lc] = exp(-w->taucpr[lc] / in->umu0);
+    }
+    int lyrcut = 0;
+    if (abstau >= abscut && !in->plank && L > 1) lyrcut = 1;
+    if (!lyrcut) ncut = L;
+    w->ncut = ncut;
+    w->lyrcut = lyrcut;
+    for (int lu = 1; lu <= ntau; ++lu) {
+        int lc;
+        for (lc = 1; lc <= L; ++lc)
+            if (utau[lu - 1] >= tauc[lc - 1] && utau[lu - 1] <= tauc[lc]) break;
+        if (lc > L) lc = L;
+        utaupr[lu - 1] = w->taucpr[lc - 1] + (1.0 - ssalb[lc - 1] * w->flyr[lc - 1]) * (utau[lu - 1] - tauc[lc - 1]);
+        layru[lu - 1] = lc;
+    }
+    sbdo_qgausn(nn, w->cmu, w->cwt);
+    for (int iq = 1; iq <= nn; ++iq) { CMU(iq + nn) = -CMU(iq); CWT(iq + nn) = CWT(iq); }
+    if (in->fbeam > 0.0) {
+        int hit = 0;
+        for (int iq = 1; iq <= nn; ++iq)
+            if (fabs(in->umu0 - CMU(iq)) / in->umu0 < f32(1.0e-4f)) hit = 1;
+        if (hit) { /* disort.f:2645-2650: caller retries with another NSTR */
+            out->nstr_out = -abs(n0);
+            status |= SBDO_RETRY_NSTR;
+            goto done;
+        }
+    }
+    const double *umu = in->umu;
+
+    /* ---- Planck functions (disort.f:548-571) ---- */
+    double bplank = 0.0, tplank = 0.0;
+    if (in->plank) {
+        int pw = 0;
+        tplank = in->temis * sbdo_plkavg(in->wvnmlo, in->wvnmhi, in->ttemp, &pw);
+        bplank = sbdo_plkavg(in->wvnmlo, in->wvnmhi, in->btemp, &pw);
+        for (int lev = 0; lev <= L; ++lev) w->pkag[lev] = sbdo_plkavg(in->wvnmlo, in->wvnmhi, in->temper[lev], &pw);
+        if (pw) status |= SBDO_WARN_PLKAVG;
+    }
+
+    /* ---- azimuth loop (disort.f:577-829) ---- */
+    int kconv = 0;
+    int naz = n - 1;
+    {
+        const double e5 = f32(1.0e-5f);
+        if (in->fbeam == 0.0 || fabs(1.0 - in->umu0) < e5 || in->onlyfl
+            || (numu == 1 && fabs(1.0 - umu[0]) < e5) || (numu == 1 && fabs(1.0 + umu[0]) < e5)
+            || (numu == 2 && fabs(1.0 + umu[0]) < e5 && fabs(1.0 - umu[1]) < e5))
+            naz = 0;
+    }
+    for (int mazim = 0; mazim <= naz; ++mazim) {
+        double delm0 = (mazim == 0) ? 1.0 : 0.0;
+        if (in->fbeam > 0.0) {
+            double angcos = -in->umu0;
+            sbdo_lepoly(1, mazim, n, n - 1, &angcos, w->ylm0);
+        }
+        if (!in->onlyfl && in->usrang) sbdo_lepoly(numu, mazim, n, n - 1, umu, w->ylmu);
+        sbdo_lepoly(nn, mazim, n, n - 1, w->cmu, w->ylmc);
+        double sgn = -1.0;
+        for (int l = mazim; l <= n - 1; ++l) {
+            sgn = -sgn;
+            for (int iq = nn + 1; iq <= n; ++iq) YLMC(l, iq) = sgn * YLMC(l, iq - nn);
+        }
+        /* SURFAC, Lambertian branch (disort.f:3746-3763, 3843-3849) */
+        if (!lyrcut) {
+            for (int i = 0; i < nn * (nn + 1); ++i) w->bdr[i] = 0.0;
+            for (int i = 0; i < nn; ++i) w->bem[i] = 0.0;
+            if (mazim == 0) {
+                for (int iq = 1; iq <= nn; ++iq) {
+                    w->bem[iq - 1] = 1.0 - in->albedo;
+                    for (int jq = 0; jq <= nn; ++jq) BDR(iq, jq) = in->albedo;
+                }
+            }
+            if (!in->onlyfl && in->usrang) {
+                for (int i = 0; i < numu; ++i) w->emu[i] = 0.0;
+                for (int i = 0; i < numu * (nn + 1); ++i) w->rmu[i] = 0.0;
+                for (int iu = 1; iu <= numu; ++iu)
+                    if (umu[iu - 1] > 0.0 && mazim == 0) {
+                        for (int iq = 0; iq <= nn; ++iq) RMU(iu, iq) = in->albedo;
+                        w->emu[iu - 1] = 1.0 - in->albedo;
+                    }
+            }
+        }
+        /* layer loop (disort.f:638-693) */
+        for (int lc = 1; lc <= ncut; ++lc) {
+            int ier = soleig(w, lc, mazim, amb, apb, array, cc, evecc, eval, wkd);
+            if (ier != 0) { status |= SBDO_ERR_ASYMTX; goto done; }
+            if (in->fbeam > 0.0)
+                if (upbeam(w, lc, mazim, delm0, in->fbeam, pi, in->umu0, cc, array, ipvt, wk, zj))
+                    status |= SBDO_WARN_UPBEAM_RCOND;
+            if (in->plank && mazim == 0) {
+                w->xr1[lc - 1] = 0.0;
+                if (w->dtaucp[lc - 1] > 0.0) w->xr1[lc - 1] = (w->pkag[lc] - w->pkag[lc - 1]) / w->dtaucp[lc - 1];
+                w->xr0[lc - 1] = w->pkag[lc - 1] - w->xr1[lc - 1] * w->taucpr[lc - 1];
+                if (upisot(w, lc, cc, array, ipvt, wk, z0, z1)) status |= SBDO_WARN_UPISOT_RCOND;
+            }
+            if (!in->onlyfl && in->usrang) {
+                terpev(w, lc, mazim, evecc, wk);
+                terpso(w, lc, mazim, delm0, in->fbeam, in->plank, pi, z0, z1, zj, psi0, psi1);
+            }
+        }
+        int ncol = 0;
+        setmtx(w, cband, lda, delm0, in->lamber, wk, &ncol);
+        if (solve0(w, b, cband, lda, ncol, mazim, in->fbeam, in->fisot, in->lamber, pi, bplank, tplank,
+                   in->umu0, ipvt, zwork))
+            status |= SBDO_WARN_SOLVE0_RCOND;
+        if (mazim == 0) fluxes(w, ntau, layru, utau, utaupr, ssalb, in->fbeam, in->umu0, pi, out);
+        if (in->onlyfl) break;
+
+        for (size_t i = 0; i < (size_t)numu * ntau; ++i) uum[i] = 0.0;
+        usrint(w, ntau, layru, utaupr, umu, mazim, delm0, in->fbeam, in->fisot, in->lamber, in->plank,
+               pi, bplank, tplank, in->umu0, wk, uum);
+#define UU(iu, lu, j) out->uu[((size_t)((j) - 1) * ntau + (size_t)((lu) - 1)) * numu + (size_t)((iu) - 1)]
+        if (mazim == 0) {
+            for (int lu = 1; lu <= ntau; ++lu)
+                for (int iu = 1; iu <= numu; ++iu)
+                    for (int j = 1; j <= nphi; ++j) UU(iu, lu, j) = F2(uum, numu, iu, lu);
+            if (naz > 0)
+                for (int j = 1; j <= nphi; ++j) phirad[j - 1] = rpd * (in->phi[j - 1] - in->phi0);
+        } else {
+            double azerr = 0.0;
+            for (int j = 1; j <= nphi; ++j) {
+                double cosphi = cos((double)mazim * phirad[j - 1]);
+                for (int lu = 1; lu <= ntau; ++lu)
+                    for (int iu = 1; iu <= numu; ++iu) {
+                        double azterm = F2(uum, numu, iu, lu) * cosphi;
+                        UU(iu, lu, j) = UU(iu, lu, j) + azterm;
+                        double rr = ratio_(fabs(azterm), fabs(UU(iu, lu, j)));
+                        if (rr > azerr) azerr = rr;
+                    }
+            }
+            if (azerr <= in->accur /* ACCUR = 0 in SBDART, drt.f:142 */) kconv = kconv + 1;
+            if (kconv >= 2) break;
+        }
+#undef UU
+    }
+
+done:
+    out->status = status;
+    free(arena); free(ipvt); free(layru);
+    free(dtauc); free(tauc); free(utau);
+    return status;
+}

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Generate the golden DISORT records + stdout goldens under tests/golden/.
+
+Runs ONLY in the build container (needs /root/reference and amdflang):
+
+    ./oracle/build_ref.sh && python tests/golden/make_golden.py
+
+For every case below it writes the INPUT namelist the reference's own test
+script uses (TestRuns/test_runs:31-145) or a BASELINE.json config, runs
+oracle/_ref/sbdart_capture (the unmodified reference objects with the DISORT
+call site interposed, see oracle/ref/sbd_ref_capture.f90) and keeps a
+sub-sample of the captured DISORT input/output records, plus the stdout.
+
+Outputs are DATA (inputs + expected outputs): no reference source is copied.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from sbdart_amd.records import read_records, write_records  # noqa: E402
+
+CAPTURE = os.path.join(ROOT, "oracle", "_ref", "sbdart_capture")
+
+
+def run_case(namelist: str):
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "INPUT"), "w") as f:
+            f.write("\n &INPUT\n" + namelist + "\n /\n")
+        env = dict(os.environ, SBD_CAPTURE_FILE=os.path.join(d, "cap.sbdrec"))
+        out = subprocess.run([CAPTURE], cwd=d, env=env, capture_output=True, text=True, check=True).stdout
+        recs = read_records(os.path.join(d, "cap.sbdrec"))
+        warns = sorted(f for f in os.listdir(d) if f.startswith("SBDART_WARNING"))
+    return out, recs, warns
+
+
+def every_nth_wl(recs, n, offset=0):
+    return [r for r in recs if (r.iwl - 1 - offset) % n == 0]
+
+
+def main():
+    manifest = {}
+
+    def emit(name, namelists, pick, keep_stdout=True, full_inputs=False):
+        allrec, stdout, allw = [], "", []
+        for nl in namelists:
+            out, recs, warns = run_case(nl)
+            stdout += out
+            allrec += pick(recs)
+            allw += warns
+        path = os.path.join(HERE, name + ".sbdrec")
+        write_records(path, allrec, with_out=True)
+        entry = {"namelists": namelists, "records": len(allrec),
+                 "bytes": os.path.getsize(path),
+                 "sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(),
+                 "reference_warnings": sorted(set(allw))}
+        if keep_stdout:
+            with open(os.path.join(HERE, name + ".stdout"), "w") as f:
+                f.write(stdout)
+        manifest[name] = entry
+        print(name, entry["records"], "records", entry["bytes"], "bytes", entry["reference_warnings"])
+        return allrec
+
+    # --- TestRuns example 1 (test_runs:31-39): keep EVERY record (inputs+outputs): the
+    #     Fortran host replays this file end to end and must reproduce sbchk.1's stdout.
+    emit("sbchk1", ["    idatm=4,   isat=0, wlinf=.25, wlsup=1.0, wlinc=.005, iout=1,"],
+         lambda r: r)
+    # --- example 2 (test_runs:45-66): 48 single-wavelength runs, all kept
+    emit("sbchk2", [f" tcloud={t}\n albcon={a}\n idatm=4\n isat=0\n wlinf=.55\n wlsup=.55\n"
+                    f" isalb=0\n iout=10\n sza=30"
+                    for a in ("0", ".2", ".4", ".6", ".8", "1")
+                    for t in (0, 1, 2, 4, 8, 16, 32, 64)], lambda r: r)
+    # --- example 3 (test_runs:72-94): thermal, every 12th wavelength
+    emit("sbchk3", [f"  tcloud={t}\n  zcloud=8\n  nre=10\n  idatm=4\n  sza=95\n  wlinf=4\n"
+                    f"  wlsup=20\n  wlinc=-.01\n  iout=1" for t in (0, 1, 5)],
+         lambda r: every_nth_wl(r, 12))
+    # --- example 4 (test_runs:99-119): every 3rd case
+    cases4 = [f" tcloud={t}\n nre={n}\n wlinf={w}\n wlsup={w}\n idatm=1\n isat=0\n isalb=6\n"
+              f" iout=10\n sza=0"
+              for t in (0, 1, 2, 4, 8, 16, 32, 64, 128) for n in (2, 4, 8, 16, 32, 64, 128)
+              for w in (".55", "2.16")]
+    emit("sbchk4", cases4[::3], lambda r: r, keep_stdout=False)
+    # --- example 5 (test_runs:124-145): nstr=20 radiance
+    emit("sbchk5", [f"  tcloud= {t}\n  zcloud= 1\n  wlinf=.72\n  wlsup=.72\n  idatm=1\n  isalb=4\n"
+                    f"  sza=60\n  iout=21\n  nstr=20\n"
+                    f"  uzen=5,15,25,35,45,55,65,75,85,95,105,115,125,135,145,155,165,175\n"
+                    f"  phi=0,15,30,45,60,75,90,105,120,135,150,165,180" for t in (5, 15)],
+         lambda r: r)
+    # --- BASELINE.json configs ---
+    emit("cfgA_sw_nstr4", ["idatm=6 isat=0 wlinf=.25 wlsup=4.0 wlinc=.005 iout=1 nstr=4"],
+         lambda r: every_nth_wl(r, 60), keep_stdout=False)
+    emit("cfgB_sw_nstr16", ["idatm=6 isat=0 wlinf=.25 wlsup=4.0 wlinc=.005 iout=1 nstr=16"],
+         lambda r: every_nth_wl(r, 40, 3), keep_stdout=False)
+    emit("cfg3_lw_nstr16_cloud",
+         ["idatm=6 wlinf=4 wlsup=80 wlinc=-.01 nstr=16 tcloud=10 zcloud=1 nre=8 sza=95 iout=1"],
+         lambda r: every_nth_wl(r, 25, 2), keep_stdout=False)
+    emit("cfgC_rad_nstr32",
+         ["idatm=6 wlinf=.5 wlsup=.9 wlinc=.2 iout=5 nstr=32 iaer=1 vis=23 nzen=20 uzen=0,85 "
+          "nphi=16 phi=0,180 sza=30"], lambda r: r[:3], keep_stdout=False)
+    emit("cfgD_nstr32_50ly",
+         ["idatm=6 wlinf=.25 wlsup=100 wlinc=20 nstr=32 ngrid=50 iout=10 sza=30"],
+         lambda r: every_nth_wl(r, 250, 7), keep_stdout=False)
+
+    with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("total bytes", sum(e["bytes"] for e in manifest.values()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""The C oracle (oracle/disort_oracle.c) against DISORT input/output records
+captured from the reference executable (tests/golden/make_golden.py).
+
+The restatement reproduces the reference bit for bit on all of them (fp64,
+same libm); the assertion allows 1e-12 of the column maximum so that a
+different libm build cannot turn a last-ulp exp() difference into a failure.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle
+from sbdart_amd.records import read_records
+
+from conftest import GOLDEN
+
+FILES = sorted(glob.glob(os.path.join(GOLDEN, "*.sbdrec")))
+FLUX = ("rfldir", "rfldn", "flup", "dfdt", "uavg")
+TOL = 1e-12
+
+
+def test_golden_files_present():
+    names = {os.path.basename(f) for f in FILES}
+    for want in ("sbchk1", "sbchk2", "sbchk3", "sbchk4", "sbchk5", "cfgA_sw_nstr4",
+                 "cfgB_sw_nstr16", "cfg3_lw_nstr16_cloud", "cfgC_rad_nstr32", "cfgD_nstr32_50ly"):
+        assert want + ".sbdrec" in names
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_oracle_matches_reference_records(path):
+    recs = read_records(path)
+    assert recs
+    nbit = 0
+    for r in recs:
+        o = pyoracle.disort(r)
+        assert o["nstr_out"] == r.nstr_out
+        for f in FLUX:
+            ref = getattr(r, f)
+            scale = max(np.abs(ref).max(), 1e-300)
+            assert np.abs(o[f] - ref).max() <= TOL * scale, (path, f)
+            nbit += int(np.array_equal(o[f], ref))
+        if not r.onlyfl:
+            assert np.abs(o["uu"] - r.uu).max() <= TOL * np.abs(r.uu).max()
+            nbit += int(np.array_equal(o["uu"], r.uu))
+    # informational: how many arrays were bit-identical
+    print(os.path.basename(path), "bit-identical arrays:", nbit)
+
+
+def test_oracle_does_not_mutate_inputs():
+    r = read_records(os.path.join(GOLDEN, "sbchk2.sbdrec"))[5]
+    d0, s0, p0 = r.dtauc.copy(), r.ssalb.copy(), r.pmom.copy()
+    pyoracle.disort(r)
+    assert np.array_equal(d0, r.dtauc) and np.array_equal(s0, r.ssalb) and np.array_equal(p0, r.pmom)

@@ -1,0 +1,176 @@
+"""Known answers and building blocks of the C oracle.
+
+* SLFTST (disort.f:6268-6512): the reference's built-in known-answer case.
+  Its UU answer needs CORINT (Nakajima-Tanaka correction, out of scope: SURVEY
+  section 2 row 3b), so the three flux answers are the gate here.
+* When oracle/_ref/ref_units_cli exists (build container, GPU box via the
+  prebuilt binary) single reference routines are compared with the restatement.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import pyoracle
+from sbdart_amd.records import F_LAMBER, F_PLANK, F_USRANG, SolveRecord
+
+from conftest import REF_DIR, have_ref
+
+f32 = lambda x: float(np.float32(x))  # Fortran default-real literals
+dp = C.POINTER(C.c_double)
+
+
+def slftst_record():
+    # disort.f:6393-6430 (inputs are single-precision literals)
+    return SolveRecord(
+        nlyr=1, nstr=4, nmom=4, flags=F_PLANK | F_LAMBER | F_USRANG, wvnmlo=0.0, wvnmhi=50000.0,
+        fbeam=f32(3.14159265), umu0=f32(0.866), phi0=0.0, albedo=f32(0.7), btemp=300.0,
+        ttemp=100.0, temis=f32(0.8), fisot=1.0, dtauc=np.array([1.0]), ssalb=np.array([f32(0.9)]),
+        temper=np.array([210.0, 200.0]),
+        pmom=np.array([[1.0, f32(0.8042), f32(0.646094), f32(0.481851), f32(0.359056)]]),
+        umu=np.array([0.5]), phi=np.array([90.0]))
+
+
+def test_slftst_known_answers():
+    o = pyoracle.disort(slftst_record(), utau=[0.5], accur=f32(1e-4))
+    assert o["status"] == 0
+    # disort.f:6446-6449; the reference accepts 1e-4, the printed digits give ~1e-7
+    assert abs(o["rfldir"][0] / 1.527286 - 1) < 3e-7
+    assert abs(o["rfldn"][0] / 28.372225 - 1) < 3e-7
+    assert abs(o["flup"][0] / 152.585284 - 1) < 3e-7
+    # without CORINT the intensity sits 1.2e-4 below the corrected 47.865571
+    assert abs(o["uu"][0, 0, 0] / 47.865571 - 1) < 2e-4
+
+
+def test_constants():
+    L = pyoracle.lib()
+    assert L.sbdo_pi() == 3.14159274101257324  # 2.*ASIN(1.0) in fp32 (disort.f:441)
+    assert L.sbdo_dither() == 100 * 2.0 ** -52   # disort.f:442-448
+
+
+def test_qgausn_properties():
+    L = pyoracle.lib()
+    for m in (1, 2, 3, 4, 8, 10, 16, 20):
+        g, w = np.zeros(m), np.zeros(m)
+        L.sbdo_qgausn(m, g.ctypes.data_as(dp), w.ctypes.data_as(dp))
+        assert np.all(np.diff(g) > 0) and g[0] > 0 and g[-1] < 1
+        assert abs(w.sum() - 1) < 1e-14
+        for k in range(2 * m):  # exact for polynomials up to degree 2m-1
+            assert abs((w * g ** k).sum() - 1 / (k + 1)) < 1e-13
+
+
+def test_retry_request_when_beam_hits_quadrature_angle():
+    L = pyoracle.lib()
+    g, w = np.zeros(2), np.zeros(2)
+    L.sbdo_qgausn(2, g.ctypes.data_as(dp), w.ctypes.data_as(dp))
+    r = slftst_record()
+    r.umu0 = float(g[1])
+    o = pyoracle.disort(r)
+    assert o["nstr_out"] == -4 and o["status"] & pyoracle.RETRY_NSTR
+
+
+def test_input_errors():
+    r = slftst_record()
+    r.ssalb = np.array([1.5])
+    assert pyoracle.disort(r)["status"] & pyoracle.ERR_INPUT
+    r = slftst_record()
+    r.nstr = 5
+    assert pyoracle.disort(r)["status"] & pyoracle.ERR_INPUT
+
+
+def _run_ref_units(payload):
+    cli = os.path.join(REF_DIR, "ref_units_cli")
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "in.bin"), "wb") as f:
+            f.write(payload)
+        subprocess.check_call([cli, os.path.join(d, "in.bin"), os.path.join(d, "out.bin")], cwd=d)
+        return np.fromfile(os.path.join(d, "out.bin"), dtype="<f8")
+
+
+needs_ref = pytest.mark.skipif(not have_ref("ref_units_cli"), reason="oracle/_ref not built")
+
+
+@needs_ref
+def test_qgausn_vs_reference():
+    L = pyoracle.lib()
+    for m in (2, 4, 8, 10, 16, 20):
+        ref = _run_ref_units(struct.pack("<ii", 1, m))
+        g, w = np.zeros(m), np.zeros(m)
+        L.sbdo_qgausn(m, g.ctypes.data_as(dp), w.ctypes.data_as(dp))
+        assert np.array_equal(ref[:m], g) and np.array_equal(ref[m:], w)
+
+
+@needs_ref
+def test_plkavg_vs_reference():
+    L = pyoracle.lib()
+    cases = [(0, 50000, 300), (500, 520, 250), (2000, 2005, 288.0), (100, 3000, 210),
+             (12500, 12600, 5800), (100.0, 100.5, 300), (2500, 2525.25, 287), (10, 3000, 1e-5)]
+    for lo, hi, t in cases:
+        ref = _run_ref_units(struct.pack("<iddd", 2, lo, hi, t))[0]
+        assert L.sbdo_plkavg(lo, hi, t, None) == ref
+
+
+@needs_ref
+def test_asymtx_vs_reference():
+    L = pyoracle.lib()
+    rng = np.random.default_rng(7)
+    for m in (3, 4, 8, 10, 16):
+        g, w = np.zeros(m), np.zeros(m)
+        L.sbdo_qgausn(m, g.ctypes.data_as(dp), w.ctypes.data_as(dp))
+        for trial in range(6):
+            a = (np.diag(1 / g) @ (rng.random((m, m)) * 0.1 - np.eye(m)) @ np.diag(1 / g)
+                 @ (rng.random((m, m)) * 0.1 - np.eye(m)))
+            if trial == 5:  # isolated eigenvalues exercise the balancing permutations
+                a[0, 1:] = 0.0
+                a[2:, 1] = 0.0
+            af = np.asfortranarray(a)
+            ref = _run_ref_units(struct.pack("<ii", 3, m) + af.tobytes(order="F"))
+            aa = af.copy(order="F")
+            ev = np.zeros((m, m), order="F")
+            evl, wk = np.zeros(m), np.zeros(2 * m)
+            ier = L.sbdo_asymtx(aa.ctypes.data_as(dp), ev.ctypes.data_as(dp),
+                                evl.ctypes.data_as(dp), m, m, m, wk.ctypes.data_as(dp))
+            assert ier == int(ref[0])
+            assert np.array_equal(ref[1:1 + m], evl)
+            assert np.array_equal(ref[1 + m:], ev.flatten(order="F"))
+
+
+@needs_ref
+def test_lepoly_vs_reference():
+    L = pyoracle.lib()
+    mu = np.array([0.1, 0.5, -0.3, 0.9, -0.866])
+    n = 20
+    ref = _run_ref_units(struct.pack("<iiii", 4, len(mu), n, n - 1) + mu.tobytes())
+    ref = ref.reshape(n, len(mu), n + 1)
+    ylm = np.zeros((len(mu), n + 1))
+    for m in range(n):
+        L.sbdo_lepoly(len(mu), m, n, n - 1, mu.ctypes.data_as(dp), ylm.ctypes.data_as(dp))
+        assert np.array_equal(ylm, ref[m])
+
+
+@needs_ref
+def test_banded_solver_vs_reference():
+    L = pyoracle.lib()
+    rng = np.random.default_rng(3)
+    n, ml, mu = 40, 5, 5
+    lda = 2 * ml + mu + 1
+    m = ml + mu + 1
+    abd = np.zeros((lda, n), order="F")
+    for j in range(n):
+        for i in range(max(0, j - mu), min(n, j + ml + 1)):
+            abd[i - j + m - 1, j] = rng.standard_normal()
+    b = rng.standard_normal(n)
+    ref = _run_ref_units(struct.pack("<iiiii", 5, n, ml, mu, lda) + abd.tobytes(order="F") + b.tobytes())
+    a2 = abd.copy(order="F")
+    ipvt = np.zeros(n, dtype=np.int32)
+    info = C.c_int(0)
+    L.sbdo_sgbfa(a2.ctypes.data_as(dp), lda, n, ml, mu, ipvt.ctypes.data_as(C.POINTER(C.c_int)),
+                 C.byref(info))
+    x = b.copy()
+    L.sbdo_sgbsl(a2.ctypes.data_as(dp), lda, n, ml, mu, ipvt.ctypes.data_as(C.POINTER(C.c_int)),
+                 x.ctypes.data_as(dp))
+    assert np.array_equal(x, ref[1:])
