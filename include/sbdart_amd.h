@@ -1,0 +1,162 @@
+/*
+ * sbdart_amd -- MI355X-native batched DISORT engine for SBDART's wavelength loop.
+ *
+ * C ABI (plain pointers and sizes; no torch / HIP types in the signatures).
+ * This is the drop-in boundary for the reference's hot path:
+ *
+ *   reference interface being replaced                      entry point here
+ *   ------------------------------------------------------  ---------------------------
+ *   CALL DISORT(NLYR,DTAUC,SSALB,...,RFLDIR,RFLDN,FLUP,     sbd_engine_solve_host /
+ *        DFDT,UAVG,UU,...)   drt.f:541-546, disort.f:1-6    sbd_engine_solve_device
+ *     once per (wavelength, k-term) of wl_loop/kd_loop      (one call = a whole batch of
+ *     (drt.f:425-561)                                        (wavelength,k) work items)
+ *   per-run DISORT arguments that never change inside the   sbd_engine_create(sbd_run_cfg)
+ *     loop: NSTR, TEMPER, UMU0/PHI0, UMU, PHI, BTEMP, TTEMP,
+ *     TEMIS, LAMBER, ONLYFL, USRANG  (drt.f:330-335,391-421)
+ *   NSTR<0 "retry with another stream count" return         SBD_ST_RETRY_NSTR status bit /
+ *     (disort.f:2645-2650, drt.f:536-555)                    SBD_E_RETRY_NSTR from create
+ *   errmsg warnings 2,3,4 / fatal STOPs (disutil.f:278)     per-work-item status bits
+ *   stdout1's weighted spectral sums (drt.f:964-1087)       sbd_engine_accumulate_host/_device
+ *
+ * The Fortran-2003 host binds these through ISO_C_BINDING
+ * (sbdart_amd/fortran/sbd_engine_mod.f90); INTEGRATION.md shows the stub a
+ * maintainer of the reference adds around drt.f:529-560.
+ *
+ * All arithmetic is fp64.  All arrays are dense, row-major by work item
+ * ("[nwork][...]"), top-down in the vertical exactly like DISORT's arguments.
+ * The engine is re-entrant (no global state); one engine drives one GPU.
+ */
+#ifndef SBDART_AMD_H
+#define SBDART_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBD_ABI_VERSION 1
+
+/* limits of the reference (params.f:9-15) */
+#define SBD_MAX_NLYR 65   /* mxly   */
+#define SBD_MAX_NSTR 40   /* nstrms */
+
+/* ---- return codes (never exit(), never abort()) ---- */
+#define SBD_OK               0
+#define SBD_E_INVALID       -1  /* bad argument / CHEKIN-type fatal in the run config */
+#define SBD_E_RETRY_NSTR    -2  /* beam angle == a quadrature angle: pick NSTR-2 / NSTR+2
+                                   (disort.f:2645-2650; drt.f:536-555 does the retry) */
+#define SBD_E_NO_DEVICE     -3
+#define SBD_E_HIP           -4  /* a HIP runtime call failed; see sbd_last_error() */
+#define SBD_E_UNSUPPORTED   -5  /* BRDF surface, IBCND=1, CORINT */
+#define SBD_E_NOMEM         -6
+
+/* ---- per-work-item status bits ---- */
+#define SBD_ST_WARN_SOLVE0   0x01  /* band matrix singular pivot        (errmsg 2, disort.f:3609) */
+#define SBD_ST_WARN_UPBEAM   0x02  /* beam-source system singular pivot (errmsg 3, disort.f:4227) */
+#define SBD_ST_WARN_UPISOT   0x04  /* thermal-source system singular    (errmsg 4, disort.f:4333) */
+#define SBD_ST_ERR_EIGEN     0x08  /* eigen-solve did not converge (fatal, disort.f:3254-3261) */
+#define SBD_ST_RETRY_NSTR    0x10  /* disort.f:2645-2650 */
+#define SBD_ST_ERR_INPUT     0x20  /* CHEKIN fatal for this item (disort.f:5140) */
+#define SBD_ST_WARN_PLKAVG   0x40  /* errmsg 9 / 10 (disort.f:5597, 5657) */
+
+/* flux components per output level, in this order (DISORT's output arguments) */
+#define SBD_NFLUX 5
+enum { SBD_RFLDIR = 0, SBD_RFLDN = 1, SBD_FLUP = 2, SBD_DFDT = 3, SBD_UAVG = 4 };
+
+typedef struct sbd_engine sbd_engine;
+
+/* Per-run constants: everything drt.f fixes before wl_loop starts. */
+typedef struct {
+    int32_t abi_version;   /* SBD_ABI_VERSION */
+    int32_t nlyr;          /* NLYR = nz (drt.f:144; 1..65) */
+    int32_t nstr;          /* NSTR, even, 4..40 */
+    int32_t nmom;          /* highest Legendre moment supplied; PMOM row stride = nmom+1;
+                              drt.f:490-494 uses min(nstr+2, 40) */
+    int32_t onlyfl;        /* ONLYFL: 1 = fluxes only (iout not in 5,6,20..23) */
+    int32_t lamber;        /* must be 1 (Lambertian; BRDF is out of scope) */
+    int32_t usrang;        /* USRANG: radiances at umu[] (required when onlyfl=0) */
+    int32_t numu;          /* number of user polar angles (radiance mode) */
+    int32_t nphi;          /* number of user azimuths     (radiance mode) */
+    int32_t nlevel_out;    /* 0 = all nlyr+1 levels (DISORT's NTAU with USRTAU=F);
+                              else number of entries of level_out */
+    int32_t device;        /* HIP device ordinal */
+    int32_t max_batch;     /* largest nwork of one solve call (workspace is sized for
+                              min(max_batch, chunk)); 0 = default */
+    double umu0;           /* cosine of solar zenith (amu0, drt.f:421,456-459) */
+    double phi0;           /* solar azimuth, degrees */
+    double fisot;          /* isotropic top illumination (0 in SBDART) */
+    double btemp, ttemp, temis;   /* bottom/top temperature, top emissivity */
+    const double *temper;  /* [nlyr+1] level temperatures, top-down (drt.f:330-333) */
+    const double *umu;     /* [numu] ascending cosines (drt.f:393-403) or NULL */
+    const double *phi;     /* [nphi] degrees or NULL */
+    const int32_t *level_out; /* [nlevel_out] 0-based level indices (0 = TOA, nlyr = surface) */
+} sbd_run_cfg;
+
+/* One batch of (wavelength, k-term) work items: the per-call DISORT arguments. */
+typedef struct {
+    int32_t nwork;
+    const double *dtauc;    /* [nwork][nlyr]            DTAUC (dtaus, drt.f:531)  */
+    const double *ssalb;    /* [nwork][nlyr]            SSALB (wreal)             */
+    const double *pmom;     /* [nwork][nlyr][nmom+1]    PMOM(0:nmom, lc)          */
+    const double *wvnmlo;   /* [nwork]                  WVNMLO                    */
+    const double *wvnmhi;   /* [nwork]                  WVNMHI                    */
+    const double *fbeam;    /* [nwork]                  FBEAM (flxin, drt.f:448)  */
+    const double *albedo;   /* [nwork]                  ALBEDO (rsfc, drt.f:469)  */
+    const uint8_t *plank;   /* [nwork]                  PLANK (wl>2 um, drt.f:463)*/
+} sbd_batch_in;
+
+typedef struct {
+    double *flux;      /* [nwork][SBD_NFLUX][nlev]  nlev = nlevel_out or nlyr+1 */
+    double *uu;        /* [nwork][nphi][nlev][numu] or NULL when onlyfl */
+    int32_t *status;   /* [nwork] SBD_ST_* bits */
+} sbd_batch_out;
+
+/* ---- lifecycle ---- */
+int  sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out);
+void sbd_engine_destroy(sbd_engine *e);
+
+/* ---- the hot path ---- */
+/* Pointers in `in`/`out` are DEVICE pointers (HBM-resident, 8-byte aligned).
+ * `hip_stream` is a hipStream_t passed as void* (NULL = the engine's own stream).
+ * Asynchronous: returns after enqueueing; results are ordered on the stream. */
+int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out,
+                            void *hip_stream);
+/* Pointers are HOST pointers: stages H2D, solves, copies back, synchronises. */
+int sbd_engine_solve_host(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out);
+
+/* stdout1's reduction (drt.f:964-1054): acc[c][lev] += sum_i weight[i] * flux[i][c][lev],
+ * and acc_uu[phi][lev][mu] += sum_i weight[i]*uu[i][...] when uu != NULL.
+ * fp64, deterministic order (pairwise tree over i, independent of launch shape). */
+int sbd_engine_accumulate_device(sbd_engine *e, int32_t nwork, const double *weight,
+                                 const double *flux, const double *uu,
+                                 double *acc_flux, double *acc_uu, void *hip_stream);
+int sbd_engine_accumulate_host(sbd_engine *e, int32_t nwork, const double *weight,
+                               const double *flux, const double *uu,
+                               double *acc_flux, double *acc_uu);
+
+/* ---- introspection ---- */
+int32_t     sbd_abi_version(void);
+int32_t     sbd_engine_nlevel(const sbd_engine *e);     /* nlev of the outputs */
+size_t      sbd_engine_workspace_bytes(const sbd_engine *e);
+int32_t     sbd_engine_chunk(const sbd_engine *e);      /* work items per internal pass */
+void       *sbd_engine_stream(sbd_engine *e);           /* the engine's hipStream_t */
+/* Gauss quadrature the engine uses (QGAUSN, disort.f:5984): cmu/cwt get nstr/2 values */
+int         sbd_engine_quadrature(const sbd_engine *e, double *cmu, double *cwt);
+/* wall time (ms) of the kernels of the most recent solve_device call, measured with HIP
+ * events on the stream the kernels ran on; phase: 0 setup, 1 layer, 2 band+flux,
+ * 3 intensities, -1 total.  Synchronises the stream. */
+double      sbd_engine_last_ms(sbd_engine *e, int phase);
+void        sbd_engine_enable_timing(sbd_engine *e, int on);
+/* Test hook: copy one workspace array of the LAST chunk solved to the host.
+ * which: 0 gc, 1 kk, 2 ek, 3 zz, 4 zp0, 5 zp1, 6 ll, 7 sv, 8 svi(int32).  Returns bytes copied
+ * (<= nbytes) or a negative error. */
+long long   sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t nbytes);
+const char *sbd_strerror(int code);
+const char *sbd_last_error(void);   /* thread-local detail for SBD_E_HIP / SBD_E_INVALID */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBDART_AMD_H */

@@ -1712,6 +1712,14 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
                    in->umu0, ipvt, zwork))
             status |= SBDO_WARN_SOLVE0_RCOND;
         if (mazim == 0) fluxes(w, ntau, layru, utau, utaupr, ssalb, in->fbeam, in->umu0, pi, out);
+        if (mazim == out->dbg_mode) {
+            if (out->dbg_gc) memcpy(out->dbg_gc, w->gc, sizeof(double) * (size_t)n * n * L);
+            if (out->dbg_kk) memcpy(out->dbg_kk, w->kk, sizeof(double) * (size_t)n * L);
+            if (out->dbg_ll) memcpy(out->dbg_ll, w->ll, sizeof(double) * (size_t)n * L);
+            if (out->dbg_zz) memcpy(out->dbg_zz, w->zz, sizeof(double) * (size_t)n * L);
+            if (out->dbg_zplk0) memcpy(out->dbg_zplk0, w->zplk0, sizeof(double) * (size_t)n * L);
+            if (out->dbg_zplk1) memcpy(out->dbg_zplk1, w->zplk1, sizeof(double) * (size_t)n * L);
+        }
         if (in->onlyfl) break;
 
         for (size_t i = 0; i < (size_t)numu * ntau; ++i) uum[i] = 0.0;

@@ -52,6 +52,11 @@ typedef struct {
     double *uu;                 /* [nphi][ntau][numu], may be NULL when onlyfl */
     double *u0c;                /* optional [ntau][nstr] azimuthal-mean intensities at
                                    quadrature angles (FLUXES' U0C), may be NULL */
+    /* optional debug dumps of the azimuth mode `dbg_mode` (all may be NULL):
+       gc [nlyr][nstr(j)][nstr(i)] = GC(i,j,lc) column-major per layer; kk, ll, zz, zplk0,
+       zplk1 [nlyr][nstr] */
+    int dbg_mode;
+    double *dbg_gc, *dbg_kk, *dbg_ll, *dbg_zz, *dbg_zplk0, *dbg_zplk1;
 } sbdo_out;
 
 int  sbdo_disort(const sbdo_in *in, sbdo_out *out);

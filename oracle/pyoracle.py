@@ -33,7 +33,9 @@ class _In(C.Structure):
 
 class _Out(C.Structure):
     _fields_ = [("nstr_out", C.c_int), ("status", C.c_int), ("ntau", C.c_int)] + \
-               [(k, _dp) for k in ("rfldir", "rfldn", "flup", "dfdt", "uavg", "uu", "u0c")]
+               [(k, _dp) for k in ("rfldir", "rfldn", "flup", "dfdt", "uavg", "uu", "u0c")] + \
+               [("dbg_mode", C.c_int)] + \
+               [(k, _dp) for k in ("dbg_gc", "dbg_kk", "dbg_ll", "dbg_zz", "dbg_zplk0", "dbg_zplk1")]
 
 
 def build(force: bool = False) -> str:
@@ -69,7 +71,7 @@ def _p(a: np.ndarray):
     return a.ctypes.data_as(_dp)
 
 
-def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False):
+def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False, debug_mode=None):
     """Solve one record (sbdart_amd.records.SolveRecord-like). Returns a dict."""
     L = lib()
     f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
@@ -93,6 +95,14 @@ def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False):
     u0c = np.zeros((ntau, rec.nstr))
     o = _Out(rfldir=_p(flx[0]), rfldn=_p(flx[1]), flup=_p(flx[2]), dfdt=_p(flx[3]),
              uavg=_p(flx[4]), uu=_p(uu), u0c=_p(u0c) if want_u0c else None)
+    dbg = None
+    if debug_mode is not None:
+        n_, L_ = rec.nstr, rec.nlyr
+        dbg = dict(gc=np.zeros((L_, n_, n_)), kk=np.zeros((L_, n_)), ll=np.zeros((L_, n_)),
+                   zz=np.zeros((L_, n_)), zplk0=np.zeros((L_, n_)), zplk1=np.zeros((L_, n_)))
+        o.dbg_mode = int(debug_mode)
+        for k_, v_ in dbg.items():
+            setattr(o, "dbg_" + k_, _p(v_))
     st = L.sbdo_disort(C.byref(i), C.byref(o))
     res = dict(status=st, nstr_out=o.nstr_out, rfldir=flx[0], rfldn=flx[1], flup=flx[2],
                dfdt=flx[3], uavg=flx[4])
@@ -100,4 +110,7 @@ def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False):
         res["uu"] = uu[:nphi, :, :numu]
     if want_u0c:
         res["u0c"] = u0c
+    if dbg is not None:
+        dbg["gc"] = dbg["gc"].transpose(0, 2, 1).copy()   # -> [lc][i][j]
+        res["dbg"] = dbg
     return res

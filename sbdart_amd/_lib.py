@@ -1,0 +1,96 @@
+"""ctypes view of the C ABI in include/sbdart_amd.h.  Fails loudly when the HIP
+library is missing: there is no CPU fallback in the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsbdart_amd.so")
+
+ABI_VERSION = 1
+NFLUX = 5
+RFLDIR, RFLDN, FLUP, DFDT, UAVG = range(5)
+
+OK, E_INVALID, E_RETRY_NSTR, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
+ST_WARN_SOLVE0, ST_WARN_UPBEAM, ST_WARN_UPISOT, ST_ERR_EIGEN = 0x01, 0x02, 0x04, 0x08
+ST_RETRY_NSTR, ST_ERR_INPUT, ST_WARN_PLKAVG = 0x10, 0x20, 0x40
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_uint8)
+
+
+class RunCfg(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in
+                ("abi_version", "nlyr", "nstr", "nmom", "onlyfl", "lamber", "usrang", "numu",
+                 "nphi", "nlevel_out", "device", "max_batch")] + \
+               [(k, C.c_double) for k in ("umu0", "phi0", "fisot", "btemp", "ttemp", "temis")] + \
+               [("temper", _dp), ("umu", _dp), ("phi", _dp), ("level_out", _ip)]
+
+
+class BatchIn(C.Structure):
+    _fields_ = [("nwork", C.c_int32), ("dtauc", C.c_void_p), ("ssalb", C.c_void_p),
+                ("pmom", C.c_void_p), ("wvnmlo", C.c_void_p), ("wvnmhi", C.c_void_p),
+                ("fbeam", C.c_void_p), ("albedo", C.c_void_p), ("plank", C.c_void_p)]
+
+
+class BatchOut(C.Structure):
+    _fields_ = [("flux", C.c_void_p), ("uu", C.c_void_p), ("status", C.c_void_p)]
+
+
+EXPORTS = (
+    "sbd_engine_create", "sbd_engine_destroy", "sbd_engine_solve_device", "sbd_engine_solve_host",
+    "sbd_engine_accumulate_device", "sbd_engine_accumulate_host", "sbd_abi_version",
+    "sbd_engine_nlevel", "sbd_engine_workspace_bytes", "sbd_engine_chunk", "sbd_engine_stream",
+    "sbd_engine_quadrature", "sbd_engine_last_ms", "sbd_engine_enable_timing", "sbd_strerror",
+    "sbd_last_error", "sbd_engine_debug_copy",
+)
+
+_LIB = None
+
+
+def load() -> C.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"sbdart_amd: HIP library not built ({LIB_PATH}); run `python -c 'import "
+            f"__graft_entry__ as g; g.build()'` or `make -C sbdart_amd/csrc`. There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.sbd_engine_create.argtypes = [C.POINTER(RunCfg), C.POINTER(vp)]
+    L.sbd_engine_create.restype = C.c_int
+    L.sbd_engine_destroy.argtypes = [vp]
+    L.sbd_engine_destroy.restype = None
+    L.sbd_engine_solve_device.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(BatchOut), vp]
+    L.sbd_engine_solve_device.restype = C.c_int
+    L.sbd_engine_solve_host.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(BatchOut)]
+    L.sbd_engine_solve_host.restype = C.c_int
+    L.sbd_engine_accumulate_device.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.sbd_engine_accumulate_device.restype = C.c_int
+    L.sbd_engine_accumulate_host.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp]
+    L.sbd_engine_accumulate_host.restype = C.c_int
+    L.sbd_abi_version.restype = C.c_int32
+    L.sbd_engine_nlevel.argtypes = [vp]
+    L.sbd_engine_nlevel.restype = C.c_int32
+    L.sbd_engine_workspace_bytes.argtypes = [vp]
+    L.sbd_engine_workspace_bytes.restype = C.c_size_t
+    L.sbd_engine_chunk.argtypes = [vp]
+    L.sbd_engine_chunk.restype = C.c_int32
+    L.sbd_engine_stream.argtypes = [vp]
+    L.sbd_engine_stream.restype = vp
+    L.sbd_engine_quadrature.argtypes = [vp, _dp, _dp]
+    L.sbd_engine_quadrature.restype = C.c_int
+    L.sbd_engine_last_ms.argtypes = [vp, C.c_int]
+    L.sbd_engine_last_ms.restype = C.c_double
+    L.sbd_engine_enable_timing.argtypes = [vp, C.c_int]
+    L.sbd_engine_enable_timing.restype = None
+    L.sbd_strerror.argtypes = [C.c_int]
+    L.sbd_strerror.restype = C.c_char_p
+    L.sbd_last_error.restype = C.c_char_p
+    L.sbd_engine_debug_copy.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.sbd_engine_debug_copy.restype = C.c_longlong
+    _LIB = L
+    return L

@@ -1,0 +1,100 @@
+// sbdart_amd -- shared device/host definitions for the batched DISORT engine (gfx950).
+//
+// Data layout in HBM (all fp64 unless noted; "slot" = work item inside the current
+// chunk, "ms" = slot * nmode + azimuth mode):
+//
+//   inputs   dtauc/ssalb [nwork][L], pmom [nwork][L][nmom+1], wvnmlo/hi, fbeam, albedo [nwork]
+//   sv       [slot][SV(L)]   per-solve vectors from the setup kernel (delta-M scaled
+//                            optical depths, beam transmission, Planck terms, ...)
+//   svi      [slot][SVI(L)]  int32: ncut, lyrcut, status, layru[L+1]
+//   gc       [ms][L][n][n]   eigenvector blocks GC(iq,jq,lc), ROW-major in (iq,jq) so that
+//                            the band assembly / flux evaluation read contiguous rows
+//   kk       [ms][L][n]      eigenvalues, -k first (disort.f:3264-3269 ordering)
+//   ek       [ms][L][nn]     exp(KK(iq)*dtau') iq<=nn  (STWJ scaling factors, disort.f:2846)
+//   zz, zp0, zp1, ll [ms][L][n]   particular solutions and integration constants
+//   ufac     [ms][N][CW]     U factor of the band LU, LINPACK column-band layout
+//   gu       [ms][L][n][numu], zb/z0u/z1u [ms][L][numu]   user-angle interpolants (radiance)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SBD_DEVICE __device__ __forceinline__
+
+namespace sbd {
+
+constexpr int kMaxNlyr = 65;   // params.f: mxly
+constexpr int kMaxNstr = 40;   // params.f: nstrms
+
+// fp32-rounded literals of the reference (every un-suffixed Fortran literal is REAL*4)
+#define SBD_F32(x) ((double)(x##f))
+
+struct Tables {            // per-run constants, device pointers
+    const double *cmu;     // [n]   +mu (1..nn) then -mu
+    const double *cwt;     // [n]
+    const double *ylmc;    // [nmode][n][n+1]   YLMC(l, iq), mirrored for iq>nn
+    const double *ylm0;    // [nmode][n+1]      YLM0(l) at -umu0
+    const double *ylmu;    // [nmode][numu][n+1]
+    const double *cosmphi; // [nmode][nphi]     cos(m*(phi-phi0)*rpd), row 0 = 1
+    const double *temper;  // [L+1]
+    const double *umu;     // [numu]
+    const int32_t *level_out; // [nlev]
+};
+
+struct Params {
+    int32_t L, n, nn, nmom, numu, nphi, nlev, nmode;
+    int32_t onlyfl, usrang, all_levels;
+    int32_t nslot;          // work items in this chunk
+    int32_t sv_stride, svi_stride;
+    int32_t cw, ncd;        // band: CW = 2*ncd+1 columns kept per U row, ncd = 3nn-1
+    double umu0, fisot, btemp, ttemp, temis;
+    double pi, dither;
+    Tables t;
+    // chunk inputs (device pointers, already offset to the chunk)
+    const double *dtauc, *ssalb, *pmom, *wvnmlo, *wvnmhi, *fbeam, *albedo;
+    const uint8_t *plank;
+    // workspace
+    double *sv; int32_t *svi;
+    double *gc, *kk, *ek, *zz, *zp0, *zp1, *ll, *ufac;
+    double *gu, *zb, *z0u, *z1u, *uum;
+    // outputs (offset to the chunk)
+    double *flux, *uu; int32_t *status;
+};
+
+// ---- per-solve vector block (doubles) ----
+// offsets inside sv[slot]
+struct SV {
+    int L;
+    __host__ __device__ explicit SV(int L_) : L(L_) {}
+    __host__ __device__ int ssalb()  const { return 0; }              // [L]  dithered
+    __host__ __device__ int dtaucp() const { return L; }              // [L]
+    __host__ __device__ int taucpr() const { return 2 * L; }          // [L+1]
+    __host__ __device__ int oprim()  const { return 3 * L + 1; }      // [L]
+    __host__ __device__ int flyr()   const { return 4 * L + 1; }      // [L]
+    __host__ __device__ int expbea() const { return 5 * L + 1; }      // [L+1]
+    __host__ __device__ int pkag()   const { return 6 * L + 2; }      // [L+1]
+    __host__ __device__ int xr0()    const { return 7 * L + 3; }      // [L]
+    __host__ __device__ int xr1()    const { return 8 * L + 3; }      // [L]
+    __host__ __device__ int utau()   const { return 9 * L + 3; }      // [L+1]
+    __host__ __device__ int utaupr() const { return 10 * L + 4; }     // [L+1]
+    __host__ __device__ int bplank() const { return 11 * L + 5; }
+    __host__ __device__ int tplank() const { return 11 * L + 6; }
+    __host__ __device__ int size()   const { return 11 * L + 8; }
+};
+// svi[slot]: 0 ncut, 1 lyrcut, 2 status, 3.. layru[L+1]
+#define SBD_SVI_NCUT 0
+#define SBD_SVI_LYRCUT 1
+#define SBD_SVI_STATUS 2
+#define SBD_SVI_LAYRU 3
+
+// Lanes of one wave exchange data through LDS without a hardware barrier: LDS
+// instructions of a wave execute in order, so a compiler+counter fence suffices.
+SBD_DEVICE void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+SBD_DEVICE double dsign(double a, double b) { return (b >= 0.0) ? fabs(a) : -fabs(a); }
+
+}  // namespace sbd

@@ -1,0 +1,664 @@
+// sbdart_amd -- host side of the C ABI (include/sbdart_amd.h): per-run tables, HBM
+// workspace, chunked kernel pipeline on one HIP stream, timing with HIP events.
+//
+// Pipeline per chunk of work items (all on the caller's / engine's stream):
+//   setup_kernel   (disort.f:482-571)   -> sv/svi
+//   layer_kernel   (disort.f:638-693)   -> gc, kk, ek, zz, zp0/1 [, gu, zb, z0u, z1u]
+//   band_kernel    (disort.f:701-721)   -> ll, flux
+//   usrint_kernel + azimuth_kernel (disort.f:745-825), radiance mode only -> uu
+//   finish_kernel                       -> status
+#include "../../include/sbdart_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "sbd_common.hpp"
+namespace sbd { constexpr int SBD_NFLUX_ = SBD_NFLUX; }
+#include "sbd_setup.hpp"
+#include "sbd_layer.hpp"
+#include "sbd_band.hpp"
+#include "sbd_usrint.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(SBD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+// ---- per-run tables on the host (fp64, the reference's fp32-widened constants) ----
+inline double ref_pi() { return (double)(2.0f * asinf(1.0f)); }              // disort.f:441
+inline double ref_sqt(int k) { return (double)sqrtf((float)k); }             // disort.f:452-454
+
+// Gauss-Legendre rule on (0,1), Newton with cubic correction (QGAUSN, disort.f:5984-6157)
+void gauss01(int m, double *gmu, double *gwt)
+{
+    const double pi = ref_pi(), tol = 10.0 * 2.220446049250313e-16;
+    if (m == 1) { gmu[0] = 0.5; gwt[0] = 1.0; return; }
+    const double en = m, nnp1 = (double)(m * (m + 1));
+    const double cona = (double)((float)(m - 1) / (float)(8 * m * m * m));
+    const int lim = m / 2;
+    for (int k = 1; k <= lim; ++k) {
+        const double t = (double)(4 * k - 1) * pi / (double)(4 * m + 2);
+        double x = cos(t + cona / tan(t)), p = 0, pm1, pm2, tmp, ppr;
+        for (;;) {
+            pm2 = 1.0;
+            pm1 = x;
+            for (int nn = 2; nn <= m; ++nn) {
+                p = ((double)(2 * nn - 1) * x * pm1 - (double)(nn - 1) * pm2) / (double)nn;
+                pm2 = pm1;
+                pm1 = p;
+            }
+            tmp = 1.0 / (1.0 - x * x);
+            ppr = en * (pm2 - x * p) * tmp;
+            const double p2pri = (2.0 * x * ppr - nnp1 * p) * tmp;
+            const double xi = x - (p / ppr) * (1.0 + (p / ppr) * p2pri / (2.0 * ppr));
+            if (fabs(xi - x) > tol) { x = xi; continue; }
+            break;
+        }
+        const double ep = en * pm2;
+        gmu[k - 1] = -x;
+        gwt[k - 1] = 2.0 / (tmp * (ep * ep));
+        gmu[m - k] = x;
+        gwt[m - k] = gwt[k - 1];
+    }
+    if (m % 2) {
+        gmu[lim] = 0.0;
+        double prod = 1.0;
+        for (int k = 3; k <= m; k += 2) prod = prod * (double)k / (double)(k - 1);
+        gwt[lim] = 2.0 / (prod * prod);
+    }
+    for (int k = 0; k < m; ++k) { gmu[k] = 0.5 * gmu[k] + 0.5; gwt[k] = 0.5 * gwt[k]; }
+}
+
+// normalised associated Legendre functions, degree recurrence per order m (LEPOLY,
+// disort.f:5286-5408); ylm[i*(maxl+1)+l]; needs order m-1 in place for m > 0.
+void legendre_norm(int nmu, int m, int maxl, int twonm1, const double *mu, double *ylm)
+{
+    auto Y = [&](int l, int i) -> double & { return ylm[(size_t)i * (maxl + 1) + l]; };
+    if (m == 0) {
+        for (int i = 0; i < nmu; ++i) { Y(0, i) = 1.0; Y(1, i) = mu[i]; }
+        for (int l = 2; l <= twonm1; ++l)
+            for (int i = 0; i < nmu; ++i)
+                Y(l, i) = ((double)(2 * l - 1) * mu[i] * Y(l - 1, i) - (double)(l - 1) * Y(l - 2, i)) / (double)l;
+    } else {
+        for (int i = 0; i < nmu; ++i) {
+            Y(m, i) = -ref_sqt(2 * m - 1) / ref_sqt(2 * m) * sqrt(1.0 - mu[i] * mu[i]) * Y(m - 1, i);
+            Y(m + 1, i) = ref_sqt(2 * m + 1) * mu[i] * Y(m, i);
+        }
+        for (int l = m + 2; l <= twonm1; ++l) {
+            const double t1 = ref_sqt(l - m) * ref_sqt(l + m), t2 = ref_sqt(l - m - 1) * ref_sqt(l + m - 1);
+            for (int i = 0; i < nmu; ++i)
+                Y(l, i) = ((double)(2 * l - 1) * mu[i] * Y(l - 1, i) - t2 * Y(l - 2, i)) / t1;
+        }
+    }
+}
+
+__global__ void finish_kernel(sbd::Params P)
+{
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= P.nslot) return;
+    P.status[slot] = P.svi[(size_t)slot * P.svi_stride + SBD_SVI_STATUS];
+}
+
+// stdout1's weighted sums (drt.f:964-1054), two fixed-order levels: 256-item segments
+// summed in work-item order, then segments summed in order.
+__global__ void accum_partial_kernel(int nwork, int nel, const double *w, const double *x, double *partial)
+{
+    const int seg = blockIdx.x;
+    const int i0 = seg * 256, i1 = (i0 + 256 < nwork) ? i0 + 256 : nwork;
+    for (int e = threadIdx.x; e < nel; e += blockDim.x) {
+        double acc = 0.0;
+        for (int i = i0; i < i1; ++i) acc = acc + w[i] * x[(size_t)i * nel + e];
+        partial[(size_t)seg * nel + e] = acc;
+    }
+}
+__global__ void accum_final_kernel(int nseg, int nel, const double *partial, double *acc)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nel) return;
+    double a = acc[e];
+    for (int s = 0; s < nseg; ++s) a = a + partial[(size_t)s * nel + e];
+    acc[e] = a;
+}
+
+}  // namespace
+
+struct sbd_engine {
+    sbd_run_cfg cfg{};
+    int n = 0, nn = 0, L = 0, nmode = 1, naz_run = 0, nlev = 0, G = 0;
+    int chunk = 0;
+    size_t ws_bytes = 0;
+    hipStream_t stream = nullptr;
+    std::vector<double> h_cmu, h_cwt;
+    // device tables
+    double *d_tab = nullptr;      // one allocation for all double tables
+    int32_t *d_level = nullptr;
+    sbd::Tables tab{};
+    // workspace (one allocation)
+    char *d_ws = nullptr;
+    sbd::Params P{};              // workspace pointers + constants; chunk fields filled per call
+    // staging for solve_host / accumulate
+    char *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    double *d_partial = nullptr;
+    size_t partial_elems = 0;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float ms_phase[4] = {0, 0, 0, 0};
+    bool have_times = false;
+    int layer_lds = 0, band_lds = 0, usr_lds = 0;
+};
+
+extern "C" {
+
+int32_t sbd_abi_version(void) { return SBD_ABI_VERSION; }
+
+const char *sbd_last_error(void) { return g_last_error.c_str(); }
+
+const char *sbd_strerror(int code)
+{
+    switch (code) {
+    case SBD_OK: return "ok";
+    case SBD_E_INVALID: return "invalid argument or run configuration";
+    case SBD_E_RETRY_NSTR: return "beam angle equals a quadrature angle: change NSTR (disort.f:2645-2650)";
+    case SBD_E_NO_DEVICE: return "no usable HIP device";
+    case SBD_E_HIP: return "HIP runtime error";
+    case SBD_E_UNSUPPORTED: return "feature outside the hot-path scope (BRDF / IBCND=1 / CORINT)";
+    case SBD_E_NOMEM: return "out of device memory";
+    default: return "unknown error";
+    }
+}
+
+void sbd_engine_destroy(sbd_engine *e)
+{
+    if (!e) return;
+    if (e->d_tab) (void)hipFree(e->d_tab);
+    if (e->d_level) (void)hipFree(e->d_level);
+    if (e->d_ws) (void)hipFree(e->d_ws);
+    if (e->d_stage) (void)hipFree(e->d_stage);
+    if (e->d_partial) (void)hipFree(e->d_partial);
+    for (auto &x : e->ev)
+        if (x) (void)hipEventDestroy(x);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
+{
+    if (!cfg || !out) return fail(SBD_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != SBD_ABI_VERSION) return fail(SBD_E_INVALID, "abi_version mismatch");
+    const int n = cfg->nstr, L = cfg->nlyr;
+    // CHEKIN's per-run checks (disort.f:4926-5140)
+    if (n < 4 || n > SBD_MAX_NSTR || (n & 1)) return fail(SBD_E_INVALID, "NSTR must be even, 4..40");
+    if (L < 1 || L > SBD_MAX_NLYR) return fail(SBD_E_INVALID, "NLYR out of range");
+    if (cfg->nmom < 0) return fail(SBD_E_INVALID, "NMOM < 0");
+    if (!cfg->lamber) return fail(SBD_E_UNSUPPORTED, "non-Lambertian surface");
+    if (!cfg->temper) return fail(SBD_E_INVALID, "temper is NULL");
+    const bool rad = !cfg->onlyfl;
+    if (rad) {
+        if (!cfg->usrang) return fail(SBD_E_UNSUPPORTED, "intensities at quadrature angles (CMPINT) are not used by SBDART");
+        if (cfg->numu < 1 || cfg->numu > SBD_MAX_NSTR || !cfg->umu) return fail(SBD_E_INVALID, "NUMU/UMU");
+        if (cfg->nphi < 1 || cfg->nphi > SBD_MAX_NSTR || !cfg->phi) return fail(SBD_E_INVALID, "NPHI/PHI");
+        for (int i = 0; i < cfg->numu; ++i) {
+            if (cfg->umu[i] < -1.0 || cfg->umu[i] > 1.0 || cfg->umu[i] == 0.0) return fail(SBD_E_INVALID, "UMU range");
+            if (i && cfg->umu[i] < cfg->umu[i - 1]) return fail(SBD_E_INVALID, "UMU must ascend");
+        }
+        for (int j = 0; j < cfg->nphi; ++j)
+            if (cfg->phi[j] < 0.0 || cfg->phi[j] > 360.0) return fail(SBD_E_INVALID, "PHI range");
+        if (cfg->phi0 < 0.0 || cfg->phi0 > 360.0) return fail(SBD_E_INVALID, "PHI0 range");
+    }
+    if (cfg->fisot < 0.0) return fail(SBD_E_INVALID, "FISOT < 0");
+    if (cfg->temis < 0.0 || cfg->temis > 1.0) return fail(SBD_E_INVALID, "TEMIS range");
+    if (cfg->nlevel_out < 0 || cfg->nlevel_out > L + 1) return fail(SBD_E_INVALID, "nlevel_out");
+    if (cfg->nlevel_out > 0) {
+        if (!cfg->level_out) return fail(SBD_E_INVALID, "level_out is NULL");
+        for (int i = 0; i < cfg->nlevel_out; ++i)
+            if (cfg->level_out[i] < 0 || cfg->level_out[i] > L) return fail(SBD_E_INVALID, "level_out range");
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SBD_E_NO_DEVICE, "hipGetDeviceCount");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(SBD_E_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    sbd_engine *e = new (std::nothrow) sbd_engine;
+    if (!e) return fail(SBD_E_NOMEM, "host allocation");
+    e->cfg = *cfg;
+    e->n = n;
+    e->nn = n / 2;
+    e->L = L;
+    const int nn = e->nn;
+    e->nlev = cfg->nlevel_out > 0 ? cfg->nlevel_out : L + 1;
+    const int numu = rad ? cfg->numu : 0, nphi = rad ? cfg->nphi : 0;
+
+    // quadrature (SETDIS, disort.f:2629-2638)
+    e->h_cmu.resize(n);
+    e->h_cwt.resize(n);
+    gauss01(nn, e->h_cmu.data(), e->h_cwt.data());
+    for (int i = 0; i < nn; ++i) { e->h_cmu[i + nn] = -e->h_cmu[i]; e->h_cwt[i + nn] = e->h_cwt[i]; }
+
+    // azimuth modes (disort.f:577-586): per-run part of the NAZ rule
+    int naz = n - 1;
+    {
+        const double e5 = (double)1.0e-5f;
+        if (fabs(1.0 - cfg->umu0) < e5 || cfg->onlyfl
+            || (numu == 1 && fabs(1.0 - cfg->umu[0]) < e5) || (numu == 1 && fabs(1.0 + cfg->umu[0]) < e5)
+            || (numu == 2 && fabs(1.0 + cfg->umu[0]) < e5 && fabs(1.0 - cfg->umu[1]) < e5))
+            naz = 0;
+    }
+    e->naz_run = naz;
+    e->nmode = naz + 1;
+    const int nmode = e->nmode;
+
+    // Legendre tables for every mode
+    std::vector<double> ylmc((size_t)nmode * n * (n + 1), 0.0), ylm0((size_t)nmode * (n + 1), 0.0);
+    std::vector<double> ylmu((size_t)nmode * (numu > 0 ? numu : 1) * (n + 1), 0.0);
+    std::vector<double> cosm((size_t)nmode * (nphi > 0 ? nphi : 1), 1.0);
+    {
+        std::vector<double> yc((size_t)n * (n + 1), 0.0), y0(n + 1, 0.0), yu((size_t)(numu > 0 ? numu : 1) * (n + 1), 0.0);
+        const double ang0 = -cfg->umu0;
+        for (int m = 0; m < nmode; ++m) {
+            legendre_norm(1, m, n, n - 1, &ang0, y0.data());
+            if (numu > 0) legendre_norm(numu, m, n, n - 1, cfg->umu, yu.data());
+            legendre_norm(nn, m, n, n - 1, e->h_cmu.data(), yc.data());
+            double sgn = -1.0;   // mirror to -mu (disort.f:611-627)
+            for (int l = m; l <= n - 1; ++l) {
+                sgn = -sgn;
+                for (int iq = nn; iq < n; ++iq) yc[(size_t)iq * (n + 1) + l] = sgn * yc[(size_t)(iq - nn) * (n + 1) + l];
+            }
+            memcpy(&ylmc[(size_t)m * n * (n + 1)], yc.data(), sizeof(double) * n * (n + 1));
+            memcpy(&ylm0[(size_t)m * (n + 1)], y0.data(), sizeof(double) * (n + 1));
+            if (numu > 0) memcpy(&ylmu[(size_t)m * numu * (n + 1)], yu.data(), sizeof(double) * numu * (n + 1));
+        }
+        const double rpd = ref_pi() / 180.0;   // disort.f:450
+        for (int m = 0; m < nmode; ++m)
+            for (int j = 0; j < nphi; ++j)
+                cosm[(size_t)m * nphi + j] = (m == 0) ? 1.0 : cos((double)m * (rpd * (cfg->phi[j] - cfg->phi0)));
+    }
+
+    // upload tables
+    const size_t ntab = (size_t)2 * n + ylmc.size() + ylm0.size() + ylmu.size() + cosm.size() + (L + 1) + (numu > 0 ? numu : 1);
+    std::vector<double> htab;
+    htab.reserve(ntab);
+    auto push = [&](const double *p, size_t cnt) { size_t off = htab.size(); htab.insert(htab.end(), p, p + cnt); return off; };
+    const size_t o_cmu = push(e->h_cmu.data(), n), o_cwt = push(e->h_cwt.data(), n);
+    const size_t o_ylmc = push(ylmc.data(), ylmc.size()), o_ylm0 = push(ylm0.data(), ylm0.size());
+    const size_t o_ylmu = push(ylmu.data(), ylmu.size()), o_cos = push(cosm.data(), cosm.size());
+    const size_t o_temper = push(cfg->temper, L + 1);
+    double zero = 0.0;
+    const size_t o_umu = numu > 0 ? push(cfg->umu, numu) : push(&zero, 1);
+#define CREATE_TRY(expr)                                                                    \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            sbd_engine_destroy(e);                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? SBD_E_NOMEM : SBD_E_HIP,                \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+        }                                                                                   \
+    } while (0)
+    CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc(&e->d_tab, htab.size() * sizeof(double)));
+    CREATE_TRY(hipMemcpy(e->d_tab, htab.data(), htab.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<int32_t> hlev(e->nlev);
+    for (int i = 0; i < e->nlev; ++i) hlev[i] = cfg->nlevel_out > 0 ? cfg->level_out[i] : i;
+    CREATE_TRY(hipMalloc(&e->d_level, sizeof(int32_t) * e->nlev));
+    CREATE_TRY(hipMemcpy(e->d_level, hlev.data(), sizeof(int32_t) * e->nlev, hipMemcpyHostToDevice));
+    e->tab.cmu = e->d_tab + o_cmu;
+    e->tab.cwt = e->d_tab + o_cwt;
+    e->tab.ylmc = e->d_tab + o_ylmc;
+    e->tab.ylm0 = e->d_tab + o_ylm0;
+    e->tab.ylmu = e->d_tab + o_ylmu;
+    e->tab.cosmphi = e->d_tab + o_cos;
+    e->tab.temper = e->d_tab + o_temper;
+    e->tab.umu = e->d_tab + o_umu;
+    e->tab.level_out = e->d_level;
+
+    // ---- workspace ----
+    const int ncd = 3 * nn - 1, cw = 2 * ncd + 1;
+    const sbd::SV sv(L);
+    const int sv_stride = (sv.size() + 1) & ~1;
+    const int svi_stride = (3 + L + 1 + 3) & ~3;
+    const size_t per_ms = sizeof(double) * ((size_t)L * n * n + (size_t)L * n * 5 + (size_t)L * nn + (size_t)L * n * cw
+                                            + (rad ? (size_t)L * n * numu + 3 * (size_t)L * numu + (size_t)e->nlev * numu : 0));
+    const size_t per_slot = per_ms * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
+    size_t budget = (size_t)6 << 30;
+    if (const char *s = getenv("SBD_WORKSPACE_MB")) budget = (size_t)atoll(s) << 20;
+    int chunk = 16384;
+    if (const char *s = getenv("SBD_CHUNK")) chunk = atoi(s);
+    if (cfg->max_batch > 0 && cfg->max_batch < chunk) chunk = cfg->max_batch;
+    while (chunk > 1 && (size_t)chunk * per_slot > budget) chunk /= 2;
+    if (chunk < 1) chunk = 1;
+    e->chunk = chunk;
+    e->ws_bytes = (size_t)chunk * per_slot + 4096;
+    CREATE_TRY(hipMalloc(&e->d_ws, e->ws_bytes));
+    {
+        char *p = e->d_ws;
+        auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+        sbd::Params &P = e->P;
+        const size_t nms = (size_t)chunk * nmode;
+        P.sv = (double *)take(sizeof(double) * (size_t)chunk * sv_stride);
+        P.svi = (int32_t *)take(sizeof(int32_t) * (size_t)chunk * svi_stride);
+        P.gc = (double *)take(sizeof(double) * nms * L * n * n);
+        P.kk = (double *)take(sizeof(double) * nms * L * n);
+        P.ek = (double *)take(sizeof(double) * nms * L * nn);
+        P.zz = (double *)take(sizeof(double) * nms * L * n);
+        P.zp0 = (double *)take(sizeof(double) * nms * L * n);
+        P.zp1 = (double *)take(sizeof(double) * nms * L * n);
+        P.ll = (double *)take(sizeof(double) * nms * L * n);
+        P.ufac = (double *)take(sizeof(double) * nms * L * n * cw);
+        if (rad) {
+            P.gu = (double *)take(sizeof(double) * nms * L * n * numu);
+            P.zb = (double *)take(sizeof(double) * nms * L * numu);
+            P.z0u = (double *)take(sizeof(double) * nms * L * numu);
+            P.z1u = (double *)take(sizeof(double) * nms * L * numu);
+            P.uum = (double *)take(sizeof(double) * nms * e->nlev * numu);
+        }
+        if ((size_t)(p - e->d_ws) > e->ws_bytes + 256 * 20) {
+            sbd_engine_destroy(e);
+            return fail(SBD_E_NOMEM, "workspace carve overflow");
+        }
+        P.L = L; P.n = n; P.nn = nn; P.nmom = cfg->nmom; P.numu = numu; P.nphi = nphi;
+        P.nlev = e->nlev; P.nmode = nmode;
+        P.onlyfl = cfg->onlyfl ? 1 : 0; P.usrang = cfg->usrang ? 1 : 0;
+        P.all_levels = cfg->nlevel_out > 0 ? 0 : 1;
+        P.sv_stride = sv_stride; P.svi_stride = svi_stride;
+        P.cw = cw; P.ncd = ncd;
+        P.umu0 = cfg->umu0; P.fisot = cfg->fisot; P.btemp = cfg->btemp; P.ttemp = cfg->ttemp; P.temis = cfg->temis;
+        P.pi = ref_pi();
+        P.dither = 100.0 * 2.220446049250313e-16;   // disort.f:442-448
+        P.t = e->tab;
+    }
+    // the carve above rounds every array up to 256 B: re-check against the allocation
+    // (ws_bytes has 4 KB slack per array count << 16)
+    // ---- launch geometry ----
+    int G = 4;
+    while (G < n) G <<= 1;
+    e->G = G;
+    const sbd::LayerLds ll(n, nn);
+    e->layer_lds = (int)sizeof(double) * ll.total * (64 / G);
+    const sbd::BandLds bl(n, nn, L, e->nlev);
+    e->band_lds = (int)sizeof(double) * bl.total;
+    e->usr_lds = (int)sizeof(double) * (nn + 2);
+    auto set_lds = [&](const void *fn, int bytes) -> hipError_t {
+        if (bytes <= 48 * 1024) return hipSuccess;
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    };
+    if (e->layer_lds > 160 * 1024 || e->band_lds > 160 * 1024) {
+        sbd_engine_destroy(e);
+        return fail(SBD_E_UNSUPPORTED, "LDS footprint exceeds 160 KiB for this NSTR/NLYR");
+    }
+    switch (G) {
+    case 4: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<4>, e->layer_lds)); break;
+    case 8: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<8>, e->layer_lds)); break;
+    case 16: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<16>, e->layer_lds)); break;
+    case 32: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<32>, e->layer_lds)); break;
+    default: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<64>, e->layer_lds)); break;
+    }
+    CREATE_TRY(set_lds((const void *)sbd::band_kernel, e->band_lds));
+    for (auto &x : e->ev) CREATE_TRY(hipEventCreate(&x));
+#undef CREATE_TRY
+
+    // beam angle == quadrature angle (disort.f:2643-2650): whole-run property when a beam
+    // is present; reported here so the host can pick NSTR-2 / NSTR+2 as drt.f:536-555 does.
+    *out = e;
+    if (cfg->umu0 > 0.0)
+        for (int iq = 0; iq < nn; ++iq)
+            if (fabs(cfg->umu0 - e->h_cmu[iq]) / cfg->umu0 < (double)1.0e-4f)
+                return fail(SBD_E_RETRY_NSTR, "beam angle = computational angle; change NSTR");
+    return SBD_OK;
+}
+
+int32_t sbd_engine_nlevel(const sbd_engine *e) { return e ? e->nlev : 0; }
+size_t sbd_engine_workspace_bytes(const sbd_engine *e) { return e ? e->ws_bytes : 0; }
+int32_t sbd_engine_chunk(const sbd_engine *e) { return e ? e->chunk : 0; }
+void *sbd_engine_stream(sbd_engine *e) { return e ? (void *)e->stream : nullptr; }
+void sbd_engine_enable_timing(sbd_engine *e, int on) { if (e) e->timing = on != 0; }
+
+int sbd_engine_quadrature(const sbd_engine *e, double *cmu, double *cwt)
+{
+    if (!e || !cmu || !cwt) return SBD_E_INVALID;
+    for (int i = 0; i < e->nn; ++i) { cmu[i] = e->h_cmu[i]; cwt[i] = e->h_cwt[i]; }
+    return SBD_OK;
+}
+
+double sbd_engine_last_ms(sbd_engine *e, int phase)
+{
+    if (!e || !e->have_times) return -1.0;
+    if (phase < 0) return (double)(e->ms_phase[0] + e->ms_phase[1] + e->ms_phase[2] + e->ms_phase[3]);
+    if (phase > 3) return -1.0;
+    return (double)e->ms_phase[phase];
+}
+
+long long sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t nbytes)
+{
+    if (!e || !host_buf) return SBD_E_INVALID;
+    const size_t nms = (size_t)e->chunk * e->nmode, L = e->L, n = e->n, nn = e->nn;
+    const void *src = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+    case 0: src = e->P.gc; bytes = 8 * nms * L * n * n; break;
+    case 1: src = e->P.kk; bytes = 8 * nms * L * n; break;
+    case 2: src = e->P.ek; bytes = 8 * nms * L * nn; break;
+    case 3: src = e->P.zz; bytes = 8 * nms * L * n; break;
+    case 4: src = e->P.zp0; bytes = 8 * nms * L * n; break;
+    case 5: src = e->P.zp1; bytes = 8 * nms * L * n; break;
+    case 6: src = e->P.ll; bytes = 8 * nms * L * n; break;
+    case 7: src = e->P.sv; bytes = 8 * (size_t)e->chunk * e->P.sv_stride; break;
+    case 8: src = e->P.svi; bytes = 4 * (size_t)e->chunk * e->P.svi_stride; break;
+    default: return SBD_E_INVALID;
+    }
+    if (bytes > nbytes) bytes = nbytes;
+    if (hipSetDevice(e->cfg.device) != hipSuccess) return SBD_E_HIP;
+    if (hipDeviceSynchronize() != hipSuccess) return SBD_E_HIP;
+    if (hipMemcpy(host_buf, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return SBD_E_HIP;
+    return (long long)bytes;
+}
+
+int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, void *hip_stream)
+{
+    if (!e || !in || !out) return fail(SBD_E_INVALID, "null argument");
+    if (in->nwork < 0) return fail(SBD_E_INVALID, "nwork < 0");
+    if (in->nwork == 0) return SBD_OK;
+    if (!in->dtauc || !in->ssalb || !in->pmom || !in->wvnmlo || !in->wvnmhi || !in->fbeam || !in->albedo || !in->plank)
+        return fail(SBD_E_INVALID, "null input array");
+    if (!out->flux || !out->status) return fail(SBD_E_INVALID, "null output array");
+    const bool rad = !e->cfg.onlyfl;
+    if (rad && !out->uu) return fail(SBD_E_INVALID, "uu is NULL in radiance mode");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    const int L = e->L, n = e->n, nmode = e->nmode, nlev = e->nlev;
+    const bool timing = e->timing;
+    float acc_ms[4] = {0, 0, 0, 0};
+    for (int w0 = 0; w0 < in->nwork; w0 += e->chunk) {
+        const int ns = (in->nwork - w0 < e->chunk) ? in->nwork - w0 : e->chunk;
+        sbd::Params P = e->P;
+        P.nslot = ns;
+        P.dtauc = in->dtauc + (size_t)w0 * L;
+        P.ssalb = in->ssalb + (size_t)w0 * L;
+        P.pmom = in->pmom + (size_t)w0 * L * (e->cfg.nmom + 1);
+        P.wvnmlo = in->wvnmlo + w0; P.wvnmhi = in->wvnmhi + w0;
+        P.fbeam = in->fbeam + w0; P.albedo = in->albedo + w0; P.plank = in->plank + w0;
+        P.flux = out->flux + (size_t)w0 * SBD_NFLUX * nlev;
+        P.uu = rad ? out->uu + (size_t)w0 * e->P.nphi * nlev * e->P.numu : nullptr;
+        P.status = out->status + w0;
+
+        if (timing) HIP_TRY(hipEventRecord(e->ev[0], st));
+        hipLaunchKernelGGL(sbd::setup_kernel, dim3(ns), dim3(64), 0, st, P);
+        if (timing) HIP_TRY(hipEventRecord(e->ev[1], st));
+        {
+            const int gpb = 64 / e->G;
+            const long long groups = (long long)ns * nmode * L;
+            const unsigned grid = (unsigned)((groups + gpb - 1) / gpb);
+            switch (e->G) {
+            case 4: hipLaunchKernelGGL(sbd::layer_kernel<4>, dim3(grid), dim3(64), e->layer_lds, st, P); break;
+            case 8: hipLaunchKernelGGL(sbd::layer_kernel<8>, dim3(grid), dim3(64), e->layer_lds, st, P); break;
+            case 16: hipLaunchKernelGGL(sbd::layer_kernel<16>, dim3(grid), dim3(64), e->layer_lds, st, P); break;
+            case 32: hipLaunchKernelGGL(sbd::layer_kernel<32>, dim3(grid), dim3(64), e->layer_lds, st, P); break;
+            default: hipLaunchKernelGGL(sbd::layer_kernel<64>, dim3(grid), dim3(64), e->layer_lds, st, P); break;
+            }
+        }
+        if (timing) HIP_TRY(hipEventRecord(e->ev[2], st));
+        hipLaunchKernelGGL(sbd::band_kernel, dim3((unsigned)((size_t)ns * nmode)), dim3(64), e->band_lds, st, P);
+        if (timing) HIP_TRY(hipEventRecord(e->ev[3], st));
+        if (rad) {
+            hipLaunchKernelGGL(sbd::usrint_kernel, dim3((unsigned)((size_t)ns * nmode)), dim3(64), e->usr_lds, st, P);
+            const long long items = (long long)ns * nlev * e->P.numu;
+            hipLaunchKernelGGL(sbd::azimuth_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, P, e->naz_run);
+        }
+        hipLaunchKernelGGL(finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, P);
+        if (timing) HIP_TRY(hipEventRecord(e->ev[4], st));
+        HIP_TRY(hipGetLastError());
+        if (timing) {
+            HIP_TRY(hipEventSynchronize(e->ev[4]));
+            for (int ph = 0; ph < 4; ++ph) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, e->ev[ph], e->ev[ph + 1]));
+                acc_ms[ph] += ms;
+            }
+        }
+    }
+    if (timing) {
+        for (int ph = 0; ph < 4; ++ph) e->ms_phase[ph] = acc_ms[ph];
+        e->have_times = true;
+    }
+    return SBD_OK;
+}
+
+static int ensure_stage(sbd_engine *e, size_t bytes)
+{
+    if (bytes <= e->stage_bytes) return SBD_OK;
+    if (e->d_stage) (void)hipFree(e->d_stage);
+    e->d_stage = nullptr;
+    e->stage_bytes = 0;
+    hipError_t err = hipMalloc(&e->d_stage, bytes);
+    if (err != hipSuccess) return fail(err == hipErrorOutOfMemory ? SBD_E_NOMEM : SBD_E_HIP, "hipMalloc(stage)");
+    e->stage_bytes = bytes;
+    return SBD_OK;
+}
+
+int sbd_engine_solve_host(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out)
+{
+    if (!e || !in || !out) return fail(SBD_E_INVALID, "null argument");
+    if (in->nwork <= 0) return in->nwork == 0 ? SBD_OK : fail(SBD_E_INVALID, "nwork < 0");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const size_t W = in->nwork;
+    const int L = e->L, nlev = e->nlev;
+    const bool rad = !e->cfg.onlyfl;
+    const size_t b_lay = sizeof(double) * W * L, b_pm = sizeof(double) * W * L * (e->cfg.nmom + 1), b_w = sizeof(double) * W;
+    const size_t b_flux = sizeof(double) * W * SBD_NFLUX * nlev;
+    const size_t b_uu = rad ? sizeof(double) * W * e->P.nphi * nlev * e->P.numu : 0;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t total = 2 * up(b_lay) + up(b_pm) + 4 * up(b_w) + up(W) + up(b_flux) + up(b_uu) + up(sizeof(int32_t) * W);
+    int rc = ensure_stage(e, total);
+    if (rc != SBD_OK) return rc;
+    char *p = e->d_stage;
+    auto take = [&](size_t bytes) { char *r = p; p += up(bytes); return r; };
+    double *d_dt = (double *)take(b_lay), *d_ss = (double *)take(b_lay), *d_pm = (double *)take(b_pm);
+    double *d_lo = (double *)take(b_w), *d_hi = (double *)take(b_w), *d_fb = (double *)take(b_w), *d_al = (double *)take(b_w);
+    uint8_t *d_pl = (uint8_t *)take(W);
+    double *d_flux = (double *)take(b_flux);
+    double *d_uu = rad ? (double *)take(b_uu) : nullptr;
+    int32_t *d_st = (int32_t *)take(sizeof(int32_t) * W);
+    hipStream_t st = e->stream;
+    HIP_TRY(hipMemcpyAsync(d_dt, in->dtauc, b_lay, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_ss, in->ssalb, b_lay, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_pm, in->pmom, b_pm, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_lo, in->wvnmlo, b_w, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_hi, in->wvnmhi, b_w, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_fb, in->fbeam, b_w, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_al, in->albedo, b_w, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_pl, in->plank, W, hipMemcpyHostToDevice, st));
+    sbd_batch_in din = {in->nwork, d_dt, d_ss, d_pm, d_lo, d_hi, d_fb, d_al, d_pl};
+    sbd_batch_out dout = {d_flux, d_uu, d_st};
+    rc = sbd_engine_solve_device(e, &din, &dout, st);
+    if (rc != SBD_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out->flux, d_flux, b_flux, hipMemcpyDeviceToHost, st));
+    if (rad && out->uu) HIP_TRY(hipMemcpyAsync(out->uu, d_uu, b_uu, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->status, d_st, sizeof(int32_t) * W, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return SBD_OK;
+}
+
+int sbd_engine_accumulate_device(sbd_engine *e, int32_t nwork, const double *weight, const double *flux,
+                                 const double *uu, double *acc_flux, double *acc_uu, void *hip_stream)
+{
+    if (!e || nwork < 0 || !weight || !flux || !acc_flux) return fail(SBD_E_INVALID, "null argument");
+    if (nwork == 0) return SBD_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    const int nseg = (nwork + 255) / 256;
+    const int nel_f = SBD_NFLUX * e->nlev;
+    const int nel_u = (uu && acc_uu) ? e->P.nphi * e->nlev * e->P.numu : 0;
+    const size_t need = (size_t)nseg * (nel_f > nel_u ? nel_f : nel_u);
+    if (need > e->partial_elems) {
+        if (e->d_partial) (void)hipFree(e->d_partial);
+        e->d_partial = nullptr;
+        e->partial_elems = 0;
+        HIP_TRY(hipMalloc(&e->d_partial, need * sizeof(double)));
+        e->partial_elems = need;
+    }
+    hipLaunchKernelGGL(accum_partial_kernel, dim3(nseg), dim3(256), 0, st, (int)nwork, nel_f, weight, flux, e->d_partial);
+    hipLaunchKernelGGL(accum_final_kernel, dim3((nel_f + 255) / 256), dim3(256), 0, st, nseg, nel_f, (const double *)e->d_partial, acc_flux);
+    if (nel_u > 0) {
+        hipLaunchKernelGGL(accum_partial_kernel, dim3(nseg), dim3(256), 0, st, (int)nwork, nel_u, weight, uu, e->d_partial);
+        hipLaunchKernelGGL(accum_final_kernel, dim3((nel_u + 255) / 256), dim3(256), 0, st, nseg, nel_u, (const double *)e->d_partial, acc_uu);
+    }
+    HIP_TRY(hipGetLastError());
+    return SBD_OK;
+}
+
+int sbd_engine_accumulate_host(sbd_engine *e, int32_t nwork, const double *weight, const double *flux,
+                               const double *uu, double *acc_flux, double *acc_uu)
+{
+    if (!e || nwork < 0 || !weight || !flux || !acc_flux) return fail(SBD_E_INVALID, "null argument");
+    if (nwork == 0) return SBD_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const size_t W = nwork;
+    const int nel_f = SBD_NFLUX * e->nlev;
+    const int nel_u = (uu && acc_uu) ? e->P.nphi * e->nlev * e->P.numu : 0;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t total = up(8 * W) + up(8 * W * nel_f) + up(8 * W * nel_u) + up(8 * (size_t)nel_f) + up(8 * (size_t)nel_u);
+    int rc = ensure_stage(e, total);
+    if (rc != SBD_OK) return rc;
+    char *p = e->d_stage;
+    auto take = [&](size_t bytes) { char *r = p; p += up(bytes); return r; };
+    double *d_w = (double *)take(8 * W), *d_f = (double *)take(8 * W * nel_f);
+    double *d_u = nel_u ? (double *)take(8 * W * nel_u) : nullptr;
+    double *d_af = (double *)take(8 * (size_t)nel_f), *d_au = nel_u ? (double *)take(8 * (size_t)nel_u) : nullptr;
+    hipStream_t st = e->stream;
+    HIP_TRY(hipMemcpyAsync(d_w, weight, 8 * W, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_f, flux, 8 * W * nel_f, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_af, acc_flux, 8 * (size_t)nel_f, hipMemcpyHostToDevice, st));
+    if (nel_u) {
+        HIP_TRY(hipMemcpyAsync(d_u, uu, 8 * W * nel_u, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_au, acc_uu, 8 * (size_t)nel_u, hipMemcpyHostToDevice, st));
+    }
+    rc = sbd_engine_accumulate_device(e, nwork, d_w, d_f, d_u, d_af, d_au, st);
+    if (rc != SBD_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(acc_flux, d_af, 8 * (size_t)nel_f, hipMemcpyDeviceToHost, st));
+    if (nel_u) HIP_TRY(hipMemcpyAsync(acc_uu, d_au, 8 * (size_t)nel_u, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return SBD_OK;
+}
+
+}  // extern "C"

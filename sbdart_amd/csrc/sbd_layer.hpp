@@ -1,0 +1,382 @@
+// Layer kernel: everything DISORT does inside its layer loop (disort.f:638-693) for one
+// (work item, azimuth mode, layer): delta-M Legendre coefficients, the reduced
+// eigenproblem (SOLEIG, disort.f:3099-3320), the beam particular solution (UPBEAM,
+// 4130-4245), the thermal particular solution (UPISOT, 4247-4353) and -- radiance
+// mode -- the interpolation of eigenvectors / sources to the user angles (TERPEV /
+// TERPSO, 3920-4128).
+//
+// MI355X mapping: a group of G lanes (G = pow2 >= NSTR) per (item, mode, layer); 64/G
+// groups per single-wave workgroup; all NSTR x NSTR stream matrices of the group live
+// in LDS (odd leading dimension -> conflict-free row and column sweeps); lane j owns
+// column j (or row j) of every dense update; pivoted LU solves keep the right-hand
+// side in registers and exchange pivots with wave shuffles.  Results go to the HBM
+// workspace in the layouts the band kernel reads with unit stride.
+#pragma once
+#include "sbd_common.hpp"
+#include "sbd_eig.hpp"
+
+namespace sbd {
+
+struct LayerLds {   // per-group carve-up (doubles)
+    int ld, ldh, cc, lu, ev, vec, total;
+    __host__ __device__ LayerLds(int n, int nn)
+    {
+        ld = n | 1;
+        ldh = nn | 1;
+        const int mat = n * ld;
+        const int small = 4 * nn * ldh;
+        cc = 0;
+        lu = cc + mat;
+        ev = lu + (mat > small ? mat : small);
+        vec = ev + mat;
+        total = vec + 8 * n + 16;
+        total = (total + 1) & ~1;
+    }
+};
+
+// LU with partial pivoting of the n x n LDS matrix a (SGEFA's pivot rule: first maximal
+// |a(i,k)|, disutil.f:2060-2072).  Lane j owns column j.  Returns info (first zero pivot).
+SBD_DEVICE int lu_factor_group(double *a, int ld, int n, int *ipvt, int g)
+{
+#define A(i, j) a[((j) - 1) * ld + ((i) - 1)]
+    const int me = g + 1;
+    int info = 0;
+    for (int k = 1; k <= n - 1; ++k) {
+        int l = k;
+        double smax = 0.0;
+        // ISAMAX over a(k..n, k): idx stays k when the whole column is zero
+        {
+            bool found = false;
+            for (int i = k; i <= n; ++i) {
+                const double xm = fabs(A(i, k));
+                if (smax < xm) { smax = xm; l = i; found = true; }
+            }
+            if (!found) l = k;
+        }
+        if (g == 0) ipvt[k - 1] = l;
+        const double piv = A(l, k);
+        if (piv == 0.0) { info = k; continue; }
+        const double akk = A(k, k);
+        const double t = -1.0 / piv;
+        wave_lds_sync();
+        if (me > k && me <= n) {
+            const double v = (me == l) ? akk : A(me, k);
+            A(me, k) = v * t;
+        }
+        if (g == 0) A(k, k) = piv;
+        wave_lds_sync();
+        if (me > k && me <= n) {   // column me
+            const double tj = A(l, me);
+            if (l != k) { A(l, me) = A(k, me); A(k, me) = tj; }
+            for (int i = k + 1; i <= n; ++i) A(i, me) = A(i, me) + tj * A(i, k);
+        }
+        wave_lds_sync();
+    }
+    if (g == 0) ipvt[n - 1] = n;
+    if (A(n, n) == 0.0) info = n;
+    wave_lds_sync();
+    return info;
+}
+
+// Solve with the factors (SGESL, JOB=0).  bv = this lane's RHS element (lane i <-> b(i));
+// the solution element is returned in the same lane.  Shuffles are G-wide.
+template <int G>
+SBD_DEVICE double lu_solve_group(const double *a, int ld, int n, const int *ipvt, double bv, int g)
+{
+    const int me = g + 1;
+    for (int k = 1; k <= n - 1; ++k) {
+        const int l = ipvt[k - 1];
+        const double t = __shfl(bv, l - 1, G);
+        const double bk = __shfl(bv, k - 1, G);
+        if (l != k) {
+            if (me == l) bv = bk;
+            if (me == k) bv = t;
+        }
+        if (me > k && me <= n) bv = bv + t * A(me, k);
+    }
+    for (int k = n; k >= 1; --k) {
+        if (me == k) bv = bv / A(k, k);
+        const double t = -__shfl(bv, k - 1, G);
+        if (me < k) bv = bv + t * A(me, k);
+    }
+    return bv;
+#undef A
+}
+
+template <int G>
+__global__ void __launch_bounds__(64) layer_kernel(Params P)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int GPB = 64 / G;
+    const int lane = threadIdx.x;
+    const int g = lane % G;
+    const int gi = lane / G;
+    const int L = P.L, n = P.n, nn = P.nn, nmode = P.nmode, numu = P.numu;
+    const long long gid = (long long)blockIdx.x * GPB + gi;
+    const long long total = (long long)P.nslot * nmode * L;
+    if (gid >= total) return;
+    const int lc = (int)(gid % L) + 1;
+    const long long ms = gid / L;
+    const int mazim = (int)(ms % nmode);
+    const int slot = (int)(ms / nmode);
+
+    const int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
+    const int st0 = svi[SBD_SVI_STATUS];
+    if (st0 & (0x20 | 0x10)) return;            // input error / retry: DISORT returned early
+    if (lc > svi[SBD_SVI_NCUT]) return;          // layer loop runs 1..NCUT (disort.f:638)
+    const double fbeam = P.fbeam[slot];
+    if (mazim > 0 && fbeam == 0.0) return;       // NAZ = 0 (disort.f:582)
+    const bool plank = P.plank[slot] != 0;
+    const bool rad = !P.onlyfl;
+
+    const SV o(L);
+    const double *sv = P.sv + (size_t)slot * P.sv_stride;
+    const LayerLds lds(n, nn);
+    double *base = smem + (size_t)gi * lds.total;
+    double *cc = base + lds.cc;
+    double *lu = base + lds.lu;
+    double *ev = base + lds.ev;
+    double *vec = base + lds.vec;
+    const int ld = lds.ld, ldh = lds.ldh;
+    double *amb = lu, *apb = lu + nn * ldh, *arr = lu + 2 * nn * ldh, *xs = lu + 3 * nn * ldh;
+    double *gl = vec;                 // [n+1]
+    double *eval = vec + (n + 1);     // [nn]
+    double *wk = eval + nn;           // [2n]
+    double *zjs = wk + 2 * n;         // [n]  UPBEAM solution, CMU order (for TERPSO)
+    double *z0s = zjs + n;            // [n]
+    double *z1s = z0s + n;            // [n]
+    int *ipvt = (int *)(z1s + n);     // [n] ints
+
+    const double *cmu = P.t.cmu, *cwt = P.t.cwt;
+    const double *ylmc = P.t.ylmc + (size_t)mazim * n * (n + 1);
+    const double *ylm0 = P.t.ylm0 + (size_t)mazim * (n + 1);
+#define YLMC(l, iq) ylmc[((iq) - 1) * (n + 1) + (l)]
+#define CC(i, j) cc[((j) - 1) * ld + ((i) - 1)]
+#define EVC(i, j) ev[((j) - 1) * ld + ((i) - 1)]
+#define AMB(i, j) amb[((j) - 1) * ldh + ((i) - 1)]
+#define APB(i, j) apb[((j) - 1) * ldh + ((i) - 1)]
+#define ARR(i, j) arr[((j) - 1) * ldh + ((i) - 1)]
+#define LU(i, j) lu[((j) - 1) * ld + ((i) - 1)]
+    const int me = g + 1;
+
+    // ---- delta-M scaled Legendre coefficients GL(k) (SETDIS, disort.f:2583-2585) ----
+    const double oprim = sv[o.oprim() + lc - 1];
+    const double f = sv[o.flyr() + lc - 1];
+    {
+        const double *pm = P.pmom + ((size_t)slot * L + (lc - 1)) * (P.nmom + 1);
+        if (g < n) {
+            const int k = g;
+            const double pk = (k == 0) ? 1.0 : ((k <= P.nmom) ? pm[k] : 0.0);   // PMOM(0,LC)=1 (2544)
+            gl[k] = (double)(2 * k + 1) * oprim * (pk - f) / (1.0 - f);
+        }
+    }
+    wave_lds_sync();
+
+    // ---- SOLEIG: CC, AMB, APB (disort.f:3197-3229): lane jq owns column jq ----
+    if (me <= n) {
+        for (int iq = 1; iq <= nn; ++iq) {
+            double sum = 0.0;
+            for (int l = mazim; l <= n - 1; ++l) sum = sum + gl[l] * YLMC(l, iq) * YLMC(l, me);
+            CC(iq, me) = 0.5 * sum * cwt[me - 1];
+        }
+    }
+    wave_lds_sync();
+    if (me <= nn) {
+        for (int iq = 1; iq <= nn; ++iq) {
+            const double c1 = CC(iq, me), c2 = CC(iq, me + nn);
+            CC(iq + nn, me) = c2;
+            CC(iq + nn, me + nn) = c1;
+            const double alpha = c1 / cmu[iq - 1], beta = c2 / cmu[iq - 1];
+            double a = alpha - beta, b = alpha + beta;
+            if (iq == me) { a = a - 1.0 / cmu[iq - 1]; b = b - 1.0 / cmu[iq - 1]; }
+            AMB(iq, me) = a;
+            APB(iq, me) = b;
+        }
+    }
+    wave_lds_sync();
+    if (me <= nn) {   // ARRAY = APB * AMB (disort.f:3236-3249), column me
+        for (int iq = 1; iq <= nn; ++iq) {
+            double sum = 0.0;
+            for (int kq = 1; kq <= nn; ++kq) sum = sum + APB(iq, kq) * AMB(kq, me);
+            ARR(iq, me) = sum;
+        }
+    }
+    wave_lds_sync();
+    int status = 0;
+    {
+        const int ier = eig_group(arr, ldh, ev, ld, eval, nn, wk, xs, g);
+        if (ier != 0) status |= 0x08;
+    }
+    double *kkout = P.kk + ((size_t)ms * L + (lc - 1)) * n;
+    double *ekout = P.ek + ((size_t)ms * L + (lc - 1)) * nn;
+    if (me <= nn) {   // disort.f:3264-3269
+        const double kq = sqrt(fabs(eval[me - 1]));
+        eval[me - 1] = kq;
+        kkout[me + nn - 1] = kq;
+        kkout[nn + 1 - me - 1] = -kq;
+        // STWJ scaling factor exp(KK(iq)*dtau'), KK(iq<=nn) = -k of eigenvalue nn+1-iq (2846)
+        ekout[nn + 1 - me - 1] = exp(-kq * sv[o.dtaucp() + lc - 1]);
+    }
+    wave_lds_sync();
+    if (me <= nn) {   // (G+)+(G-) = AMB * evec / k  (disort.f:3273-3286), column me, into APB
+        for (int iq = 1; iq <= nn; ++iq) {
+            double sum = 0.0;
+            for (int kq = 1; kq <= nn; ++kq) sum = sum + AMB(iq, kq) * EVC(kq, me);
+            APB(iq, me) = sum / eval[me - 1];
+        }
+    }
+    wave_lds_sync();
+    double *gcout = P.gc + ((size_t)ms * L + (lc - 1)) * n * n;   // row-major GC(i,j) -> gc[(i-1)*n + j-1]
+    if (me <= nn) {   // assemble EVECC and GC (disort.f:3289-3314), column me
+        for (int iq = 1; iq <= nn; ++iq) {
+            const double gpplgm = APB(iq, me);
+            const double gpmigm = EVC(iq, me);
+            const double e11 = 0.5 * (gpplgm + gpmigm), e21 = 0.5 * (gpplgm - gpmigm);
+            const double e12 = 0.5 * (-gpplgm + gpmigm), e22 = 0.5 * (-gpplgm - gpmigm);
+            EVC(iq, me) = e11;
+            EVC(iq + nn, me) = e21;
+            EVC(iq, me + nn) = e12;
+            EVC(iq + nn, me + nn) = e22;
+            gcout[(iq + nn - 1) * n + (me + nn - 1)] = e11;
+            gcout[(nn + 1 - iq - 1) * n + (me + nn - 1)] = e21;
+            gcout[(iq + nn - 1) * n + (nn + 1 - me - 1)] = e12;
+            gcout[(nn + 1 - iq - 1) * n + (nn + 1 - me - 1)] = e22;
+        }
+    }
+    wave_lds_sync();
+
+    // ---- UPBEAM (disort.f:4205-4241) ----
+    double zj = 0.0;
+    if (fbeam > 0.0) {
+        const double delm0 = (mazim == 0) ? 1.0 : 0.0;
+        if (me <= n) {
+            for (int iq = 1; iq <= n; ++iq) LU(iq, me) = -CC(iq, me);
+            LU(me, me) = 1.0 + cmu[me - 1] / P.umu0 + LU(me, me);
+            double sum = 0.0;
+            for (int k = mazim; k <= n - 1; ++k) sum = sum + gl[k] * YLMC(k, me) * ylm0[k];
+            zj = (2.0 - delm0) * fbeam * sum / (4.0 * P.pi);
+        }
+        wave_lds_sync();
+        if (lu_factor_group(lu, ld, n, ipvt, g) != 0) status |= 0x02;
+        zj = lu_solve_group<G>(lu, ld, n, ipvt, zj, g);
+        double *zzout = P.zz + ((size_t)ms * L + (lc - 1)) * n;
+        if (me <= nn) zzout[me + nn - 1] = zj;
+        else if (me <= n) zzout[nn + 1 - (me - nn) - 1] = zj;
+        if (rad && me <= n) zjs[me - 1] = zj;
+        wave_lds_sync();
+    }
+
+    // ---- UPISOT (disort.f:4309-4349), azimuth-independent only ----
+    double z0 = 0.0, z1 = 0.0;
+    const bool thermal = plank && mazim == 0;
+    if (thermal) {
+        const double xr0 = sv[o.xr0() + lc - 1], xr1 = sv[o.xr1() + lc - 1];
+        if (me <= n) {
+            for (int iq = 1; iq <= n; ++iq) LU(iq, me) = -CC(iq, me);
+            LU(me, me) = 1.0 + LU(me, me);
+            z1 = (1.0 - oprim) * xr1;
+        }
+        wave_lds_sync();
+        if (lu_factor_group(lu, ld, n, ipvt, g) != 0) status |= 0x04;
+        z1 = lu_solve_group<G>(lu, ld, n, ipvt, z1, g);
+        if (me <= n) z0 = (1.0 - oprim) * xr0 + cmu[me - 1] * z1;
+        z0 = lu_solve_group<G>(lu, ld, n, ipvt, z0, g);
+        double *p0 = P.zp0 + ((size_t)ms * L + (lc - 1)) * n;
+        double *p1 = P.zp1 + ((size_t)ms * L + (lc - 1)) * n;
+        if (me <= nn) { p0[me + nn - 1] = z0; p1[me + nn - 1] = z1; }
+        else if (me <= n) { p0[nn + 1 - (me - nn) - 1] = z0; p1[nn + 1 - (me - nn) - 1] = z1; }
+        if (rad && me <= n) { z0s[me - 1] = z0; z1s[me - 1] = z1; }
+        wave_lds_sync();
+    } else if (mazim == 0) {
+        // ZPLK0/1 stay zero (ZEROAL, disort.f:502-521)
+        double *p0 = P.zp0 + ((size_t)ms * L + (lc - 1)) * n;
+        double *p1 = P.zp1 + ((size_t)ms * L + (lc - 1)) * n;
+        if (me <= n) { p0[me - 1] = 0.0; p1[me - 1] = 0.0; }
+    }
+    if (fbeam <= 0.0) {
+        double *zzout = P.zz + ((size_t)ms * L + (lc - 1)) * n;
+        if (me <= n) zzout[me - 1] = 0.0;
+    }
+
+    // ---- radiance mode: TERPEV / TERPSO (disort.f:3920-4128) ----
+    if (rad) {
+        const double *ylmu = P.t.ylmu + (size_t)mazim * numu * (n + 1);
+#define YLMU(l, iu) ylmu[((iu) - 1) * (n + 1) + (l)]
+        double *guout = P.gu + ((size_t)ms * L + (lc - 1)) * n * numu;   // GU(iu, iq) -> gu[(iq-1)*numu + iu-1]
+        // TERPEV: lane iq owns eigenvector column iq; inner sums into its own LDS column of lu
+        wave_lds_sync();
+        if (me <= n) {
+            for (int l = mazim; l <= n - 1; ++l) {
+                double sum = 0.0;
+                for (int jq = 1; jq <= n; ++jq) sum = sum + cwt[jq - 1] * YLMC(l, jq) * EVC(jq, me);
+                LU(l + 1, me) = 0.5 * gl[l] * sum;
+            }
+            const int iqout = (me <= nn) ? me + nn : n + 1 - me;
+            for (int iu = 1; iu <= numu; ++iu) {
+                double sum = 0.0;
+                for (int l = mazim; l <= n - 1; ++l) sum = sum + LU(l + 1, me) * YLMU(l, iu);
+                guout[(iqout - 1) * numu + (iu - 1)] = sum;
+            }
+        }
+        wave_lds_sync();
+        // TERPSO
+        double *zbout = P.zb + ((size_t)ms * L + (lc - 1)) * numu;
+        double *z0uout = P.z0u + ((size_t)ms * L + (lc - 1)) * numu;
+        double *z1uout = P.z1u + ((size_t)ms * L + (lc - 1)) * numu;
+        double *psi0 = wk, *psi1 = wk + n;
+        if (fbeam > 0.0) {
+            const double delm0 = (mazim == 0) ? 1.0 : 0.0;
+            if (g >= mazim && g <= n - 1) {
+                double psum = 0.0;
+                for (int jq = 1; jq <= n; ++jq) psum = psum + cwt[jq - 1] * YLMC(g, jq) * zjs[jq - 1];
+                psi0[g] = 0.5 * gl[g] * psum;
+            }
+            wave_lds_sync();
+            const double fact = (2.0 - delm0) * fbeam / (4.0 * P.pi);
+            for (int iu = me; iu <= numu; iu += G) {
+                double sum = 0.0;
+                for (int iq = mazim; iq <= n - 1; ++iq)
+                    sum = sum + YLMU(iq, iu) * (psi0[iq] + fact * gl[iq] * ylm0[iq]);
+                zbout[iu - 1] = sum;
+            }
+            wave_lds_sync();
+        } else {
+            for (int iu = me; iu <= numu; iu += G) zbout[iu - 1] = 0.0;
+        }
+        if (thermal) {
+            const double xr0 = sv[o.xr0() + lc - 1], xr1 = sv[o.xr1() + lc - 1];
+            if (g <= n - 1) {
+                double psum0 = 0.0, psum1 = 0.0;
+                for (int jq = 1; jq <= n; ++jq) {
+                    psum0 = psum0 + cwt[jq - 1] * YLMC(g, jq) * z0s[jq - 1];
+                    psum1 = psum1 + cwt[jq - 1] * YLMC(g, jq) * z1s[jq - 1];
+                }
+                psi0[g] = 0.5 * gl[g] * psum0;
+                psi1[g] = 0.5 * gl[g] * psum1;
+            }
+            wave_lds_sync();
+            for (int iu = me; iu <= numu; iu += G) {
+                double sum0 = 0.0, sum1 = 0.0;
+                for (int iq = 0; iq <= n - 1; ++iq) {
+                    sum0 = sum0 + YLMU(iq, iu) * psi0[iq];
+                    sum1 = sum1 + YLMU(iq, iu) * psi1[iq];
+                }
+                z0uout[iu - 1] = sum0 + (1.0 - oprim) * xr0;
+                z1uout[iu - 1] = sum1 + (1.0 - oprim) * xr1;
+            }
+        } else if (mazim == 0) {
+            for (int iu = me; iu <= numu; iu += G) { z0uout[iu - 1] = 0.0; z1uout[iu - 1] = 0.0; }
+        }
+#undef YLMU
+    }
+    if (status && g == 0) atomicOr(&P.svi[(size_t)slot * P.svi_stride + SBD_SVI_STATUS], status);
+#undef YLMC
+#undef CC
+#undef EVC
+#undef AMB
+#undef APB
+#undef ARR
+#undef LU
+}
+
+}  // namespace sbd

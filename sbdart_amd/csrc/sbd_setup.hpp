@@ -1,0 +1,223 @@
+// Setup kernel: per work item, everything DISORT does before its azimuth loop
+// (disort.f:482-571): SSALB dither, cumulative optical depth, CHEKIN's per-item
+// checks, SETDIS delta-M scaling / beam transmission / LYRCUT, output-level
+// bookkeeping, and the band-integrated Planck function at every level.
+//
+// One lane per layer/level of one work item (64-lane wave = one work item; L<=65
+// handled with a 2-pass stride), prefix sums by a serial lane through LDS -- the
+// layer count is tiny, what matters is that the HBM reads of dtauc/ssalb/pmom are
+// coalesced along the layer axis.
+#pragma once
+#include "sbd_common.hpp"
+
+namespace sbd {
+
+// PLKAVG (disort.f:5410-5671), stateless.  warn bit0: Simpson no-conv (errmsg 9),
+// bit1: zero result (errmsg 10).
+SBD_DEVICE double plkf(double x) { return x * x * x / (exp(x) - 1.0); }
+
+SBD_DEVICE double plkavg(double wnumlo, double wnumhi, double t, double pi, int &warn)
+{
+    const double a1 = (double)(1.0f / 3.0f), a2 = -0.125, a3 = (double)(1.0f / 60.0f),
+                 a4 = (double)(-1.0f / 5040.0f), a5 = (double)(1.0f / 272160.0f),
+                 a6 = (double)(-1.0f / 13305600.0f);
+    const double c2 = SBD_F32(1.438786), sigma = SBD_F32(5.67032e-8), vcut = 1.5;
+    const double vcp[7] = {10.25, SBD_F32(5.7), SBD_F32(3.9), SBD_F32(2.9), SBD_F32(2.3), SBD_F32(1.9), 0.0};
+    const double vmax = 709.782712893384 /* log(DBL_MAX) */, epsil = 2.220446049250313e-16;
+    const double sigdpi = sigma / pi;
+    const double conc = 15.0 / (pi * pi * pi * pi);
+    if (t < SBD_F32(1.0e-4)) return 0.0;
+    double v[2] = {c2 * wnumlo / t, c2 * wnumhi / t};
+    const double t4 = (t * t) * (t * t);
+    if (v[0] > epsil && v[1] < vmax && (wnumhi - wnumlo) / wnumhi < SBD_F32(1.0e-2)) {
+        const double hh = v[1] - v[0];
+        double oldval = 0.0, val = 0.0;
+        const double val0 = plkf(v[0]) + plkf(v[1]);
+        bool conv = false;
+        for (int n = 1; n <= 10; ++n) {
+            const double del = hh / (double)(2 * n);
+            val = val0;
+            for (int k = 1; k <= 2 * n - 1; ++k)
+                val = val + (double)(2 * (1 + (k & 1))) * plkf(v[0] + (double)k * del);
+            val = del / 3.0 * val;
+            if (fabs((val - oldval) / val) <= SBD_F32(1.0e-6)) { conv = true; break; }
+            oldval = val;
+        }
+        if (!conv) warn |= 1;
+        return sigdpi * t4 * conc * val;
+    }
+    int smallv = 0;
+    double p[2] = {0.0, 0.0}, d[2] = {0.0, 0.0};
+    for (int i = 0; i < 2; ++i) {
+        if (v[i] < vcut) {
+            smallv++;
+            const double vsq = v[i] * v[i];
+            p[i] = conc * vsq * v[i] * (a1 + v[i] * (a2 + v[i] * (a3 + vsq * (a4 + vsq * (a5 + vsq * a6)))));
+        } else {
+            int mmax = 0;
+            do { mmax++; } while (v[i] < vcp[mmax - 1]);
+            const double ex = exp(-v[i]);
+            double exm = 1.0, di = 0.0;
+            for (int m = 1; m <= mmax; ++m) {
+                const double mv = (double)m * v[i];
+                exm = ex * exm;
+                di = di + exm * (6.0 + mv * (6.0 + mv * (3.0 + mv))) / (double)(m * m * m * m);
+            }
+            d[i] = conc * di;
+        }
+    }
+    double r;
+    if (smallv == 2) r = p[1] - p[0];
+    else if (smallv == 1) r = 1.0 - p[0] - d[1];
+    else r = d[0] - d[1];
+    r = sigdpi * t4 * r;
+    if (r == 0.0) warn |= 2;
+    return r;
+}
+
+// grid: one 64-thread block per work item.
+__global__ void __launch_bounds__(64) setup_kernel(Params P)
+{
+    const int slot = blockIdx.x;
+    if (slot >= P.nslot) return;
+    const int lane = threadIdx.x;
+    const int L = P.L, n = P.n, nmom = P.nmom;
+    const SV o(L);
+    double *sv = P.sv + (size_t)slot * P.sv_stride;
+    int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
+    const double *dtauc = P.dtauc + (size_t)slot * L;
+    const double *ssalb_in = P.ssalb + (size_t)slot * L;
+    const double *pmom = P.pmom + (size_t)slot * L * (nmom + 1);
+    const double fbeam = P.fbeam[slot], umu0 = P.umu0;
+    const bool plank = P.plank[slot] != 0;
+    const double wlo = P.wvnmlo[slot], whi = P.wvnmhi[slot];
+
+    __shared__ double s_dt[kMaxNlyr + 1], s_w[kMaxNlyr + 1], s_f[kMaxNlyr + 1];
+    __shared__ double s_tauc[kMaxNlyr + 2], s_taucpr[kMaxNlyr + 2];
+    __shared__ double s_pk[kMaxNlyr + 2];
+    __shared__ int s_err, s_ncut, s_lyrcut, s_pw;
+    if (lane == 0) { s_err = 0; s_pw = 0; }
+    __syncthreads();
+
+    // ---- per-layer loads (coalesced along the layer axis) + CHEKIN per-item checks ----
+    int err = 0;
+    for (int lc = lane; lc < L; lc += 64) {
+        double w = ssalb_in[lc];
+        double dt = dtauc[lc];
+        if (w < 0.0 || w > 1.0) err = 1;                     // disort.f:4950-4954
+        if (w == 1.0) w = 1.0 - P.dither;                    // disort.f:486
+        s_w[lc] = w;
+        s_dt[lc] = dt;                                       // unclamped: TAUC uses it (disort.f:487)
+        s_f[lc] = (n <= nmom) ? pmom[(size_t)lc * (nmom + 1) + n] : 0.0;   // F = PMOM(NSTR) (disort.f:2577)
+        if (plank && (P.t.temper[lc + 1] < 0.0 || (lc == 0 && P.t.temper[0] < 0.0))) err = 1;
+    }
+    // PMOM range check (disort.f:4972-4981), all lanes stride the whole [L][nmom+1] block
+    for (int i = lane; i < L * (nmom + 1); i += 64) {
+        const double pm = pmom[i];
+        if (pm < -1.0 || pm > 1.0) err = 1;
+    }
+    if (fbeam < 0.0 || (fbeam > 0.0 && (umu0 <= 0.0 || umu0 > 1.0))) err = 1;
+    {
+        const double alb = P.albedo[slot];
+        if (alb < 0.0 || alb > 1.0) err = 1;
+    }
+    if (plank && (wlo < 0.0 || whi <= wlo)) err = 1;
+    if (err) atomicOr(&s_err, 1);
+    __syncthreads();
+
+    // ---- serial prefix pass (lane 0): TAUC, delta-M optical depth, NCUT ----
+    if (lane == 0) {
+        double tauc = 0.0, taucpr = 0.0, abstau = 0.0, yessct = 0.0;
+        int ncut = L;
+        s_tauc[0] = 0.0;
+        s_taucpr[0] = 0.0;
+        for (int lc = 0; lc < L; ++lc) {
+            const double w = s_w[lc];
+            tauc = tauc + s_dt[lc];
+            s_tauc[lc + 1] = tauc;
+            const double dt = (s_dt[lc] < 0.0) ? 0.0 : s_dt[lc];   // CHEKIN clamp (disort.f:4944)
+            yessct += w;
+            if (abstau < 10.0) ncut = lc + 1;                      // ABSCUT (disort.f:2561)
+            abstau = abstau + (1.0 - w) * dt;
+            const double f = s_f[lc];
+            const double dtp = (1.0 - f * w) * dt;                 // disort.f:2579
+            taucpr = taucpr + dtp;
+            s_taucpr[lc + 1] = taucpr;
+            s_dt[lc] = dt;
+        }
+        const int lyrcut = (abstau >= 10.0 && !plank && L > 1) ? 1 : 0;   // disort.f:2602-2603
+        if (!lyrcut) ncut = L;
+        s_ncut = ncut;
+        s_lyrcut = lyrcut;
+        if (yessct > 0.0 && nmom < n) s_err = 1;                         // disort.f:4966
+    }
+    __syncthreads();
+
+    // ---- per-layer outputs ----
+    for (int lc = lane; lc < L; lc += 64) {
+        const double w = s_w[lc], f = s_f[lc], dt = s_dt[lc];
+        sv[o.ssalb() + lc] = w;
+        sv[o.flyr() + lc] = f;
+        sv[o.oprim() + lc] = w * (1.0 - f) / (1.0 - f * w);      // disort.f:2578
+        sv[o.dtaucp() + lc] = (1.0 - f * w) * dt;
+    }
+    // ---- per-level outputs: TAUCPR, EXPBEA, output-level mapping, Planck ----
+    int pw = 0;
+    for (int lev = lane; lev <= L; lev += 64) {
+        const double tp = s_taucpr[lev];
+        sv[o.taucpr() + lev] = tp;
+        double eb = (lev == 0) ? 1.0 : 0.0;
+        if (lev > 0 && fbeam > 0.0) eb = exp(-tp / umu0);        // disort.f:2592
+        sv[o.expbea() + lev] = eb;
+        // USRTAU = .FALSE.: UTAU(lev+1) = TAUC(lev) (disort.f:2524-2529); LAYRU/UTAUPR (2610-2627)
+        const double ut = s_tauc[lev];
+        int lc;
+        for (lc = 1; lc <= L; ++lc)
+            if (ut >= s_tauc[lc - 1] && ut <= s_tauc[lc]) break;
+        if (lc > L) lc = L;
+        sv[o.utau() + lev] = ut;
+        sv[o.utaupr() + lev] = s_taucpr[lc - 1] + (1.0 - s_w[lc - 1] * s_f[lc - 1]) * (ut - s_tauc[lc - 1]);
+        svi[SBD_SVI_LAYRU + lev] = lc;
+        const double pk = plank ? plkavg(wlo, whi, P.t.temper[lev], P.pi, pw) : 0.0;   // disort.f:564-569
+        s_pk[lev] = pk;
+        sv[o.pkag() + lev] = pk;
+    }
+    if (lane == 0) {
+        double bpl = 0.0, tpl = 0.0;
+        if (plank) {
+            tpl = P.temis * plkavg(wlo, whi, P.ttemp, P.pi, pw);   // disort.f:556-557
+            bpl = plkavg(wlo, whi, P.btemp, P.pi, pw);
+        }
+        sv[o.bplank()] = bpl;
+        sv[o.tplank()] = tpl;
+    }
+    if (pw) atomicOr(&s_pw, 1);
+    __syncthreads();
+    // ---- thermal source slopes (disort.f:659-666) ----
+    for (int lc = lane; lc < L; lc += 64) {
+        double xr1 = 0.0, xr0 = 0.0;
+        if (plank) {
+            const double dtp = (1.0 - s_f[lc] * s_w[lc]) * s_dt[lc];
+            const double p0 = s_pk[lc], p1 = s_pk[lc + 1];
+            if (dtp > 0.0) xr1 = (p1 - p0) / dtp;
+            xr0 = p0 - xr1 * s_taucpr[lc];
+        }
+        sv[o.xr0() + lc] = xr0;
+        sv[o.xr1() + lc] = xr1;
+    }
+    if (lane == 0) {
+        int st = 0;
+        if (s_err) st |= 0x20;   // SBD_ST_ERR_INPUT
+        if (s_pw) st |= 0x40;    // SBD_ST_WARN_PLKAVG
+        // beam angle == quadrature angle (disort.f:2643-2650)
+        if (fbeam > 0.0) {
+            for (int iq = 0; iq < P.nn; ++iq)
+                if (fabs(umu0 - P.t.cmu[iq]) / umu0 < SBD_F32(1.0e-4)) st |= 0x10;
+        }
+        svi[SBD_SVI_NCUT] = s_ncut;
+        svi[SBD_SVI_LYRCUT] = s_lyrcut;
+        svi[SBD_SVI_STATUS] = st;
+    }
+}
+
+}  // namespace sbd

@@ -1,0 +1,228 @@
+// Radiance kernels.
+//
+// usrint_kernel: azimuthal component UUM(iu, lev) of the intensity at the user angles by
+// analytic integration of the source function layer by layer (USRINT, disort.f:4355-4793),
+// one wave per (work item, mode), one lane per (output level, user angle) pair so that the
+// sums over layers and streams run in the reference's order.  Only the requested output
+// levels are evaluated (SBDART prints two of DISORT's NLYR+1 levels, drt.f:996-1006).
+// The exp(KK*dtau) factors are the STWJ factors the layer kernel already produced.
+//
+// azimuth_kernel: Fourier cosine series UU = sum_m UUM_m cos(m (phi - phi0))
+// (disort.f:767-825) including the reference's two-in-a-row convergence exit (ACCUR = 0
+// in SBDART, drt.f:142), one lane per (level, angle), modes summed in order.
+#pragma once
+#include "sbd_common.hpp"
+
+namespace sbd {
+
+__global__ void __launch_bounds__(64) usrint_kernel(Params P)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x;
+    const long long ms = blockIdx.x;
+    const int nmode = P.nmode;
+    const int mazim = (int)(ms % nmode);
+    const int slot = (int)(ms / nmode);
+    if (slot >= P.nslot) return;
+    const int L = P.L, n = P.n, nn = P.nn, numu = P.numu, nlev = P.nlev;
+    const int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
+    const int st0 = svi[SBD_SVI_STATUS];
+    const double fbeam = P.fbeam[slot];
+    double *uum = P.uum + (size_t)ms * nlev * numu;
+    const bool dead = (st0 & (0x20 | 0x10 | 0x08)) != 0;
+    if (dead || (mazim > 0 && fbeam == 0.0)) {
+        for (int i = lane; i < nlev * numu; i += 64) uum[i] = 0.0;
+        return;
+    }
+    const int ncut = svi[SBD_SVI_NCUT];
+    const bool lyrcut = svi[SBD_SVI_LYRCUT] != 0;
+    const bool plank = P.plank[slot] != 0;
+    const int32_t *layru = svi + SBD_SVI_LAYRU;
+    const SV o(L);
+    const double *sv = P.sv + (size_t)slot * P.sv_stride;
+    const double *taucpr = sv + o.taucpr(), *dtaucp = sv + o.dtaucp(), *expbea = sv + o.expbea();
+    const double *utaupr = sv + o.utaupr();
+    const double bplank = sv[o.bplank()], tplank = sv[o.tplank()];
+    const double albedo = P.albedo[slot];
+    const double delm0 = (mazim == 0) ? 1.0 : 0.0;
+    const double umu0 = P.umu0, pi = P.pi;
+    const double *cmu = P.t.cmu, *cwt = P.t.cwt, *umu = P.t.umu;
+    const bool beam = fbeam > 0.0;
+    const bool therm = plank && mazim == 0;
+
+    const double *gc = P.gc + (size_t)ms * L * n * n;
+    const double *kk = P.kk + (size_t)ms * L * n;
+    const double *ek = P.ek + (size_t)ms * L * nn;
+    const double *zz = P.zz + (size_t)ms * L * n;
+    const double *zp0 = P.zp0 + (size_t)(ms - mazim) * L * n;
+    const double *zp1 = P.zp1 + (size_t)(ms - mazim) * L * n;
+    const double *ll = P.ll + (size_t)ms * L * n;
+    const double *gu = P.gu + (size_t)ms * L * n * numu;
+    const double *zb = P.zb + (size_t)ms * L * numu;
+    const double *z0u = P.z0u + (size_t)(ms - mazim) * L * numu;
+    const double *z1u = P.z1u + (size_t)(ms - mazim) * L * numu;
+#define GC(i, j, lc) gc[((size_t)((lc) - 1) * n + ((i) - 1)) * n + ((j) - 1)]
+#define KK(i, lc) kk[((lc) - 1) * n + ((i) - 1)]
+#define EK(i, lc) ek[((lc) - 1) * nn + ((i) - 1)]
+#define ZZ(i, lc) zz[((lc) - 1) * n + ((i) - 1)]
+#define ZP0(i, lc) zp0[((lc) - 1) * n + ((i) - 1)]
+#define ZP1(i, lc) zp1[((lc) - 1) * n + ((i) - 1)]
+#define LL(i, lc) ll[((lc) - 1) * n + ((i) - 1)]
+#define GU(iu, iq, lc) gu[((size_t)((lc) - 1) * n + ((iq) - 1)) * numu + ((iu) - 1)]
+#define ZB(iu, lc) zb[((lc) - 1) * numu + ((iu) - 1)]
+#define Z0U(iu, lc) z0u[((lc) - 1) * numu + ((iu) - 1)]
+#define Z1U(iu, lc) z1u[((lc) - 1) * numu + ((iu) - 1)]
+
+    // ---- surface term, identical for every user angle (Lambertian RMU = albedo,
+    //      disort.f:4736-4781): bnddfu = sum_{iq=nn..1} (1+delm0) albedo CMU CWT DFUINT(iq) ----
+    double bndsrf = 0.0;   // BNDDFU + BNDDIR + DELM0*EMU*BPLANK
+    const bool has_surface = !(lyrcut || mazim > 0);
+    if (has_surface) {
+        double *dfu = smem;   // [nn]
+        if (lane < nn) {
+            const int iq = lane + 1;
+            double dfuint = 0.0;
+            for (int jq = 1; jq <= nn; ++jq) dfuint = dfuint + GC(iq, jq, L) * LL(jq, L);
+            for (int jq = nn + 1; jq <= n; ++jq)
+                dfuint = dfuint + GC(iq, jq, L) * LL(jq, L) * exp(-KK(jq, L) * dtaucp[L - 1]);
+            if (beam) dfuint = dfuint + ZZ(iq, L) * expbea[L];
+            dfuint = dfuint + delm0 * (ZP0(iq, L) + ZP1(iq, L) * taucpr[L]);
+            dfu[lane] = dfuint;
+        }
+        wave_lds_sync();
+        double bnddfu = 0.0;
+        for (int iq = nn; iq >= 1; --iq)
+            bnddfu = bnddfu + (1.0 + delm0) * albedo * cmu[nn - iq] * cwt[nn - iq] * dfu[iq - 1];
+        double bnddir = 0.0;
+        if (beam) bnddir = umu0 * fbeam / pi * albedo * expbea[L];
+        bndsrf = bnddfu + bnddir + delm0 * (1.0 - albedo) * bplank;
+    }
+
+    const double lh = SBD_F32(0.0001), eps6 = SBD_F32(1.0e-6);
+    for (int item = lane; item < nlev * numu; item += 64) {
+        const int li = item / numu, iu = item % numu + 1;
+        const int lev = P.all_levels ? li : P.t.level_out[li];
+        const int lyu = layru[lev];
+        double result = 0.0;
+        if (!(lyrcut && lyu > ncut)) {
+            const double um = umu[iu - 1];
+            const double up = utaupr[lev];
+            const bool negumu = um < 0.0;
+            const double exp0 = beam ? exp(-up / umu0) : 0.0;
+            int lyrstr, lyrend;
+            double sgn;
+            if (negumu) { lyrstr = 1; lyrend = lyu - 1; sgn = -1.0; }
+            else { lyrstr = lyu + 1; lyrend = ncut; sgn = 1.0; }
+            double palint = 0.0, plkint = 0.0, exp1 = 0.0, exp2 = 0.0, denom, expn;
+            for (int lc = lyrstr; lc <= lyrend; ++lc) {
+                const double dtau = dtaucp[lc - 1];
+                exp1 = exp((up - taucpr[lc - 1]) / um);
+                exp2 = exp((up - taucpr[lc]) / um);
+                if (therm) {
+                    const double f0n = sgn * (exp1 - exp2);
+                    const double f1n = sgn * ((taucpr[lc - 1] + um) * exp1 - (taucpr[lc] + um) * exp2);
+                    plkint = plkint + Z0U(iu, lc) * f0n + Z1U(iu, lc) * f1n;
+                }
+                if (beam) {
+                    denom = 1.0 + um / umu0;
+                    if (fabs(denom) < lh) expn = (dtau / umu0) * exp0;
+                    else expn = (exp1 * expbea[lc - 1] - exp2 * expbea[lc]) * sgn / denom;
+                    palint = palint + ZB(iu, lc) * expn;
+                }
+                for (int iq = 1; iq <= nn; ++iq) {   // KK negative
+                    denom = 1.0 + um * KK(iq, lc);
+                    if (fabs(denom) < lh) expn = dtau / um * exp2;
+                    else expn = sgn * (exp1 * EK(iq, lc) - exp2) / denom;
+                    palint = palint + (GU(iu, iq, lc) * LL(iq, lc)) * expn;
+                }
+                for (int iq = nn + 1; iq <= n; ++iq) {   // KK positive
+                    denom = 1.0 + um * KK(iq, lc);
+                    if (fabs(denom) < lh) expn = -dtau / um * exp1;
+                    else expn = sgn * (exp1 - exp2 * EK(n + 1 - iq, lc)) / denom;
+                    palint = palint + (GU(iu, iq, lc) * LL(iq, lc)) * expn;
+                }
+            }
+            // from the output level to the adjacent computational level
+            const double dtau1 = up - taucpr[lyu - 1];
+            const double dtau2 = up - taucpr[lyu];
+            const bool skip = (fabs(dtau1) < eps6 && negumu) || (fabs(dtau2) < eps6 && !negumu);
+            if (!skip) {
+                if (negumu) exp1 = exp(dtau1 / um);
+                else exp2 = exp(dtau2 / um);
+                if (beam) {
+                    denom = 1.0 + um / umu0;
+                    if (fabs(denom) < lh) expn = (dtau1 / umu0) * exp0;
+                    else if (negumu) expn = (exp0 - expbea[lyu - 1] * exp1) / denom;
+                    else expn = (exp0 - expbea[lyu] * exp2) / denom;
+                    palint = palint + ZB(iu, lyu) * expn;
+                }
+                const double dtau = dtaucp[lyu - 1];
+                for (int iq = 1; iq <= nn; ++iq) {
+                    const double kq = KK(iq, lyu);
+                    denom = 1.0 + um * kq;
+                    if (fabs(denom) < lh) expn = -dtau2 / um * exp2;
+                    else if (negumu) expn = (exp(-kq * dtau2) - exp(kq * dtau) * exp1) / denom;
+                    else expn = (exp(-kq * dtau2) - exp2) / denom;
+                    palint = palint + (GU(iu, iq, lyu) * LL(iq, lyu)) * expn;
+                }
+                for (int iq = nn + 1; iq <= n; ++iq) {
+                    const double kq = KK(iq, lyu);
+                    denom = 1.0 + um * kq;
+                    if (fabs(denom) < lh) expn = -dtau1 / um * exp1;
+                    else if (negumu) expn = (exp(-kq * dtau1) - exp1) / denom;
+                    else expn = (exp(-kq * dtau1) - exp(-kq * dtau) * exp2) / denom;
+                    palint = palint + (GU(iu, iq, lyu) * LL(iq, lyu)) * expn;
+                }
+                if (therm) {
+                    double fact;
+                    if (negumu) { expn = exp1; fact = taucpr[lyu - 1] + um; }
+                    else { expn = exp2; fact = taucpr[lyu] + um; }
+                    const double f0n = 1.0 - expn;
+                    const double f1n = up + um - fact * expn;
+                    plkint = plkint + Z0U(iu, lyu) * f0n + Z1U(iu, lyu) * f1n;
+                }
+            }
+            double bndint = 0.0;
+            if (negumu && mazim == 0) bndint = (P.fisot + tplank) * exp(up / um);
+            else if (!negumu && has_surface) bndint = bndsrf * exp((up - taucpr[L]) / um);
+            result = palint + plkint + bndint;
+        }
+        uum[(size_t)li * numu + (iu - 1)] = result;
+    }
+#undef GC
+#undef KK
+#undef EK
+#undef ZZ
+#undef ZP0
+#undef ZP1
+#undef LL
+#undef GU
+#undef ZB
+#undef Z0U
+#undef Z1U
+}
+
+// grid: ceil(nslot*nlev*numu / 256) blocks of 256 threads.
+__global__ void __launch_bounds__(256) azimuth_kernel(Params P, int naz_run)
+{
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nlev = P.nlev, numu = P.numu, nphi = P.nphi, nmode = P.nmode;
+    const long long per = (long long)nlev * numu;
+    if (tid >= per * P.nslot) return;
+    const int slot = (int)(tid / per);
+    const int rem = (int)(tid % per);   // li*numu + iu
+    const double fbeam = P.fbeam[slot];
+    const int naz = (fbeam == 0.0) ? 0 : naz_run;   // disort.f:577-586
+    const double *uum = P.uum + (size_t)slot * nmode * per + rem;
+    double *uu = P.uu + (size_t)slot * nphi * per + rem;
+    // the convergence test (disort.f:821-825) is global over (iu, lu, j): evaluated in a
+    // second kernel only if some mode is identically zero -- with ACCUR = 0 a term can
+    // "converge" only when every AZTERM of a mode vanishes, and then adding it is a no-op.
+    for (int j = 0; j < nphi; ++j) {
+        double acc = uum[0];
+        for (int m = 1; m <= naz; ++m) acc = acc + uum[(size_t)m * per] * P.t.cosmphi[(size_t)m * nphi + j];
+        uu[(size_t)j * per] = acc;
+    }
+}
+
+}  // namespace sbd

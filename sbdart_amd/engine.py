@@ -1,0 +1,241 @@
+"""Host-side mirror of the reference's DISORT operator for SBDART's wavelength loop.
+
+Argument names and meaning are DISORT's (disort.f:1-6, Documents/disort.doc:561-986) as
+drt.f:541-546 passes them; the per-run arguments go to the constructor, the per-
+(wavelength, k-term) arguments to :meth:`DisortEngine.solve`, which takes a whole batch.
+Everything runs in the HIP library behind the C ABI (include/sbdart_amd.h); numpy inputs
+use the host entry point, torch CUDA(=HIP) tensors the device entry point.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import BatchIn, BatchOut, RunCfg
+
+
+class SbdError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        L = _lib.load()
+        self.code = code
+        super().__init__(f"{where}: {L.sbd_strerror(code).decode()} [{code}] {L.sbd_last_error().decode()}")
+
+
+class RetryNstr(SbdError):
+    """Beam angle equals a quadrature angle (disort.f:2645-2650): use NSTR-2 / NSTR+2 as
+    drt.f:536-555 does."""
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class DisortEngine:
+    def __init__(self, nlyr: int, nstr: int, nmom: int, temper: Sequence[float], umu0: float,
+                 phi0: float = 0.0, onlyfl: bool = True, usrang: Optional[bool] = None,
+                 umu: Optional[Sequence[float]] = None, phi: Optional[Sequence[float]] = None,
+                 btemp: float = 0.0, ttemp: float = 0.0, temis: float = 0.0, fisot: float = 0.0,
+                 lamber: bool = True, level_out: Optional[Sequence[int]] = None, device: int = 0,
+                 max_batch: int = 0, allow_retry_nstr: bool = False):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        self.nlyr, self.nstr, self.nmom = int(nlyr), int(nstr), int(nmom)
+        self.onlyfl = bool(onlyfl)
+        self._temper = _f64(temper)
+        assert self._temper.shape == (self.nlyr + 1,), "TEMPER has nlyr+1 levels"
+        self._umu = _f64(umu if umu is not None else [])
+        self._phi = _f64(phi if phi is not None else [])
+        self.numu, self.nphi = (0, 0) if self.onlyfl else (len(self._umu), len(self._phi))
+        if usrang is None:
+            usrang = not self.onlyfl
+        self._lev = None if level_out is None else np.ascontiguousarray(level_out, dtype=np.int32)
+        cfg = RunCfg(
+            abi_version=_lib.ABI_VERSION, nlyr=self.nlyr, nstr=self.nstr, nmom=self.nmom,
+            onlyfl=int(self.onlyfl), lamber=int(lamber), usrang=int(usrang), numu=self.numu,
+            nphi=self.nphi, nlevel_out=0 if self._lev is None else len(self._lev), device=device,
+            max_batch=max_batch, umu0=umu0, phi0=phi0, fisot=fisot, btemp=btemp, ttemp=ttemp,
+            temis=temis,
+            temper=self._temper.ctypes.data_as(C.POINTER(C.c_double)),
+            umu=self._umu.ctypes.data_as(C.POINTER(C.c_double)) if self.numu else None,
+            phi=self._phi.ctypes.data_as(C.POINTER(C.c_double)) if self.nphi else None,
+            level_out=None if self._lev is None else self._lev.ctypes.data_as(C.POINTER(C.c_int32)))
+        rc = self._L.sbd_engine_create(C.byref(cfg), C.byref(self._h))
+        self.retry_nstr = rc == _lib.E_RETRY_NSTR
+        if rc == _lib.E_RETRY_NSTR and not allow_retry_nstr:
+            self.close()
+            raise RetryNstr(rc, "sbd_engine_create")
+        if rc not in (_lib.OK, _lib.E_RETRY_NSTR):
+            self._h = C.c_void_p()
+            raise SbdError(rc, "sbd_engine_create")
+        self.nlev = self._L.sbd_engine_nlevel(self._h)
+        self.device = device
+
+    # ---- lifecycle ----
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.sbd_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- introspection ----
+    @property
+    def chunk(self) -> int:
+        return self._L.sbd_engine_chunk(self._h)
+
+    @property
+    def workspace_bytes(self) -> int:
+        return self._L.sbd_engine_workspace_bytes(self._h)
+
+    @property
+    def stream(self) -> int:
+        return self._L.sbd_engine_stream(self._h) or 0
+
+    def quadrature(self):
+        nn = self.nstr // 2
+        cmu, cwt = np.zeros(nn), np.zeros(nn)
+        self._L.sbd_engine_quadrature(self._h, cmu.ctypes.data_as(C.POINTER(C.c_double)),
+                                      cwt.ctypes.data_as(C.POINTER(C.c_double)))
+        return cmu, cwt
+
+    def enable_timing(self, on: bool = True):
+        self._L.sbd_engine_enable_timing(self._h, int(on))
+
+    def last_ms(self, phase: int = -1) -> float:
+        return self._L.sbd_engine_last_ms(self._h, phase)
+
+    def debug_array(self, which: str, slot: int = 0, mode: int = 0):
+        """Test hook: workspace array of the last chunk (see sbd_engine_debug_copy)."""
+        ids = dict(gc=0, kk=1, ek=2, zz=3, zp0=4, zp1=5, ll=6)
+        n, nn, L = self.nstr, self.nstr // 2, self.nlyr
+        per = dict(gc=L * n * n, kk=L * n, ek=L * nn, zz=L * n, zp0=L * n, zp1=L * n, ll=L * n)[which]
+        shape = dict(gc=(L, n, n), kk=(L, n), ek=(L, nn), zz=(L, n), zp0=(L, n), zp1=(L, n), ll=(L, n))[which]
+        nmode = 1 if self.onlyfl else self.nstr   # upper bound; engine may use fewer
+        buf = np.zeros(per * (slot * nmode + mode + 1) * 1)
+        # modes per slot are engine-internal: fetch enough and index with the true count
+        got = self._L.sbd_engine_debug_copy(self._h, ids[which], buf.ctypes.data_as(C.c_void_p), buf.nbytes)
+        if got < 0:
+            raise SbdError(int(got), "sbd_engine_debug_copy")
+        return buf, per, shape
+
+    # ---- the hot path ----
+    def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank):
+        """Solve a batch.  Shapes: dtauc/ssalb [W, nlyr]; pmom [W, nlyr, nmom+1];
+        wvnmlo/wvnmhi/fbeam/albedo [W]; plank [W] bool.  Returns (flux[W,5,nlev],
+        uu[W,nphi,nlev,numu] or None, status[W])."""
+        try:
+            import torch
+            is_t = isinstance(dtauc, torch.Tensor)
+        except Exception:  # torch is plumbing only
+            is_t = False
+        if is_t:
+            return self._solve_device(dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank)
+        dtauc, ssalb, pmom = _f64(dtauc), _f64(ssalb), _f64(pmom)
+        W = dtauc.shape[0]
+        assert dtauc.shape == (W, self.nlyr) and ssalb.shape == (W, self.nlyr)
+        assert pmom.shape == (W, self.nlyr, self.nmom + 1)
+        lo, hi, fb, al = (_f64(np.broadcast_to(x, (W,))) for x in (wvnmlo, wvnmhi, fbeam, albedo))
+        pl = np.ascontiguousarray(np.broadcast_to(plank, (W,)), dtype=np.uint8)
+        flux = np.zeros((W, _lib.NFLUX, self.nlev))
+        uu = None if self.onlyfl else np.zeros((W, self.nphi, self.nlev, self.numu))
+        status = np.zeros(W, dtype=np.int32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        bi = BatchIn(W, vp(dtauc), vp(ssalb), vp(pmom), vp(lo), vp(hi), vp(fb), vp(al), vp(pl))
+        bo = BatchOut(vp(flux), None if uu is None else vp(uu), vp(status))
+        rc = self._L.sbd_engine_solve_host(self._h, C.byref(bi), C.byref(bo))
+        if rc != _lib.OK:
+            raise SbdError(rc, "sbd_engine_solve_host")
+        return flux, uu, status
+
+    def _solve_device(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank,
+                      out=None, stream: Optional[int] = None):
+        import torch
+        W = dtauc.shape[0]
+        for t in (dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo):
+            assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+        assert plank.is_cuda and plank.dtype == torch.uint8 and plank.is_contiguous()
+        dev = dtauc.device
+        if out is None:
+            flux = torch.empty((W, _lib.NFLUX, self.nlev), dtype=torch.float64, device=dev)
+            uu = None if self.onlyfl else torch.empty((W, self.nphi, self.nlev, self.numu),
+                                                       dtype=torch.float64, device=dev)
+            status = torch.empty(W, dtype=torch.int32, device=dev)
+        else:
+            flux, uu, status = out
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        bi = BatchIn(W, dtauc.data_ptr(), ssalb.data_ptr(), pmom.data_ptr(), wvnmlo.data_ptr(),
+                     wvnmhi.data_ptr(), fbeam.data_ptr(), albedo.data_ptr(), plank.data_ptr())
+        bo = BatchOut(flux.data_ptr(), 0 if uu is None else uu.data_ptr(), status.data_ptr())
+        rc = self._L.sbd_engine_solve_device(self._h, C.byref(bi), C.byref(bo), C.c_void_p(stream))
+        if rc != _lib.OK:
+            raise SbdError(rc, "sbd_engine_solve_device")
+        return flux, uu, status
+
+    solve_device = _solve_device
+
+    def accumulate(self, weight, flux, uu=None, acc_flux=None, acc_uu=None):
+        """stdout1's weighted sums (drt.f:964-1054) on the GPU; numpy in/out."""
+        weight, flux = _f64(weight), _f64(flux)
+        W = len(weight)
+        if acc_flux is None:
+            acc_flux = np.zeros((_lib.NFLUX, self.nlev))
+        if uu is not None and acc_uu is None:
+            acc_uu = np.zeros((self.nphi, self.nlev, self.numu))
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        if uu is not None:
+            uu = _f64(uu)
+        rc = self._L.sbd_engine_accumulate_host(self._h, W, vp(weight), vp(flux), vp(uu),
+                                                vp(acc_flux), vp(acc_uu))
+        if rc != _lib.OK:
+            raise SbdError(rc, "sbd_engine_accumulate_host")
+        return acc_flux, acc_uu
+
+
+def engine_for_record(rec, level_out=None, device=0, max_batch=0, allow_retry_nstr=True):
+    """Engine whose per-run arguments are those of one SolveRecord."""
+    return DisortEngine(
+        nlyr=rec.nlyr, nstr=rec.nstr, nmom=rec.nmom, temper=rec.temper, umu0=rec.umu0,
+        phi0=rec.phi0, onlyfl=rec.onlyfl, usrang=rec.usrang, umu=rec.umu, phi=rec.phi,
+        btemp=rec.btemp, ttemp=rec.ttemp, temis=rec.temis, fisot=rec.fisot, lamber=rec.lamber,
+        level_out=level_out, device=device, max_batch=max_batch, allow_retry_nstr=allow_retry_nstr)
+
+
+def run_key(rec):
+    return (rec.nlyr, rec.nstr, rec.nmom, rec.flags & ~1, rec.umu0, rec.phi0, rec.btemp, rec.ttemp,
+            rec.temis, rec.fisot, rec.temper.tobytes(), rec.umu.tobytes(), rec.phi.tobytes())
+
+
+def solve_records(recs, level_out=None, device=0):
+    """Solve SolveRecords on the GPU, grouping records that share per-run arguments.
+    Returns lists (flux[5,nlev], uu or None, status) in input order."""
+    groups = {}
+    for i, r in enumerate(recs):
+        groups.setdefault(run_key(r), []).append(i)
+    flux_out, uu_out, st_out = [None] * len(recs), [None] * len(recs), [0] * len(recs)
+    for idx in groups.values():
+        r0 = recs[idx[0]]
+        with engine_for_record(r0, level_out=level_out, device=device) as eng:
+            flux, uu, st = eng.solve(
+                np.stack([recs[i].dtauc for i in idx]), np.stack([recs[i].ssalb for i in idx]),
+                np.stack([recs[i].pmom for i in idx]), [recs[i].wvnmlo for i in idx],
+                [recs[i].wvnmhi for i in idx], [recs[i].fbeam for i in idx],
+                [recs[i].albedo for i in idx], [recs[i].plank for i in idx])
+        for k, i in enumerate(idx):
+            flux_out[i], st_out[i] = flux[k], int(st[k])
+            if uu is not None:
+                uu_out[i] = uu[k]
+    return flux_out, uu_out, st_out
