@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: spectral-points/sec of the DISORT hot path on a synthetic
+16-stream short-wave sweep (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: every (wavelength, k-term) work
+item of the sweep is solved on the GPU (inputs already resident in HBM), the spectrally
+integrated fluxes are accumulated with stdout1's weights (drt.f:964-1054) and, for N>1,
+summed over ranks with one RCCL reduce.  Work is sharded by spectral point, weak scaling
+(each rank owns `--nwl` points of a N-times longer sweep).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_VEC_PEAK_TF = 78.6        # fp64 vector peak
+
+
+def algorithmic_bytes_per_solve(nlyr, nstr, nlev):
+    # in = 8*[L*(NSTR+3)+8], out = 8*3*nlev (rfldir, rfldn, flup at nlev levels)
+    return 8 * (nlyr * (nstr + 3) + 8) + 8 * 3 * nlev
+
+
+def algorithmic_flops_per_solve(nlyr, nstr):
+    nn = nstr // 2
+    ncd = 3 * nn - 1
+    per_layer = 3 * nn * nstr ** 2 + 2 * nn ** 3 + 25 * nn ** 3 + 2 * nn ** 3 + (2.0 / 3.0) * nstr ** 3 + 4 * nstr ** 2
+    N = nstr * nlyr
+    band = 2 * N * ncd * (2 * ncd) + 2 * N * 3 * ncd
+    return nlyr * per_layer + band + 2 * nstr ** 2 * 3
+
+
+def cpu_baseline(sw, seconds_target=12.0):
+    """Reference DISORT (oracle/_ref/disort_ref_cli, kind "reference") or the C restatement
+    (kind "port") timed on ONE host core over a bounded sample of the same workload."""
+    from sbdart_amd.records import write_records
+    from sbdart_amd.workload import sweep_to_records
+    cli = os.path.join(ROOT, "oracle", "_ref", "disort_ref_cli")
+    avg_nk = sw.nwork / sw.nwl
+    if os.path.isfile(cli) and os.access(cli, os.X_OK):
+        nsample = min(sw.nwork, 2000)
+        recs = sweep_to_records(sw, range(nsample))
+        with tempfile.TemporaryDirectory() as d:
+            write_records(os.path.join(d, "in.sbdrec"), recs, with_out=False)
+            t0 = time.time()
+            out = subprocess.run([cli, "in.sbdrec", "out.sbdrec", "1"], cwd=d, capture_output=True, text=True)
+            probe = time.time() - t0
+            rep = max(1, min(20, int(seconds_target / max(probe, 1e-3))))
+            out = subprocess.run([cli, "in.sbdrec", "out.sbdrec", str(rep)], cwd=d, capture_output=True, text=True)
+        for line in out.stdout.splitlines():
+            if line.startswith("TIMING"):
+                _, nsolve, secs = line.split()
+                sps = float(nsolve) / float(secs)
+                return {"value": sps / avg_nk, "unit": "spectral-points/s", "cores": 1, "kind": "reference",
+                        "solves_per_s": sps,
+                        "sample": f"{nsample} solves of this workload x {rep} repeats, reference DISORT "
+                                  f"(amdflang -O2) on 1 host core, DISORT calls only"}
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle  # baseline leg only
+    nsample = min(sw.nwork, 1500)
+    recs = sweep_to_records(sw, range(nsample))
+    pyoracle.disort(recs[0])
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < seconds_target:
+        for r in recs:
+            pyoracle.disort(r)
+        n += nsample
+    secs = time.time() - t0
+    return {"value": n / secs / avg_nk, "unit": "spectral-points/s", "cores": 1, "kind": "port",
+            "solves_per_s": n / secs,
+            "sample": f"{nsample} solves of this workload repeated for {secs:.1f}s, C restatement "
+                      f"(oracle/disort_oracle.c, gcc -O2) through ctypes on 1 host core"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nwl", type=int, default=49152, help="spectral points per GPU (W = 2.67x)")
+    ap.add_argument("--nstr", type=int, default=16)
+    ap.add_argument("--nlyr", type=int, default=33)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, (world, args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from sbdart_amd.engine import DisortEngine
+    from sbdart_amd.workload import sw_sweep
+
+    sw = sw_sweep(nwl=args.nwl, nstr=args.nstr, nlyr=args.nlyr, seed=12345, shard=rank)
+    W = sw.nwork
+    level_out = [0, sw.nlyr]                      # ntop, nbot of IOUT 1/10 (drt.f:376-381)
+    eng = DisortEngine(nlyr=sw.nlyr, nstr=sw.nstr, nmom=sw.nmom, temper=sw.temper, umu0=sw.umu0,
+                       btemp=sw.btemp, ttemp=sw.ttemp, temis=sw.temis, onlyfl=True,
+                       level_out=level_out, device=local_rank)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_in = [t(sw.dtauc), t(sw.ssalb), t(sw.pmom), t(sw.wvnmlo), t(sw.wvnmhi), t(sw.fbeam), t(sw.albedo), t(sw.plank)]
+    d_w = t(sw.weight)
+    flux = torch.empty((W, 5, eng.nlev), dtype=torch.float64, device=dev)
+    status = torch.empty(W, dtype=torch.int32, device=dev)
+    acc = torch.zeros((5, eng.nlev), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    import ctypes as C
+    L = eng._L
+
+    def step():
+        eng.solve_device(*d_in, out=(flux, None, status), stream=stream)
+        acc.zero_()
+        rc = L.sbd_engine_accumulate_device(eng._h, W, d_w.data_ptr(), flux.data_ptr(), None,
+                                            acc.data_ptr(), None, C.c_void_p(stream))
+        assert rc == 0, rc
+        if world > 1:
+            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)   # the one RCCL collective of the path
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    bad = int((status != 0).sum().item())
+
+    # ---- per-kernel timing pass (HIP events on the launch stream), outside the timed region ----
+    eng.enable_timing(True)
+    phase_ms = np.zeros(4)
+    nrep = 3
+    for _ in range(nrep):
+        eng.solve_device(*d_in, out=(flux, None, status), stream=stream)
+        phase_ms += [eng.last_ms(p) for p in range(4)]
+    phase_ms /= nrep
+    eng.enable_timing(False)
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        nwl_total = sw.nwl * world
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = nwl_total * args.steps / elapsed
+        names = ["setup_kernel", "layer_kernel", "band_kernel", "usrint+azimuth"]
+        dom = int(np.argmax(phase_ms))
+        abytes = algorithmic_bytes_per_solve(sw.nlyr, sw.nstr, eng.nlev)
+        nlaunch = (W + eng.chunk - 1) // eng.chunk
+        ach = abytes * W / (phase_ms[dom] * 1e-3) / 1e9
+        flops = algorithmic_flops_per_solve(sw.nlyr, sw.nstr)
+        out = {
+            "metric": "spectral-points/sec (whole node) + flux RMSE vs CPU, 16-stream SW sweep",
+            "value": value, "unit": "spectral-points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"SW 0.25-4.0um synthetic sweep, nstr={sw.nstr}, {sw.nlyr} layers, "
+                                   f"{sw.nwl} spectral points/GPU, {W} DISORT solves/GPU (avg nk {W / sw.nwl:.2f}), "
+                                   f"flux at TOA+surface, seed 12345",
+                       "nstr": sw.nstr, "nlyr": sw.nlyr, "nwl_per_gpu": sw.nwl, "solves_per_gpu": W,
+                       "parallelism": f"spectral shard x{world}, 1 RCCL reduce of {5 * eng.nlev} doubles/step",
+                       "chunk": eng.chunk, "workspace_bytes": eng.workspace_bytes},
+            "solves_per_s": W * world * args.steps / elapsed,
+            "nonzero_status": bad,
+            "kernel_ms": {names[i]: float(phase_ms[i]) for i in range(4)},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_solve": abytes, "solves_per_launch": min(W, eng.chunk),
+                         "launches": nlaunch, "avg_launch_ms": float(phase_ms[dom] / nlaunch),
+                         "note": "path is fp64-VALU/LDS/latency bound by construction (SURVEY 8d); "
+                                 "fp64 fraction reported beside it",
+                         "fp64_achieved_tflops": flops * W / (phase_ms.sum() * 1e-3) / 1e12,
+                         "fp64_frac_of_vector_peak": flops * W / (phase_ms.sum() * 1e-3) / 1e12 / FP64_VEC_PEAK_TF},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sw)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,68 @@
+"""The N>1 path on CPU: two gloo ranks shard a small sweep by spectral point, each
+integrates its shard (with the C oracle standing in for the GPU solve -- this test is
+about the sharding and the single reduce, not the kernels), and the reduced accumulators
+equal the single-process sums."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ORACLE_DIR, ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _integrate(sw, lo, hi):
+    import pyoracle
+    from sbdart_amd.workload import sweep_to_records
+    idx = np.nonzero((sw.wl_of >= lo) & (sw.wl_of < hi))[0]
+    acc = np.zeros((5, 2))
+    for i, rec in zip(idx, sweep_to_records(sw, idx)):
+        o = pyoracle.disort(rec)
+        for c, f in enumerate(("rfldir", "rfldn", "flup", "dfdt", "uavg")):
+            acc[c] += sw.weight[i] * o[f][[0, -1]]
+    return acc
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, ORACLE_DIR)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sbdart_amd.shard import reduce_accumulators, shard_range
+    from sbdart_amd.workload import sw_sweep
+    sw = sw_sweep(nwl=12, nstr=8, nlyr=5, seed=99)
+    lo, hi = shard_range(sw.nwl, rank, world)
+    acc = torch.from_numpy(_integrate(sw, lo, hi))
+    reduce_accumulators(acc, dst=0)
+    if rank == 0:
+        q.put(acc.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_spectral_shard_and_reduce():
+    sys.path.insert(0, ORACLE_DIR)
+    from sbdart_amd.workload import sw_sweep
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sw = sw_sweep(nwl=12, nstr=8, nlyr=5, seed=99)
+    whole = _integrate(sw, 0, sw.nwl)
+    assert np.allclose(got, whole, rtol=1e-13, atol=0)
