@@ -1,0 +1,129 @@
+! ISO_C_BINDING view of include/sbdart_amd.h -- the thin shim through which the
+! Fortran-2003 host (program sbdart_amd, or the reference's own drt.f, see
+! INTEGRATION.md) drives the MI355X engine.  One type per C struct, one interface
+! per C entry point; no logic lives here.
+module sbd_engine_mod
+  use iso_c_binding
+  implicit none
+  private
+  public :: sbd_run_cfg, sbd_batch_in, sbd_batch_out
+  public :: sbd_engine_create, sbd_engine_destroy, sbd_engine_solve_host, &
+            sbd_engine_solve_device, sbd_engine_accumulate_host, sbd_engine_nlevel, &
+            sbd_engine_chunk, sbd_strerror_f, sbd_last_error_f, sbd_abi_version
+  public :: SBD_OK, SBD_E_RETRY_NSTR, SBD_NFLUX, SBD_ABI_VER
+  public :: SBD_ST_WARN_SOLVE0, SBD_ST_WARN_UPBEAM, SBD_ST_WARN_UPISOT, SBD_ST_ERR_EIGEN, &
+            SBD_ST_RETRY_NSTR, SBD_ST_ERR_INPUT, SBD_ST_WARN_PLKAVG
+
+  integer(c_int), parameter :: SBD_ABI_VER = 1, SBD_OK = 0, SBD_E_RETRY_NSTR = -2, SBD_NFLUX = 5
+  integer(c_int), parameter :: SBD_ST_WARN_SOLVE0 = 1, SBD_ST_WARN_UPBEAM = 2, SBD_ST_WARN_UPISOT = 4, &
+       SBD_ST_ERR_EIGEN = 8, SBD_ST_RETRY_NSTR = 16, SBD_ST_ERR_INPUT = 32, SBD_ST_WARN_PLKAVG = 64
+
+  type, bind(C) :: sbd_run_cfg
+    integer(c_int32_t) :: abi_version, nlyr, nstr, nmom, onlyfl, lamber, usrang, numu, nphi, &
+                          nlevel_out, device, max_batch
+    real(c_double) :: umu0, phi0, fisot, btemp, ttemp, temis
+    type(c_ptr) :: temper, umu, phi, level_out
+  end type
+
+  type, bind(C) :: sbd_batch_in
+    integer(c_int32_t) :: nwork
+    type(c_ptr) :: dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank
+  end type
+
+  type, bind(C) :: sbd_batch_out
+    type(c_ptr) :: flux, uu, status
+  end type
+
+  interface
+    function sbd_engine_create(cfg, eng) bind(C, name='sbd_engine_create') result(rc)
+      import
+      type(sbd_run_cfg), intent(in) :: cfg
+      type(c_ptr), intent(out) :: eng
+      integer(c_int) :: rc
+    end function
+    subroutine sbd_engine_destroy(eng) bind(C, name='sbd_engine_destroy')
+      import
+      type(c_ptr), value :: eng
+    end subroutine
+    function sbd_engine_solve_host(eng, bin, bout) bind(C, name='sbd_engine_solve_host') result(rc)
+      import
+      type(c_ptr), value :: eng
+      type(sbd_batch_in), intent(in) :: bin
+      type(sbd_batch_out), intent(in) :: bout
+      integer(c_int) :: rc
+    end function
+    function sbd_engine_solve_device(eng, bin, bout, stream) bind(C, name='sbd_engine_solve_device') result(rc)
+      import
+      type(c_ptr), value :: eng, stream
+      type(sbd_batch_in), intent(in) :: bin
+      type(sbd_batch_out), intent(in) :: bout
+      integer(c_int) :: rc
+    end function
+    function sbd_engine_accumulate_host(eng, nwork, weight, flux, uu, acc_flux, acc_uu) &
+         bind(C, name='sbd_engine_accumulate_host') result(rc)
+      import
+      type(c_ptr), value :: eng, weight, flux, uu, acc_flux, acc_uu
+      integer(c_int32_t), value :: nwork
+      integer(c_int) :: rc
+    end function
+    function sbd_engine_nlevel(eng) bind(C, name='sbd_engine_nlevel') result(n)
+      import
+      type(c_ptr), value :: eng
+      integer(c_int32_t) :: n
+    end function
+    function sbd_engine_chunk(eng) bind(C, name='sbd_engine_chunk') result(n)
+      import
+      type(c_ptr), value :: eng
+      integer(c_int32_t) :: n
+    end function
+    function sbd_abi_version() bind(C, name='sbd_abi_version') result(n)
+      import
+      integer(c_int32_t) :: n
+    end function
+    function sbd_strerror_c(code) bind(C, name='sbd_strerror') result(p)
+      import
+      integer(c_int), value :: code
+      type(c_ptr) :: p
+    end function
+    function sbd_last_error_c() bind(C, name='sbd_last_error') result(p)
+      import
+      type(c_ptr) :: p
+    end function
+    function c_strlen(p) bind(C, name='strlen') result(n)
+      import
+      type(c_ptr), value :: p
+      integer(c_size_t) :: n
+    end function
+  end interface
+
+contains
+
+  function cstr(p) result(s)
+    type(c_ptr), intent(in) :: p
+    character(len=:), allocatable :: s
+    character(kind=c_char), pointer :: f(:)
+    integer :: n, i
+    if (.not. c_associated(p)) then
+      s = ''
+      return
+    end if
+    n = int(c_strlen(p))
+    call c_f_pointer(p, f, [n])
+    allocate(character(len=n) :: s)
+    do i = 1, n
+      s(i:i) = f(i)
+    end do
+  end function
+
+  function sbd_strerror_f(code) result(s)
+    integer(c_int), intent(in) :: code
+    character(len=:), allocatable :: s
+    s = cstr(sbd_strerror_c(code))
+  end function
+
+  function sbd_last_error_f() result(s)
+    character(len=:), allocatable :: s
+    s = cstr(sbd_last_error_c())
+  end function
+
+end module sbd_engine_mod
