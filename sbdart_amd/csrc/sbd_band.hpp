@@ -89,9 +89,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     double *win = smem + lds.win;
     double *b = smem + lds.b;
     double *mult = smem + lds.mult;
-    int *pslot = (int *)(smem + lds.misc);
     double *sbot = smem + lds.misc + RW / 2 + 2;      // [n] surface-reflection sums (bottom BC)
-    double *sums = sbot + n;                           // scratch [n]
 
     const double *gc = P.gc + (size_t)ms * L * n * n;
     const double *kk = P.kk + (size_t)ms * L * n;
@@ -122,7 +120,6 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     // ---- right-hand side B (SOLVE0, disort.f:3434-3599), unknown index = (lc-1)*n + iq ----
     const double bplank = sv[o.bplank()], tplank = sv[o.tplank()];
     const bool beam = fbeam > 0.0;
-    const bool therm = plank && mazim == 0;   // ZPLK arrays are zero otherwise
     for (int it = lane + 1; it <= N; it += 64) {
         double v;
         if (it <= nn) {   // top boundary
@@ -172,130 +169,190 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         }
         b[it - 1] = v;
     }
-    (void)therm;
-    if (lane < RW) pslot[lane] = lane;
     wave_lds_sync();
 
-    // ---- row generator (SETMTX): fills physical slot s with row r of the coefficient matrix ----
-    auto fill_row = [&](int r, int s) {
-        for (int c = lane; c < CW; c += 64) win[s * CWP + c] = 0.0;
-        wave_lds_sync();
-        if (r <= nn) {   // top boundary (disort.f:2887-2915): A(r, j) = GC(nn+1-r, j, 1) * [exp(KK(j,1)*TAUCPR(1))]
-            if (lane < n) {
-                const int j = lane + 1;
-                double v = GC(nn + 1 - r, j, 1);
-                if (j <= nn) v = v * exp(KK(j, 1) * taucpr[1]);
-                WIN(s, j) = v;
+    // ---- matrix entry generator (SETMTX, disort.f:2844-2990): element (r, col) of the
+    //      coefficient matrix as a product g*f of one GC element and one STWJ factor ----
+    auto entry = [&](int r, int col, double &g, double &f) {
+        g = 0.0;
+        f = 1.0;
+        if (col < 1 || col > N) return;
+        if (r <= nn) {                       // top boundary: GC(nn+1-r, j, 1) * exp(KK(j,1)*TAUCPR(1))
+            if (col <= n) {
+                g = GC(nn + 1 - r, col, 1);
+                if (col <= nn) f = exp(KK(col, 1) * taucpr[1]);
             }
-        } else if (r > N - nn) {   // bottom boundary (disort.f:2919-2990)
-            if (lane < n) {
-                const int iq = lane + 1;
-                const int jq = nn + (r - (N - nn));
-                double v = GC(jq, iq, ncut);
-                if (refl) v = v - (1.0 + delm0) * sbot[lane];
-                if (iq > nn) v = v * EK(n + 1 - iq, ncut);
-                WIN(s, N - n + iq) = v;
+        } else if (r > N - nn) {             // bottom boundary, Lambertian reflection folded in
+            const int iq = col - (N - n);
+            if (iq >= 1) {
+                g = GC(nn + (r - (N - nn)), iq, ncut);
+                if (refl) g = g - (1.0 + delm0) * sbot[iq - 1];
+                if (iq > nn) f = EK(n + 1 - iq, ncut);
             }
-        } else {   // continuity at the interface between layers lc and lc+1 (disort.f:2844-2884)
+        } else {                             // continuity between layers lc and lc+1
             const int q = r - nn - 1;
-            const int lc = q / n + 1, jq = q % n + 1;
-            for (int c = lane; c < 2 * n; c += 64) {
-                double v;
-                int col;
-                if (c < n) {
-                    const int iq = c + 1;
-                    v = GC(jq, iq, lc);
-                    if (iq > nn) v = v * EK(n + 1 - iq, lc);
-                    col = (lc - 1) * n + iq;
-                } else {
-                    const int iq = c - n + 1;
-                    v = -GC(jq, iq, lc + 1);
-                    if (iq <= nn) v = v * EK(iq, lc + 1);
-                    col = lc * n + iq;
-                }
-                WIN(s, col) = v;
+            const int lc = q / n + 1, jq = q - (lc - 1) * n + 1;
+            const int d = col - (lc - 1) * n;
+            if (d >= 1 && d <= n) {
+                g = GC(jq, d, lc);
+                if (d > nn) f = EK(n + 1 - d, lc);
+            } else if (d > n && d <= 2 * n) {
+                g = -GC(jq, d - n, lc + 1);
+                if (d - n <= nn) f = EK(d - n, lc + 1);
+            }
+        }
+    };
+
+    // logical row r lives in slot r % RW, column j at position j % CW; both are tracked
+    // with wrap-around counters (no integer division in the loop)
+    {
+        const int nfirst = (N < RW) ? N : RW;
+        for (int r = 1; r <= nfirst; ++r) {
+            const int s = r % RW;
+            for (int c = lane; c < CW; c += 64) {      // window columns 1..CW at start
+                double g, f;
+                entry(r, c + 1, g, f);
+                win[s * CWP + ((c + 1) % CW)] = g * f;
             }
         }
         wave_lds_sync();
-    };
-
-    {
-        const int nfirst = (N < RW) ? N : RW;
-        for (int r = 1; r <= nfirst; ++r) fill_row(r, r % RW);
     }
 
     // ---- banded LU with partial pivoting + forward elimination of B ----
     int status = 0;
     int ju = 0;
+    int kr = 1 % RW, kc = 1 % CW;            // slot of row k, position of column k
+    const bool two = CW > 64;                // second pass of lanes over the window width
     for (int k = 1; k <= N - 1; ++k) {
         const int lm = (ncd < N - k) ? ncd : N - k;
-        // pivot search over rows k..k+lm of column k
+        // (A) prefetch the row entering after this step (r = k+RW): lane c <-> column k+1+c
+        const int rin = k + RW;
+        double pg0 = 0.0, pf0 = 1.0, pg1 = 0.0, pf1 = 1.0;
+        if (rin <= N) {
+            entry(rin, k + 1 + lane, pg0, pf0);
+            if (two) entry(rin, k + 1 + lane + 64, pg1, pf1);
+        }
+        // (B) pivot search over rows k..k+lm of column k (ISAMAX's first-maximum rule);
+        //     lane t keeps the signed element a(k+t, k) for the multiplier
+        double ak = 0.0;
         double v = -1.0;
         int idx = 1 << 30;
         if (lane <= lm) {
-            v = fabs(WIN(pslot[(k + lane) % RW], k));
+            int s = kr + lane;
+            if (s >= RW) s -= RW;
+            ak = win[s * CWP + kc];
+            v = fabs(ak);
             idx = lane;
         }
         wave_argmax(v, idx);
-        if (v == 0.0) idx = 0;          // all-zero column: keep the diagonal, flag it
+        if (v == 0.0) idx = 0;               // all-zero column: keep the diagonal, flag it
         const int l = k + idx;
-        const int sk_old = pslot[k % RW], sl = pslot[l % RW];
-        const double piv = WIN(sl, k);
-        wave_lds_sync();
-        if (lane == 0 && l != k) {      // interchange = slot swap + RHS swap (SGBSL, disutil.f:1024-1032)
-            pslot[k % RW] = sl;
-            pslot[l % RW] = sk_old;
-            const double t = b[l - 1];
-            b[l - 1] = b[k - 1];
-            b[k - 1] = t;
-        }
-        wave_lds_sync();
-        const int sk = sl;              // slot of the pivot row
+        int sl = kr + idx;
+        if (sl >= RW) sl -= RW;
+        const int sk = kr;
+        const double piv = __shfl(ak, idx, 64);
+        const double akk = __shfl(ak, 0, 64);
         {
             const int junew = ncd + l;
             ju = (ju > junew) ? ju : junew;
             if (ju > N) ju = N;
         }
-        if (piv == 0.0) {
-            status |= 0x01;
-        } else {
-            const double t = -1.0 / piv;
-            const double bk = b[k - 1];
-            if (lane >= 1 && lane <= lm) {   // multipliers, applied to B at once
-                double *pk = &WIN(pslot[(k + lane) % RW], k);
-                const double m = *pk * t;
-                *pk = 0.0;   // this LDS column slot is reused by column k+CW (LINPACK's fill-in zeroing)
-                mult[lane] = m;
-                b[k + lane - 1] = b[k + lane - 1] + bk * m;
+        wave_lds_sync();
+        // (C) row interchange (physical, whole window width; column k handled apart: the
+        //     pivot goes to the diagonal, every sub-diagonal slot of column k is cleared
+        //     because column k+CW reuses it -- LINPACK's fill-in zeroing) + RHS interchange,
+        // (D) multipliers (-a/pivot) straight from the registers of the pivot search,
+        //     applied to B at once (SGBSL's forward sweep, disutil.f:1019-1036)
+        if (idx != 0) {
+            for (int c = lane; c < CW; c += 64) {
+                if (c != kc) {
+                    const double a = win[sk * CWP + c], bb = win[sl * CWP + c];
+                    win[sk * CWP + c] = bb;
+                    win[sl * CWP + c] = a;
+                }
             }
-            wave_lds_sync();
-            // rank-1 update: lane <-> column j, serial over the lm rows
+        }
+        const double bk_old = b[k - 1], bl_old = b[l - 1];
+        const double bk = (idx != 0) ? bl_old : bk_old;      // B(k) after the interchange
+        if (piv == 0.0) status |= 0x01;
+        const double tinv = (piv != 0.0) ? -1.0 / piv : 0.0;
+        if (lane == 0) {
+            win[sk * CWP + kc] = piv;
+            b[k - 1] = bk;
+        }
+        if (lane >= 1 && lane <= lm) {
+            int s = kr + lane;
+            if (s >= RW) s -= RW;
+            const double aik = (lane == idx) ? akk : ak;     // element below the pivot after the swap
+            const double m = aik * tinv;
+            win[s * CWP + kc] = 0.0;
+            mult[lane] = m;
+            const double bi = (lane == idx) ? bk_old : b[k + lane - 1];
+            b[k + lane - 1] = bi + bk * m;
+        }
+        wave_lds_sync();
+        // (E) rank-1 update: lane <-> column, rows in register chunks of 8 (loads, FMAs,
+        //     stores) so that the LDS latency is paid per chunk, not per row
+        if (piv != 0.0) {
             const int ncols = ju - k;
             for (int c = lane; c < ncols; c += 64) {
-                const int j = k + 1 + c;
-                const double tj = WIN(sk, j);
-                if (tj != 0.0) {              // SAXPY's early return (disutil.f:1711)
-                    for (int i = 1; i <= lm; ++i) {
-                        double *p = &WIN(pslot[(k + i) % RW], j);
-                        *p = *p + tj * mult[i];
+                int pc = kc + 1 + c;
+                if (pc >= CW) pc -= CW;
+                const double tj = win[sk * CWP + pc];
+                if (tj != 0.0) {                   // SAXPY's early return (disutil.f:1711)
+                    double *col = win + pc;
+                    int s0 = kr;
+                    for (int i0 = 1; i0 <= lm; i0 += 8) {
+                        double a[8];
+                        int so[8];
+                        int s = s0;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            s = (s + 1 == RW) ? 0 : s + 1;
+                            so[u] = s * CWP;
+                            a[u] = (i0 + u <= lm) ? col[so[u]] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (i0 + u <= lm) a[u] = a[u] + tj * mult[i0 + u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (i0 + u <= lm) col[so[u]] = a[u];
+                        s0 = s;
                     }
                 }
             }
         }
-        // retire row k: stream U(k, k..ju) to HBM in column-band order
+        // (F) retire row k: stream U(k, k..k+2ncd) to HBM in column-band order (zeros beyond
+        //     ju belong to U's band), then put the prefetched row into the freed slot
         {
-            const int wmax = (2 * ncd < N - k) ? 2 * ncd : N - k;   // zeros beyond ju are part of U's band
+            const int wmax = (2 * ncd < N - k) ? 2 * ncd : N - k;
             for (int c = lane; c <= wmax; c += 64) {
+                int pc = kc + c;
+                if (pc >= CW) pc -= CW;
                 const int j = k + c;
-                ufac[(size_t)(j - 1) * CW + (k - j + 2 * ncd)] = WIN(sk, j);
+                ufac[(size_t)(j - 1) * CW + (2 * ncd - c)] = win[sk * CWP + pc];
             }
         }
         wave_lds_sync();
-        if (k + RW <= N) fill_row(k + RW, sk);
+        if (rin <= N) {
+            {
+                int pc = kc + 1 + lane;          // column k+1+lane
+                if (pc >= CW) pc -= CW;
+                if (lane < CW) win[sk * CWP + pc] = pg0 * pf0;
+            }
+            if (two && lane + 64 < CW) {
+                int pc = kc + 1 + lane + 64;
+                if (pc >= CW) pc -= CW;
+                win[sk * CWP + pc] = pg1 * pf1;
+            }
+        }
+        wave_lds_sync();
+        kr = (kr + 1 == RW) ? 0 : kr + 1;
+        kc = (kc + 1 == CW) ? 0 : kc + 1;
     }
     {   // last row
-        const int sN = pslot[N % RW];
-        const double d = WIN(sN, N);
+        const double d = win[kr * CWP + kc];
         if (d == 0.0) status |= 0x01;
         if (lane == 0) ufac[(size_t)(N - 1) * CW + 2 * ncd] = d;
     }
