@@ -5,12 +5,18 @@
 //
 // The reference builds a dense LINPACK band array (LDA x N, 296 KB at NSTR=16, 33 layers)
 // and factors it in place.  Here the matrix is never materialised: partial-pivot LU only
-// ever touches rows k..k+NCD and columns k..k+2*NCD, so the wave keeps exactly that
-// (NCD+1) x (2*NCD+1) sliding window in LDS.  Rows enter the window generated on the fly
-// from the layer eigenvectors (GC rows, unit-stride HBM reads), pivot-row interchanges
-// are pointer swaps in a slot table, the multipliers are applied to the right-hand side
-// immediately (so L is never stored), and each finished U row is streamed to the HBM
-// workspace in column-band order so that back-substitution reads unit-stride columns.
+// ever touches rows k..k+NCD and columns k..k+2*NCD, so the wave keeps exactly that sliding
+// window in LDS.  NSTR is a template parameter, so the window geometry is compile time:
+//   * rows are stored without wrap-around in RW+MARGIN physical rows (re-based every MARGIN
+//     steps), so the rank-1 update addresses them with immediate offsets;
+//   * columns use a ring of CW positions (one add/compare per lane per step);
+//   * rows enter the window generated on the fly from the layer eigenvectors (prefetched
+//     one step ahead, unit-stride HBM reads), the pivot-row interchange is physical;
+//   * the multipliers stay in the registers of the pivot search, reach the other lanes by
+//     v_readlane, and are applied to the right-hand side at once (L is never stored);
+//   * each finished U row is streamed to HBM row-major (coalesced); back-substitution
+//     re-reads U in blocks of 16 columns through an LDS transpose stage and runs LINPACK's
+//     column-oriented sweep from there.
 // Pivot choice (first maximal |a|), multiplier scaling (-1/pivot) and the element-wise
 // update order are LINPACK's, so the factors agree with the reference up to FMA
 // contraction.
@@ -19,8 +25,11 @@
 
 namespace sbd {
 
+constexpr int kBandMargin = 8;    // extra physical rows before the window is re-based
+constexpr int kBackBlock = 16;    // columns per back-substitution block
+
 struct BandLds {   // per-wave carve-up (doubles)
-    int rw, cw, cwp, win, b, mult, misc, total;
+    int rw, cw, cwp, win, b, misc, total;
     __host__ __device__ BandLds(int n, int nn, int L, int nlev)
     {
         const int ncd = 3 * nn - 1;
@@ -28,13 +37,14 @@ struct BandLds {   // per-wave carve-up (doubles)
         cw = 2 * ncd + 1;
         cwp = cw | 1;
         win = 0;
-        int winsz = rw * cwp;
-        const int fluxsz = 2 * 16 * n + 64;   // E / U0C staging for 16 levels at a time
+        int winsz = (rw + kBandMargin) * cwp;
+        const int fluxsz = 2 * 16 * n + 64;                        // E / U0C staging, 16 levels at a time
+        const int stagesz = (2 * ncd + kBackBlock) * (kBackBlock + 1);   // back-substitution stage
         if (winsz < fluxsz) winsz = fluxsz;
+        if (winsz < stagesz) winsz = stagesz;
         b = win + winsz;
-        mult = b + n * L;
-        misc = mult + rw;            // pslot ints (rw) + a few scalars
-        total = misc + rw / 2 + 8 + 2 * n;
+        misc = b + n * L;
+        total = misc + 8 + n;
         total = (total + 1) & ~1;
         (void)nlev;
     }
@@ -51,6 +61,32 @@ SBD_DEVICE void wave_argmax(double &v, int &idx)
     }
 }
 
+// broadcast lane `src` (compile-time) of a double to the whole wave through SGPRs
+template <int SRC>
+SBD_DEVICE double bcast_lane(double x)
+{
+    const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(x), SRC);
+    const unsigned hi = __builtin_amdgcn_readlane((int)__double2hiint(x), SRC);
+    return __hiloint2double((int)hi, (int)lo);
+}
+
+template <int I, int CNT>
+struct RowUpdate {   // a(i) += tj * m(i) for CNT rows, m(i) = multiplier held by lane i
+    SBD_DEVICE static void load(const double *colp, int stride, double *a)
+    {
+        if constexpr (I <= CNT) { a[I - 1] = colp[I * stride]; RowUpdate<I + 1, CNT>::load(colp, stride, a); }
+    }
+    SBD_DEVICE static void fma(double tj, double mreg, double *a)
+    {
+        if constexpr (I <= CNT) { a[I - 1] = a[I - 1] + tj * bcast_lane<I>(mreg); RowUpdate<I + 1, CNT>::fma(tj, mreg, a); }
+    }
+    SBD_DEVICE static void store(double *colp, int stride, const double *a)
+    {
+        if constexpr (I <= CNT) { colp[I * stride] = a[I - 1]; RowUpdate<I + 1, CNT>::store(colp, stride, a); }
+    }
+};
+
+template <int NN>
 __global__ void __launch_bounds__(64) band_kernel(Params P)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -60,7 +96,8 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     const int mazim = (int)(ms % nmode);
     const int slot = (int)(ms / nmode);
     if (slot >= P.nslot) return;
-    const int L = P.L, n = P.n, nn = P.nn;
+    constexpr int n = 2 * NN, nn = NN;
+    const int L = P.L;
     int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
     const int st0 = svi[SBD_SVI_STATUS];
     const double fbeam = P.fbeam[slot];
@@ -85,11 +122,10 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     const double *cmu = P.t.cmu, *cwt = P.t.cwt;
 
     const BandLds lds(n, nn, L, nlev);
-    const int RW = lds.rw, CW = lds.cw, CWP = lds.cwp, ncd = RW - 1;
+    constexpr int ncd = 3 * NN - 1, RW = ncd + 1, CW = 2 * ncd + 1, CWP = CW | 1, MG = kBandMargin;
     double *win = smem + lds.win;
     double *b = smem + lds.b;
-    double *mult = smem + lds.mult;
-    double *sbot = smem + lds.misc + RW / 2 + 2;      // [n] surface-reflection sums (bottom BC)
+    double *sbot = smem + lds.misc + 4;               // [n] surface-reflection sums (bottom BC)
 
     const double *gc = P.gc + (size_t)ms * L * n * n;
     const double *kk = P.kk + (size_t)ms * L * n;
@@ -203,16 +239,15 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         }
     };
 
-    // logical row r lives in slot r % RW, column j at position j % CW; both are tracked
-    // with wrap-around counters (no integer division in the loop)
+    // logical row k+i lives in physical row kq+i (kq = k - kbase < MARGIN, re-based every
+    // MARGIN steps); column j sits at ring position j % CW, tracked by a wrap-around counter
     {
         const int nfirst = (N < RW) ? N : RW;
         for (int r = 1; r <= nfirst; ++r) {
-            const int s = r % RW;
             for (int c = lane; c < CW; c += 64) {      // window columns 1..CW at start
                 double g, f;
                 entry(r, c + 1, g, f);
-                win[s * CWP + ((c + 1) % CW)] = g * f;
+                win[(r - 1) * CWP + ((c + 1) % CW)] = g * f;
             }
         }
         wave_lds_sync();
@@ -221,8 +256,8 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     // ---- banded LU with partial pivoting + forward elimination of B ----
     int status = 0;
     int ju = 0;
-    int kr = 1 % RW, kc = 1 % CW;            // slot of row k, position of column k
-    const bool two = CW > 64;                // second pass of lanes over the window width
+    int kq = 0, kc = 1 % CW;                 // physical row of row k, ring position of column k
+    constexpr bool two = CW > 64;            // second pass of lanes over the window width
     for (int k = 1; k <= N - 1; ++k) {
         const int lm = (ncd < N - k) ? ncd : N - k;
         // (A) prefetch the row entering after this step (r = k+RW): lane c <-> column k+1+c
@@ -238,25 +273,21 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         double v = -1.0;
         int idx = 1 << 30;
         if (lane <= lm) {
-            int s = kr + lane;
-            if (s >= RW) s -= RW;
-            ak = win[s * CWP + kc];
+            ak = win[(kq + lane) * CWP + kc];
             v = fabs(ak);
             idx = lane;
         }
         wave_argmax(v, idx);
         if (v == 0.0) idx = 0;               // all-zero column: keep the diagonal, flag it
         const int l = k + idx;
-        int sl = kr + idx;
-        if (sl >= RW) sl -= RW;
-        const int sk = kr;
         const double piv = __shfl(ak, idx, 64);
-        const double akk = __shfl(ak, 0, 64);
+        const double akk = bcast_lane<0>(ak);
         {
             const int junew = ncd + l;
             ju = (ju > junew) ? ju : junew;
             if (ju > N) ju = N;
         }
+        double *rowk = win + kq * CWP;
         wave_lds_sync();
         // (C) row interchange (physical, whole window width; column k handled apart: the
         //     pivot goes to the diagonal, every sub-diagonal slot of column k is cleared
@@ -264,11 +295,12 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         // (D) multipliers (-a/pivot) straight from the registers of the pivot search,
         //     applied to B at once (SGBSL's forward sweep, disutil.f:1019-1036)
         if (idx != 0) {
+            double *rowl = rowk + idx * CWP;
             for (int c = lane; c < CW; c += 64) {
                 if (c != kc) {
-                    const double a = win[sk * CWP + c], bb = win[sl * CWP + c];
-                    win[sk * CWP + c] = bb;
-                    win[sl * CWP + c] = a;
+                    const double a = rowk[c], bb = rowl[c];
+                    rowk[c] = bb;
+                    rowl[c] = a;
                 }
             }
         }
@@ -276,114 +308,126 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         const double bk = (idx != 0) ? bl_old : bk_old;      // B(k) after the interchange
         if (piv == 0.0) status |= 0x01;
         const double tinv = (piv != 0.0) ? -1.0 / piv : 0.0;
+        double mreg = 0.0;                                   // lane t: multiplier of row k+t
         if (lane == 0) {
-            win[sk * CWP + kc] = piv;
+            rowk[kc] = piv;
             b[k - 1] = bk;
         }
         if (lane >= 1 && lane <= lm) {
-            int s = kr + lane;
-            if (s >= RW) s -= RW;
             const double aik = (lane == idx) ? akk : ak;     // element below the pivot after the swap
-            const double m = aik * tinv;
-            win[s * CWP + kc] = 0.0;
-            mult[lane] = m;
+            mreg = aik * tinv;
+            rowk[lane * CWP + kc] = 0.0;
             const double bi = (lane == idx) ? bk_old : b[k + lane - 1];
-            b[k + lane - 1] = bi + bk * m;
+            b[k + lane - 1] = bi + bk * mreg;
         }
         wave_lds_sync();
-        // (E) rank-1 update: lane <-> column, rows in register chunks of 8 (loads, FMAs,
-        //     stores) so that the LDS latency is paid per chunk, not per row
+        // (E) rank-1 update: lane <-> column; the rows of a column are loaded into registers
+        //     with immediate offsets, updated with the multipliers read from lanes 1..lm by
+        //     v_readlane, and stored back (one LDS latency per column, not per row)
         if (piv != 0.0) {
             const int ncols = ju - k;
-            for (int c = lane; c < ncols; c += 64) {
+            for (int c0 = 0; c0 < ncols; c0 += 64) {
+                const int c = c0 + lane;
                 int pc = kc + 1 + c;
                 if (pc >= CW) pc -= CW;
-                const double tj = win[sk * CWP + pc];
-                if (tj != 0.0) {                   // SAXPY's early return (disutil.f:1711)
-                    double *col = win + pc;
-                    int s0 = kr;
-                    for (int i0 = 1; i0 <= lm; i0 += 8) {
-                        double a[8];
-                        int so[8];
-                        int s = s0;
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            s = (s + 1 == RW) ? 0 : s + 1;
-                            so[u] = s * CWP;
-                            a[u] = (i0 + u <= lm) ? col[so[u]] : 0.0;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (i0 + u <= lm) a[u] = a[u] + tj * mult[i0 + u];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u)
-                            if (i0 + u <= lm) col[so[u]] = a[u];
-                        s0 = s;
+                const bool actv = c < ncols;
+                double tj = actv ? rowk[pc] : 0.0;
+                double *colp = rowk + pc;
+                if (lm == ncd) {                   // full window: compile-time row count
+                    double a[ncd];
+                    RowUpdate<1, ncd>::load(colp, CWP, a);   // inactive lanes read harmless LDS
+                    RowUpdate<1, ncd>::fma(tj, mreg, a);      // readlane needs every lane here
+                    if (actv && tj != 0.0) RowUpdate<1, ncd>::store(colp, CWP, a);
+                } else {                           // the last NCD steps: shrinking window
+                    for (int i = 1; i <= lm; ++i) {
+                        const double mi = __shfl(mreg, i, 64);
+                        if (actv && tj != 0.0) colp[i * CWP] = colp[i * CWP] + tj * mi;
                     }
                 }
             }
         }
-        // (F) retire row k: stream U(k, k..k+2ncd) to HBM in column-band order (zeros beyond
-        //     ju belong to U's band), then put the prefetched row into the freed slot
+        // (F) retire row k: stream U(k, k..k+2ncd) to HBM row-major (zeros beyond ju belong
+        //     to U's band), then put the prefetched row at the bottom of the window
         {
             const int wmax = (2 * ncd < N - k) ? 2 * ncd : N - k;
+            double *urow = ufac + (size_t)(k - 1) * CW;
             for (int c = lane; c <= wmax; c += 64) {
                 int pc = kc + c;
                 if (pc >= CW) pc -= CW;
-                const int j = k + c;
-                ufac[(size_t)(j - 1) * CW + (2 * ncd - c)] = win[sk * CWP + pc];
+                urow[c] = rowk[pc];
             }
         }
-        wave_lds_sync();
         if (rin <= N) {
+            double *rowin = rowk + RW * CWP;
             {
                 int pc = kc + 1 + lane;          // column k+1+lane
                 if (pc >= CW) pc -= CW;
-                if (lane < CW) win[sk * CWP + pc] = pg0 * pf0;
+                if (lane < CW) rowin[pc] = pg0 * pf0;
             }
             if (two && lane + 64 < CW) {
                 int pc = kc + 1 + lane + 64;
                 if (pc >= CW) pc -= CW;
-                win[sk * CWP + pc] = pg1 * pf1;
+                rowin[pc] = pg1 * pf1;
             }
         }
         wave_lds_sync();
-        kr = (kr + 1 == RW) ? 0 : kr + 1;
+        kq = kq + 1;
         kc = (kc + 1 == CW) ? 0 : kc + 1;
+        if (kq == MG) {                       // re-base: physical rows MG.. -> 0.. (lane <-> column)
+            for (int c = lane; c < CW; c += 64) {
+#pragma unroll
+                for (int i = 0; i < RW; ++i) win[i * CWP + c] = win[(MG + i) * CWP + c];
+            }
+            kq = 0;
+            wave_lds_sync();
+        }
     }
     {   // last row
-        const double d = win[kr * CWP + kc];
+        const double d = win[kq * CWP + kc];
         if (d == 0.0) status |= 0x01;
-        if (lane == 0) ufac[(size_t)(N - 1) * CW + 2 * ncd] = d;
+        if (lane == 0) ufac[(size_t)(N - 1) * CW] = d;
     }
     __threadfence_block();
     wave_lds_sync();
 
-    // ---- back-substitution, column oriented (SGBSL second loop, disutil.f:1038-1050) ----
+    // ---- back-substitution, column oriented (SGBSL second loop, disutil.f:1038-1050).
+    //      U is row-major in HBM (ufac[i][j-i]); blocks of 16 columns are transposed through
+    //      an LDS stage: stage[r][c] = U(i0+r, k0+c), rows i0 = k0-2ncd .. k1 ----
     {
-        const int M = CW;   // ml + mu + 1
-        double ucol = 0.0, ucol2 = 0.0, diag = 0.0;
-        // column k: entries U(k-lm..k-1, k) live at ufac[k][2ncd-lm .. 2ncd-1]; lane c <-> row k-1-c
-        auto load_col = [&](int k, double &u0, double &u1, double &dg) {
-            const int lmk = ((k < M) ? k : M) - 1;
-            const double *col = ufac + (size_t)(k - 1) * CW;
-            u0 = (lane < lmk) ? col[2 * ncd - 1 - lane] : 0.0;
-            u1 = (lane + 64 < lmk) ? col[2 * ncd - 1 - (lane + 64)] : 0.0;
-            dg = col[2 * ncd];
-        };
-        load_col(N, ucol, ucol2, diag);
-        for (int k = N; k >= 1; --k) {
-            double nu0 = 0.0, nu1 = 0.0, nd = 0.0;
-            if (k > 1) load_col(k - 1, nu0, nu1, nd);   // prefetch the next column
-            const int lmk = ((k < M) ? k : M) - 1;
-            const double xk = b[k - 1] / diag;
+        constexpr int BC = kBackBlock, SP = BC + 1, NR = 2 * ncd + BC;
+        double *stage = win;
+        for (int k1 = N; k1 >= 1; k1 -= BC) {
+            const int k0 = (k1 - BC + 1 > 1) ? k1 - BC + 1 : 1;
+            const int i0 = k0 - 2 * ncd;                   // may be <= 0: rows < 1 hold zeros
             wave_lds_sync();
-            if (lane == 0) b[k - 1] = xk;
-            const double t = -xk;
-            if (lane < lmk) b[k - 2 - lane] = b[k - 2 - lane] + t * ucol;
-            if (lane + 64 < lmk) b[k - 2 - (lane + 64)] = b[k - 2 - (lane + 64)] + t * ucol2;
+            {
+                const int rr = lane >> 4, c = lane & 15;
+                const int j = k0 + c;
+#pragma unroll 4
+                for (int r0 = 0; r0 < NR; r0 += 4) {
+                    const int r = r0 + rr;
+                    const int i = i0 + r;
+                    double val = 0.0;
+                    if (r < NR && i >= 1 && i <= k1 && j <= k1 && j >= i && j - i <= 2 * ncd)
+                        val = ufac[(size_t)(i - 1) * CW + (j - i)];
+                    if (r < NR) stage[r * SP + c] = val;
+                }
+            }
             wave_lds_sync();
-            ucol = nu0; ucol2 = nu1; diag = nd;
+            for (int k = k1; k >= k0; --k) {
+                const int c = k - k0;
+                const int lmk = ((k < CW) ? k : CW) - 1;
+                const double diag = stage[(k - i0) * SP + c];
+                const double xk = b[k - 1] / diag;
+                wave_lds_sync();
+                if (lane == 0) b[k - 1] = xk;
+                const double t = -xk;
+                // row i = k-1-lane  ->  stage row (i - i0)
+                if (lane < lmk) b[k - 2 - lane] = b[k - 2 - lane] + t * stage[(k - 1 - lane - i0) * SP + c];
+                if (two && lane + 64 < lmk)
+                    b[k - 2 - (lane + 64)] = b[k - 2 - (lane + 64)] + t * stage[(k - 1 - (lane + 64) - i0) * SP + c];
+                wave_lds_sync();
+            }
         }
     }
     // LL(j, lc) = B((lc-1)*n + j) (disort.f:3624-3633)

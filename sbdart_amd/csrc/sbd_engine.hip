@@ -23,6 +23,7 @@
 namespace sbd { constexpr int SBD_NFLUX_ = SBD_NFLUX; }
 #include "sbd_setup.hpp"
 #include "sbd_layer.hpp"
+#include "sbd_layer2.hpp"
 #include "sbd_band.hpp"
 #include "sbd_usrint.hpp"
 
@@ -141,6 +142,12 @@ __global__ void accum_final_kernel(int nseg, int nel, const double *partial, dou
 
 }  // namespace
 
+
+// (NN, G, RAD) dispatch of the fast layer kernel
+#define SBD_L2_CASES(M)                                                                        \
+    M(2, 4) M(3, 8) M(4, 8) M(5, 16) M(6, 16) M(7, 16) M(8, 16) M(9, 32) M(10, 32) M(11, 32)   \
+    M(12, 32) M(13, 32) M(14, 32) M(15, 32) M(16, 32) M(17, 64) M(18, 64) M(19, 64) M(20, 64)
+
 struct sbd_engine {
     sbd_run_cfg cfg{};
     int n = 0, nn = 0, L = 0, nmode = 1, naz_run = 0, nlev = 0, G = 0;
@@ -165,7 +172,9 @@ struct sbd_engine {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float ms_phase[4] = {0, 0, 0, 0};
     bool have_times = false;
-    int layer_lds = 0, band_lds = 0, usr_lds = 0;
+    int layer_lds = 0, band_lds = 0, usr_lds = 0, layer2_lds = 0;
+    int32_t *d_eigflag = nullptr;
+    bool use_layer2 = true;
 };
 
 extern "C" {
@@ -349,13 +358,15 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     while (chunk > 1 && (size_t)chunk * per_slot > budget) chunk /= 2;
     if (chunk < 1) chunk = 1;
     e->chunk = chunk;
-    e->ws_bytes = (size_t)chunk * per_slot + 4096;
+    const size_t flag_bytes = sizeof(int32_t) * (size_t)chunk * nmode * L;
+    e->ws_bytes = (size_t)chunk * per_slot + flag_bytes + 8192;
     CREATE_TRY(hipMalloc(&e->d_ws, e->ws_bytes));
     {
         char *p = e->d_ws;
         auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~(size_t)255; return r; };
         sbd::Params &P = e->P;
         const size_t nms = (size_t)chunk * nmode;
+        e->d_eigflag = (int32_t *)take(flag_bytes);
         P.sv = (double *)take(sizeof(double) * (size_t)chunk * sv_stride);
         P.svi = (int32_t *)take(sizeof(int32_t) * (size_t)chunk * svi_stride);
         P.gc = (double *)take(sizeof(double) * nms * L * n * n);
@@ -387,6 +398,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         P.pi = ref_pi();
         P.dither = 100.0 * 2.220446049250313e-16;   // disort.f:442-448
         P.t = e->tab;
+        P.force_fallback = 0;
+        if (const char *s = getenv("SBD_FORCE_EIG_FALLBACK")) P.force_fallback = atoi(s) != 0;
     }
     // the carve above rounds every array up to 256 B: re-check against the allocation
     // (ws_bytes has 4 KB slack per array count << 16)
@@ -414,7 +427,30 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     case 32: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<32>, e->layer_lds)); break;
     default: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<64>, e->layer_lds)); break;
     }
-    CREATE_TRY(set_lds((const void *)sbd::band_kernel, e->band_lds));
+#define SBD_BAND_CASE(NNv) case NNv: CREATE_TRY(set_lds((const void *)sbd::band_kernel<NNv>, e->band_lds)); break;
+    switch (nn) {
+        SBD_BAND_CASE(2) SBD_BAND_CASE(3) SBD_BAND_CASE(4) SBD_BAND_CASE(5) SBD_BAND_CASE(6) SBD_BAND_CASE(7)
+        SBD_BAND_CASE(8) SBD_BAND_CASE(9) SBD_BAND_CASE(10) SBD_BAND_CASE(11) SBD_BAND_CASE(12) SBD_BAND_CASE(13)
+        SBD_BAND_CASE(14) SBD_BAND_CASE(15) SBD_BAND_CASE(16) SBD_BAND_CASE(17) SBD_BAND_CASE(18) SBD_BAND_CASE(19)
+        SBD_BAND_CASE(20)
+    default: break;
+    }
+#undef SBD_BAND_CASE
+    {
+        const sbd::Layer2Lds l2(n, nn);
+        e->layer2_lds = (int)sizeof(double) * (l2.shared_total + l2.group_total * (64 / G));
+        if (const char *s = getenv("SBD_LAYER_V1")) e->use_layer2 = atoi(s) == 0;
+        if (e->layer2_lds > 160 * 1024) e->use_layer2 = false;
+        // flags are raised by layer_kernel2 and lowered again by the QR kernel that serves them
+        CREATE_TRY(hipMemset(e->d_eigflag, 0, sizeof(int32_t) * (size_t)chunk * nmode * L));
+#define SBD_L2_ATTR(NNv, Gv)                                                                                    \
+        if (nn == NNv) {                                                                                        \
+            if (rad) CREATE_TRY(set_lds((const void *)sbd::layer_kernel2<NNv, Gv, true>, e->layer2_lds));        \
+            else CREATE_TRY(set_lds((const void *)sbd::layer_kernel2<NNv, Gv, false>, e->layer2_lds));          \
+        }
+        SBD_L2_CASES(SBD_L2_ATTR)
+#undef SBD_L2_ATTR
+    }
     for (auto &x : e->ev) CREATE_TRY(hipEventCreate(&x));
 #undef CREATE_TRY
 
@@ -465,6 +501,10 @@ long long sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t
     case 6: src = e->P.ll; bytes = 8 * nms * L * n; break;
     case 7: src = e->P.sv; bytes = 8 * (size_t)e->chunk * e->P.sv_stride; break;
     case 8: src = e->P.svi; bytes = 4 * (size_t)e->chunk * e->P.svi_stride; break;
+    case 9: src = e->P.gu; bytes = 8 * nms * L * n * e->P.numu; break;
+    case 10: src = e->P.zb; bytes = 8 * nms * L * e->P.numu; break;
+    case 11: src = e->P.z0u; bytes = 8 * nms * L * e->P.numu; break;
+    case 12: src = e->P.z1u; bytes = 8 * nms * L * e->P.numu; break;
     default: return SBD_E_INVALID;
     }
     if (bytes > nbytes) bytes = nbytes;
@@ -488,6 +528,8 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
     const int L = e->L, n = e->n, nmode = e->nmode, nlev = e->nlev;
     const bool timing = e->timing;
+    const bool dbg = getenv("SBD_DEBUG_SYNC") != nullptr;
+#define SBD_DBG(tag) do { if (dbg) { hipError_t de_ = hipStreamSynchronize(st); fprintf(stderr, "[sbd] %s: %s (eigflag=%p partial=%p ws=%p..%p)\n", tag, hipGetErrorString(de_), (void*)e->d_eigflag, (void*)e->d_partial, (void*)e->d_ws, (void*)(e->d_ws + e->ws_bytes)); } } while (0)
     float acc_ms[4] = {0, 0, 0, 0};
     for (int w0 = 0; w0 < in->nwork; w0 += e->chunk) {
         const int ns = (in->nwork - w0 < e->chunk) ? in->nwork - w0 : e->chunk;
@@ -504,21 +546,49 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
 
         if (timing) HIP_TRY(hipEventRecord(e->ev[0], st));
         hipLaunchKernelGGL(sbd::setup_kernel, dim3(ns), dim3(64), 0, st, P);
+        SBD_DBG("setup");
         if (timing) HIP_TRY(hipEventRecord(e->ev[1], st));
         {
             const int gpb = 64 / e->G;
             const long long groups = (long long)ns * nmode * L;
             const unsigned grid = (unsigned)((groups + gpb - 1) / gpb);
+            int32_t *flt = nullptr;
+            if (e->use_layer2) {
+                const unsigned g2 = (unsigned)((size_t)ns * nmode * ((L + gpb - 1) / gpb));
+                int32_t *flag = e->d_eigflag;
+#define SBD_L2_LAUNCH(NNv, Gv)                                                                                        \
+                if (e->nn == NNv) {                                                                                   \
+                    if (rad) hipLaunchKernelGGL((sbd::layer_kernel2<NNv, Gv, true>), dim3(g2), dim3(64), e->layer2_lds, st, P, flag);   \
+                    else hipLaunchKernelGGL((sbd::layer_kernel2<NNv, Gv, false>), dim3(g2), dim3(64), e->layer2_lds, st, P, flag);      \
+                }
+                SBD_L2_CASES(SBD_L2_LAUNCH)
+#undef SBD_L2_LAUNCH
+                flt = e->d_eigflag;     // the QR kernel below only redoes flagged layers
+                SBD_DBG("layer2");
+            }
             switch (e->G) {
-            case 4: hipLaunchKernelGGL(sbd::layer_kernel<4>, dim3(grid), dim3(64), e->layer_lds, st, P); break;
-            case 8: hipLaunchKernelGGL(sbd::layer_kernel<8>, dim3(grid), dim3(64), e->layer_lds, st, P); break;
-            case 16: hipLaunchKernelGGL(sbd::layer_kernel<16>, dim3(grid), dim3(64), e->layer_lds, st, P); break;
-            case 32: hipLaunchKernelGGL(sbd::layer_kernel<32>, dim3(grid), dim3(64), e->layer_lds, st, P); break;
-            default: hipLaunchKernelGGL(sbd::layer_kernel<64>, dim3(grid), dim3(64), e->layer_lds, st, P); break;
+            case 4: hipLaunchKernelGGL(sbd::layer_kernel<4>, dim3(grid), dim3(64), e->layer_lds, st, P, flt); break;
+            case 8: hipLaunchKernelGGL(sbd::layer_kernel<8>, dim3(grid), dim3(64), e->layer_lds, st, P, flt); break;
+            case 16: hipLaunchKernelGGL(sbd::layer_kernel<16>, dim3(grid), dim3(64), e->layer_lds, st, P, flt); break;
+            case 32: hipLaunchKernelGGL(sbd::layer_kernel<32>, dim3(grid), dim3(64), e->layer_lds, st, P, flt); break;
+            default: hipLaunchKernelGGL(sbd::layer_kernel<64>, dim3(grid), dim3(64), e->layer_lds, st, P, flt); break;
             }
         }
+        SBD_DBG("layer(v1/fallback)");
         if (timing) HIP_TRY(hipEventRecord(e->ev[2], st));
-        hipLaunchKernelGGL(sbd::band_kernel, dim3((unsigned)((size_t)ns * nmode)), dim3(64), e->band_lds, st, P);
+        {
+            const dim3 bgrid((unsigned)((size_t)ns * nmode));
+#define SBD_BAND_CASE(NNv) case NNv: hipLaunchKernelGGL(sbd::band_kernel<NNv>, bgrid, dim3(64), e->band_lds, st, P); break;
+            switch (e->nn) {
+                SBD_BAND_CASE(2) SBD_BAND_CASE(3) SBD_BAND_CASE(4) SBD_BAND_CASE(5) SBD_BAND_CASE(6) SBD_BAND_CASE(7)
+                SBD_BAND_CASE(8) SBD_BAND_CASE(9) SBD_BAND_CASE(10) SBD_BAND_CASE(11) SBD_BAND_CASE(12) SBD_BAND_CASE(13)
+                SBD_BAND_CASE(14) SBD_BAND_CASE(15) SBD_BAND_CASE(16) SBD_BAND_CASE(17) SBD_BAND_CASE(18) SBD_BAND_CASE(19)
+                SBD_BAND_CASE(20)
+            default: break;
+            }
+#undef SBD_BAND_CASE
+        }
+        SBD_DBG("band");
         if (timing) HIP_TRY(hipEventRecord(e->ev[3], st));
         if (rad) {
             hipLaunchKernelGGL(sbd::usrint_kernel, dim3((unsigned)((size_t)ns * nmode)), dim3(64), e->usr_lds, st, P);

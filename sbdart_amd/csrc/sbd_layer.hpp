@@ -104,7 +104,7 @@ SBD_DEVICE double lu_solve_group(const double *a, int ld, int n, const int *ipvt
 }
 
 template <int G>
-__global__ void __launch_bounds__(64) layer_kernel(Params P)
+__global__ void __launch_bounds__(64) layer_kernel(Params P, int32_t *only_flagged)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int GPB = 64 / G;
@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(64) layer_kernel(Params P)
     const long long ms = gid / L;
     const int mazim = (int)(ms % nmode);
     const int slot = (int)(ms / nmode);
+    if (only_flagged && !only_flagged[(size_t)ms * L + (lc - 1)]) return;   // fallback pass of sbd_layer2.hpp
 
     const int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
     const int st0 = svi[SBD_SVI_STATUS];
@@ -370,6 +371,7 @@ __global__ void __launch_bounds__(64) layer_kernel(Params P)
 #undef YLMU
     }
     if (status && g == 0) atomicOr(&P.svi[(size_t)slot * P.svi_stride + SBD_SVI_STATUS], status);
+    if (only_flagged && g == 0) only_flagged[(size_t)ms * L + (lc - 1)] = 0;   // served
 #undef YLMC
 #undef CC
 #undef EVC

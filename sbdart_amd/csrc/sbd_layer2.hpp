@@ -1,0 +1,427 @@
+// Layer kernel, fast path.  Same role as sbd_layer.hpp (SOLEIG/UPBEAM/UPISOT/TERPEV/TERPSO
+// per (work item, azimuth mode, layer), disort.f:638-693) but the reduced eigenproblem is
+// solved the MI355X way instead of with a sequential QR iteration:
+//
+//   ARRAY = APB*AMB (disort.f:3236-3249) with AMB = M^-1 (S- W - I), APB = M^-1 (S+ W - I),
+//   S+ / S- = the even / odd (l-m) parts of sum_l GL_l Y_l(mu_i) Y_l(mu_j)  (both symmetric).
+//   With R = (W/M)^1/2 and Q+- = R (W^-1 - S+-) R (symmetric positive definite for physical
+//   phase functions), ARRAY is similar to Q- Q+.  Cholesky Q+ = L L^T, Q- = C C^T gives
+//   Q- Q+ ~ B^T B with B = C^T L, so the eigenvalues k^2 are the squared singular values of B
+//   and the eigenvectors of ARRAY are x = (M R)^-1 L v for the right singular vectors v.
+//   B's SVD is computed by ONE-SIDED JACOBI: lane j keeps column j of B and of X in registers,
+//   column pairs meet by wave shuffles in a round-robin tournament, every rotation is local
+//   to the two lanes -- no LDS traffic, no barriers, NSTR/2 lanes busy per matrix.
+//
+// When a Cholesky pivot is not positive (non-physical moments) the group raises a flag and
+// the QR kernel of sbd_layer.hpp redoes that layer (same outputs, reference algorithm).
+// UPBEAM/UPISOT keep the reference's pivoted LU of the full NSTR x NSTR system in LDS.
+#pragma once
+#include "sbd_common.hpp"
+#include "sbd_layer.hpp"
+
+namespace sbd {
+
+struct Layer2Lds {   // doubles; per-group part + per-block shared part
+    int ld, ldh, gl, sp, sm, lu, vec, group_total, shared_y, shared_total;
+    __host__ __device__ Layer2Lds(int n, int nn)
+    {
+        ld = n | 1;
+        ldh = nn | 1;
+        gl = 0;
+        sp = gl + ((n + 2) & ~1);
+        sm = sp + nn * ldh;
+        lu = sm + nn * ldh;
+        const int a = n * ld, b2 = 2 * nn * ldh;
+        vec = lu + (a > b2 ? a : b2);
+        group_total = (vec + 5 * n + (n + 1) / 2 + 2 + 1) & ~1;   // zjs,z0s,z1s,psi[2n], ipvt[n] ints
+        shared_y = 0;                       // Y(l, iq) l-major: [n][nn]
+        shared_total = (n * nn + 2 * n + 1) & ~1;
+    }
+};
+
+template <int NN, int G, bool RAD>
+__global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int n = 2 * NN, nn = NN, GPB = 64 / G;
+    const int lane = threadIdx.x;
+    const int g = lane % G, gi = lane / G;
+    const int L = P.L, nmode = P.nmode, numu = P.numu;
+    const int bpm = (L + GPB - 1) / GPB;                 // blocks per (item, mode)
+    const long long ms = blockIdx.x / bpm;
+    const int lc = (int)(blockIdx.x % bpm) * GPB + gi + 1;
+    const int mazim = (int)(ms % nmode);
+    const int slot = (int)(ms / nmode);
+    if (slot >= P.nslot) return;
+
+    const Layer2Lds lds(n, nn);
+    double *shy = smem;                                  // shared: Y(l, iq), cmu, cwt
+    double *scmu = smem + n * nn, *scwt = scmu + n;
+    const double *ylmc = P.t.ylmc + (size_t)mazim * n * (n + 1);
+    for (int e = lane; e < n * nn; e += 64) {
+        const int l = e / nn, iq = e % nn;
+        shy[e] = ylmc[iq * (n + 1) + l];
+    }
+    if (lane < n) { scmu[lane] = P.t.cmu[lane]; scwt[lane] = P.t.cwt[lane]; }
+    __syncthreads();
+    if (lc > L) return;
+
+    const int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
+    const int st0 = svi[SBD_SVI_STATUS];
+    if (st0 & (0x20 | 0x10)) return;
+    if (lc > svi[SBD_SVI_NCUT]) return;
+    const double fbeam = P.fbeam[slot];
+    if (mazim > 0 && fbeam == 0.0) return;
+    const bool plank = P.plank[slot] != 0;
+    constexpr bool rad = RAD;
+    const SV o(L);
+    const double *sv = P.sv + (size_t)slot * P.sv_stride;
+
+    double *base = smem + lds.shared_total + (size_t)gi * lds.group_total;
+    double *gl = base + lds.gl;
+    double *sp = base + lds.sp, *sm = base + lds.sm;      // S+ , S-   (nn x nn, ld = ldh)
+    double *lu = base + lds.lu;
+    double *qp = lu, *qm = lu + nn * lds.ldh;             // Q+ -> L , Q- -> C (alias of lu)
+    double *vec = base + lds.vec;
+    double *zjs = vec, *z0s = vec + n, *z1s = vec + 2 * n, *psi = vec + 3 * n;   // psi[2n]
+    int *ipvt = (int *)(vec + 5 * n);
+    constexpr int ldh = NN | 1, ld = n | 1;
+    const int me = g + 1;
+    const size_t lidx = (size_t)ms * L + (lc - 1);
+#define YS(l, iq) shy[(l) * nn + ((iq) - 1)]             // iq in 1..nn ; Y(l,-mu) = (-1)^(l-m) Y(l,mu)
+#define SP(i, j) sp[((j) - 1) * ldh + ((i) - 1)]
+#define SM(i, j) sm[((j) - 1) * ldh + ((i) - 1)]
+#define QP(i, j) qp[((j) - 1) * ldh + ((i) - 1)]
+#define QM(i, j) qm[((j) - 1) * ldh + ((i) - 1)]
+#define LU(i, j) lu[((j) - 1) * ld + ((i) - 1)]
+
+    // ---- GL(k) (SETDIS, disort.f:2583-2585) ----
+    const double oprim = sv[o.oprim() + lc - 1];
+    const double f = sv[o.flyr() + lc - 1];
+    {
+        const double *pm = P.pmom + ((size_t)slot * L + (lc - 1)) * (P.nmom + 1);
+        if (g < n) {
+            const int k = g;
+            const double pk = (k == 0) ? 1.0 : ((k <= P.nmom) ? pm[k] : 0.0);
+            gl[k] = (double)(2 * k + 1) * oprim * (pk - f) / (1.0 - f);
+        }
+    }
+    wave_lds_sync();
+
+    // ---- S+ / S- (even / odd l-m parts), lane j <-> column j; then Q+-, all symmetric ----
+    if (me <= nn) {
+        double yj[n];
+#pragma unroll
+        for (int l = 0; l < n; ++l) yj[l] = YS(l, me);
+        const double rj = sqrt(scwt[me - 1] / scmu[me - 1]);
+        for (int iq = 1; iq <= nn; ++iq) {
+            double se = 0.0, so = 0.0;
+#pragma unroll
+            for (int l = 0; l < n; ++l) {
+                if (l >= mazim) {
+                    const double t = gl[l] * YS(l, iq) * yj[l];
+                    if (((l - mazim) & 1) == 0) se = se + t; else so = so + t;
+                }
+            }
+            SP(iq, me) = se;
+            SM(iq, me) = so;
+            const double ri = sqrt(scwt[iq - 1] / scmu[iq - 1]);
+            const double dg = (iq == me) ? 1.0 / scwt[me - 1] : 0.0;
+            QP(iq, me) = ri * rj * (dg - se);
+            QM(iq, me) = ri * rj * (dg - so);
+        }
+    }
+    wave_lds_sync();
+
+    // ---- two Cholesky factorisations side by side (lane i <-> row i), lower factors ----
+    bool spd = true;
+    for (int k = 1; k <= nn; ++k) {
+        const double dp = QP(k, k), dm = QM(k, k);
+        if (!(dp > 0.0) || !(dm > 0.0)) { spd = false; break; }
+        const double sdp = sqrt(dp), sdm = sqrt(dm);
+        wave_lds_sync();
+        if (me == k) { QP(k, k) = sdp; QM(k, k) = sdm; }
+        if (me > k && me <= nn) { QP(me, k) = QP(me, k) / sdp; QM(me, k) = QM(me, k) / sdm; }
+        wave_lds_sync();
+        if (me > k && me <= nn) {
+            const double lp = QP(me, k), lm_ = QM(me, k);
+            for (int j = k + 1; j <= me; ++j) {
+                QP(me, j) = QP(me, j) - lp * QP(j, k);
+                QM(me, j) = QM(me, j) - lm_ * QM(j, k);
+            }
+        }
+        wave_lds_sync();
+    }
+    if (!spd || P.force_fallback) {   // group-uniform: hand this layer to the QR kernel
+        if (g == 0) eigflag[lidx] = 1;
+        return;
+    }
+
+    // ---- B = C^T L and X0 = (M R)^-1 L : lane j <-> column j, in registers ----
+    double bcol[nn], xcol[nn];
+    if (me <= nn) {
+#pragma unroll
+        for (int i = 1; i <= nn; ++i) {
+            double s = 0.0;
+            // (C^T L)(i,j) = sum_{k >= max(i,j)} C(k,i) L(k,j)
+            for (int k = (i > me ? i : me); k <= nn; ++k) s = s + QM(k, i) * QP(k, me);
+            bcol[i - 1] = s;
+            const double ri = sqrt(scwt[i - 1] / scmu[i - 1]);
+            xcol[i - 1] = (i >= me) ? QP(i, me) / (scmu[i - 1] * ri) : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < nn; ++i) { bcol[i] = 0.0; xcol[i] = 0.0; }
+    }
+
+    // ---- one-sided Jacobi, round-robin pairing over the nn columns (nn even or odd) ----
+    {
+        constexpr int NP = (nn + 1) & ~1;               // players (a dummy when nn is odd)
+        const int j = g;                                 // player index 0..NP-1 (lanes >= NP idle)
+        const double tol = 2.220446049250313e-16;
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            bool rotated = false;
+            for (int s = 0; s < NP - 1; ++s) {
+                // circle method: player 0 fixed, the others rotate
+                int pos = (j == 0) ? 0 : 1 + (j - 1 - s + 2 * (NP - 1)) % (NP - 1);
+                const int ppos = NP - 1 - pos;
+                const int partner = (ppos == 0) ? 0 : 1 + (ppos - 1 + s) % (NP - 1);
+                const bool valid = (j < nn) && (partner < nn) && (j < NP);
+                const int src = (j < NP) ? partner : j;
+                double ob[nn], ox[nn];
+#pragma unroll
+                for (int i = 0; i < nn; ++i) {
+                    ob[i] = __shfl(bcol[i], src, G);
+                    ox[i] = __shfl(xcol[i], src, G);
+                }
+                if (valid) {
+                    double aa = 0.0, bb = 0.0, gg = 0.0;
+#pragma unroll
+                    for (int i = 0; i < nn; ++i) {
+                        aa = aa + bcol[i] * bcol[i];
+                        bb = bb + ob[i] * ob[i];
+                        gg = gg + bcol[i] * ob[i];
+                    }
+                    if (fabs(gg) > tol * sqrt(aa * bb)) {
+                        rotated = true;
+                        const bool lo = j < partner;
+                        // rotation defined for the ordered pair (p<q): alpha=|b_p|^2, beta=|b_q|^2
+                        const double alpha = lo ? aa : bb, beta = lo ? bb : aa;
+                        const double zeta = (beta - alpha) / (2.0 * gg);
+                        const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                        // p' = c p - s q ; q' = s p + c q
+                        const double mine = c, other = lo ? -sn : sn;
+#pragma unroll
+                        for (int i = 0; i < nn; ++i) {
+                            bcol[i] = mine * bcol[i] + other * ob[i];
+                            xcol[i] = mine * xcol[i] + other * ox[i];
+                        }
+                    }
+                }
+            }
+            if (!__any(rotated)) break;
+        }
+    }
+
+    // ---- eigenvalues, (G+)+(G-) = AMB x / k (disort.f:3264-3286), outputs ----
+    double kq = 0.0;
+    double gp[nn];
+    if (me <= nn) {
+        double lam = 0.0;
+#pragma unroll
+        for (int i = 0; i < nn; ++i) lam = lam + bcol[i] * bcol[i];
+        kq = sqrt(fabs(lam));
+#pragma unroll
+        for (int i = 1; i <= nn; ++i) {
+            // AMB(i,k) = (S-(i,k) w_k - delta_ik) / mu_i
+            double s = 0.0;
+#pragma unroll
+            for (int k = 1; k <= nn; ++k) s = s + (SM(i, k) * scwt[k - 1] - ((i == k) ? 1.0 : 0.0)) * xcol[k - 1];
+            gp[i - 1] = s / (scmu[i - 1] * kq);
+        }
+        double *kkout = P.kk + lidx * n;
+        double *ekout = P.ek + lidx * nn;
+        kkout[me + nn - 1] = kq;
+        kkout[nn + 1 - me - 1] = -kq;
+        ekout[nn + 1 - me - 1] = exp(-kq * sv[o.dtaucp() + lc - 1]);
+    }
+    wave_lds_sync();      // Q+/Q- (alias of lu) are dead from here on
+    // GC staged through LDS (lu) so that HBM sees whole rows: GC(i,j) -> lu[(i-1)*ld + j-1]
+    if (me <= nn) {
+#pragma unroll
+        for (int iq = 1; iq <= nn; ++iq) {
+            const double gpp = gp[iq - 1], gmm = xcol[iq - 1];
+            lu[(iq + nn - 1) * ld + (me + nn - 1)] = 0.5 * (gpp + gmm);
+            lu[(nn + 1 - iq - 1) * ld + (me + nn - 1)] = 0.5 * (gpp - gmm);
+            lu[(iq + nn - 1) * ld + (nn + 1 - me - 1)] = 0.5 * (-gpp + gmm);
+            lu[(nn + 1 - iq - 1) * ld + (nn + 1 - me - 1)] = 0.5 * (-gpp - gmm);
+        }
+    }
+    wave_lds_sync();
+    {
+        double *gcout = P.gc + lidx * n * n;
+        for (int e = g; e < n * n; e += G) gcout[e] = lu[(e / n) * ld + (e % n)];
+    }
+    wave_lds_sync();
+
+    // ---- radiance mode: TERPEV from the register-resident eigenvector columns ----
+    if constexpr (rad) {
+        const double *ylmu = P.t.ylmu + (size_t)mazim * numu * (n + 1);
+        double *guout = P.gu + lidx * n * numu;
+        if (me <= nn) {
+            // EVECC column me (k>0) and me+nn (k<0): rows iq<=nn / iq>nn
+            double wkp[n], wkn[n];
+#pragma unroll
+            for (int l = 0; l < n; ++l) {
+                double sp_ = 0.0, sn_ = 0.0;
+                if (l >= mazim) {
+                    const double sgn = (((l - mazim) & 1) == 0) ? 1.0 : -1.0;   // Y(l,-mu) = sgn * Y(l,mu)
+                    for (int jq = 1; jq <= nn; ++jq) {
+                        const double y = YS(l, jq) * scwt[jq - 1];
+                        const double e11 = 0.5 * (gp[jq - 1] + xcol[jq - 1]), e21 = 0.5 * (gp[jq - 1] - xcol[jq - 1]);
+                        sp_ = sp_ + y * e11 + sgn * y * e21;          // column me
+                        sn_ = sn_ + y * (-e21) + sgn * y * (-e11);    // column me+nn
+                    }
+                    sp_ = 0.5 * gl[l] * sp_;
+                    sn_ = 0.5 * gl[l] * sn_;
+                }
+                wkp[l] = sp_;
+                wkn[l] = sn_;
+            }
+            for (int iu = 1; iu <= numu; ++iu) {
+                double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int l = 0; l < n; ++l) {
+                    if (l >= mazim) {
+                        const double yu = ylmu[(iu - 1) * (n + 1) + l];
+                        s1 = s1 + wkp[l] * yu;
+                        s2 = s2 + wkn[l] * yu;
+                    }
+                }
+                guout[(me + nn - 1) * numu + (iu - 1)] = s1;        // IQ = me      -> GU(iu, me+nn)
+                guout[(nn + 1 - me - 1) * numu + (iu - 1)] = s2;    // IQ = me+nn   -> GU(iu, n+1-(me+nn))
+            }
+        }
+    }
+
+    // ---- UPBEAM / UPISOT: the reference's pivoted LU of (D - CC) in LDS ----
+    const double *ylm0 = P.t.ylm0 + (size_t)mazim * (n + 1);
+    auto cc_elem = [&](int iq, int jq) -> double {   // CC(iq,jq), disort.f:3197-3216
+        const int i = (iq <= nn) ? iq : iq - nn, j = (jq <= nn) ? jq : jq - nn;
+        const bool same = (iq <= nn) == (jq <= nn);
+        const double se = SP(i, j), so = SM(i, j);
+        return 0.5 * (same ? se + so : se - so) * scwt[j - 1];
+    };
+    auto ylmc_full = [&](int l, int iq) -> double {   // YLMC(l, iq) including the mirrored half
+        if (iq <= nn) return YS(l, iq);
+        return ((((l - mazim) & 1) == 0) ? 1.0 : -1.0) * YS(l, iq - nn);
+    };
+    int status = 0;
+    double zj = 0.0;
+    if (fbeam > 0.0) {
+        const double delm0 = (mazim == 0) ? 1.0 : 0.0;
+        if (me <= n) {
+            for (int iq = 1; iq <= n; ++iq) LU(iq, me) = -cc_elem(iq, me);
+            const double cm = scmu[me - 1];     // signed: -mu for the downward half
+            LU(me, me) = 1.0 + cm / P.umu0 + LU(me, me);
+            double sum = 0.0;
+            for (int k = mazim; k <= n - 1; ++k) sum = sum + gl[k] * ylmc_full(k, me) * ylm0[k];
+            zj = (2.0 - delm0) * fbeam * sum / (4.0 * P.pi);
+        }
+        wave_lds_sync();
+        if (lu_factor_group(lu, ld, n, ipvt, g) != 0) status |= 0x02;
+        zj = lu_solve_group<G>(lu, ld, n, ipvt, zj, g);
+        double *zzout = P.zz + lidx * n;
+        if (me <= nn) zzout[me + nn - 1] = zj;
+        else if (me <= n) zzout[nn + 1 - (me - nn) - 1] = zj;
+        if (rad && me <= n) zjs[me - 1] = zj;
+        wave_lds_sync();
+    } else if (me <= n) {
+        P.zz[lidx * n + me - 1] = 0.0;
+    }
+    double z0 = 0.0, z1 = 0.0;
+    const bool thermal = plank && mazim == 0;
+    if (thermal) {
+        const double xr0 = sv[o.xr0() + lc - 1], xr1 = sv[o.xr1() + lc - 1];
+        if (me <= n) {
+            for (int iq = 1; iq <= n; ++iq) LU(iq, me) = -cc_elem(iq, me);
+            LU(me, me) = 1.0 + LU(me, me);
+            z1 = (1.0 - oprim) * xr1;
+        }
+        wave_lds_sync();
+        if (lu_factor_group(lu, ld, n, ipvt, g) != 0) status |= 0x04;
+        z1 = lu_solve_group<G>(lu, ld, n, ipvt, z1, g);
+        if (me <= n) z0 = (1.0 - oprim) * xr0 + scmu[me - 1] * z1;
+        z0 = lu_solve_group<G>(lu, ld, n, ipvt, z0, g);
+        double *p0 = P.zp0 + lidx * n, *p1 = P.zp1 + lidx * n;
+        if (me <= nn) { p0[me + nn - 1] = z0; p1[me + nn - 1] = z1; }
+        else if (me <= n) { p0[nn + 1 - (me - nn) - 1] = z0; p1[nn + 1 - (me - nn) - 1] = z1; }
+        if (rad && me <= n) { z0s[me - 1] = z0; z1s[me - 1] = z1; }
+        wave_lds_sync();
+    } else if (mazim == 0 && me <= n) {
+        P.zp0[lidx * n + me - 1] = 0.0;
+        P.zp1[lidx * n + me - 1] = 0.0;
+    }
+
+    // ---- TERPSO (disort.f:3980-4128) ----
+    if constexpr (rad) {
+        const double *ylmu = P.t.ylmu + (size_t)mazim * numu * (n + 1);
+        double *zbout = P.zb + lidx * numu, *z0uout = P.z0u + lidx * numu, *z1uout = P.z1u + lidx * numu;
+        double *psi0 = psi, *psi1 = psi + n;
+        if (fbeam > 0.0) {
+            const double delm0 = (mazim == 0) ? 1.0 : 0.0;
+            if (g >= mazim && g <= n - 1) {
+                double psum = 0.0;
+                for (int jq = 1; jq <= n; ++jq) psum = psum + scwt[jq - 1] * ylmc_full(g, jq) * zjs[jq - 1];
+                psi0[g] = 0.5 * gl[g] * psum;
+            }
+            wave_lds_sync();
+            const double fact = (2.0 - delm0) * fbeam / (4.0 * P.pi);
+            for (int iu = me; iu <= numu; iu += G) {
+                double sum = 0.0;
+                for (int iq = mazim; iq <= n - 1; ++iq)
+                    sum = sum + ylmu[(iu - 1) * (n + 1) + iq] * (psi0[iq] + fact * gl[iq] * ylm0[iq]);
+                zbout[iu - 1] = sum;
+            }
+            wave_lds_sync();
+        } else {
+            for (int iu = me; iu <= numu; iu += G) zbout[iu - 1] = 0.0;
+        }
+        if (thermal) {
+            const double xr0 = sv[o.xr0() + lc - 1], xr1 = sv[o.xr1() + lc - 1];
+            if (g <= n - 1) {
+                double psum0 = 0.0, psum1 = 0.0;
+                for (int jq = 1; jq <= n; ++jq) {
+                    const double y = scwt[jq - 1] * ylmc_full(g, jq);
+                    psum0 = psum0 + y * z0s[jq - 1];
+                    psum1 = psum1 + y * z1s[jq - 1];
+                }
+                psi0[g] = 0.5 * gl[g] * psum0;
+                psi1[g] = 0.5 * gl[g] * psum1;
+            }
+            wave_lds_sync();
+            for (int iu = me; iu <= numu; iu += G) {
+                double sum0 = 0.0, sum1 = 0.0;
+                for (int iq = 0; iq <= n - 1; ++iq) {
+                    const double yu = ylmu[(iu - 1) * (n + 1) + iq];
+                    sum0 = sum0 + yu * psi0[iq];
+                    sum1 = sum1 + yu * psi1[iq];
+                }
+                z0uout[iu - 1] = sum0 + (1.0 - oprim) * xr0;
+                z1uout[iu - 1] = sum1 + (1.0 - oprim) * xr1;
+            }
+        } else if (mazim == 0) {
+            for (int iu = me; iu <= numu; iu += G) { z0uout[iu - 1] = 0.0; z1uout[iu - 1] = 0.0; }
+        }
+    }
+    if (status && g == 0) atomicOr(&P.svi[(size_t)slot * P.svi_stride + SBD_SVI_STATUS], status);
+#undef YS
+#undef SP
+#undef SM
+#undef QP
+#undef QM
+#undef LU
+}
+
+}  // namespace sbd
