@@ -12,8 +12,10 @@
 //   * columns use a ring of CW positions (one add/compare per lane per step);
 //   * rows enter the window generated on the fly from the layer eigenvectors (prefetched
 //     one step ahead, unit-stride HBM reads), the pivot-row interchange is physical;
-//   * the multipliers stay in the registers of the pivot search, reach the other lanes by
-//     v_readlane, and are applied to the right-hand side at once (L is never stored);
+//   * the multipliers come straight from the registers of the pivot search (found with a
+//     DPP max-scan, no LDS round trip), reach the other lanes as broadcast LDS reads, and are
+//     applied to the right-hand side at once (L is never stored);
+//   * rows enter from the matrix-ready interface blocks ga/gb the layer kernel wrote;
 //   * each finished U row is streamed to HBM row-major (coalesced); back-substitution
 //     re-reads U in blocks of 16 columns through an LDS transpose stage and runs LINPACK's
 //     column-oriented sweep from there.
@@ -29,7 +31,7 @@ constexpr int kBandMargin = 8;    // extra physical rows before the window is re
 constexpr int kBackBlock = 16;    // columns per back-substitution block
 
 struct BandLds {   // per-wave carve-up (doubles)
-    int rw, cw, cwp, win, b, misc, total;
+    int rw, cw, cwp, win, bw, x, mult, misc, total;
     __host__ __device__ BandLds(int n, int nn, int L, int nlev)
     {
         const int ncd = 3 * nn - 1;
@@ -37,28 +39,53 @@ struct BandLds {   // per-wave carve-up (doubles)
         cw = 2 * ncd + 1;
         cwp = cw | 1;
         win = 0;
-        int winsz = (rw + kBandMargin) * cwp;
-        const int fluxsz = 2 * 16 * n + 64;                        // E / U0C staging, 16 levels at a time
+        const int winsz = (rw + kBandMargin) * cwp;                 // LU phase: window ...
+        bw = win + winsz;                                           // ... + RHS window
+        const int lusz = winsz + ((rw + kBandMargin + 2) & ~1);
+        const int fluxsz = 2 * 16 * n + 64;                         // E / U0C staging, 16 levels at a time
         const int stagesz = (2 * ncd + kBackBlock) * (kBackBlock + 1);   // back-substitution stage
-        if (winsz < fluxsz) winsz = fluxsz;
-        if (winsz < stagesz) winsz = stagesz;
-        b = win + winsz;
-        misc = b + n * L;
+        x = (stagesz > fluxsz ? stagesz : fluxsz);                  // solve phase: stage|flux + X(N)
+        x = (x + 1) & ~1;
+        const int solvesz = x + n * L;
+        mult = ((lusz > solvesz ? lusz : solvesz) + 1) & ~1;
+        misc = mult + ((rw + 2) & ~1);
         total = misc + 8 + n;
         total = (total + 1) & ~1;
         (void)nlev;
     }
 };
 
-// (value, index) arg-max across the wave with LINPACK's first-maximum tie rule.
+// (value, index) arg-max over the low lanes of the wave with LINPACK's first-maximum tie
+// rule, on the DPP network (no LDS round trips): an inclusive max-scan towards the higher
+// lanes inside each row of 16 (row_shr 1,2,4,8), then row_bcast15 (and row_bcast31 when more
+// than 32 candidates).  At every step the incoming value stems from lower lanes only, so
+// "incoming >= mine" keeps the smallest index among equal maxima.  Result in lane 31 / 63.
+template <int CTRL, int ROWMASK>
+SBD_DEVICE void argmax_step(double &v, int &idx)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
+    const int oi = __builtin_amdgcn_update_dpp(idx, idx, CTRL, ROWMASK, 0xF, false);
+    const double ov = __hiloint2double(ohi, olo);
+    const bool take = ov >= v;
+    v = take ? ov : v;
+    idx = take ? oi : idx;
+}
+template <bool WIDE>
 SBD_DEVICE void wave_argmax(double &v, int &idx)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double ov = __shfl_xor(v, off, 64);
-        const int oi = __shfl_xor(idx, off, 64);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
+    argmax_step<0x111, 0xF>(v, idx);   // row_shr:1
+    argmax_step<0x112, 0xF>(v, idx);   // row_shr:2
+    argmax_step<0x114, 0xF>(v, idx);   // row_shr:4
+    argmax_step<0x118, 0xF>(v, idx);   // row_shr:8
+    argmax_step<0x142, 0xA>(v, idx);   // row_bcast:15 -> rows 1,3
+    if (WIDE) argmax_step<0x143, 0xC>(v, idx);   // row_bcast:31 -> rows 2,3
+    constexpr int SRC = WIDE ? 63 : 31;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
+    v = __hiloint2double(hi, lo);
+    idx = __builtin_amdgcn_readlane(idx, SRC);
 }
 
 // broadcast lane `src` (compile-time) of a double to the whole wave through SGPRs
@@ -76,9 +103,9 @@ struct RowUpdate {   // a(i) += tj * m(i) for CNT rows, m(i) = multiplier held b
     {
         if constexpr (I <= CNT) { a[I - 1] = colp[I * stride]; RowUpdate<I + 1, CNT>::load(colp, stride, a); }
     }
-    SBD_DEVICE static void fma(double tj, double mreg, double *a)
+    SBD_DEVICE static void fma(double tj, const double *m, double *a)
     {
-        if constexpr (I <= CNT) { a[I - 1] = a[I - 1] + tj * bcast_lane<I>(mreg); RowUpdate<I + 1, CNT>::fma(tj, mreg, a); }
+        if constexpr (I <= CNT) { a[I - 1] = a[I - 1] + tj * m[I]; RowUpdate<I + 1, CNT>::fma(tj, m, a); }
     }
     SBD_DEVICE static void store(double *colp, int stride, const double *a)
     {
@@ -124,7 +151,10 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     const BandLds lds(n, nn, L, nlev);
     constexpr int ncd = 3 * NN - 1, RW = ncd + 1, CW = 2 * ncd + 1, CWP = CW | 1, MG = kBandMargin;
     double *win = smem + lds.win;
-    double *b = smem + lds.b;
+    double *bw = smem + lds.bw;                       // RHS entries of the window rows (LU phase)
+    double *b = smem + lds.x;                         // solution vector (solve phase)
+    double *yv = P.yv + (size_t)ms * L * n;           // RHS / forward-eliminated RHS in HBM
+    double *mult = smem + lds.mult;                   // [RW] multipliers of the current step
     double *sbot = smem + lds.misc + 4;               // [n] surface-reflection sums (bottom BC)
 
     const double *gc = P.gc + (size_t)ms * L * n * n;
@@ -203,8 +233,10 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
                 v = ZP0(iq, lc + 1) - ZP0(iq, lc) + (ZP1(iq, lc + 1) - ZP1(iq, lc)) * taucpr[lc];
             }
         }
-        b[it - 1] = v;
+        yv[it - 1] = v;
+        if (it <= RW) bw[it - 1] = v;
     }
+    __threadfence_block();   // RHS in HBM is re-read by this wave (row prefetch)
     wave_lds_sync();
 
     // ---- matrix entry generator (SETMTX, disort.f:2844-2990): element (r, col) of the
@@ -258,15 +290,37 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     int ju = 0;
     int kq = 0, kc = 1 % CW;                 // physical row of row k, ring position of column k
     constexpr bool two = CW > 64;            // second pass of lanes over the window width
-    for (int k = 1; k <= N - 1; ++k) {
-        const int lm = (ncd < N - k) ? ncd : N - k;
-        // (A) prefetch the row entering after this step (r = k+RW): lane c <-> column k+1+c
-        const int rin = k + RW;
-        double pg0 = 0.0, pf0 = 1.0, pg1 = 0.0, pf1 = 1.0;
-        if (rin <= N) {
-            entry(rin, k + 1 + lane, pg0, pf0);
-            if (two) entry(rin, k + 1 + lane + 64, pg1, pf1);
+    // Rows enter the window U steps after their HBM loads were issued (software pipeline of
+    // depth U over the unrolled step loop): the step never waits for memory latency.
+    struct Pre { double g0, f0, g1, f1, bv; };
+    const double *ga_ms = P.ga + (size_t)ms * L * n * n;
+    const double *gb_ms = P.gb + (size_t)ms * L * n * n + (size_t)n * n;    // block of layer lc+1
+    auto load_row = [&](int r, Pre &q) {     // lane c <-> column r-RW+1+c (the window after step r-RW)
+        q.g0 = 0.0; q.f0 = 1.0; q.g1 = 0.0; q.f1 = 1.0;
+        q.bv = (r <= N) ? yv[r - 1] : 0.0;
+        if (r <= N - nn) {                   // interface row: matrix-ready blocks, unit stride
+            const int qq = r - nn - 1;                       // row jq = qq % n of interface lc = qq / n + 1
+            const double *ga_r = ga_ms + (size_t)qq * n, *gb_r = gb_ms + (size_t)qq * n;
+            const int d0 = r - RW + 1 + lane - (qq / n) * n;  // 1..2n inside the row's support
+            if (d0 >= 1 && d0 <= n) q.g0 = ga_r[d0 - 1];
+            else if (d0 > n && d0 <= 2 * n) q.g0 = gb_r[d0 - n - 1];
+            if (two) {
+                const int d1 = d0 + 64;
+                if (d1 >= 1 && d1 <= n) q.g1 = ga_r[d1 - 1];
+                else if (d1 > n && d1 <= 2 * n) q.g1 = gb_r[d1 - n - 1];
+            }
+        } else if (r <= N) {                 // bottom-boundary rows
+            entry(r, r - RW + 1 + lane, q.g0, q.f0);
+            if (two) entry(r, r - RW + 1 + lane + 64, q.g1, q.f1);
         }
+    };
+    constexpr int U = 4;
+    Pre pre[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) load_row(RW + 1 + u, pre[u]);
+    auto step = [&](const int k, Pre &pq) {
+        const int lm = (ncd < N - k) ? ncd : N - k;
+        const int rin = k + RW;
         // (B) pivot search over rows k..k+lm of column k (ISAMAX's first-maximum rule);
         //     lane t keeps the signed element a(k+t, k) for the multiplier
         double ak = 0.0;
@@ -277,10 +331,16 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             v = fabs(ak);
             idx = lane;
         }
-        wave_argmax(v, idx);
-        if (v == 0.0) idx = 0;               // all-zero column: keep the diagonal, flag it
+        // -1/a for every candidate, computed while the max-scan runs (off the critical path)
+        const double rk = -1.0 / ak;
+        wave_argmax<(RW > 32)>(v, idx);
+        if (!(v > 0.0)) idx = 0;             // all-zero (or NaN) column: keep the diagonal, flag it
         const int l = k + idx;
-        const double piv = __shfl(ak, idx, 64);
+        // idx is wave-uniform: v_readlane with a scalar lane select instead of a bpermute
+        const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ak), idx),
+                                            __builtin_amdgcn_readlane(__double2loint(ak), idx));
+        const double tsel = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rk), idx),
+                                             __builtin_amdgcn_readlane(__double2loint(rk), idx));
         const double akk = bcast_lane<0>(ak);
         {
             const int junew = ncd + l;
@@ -304,21 +364,22 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
                 }
             }
         }
-        const double bk_old = b[k - 1], bl_old = b[l - 1];
+        const double bk_old = bw[kq], bl_old = bw[kq + idx];
         const double bk = (idx != 0) ? bl_old : bk_old;      // B(k) after the interchange
         if (piv == 0.0) status |= 0x01;
-        const double tinv = (piv != 0.0) ? -1.0 / piv : 0.0;
+        const double tinv = (piv != 0.0) ? tsel : 0.0;
         double mreg = 0.0;                                   // lane t: multiplier of row k+t
         if (lane == 0) {
             rowk[kc] = piv;
-            b[k - 1] = bk;
+            yv[k - 1] = bk;                  // forward-eliminated RHS, final for row k
         }
         if (lane >= 1 && lane <= lm) {
             const double aik = (lane == idx) ? akk : ak;     // element below the pivot after the swap
             mreg = aik * tinv;
+            mult[lane] = mreg;
             rowk[lane * CWP + kc] = 0.0;
-            const double bi = (lane == idx) ? bk_old : b[k + lane - 1];
-            b[k + lane - 1] = bi + bk * mreg;
+            const double bi = (lane == idx) ? bk_old : bw[kq + lane];
+            bw[kq + lane] = bi + bk * mreg;
         }
         wave_lds_sync();
         // (E) rank-1 update: lane <-> column; the rows of a column are loaded into registers
@@ -334,9 +395,11 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
                 double tj = actv ? rowk[pc] : 0.0;
                 double *colp = rowk + pc;
                 if (lm == ncd) {                   // full window: compile-time row count
-                    double a[ncd];
+                    double a[ncd], m[ncd + 1];
+#pragma unroll
+                    for (int i = 1; i <= ncd; ++i) m[i] = mult[i];       // uniform LDS reads (broadcast)
                     RowUpdate<1, ncd>::load(colp, CWP, a);   // inactive lanes read harmless LDS
-                    RowUpdate<1, ncd>::fma(tj, mreg, a);      // readlane needs every lane here
+                    RowUpdate<1, ncd>::fma(tj, m, a);
                     if (actv && tj != 0.0) RowUpdate<1, ncd>::store(colp, CWP, a);
                 } else {                           // the last NCD steps: shrinking window
                     for (int i = 1; i <= lm; ++i) {
@@ -362,32 +425,49 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             {
                 int pc = kc + 1 + lane;          // column k+1+lane
                 if (pc >= CW) pc -= CW;
-                if (lane < CW) rowin[pc] = pg0 * pf0;
+                if (lane < CW) rowin[pc] = pq.g0 * pq.f0;
             }
             if (two && lane + 64 < CW) {
                 int pc = kc + 1 + lane + 64;
                 if (pc >= CW) pc -= CW;
-                rowin[pc] = pg1 * pf1;
+                rowin[pc] = pq.g1 * pq.f1;
             }
+            if (lane == 0) bw[kq + RW] = pq.bv;
         }
         wave_lds_sync();
         kq = kq + 1;
         kc = (kc + 1 == CW) ? 0 : kc + 1;
+        load_row(rin + U, pq);               // issue the loads for the row this slot serves next
         if (kq == MG) {                       // re-base: physical rows MG.. -> 0.. (lane <-> column)
             for (int c = lane; c < CW; c += 64) {
 #pragma unroll
                 for (int i = 0; i < RW; ++i) win[i * CWP + c] = win[(MG + i) * CWP + c];
             }
+            const double bmove = (lane < RW) ? bw[MG + lane] : 0.0;
+            wave_lds_sync();
+            if (lane < RW) bw[lane] = bmove;
             kq = 0;
             wave_lds_sync();
         }
+    };
+    for (int k = 1; k <= N - 1; k += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k + u <= N - 1) step(k + u, pre[u]);
     }
     {   // last row
         const double d = win[kq * CWP + kc];
         if (d == 0.0) status |= 0x01;
-        if (lane == 0) ufac[(size_t)(N - 1) * CW] = d;
+        if (lane == 0) { ufac[(size_t)(N - 1) * CW] = d; yv[N - 1] = bw[kq]; }
     }
     __threadfence_block();
+    wave_lds_sync();
+    // forward-eliminated RHS into LDS; agent-scope (sc1, L2-served) loads: these addresses were
+    // read earlier by the prefetch and rewritten since, so the CU's L1 may hold stale lines
+    for (int i = lane; i < N; i += 64) {
+        const unsigned long long bits = __hip_atomic_load((const unsigned long long *)&yv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b[i] = __longlong_as_double((long long)bits);
+    }
     wave_lds_sync();
 
     // ---- back-substitution, column oriented (SGBSL second loop, disutil.f:1038-1050).

@@ -12,7 +12,10 @@
 //   kk       [ms][L][n]      eigenvalues, -k first (disort.f:3264-3269 ordering)
 //   ek       [ms][L][nn]     exp(KK(iq)*dtau') iq<=nn  (STWJ scaling factors, disort.f:2846)
 //   zz, zp0, zp1, ll [ms][L][n]   particular solutions and integration constants
-//   ufac     [ms][N][CW]     U factor of the band LU, LINPACK column-band layout
+//   ga, gb   [ms][L][n][n]   interface blocks of the boundary-value matrix, ready to load:
+//                            ga(jq,iq) = +GC(jq,iq,lc)*[EK(n+1-iq) if iq>nn] (row jq of interface lc),
+//                            gb(jq,iq) = -GC(jq,iq,lc)*[EK(iq) if iq<=nn]    (row jq of interface lc-1)
+//   ufac     [ms][N][CW]     U factor of the band LU, row-major (row k holds U(k, k..k+2NCD))
 //   gu       [ms][L][n][numu], zb/z0u/z1u [ms][L][numu]   user-angle interpolants (radiance)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -56,6 +59,8 @@ struct Params {
     // workspace
     double *sv; int32_t *svi;
     double *gc, *kk, *ek, *zz, *zp0, *zp1, *ll, *ufac;
+    double *yv;             // [ms][L*n] right-hand side / forward-eliminated RHS of the band system
+    double *ga, *gb;        // matrix-ready interface blocks (see sbd_band.hpp), [ms][L][n][n] each
     double *gu, *zb, *z0u, *z1u, *uum;
     // outputs (offset to the chunk)
     double *flux, *uu; int32_t *status;

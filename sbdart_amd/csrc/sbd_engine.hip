@@ -347,10 +347,10 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const sbd::SV sv(L);
     const int sv_stride = (sv.size() + 1) & ~1;
     const int svi_stride = (3 + L + 1 + 3) & ~3;
-    const size_t per_ms = sizeof(double) * ((size_t)L * n * n + (size_t)L * n * 5 + (size_t)L * nn + (size_t)L * n * cw
+    const size_t per_ms = sizeof(double) * ((size_t)3 * L * n * n + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * cw
                                             + (rad ? (size_t)L * n * numu + 3 * (size_t)L * numu + (size_t)e->nlev * numu : 0));
     const size_t per_slot = per_ms * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
-    size_t budget = (size_t)6 << 30;
+    size_t budget = (size_t)12 << 30;   // of 288 GB
     if (const char *s = getenv("SBD_WORKSPACE_MB")) budget = (size_t)atoll(s) << 20;
     int chunk = 16384;
     if (const char *s = getenv("SBD_CHUNK")) chunk = atoi(s);
@@ -370,12 +370,15 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         P.sv = (double *)take(sizeof(double) * (size_t)chunk * sv_stride);
         P.svi = (int32_t *)take(sizeof(int32_t) * (size_t)chunk * svi_stride);
         P.gc = (double *)take(sizeof(double) * nms * L * n * n);
+        P.ga = (double *)take(sizeof(double) * nms * L * n * n);
+        P.gb = (double *)take(sizeof(double) * nms * L * n * n);
         P.kk = (double *)take(sizeof(double) * nms * L * n);
         P.ek = (double *)take(sizeof(double) * nms * L * nn);
         P.zz = (double *)take(sizeof(double) * nms * L * n);
         P.zp0 = (double *)take(sizeof(double) * nms * L * n);
         P.zp1 = (double *)take(sizeof(double) * nms * L * n);
         P.ll = (double *)take(sizeof(double) * nms * L * n);
+        P.yv = (double *)take(sizeof(double) * nms * L * n);
         P.ufac = (double *)take(sizeof(double) * nms * L * n * cw);
         if (rad) {
             P.gu = (double *)take(sizeof(double) * nms * L * n * numu);

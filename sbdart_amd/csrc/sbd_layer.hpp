@@ -245,6 +245,21 @@ __global__ void __launch_bounds__(64) layer_kernel(Params P, int32_t *only_flagg
         }
     }
     wave_lds_sync();
+    {   // matrix-ready interface blocks for the band kernel (disort.f:2851-2876); eval[] holds k
+        double *gaout = P.ga + ((size_t)ms * L + (lc - 1)) * n * n, *gbout = P.gb + ((size_t)ms * L + (lc - 1)) * n * n;
+        const double dtp = sv[o.dtaucp() + lc - 1];
+        __threadfence_block();
+        for (int e = g; e < n * n; e += G) {
+            const int j = e % n;                         // iq - 1
+            const double v = gcout[e];
+            // EK(iq) = exp(KK(iq)*dtau'), KK(iq<=nn) = -k of eigenvalue nn+1-iq
+            const double eka = (j >= nn) ? exp(-eval[nn - (n - j)] * dtp) : 1.0;      // EK(n+1-iq), iq = j+1 > nn
+            const double ekb = (j < nn) ? exp(-eval[nn - 1 - j] * dtp) : 1.0;          // EK(iq), iq = j+1 <= nn
+            gaout[e] = v * eka;
+            gbout[e] = -v * ekb;
+        }
+    }
+    wave_lds_sync();
 
     // ---- UPBEAM (disort.f:4205-4241) ----
     double zj = 0.0;

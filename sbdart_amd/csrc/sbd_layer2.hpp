@@ -244,7 +244,9 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         double *ekout = P.ek + lidx * nn;
         kkout[me + nn - 1] = kq;
         kkout[nn + 1 - me - 1] = -kq;
-        ekout[nn + 1 - me - 1] = exp(-kq * sv[o.dtaucp() + lc - 1]);
+        const double ekv = exp(-kq * sv[o.dtaucp() + lc - 1]);
+        ekout[nn + 1 - me - 1] = ekv;
+        psi[nn + 1 - me - 1] = ekv;          // EK(iq), iq = nn+1-me, kept in LDS for the blocks below
     }
     wave_lds_sync();      // Q+/Q- (alias of lu) are dead from here on
     // GC staged through LDS (lu) so that HBM sees whole rows: GC(i,j) -> lu[(i-1)*ld + j-1]
@@ -260,8 +262,14 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     }
     wave_lds_sync();
     {
-        double *gcout = P.gc + lidx * n * n;
-        for (int e = g; e < n * n; e += G) gcout[e] = lu[(e / n) * ld + (e % n)];
+        double *gcout = P.gc + lidx * n * n, *gaout = P.ga + lidx * n * n, *gbout = P.gb + lidx * n * n;
+        for (int e = g; e < n * n; e += G) {
+            const int j = e % n;                         // iq - 1
+            const double v = lu[(e / n) * ld + j];
+            gcout[e] = v;
+            gaout[e] = (j >= nn) ? v * psi[n - 1 - j] : v;          // disort.f:2851-2876
+            gbout[e] = (j < nn) ? -v * psi[j] : -v;
+        }
     }
     wave_lds_sync();
 
