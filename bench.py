@@ -175,6 +175,17 @@ def main():
         abytes = algorithmic_bytes_per_solve(sw.nlyr, sw.nstr, eng.nlev)
         nlaunch = (W + eng.chunk - 1) // eng.chunk
         ach = abytes * W / (phase_ms[dom] * 1e-3) / 1e9
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/make_traffic_profile.py)
+        traffic = None
+        try:
+            tp = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            key = {"layer_kernel": "layer_kernel2", "band_kernel": "band_kernel"}.get(names[dom], names[dom])
+            for kname, kd in tp["kernels"].items():
+                if key in kname and (sw.nstr == 16):
+                    traffic = kd["bytes_per_solve"] * min(W, eng.chunk)
+        except Exception:
+            traffic = None
         flops = algorithmic_flops_per_solve(sw.nlyr, sw.nstr)
         out = {
             "metric": "spectral-points/sec (whole node) + flux RMSE vs CPU, 16-stream SW sweep",
@@ -191,7 +202,8 @@ def main():
             "nonzero_status": bad,
             "kernel_ms": {names[i]: float(phase_ms[i]) for i in range(4)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
                          "algorithmic_bytes_per_solve": abytes, "solves_per_launch": min(W, eng.chunk),
                          "launches": nlaunch, "avg_launch_ms": float(phase_ms[dom] / nlaunch),
                          "note": "path is fp64-VALU/LDS/latency bound by construction (SURVEY 8d); "
