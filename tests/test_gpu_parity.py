@@ -193,3 +193,68 @@ def test_full_size_properties():
             ref = o[f][[0, -1]]
             sc = max(np.abs(o[f]).max(), 1e-300)
             assert np.abs(f1[i, c] - ref).max() <= TOL * sc, (i, f)
+
+
+def _random_record(rng, nstr, nlyr, rad, plank, beam):
+    from sbdart_amd.records import F_LAMBER, F_ONLYFL, F_PLANK, F_USRANG, SolveRecord
+    nmom = nstr + 2
+    k = np.arange(nmom + 1)
+    g = rng.uniform(0.0, 0.9, nlyr)
+    mix = rng.uniform(0.0, 1.0, nlyr)
+    ray = np.zeros(nmom + 1); ray[0], ray[2] = 1.0, 0.1
+    pm = (1 - mix)[:, None] * g[:, None] ** k[None, :] + mix[:, None] * ray[None, :]
+    dt = np.exp(rng.uniform(-7, 1.5, nlyr))
+    dt[rng.random(nlyr) < 0.05] = 0.0
+    w = rng.uniform(0.0, 1.0, nlyr)
+    w[rng.random(nlyr) < 0.05] = 1.0
+    flags = F_LAMBER | (F_PLANK if plank else 0) | (F_USRANG if rad else F_ONLYFL)
+    lo = rng.uniform(300.0, 2500.0)
+    return SolveRecord(nlyr=nlyr, nstr=nstr, nmom=nmom, flags=flags, wvnmlo=lo, wvnmhi=lo * rng.uniform(1.001, 1.3),
+                       fbeam=rng.uniform(0.5, 3.0) if beam else 0.0, umu0=float(rng.uniform(0.15, 0.97)), phi0=30.0,
+                       albedo=float(rng.uniform(0, 1)), btemp=295.0, ttemp=180.0, temis=0.3 if plank else 0.0,
+                       dtauc=dt, ssalb=w, temper=np.linspace(200.0, 290.0, nlyr + 1) + rng.uniform(-3, 3, nlyr + 1),
+                       pmom=pm, umu=np.array([-0.8, -0.35, 0.1, 0.6, 0.95]) if rad else np.zeros(0),
+                       phi=np.array([0.0, 45.0, 200.0]) if rad else np.zeros(0))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_all_stream_counts_and_layer_counts(seed):
+    """Every even NSTR 4..40 (incl. odd NSTR/2, the 64-lane groups and the two-pass window of
+    NSTR>=24) x layer counts up to the reference's maximum (mxly=65), flux and radiance,
+    beam/thermal on/off -- against the oracle."""
+    import pyoracle
+    from sbdart_amd.engine import solve_records
+    rng = np.random.default_rng(1000 + seed)
+    recs = []
+    for nstr in range(4, 41, 2):
+        nlyr = int(rng.choice([1, 2, 3, 7, 20, 33, 50, 65]))
+        if nstr > 24 and nlyr > 33:
+            nlyr = 33
+        rad = bool(rng.random() < 0.35) and nstr <= 24
+        plank = bool(rng.random() < 0.5)
+        beam = bool(rng.random() < 0.8) or not plank
+        r = _random_record(rng, nstr, nlyr, rad, plank, beam)
+        o = pyoracle.disort(r)
+        if o["status"] & pyoracle.RETRY_NSTR:
+            continue
+        recs.append((r, o))
+    flux, uu, st = solve_records([r for r, _ in recs])
+    _check(flux, uu, st, [r for r, _ in recs], [o for _, o in recs])
+
+
+def test_qr_fallback_path_matches():
+    """SBD_FORCE_EIG_FALLBACK routes every layer through the QR kernel (the path taken when a
+    Cholesky pivot of the symmetrised problem is not positive): same answers."""
+    import subprocess, sys, json
+    code = ("import numpy as np,sys,os,json;sys.path.insert(0,'.');"
+            "from sbdart_amd.engine import solve_records;from sbdart_amd.records import read_records;"
+            "r=read_records('tests/golden/cfgB_sw_nstr16.sbdrec')[:12]+read_records('tests/golden/sbchk5.sbdrec')[:2];"
+            "f,u,s=solve_records(r);"
+            "print(json.dumps([float(np.abs(f[i][c]-getattr(r[i],n)).max()/max(np.abs(getattr(r[i],n)).max(),1e-300))"
+            " for i in range(len(r)) for c,n in enumerate(('rfldir','rfldn','flup','dfdt','uavg'))]"
+            "+[float(np.abs(u[i]-r[i].uu).max()/np.abs(r[i].uu).max()) for i in range(12,14)]))")
+    from conftest import ROOT
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT,
+                                  env=dict(os.environ, SBD_FORCE_EIG_FALLBACK="1"), text=True)
+    errs = json.loads(out.strip().splitlines()[-1])
+    assert max(errs) < TOL, max(errs)
