@@ -46,13 +46,17 @@ extern "C" {
 #define SBD_OK               0
 #define SBD_E_INVALID       -1  /* bad argument / CHEKIN-type fatal in the run config */
 #define SBD_E_RETRY_NSTR    -2  /* beam angle == a quadrature angle: pick NSTR-2 / NSTR+2
-                                   (disort.f:2645-2650; drt.f:536-555 does the retry) */
+                                   (disort.f:2645-2650; drt.f:536-555 does the retry).  The
+                                   engine IS created (*out valid, destroy it): work items
+                                   without a beam (FBEAM = 0) can still be solved with it */
 #define SBD_E_NO_DEVICE     -3
 #define SBD_E_HIP           -4  /* a HIP runtime call failed; see sbd_last_error() */
 #define SBD_E_UNSUPPORTED   -5  /* BRDF surface, IBCND=1, CORINT */
 #define SBD_E_NOMEM         -6
 
 /* ---- per-work-item status bits ---- */
+/* warnings 2/3/4: the reference raises them from LINPACK's RCOND estimate (1+RCOND == 1);
+ * this engine raises them on an exactly singular pivot only (no condition estimate). */
 #define SBD_ST_WARN_SOLVE0   0x01  /* band matrix singular pivot        (errmsg 2, disort.f:3609) */
 #define SBD_ST_WARN_UPBEAM   0x02  /* beam-source system singular pivot (errmsg 3, disort.f:4227) */
 #define SBD_ST_WARN_UPISOT   0x04  /* thermal-source system singular    (errmsg 4, disort.f:4333) */
@@ -128,7 +132,8 @@ int sbd_engine_solve_host(sbd_engine *e, const sbd_batch_in *in, const sbd_batch
 
 /* stdout1's reduction (drt.f:964-1054): acc[c][lev] += sum_i weight[i] * flux[i][c][lev],
  * and acc_uu[phi][lev][mu] += sum_i weight[i]*uu[i][...] when uu != NULL.
- * fp64, deterministic order (pairwise tree over i, independent of launch shape). */
+ * fp64, deterministic order: 256-item segments summed in work-item order, then the segment
+ * sums added in order (independent of the launch shape and of the GPU). */
 int sbd_engine_accumulate_device(sbd_engine *e, int32_t nwork, const double *weight,
                                  const double *flux, const double *uu,
                                  double *acc_flux, double *acc_uu, void *hip_stream);

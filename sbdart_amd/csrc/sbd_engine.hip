@@ -402,6 +402,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         P.dither = 100.0 * 2.220446049250313e-16;   // disort.f:442-448
         P.t = e->tab;
         P.force_fallback = 0;
+        P.dbg = 0;
+        if (const char *s2 = getenv("SBD_DBG_FLAGS")) P.dbg = atoi(s2);
         if (const char *s = getenv("SBD_FORCE_EIG_FALLBACK")) P.force_fallback = atoi(s) != 0;
     }
     // the carve above rounds every array up to 256 B: re-check against the allocation

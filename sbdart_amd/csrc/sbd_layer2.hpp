@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                     }
                 }
             }
-            if (!__any(rotated)) break;
+            if (!__any(rotated) || (P.dbg & 1)) break;
         }
     }
 
@@ -338,8 +338,10 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
             zj = (2.0 - delm0) * fbeam * sum / (4.0 * P.pi);
         }
         wave_lds_sync();
+        if (!(P.dbg & 2)) {
         if (lu_factor_group(lu, ld, n, ipvt, g) != 0) status |= 0x02;
         zj = lu_solve_group<G>(lu, ld, n, ipvt, zj, g);
+        }
         double *zzout = P.zz + lidx * n;
         if (me <= nn) zzout[me + nn - 1] = zj;
         else if (me <= n) zzout[nn + 1 - (me - nn) - 1] = zj;

@@ -96,6 +96,10 @@ def _edge_records():
                    plank=True, wl=(2000.0, 2200.0)))
     out.append(rec(5, 8, [3.0, 4.0, 5.0, 6.0, 1.0], [0.2] * 5, [0.5] * 5, rad=True))      # LYRCUT + radiance
     out.append(rec(5, 8, [0.3] * 5, [0.8] * 5, [0.6] * 5, rad=True, fbeam=0.0, plank=True, wl=(900.0, 950.0)))
+    # the reference's maximum dimensions: nstrms = 40 streams, mxly = 65 layers (params.f:9-11)
+    out.append(rec(65, 40, rng.uniform(0.01, 0.3, 65), rng.uniform(0.2, 0.99, 65), rng.uniform(0, 0.8, 65),
+                   plank=True, wl=(2100.0, 2300.0)))
+    out.append(rec(65, 40, rng.uniform(0.01, 0.2, 65), rng.uniform(0.5, 1.0, 65), rng.uniform(0, 0.85, 65), rad=True))
     return out
 
 
