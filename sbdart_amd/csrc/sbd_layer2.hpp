@@ -110,16 +110,16 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 
     // ---- S+ / S- (even / odd l-m parts), lane j <-> column j; then Q+-, all symmetric ----
     if (me <= nn) {
-        double yj[n];
+        double yj[n];   // GL(l) * Y(l, mu_j): the j-dependent factor of every term
 #pragma unroll
-        for (int l = 0; l < n; ++l) yj[l] = YS(l, me);
+        for (int l = 0; l < n; ++l) yj[l] = gl[l] * YS(l, me);
         const double rj = sqrt(scwt[me - 1] / scmu[me - 1]);
         for (int iq = 1; iq <= nn; ++iq) {
             double se = 0.0, so = 0.0;
 #pragma unroll
             for (int l = 0; l < n; ++l) {
                 if (l >= mazim) {
-                    const double t = gl[l] * YS(l, iq) * yj[l];
+                    const double t = YS(l, iq) * yj[l];
                     if (((l - mazim) & 1) == 0) se = se + t; else so = so + t;
                 }
             }
@@ -181,6 +181,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         const double tol = 2.220446049250313e-16;
         for (int sweep = 0; sweep < 30; ++sweep) {
             bool rotated = false;
+            double worst = 0.0;      // largest |cos(angle)| between two columns met in this sweep
             for (int s = 0; s < NP - 1; ++s) {
                 // circle method: player 0 fixed, the others rotate
                 int pos = (j == 0) ? 0 : 1 + (j - 1 - s + 2 * (NP - 1)) % (NP - 1);
@@ -202,8 +203,10 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                         bb = bb + ob[i] * ob[i];
                         gg = gg + bcol[i] * ob[i];
                     }
-                    if (fabs(gg) > tol * sqrt(aa * bb)) {
+                    const double lim = sqrt(aa * bb);
+                    if (fabs(gg) > tol * lim) {
                         rotated = true;
+                        worst = fmax(worst, fabs(gg) / lim);
                         const bool lo = j < partner;
                         // rotation defined for the ordered pair (p<q): alpha=|b_p|^2, beta=|b_q|^2
                         const double alpha = lo ? aa : bb, beta = lo ? bb : aa;
@@ -220,7 +223,8 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                     }
                 }
             }
-            if (!__any(rotated) || (P.dbg & 1)) break;
+            // quadratic convergence: a sweep that started below 1e-8 ends below 1e-16
+            if (!__any(rotated) || !__any(worst > 1.0e-8) || (P.dbg & 1)) break;
         }
     }
 
