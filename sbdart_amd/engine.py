@@ -117,20 +117,6 @@ class DisortEngine:
     def last_ms(self, phase: int = -1) -> float:
         return self._L.sbd_engine_last_ms(self._h, phase)
 
-    def debug_array(self, which: str, slot: int = 0, mode: int = 0):
-        """Test hook: workspace array of the last chunk (see sbd_engine_debug_copy)."""
-        ids = dict(gc=0, kk=1, ek=2, zz=3, zp0=4, zp1=5, ll=6)
-        n, nn, L = self.nstr, self.nstr // 2, self.nlyr
-        per = dict(gc=L * n * n, kk=L * n, ek=L * nn, zz=L * n, zp0=L * n, zp1=L * n, ll=L * n)[which]
-        shape = dict(gc=(L, n, n), kk=(L, n), ek=(L, nn), zz=(L, n), zp0=(L, n), zp1=(L, n), ll=(L, n))[which]
-        nmode = 1 if self.onlyfl else self.nstr   # upper bound; engine may use fewer
-        buf = np.zeros(per * (slot * nmode + mode + 1) * 1)
-        # modes per slot are engine-internal: fetch enough and index with the true count
-        got = self._L.sbd_engine_debug_copy(self._h, ids[which], buf.ctypes.data_as(C.c_void_p), buf.nbytes)
-        if got < 0:
-            raise SbdError(int(got), "sbd_engine_debug_copy")
-        return buf, per, shape
-
     # ---- the hot path ----
     def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank):
         """Solve a batch.  Shapes: dtauc/ssalb [W, nlyr]; pmom [W, nlyr, nmom+1];
