@@ -157,11 +157,11 @@ def main():
 
     # ---- per-kernel timing pass (HIP events on the launch stream), outside the timed region ----
     eng.enable_timing(True)
-    phase_ms = np.zeros(4)
+    phase_ms = np.zeros(5)
     nrep = 3
     for _ in range(nrep):
         eng.solve_device(*d_in, out=(flux, None, status), stream=stream)
-        phase_ms += [eng.last_ms(p) for p in range(4)]
+        phase_ms += [eng.last_ms(p) for p in range(5)]
     phase_ms /= nrep
     eng.enable_timing(False)
     torch.cuda.synchronize()
@@ -170,7 +170,7 @@ def main():
         nwl_total = sw.nwl * world
         ms_per_step = 1e3 * elapsed / args.steps
         value = nwl_total * args.steps / elapsed
-        names = ["setup_kernel", "layer_kernel", "band_kernel", "usrint+azimuth"]
+        names = ["setup_kernel", "layer_kernel", "band_kernel", "backsolve_kernel", "usrint+azimuth"]
         dom = int(np.argmax(phase_ms))
         abytes = algorithmic_bytes_per_solve(sw.nlyr, sw.nstr, eng.nlev)
         nlaunch = (W + eng.chunk - 1) // eng.chunk
@@ -200,7 +200,7 @@ def main():
                        "chunk": eng.chunk, "workspace_bytes": eng.workspace_bytes},
             "solves_per_s": W * world * args.steps / elapsed,
             "nonzero_status": bad,
-            "kernel_ms": {names[i]: float(phase_ms[i]) for i in range(4)},
+            "kernel_ms": {names[i]: float(phase_ms[i]) for i in range(5)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",

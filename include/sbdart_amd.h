@@ -150,8 +150,8 @@ void       *sbd_engine_stream(sbd_engine *e);           /* the engine's hipStrea
 /* Gauss quadrature the engine uses (QGAUSN, disort.f:5984): cmu/cwt get nstr/2 values */
 int         sbd_engine_quadrature(const sbd_engine *e, double *cmu, double *cwt);
 /* wall time (ms) of the kernels of the most recent solve_device call, measured with HIP
- * events on the stream the kernels ran on; phase: 0 setup, 1 layer, 2 band+flux,
- * 3 intensities, -1 total.  Synchronises the stream. */
+ * events on the stream the kernels ran on; phase: 0 setup, 1 layer, 2 band LU,
+ * 3 back-substitution + fluxes, 4 intensities, -1 total.  Synchronises the stream. */
 double      sbd_engine_last_ms(sbd_engine *e, int phase);
 void        sbd_engine_enable_timing(sbd_engine *e, int on);
 /* Test hook: copy one workspace array of the LAST chunk solved to the host.

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsbdart_amd.so")
+# SBDART_AMD_LIB points at another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("SBDART_AMD_LIB") or os.path.join(_HERE, "lib", "libsbdart_amd.so")
 
 ABI_VERSION = 1
 NFLUX = 5

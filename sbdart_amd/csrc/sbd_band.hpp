@@ -27,31 +27,34 @@
 
 namespace sbd {
 
-constexpr int kBandMargin = 8;    // extra physical rows before the window is re-based
-constexpr int kBackBlock = 16;    // columns per back-substitution block
+constexpr int kBandMargin = 4;    // extra physical rows before the window is re-based
+constexpr int kBackBlock = 8;     // columns per back-substitution block
 
-struct BandLds {   // per-wave carve-up (doubles)
-    int rw, cw, cwp, win, bw, x, mult, misc, total;
-    __host__ __device__ BandLds(int n, int nn, int L, int nlev)
+struct BandLds {   // per-wave carve-up of the LU kernel (doubles)
+    int rw, cw, cwp, win, bw, misc, total;
+    __host__ __device__ BandLds(int n, int nn)
     {
         const int ncd = 3 * nn - 1;
         rw = ncd + 1;
         cw = 2 * ncd + 1;
         cwp = cw | 1;
-        win = 0;
-        const int winsz = (rw + kBandMargin) * cwp;                 // LU phase: window ...
-        bw = win + winsz;                                           // ... + RHS window
-        const int lusz = winsz + ((rw + kBandMargin + 2) & ~1);
+        win = 0;                                                    // sliding window ...
+        bw = win + (rw + kBandMargin) * cwp;                        // ... + its RHS entries
+        misc = bw + ((rw + kBandMargin + 2) & ~1);
+        total = (misc + 8 + n + 1) & ~1;                            // [n] surface-reflection sums
+    }
+};
+
+struct SolveLds {   // per-wave carve-up of the back-substitution + flux kernel (doubles)
+    int stage, x, total;
+    __host__ __device__ SolveLds(int n, int nn, int L)
+    {
+        const int ncd = 3 * nn - 1;
         const int fluxsz = 2 * 16 * n + 64;                         // E / U0C staging, 16 levels at a time
-        const int stagesz = (2 * ncd + kBackBlock) * (kBackBlock + 1);   // back-substitution stage
-        x = (stagesz > fluxsz ? stagesz : fluxsz);                  // solve phase: stage|flux + X(N)
-        x = (x + 1) & ~1;
-        const int solvesz = x + n * L;
-        mult = ((lusz > solvesz ? lusz : solvesz) + 1) & ~1;
-        misc = mult + ((rw + 2) & ~1);
-        total = misc + 8 + n;
-        total = (total + 1) & ~1;
-        (void)nlev;
+        const int stagesz = (2 * ncd + kBackBlock + 1) * (kBackBlock + 1);   // U block + a zero row
+        stage = 0;
+        x = ((stagesz > fluxsz ? stagesz : fluxsz) + 1) & ~1;       // X(N) behind the stage
+        total = (x + n * L + 1) & ~1;
     }
 };
 
@@ -131,7 +134,7 @@ struct RowUpdate {   // rows I..LAST of one column: a(i) += tj * m(i); lane i ho
             fmas<U + 1>(tj, mreg, a);
         }
     }
-    SBD_DEVICE static void run(double *colp, double mreg, double tj)
+    SBD_DEVICE static void run(double *colp, double mreg, double tj, bool nostore = false)
     {
         if constexpr (I <= LAST) {
             constexpr int CNT = LAST - I + 1;
@@ -139,7 +142,7 @@ struct RowUpdate {   // rows I..LAST of one column: a(i) += tj * m(i); lane i ho
             loads<0>(lds_addr(colp), a);
             lds_wait();
             fmas<0>(tj, mreg, a);
-            if (tj != 0.0) {                                            // SAXPY's early return
+            if (tj != 0.0 && !nostore) {                                // SAXPY's early return
 #pragma unroll
                 for (int u = 0; u < CNT; ++u) colp[(I + u) * STRIDE] = a[u];
             }
@@ -182,13 +185,11 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     const double umu0 = P.umu0;
     const double *cmu = P.t.cmu, *cwt = P.t.cwt;
 
-    const BandLds lds(n, nn, L, nlev);
+    const BandLds lds(n, nn);
     constexpr int ncd = 3 * NN - 1, RW = ncd + 1, CW = 2 * ncd + 1, CWP = CW | 1, MG = kBandMargin;
     double *win = smem + lds.win;
     double *bw = smem + lds.bw;                       // RHS entries of the window rows (LU phase)
-    double *b = smem + lds.x;                         // solution vector (solve phase)
     double *yv = P.yv + (size_t)ms * L * n;           // RHS / forward-eliminated RHS in HBM
-    double *mult = smem + lds.mult;                   // [RW] multipliers of the current step
     double *sbot = smem + lds.misc + 4;               // [n] surface-reflection sums (bottom BC)
 
     const double *gc = P.gc + (size_t)ms * L * n * n;
@@ -455,8 +456,8 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
                 double *colp = rowk + pcl;
                 if (lm == ncd) {                   // full window: compile-time row count, two halves
                     constexpr int H = (ncd + 1) / 2;
-                    RowUpdate<1, H, CWP>::run(colp, mreg, t1);      // inactive lanes: t1 = 0, no stores
-                    RowUpdate<H + 1, ncd, CWP>::run(colp, mreg, t1);
+                    RowUpdate<1, H, CWP>::run(colp, mreg, t1, (P.dbg & 16) != 0);      // inactive lanes: t1 = 0, no stores
+                    RowUpdate<H + 1, ncd, CWP>::run(colp, mreg, t1, (P.dbg & 16) != 0);
                     if (two && ncols >= 64) {
                         const double t2 = (lane + 64 <= ncols) ? tj2 : 0.0;
                         double *colp2 = rowk + pcl2;
@@ -489,7 +490,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             wave_lds_sync();
         }
     };
-    for (int k = 1; k <= N - 1; k += U) {
+    for (int k = 1; k <= ((P.dbg & 64) ? 0 : N - 1); k += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (k + u <= N - 1) step(k + u, pre[u]);
@@ -499,146 +500,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         if (d == 0.0) status |= 0x01;
         if (lane == 0) { ufac[(size_t)(N - 1) * CW] = d; yv[N - 1] = bw[kq]; }
     }
-    __threadfence_block();
-    wave_lds_sync();
-    // forward-eliminated RHS into LDS; agent-scope (sc1, L2-served) loads: these addresses were
-    // read earlier by the prefetch and rewritten since, so the CU's L1 may hold stale lines
-    for (int i = lane; i < N; i += 64) {
-        const unsigned long long bits = __hip_atomic_load((const unsigned long long *)&yv[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b[i] = __longlong_as_double((long long)bits);
-    }
-    wave_lds_sync();
-
-    // ---- back-substitution, column oriented (SGBSL second loop, disutil.f:1038-1050).
-    //      U is row-major in HBM (ufac[i][j-i]); blocks of 16 columns are transposed through
-    //      an LDS stage: stage[r][c] = U(i0+r, k0+c), rows i0 = k0-2ncd .. k1 ----
-    {
-        constexpr int BC = kBackBlock, SP = BC + 1, NR = 2 * ncd + BC;
-        double *stage = win;
-        for (int k1 = N; k1 >= 1; k1 -= BC) {
-            const int k0 = (k1 - BC + 1 > 1) ? k1 - BC + 1 : 1;
-            const int i0 = k0 - 2 * ncd;                   // may be <= 0: rows < 1 hold zeros
-            wave_lds_sync();
-            {
-                const int rr = lane >> 4, c = lane & 15;
-                const int j = k0 + c;
-#pragma unroll 4
-                for (int r0 = 0; r0 < NR; r0 += 4) {
-                    const int r = r0 + rr;
-                    const int i = i0 + r;
-                    double val = 0.0;
-                    if (r < NR && i >= 1 && i <= k1 && j <= k1 && j >= i && j - i <= 2 * ncd)
-                        val = ufac[(size_t)(i - 1) * CW + (j - i)];
-                    if (r < NR) stage[r * SP + c] = val;
-                }
-            }
-            wave_lds_sync();
-            for (int k = k1; k >= k0; --k) {
-                const int c = k - k0;
-                const int lmk = ((k < CW) ? k : CW) - 1;
-                const double diag = stage[(k - i0) * SP + c];
-                const double xk = b[k - 1] / diag;
-                wave_lds_sync();
-                if (lane == 0) b[k - 1] = xk;
-                const double t = -xk;
-                // row i = k-1-lane  ->  stage row (i - i0)
-                if (lane < lmk) b[k - 2 - lane] = b[k - 2 - lane] + t * stage[(k - 1 - lane - i0) * SP + c];
-                if (two && lane + 64 < lmk)
-                    b[k - 2 - (lane + 64)] = b[k - 2 - (lane + 64)] + t * stage[(k - 1 - (lane + 64) - i0) * SP + c];
-                wave_lds_sync();
-            }
-        }
-    }
-    // LL(j, lc) = B((lc-1)*n + j) (disort.f:3624-3633)
-    {
-        double *ll = P.ll + (size_t)ms * L * n;
-        for (int i = lane; i < N; i += 64) ll[i] = b[i];
-    }
     if (status && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], status);
-
-    // ---- FLUXES (mode 0) ----
-    if (mazim != 0) return;
-    {
-        const int32_t *layru = svi + SBD_SVI_LAYRU;
-        const double *utau = sv + o.utau(), *utaupr = sv + o.utaupr(), *ssalbv = sv + o.ssalb();
-        const double *xr0 = sv + o.xr0(), *xr1 = sv + o.xr1();
-        double *efac = win;                 // [16][n]
-        double *u0c = win + 16 * n;         // [16][n]
-        const double pi = P.pi;
-        for (int lev0 = 0; lev0 < nlev; lev0 += 16) {
-            const int nb = (nlev - lev0 < 16) ? nlev - lev0 : 16;
-            wave_lds_sync();
-            // E(jq, lev) = exp(-KK(jq,lyu) * (utaupr - taucpr(lyu or lyu-1)))
-            for (int e = lane; e < nb * n; e += 64) {
-                const int li = e / n, jq = e % n + 1;
-                const int lev = P.all_levels ? lev0 + li : P.t.level_out[lev0 + li];
-                const int lyu = layru[lev];
-                double val = 0.0;
-                if (!(lyrcut && lyu > ncut)) {
-                    const double up = utaupr[lev];
-                    const double ref = (jq <= nn) ? taucpr[lyu] : taucpr[lyu - 1];
-                    val = exp(-KK(jq, lyu) * (up - ref));
-                }
-                efac[li * n + jq - 1] = val;
-            }
-            wave_lds_sync();
-            for (int e = lane; e < nb * n; e += 64) {
-                const int li = e / n, iq = e % n + 1;
-                const int lev = P.all_levels ? lev0 + li : P.t.level_out[lev0 + li];
-                const int lyu = layru[lev];
-                double val = 0.0;
-                if (!(lyrcut && lyu > ncut)) {
-                    double zint = 0.0;
-                    const double *grow = &GC(iq, 1, lyu);
-                    const double *llv = b + (lyu - 1) * n;
-                    for (int jq = 1; jq <= n; ++jq) zint = zint + grow[jq - 1] * llv[jq - 1] * efac[li * n + jq - 1];
-                    val = zint;
-                    if (beam) val = zint + ZZ(iq, lyu) * exp(-utaupr[lev] / umu0);
-                    val = val + ZP0(iq, lyu) + ZP1(iq, lyu) * utaupr[lev];
-                }
-                u0c[li * n + iq - 1] = val;
-            }
-            wave_lds_sync();
-            if (lane < nb) {   // one lane per level: sums in the reference's order
-                const int li = lane;
-                const int lev = P.all_levels ? lev0 + li : P.t.level_out[lev0 + li];
-                const int lyu = layru[lev];
-                double rfldir = 0.0, rfldn = 0.0, flup = 0.0, dfdt = 0.0, uavg = 0.0;
-                if (!(lyrcut && lyu > ncut)) {
-                    double dirint = 0.0, fldir = 0.0, fldn = 0.0;
-                    if (beam) {
-                        const double fact = exp(-utaupr[lev] / umu0);
-                        dirint = fbeam * fact;
-                        fldir = umu0 * (fbeam * fact);
-                        rfldir = umu0 * fbeam * exp(-utau[lev] / umu0);
-                    }
-                    for (int iq = 1; iq <= nn; ++iq) {
-                        const double u = u0c[li * n + iq - 1];
-                        uavg = uavg + cwt[nn - iq] * u;
-                        fldn = fldn + cwt[nn - iq] * cmu[nn - iq] * u;
-                    }
-                    for (int iq = nn + 1; iq <= n; ++iq) {
-                        const double u = u0c[li * n + iq - 1];
-                        uavg = uavg + cwt[iq - nn - 1] * u;
-                        flup = flup + cwt[iq - nn - 1] * cmu[iq - nn - 1] * u;
-                    }
-                    flup = 2.0 * pi * flup;
-                    fldn = 2.0 * pi * fldn;
-                    const double fdntot = fldn + fldir;
-                    rfldn = fdntot - rfldir;
-                    uavg = (2.0 * pi * uavg + dirint) / (4.0 * pi);
-                    const double plsorc = xr0[lyu - 1] + xr1[lyu - 1] * utaupr[lev];
-                    dfdt = (1.0 - ssalbv[lyu - 1]) * 4.0 * pi * (uavg - plsorc);
-                }
-                const int ol = lev0 + li;
-                flux[0 * nlev + ol] = rfldir;
-                flux[1 * nlev + ol] = rfldn;
-                flux[2 * nlev + ol] = flup;
-                flux[3 * nlev + ol] = dfdt;
-                flux[4 * nlev + ol] = uavg;
-            }
-        }
-    }
 #undef GC
 #undef KK
 #undef EK

@@ -18,6 +18,7 @@
 //   ufac     [ms][N][CW]     U factor of the band LU, row-major (row k holds U(k, k..k+2NCD))
 //   gu       [ms][L][n][numu], zb/z0u/z1u [ms][L][numu]   user-angle interpolants (radiance)
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -103,5 +104,15 @@ SBD_DEVICE void wave_lds_sync()
 }
 
 SBD_DEVICE double dsign(double a, double b) { return (b >= 0.0) ? fabs(a) : -fabs(a); }
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <int N, int I = 0, class F>
+SBD_DEVICE void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
 
 }  // namespace sbd

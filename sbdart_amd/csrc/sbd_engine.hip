@@ -25,6 +25,7 @@ namespace sbd { constexpr int SBD_NFLUX_ = SBD_NFLUX; }
 #include "sbd_layer.hpp"
 #include "sbd_layer2.hpp"
 #include "sbd_band.hpp"
+#include "sbd_solve.hpp"
 #include "sbd_usrint.hpp"
 
 namespace {
@@ -169,10 +170,11 @@ struct sbd_engine {
     size_t partial_elems = 0;
     // timing
     bool timing = false;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    float ms_phase[4] = {0, 0, 0, 0};
+    static constexpr int kPhases = 5;   // setup, layer, band LU, back-substitution + fluxes, intensities
+    hipEvent_t ev[kPhases + 1] = {};
+    float ms_phase[kPhases] = {};
     bool have_times = false;
-    int layer_lds = 0, band_lds = 0, usr_lds = 0, layer2_lds = 0;
+    int layer_lds = 0, band_lds = 0, solve_lds = 0, usr_lds = 0, layer2_lds = 0;
     int32_t *d_eigflag = nullptr;
     bool use_layer2 = true;
 };
@@ -414,14 +416,16 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->G = G;
     const sbd::LayerLds ll(n, nn);
     e->layer_lds = (int)sizeof(double) * ll.total * (64 / G);
-    const sbd::BandLds bl(n, nn, L, e->nlev);
+    const sbd::BandLds bl(n, nn);
     e->band_lds = (int)sizeof(double) * bl.total;
+    const sbd::SolveLds sl(n, nn, L);
+    e->solve_lds = (int)sizeof(double) * sl.total;
     e->usr_lds = (int)sizeof(double) * (nn + 2);
     auto set_lds = [&](const void *fn, int bytes) -> hipError_t {
         if (bytes <= 48 * 1024) return hipSuccess;
         return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     };
-    if (e->layer_lds > 160 * 1024 || e->band_lds > 160 * 1024) {
+    if (e->layer_lds > 160 * 1024 || e->band_lds > 160 * 1024 || e->solve_lds > 160 * 1024) {
         sbd_engine_destroy(e);
         return fail(SBD_E_UNSUPPORTED, "LDS footprint exceeds 160 KiB for this NSTR/NLYR");
     }
@@ -432,7 +436,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     case 32: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<32>, e->layer_lds)); break;
     default: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<64>, e->layer_lds)); break;
     }
-#define SBD_BAND_CASE(NNv) case NNv: CREATE_TRY(set_lds((const void *)sbd::band_kernel<NNv>, e->band_lds)); break;
+#define SBD_BAND_CASE(NNv) case NNv: CREATE_TRY(set_lds((const void *)sbd::band_kernel<NNv>, e->band_lds)); \
+                                 CREATE_TRY(set_lds((const void *)sbd::backsolve_kernel<NNv>, e->solve_lds)); break;
     switch (nn) {
         SBD_BAND_CASE(2) SBD_BAND_CASE(3) SBD_BAND_CASE(4) SBD_BAND_CASE(5) SBD_BAND_CASE(6) SBD_BAND_CASE(7)
         SBD_BAND_CASE(8) SBD_BAND_CASE(9) SBD_BAND_CASE(10) SBD_BAND_CASE(11) SBD_BAND_CASE(12) SBD_BAND_CASE(13)
@@ -485,8 +490,12 @@ int sbd_engine_quadrature(const sbd_engine *e, double *cmu, double *cwt)
 double sbd_engine_last_ms(sbd_engine *e, int phase)
 {
     if (!e || !e->have_times) return -1.0;
-    if (phase < 0) return (double)(e->ms_phase[0] + e->ms_phase[1] + e->ms_phase[2] + e->ms_phase[3]);
-    if (phase > 3) return -1.0;
+    if (phase < 0) {
+        double t = 0.0;
+        for (float m : e->ms_phase) t += (double)m;
+        return t;
+    }
+    if (phase >= sbd_engine::kPhases) return -1.0;
     return (double)e->ms_phase[phase];
 }
 
@@ -535,7 +544,7 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
     const bool timing = e->timing;
     const bool dbg = getenv("SBD_DEBUG_SYNC") != nullptr;
 #define SBD_DBG(tag) do { if (dbg) { hipError_t de_ = hipStreamSynchronize(st); fprintf(stderr, "[sbd] %s: %s (eigflag=%p partial=%p ws=%p..%p)\n", tag, hipGetErrorString(de_), (void*)e->d_eigflag, (void*)e->d_partial, (void*)e->d_ws, (void*)(e->d_ws + e->ws_bytes)); } } while (0)
-    float acc_ms[4] = {0, 0, 0, 0};
+    float acc_ms[sbd_engine::kPhases] = {};
     for (int w0 = 0; w0 < in->nwork; w0 += e->chunk) {
         const int ns = (in->nwork - w0 < e->chunk) ? in->nwork - w0 : e->chunk;
         sbd::Params P = e->P;
@@ -595,17 +604,31 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
         }
         SBD_DBG("band");
         if (timing) HIP_TRY(hipEventRecord(e->ev[3], st));
+        {
+            const dim3 bgrid((unsigned)((size_t)ns * nmode));
+#define SBD_BAND_CASE(NNv) case NNv: hipLaunchKernelGGL(sbd::backsolve_kernel<NNv>, bgrid, dim3(64), e->solve_lds, st, P); break;
+            switch (e->nn) {
+                SBD_BAND_CASE(2) SBD_BAND_CASE(3) SBD_BAND_CASE(4) SBD_BAND_CASE(5) SBD_BAND_CASE(6) SBD_BAND_CASE(7)
+                SBD_BAND_CASE(8) SBD_BAND_CASE(9) SBD_BAND_CASE(10) SBD_BAND_CASE(11) SBD_BAND_CASE(12) SBD_BAND_CASE(13)
+                SBD_BAND_CASE(14) SBD_BAND_CASE(15) SBD_BAND_CASE(16) SBD_BAND_CASE(17) SBD_BAND_CASE(18) SBD_BAND_CASE(19)
+                SBD_BAND_CASE(20)
+            default: break;
+            }
+#undef SBD_BAND_CASE
+        }
+        SBD_DBG("backsolve");
+        if (timing) HIP_TRY(hipEventRecord(e->ev[4], st));
         if (rad) {
             hipLaunchKernelGGL(sbd::usrint_kernel, dim3((unsigned)((size_t)ns * nmode)), dim3(64), e->usr_lds, st, P);
             const long long items = (long long)ns * nlev * e->P.numu;
             hipLaunchKernelGGL(sbd::azimuth_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, P, e->naz_run);
         }
         hipLaunchKernelGGL(finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, P);
-        if (timing) HIP_TRY(hipEventRecord(e->ev[4], st));
+        if (timing) HIP_TRY(hipEventRecord(e->ev[5], st));
         HIP_TRY(hipGetLastError());
         if (timing) {
-            HIP_TRY(hipEventSynchronize(e->ev[4]));
-            for (int ph = 0; ph < 4; ++ph) {
+            HIP_TRY(hipEventSynchronize(e->ev[sbd_engine::kPhases]));
+            for (int ph = 0; ph < sbd_engine::kPhases; ++ph) {
                 float ms = 0.f;
                 HIP_TRY(hipEventElapsedTime(&ms, e->ev[ph], e->ev[ph + 1]));
                 acc_ms[ph] += ms;
@@ -613,7 +636,7 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
         }
     }
     if (timing) {
-        for (int ph = 0; ph < 4; ++ph) e->ms_phase[ph] = acc_ms[ph];
+        for (int ph = 0; ph < sbd_engine::kPhases; ++ph) e->ms_phase[ph] = acc_ms[ph];
         e->have_times = true;
     }
     return SBD_OK;

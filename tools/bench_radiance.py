@@ -23,5 +23,5 @@ eng.solve(*ins); torch.cuda.synchronize()
 eng.enable_timing(True)
 t0 = time.perf_counter(); f, uu, st = eng.solve(*ins); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"radiance nstr={nstr}: {sw.nwork} solves ({nwl} spectral points) x {nstr} azimuth modes in {dt*1e3:.1f} ms -> "
-      f"{nwl/dt:.0f} spectral-points/s, chunk {eng.chunk}, phases ms {[round(eng.last_ms(p),2) for p in range(4)]}, "
+      f"{nwl/dt:.0f} spectral-points/s, chunk {eng.chunk}, phases ms {[round(eng.last_ms(p),2) for p in range(5)]}, "
       f"status!=0: {int((st!=0).sum())}, finite {bool(torch.isfinite(uu).all())}")
