@@ -134,7 +134,7 @@ struct RowUpdate {   // rows I..LAST of one column: a(i) += tj * m(i); lane i ho
             fmas<U + 1>(tj, mreg, a);
         }
     }
-    SBD_DEVICE static void run(double *colp, double mreg, double tj, bool nostore = false)
+    SBD_DEVICE static void run(double *colp, double mreg, double tj)
     {
         if constexpr (I <= LAST) {
             constexpr int CNT = LAST - I + 1;
@@ -142,13 +142,31 @@ struct RowUpdate {   // rows I..LAST of one column: a(i) += tj * m(i); lane i ho
             loads<0>(lds_addr(colp), a);
             lds_wait();
             fmas<0>(tj, mreg, a);
-            if (tj != 0.0 && !nostore) {                                // SAXPY's early return
+            if (tj != 0.0) {                                            // SAXPY's early return
 #pragma unroll
                 for (int u = 0; u < CNT; ++u) colp[(I + u) * STRIDE] = a[u];
             }
         }
     }
 };
+
+// rows 1..R of one window column, R = the smallest of four compile-time counts >= lme
+template <int R, int STRIDE>
+SBD_DEVICE void update_rows_fixed(double *colp, double mreg, double tj)
+{
+    constexpr int H = (R + 1) / 2;                   // two batches: loads in flight vs registers
+    RowUpdate<1, H, STRIDE>::run(colp, mreg, tj);
+    RowUpdate<H + 1, R, STRIDE>::run(colp, mreg, tj);
+}
+template <int NN>
+SBD_DEVICE void update_rows(double *colp, double mreg, double tj, int lme)
+{
+    constexpr int ncd = 3 * NN - 1, CWP = (2 * ncd + 1) | 1, D = (2 * NN + 3) / 4;
+    if (lme > ncd - D) update_rows_fixed<ncd, CWP>(colp, mreg, tj);
+    else if (lme > ncd - 2 * D) update_rows_fixed<ncd - D, CWP>(colp, mreg, tj);
+    else if (lme > ncd - 3 * D) update_rows_fixed<ncd - 2 * D, CWP>(colp, mreg, tj);
+    else update_rows_fixed<ncd - 3 * D, CWP>(colp, mreg, tj);
+}
 
 template <int NN>
 __global__ void __launch_bounds__(64) band_kernel(Params P)
@@ -445,33 +463,21 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             if (two && lane + 64 <= wmax && lane + 64 < CW) urow[lane + 64] = tj2;
         }
         wave_lds_sync();
-        // (E) rank-1 update: lane c <-> column k+c (c >= 1).  LDS round trip 3: the multipliers
-        //     (broadcast reads) and all rows of the lane's column in one batch with immediate
-        //     offsets; FMAs; stores
-        if (piv != 0.0) {
+        // (E) rank-1 update: lane c <-> column k+c (c >= 1).  LDS round trip 3: all rows of the
+        //     lane's column in one batch with immediate offsets; FMAs with the multipliers read
+        //     lane by lane through SGPRs; stores.  Only rows up to the last non-zero multiplier
+        //     take part: column k of a layer's block is structurally empty below the next
+        //     interface (3nn - j rows for the j-th column of a layer instead of NCD), and a
+        //     zero multiplier leaves its row unchanged in LINPACK as well.
+        const unsigned long long nzm = __ballot(mreg != 0.0);
+        if (nzm != 0ull) {
+            const int lme = 63 - __clzll((long long)nzm);    // rows k+1..k+lme
             const int ncols = ju - k;                        // columns k+1..ju
-            {
-                const bool actv = lane >= 1 && lane <= ncols;
-                const double t1 = actv ? tj : 0.0;
-                double *colp = rowk + pcl;
-                if (lm == ncd) {                   // full window: compile-time row count, two halves
-                    constexpr int H = (ncd + 1) / 2;
-                    RowUpdate<1, H, CWP>::run(colp, mreg, t1, (P.dbg & 16) != 0);      // inactive lanes: t1 = 0, no stores
-                    RowUpdate<H + 1, ncd, CWP>::run(colp, mreg, t1, (P.dbg & 16) != 0);
-                    if (two && ncols >= 64) {
-                        const double t2 = (lane + 64 <= ncols) ? tj2 : 0.0;
-                        double *colp2 = rowk + pcl2;
-                        RowUpdate<1, H, CWP>::run(colp2, mreg, t2);
-                        RowUpdate<H + 1, ncd, CWP>::run(colp2, mreg, t2);
-                    }
-                } else {                           // the last NCD steps: shrinking window
-                    const double t2 = (two && lane + 64 <= ncols) ? tj2 : 0.0;
-                    for (int i = 1; i <= lm; ++i) {
-                        const double mi = __shfl(mreg, i, 64);
-                        if (t1 != 0.0) colp[i * CWP] = colp[i * CWP] + t1 * mi;
-                        if (two && t2 != 0.0) rowk[pcl2 + i * CWP] = rowk[pcl2 + i * CWP] + t2 * mi;
-                    }
-                }
+            const double t1 = (lane >= 1 && lane <= ncols) ? tj : 0.0;    // inactive lanes: no stores
+            update_rows<NN>(rowk + pcl, mreg, t1, lme);
+            if (two && ncols >= 64) {
+                const double t2 = (lane + 64 <= ncols) ? tj2 : 0.0;
+                update_rows<NN>(rowk + pcl2, mreg, t2, lme);
             }
         }
         wave_lds_sync();
@@ -490,7 +496,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             wave_lds_sync();
         }
     };
-    for (int k = 1; k <= ((P.dbg & 64) ? 0 : N - 1); k += U) {
+    for (int k = 1; k <= N - 1; k += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (k + u <= N - 1) step(k + u, pre[u]);
