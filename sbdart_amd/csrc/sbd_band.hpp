@@ -32,15 +32,15 @@ constexpr int kBackBlock = 8;     // columns per back-substitution block
 
 struct BandLds {   // per-wave carve-up of the LU kernel (doubles)
     int rw, cw, cwp, win, bw, misc, total;
-    __host__ __device__ BandLds(int n, int nn)
+    __host__ __device__ BandLds(int n, int nn, bool reg)
     {
         const int ncd = 3 * nn - 1;
         rw = ncd + 1;
         cw = 2 * ncd + 1;
         cwp = cw | 1;
         win = 0;                                                    // sliding window ...
-        bw = win + (rw + kBandMargin) * cwp;                        // ... + its RHS entries
-        misc = bw + ((rw + kBandMargin + 2) & ~1);
+        bw = win + (reg ? ((rw + 1) & ~1) : (rw + kBandMargin) * cwp);   // (register variant: the pivot column only)
+        misc = bw + (reg ? 0 : ((rw + kBandMargin + 2) & ~1));      // ... + its RHS entries
         total = (misc + 8 + n + 1) & ~1;                            // [n] surface-reflection sums
     }
 };
@@ -168,7 +168,33 @@ SBD_DEVICE void update_rows(double *colp, double mreg, double tj, int lme)
     else update_rows_fixed<ncd - 3 * D, CWP>(colp, mreg, tj);
 }
 
-template <int NN>
+// register-window helpers (band_kernel<NN, true>)
+// t = a[idx], a[idx] = a[0] for a wave-uniform idx: a tree of scalar branches, one leaf runs
+template <int LO, int HI, int RW>
+SBD_DEVICE void take_row(double (&a)[RW], int idx, double &t)
+{
+    if constexpr (LO == HI) {
+        t = a[LO];
+        if constexpr (LO != 0) a[LO] = a[0];
+        asm volatile("" : "+v"(t));                  // keep the leaves as branches, not selects
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (idx <= MID) take_row<LO, MID>(a, idx, t);
+        else take_row<MID + 1, HI>(a, idx, t);
+    }
+}
+// a[i-1] = a[i] + t * m(i) for i <= R (lane i holds m(i) in mreg), a[i-1] = a[i] beyond
+template <int R, int RW>
+SBD_DEVICE void update_shift(double (&a)[RW], double t, double mreg)
+{
+    static_for<RW - 1>([&](auto ii) {
+        constexpr int i = decltype(ii)::value + 1;
+        if constexpr (i <= R) a[i - 1] = a[i] + t * bcast_lane<i>(mreg);
+        else a[i - 1] = a[i];
+    });
+}
+
+template <int NN, bool REG>
 __global__ void __launch_bounds__(64) band_kernel(Params P)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -203,7 +229,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     const double umu0 = P.umu0;
     const double *cmu = P.t.cmu, *cwt = P.t.cwt;
 
-    const BandLds lds(n, nn);
+    const BandLds lds(n, nn, REG);
     constexpr int ncd = 3 * NN - 1, RW = ncd + 1, CW = 2 * ncd + 1, CWP = CW | 1, MG = kBandMargin;
     double *win = smem + lds.win;
     double *bw = smem + lds.bw;                       // RHS entries of the window rows (LU phase)
@@ -287,7 +313,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             }
         }
         yv[it - 1] = v;
-        if (it <= RW) bw[it - 1] = v;
+        if (!REG && it <= RW) bw[it - 1] = v;
     }
     __threadfence_block();   // RHS in HBM is re-read by this wave (row prefetch)
     wave_lds_sync();
@@ -324,6 +350,159 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         }
     };
 
+    const double *ga_ms = P.ga + (size_t)ms * L * n * n;
+    const double *gb_ms = P.gb + (size_t)ms * L * n * n + (size_t)n * n;    // block of layer lc+1
+    auto row_elem = [&](int r, int col) -> double {      // element (r, col) of an entering row
+        if (col > N) return 0.0;
+        if (r > nn && r <= N - nn) {         // interface row: matrix-ready blocks, unit stride
+            const int qq = r - nn - 1;                   // row jq = qq % n of interface lc = qq / n + 1
+            const int d = col - (qq / n) * n;            // 1..2n inside the row's support
+            const int qs = (P.dbg & 8) ? n + qq % n : qq;   // profiling: always the same (cached) block
+            if (d >= 1 && d <= n) return ga_ms[(size_t)qs * n + d - 1];
+            if (d > n && d <= 2 * n) return gb_ms[(size_t)qs * n + d - n - 1];
+            return 0.0;
+        }
+        double g, f;                         // boundary rows
+        entry(r, col, g, f);
+        return g * f;
+    };
+
+    if constexpr (REG) {
+        // ================= register-resident window (NSTR <= 20) =================
+        // The window never touches LDS: lane l < 63 owns the column j == l (mod 63) and keeps
+        // its RW window rows in registers (a[i] = A(k+i, j)); lane 63 carries the right-hand
+        // side as one more column, so interchange and elimination treat it like the rest
+        // (SGBSL's forward sweep, disutil.f:1019-1036).  One step: the pivot column crosses
+        // to "lane t <-> row k+t" through RW doubles of LDS for the DPP pivot search; the pivot
+        // row is taken out of its register (row k's old content takes its place: LINPACK's
+        // interchange), retired to U in HBM, and rows 1.. slide down one register inside the
+        // elimination FMAs whose multipliers arrive through SGPRs.  A column's lane is reused
+        // 63 - CW steps after it left the window and is cleared in between.
+        static_assert(!REG || (2 * (3 * NN - 1) + 1) <= 59, "register variant: window must fit 63 lanes");
+        constexpr int RING = 63;
+        constexpr int ZPER = ((RING - CW) / 4) * 4;      // clearing period of idle lanes (steps)
+        double *tcol = smem + lds.win;                   // [RW] pivot column, transposed
+        double a[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) a[i] = 0.0;
+        int status = 0;
+        int km = 1 % RING;                               // k mod RING
+        const bool rhs = lane == 63;
+        auto elem_for = [&](int r, int kmr, int kfirst) -> double {   // row r, lane's column when k = kfirst
+            if (r > N) return 0.0;
+            if (rhs) return yv[r - 1];
+            int c = lane - kmr;
+            if (c < 0) c += RING;
+            return (c < CW) ? row_elem(r, kfirst + c) : 0.0;
+        };
+        // rows 1..RW enter through the same shift register, PB rows per batch of loads
+        {
+            constexpr int PB = 6;
+            for (int r0 = 1; r0 <= RW; r0 += PB) {
+                double tmp[PB];
+#pragma unroll
+                for (int j = 0; j < PB; ++j) tmp[j] = (r0 + j <= RW) ? elem_for(r0 + j, km, 1) : 0.0;
+#pragma unroll
+                for (int j = 0; j < PB; ++j) {
+                    if (r0 + j <= RW) {
+                        static_for<RW - 1>([&](auto ii) { constexpr int i = decltype(ii)::value; a[i] = a[i + 1]; });
+                        a[RW - 1] = tmp[j];
+                    }
+                }
+            }
+        }
+        constexpr int U = 4;
+        double pre[U];
+        auto load_row = [&](int r, double &g) {          // row r enters at the end of step r - RW
+            const int k1 = r - RW + 1;
+            g = elem_for(r, k1 % RING, k1);
+        };
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_row(RW + 1 + u, pre[u]);
+        auto step = [&](const int k, double &pq) {
+            const int lm = (ncd < N - k) ? ncd : N - k;
+            // (A) pivot column -> lanes (lane t <-> row k+t)
+            if (lane == km) {
+#pragma unroll
+                for (int i = 0; i < RW; ++i) tcol[i] = a[i];
+            }
+            wave_lds_sync();
+            double ak = 0.0, v = -1.0;
+            int idx = 1 << 30;
+            if (lane <= lm) {
+                ak = tcol[lane];
+                v = fabs(ak);
+                idx = lane;
+            }
+            double rk = __builtin_amdgcn_rcp(ak);        // -1/a for every candidate (v_rcp + 2 Newton steps)
+            rk = rk * (2.0 - ak * rk);
+            rk = rk * (2.0 - ak * rk);
+            rk = -rk;
+            // (B) ISAMAX's first-maximum rule on the DPP network
+            wave_argmax<false>(v, idx);
+            if (!(v > 0.0)) idx = 0;                     // all-zero (or NaN) column: keep the diagonal, flag it
+            auto pick = [&](double x, int src) {
+                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src),
+                                        __builtin_amdgcn_readlane(__double2loint(x), src));
+            };
+            const double piv = pick(ak, idx), tsel = pick(rk, idx);
+            const double akk = bcast_lane<0>(ak);
+            if (piv == 0.0) status |= 0x01;
+            const double tinv = (piv != 0.0) ? tsel : 0.0;
+            // (C) multipliers -a/pivot (after the interchange), lane t holds the one of row k+t
+            double mreg = 0.0;
+            if (lane >= 1 && lane <= lm) mreg = ((lane == idx) ? akk : ak) * tinv;
+            // (D) pivot row out of its register, old row k into that register
+            double tj;
+            take_row<0, RW - 1>(a, idx, tj);
+            // (E) U(k, k..k+2ncd) row-major to HBM; forward-eliminated B(k)
+            {
+                int c = lane - km;
+                if (c < 0) c += RING;
+                const int wmax = (2 * ncd < N - k) ? 2 * ncd : N - k;
+                if (!rhs && c <= wmax) ufac[(size_t)(k - 1) * CW + c] = tj;
+                if (rhs) yv[k - 1] = tj;
+            }
+            // (F) elimination + slide: a[i-1] = a[i] + tj * m(i) for the rows with a non-zero
+            //     multiplier (structural zeros below the next interface), plain moves beyond
+            const unsigned long long nzm = __ballot(mreg != 0.0);
+            const int lme = nzm ? 63 - __clzll((long long)nzm) : 0;
+            {
+                constexpr int D = (2 * NN + 3) / 4;
+                if (lme > ncd - D) update_shift<ncd>(a, tj, mreg);
+                else if (lme > ncd - 2 * D) update_shift<ncd - D>(a, tj, mreg);
+                else if (lme > ncd - 3 * D) update_shift<ncd - 2 * D>(a, tj, mreg);
+                else if (lme > 0) update_shift<ncd - 3 * D>(a, tj, mreg);
+                else update_shift<0>(a, tj, mreg);
+            }
+            // (G) the entering row takes the last register
+            a[RW - 1] = pq;
+            km = (km + 1 == RING) ? 0 : km + 1;
+            load_row(k + RW + U, pq);
+        };
+        for (int k = 1; k <= N - 1; k += U) {
+            if (((k - 1) % ZPER) == 0) {                 // clear the lanes whose column has left the window
+                int c = lane - km;
+                if (c < 0) c += RING;
+                if (!rhs && c >= CW) {
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) a[i] = 0.0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + u <= N - 1) step(k + u, pre[u]);
+        }
+        {   // last row
+            const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[0]), km),
+                                              __builtin_amdgcn_readlane(__double2loint(a[0]), km));
+            if (d == 0.0) status |= 0x01;
+            if (lane == km) ufac[(size_t)(N - 1) * CW] = a[0];
+            if (rhs) yv[N - 1] = a[0];
+        }
+        if (status && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], status);
+        return;
+    }
     // logical row k+i lives in physical row kq+i (kq = k - kbase < MARGIN, re-based every
     // MARGIN steps); column j sits at ring position j % CW, tracked by a wrap-around counter
     {
@@ -348,22 +527,6 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     // Lane mapping of a step: lane c <-> window column k+c (c = 0 is the pivot column); its
     // ring position also serves column k+CW of the entering row.
     struct Pre { double g0, g1, bv; };
-    const double *ga_ms = P.ga + (size_t)ms * L * n * n;
-    const double *gb_ms = P.gb + (size_t)ms * L * n * n + (size_t)n * n;    // block of layer lc+1
-    auto row_elem = [&](int r, int col) -> double {      // element (r, col) of an entering row
-        if (col > N) return 0.0;
-        if (r <= N - nn) {                   // interface row: matrix-ready blocks, unit stride
-            const int qq = r - nn - 1;                   // row jq = qq % n of interface lc = qq / n + 1
-            const int d = col - (qq / n) * n;            // 1..2n inside the row's support
-            const int qs = (P.dbg & 8) ? n + qq % n : qq;   // profiling: always the same (cached) block
-            if (d >= 1 && d <= n) return ga_ms[(size_t)qs * n + d - 1];
-            if (d > n && d <= 2 * n) return gb_ms[(size_t)qs * n + d - n - 1];
-            return 0.0;
-        }
-        double g, f;                         // bottom-boundary rows
-        entry(r, col, g, f);
-        return g * f;
-    };
     auto load_row = [&](int r, Pre &q) {
         q.g0 = 0.0; q.g1 = 0.0; q.bv = 0.0;
         if (r <= N) {

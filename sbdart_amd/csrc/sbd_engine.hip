@@ -177,6 +177,7 @@ struct sbd_engine {
     int layer_lds = 0, band_lds = 0, solve_lds = 0, usr_lds = 0, layer2_lds = 0;
     int32_t *d_eigflag = nullptr;
     bool use_layer2 = true;
+    bool band_reg = false;
 };
 
 extern "C" {
@@ -416,7 +417,9 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->G = G;
     const sbd::LayerLds ll(n, nn);
     e->layer_lds = (int)sizeof(double) * ll.total * (64 / G);
-    const sbd::BandLds bl(n, nn);
+    e->band_reg = nn <= 10;                       // register-resident LU window (sbd_band.hpp)
+    if (const char *s = getenv("SBD_BAND_LDS")) e->band_reg = e->band_reg && atoi(s) == 0;
+    const sbd::BandLds bl(n, nn, e->band_reg);
     e->band_lds = (int)sizeof(double) * bl.total;
     const sbd::SolveLds sl(n, nn, L);
     e->solve_lds = (int)sizeof(double) * sl.total;
@@ -436,7 +439,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     case 32: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<32>, e->layer_lds)); break;
     default: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<64>, e->layer_lds)); break;
     }
-#define SBD_BAND_CASE(NNv) case NNv: CREATE_TRY(set_lds((const void *)sbd::band_kernel<NNv>, e->band_lds)); \
+#define SBD_BAND_CASE(NNv) case NNv: CREATE_TRY(set_lds((const void *)sbd::band_kernel<NNv, false>, e->band_lds)); \
                                  CREATE_TRY(set_lds((const void *)sbd::backsolve_kernel<NNv>, e->solve_lds)); break;
     switch (nn) {
         SBD_BAND_CASE(2) SBD_BAND_CASE(3) SBD_BAND_CASE(4) SBD_BAND_CASE(5) SBD_BAND_CASE(6) SBD_BAND_CASE(7)
@@ -592,7 +595,15 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
         if (timing) HIP_TRY(hipEventRecord(e->ev[2], st));
         {
             const dim3 bgrid((unsigned)((size_t)ns * nmode));
-#define SBD_BAND_CASE(NNv) case NNv: hipLaunchKernelGGL(sbd::band_kernel<NNv>, bgrid, dim3(64), e->band_lds, st, P); break;
+#define SBD_BAND_CASE(NNv) case NNv: hipLaunchKernelGGL((sbd::band_kernel<NNv, false>), bgrid, dim3(64), e->band_lds, st, P); break;
+#define SBD_BANDR_CASE(NNv) case NNv: hipLaunchKernelGGL((sbd::band_kernel<NNv, true>), bgrid, dim3(64), e->band_lds, st, P); break;
+            if (e->band_reg) {
+                switch (e->nn) {
+                    SBD_BANDR_CASE(2) SBD_BANDR_CASE(3) SBD_BANDR_CASE(4) SBD_BANDR_CASE(5) SBD_BANDR_CASE(6)
+                    SBD_BANDR_CASE(7) SBD_BANDR_CASE(8) SBD_BANDR_CASE(9) SBD_BANDR_CASE(10)
+                default: break;
+                }
+            } else
             switch (e->nn) {
                 SBD_BAND_CASE(2) SBD_BAND_CASE(3) SBD_BAND_CASE(4) SBD_BAND_CASE(5) SBD_BAND_CASE(6) SBD_BAND_CASE(7)
                 SBD_BAND_CASE(8) SBD_BAND_CASE(9) SBD_BAND_CASE(10) SBD_BAND_CASE(11) SBD_BAND_CASE(12) SBD_BAND_CASE(13)
@@ -601,6 +612,7 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
             default: break;
             }
 #undef SBD_BAND_CASE
+#undef SBD_BANDR_CASE
         }
         SBD_DBG("band");
         if (timing) HIP_TRY(hipEventRecord(e->ev[3], st));
