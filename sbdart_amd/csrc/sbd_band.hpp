@@ -388,8 +388,25 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         int status = 0;
         int km = 1 % RING;                               // k mod RING
         const bool rhs = lane == 63;
-        auto elem_for = [&](int r, int kmr, int kfirst) -> double {   // row r, lane's column when k = kfirst
+        // interface row r (nn < r <= N-nn) for the lane's column when k = kfirst: ONE load per
+        // lane whatever it carries (the right-hand side, the layer-lc block or the layer-lc+1
+        // block) and no other memory operation, so that nothing waits on it before its use
+        auto elem_fast = [&](int r, int kmr, int kfirst) -> double {
+            int c = lane - kmr;
+            if (c < 0) c += RING;
+            const int col = kfirst + c;
+            const int qq = r - nn - 1;
+            const int d = col - (qq / n) * n;                    // 1..2n inside the row's support
+            const double *p = rhs ? yv + (r - 1)
+                                  : (d <= n ? ga_ms + ((size_t)qq * n + d - 1) : gb_ms + ((size_t)qq * n + d - n - 1));
+            const bool valid = rhs || (c < CW && col <= N && d >= 1 && d <= 2 * n);
+            double g = 0.0;
+            if (valid) g = *p;
+            return g;
+        };
+        auto elem_for = [&](int r, int kmr, int kfirst) -> double {   // any row (boundary rows included)
             if (r > N) return 0.0;
+            if (r > nn && r <= N - nn) return elem_fast(r, kmr, kfirst);
             if (rhs) return yv[r - 1];
             int c = lane - kmr;
             if (c < 0) c += RING;
@@ -413,13 +430,14 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         }
         constexpr int U = 4;
         double pre[U];
-        auto load_row = [&](int r, double &g) {          // row r enters at the end of step r - RW
+        auto load_row = [&](int r, double &g, auto fast) {   // row r enters at the end of step r - RW
             const int k1 = r - RW + 1;
-            g = elem_for(r, k1 % RING, k1);
+            if constexpr (decltype(fast)::value) g = elem_fast(r, k1 % RING, k1);
+            else g = elem_for(r, k1 % RING, k1);
         };
 #pragma unroll
-        for (int u = 0; u < U; ++u) load_row(RW + 1 + u, pre[u]);
-        auto step = [&](const int k, double &pq) {
+        for (int u = 0; u < U; ++u) load_row(RW + 1 + u, pre[u], std::false_type{});
+        auto step = [&](const int k, double &pq, auto fast) {
             const int lm = (ncd < N - k) ? ncd : N - k;
             // (A) pivot column -> lanes (lane t <-> row k+t)
             if (lane == km) {
@@ -475,12 +493,21 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
                 else if (lme > 0) update_shift<ncd - 3 * D>(a, tj, mreg);
                 else update_shift<0>(a, tj, mreg);
             }
-            // (G) the entering row takes the last register
-            a[RW - 1] = pq;
+            // (G) the entering row takes the last register.  An explicit move: the prefetched
+            //     value keeps a register of its own for the whole loop, so the only wait for its
+            //     load sits here, U steps after the issue
+            asm volatile("v_mov_b64 %0, %1" : "=v"(a[RW - 1]) : "v"(pq));
             km = (km + 1 == RING) ? 0 : km + 1;
-            load_row(k + RW + U, pq);
+            load_row(k + RW + U, pq, fast);
         };
-        for (int k = 1; k <= N - 1; k += U) {
+        // every load so far has landed before the loop: its waits then only count the loop's own
+        // loads (vmcnt(0), expcnt/lgkmcnt unconstrained)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        int k = 1;
+        // steady state: whole groups of U steps whose entering rows are all interface rows (no
+        // exits and a single kind of load inside, so the loads stay in flight across steps)
+        const int kfast = N - nn - RW - U;               // last step whose load is an interface row
+        for (; k + U - 1 <= kfast; k += U) {
             if (((k - 1) % ZPER) == 0) {                 // clear the lanes whose column has left the window
                 int c = lane - km;
                 if (c < 0) c += RING;
@@ -490,8 +517,22 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
                 }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (k + u <= N - 1) step(k + u, pre[u]);
+            for (int u = 0; u < U; ++u) step(k + u, pre[u], std::true_type{});
+        }
+        for (; k <= N - 1; ++k) {                        // the tail: boundary rows enter, then nothing
+            {
+                int c = lane - km;
+                if (c < 0) c += RING;
+                if (!rhs && c >= CW) {
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) a[i] = 0.0;
+                }
+            }
+            step(k, pre[0], std::false_type{});          // consumes pre[0], reloads it for step k+U
+            const double newest = pre[0];
+#pragma unroll
+            for (int u = 0; u + 1 < U; ++u) pre[u] = pre[u + 1];
+            pre[U - 1] = newest;
         }
         {   // last row
             const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[0]), km),
