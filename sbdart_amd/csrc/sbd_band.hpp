@@ -58,37 +58,39 @@ struct SolveLds {   // per-wave carve-up of the back-substitution + flux kernel 
     }
 };
 
-// (value, index) arg-max over the low lanes of the wave with LINPACK's first-maximum tie
-// rule, on the DPP network (no LDS round trips): an inclusive max-scan towards the higher
-// lanes inside each row of 16 (row_shr 1,2,4,8), then row_bcast15 (and row_bcast31 when more
-// than 32 candidates).  At every step the incoming value stems from lower lanes only, so
-// "incoming >= mine" keeps the smallest index among equal maxima.  Result in lane 31 / 63.
-template <int CTRL, int ROWMASK>
-SBD_DEVICE void argmax_step(double &v, int &idx)
+// Pivot search over the low lanes of the wave with LINPACK's first-maximum tie rule, on the DPP
+// network (no LDS round trips), in two moves: the maximum magnitude by an inclusive max-scan
+// towards the higher lanes inside each row of 16 (row_shr 1,2,4,8; invalid sources read 0.0,
+// neutral for magnitudes), then row_bcast15 (and row_bcast31 when more than 32 candidates), so
+// that lane 31 / 63 holds it; then the first lane that holds it (ballot + find-first-set):
+// ISAMAX's tie rule without carrying indices through the scan.
+// v >= 0 on the candidate lanes 0..lm, anything on the others.  Returns the lane, 0 when the
+// whole column is zero (or NaN); vmax gets the magnitude.
+template <int CTRL, int ROWMASK, bool BOUND>
+SBD_DEVICE double dpp_max_step(double v)
 {
     const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROWMASK, 0xF, false);
-    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROWMASK, 0xF, false);
-    const int oi = __builtin_amdgcn_update_dpp(idx, idx, CTRL, ROWMASK, 0xF, false);
-    const double ov = __hiloint2double(ohi, olo);
-    const bool take = ov >= v;
-    v = take ? ov : v;
-    idx = take ? oi : idx;
+    const int olo = __builtin_amdgcn_update_dpp(BOUND ? 0 : lo, lo, CTRL, ROWMASK, 0xF, BOUND);
+    const int ohi = __builtin_amdgcn_update_dpp(BOUND ? 0 : hi, hi, CTRL, ROWMASK, 0xF, BOUND);
+    return fmax(v, __hiloint2double(ohi, olo));
 }
 template <bool WIDE>
-SBD_DEVICE void wave_argmax(double &v, int &idx)
+SBD_DEVICE int wave_first_max(double vabs, int lm, double &vmax)
 {
-    argmax_step<0x111, 0xF>(v, idx);   // row_shr:1
-    argmax_step<0x112, 0xF>(v, idx);   // row_shr:2
-    argmax_step<0x114, 0xF>(v, idx);   // row_shr:4
-    argmax_step<0x118, 0xF>(v, idx);   // row_shr:8
-    argmax_step<0x142, 0xA>(v, idx);   // row_bcast:15 -> rows 1,3
-    if (WIDE) argmax_step<0x143, 0xC>(v, idx);   // row_bcast:31 -> rows 2,3
+    const bool cand = (int)threadIdx.x <= lm;
+    double v = cand ? vabs : 0.0;
+    const double v0 = v;
+    v = dpp_max_step<0x111, 0xF, true>(v);    // row_shr:1
+    v = dpp_max_step<0x112, 0xF, true>(v);    // row_shr:2
+    v = dpp_max_step<0x114, 0xF, true>(v);    // row_shr:4
+    v = dpp_max_step<0x118, 0xF, true>(v);    // row_shr:8
+    v = dpp_max_step<0x142, 0xA, false>(v);   // row_bcast:15 -> rows 1,3
+    if (WIDE) v = dpp_max_step<0x143, 0xC, false>(v);   // row_bcast:31 -> rows 2,3
     constexpr int SRC = WIDE ? 63 : 31;
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
-    v = __hiloint2double(hi, lo);
-    idx = __builtin_amdgcn_readlane(idx, SRC);
+    vmax = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), SRC),
+                            __builtin_amdgcn_readlane(__double2loint(v), SRC));
+    const unsigned long long hit = __ballot(cand && v0 == vmax);
+    return (vmax > 0.0 && hit != 0ull) ? __ffsll((long long)hit) - 1 : 0;
 }
 
 // broadcast lane `src` (compile-time) of a double to the whole wave through SGPRs
@@ -183,7 +185,7 @@ SBD_DEVICE void take_row(double (&a)[RW], int idx, double &t)
         else take_row<MID + 1, HI>(a, idx, t);
     }
 }
-// a[i-1] = a[i] + t * m(i) for i <= R (lane i holds m(i) in mreg), a[i-1] = a[i] beyond
+// a[i-1] = a[i] + t * m(i) for i <= R (lane i holds m(i) in mreg, read through SGPRs), a[i-1] = a[i] beyond
 template <int R, int RW>
 SBD_DEVICE void update_shift(double (&a)[RW], double t, double mreg)
 {
@@ -445,20 +447,15 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
                 for (int i = 0; i < RW; ++i) tcol[i] = a[i];
             }
             wave_lds_sync();
-            double ak = 0.0, v = -1.0;
-            int idx = 1 << 30;
-            if (lane <= lm) {
-                ak = tcol[lane];
-                v = fabs(ak);
-                idx = lane;
-            }
+            double ak = 0.0;
+            if (lane <= lm) ak = tcol[lane];
             double rk = __builtin_amdgcn_rcp(ak);        // -1/a for every candidate (v_rcp + 2 Newton steps)
             rk = rk * (2.0 - ak * rk);
             rk = rk * (2.0 - ak * rk);
             rk = -rk;
             // (B) ISAMAX's first-maximum rule on the DPP network
-            wave_argmax<false>(v, idx);
-            if (!(v > 0.0)) idx = 0;                     // all-zero (or NaN) column: keep the diagonal, flag it
+            double vmax;
+            const int idx = wave_first_max<false>(fabs(ak), lm, vmax);
             auto pick = [&](double x, int src) {
                 return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src),
                                         __builtin_amdgcn_readlane(__double2loint(x), src));
@@ -592,13 +589,9 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         // LDS round trip 1 (nothing here depends on the pivot): the pivot column (lane t <->
         // row k+t), the RHS entries of the window rows, and row k itself (lane c <-> column)
         double ak = 0.0, bwl = 0.0;
-        double v = -1.0;
-        int idx = 1 << 30;
         if (lane <= lm) {
             ak = rowk[lane * CWP + kc];
             bwl = bw[kq + lane];
-            v = fabs(ak);
-            idx = lane;
         }
         const double tk = rowk[pcl];
         double tk2 = 0.0;
@@ -610,8 +603,8 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         rk = rk * (2.0 - ak * rk);
         rk = -rk;
         // (B) pivot search over rows k..k+lm of column k (ISAMAX's first-maximum rule)
-        wave_argmax<(RW > 32)>(v, idx);
-        if (!(v > 0.0)) idx = 0;             // all-zero (or NaN) column: keep the diagonal, flag it
+        double vmax;                         // (an all-zero or NaN column keeps the diagonal and is flagged)
+        const int idx = wave_first_max<(RW > 32)>(fabs(ak), lm, vmax);
         const int l = k + idx;
         // idx is wave-uniform: v_readlane with a scalar lane select instead of a bpermute
         auto pick = [&](double x, int src) {

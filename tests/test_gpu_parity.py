@@ -246,19 +246,32 @@ def test_fuzz_all_stream_counts_and_layer_counts(seed):
     _check(flux, uu, st, [r for r, _ in recs], [o for _, o in recs])
 
 
+_ALT_CODE = ("import numpy as np,sys,os,json;sys.path.insert(0,'.');"
+             "from sbdart_amd.engine import solve_records;from sbdart_amd.records import read_records;"
+             "r=read_records('tests/golden/cfgB_sw_nstr16.sbdrec')[:12]+read_records('tests/golden/sbchk5.sbdrec')[:2]"
+             "+read_records('tests/golden/cfgA_sw_nstr4.sbdrec')[:4];"
+             "f,u,s=solve_records(r);"
+             "print(json.dumps([float(np.abs(f[i][c]-getattr(r[i],n)).max()/max(np.abs(getattr(r[i],n)).max(),1e-300))"
+             " for i in range(len(r)) for c,n in enumerate(('rfldir','rfldn','flup','dfdt','uavg'))]"
+             "+[float(np.abs(u[i]-r[i].uu).max()/np.abs(r[i].uu).max()) for i in range(12,14)]))")
+
+
+def _alt_path_errors(**env):
+    import subprocess, sys, json
+    from conftest import ROOT
+    out = subprocess.check_output([sys.executable, "-c", _ALT_CODE], cwd=ROOT, env=dict(os.environ, **env), text=True)
+    return json.loads(out.strip().splitlines()[-1])
+
+
+def test_lds_window_variant_matches():
+    """SBD_BAND_LDS=1 sends NSTR <= 20 through the LDS-window LU kernel (the one NSTR > 20 always
+    uses) instead of the register-window one: same answers."""
+    errs = _alt_path_errors(SBD_BAND_LDS="1")
+    assert max(errs) < TOL, max(errs)
+
+
 def test_qr_fallback_path_matches():
     """SBD_FORCE_EIG_FALLBACK routes every layer through the QR kernel (the path taken when a
     Cholesky pivot of the symmetrised problem is not positive): same answers."""
-    import subprocess, sys, json
-    code = ("import numpy as np,sys,os,json;sys.path.insert(0,'.');"
-            "from sbdart_amd.engine import solve_records;from sbdart_amd.records import read_records;"
-            "r=read_records('tests/golden/cfgB_sw_nstr16.sbdrec')[:12]+read_records('tests/golden/sbchk5.sbdrec')[:2];"
-            "f,u,s=solve_records(r);"
-            "print(json.dumps([float(np.abs(f[i][c]-getattr(r[i],n)).max()/max(np.abs(getattr(r[i],n)).max(),1e-300))"
-            " for i in range(len(r)) for c,n in enumerate(('rfldir','rfldn','flup','dfdt','uavg'))]"
-            "+[float(np.abs(u[i]-r[i].uu).max()/np.abs(r[i].uu).max()) for i in range(12,14)]))")
-    from conftest import ROOT
-    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT,
-                                  env=dict(os.environ, SBD_FORCE_EIG_FALLBACK="1"), text=True)
-    errs = json.loads(out.strip().splitlines()[-1])
+    errs = _alt_path_errors(SBD_FORCE_EIG_FALLBACK="1")
     assert max(errs) < TOL, max(errs)
