@@ -450,7 +450,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     }
 #undef SBD_BAND_CASE
     {
-        const sbd::Layer2Lds l2(n, nn);
+        const sbd::Layer2Lds l2(n, nn, rad);
         e->layer2_lds = (int)sizeof(double) * (l2.shared_total + l2.group_total * (64 / G));
         if (const char *s = getenv("SBD_LAYER_V1")) e->use_layer2 = atoi(s) == 0;
         if (e->layer2_lds > 160 * 1024) e->use_layer2 = false;

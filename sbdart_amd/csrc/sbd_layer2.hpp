@@ -14,7 +14,13 @@
 //
 // When a Cholesky pivot is not positive (non-physical moments) the group raises a flag and
 // the QR kernel of sbd_layer.hpp redoes that layer (same outputs, reference algorithm).
-// UPBEAM/UPISOT keep the reference's pivoted LU of the full NSTR x NSTR system in LDS.
+//
+// UPBEAM/UPISOT (disort.f:4130-4353) solve (D - CC) Z = rhs with the same +-mu symmetry taken
+// out: for s = Z+ + Z-, d = Z+ - Z- the NSTR x NSTR system splits into
+//     (I - S+ W) s + (M/mu0) d = r+ + r-,     (I - S- W) d + (M/mu0) s = r+ - r-,
+// i.e. ONE NSTR/2 x NSTR/2 pivoted LU of T = M/mu0 - mu0 (I - S+ W) M^-1 (I - S- W) for the
+// beam source and two (I - S+ W, I - S- W) for the thermal one (no M/mu0 coupling there) --
+// an eighth of the elimination work and a quarter of the LDS of the full system.
 #pragma once
 #include "sbd_common.hpp"
 #include "sbd_layer.hpp"
@@ -23,17 +29,17 @@ namespace sbd {
 
 struct Layer2Lds {   // doubles; per-group part + per-block shared part
     int ld, ldh, gl, sp, sm, lu, vec, group_total, shared_y, shared_total;
-    __host__ __device__ Layer2Lds(int n, int nn)
+    __host__ __device__ Layer2Lds(int n, int nn, bool rad)
     {
         ld = n | 1;
         ldh = nn | 1;
         gl = 0;
         sp = gl + ((n + 2) & ~1);
         sm = sp + nn * ldh;
-        lu = sm + nn * ldh;
-        const int a = n * ld, b2 = 2 * nn * ldh;
-        vec = lu + (a > b2 ? a : b2);
-        group_total = (vec + 5 * n + (n + 1) / 2 + 2 + 1) & ~1;   // zjs,z0s,z1s,psi[2n], ipvt[n] ints
+        lu = sm + nn * ldh;                 // Q+ | Q-, later the reduced UPBEAM/UPISOT matrix
+        vec = lu + 2 * nn * ldh;
+        // ipvt[nn] ints; radiance mode adds zjs, z0s, z1s, psi[2n]
+        group_total = (vec + (nn + 1) / 2 + 2 + (rad ? 5 * n : 0) + 1) & ~1;
         shared_y = 0;                       // Y(l, iq) l-major: [n][nn]
         shared_total = (n * nn + 2 * n + 1) & ~1;
     }
@@ -54,7 +60,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     const int slot = (int)(ms / nmode);
     if (slot >= P.nslot) return;
 
-    const Layer2Lds lds(n, nn);
+    const Layer2Lds lds(n, nn, RAD);
     double *shy = smem;                                  // shared: Y(l, iq), cmu, cwt
     double *scmu = smem + n * nn, *scwt = scmu + n;
     const double *ylmc = P.t.ylmc + (size_t)mazim * n * (n + 1);
@@ -82,9 +88,9 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     double *sp = base + lds.sp, *sm = base + lds.sm;      // S+ , S-   (nn x nn, ld = ldh)
     double *lu = base + lds.lu;
     double *qp = lu, *qm = lu + nn * lds.ldh;             // Q+ -> L , Q- -> C (alias of lu)
-    double *vec = base + lds.vec;
+    int *ipvt = (int *)(base + lds.vec);
+    double *vec = base + lds.vec + (nn + 1) / 2 + 2;      // radiance mode only:
     double *zjs = vec, *z0s = vec + n, *z1s = vec + 2 * n, *psi = vec + 3 * n;   // psi[2n]
-    int *ipvt = (int *)(vec + 5 * n);
     constexpr int ldh = NN | 1, ld = n | 1;
     const int me = g + 1;
     const size_t lidx = (size_t)ms * L + (lc - 1);
@@ -93,7 +99,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 #define SM(i, j) sm[((j) - 1) * ldh + ((i) - 1)]
 #define QP(i, j) qp[((j) - 1) * ldh + ((i) - 1)]
 #define QM(i, j) qm[((j) - 1) * ldh + ((i) - 1)]
-#define LU(i, j) lu[((j) - 1) * ld + ((i) - 1)]
+#define TM(i, j) lu[((j) - 1) * ldh + ((i) - 1)]       // reduced UPBEAM/UPISOT matrix (Q+- are dead by then)
 
     // ---- GL(k) (SETDIS, disort.f:2583-2585) ----
     const double oprim = sv[o.oprim() + lc - 1];
@@ -250,32 +256,33 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         kkout[nn + 1 - me - 1] = -kq;
         const double ekv = exp(-kq * sv[o.dtaucp() + lc - 1]);
         ekout[nn + 1 - me - 1] = ekv;
-        psi[nn + 1 - me - 1] = ekv;          // EK(iq), iq = nn+1-me, kept in LDS for the blocks below
-    }
-    wave_lds_sync();      // Q+/Q- (alias of lu) are dead from here on
-    // GC staged through LDS (lu) so that HBM sees whole rows: GC(i,j) -> lu[(i-1)*ld + j-1]
-    if (me <= nn) {
+        // GC (disort.f:3290-3312) and the matrix-ready interface blocks (disort.f:2851-2876)
+        // straight from registers: this lane owns columns me+nn (k > 0) and nn+1-me (k < 0) of
+        // every row, nn lanes write nn consecutive doubles per instruction.  GC itself is only
+        // read back for the layers FLUXES / the boundary rows / USRINT need.
+        bool need_gc = rad || P.all_levels || lc == 1 || lc == svi[SBD_SVI_NCUT];
+        if (!need_gc) {
+            const int32_t *layru = svi + SBD_SVI_LAYRU;
+            for (int i = 0; i < P.nlev; ++i) need_gc = need_gc || layru[P.t.level_out[i]] == lc;
+        }
+        double *gcout = P.gc + lidx * n * n, *gaout = P.ga + lidx * n * n, *gbout = P.gb + lidx * n * n;
+        const int ja = me + nn - 1, jb = nn - me;          // 0-based columns
 #pragma unroll
         for (int iq = 1; iq <= nn; ++iq) {
             const double gpp = gp[iq - 1], gmm = xcol[iq - 1];
-            lu[(iq + nn - 1) * ld + (me + nn - 1)] = 0.5 * (gpp + gmm);
-            lu[(nn + 1 - iq - 1) * ld + (me + nn - 1)] = 0.5 * (gpp - gmm);
-            lu[(iq + nn - 1) * ld + (nn + 1 - me - 1)] = 0.5 * (-gpp + gmm);
-            lu[(nn + 1 - iq - 1) * ld + (nn + 1 - me - 1)] = 0.5 * (-gpp - gmm);
+            const double vua = 0.5 * (gpp + gmm), vda = 0.5 * (gpp - gmm);   // rows iq+nn, nn+1-iq of column ja
+            const int ru = (iq + nn - 1) * n, rd = (nn - iq) * n;
+            gaout[ru + ja] = vua * ekv;  gbout[ru + ja] = -vua;
+            gaout[rd + ja] = vda * ekv;  gbout[rd + ja] = -vda;
+            gaout[ru + jb] = -vda;       gbout[ru + jb] = vda * ekv;         // column jb: -(gpp - gmm)/2, -(gpp + gmm)/2
+            gaout[rd + jb] = -vua;       gbout[rd + jb] = vua * ekv;
+            if (need_gc) {
+                gcout[ru + ja] = vua;  gcout[rd + ja] = vda;
+                gcout[ru + jb] = -vda; gcout[rd + jb] = -vua;
+            }
         }
     }
-    wave_lds_sync();
-    {
-        double *gcout = P.gc + lidx * n * n, *gaout = P.ga + lidx * n * n, *gbout = P.gb + lidx * n * n;
-        for (int e = g; e < n * n; e += G) {
-            const int j = e % n;                         // iq - 1
-            const double v = lu[(e / n) * ld + j];
-            gcout[e] = v;
-            gaout[e] = (j >= nn) ? v * psi[n - 1 - j] : v;          // disort.f:2851-2876
-            gbout[e] = (j < nn) ? -v * psi[j] : -v;
-        }
-    }
-    wave_lds_sync();
+    wave_lds_sync();      // Q+/Q- (the lu area) are dead from here on
 
     // ---- radiance mode: TERPEV from the register-resident eigenvector columns ----
     if constexpr (rad) {
@@ -317,65 +324,99 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         }
     }
 
-    // ---- UPBEAM / UPISOT: the reference's pivoted LU of (D - CC) in LDS ----
+    // ---- UPBEAM / UPISOT on the +-mu-reduced systems (see the header): lane i <-> mu_i ----
     const double *ylm0 = P.t.ylm0 + (size_t)mazim * (n + 1);
-    auto cc_elem = [&](int iq, int jq) -> double {   // CC(iq,jq), disort.f:3197-3216
-        const int i = (iq <= nn) ? iq : iq - nn, j = (jq <= nn) ? jq : jq - nn;
-        const bool same = (iq <= nn) == (jq <= nn);
-        const double se = SP(i, j), so = SM(i, j);
-        return 0.5 * (same ? se + so : se - so) * scwt[j - 1];
-    };
     auto ylmc_full = [&](int l, int iq) -> double {   // YLMC(l, iq) including the mirrored half
         if (iq <= nn) return YS(l, iq);
         return ((((l - mazim) & 1) == 0) ? 1.0 : -1.0) * YS(l, iq - nn);
     };
+    // y = A x for A = I - S W (S = S+ or S-), x spread over the lanes (lane k holds x_k)
+    auto apply_ImSW = [&](const double *smat, double xv) -> double {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 1; k <= nn; ++k) {
+            const double xk = __shfl(xv, k - 1, G);
+            if (me <= nn) acc = acc + (((me == k) ? 1.0 : 0.0) - smat[(k - 1) * ldh + (me - 1)] * scwt[k - 1]) * xk;
+        }
+        return acc;
+    };
     int status = 0;
-    double zj = 0.0;
     if (fbeam > 0.0) {
         const double delm0 = (mazim == 0) ? 1.0 : 0.0;
-        if (me <= n) {
-            for (int iq = 1; iq <= n; ++iq) LU(iq, me) = -cc_elem(iq, me);
-            const double cm = scmu[me - 1];     // signed: -mu for the downward half
-            LU(me, me) = 1.0 + cm / P.umu0 + LU(me, me);
-            double sum = 0.0;
-            for (int k = mazim; k <= n - 1; ++k) sum = sum + gl[k] * ylmc_full(k, me) * ylm0[k];
-            zj = (2.0 - delm0) * fbeam * sum / (4.0 * P.pi);
+        const double umu0 = P.umu0;
+        double rs = 0.0, rdv = 0.0;                      // r+ + r-, r+ - r-  (disort.f:4208-4216)
+        if (me <= nn) {
+            // column me of T = M/mu0 - mu0 (I - S+ W) M^-1 (I - S- W)
+            double qv[nn];
+#pragma unroll
+            for (int k = 1; k <= nn; ++k)
+                qv[k - 1] = (((k == me) ? 1.0 : 0.0) - SM(k, me) * scwt[me - 1]) / scmu[k - 1];
+            for (int i = 1; i <= nn; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 1; k <= nn; ++k)
+                    acc = acc + (((i == k) ? 1.0 : 0.0) - SP(i, k) * scwt[k - 1]) * qv[k - 1];
+                TM(i, me) = ((i == me) ? scmu[me - 1] / umu0 : 0.0) - umu0 * acc;
+            }
+            double se = 0.0, so = 0.0;
+            for (int k = mazim; k <= n - 1; ++k) {
+                const double t = gl[k] * YS(k, me) * ylm0[k];
+                if (((k - mazim) & 1) == 0) se = se + t; else so = so + t;
+            }
+            const double c = (2.0 - delm0) * fbeam / (4.0 * P.pi);
+            rs = 2.0 * c * se;
+            rdv = 2.0 * c * so;
         }
         wave_lds_sync();
+        // q = (r+ + r-) - mu0 (I - S+ W) M^-1 (r+ - r-);  T d = q;  s = mu0 M^-1 ((r+ - r-) - (I - S- W) d)
+        const double cmu_me = (me <= nn) ? scmu[me - 1] : 1.0;
+        double dv = rs - umu0 * apply_ImSW(sp, rdv / cmu_me);
         if (!(P.dbg & 2)) {
-        if (lu_factor_group(lu, ld, n, ipvt, g) != 0) status |= 0x02;
-        zj = lu_solve_group<G>(lu, ld, n, ipvt, zj, g);
+            if (lu_factor_group(lu, ldh, nn, ipvt, g) != 0) status |= 0x02;
+            dv = lu_solve_group<G>(lu, ldh, nn, ipvt, dv, g);
         }
-        double *zzout = P.zz + lidx * n;
-        if (me <= nn) zzout[me + nn - 1] = zj;
-        else if (me <= n) zzout[nn + 1 - (me - nn) - 1] = zj;
-        if (rad && me <= n) zjs[me - 1] = zj;
+        const double sv_ = umu0 * (rdv - apply_ImSW(sm, dv)) / cmu_me;
+        const double zpl = 0.5 * (sv_ + dv), zmi = 0.5 * (sv_ - dv);     // Z(+mu_me), Z(-mu_me)
+        if (me <= nn) {
+            double *zzout = P.zz + lidx * n;
+            zzout[me + nn - 1] = zpl;                    // ZZ(nn+iq) <- ZJ(iq), ZZ(nn+1-iq) <- ZJ(iq+nn) (disort.f:4238-4241)
+            zzout[nn - me] = zmi;
+            if constexpr (rad) { zjs[me - 1] = zpl; zjs[me + nn - 1] = zmi; }
+        }
         wave_lds_sync();
-    } else if (me <= n) {
+    } else if (me <= nn) {
         P.zz[lidx * n + me - 1] = 0.0;
+        P.zz[lidx * n + me + nn - 1] = 0.0;
     }
-    double z0 = 0.0, z1 = 0.0;
     const bool thermal = plank && mazim == 0;
     if (thermal) {
+        // (I - CC) Z1 = (1-w') XR1 (the same in both halves): Z1+- = (1-w') XR1 u, (I - S+ W) u = 1;
+        // (I - CC) Z0 = (1-w') XR0 + CMU Z1: Z0+- = (1-w') XR0 u +- e, (I - S- W) e = mu Z1   (disort.f:4309-4349)
         const double xr0 = sv[o.xr0() + lc - 1], xr1 = sv[o.xr1() + lc - 1];
-        if (me <= n) {
-            for (int iq = 1; iq <= n; ++iq) LU(iq, me) = -cc_elem(iq, me);
-            LU(me, me) = 1.0 + LU(me, me);
-            z1 = (1.0 - oprim) * xr1;
+        if (me <= nn)
+            for (int i = 1; i <= nn; ++i) TM(i, me) = ((i == me) ? 1.0 : 0.0) - SP(i, me) * scwt[me - 1];
+        wave_lds_sync();
+        if (lu_factor_group(lu, ldh, nn, ipvt, g) != 0) status |= 0x04;
+        const double u = lu_solve_group<G>(lu, ldh, nn, ipvt, 1.0, g);
+        wave_lds_sync();
+        if (me <= nn)
+            for (int i = 1; i <= nn; ++i) TM(i, me) = ((i == me) ? 1.0 : 0.0) - SM(i, me) * scwt[me - 1];
+        wave_lds_sync();
+        if (lu_factor_group(lu, ldh, nn, ipvt, g) != 0) status |= 0x04;
+        const double z1 = (1.0 - oprim) * xr1 * u;
+        const double cmu_me = (me <= nn) ? scmu[me - 1] : 0.0;
+        const double e = lu_solve_group<G>(lu, ldh, nn, ipvt, cmu_me * z1, g);
+        const double z0p = (1.0 - oprim) * xr0 * u + e, z0m = (1.0 - oprim) * xr0 * u - e;
+        if (me <= nn) {
+            double *p0 = P.zp0 + lidx * n, *p1 = P.zp1 + lidx * n;
+            p0[me + nn - 1] = z0p; p1[me + nn - 1] = z1;
+            p0[nn - me] = z0m;     p1[nn - me] = z1;
+            if constexpr (rad) { z0s[me - 1] = z0p; z0s[me + nn - 1] = z0m; z1s[me - 1] = z1; z1s[me + nn - 1] = z1; }
         }
         wave_lds_sync();
-        if (lu_factor_group(lu, ld, n, ipvt, g) != 0) status |= 0x04;
-        z1 = lu_solve_group<G>(lu, ld, n, ipvt, z1, g);
-        if (me <= n) z0 = (1.0 - oprim) * xr0 + scmu[me - 1] * z1;
-        z0 = lu_solve_group<G>(lu, ld, n, ipvt, z0, g);
-        double *p0 = P.zp0 + lidx * n, *p1 = P.zp1 + lidx * n;
-        if (me <= nn) { p0[me + nn - 1] = z0; p1[me + nn - 1] = z1; }
-        else if (me <= n) { p0[nn + 1 - (me - nn) - 1] = z0; p1[nn + 1 - (me - nn) - 1] = z1; }
-        if (rad && me <= n) { z0s[me - 1] = z0; z1s[me - 1] = z1; }
-        wave_lds_sync();
-    } else if (mazim == 0 && me <= n) {
-        P.zp0[lidx * n + me - 1] = 0.0;
-        P.zp1[lidx * n + me - 1] = 0.0;
+    } else if (mazim == 0 && me <= nn) {
+        P.zp0[lidx * n + me - 1] = 0.0; P.zp0[lidx * n + me + nn - 1] = 0.0;
+        P.zp1[lidx * n + me - 1] = 0.0; P.zp1[lidx * n + me + nn - 1] = 0.0;
     }
 
     // ---- TERPSO (disort.f:3980-4128) ----
@@ -435,7 +476,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 #undef SM
 #undef QP
 #undef QM
-#undef LU
+#undef TM
 }
 
 }  // namespace sbd
