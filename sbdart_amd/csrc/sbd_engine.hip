@@ -146,12 +146,20 @@ __global__ void accum_final_kernel(int nseg, int nel, const double *partial, dou
 
 // (NN, G, RAD) dispatch of the fast layer kernel
 #define SBD_L2_CASES(M)                                                                        \
-    M(2, 4) M(3, 8) M(4, 8) M(5, 16) M(6, 16) M(7, 16) M(8, 16) M(9, 32) M(10, 32) M(11, 32)   \
-    M(12, 32) M(13, 32) M(14, 32) M(15, 32) M(16, 32) M(17, 64) M(18, 64) M(19, 64) M(20, 64)
+    M(2, 4) M(3, 4) M(4, 4) M(5, 8) M(6, 8) M(7, 8) M(8, 8) M(9, 16) M(10, 16) M(11, 16)   \
+    M(12, 16) M(13, 16) M(14, 16) M(15, 16) M(16, 16) M(17, 32) M(18, 32) M(19, 32) M(20, 32)
+
+static int l2_group(int nn)   // lanes per layer of the fast layer kernel (the table above)
+{
+#define SBD_L2_G(NNv, Gv) if (nn == NNv) return Gv;
+    SBD_L2_CASES(SBD_L2_G)
+#undef SBD_L2_G
+    return 64;
+}
 
 struct sbd_engine {
     sbd_run_cfg cfg{};
-    int n = 0, nn = 0, L = 0, nmode = 1, naz_run = 0, nlev = 0, G = 0;
+    int n = 0, nn = 0, L = 0, nmode = 1, naz_run = 0, nlev = 0, G = 0, G2 = 0;
     int chunk = 0;
     size_t ws_bytes = 0;
     hipStream_t stream = nullptr;
@@ -451,7 +459,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
 #undef SBD_BAND_CASE
     {
         const sbd::Layer2Lds l2(n, nn, rad);
-        e->layer2_lds = (int)sizeof(double) * (l2.shared_total + l2.group_total * (64 / G));
+        e->G2 = l2_group(nn);
+        e->layer2_lds = (int)sizeof(double) * (l2.shared_total + l2.group_total * (64 / e->G2));
         if (const char *s = getenv("SBD_LAYER_V1")) e->use_layer2 = atoi(s) == 0;
         if (e->layer2_lds > 160 * 1024) e->use_layer2 = false;
         // flags are raised by layer_kernel2 and lowered again by the QR kernel that serves them
@@ -571,7 +580,8 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
             const unsigned grid = (unsigned)((groups + gpb - 1) / gpb);
             int32_t *flt = nullptr;
             if (e->use_layer2) {
-                const unsigned g2 = (unsigned)((size_t)ns * nmode * ((L + gpb - 1) / gpb));
+                const int gpb2 = 64 / e->G2;
+                const unsigned g2 = (unsigned)((size_t)ns * nmode * ((L + gpb2 - 1) / gpb2));
                 int32_t *flag = e->d_eigflag;
 #define SBD_L2_LAUNCH(NNv, Gv)                                                                                        \
                 if (e->nn == NNv) {                                                                                   \

@@ -106,8 +106,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     const double f = sv[o.flyr() + lc - 1];
     {
         const double *pm = P.pmom + ((size_t)slot * L + (lc - 1)) * (P.nmom + 1);
-        if (g < n) {
-            const int k = g;
+        for (int k = g; k < n; k += G) {
             const double pk = (k == 0) ? 1.0 : ((k <= P.nmom) ? pm[k] : 0.0);
             gl[k] = (double)(2 * k + 1) * oprim * (pk - f) / (1.0 - f);
         }
@@ -426,10 +425,11 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         double *psi0 = psi, *psi1 = psi + n;
         if (fbeam > 0.0) {
             const double delm0 = (mazim == 0) ? 1.0 : 0.0;
-            if (g >= mazim && g <= n - 1) {
+            for (int l = g; l <= n - 1; l += G) {
+                if (l < mazim) continue;
                 double psum = 0.0;
-                for (int jq = 1; jq <= n; ++jq) psum = psum + scwt[jq - 1] * ylmc_full(g, jq) * zjs[jq - 1];
-                psi0[g] = 0.5 * gl[g] * psum;
+                for (int jq = 1; jq <= n; ++jq) psum = psum + scwt[jq - 1] * ylmc_full(l, jq) * zjs[jq - 1];
+                psi0[l] = 0.5 * gl[l] * psum;
             }
             wave_lds_sync();
             const double fact = (2.0 - delm0) * fbeam / (4.0 * P.pi);
@@ -445,15 +445,15 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         }
         if (thermal) {
             const double xr0 = sv[o.xr0() + lc - 1], xr1 = sv[o.xr1() + lc - 1];
-            if (g <= n - 1) {
+            for (int l = g; l <= n - 1; l += G) {
                 double psum0 = 0.0, psum1 = 0.0;
                 for (int jq = 1; jq <= n; ++jq) {
-                    const double y = scwt[jq - 1] * ylmc_full(g, jq);
+                    const double y = scwt[jq - 1] * ylmc_full(l, jq);
                     psum0 = psum0 + y * z0s[jq - 1];
                     psum1 = psum1 + y * z1s[jq - 1];
                 }
-                psi0[g] = 0.5 * gl[g] * psum0;
-                psi1[g] = 0.5 * gl[g] * psum1;
+                psi0[l] = 0.5 * gl[l] * psum0;
+                psi1[l] = 0.5 * gl[l] * psum1;
             }
             wave_lds_sync();
             for (int iu = me; iu <= numu; iu += G) {
