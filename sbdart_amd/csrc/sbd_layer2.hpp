@@ -41,9 +41,23 @@ struct Layer2Lds {   // doubles; per-group part + per-block shared part
         // ipvt[nn] ints; radiance mode adds zjs, z0s, z1s, psi[2n]
         group_total = (vec + (nn + 1) / 2 + 2 + (rad ? 5 * n : 0) + 1) & ~1;
         shared_y = 0;                       // Y(l, iq) l-major: [n][nn]
-        shared_total = (n * nn + 2 * n + 1) & ~1;
+        shared_total = (n * nn + 2 * n + 3 * nn + 1) & ~1;   // + R, 1/(M R), 1/W tables
     }
 };
+
+// 1/sqrt(x) and 1/x for x > 0 from the hardware seeds and two Newton steps each
+SBD_DEVICE double rsqrt_nr(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y * (1.5 - 0.5 * x * y * y);
+}
+SBD_DEVICE double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    return r * (2.0 - x * r);
+}
 
 template <int NN, int G, bool RAD>
 __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
@@ -68,7 +82,15 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         const int l = e / nn, iq = e % nn;
         shy[e] = ylmc[iq * (n + 1) + l];
     }
+    double *srr = scwt + n, *sxi = srr + nn, *swi = sxi + nn;   // R = (W/M)^1/2, 1/(M R), 1/W
     if (lane < n) { scmu[lane] = P.t.cmu[lane]; scwt[lane] = P.t.cwt[lane]; }
+    if (lane < nn) {
+        const double w = P.t.cwt[lane], mu = P.t.cmu[lane];
+        const double r = sqrt(w / mu);
+        srr[lane] = r;
+        sxi[lane] = 1.0 / (mu * r);
+        swi[lane] = 1.0 / w;
+    }
     __syncthreads();
     if (lc > L) return;
 
@@ -118,7 +140,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         double yj[n];   // GL(l) * Y(l, mu_j): the j-dependent factor of every term
 #pragma unroll
         for (int l = 0; l < n; ++l) yj[l] = gl[l] * YS(l, me);
-        const double rj = sqrt(scwt[me - 1] / scmu[me - 1]);
+        const double rj = srr[me - 1];
         for (int iq = 1; iq <= nn; ++iq) {
             double se = 0.0, so = 0.0;
 #pragma unroll
@@ -130,8 +152,8 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
             }
             SP(iq, me) = se;
             SM(iq, me) = so;
-            const double ri = sqrt(scwt[iq - 1] / scmu[iq - 1]);
-            const double dg = (iq == me) ? 1.0 / scwt[me - 1] : 0.0;
+            const double ri = srr[iq - 1];
+            const double dg = (iq == me) ? swi[me - 1] : 0.0;
             QP(iq, me) = ri * rj * (dg - se);
             QM(iq, me) = ri * rj * (dg - so);
         }
@@ -171,8 +193,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
             // (C^T L)(i,j) = sum_{k >= max(i,j)} C(k,i) L(k,j)
             for (int k = (i > me ? i : me); k <= nn; ++k) s = s + QM(k, i) * QP(k, me);
             bcol[i - 1] = s;
-            const double ri = sqrt(scwt[i - 1] / scmu[i - 1]);
-            xcol[i - 1] = (i >= me) ? QP(i, me) / (scmu[i - 1] * ri) : 0.0;
+            xcol[i - 1] = (i >= me) ? QP(i, me) * sxi[i - 1] : 0.0;
         }
     } else {
 #pragma unroll
@@ -186,7 +207,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         const double tol = 2.220446049250313e-16;
         for (int sweep = 0; sweep < 30; ++sweep) {
             bool rotated = false;
-            double worst = 0.0;      // largest |cos(angle)| between two columns met in this sweep
+            bool coarse = false;     // some pair met in this sweep with |cos(angle)| > 1e-8
             for (int s = 0; s < NP - 1; ++s) {
                 // circle method: player 0 fixed, the others rotate
                 int pos = (j == 0) ? 0 : 1 + (j - 1 - s + 2 * (NP - 1)) % (NP - 1);
@@ -208,16 +229,22 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                         bb = bb + ob[i] * ob[i];
                         gg = gg + bcol[i] * ob[i];
                     }
-                    const double lim = sqrt(aa * bb);
-                    if (fabs(gg) > tol * lim) {
+                    const double ab = aa * bb, g2 = gg * gg;
+                    if (g2 > tol * tol * ab) {           // |cos(angle)| > tol
                         rotated = true;
-                        worst = fmax(worst, fabs(gg) / lim);
+                        coarse = coarse || (g2 > 1.0e-16 * ab);   // ... > 1e-8
                         const bool lo = j < partner;
                         // rotation defined for the ordered pair (p<q): alpha=|b_p|^2, beta=|b_q|^2
                         const double alpha = lo ? aa : bb, beta = lo ? bb : aa;
-                        const double zeta = (beta - alpha) / (2.0 * gg);
-                        const double t = ((zeta >= 0.0) ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                        // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (beta - alpha) / (2 gg), written
+                        // without zeta: t = sign(d) 2gg / (|d| + sqrt(d^2 + 4 gg^2)); c = (1 + t^2)^-1/2.
+                        // Reciprocal (square roots) from v_rsq/v_rcp + Newton steps: an ulp or two off,
+                        // which a Jacobi rotation does not care about
+                        const double d = beta - alpha, tg = 2.0 * gg;
+                        const double h2 = d * d + tg * tg;
+                        const double h = h2 * rsqrt_nr(h2);
+                        const double t = ((d >= 0.0) ? tg : -tg) * rcp_nr(fabs(d) + h);
+                        const double c = rsqrt_nr(1.0 + t * t), sn = c * t;
                         // p' = c p - s q ; q' = s p + c q
                         const double mine = c, other = lo ? -sn : sn;
 #pragma unroll
@@ -229,7 +256,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                 }
             }
             // quadratic convergence: a sweep that started below 1e-8 ends below 1e-16
-            if (!__any(rotated) || !__any(worst > 1.0e-8) || (P.dbg & 1)) break;
+            if (!__any(rotated) || !__any(coarse) || (P.dbg & 1)) break;
         }
     }
 

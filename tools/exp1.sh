@@ -1,3 +1,2 @@
 run() { python bench.py --steps 2 --warmup 1 --nwl 16384 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['kernel_ms'])"; }
-run wideG
-SBDART_AMD_LIB=$PWD/sbdart_amd/lib/libsbdart_g8.so run narrowG
+run base
