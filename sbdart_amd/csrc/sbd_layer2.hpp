@@ -41,7 +41,7 @@ struct Layer2Lds {   // doubles; per-group part + per-block shared part
         // ipvt[nn] ints; radiance mode adds zjs, z0s, z1s, psi[2n]
         group_total = (vec + (nn + 1) / 2 + 2 + (rad ? 5 * n : 0) + 1) & ~1;
         shared_y = 0;                       // Y(l, iq) l-major: [n][nn]
-        shared_total = (n * nn + 2 * n + 3 * nn + 1) & ~1;   // + R, 1/(M R), 1/W tables
+        shared_total = (n * nn + 2 * n + 4 * nn + 1) & ~1;   // + R, 1/(M R), 1/W, 1/M tables
     }
 };
 
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         const int l = e / nn, iq = e % nn;
         shy[e] = ylmc[iq * (n + 1) + l];
     }
-    double *srr = scwt + n, *sxi = srr + nn, *swi = sxi + nn;   // R = (W/M)^1/2, 1/(M R), 1/W
+    double *srr = scwt + n, *sxi = srr + nn, *swi = sxi + nn, *smi = swi + nn;   // R = (W/M)^1/2, 1/(M R), 1/W, 1/M
     if (lane < n) { scmu[lane] = P.t.cmu[lane]; scwt[lane] = P.t.cwt[lane]; }
     if (lane < nn) {
         const double w = P.t.cwt[lane], mu = P.t.cmu[lane];
@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         srr[lane] = r;
         sxi[lane] = 1.0 / (mu * r);
         swi[lane] = 1.0 / w;
+        smi[lane] = 1.0 / mu;
     }
     __syncthreads();
     if (lc > L) return;
@@ -165,10 +166,10 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     for (int k = 1; k <= nn; ++k) {
         const double dp = QP(k, k), dm = QM(k, k);
         if (!(dp > 0.0) || !(dm > 0.0)) { spd = false; break; }
-        const double sdp = sqrt(dp), sdm = sqrt(dm);
+        const double rdp = rsqrt_nr(dp), rdm = rsqrt_nr(dm);      // 1/sqrt(pivot): the factors are an ulp or two off
         wave_lds_sync();
-        if (me == k) { QP(k, k) = sdp; QM(k, k) = sdm; }
-        if (me > k && me <= nn) { QP(me, k) = QP(me, k) / sdp; QM(me, k) = QM(me, k) / sdm; }
+        if (me == k) { QP(k, k) = dp * rdp; QM(k, k) = dm * rdm; }
+        if (me > k && me <= nn) { QP(me, k) = QP(me, k) * rdp; QM(me, k) = QM(me, k) * rdm; }
         wave_lds_sync();
         if (me > k && me <= nn) {
             const double lp = QP(me, k), lm_ = QM(me, k);
@@ -268,13 +269,14 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 #pragma unroll
         for (int i = 0; i < nn; ++i) lam = lam + bcol[i] * bcol[i];
         kq = sqrt(fabs(lam));
+        const double rkq = 1.0 / kq;
 #pragma unroll
         for (int i = 1; i <= nn; ++i) {
             // AMB(i,k) = (S-(i,k) w_k - delta_ik) / mu_i
             double s = 0.0;
 #pragma unroll
             for (int k = 1; k <= nn; ++k) s = s + (SM(i, k) * scwt[k - 1] - ((i == k) ? 1.0 : 0.0)) * xcol[k - 1];
-            gp[i - 1] = s / (scmu[i - 1] * kq);
+            gp[i - 1] = s * smi[i - 1] * rkq;
         }
         double *kkout = P.kk + lidx * n;
         double *ekout = P.ek + lidx * nn;
@@ -376,7 +378,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
             double qv[nn];
 #pragma unroll
             for (int k = 1; k <= nn; ++k)
-                qv[k - 1] = (((k == me) ? 1.0 : 0.0) - SM(k, me) * scwt[me - 1]) / scmu[k - 1];
+                qv[k - 1] = (((k == me) ? 1.0 : 0.0) - SM(k, me) * scwt[me - 1]) * smi[k - 1];
             for (int i = 1; i <= nn; ++i) {
                 double acc = 0.0;
 #pragma unroll
