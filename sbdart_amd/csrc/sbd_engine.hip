@@ -361,15 +361,15 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const size_t per_ms = sizeof(double) * ((size_t)3 * L * n * n + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * cw
                                             + (rad ? (size_t)L * n * numu + 3 * (size_t)L * numu + (size_t)e->nlev * numu : 0));
     const size_t per_slot = per_ms * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
-    size_t budget = (size_t)12 << 30;   // of 288 GB
+    size_t budget = (size_t)64 << 30;   // of 288 GB: fewer, larger passes (launch tails cost ~7 % at 16k items)
     if (const char *s = getenv("SBD_WORKSPACE_MB")) budget = (size_t)atoll(s) << 20;
-    int chunk = 16384;
+    int chunk = 131072;
     if (const char *s = getenv("SBD_CHUNK")) chunk = atoi(s);
     if (cfg->max_batch > 0 && cfg->max_batch < chunk) chunk = cfg->max_batch;
     while (chunk > 1 && (size_t)chunk * per_slot > budget) chunk /= 2;
     if (chunk < 1) chunk = 1;
     e->chunk = chunk;
-    const size_t flag_bytes = sizeof(int32_t) * (size_t)chunk * nmode * L;
+    const size_t flag_bytes = sizeof(int32_t) * ((size_t)chunk * nmode * L + 4);   // count + entries
     e->ws_bytes = (size_t)chunk * per_slot + flag_bytes + 8192;
     CREATE_TRY(hipMalloc(&e->d_ws, e->ws_bytes));
     {
@@ -378,6 +378,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         sbd::Params &P = e->P;
         const size_t nms = (size_t)chunk * nmode;
         e->d_eigflag = (int32_t *)take(flag_bytes);
+        P.eiglist = e->d_eigflag;
         P.sv = (double *)take(sizeof(double) * (size_t)chunk * sv_stride);
         P.svi = (int32_t *)take(sizeof(int32_t) * (size_t)chunk * svi_stride);
         P.gc = (double *)take(sizeof(double) * nms * L * n * n);
@@ -463,8 +464,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         e->layer2_lds = (int)sizeof(double) * (l2.shared_total + l2.group_total * (64 / e->G2));
         if (const char *s = getenv("SBD_LAYER_V1")) e->use_layer2 = atoi(s) == 0;
         if (e->layer2_lds > 160 * 1024) e->use_layer2 = false;
-        // flags are raised by layer_kernel2 and lowered again by the QR kernel that serves them
-        CREATE_TRY(hipMemset(e->d_eigflag, 0, sizeof(int32_t) * (size_t)chunk * nmode * L));
+        // the list is emptied by setup_kernel, filled by layer_kernel2 and walked by the QR kernel
+        CREATE_TRY(hipMemset(e->d_eigflag, 0, flag_bytes));
 #define SBD_L2_ATTR(NNv, Gv)                                                                                    \
         if (nn == NNv) {                                                                                        \
             if (rad) CREATE_TRY(set_lds((const void *)sbd::layer_kernel2<NNv, Gv, true>, e->layer2_lds));        \
@@ -577,7 +578,7 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
         {
             const int gpb = 64 / e->G;
             const long long groups = (long long)ns * nmode * L;
-            const unsigned grid = (unsigned)((groups + gpb - 1) / gpb);
+            unsigned grid = (unsigned)((groups + gpb - 1) / gpb);
             int32_t *flt = nullptr;
             if (e->use_layer2) {
                 const int gpb2 = 64 / e->G2;
@@ -590,7 +591,8 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
                 }
                 SBD_L2_CASES(SBD_L2_LAUNCH)
 #undef SBD_L2_LAUNCH
-                flt = e->d_eigflag;     // the QR kernel below only redoes flagged layers
+                flt = e->d_eigflag;     // the QR kernel below only redoes the listed layers: a small
+                if (grid > 2048u) grid = 2048u;   // fixed grid walks the list (normally empty)
                 SBD_DBG("layer2");
             }
             switch (e->G) {

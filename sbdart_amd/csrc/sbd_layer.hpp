@@ -112,21 +112,24 @@ __global__ void __launch_bounds__(64) layer_kernel(Params P, int32_t *only_flagg
     const int g = lane % G;
     const int gi = lane / G;
     const int L = P.L, n = P.n, nn = P.nn, nmode = P.nmode, numu = P.numu;
-    const long long gid = (long long)blockIdx.x * GPB + gi;
+    // Two ways in: every (item, mode, layer) of the pass (only_flagged == nullptr, the grid covers
+    // them once), or the list layer_kernel2 (sbd_layer2.hpp) left behind -- only_flagged[0] entries
+    // follow the count -- walked by a small fixed grid.
     const long long total = (long long)P.nslot * nmode * L;
-    if (gid >= total) return;
+    const long long nwork = only_flagged ? (long long)only_flagged[0] : total;
+    for (long long it = (long long)blockIdx.x * GPB + gi; it < nwork; it += (long long)gridDim.x * GPB) {
+    const long long gid = only_flagged ? (long long)only_flagged[1 + it] : it;
     const int lc = (int)(gid % L) + 1;
     const long long ms = gid / L;
     const int mazim = (int)(ms % nmode);
     const int slot = (int)(ms / nmode);
-    if (only_flagged && !only_flagged[(size_t)ms * L + (lc - 1)]) return;   // fallback pass of sbd_layer2.hpp
 
     const int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
     const int st0 = svi[SBD_SVI_STATUS];
-    if (st0 & (0x20 | 0x10)) return;            // input error / retry: DISORT returned early
-    if (lc > svi[SBD_SVI_NCUT]) return;          // layer loop runs 1..NCUT (disort.f:638)
+    if (st0 & (0x20 | 0x10)) continue;          // input error / retry: DISORT returned early
+    if (lc > svi[SBD_SVI_NCUT]) continue;        // layer loop runs 1..NCUT (disort.f:638)
     const double fbeam = P.fbeam[slot];
-    if (mazim > 0 && fbeam == 0.0) return;       // NAZ = 0 (disort.f:582)
+    if (mazim > 0 && fbeam == 0.0) continue;     // NAZ = 0 (disort.f:582)
     const bool plank = P.plank[slot] != 0;
     const bool rad = !P.onlyfl;
 
@@ -386,7 +389,8 @@ __global__ void __launch_bounds__(64) layer_kernel(Params P, int32_t *only_flagg
 #undef YLMU
     }
     if (status && g == 0) atomicOr(&P.svi[(size_t)slot * P.svi_stride + SBD_SVI_STATUS], status);
-    if (only_flagged && g == 0) only_flagged[(size_t)ms * L + (lc - 1)] = 0;   // served
+    wave_lds_sync();   // the group's LDS is reused by its next entry
+    }
 #undef YLMC
 #undef CC
 #undef EVC

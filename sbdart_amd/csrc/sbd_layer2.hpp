@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         wave_lds_sync();
     }
     if (!spd || P.force_fallback) {   // group-uniform: hand this layer to the QR kernel
-        if (g == 0) eigflag[lidx] = 1;
+        if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;   // count, then the entries
         return;
     }
 

@@ -81,6 +81,7 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
     const int slot = blockIdx.x;
     if (slot >= P.nslot) return;
     const int lane = threadIdx.x;
+    if (slot == 0 && lane == 0) P.eiglist[0] = 0;      // empty list for this pass's layer kernels
     const int L = P.L, n = P.n, nmom = P.nmom;
     const SV o(L);
     double *sv = P.sv + (size_t)slot * P.sv_stride;

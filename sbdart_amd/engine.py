@@ -214,7 +214,7 @@ def solve_records(recs, level_out=None, device=0):
     flux_out, uu_out, st_out = [None] * len(recs), [None] * len(recs), [0] * len(recs)
     for idx in groups.values():
         r0 = recs[idx[0]]
-        with engine_for_record(r0, level_out=level_out, device=device) as eng:
+        with engine_for_record(r0, level_out=level_out, device=device, max_batch=len(idx)) as eng:
             flux, uu, st = eng.solve(
                 np.stack([recs[i].dtauc for i in idx]), np.stack([recs[i].ssalb for i in idx]),
                 np.stack([recs[i].pmom for i in idx]), [recs[i].wvnmlo for i in idx],

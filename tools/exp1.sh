@@ -1,2 +1,2 @@
-run() { python bench.py --steps 2 --warmup 1 --nwl 16384 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['kernel_ms'])"; }
+run() { python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['kernel_ms'], d['config']['chunk'])"; }
 run base
