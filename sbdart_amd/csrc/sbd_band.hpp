@@ -393,22 +393,25 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         // interface row r (nn < r <= N-nn) for the lane's column when k = kfirst: ONE load per
         // lane whatever it carries (the right-hand side, the layer-lc block or the layer-lc+1
         // block) and no other memory operation, so that nothing waits on it before its use
-        auto elem_fast = [&](int r, int kmr, int kfirst) -> double {
+        auto elem_fast = [&](int r, int kmr, int kfirst, unsigned long long &vmask) -> double {
             int c = lane - kmr;
             if (c < 0) c += RING;
             const int col = kfirst + c;
             const int qq = r - nn - 1;
             const int d = col - (qq / n) * n;                    // 1..2n inside the row's support
+            const bool valid = rhs || (c < CW && col <= N && d >= 1 && d <= 2 * n);
             const double *p = rhs ? yv + (r - 1)
                                   : (d <= n ? ga_ms + ((size_t)qq * n + d - 1) : gb_ms + ((size_t)qq * n + d - n - 1));
-            const bool valid = rhs || (c < CW && col <= N && d >= 1 && d <= 2 * n);
-            double g = 0.0;
-            if (valid) g = *p;
-            return g;
+            vmask = __ballot(valid);
+            return *(valid ? p : yv);                            // every lane loads (a safe address when it has no element)
         };
         auto elem_for = [&](int r, int kmr, int kfirst) -> double {   // any row (boundary rows included)
             if (r > N) return 0.0;
-            if (r > nn && r <= N - nn) return elem_fast(r, kmr, kfirst);
+            if (r > nn && r <= N - nn) {
+                unsigned long long vm;
+                const double g = elem_fast(r, kmr, kfirst, vm);
+                return ((vm >> lane) & 1ull) ? g : 0.0;
+            }
             if (rhs) return yv[r - 1];
             int c = lane - kmr;
             if (c < 0) c += RING;
@@ -432,14 +435,15 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         }
         constexpr int U = 4;
         double pre[U];
-        auto load_row = [&](int r, double &g, auto fast) {   // row r enters at the end of step r - RW
+        unsigned long long pmask[U];                     // lanes whose prefetched value is an element (else 0)
+        auto load_row = [&](int r, double &g, unsigned long long &vm, auto fast) {   // row r enters at the end of step r - RW
             const int k1 = r - RW + 1;
-            if constexpr (decltype(fast)::value) g = elem_fast(r, k1 % RING, k1);
-            else g = elem_for(r, k1 % RING, k1);
+            if constexpr (decltype(fast)::value) g = elem_fast(r, k1 % RING, k1, vm);
+            else { g = elem_for(r, k1 % RING, k1); vm = ~0ull; }
         };
 #pragma unroll
-        for (int u = 0; u < U; ++u) load_row(RW + 1 + u, pre[u], std::false_type{});
-        auto step = [&](const int k, double &pq, auto fast) {
+        for (int u = 0; u < U; ++u) load_row(RW + 1 + u, pre[u], pmask[u], std::false_type{});
+        auto step = [&](const int k, double &pq, unsigned long long &pm, auto fast) {
             const int lm = (ncd < N - k) ? ncd : N - k;
             // (A) pivot column -> lanes (lane t <-> row k+t)
             if (lane == km) {
@@ -494,8 +498,9 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             //     value keeps a register of its own for the whole loop, so the only wait for its
             //     load sits here, U steps after the issue
             asm volatile("v_mov_b64 %0, %1" : "=v"(a[RW - 1]) : "v"(pq));
+            if (!((pm >> lane) & 1ull)) a[RW - 1] = 0.0;
             km = (km + 1 == RING) ? 0 : km + 1;
-            load_row(k + RW + U, pq, fast);
+            load_row(k + RW + U, pq, pm, fast);
         };
         // every load so far has landed before the loop: its waits then only count the loop's own
         // loads (vmcnt(0), expcnt/lgkmcnt unconstrained)
@@ -514,7 +519,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
                 }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) step(k + u, pre[u], std::true_type{});
+            for (int u = 0; u < U; ++u) step(k + u, pre[u], pmask[u], std::true_type{});
         }
         for (; k <= N - 1; ++k) {                        // the tail: boundary rows enter, then nothing
             {
@@ -525,11 +530,13 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
                     for (int i = 0; i < RW; ++i) a[i] = 0.0;
                 }
             }
-            step(k, pre[0], std::false_type{});          // consumes pre[0], reloads it for step k+U
+            step(k, pre[0], pmask[0], std::false_type{});   // consumes pre[0], reloads it for step k+U
             const double newest = pre[0];
+            const unsigned long long newm = pmask[0];
 #pragma unroll
-            for (int u = 0; u + 1 < U; ++u) pre[u] = pre[u + 1];
+            for (int u = 0; u + 1 < U; ++u) { pre[u] = pre[u + 1]; pmask[u] = pmask[u + 1]; }
             pre[U - 1] = newest;
+            pmask[U - 1] = newm;
         }
         {   // last row
             const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[0]), km),
