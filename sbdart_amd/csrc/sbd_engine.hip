@@ -368,10 +368,18 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     if (cfg->max_batch > 0 && cfg->max_batch < chunk) chunk = cfg->max_batch;
     while (chunk > 1 && (size_t)chunk * per_slot > budget) chunk /= 2;
     if (chunk < 1) chunk = 1;
+    size_t flag_bytes = 0;
+    for (;;) {   // a GPU that cannot spare the budget right now gets smaller passes instead of an error
+        flag_bytes = sizeof(int32_t) * ((size_t)chunk * nmode * L + 4);   // count + entries
+        e->ws_bytes = (size_t)chunk * per_slot + flag_bytes + 8192;
+        const hipError_t me_ = hipMalloc(&e->d_ws, e->ws_bytes);
+        if (me_ == hipSuccess) break;
+        e->d_ws = nullptr;
+        (void)hipGetLastError();
+        if (me_ != hipErrorOutOfMemory || chunk <= 64) CREATE_TRY(me_);
+        chunk /= 2;
+    }
     e->chunk = chunk;
-    const size_t flag_bytes = sizeof(int32_t) * ((size_t)chunk * nmode * L + 4);   // count + entries
-    e->ws_bytes = (size_t)chunk * per_slot + flag_bytes + 8192;
-    CREATE_TRY(hipMalloc(&e->d_ws, e->ws_bytes));
     {
         char *p = e->d_ws;
         auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~(size_t)255; return r; };
