@@ -84,7 +84,7 @@ def main():
               f" iout=10\n sza=0"
               for t in (0, 1, 2, 4, 8, 16, 32, 64, 128) for n in (2, 4, 8, 16, 32, 64, 128)
               for w in (".55", "2.16")]
-    emit("sbchk4", cases4[::3], lambda r: r, keep_stdout=False)
+    emit("sbchk4", cases4[::3], lambda r: r)
     # --- example 5 (test_runs:124-145): nstr=20 radiance
     emit("sbchk5", [f"  tcloud= {t}\n  zcloud= 1\n  wlinf=.72\n  wlsup=.72\n  idatm=1\n  isalb=4\n"
                     f"  sza=60\n  iout=21\n  nstr=20\n"
