@@ -29,6 +29,10 @@ namespace sbd {
 
 constexpr int kBandMargin = 4;    // extra physical rows before the window is re-based
 constexpr int kBackBlock = 8;     // columns per back-substitution block
+// U's upper bandwidth: LINPACK allows 2*NCD, but the layer-block structure caps it at 2*NSTR-1 --
+// every candidate pivot row of a column of layer lc ends with layer lc+1's columns, and fill-in
+// only copies pivot-row supports -- so U rows are stored NSTR*2 wide (a third fewer bytes)
+SBD_DEVICE constexpr int u_width(int n) { return 2 * n; }
 
 struct BandLds {   // per-wave carve-up of the LU kernel (doubles)
     int rw, cw, cwp, win, bw, misc, total;
@@ -51,7 +55,7 @@ struct SolveLds {   // per-wave carve-up of the back-substitution + flux kernel 
     {
         const int ncd = 3 * nn - 1;
         const int fluxsz = 2 * 16 * n + 64;                         // E / U0C staging, 16 levels at a time
-        const int stagesz = (2 * ncd + kBackBlock + 1) * (kBackBlock + 1);   // U block + a zero row
+        const int stagesz = (2 * n - 1 + kBackBlock + 1) * (kBackBlock + 1);   // U block (2n-1 super-diagonals) + a zero row
         stage = 0;
         x = ((stagesz > fluxsz ? stagesz : fluxsz) + 1) & ~1;       // X(N) behind the stage
         total = (x + n * L + 1) & ~1;
@@ -245,7 +249,8 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     // thermal particular solutions exist for mode 0 only
     const double *zp0 = P.zp0 + (size_t)(ms - mazim) * L * n;
     const double *zp1 = P.zp1 + (size_t)(ms - mazim) * L * n;
-    double *ufac = P.ufac + (size_t)ms * (size_t)(L * n) * CW;
+    constexpr int UW = u_width(n);
+    double *ufac = P.ufac + (size_t)ms * (size_t)(L * n) * UW;
     const int N = ncut * n;
 #define GC(i, j, lc) gc[((size_t)((lc) - 1) * n + ((i) - 1)) * n + ((j) - 1)]
 #define KK(i, lc) kk[((lc) - 1) * n + ((i) - 1)]
@@ -478,8 +483,8 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             {
                 int c = lane - km;
                 if (c < 0) c += RING;
-                const int wmax = (2 * ncd < N - k) ? 2 * ncd : N - k;
-                if (!rhs && c <= wmax) ufac[(size_t)(k - 1) * CW + c] = tj;
+                const int wmax = (UW - 1 < N - k) ? UW - 1 : N - k;
+                if (!rhs && c <= wmax) ufac[(size_t)(k - 1) * UW + c] = tj;
                 if (rhs) yv[k - 1] = tj;
             }
             // (F) elimination + slide: a[i-1] = a[i] + tj * m(i) for the rows with a non-zero
@@ -542,7 +547,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[0]), km),
                                               __builtin_amdgcn_readlane(__double2loint(a[0]), km));
             if (d == 0.0) status |= 0x01;
-            if (lane == km) ufac[(size_t)(N - 1) * CW] = a[0];
+            if (lane == km) ufac[(size_t)(N - 1) * UW] = a[0];
             if (rhs) yv[N - 1] = a[0];
         }
         if (status && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], status);
@@ -658,13 +663,12 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             if (lane < CW && rin <= N) rowin[pcl] = pq.g0;
             if (two && lane + 64 < CW && rin <= N) rowin[pcl2] = pq.g1;
         }
-        // (F) retire row k from registers: stream U(k, k..k+2ncd) to HBM row-major (zeros
-        //     beyond ju belong to U's band)
+        // (F) retire row k from registers: stream U(k, k..k+2n-1) to HBM row-major
         {
-            const int wmax = (2 * ncd < N - k) ? 2 * ncd : N - k;
-            double *urow = ufac + (size_t)(k - 1) * CW;
-            if (lane <= wmax && lane < CW && !(P.dbg & 4)) urow[lane] = (lane == 0) ? piv : tj;
-            if (two && lane + 64 <= wmax && lane + 64 < CW) urow[lane + 64] = tj2;
+            const int wmax = (UW - 1 < N - k) ? UW - 1 : N - k;
+            double *urow = ufac + (size_t)(k - 1) * UW;
+            if (lane <= wmax && !(P.dbg & 4)) urow[lane] = (lane == 0) ? piv : tj;
+            if (two && lane + 64 <= wmax) urow[lane + 64] = tj2;
         }
         wave_lds_sync();
         // (E) rank-1 update: lane c <-> column k+c (c >= 1).  LDS round trip 3: all rows of the
@@ -708,7 +712,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     {   // last row
         const double d = win[kq * CWP + kc];
         if (d == 0.0) status |= 0x01;
-        if (lane == 0) { ufac[(size_t)(N - 1) * CW] = d; yv[N - 1] = bw[kq]; }
+        if (lane == 0) { ufac[(size_t)(N - 1) * UW] = d; yv[N - 1] = bw[kq]; }
     }
     if (status && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], status);
 #undef GC

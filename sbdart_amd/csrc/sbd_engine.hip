@@ -358,7 +358,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const sbd::SV sv(L);
     const int sv_stride = (sv.size() + 1) & ~1;
     const int svi_stride = (3 + L + 1 + 3) & ~3;
-    const size_t per_ms = sizeof(double) * ((size_t)3 * L * n * n + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * cw
+    const size_t per_ms = sizeof(double) * ((size_t)3 * L * n * n + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * (2 * n)
                                             + (rad ? (size_t)L * n * numu + 3 * (size_t)L * numu + (size_t)e->nlev * numu : 0));
     const size_t per_slot = per_ms * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
     size_t budget = (size_t)64 << 30;   // of 288 GB: fewer, larger passes (launch tails cost ~7 % at 16k items)
@@ -399,7 +399,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         P.zp1 = (double *)take(sizeof(double) * nms * L * n);
         P.ll = (double *)take(sizeof(double) * nms * L * n);
         P.yv = (double *)take(sizeof(double) * nms * L * n);
-        P.ufac = (double *)take(sizeof(double) * nms * L * n * cw);
+        P.ufac = (double *)take(sizeof(double) * nms * L * n * (2 * n));   // sbd::u_width(n)
         if (rad) {
             P.gu = (double *)take(sizeof(double) * nms * L * n * numu);
             P.zb = (double *)take(sizeof(double) * nms * L * numu);

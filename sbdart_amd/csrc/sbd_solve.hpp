@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64) backsolve_kernel(Params P)
     const bool beam = fbeam > 0.0;
 
     const SolveLds lds(n, nn, L);
-    constexpr int ncd = 3 * NN - 1, CW = 2 * ncd + 1;
+    constexpr int UW = u_width(n), UB = UW - 1;          // stored width / upper bandwidth of U
     double *win = smem + lds.stage;
     double *b = smem + lds.x;                         // right-hand side -> solution vector
     const double *yv = P.yv + (size_t)ms * L * n;
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(64) backsolve_kernel(Params P)
     const double *zz = P.zz + (size_t)ms * L * n;
     const double *zp0 = P.zp0 + (size_t)(ms - mazim) * L * n;
     const double *zp1 = P.zp1 + (size_t)(ms - mazim) * L * n;
-    const double *ufac = P.ufac + (size_t)ms * (size_t)(L * n) * CW;
+    const double *ufac = P.ufac + (size_t)ms * (size_t)(L * n) * UW;
     const int N = ncut * n;
 #define GC(i, j, lc) gc[((size_t)((lc) - 1) * n + ((i) - 1)) * n + ((j) - 1)]
 #define KK(i, lc) kk[((lc) - 1) * n + ((i) - 1)]
@@ -63,12 +63,12 @@ __global__ void __launch_bounds__(64) backsolve_kernel(Params P)
 
     // ---- back-substitution, column oriented (SGBSL second loop, disutil.f:1038-1050).
     //      U is row-major in HBM (ufac[i][j-i]); blocks of 16 columns are transposed through
-    //      an LDS stage: stage[r][c] = U(i0+r, k0+c), rows i0 = k0-2ncd .. k1.  The running
+    //      an LDS stage: stage[r][c] = U(i0+r, k0+c), rows i0 = k0-(2n-1) .. k1.  The running
     //      right-hand side lives in registers on a ring of RS rows (row i <-> lane i%64, slot
     //      (i%RS)/64), so the only serial chain per column is readlane -> divide -> FMA; the
     //      stage entries and the pivot reciprocals of a block are fetched ahead of it. ----
     {
-        constexpr int BC = kBackBlock, SP = BC + 1, NR = 2 * ncd + BC;
+        constexpr int BC = kBackBlock, SP = BC + 1, NR = UB + BC;
         constexpr int NB = (NR + 63) / 64, RS = 64 * NB;
         double *stage = win;                              // NR rows + one all-zero row
         double bval[NB];
@@ -84,22 +84,22 @@ __global__ void __launch_bounds__(64) backsolve_kernel(Params P)
         const int rr = lane / BC, cc = lane % BC;
         auto load_block = [&](int k1, double (&v)[NLD]) {
             const int k0 = (k1 - BC + 1 > 1) ? k1 - BC + 1 : 1;
-            const int i0 = k0 - 2 * ncd;
+            const int i0 = k0 - UB;
             const int j = k0 + cc;
 #pragma unroll
             for (int it = 0; it < NLD; ++it) {
                 const int r = it * RPL + rr;
                 const int i = i0 + r;
                 v[it] = 0.0;
-                if (r < NR && i >= 1 && i <= k1 && j <= k1 && j >= i && j - i <= 2 * ncd)
-                    v[it] = ufac[(size_t)(i - 1) * CW + (j - i)];
+                if (r < NR && i >= 1 && i <= k1 && j <= k1 && j >= i && j - i <= UB)
+                    v[it] = ufac[(size_t)(i - 1) * UW + (j - i)];
             }
         };
         double cur[NLD];
         load_block(N, cur);
         for (int k1 = N; k1 >= 1; k1 -= BC) {
             const int k0 = (k1 - BC + 1 > 1) ? k1 - BC + 1 : 1;
-            const int i0 = k0 - 2 * ncd;                   // may be <= 0: rows < 1 hold zeros
+            const int i0 = k0 - UB;                   // may be <= 0: rows < 1 hold zeros
             wave_lds_sync();
 #pragma unroll
             for (int it = 0; it < NLD; ++it)
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(64) backsolve_kernel(Params P)
                 constexpr int c = decltype(cc)::value;
 #pragma unroll
                 for (int q = 0; q < NB; ++q) u[q][c] = lds_read_b64<c * 8>(ubase[q]);
-                dg[c] = lds_read_b64<((2 * ncd + c) * SP + c) * 8>(sbase);   // U(k0+c, k0+c), broadcast
+                dg[c] = lds_read_b64<((UB + c) * SP + c) * 8>(sbase);   // U(k0+c, k0+c), broadcast
             };
             static_for<BC>(fetch);
             lds_wait();
