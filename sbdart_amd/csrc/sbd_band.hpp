@@ -1,27 +1,28 @@
-// Band kernel: one wave per (work item, azimuth mode) assembles and solves the two-point
-// boundary system for the constants of integration (SETMTX + SOLVE0, disort.f:2702-2994,
-// 3322-3637, on LINPACK's SGBFA/SGBSL, disutil.f:771-1092) and, for mode 0, evaluates
-// the fluxes at the requested levels (FLUXES, disort.f:1780-2042).
+// Band LU kernel: one wave per (work item, azimuth mode) assembles the two-point boundary
+// system for the constants of integration (SETMTX + SOLVE0, disort.f:2702-2994, 3322-3637),
+// factors it with LINPACK's partial-pivot band LU (SGBFA, disutil.f:771-912) and runs the
+// forward half of SGBSL (disutil.f:1019-1036) on the right-hand side.  The U factor (row-major)
+// and the eliminated right-hand side go to HBM; sbd_solve.hpp finishes the solve.
 //
 // The reference builds a dense LINPACK band array (LDA x N, 296 KB at NSTR=16, 33 layers)
 // and factors it in place.  Here the matrix is never materialised: partial-pivot LU only
 // ever touches rows k..k+NCD and columns k..k+2*NCD, so the wave keeps exactly that sliding
-// window in LDS.  NSTR is a template parameter, so the window geometry is compile time:
-//   * rows are stored without wrap-around in RW+MARGIN physical rows (re-based every MARGIN
-//     steps), so the rank-1 update addresses them with immediate offsets;
-//   * columns use a ring of CW positions (one add/compare per lane per step);
-//   * rows enter the window generated on the fly from the layer eigenvectors (prefetched
-//     one step ahead, unit-stride HBM reads), the pivot-row interchange is physical;
-//   * the multipliers come straight from the registers of the pivot search (found with a
-//     DPP max-scan, no LDS round trip), reach the other lanes as broadcast LDS reads, and are
-//     applied to the right-hand side at once (L is never stored);
-//   * rows enter from the matrix-ready interface blocks ga/gb the layer kernel wrote;
-//   * each finished U row is streamed to HBM row-major (coalesced); back-substitution
-//     re-reads U in blocks of 16 columns through an LDS transpose stage and runs LINPACK's
-//     column-oriented sweep from there.
-// Pivot choice (first maximal |a|), multiplier scaling (-1/pivot) and the element-wise
-// update order are LINPACK's, so the factors agree with the reference up to FMA
-// contraction.
+// window on chip.  NSTR is a template parameter, so the window geometry is compile time.
+// Two homes for the window:
+//   * band_kernel<NN, true>  (NSTR <= 20): in REGISTERS, a column per lane -- see the block
+//     comment at "register-resident window" below;
+//   * band_kernel<NN, false> (NSTR > 20): in LDS -- rows without wrap-around in RW+MARGIN
+//     physical rows (re-based every MARGIN steps) so that the rank-1 update addresses them
+//     with immediate offsets, columns on a ring of CW positions, the pivot row kept in
+//     registers, the right-hand side of the window rows beside it.
+// Common to both: rows enter from the matrix-ready interface blocks ga/gb the layer kernel
+// wrote (unit stride, prefetched U steps ahead); the pivot search is a DPP max-scan plus a
+// ballot; multipliers come from the registers of the pivot search and are applied to the
+// right-hand side at once (L is never stored); only the rows with a non-zero multiplier
+// take part in a step; each finished U row is streamed to HBM.
+// Pivot choice (first maximal |a|), multiplier scaling (-1/pivot, by reciprocal + Newton)
+// and the element-wise update order are LINPACK's, so the factors agree with the reference
+// up to FMA contraction and the last bit of the reciprocal.
 #pragma once
 #include "sbd_common.hpp"
 

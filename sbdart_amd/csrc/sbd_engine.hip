@@ -1,12 +1,14 @@
 // sbdart_amd -- host side of the C ABI (include/sbdart_amd.h): per-run tables, HBM
 // workspace, chunked kernel pipeline on one HIP stream, timing with HIP events.
 //
-// Pipeline per chunk of work items (all on the caller's / engine's stream):
-//   setup_kernel   (disort.f:482-571)   -> sv/svi
-//   layer_kernel   (disort.f:638-693)   -> gc, kk, ek, zz, zp0/1 [, gu, zb, z0u, z1u]
-//   band_kernel    (disort.f:701-721)   -> ll, flux
+// Pipeline per pass of work items (all on the caller's / engine's stream):
+//   setup_kernel     (disort.f:482-571)   -> sv/svi
+//   layer_kernel2    (disort.f:638-693)   -> kk, ek, ga/gb, zz, zp0/1 [, gc, gu, zb, z0u, z1u]
+//   layer_kernel     (same, reference algorithm) for the layers layer_kernel2 listed
+//   band_kernel      (disort.f:701-721)   -> U factor, eliminated right-hand side
+//   backsolve_kernel (same + FLUXES)      -> ll, flux
 //   usrint_kernel + azimuth_kernel (disort.f:745-825), radiance mode only -> uu
-//   finish_kernel                       -> status
+//   finish_kernel                         -> status
 #include "../../include/sbdart_amd.h"
 
 #include <hip/hip_runtime.h>
