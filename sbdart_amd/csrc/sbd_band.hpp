@@ -41,7 +41,7 @@ struct BandLds {   // per-wave carve-up of the LU kernel (doubles)
     {
         const int ncd = 3 * nn - 1;
         rw = ncd + 1;
-        cw = 2 * ncd + 1;
+        cw = reg ? 2 * ncd + 1 : 2 * n;
         cwp = cw | 1;
         win = 0;                                                    // sliding window ...
         bw = win + (reg ? ((rw + 1) & ~1) : (rw + kBandMargin) * cwp);   // (register variant: the pivot column only)
@@ -168,7 +168,7 @@ SBD_DEVICE void update_rows_fixed(double *colp, double mreg, double tj)
 template <int NN>
 SBD_DEVICE void update_rows(double *colp, double mreg, double tj, int lme)
 {
-    constexpr int ncd = 3 * NN - 1, CWP = (2 * ncd + 1) | 1, D = (2 * NN + 3) / 4;
+    constexpr int ncd = 3 * NN - 1, CWP = (4 * NN) | 1, D = (2 * NN + 3) / 4;   // (LDS variant: 2*NSTR columns)
     if (lme > ncd - D) update_rows_fixed<ncd, CWP>(colp, mreg, tj);
     else if (lme > ncd - 2 * D) update_rows_fixed<ncd - D, CWP>(colp, mreg, tj);
     else if (lme > ncd - 3 * D) update_rows_fixed<ncd - 2 * D, CWP>(colp, mreg, tj);
@@ -237,7 +237,9 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     const double *cmu = P.t.cmu, *cwt = P.t.cwt;
 
     const BandLds lds(n, nn, REG);
-    constexpr int ncd = 3 * NN - 1, RW = ncd + 1, CW = 2 * ncd + 1, CWP = CW | 1, MG = kBandMargin;
+    // window width: LINPACK's 2*NCD+1 columns for the register variant (a column per lane), the
+    // structural 2*NSTR (u_width) for the LDS variant, which is fed by columns as well as by rows
+    constexpr int ncd = 3 * NN - 1, RW = ncd + 1, CW = REG ? 2 * ncd + 1 : 2 * NN * 2, CWP = CW | 1, MG = kBandMargin;
     double *win = smem + lds.win;
     double *bw = smem + lds.bw;                       // RHS entries of the window rows (LU phase)
     double *yv = P.yv + (size_t)ms * L * n;           // RHS / forward-eliminated RHS in HBM
@@ -577,14 +579,21 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     // depth U over the unrolled step loop): the step never waits for memory latency.
     // Lane mapping of a step: lane c <-> window column k+c (c = 0 is the pivot column); its
     // ring position also serves column k+CW of the entering row.
-    struct Pre { double g0, g1, bv; };
+    // The window is 2*NSTR columns wide -- U's structural bandwidth -- although a row's support
+    // can reach further right when it enters: those elements are no target of any elimination
+    // before their column slides into the window (every pivot row ends inside it), so they are
+    // fed late, a column per step (lane t <-> row k+t; only rows k+nn+1.. can reach column k+CW).
+    // Interchanges do not disturb this: a row with a non-zero in the pivot column ends inside
+    // the window, so neither the pivot row nor the row it displaces has anything left to feed.
+    struct Pre { double g0, g1, bv, cv; };
     auto load_row = [&](int r, Pre &q) {
-        q.g0 = 0.0; q.g1 = 0.0; q.bv = 0.0;
+        q.g0 = 0.0; q.g1 = 0.0; q.bv = 0.0; q.cv = 0.0;
         if (r <= N) {
-            const int k0 = r - RW;           // the step after which the row enters
+            const int k0 = r - RW;           // the step after which the row (and column k0+CW) enters
             q.bv = yv[r - 1];
             q.g0 = row_elem(r, (lane == 0) ? k0 + CW : k0 + lane);
             if (two) q.g1 = row_elem(r, k0 + lane + 64);
+            if (lane > nn && lane <= ncd && k0 + lane <= N) q.cv = row_elem(k0 + lane, k0 + CW);
         }
     };
     constexpr int U = 4;
@@ -637,8 +646,8 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         const double tinv = (piv != 0.0) ? tsel : 0.0;
         // (C) row interchange: row k is retired by this step and never read from LDS again, so
         //     only row l has to receive the old row k (LDS round trip 2: one read, one write);
-        //     the pivot row itself lives on in registers (tj).  Column k of the sub-diagonal
-        //     rows is cleared because column k+CW reuses the slot (LINPACK's fill-in zeroing).
+        //     the pivot row itself lives on in registers (tj).  Column k's slot of the sub-diagonal
+        //     rows is handed to column k+CW in (D).
         double tj = tk, tj2 = tk2;
         if (idx != 0) {
             double *rowl = rowk + idx * CWP;
@@ -655,7 +664,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         } else if (lane <= lm) {
             const double aik = (lane == idx) ? akk : ak;     // element below the pivot after the swap
             mreg = aik * tinv;
-            rowk[lane * CWP + kc] = 0.0;
+            rowk[lane * CWP + kc] = pq.cv;                   // column k's slot now serves column k+CW
             const double bi = (lane == idx) ? bk_old : bwl;
             bw[kq + lane] = bi + bk * mreg;
         }
@@ -681,7 +690,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         const unsigned long long nzm = __ballot(mreg != 0.0);
         if (nzm != 0ull) {
             const int lme = 63 - __clzll((long long)nzm);    // rows k+1..k+lme
-            const int ncols = ju - k;                        // columns k+1..ju
+            const int ncols = (ju - k < CW - 1) ? ju - k : CW - 1;   // columns k+1..ju (all inside the window)
             const double t1 = (lane >= 1 && lane <= ncols) ? tj : 0.0;    // inactive lanes: no stores
             update_rows<NN>(rowk + pcl, mreg, t1, lme);
             if (two && ncols >= 64) {
