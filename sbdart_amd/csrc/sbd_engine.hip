@@ -592,7 +592,7 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
             int32_t *flt = nullptr;
             if (e->use_layer2) {
                 const int gpb2 = 64 / e->G2;
-                const unsigned g2 = (unsigned)((size_t)ns * nmode * ((L + gpb2 - 1) / gpb2));
+                const unsigned g2 = (unsigned)(((size_t)ns * L + gpb2 - 1) / gpb2) * (unsigned)nmode;
                 int32_t *flag = e->d_eigflag;
 #define SBD_L2_LAUNCH(NNv, Gv)                                                                                        \
                 if (e->nn == NNv) {                                                                                   \

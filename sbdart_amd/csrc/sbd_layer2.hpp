@@ -67,12 +67,16 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     const int lane = threadIdx.x;
     const int g = lane % G, gi = lane / G;
     const int L = P.L, nmode = P.nmode, numu = P.numu;
-    const int bpm = (L + GPB - 1) / GPB;                 // blocks per (item, mode)
-    const long long ms = blockIdx.x / bpm;
-    const int lc = (int)(blockIdx.x % bpm) * GPB + gi + 1;
-    const int mazim = (int)(ms % nmode);
-    const int slot = (int)(ms / nmode);
-    if (slot >= P.nslot) return;
+    // blocks are dealt per azimuth mode (the block shares that mode's Ylm table) over the
+    // flattened (item, layer) list of the pass, so that every wave is full whatever L % GPB is
+    const long long per_mode = (long long)P.nslot * L;
+    const unsigned bpmode = (unsigned)((per_mode + GPB - 1) / GPB);
+    const int mazim = (int)(blockIdx.x / bpmode);
+    const long long fid = (long long)(blockIdx.x % bpmode) * GPB + gi;
+    const bool live = fid < per_mode;                       // (the mode's last block may be partial)
+    const int slot = live ? (int)(fid / L) : 0;
+    const int lc = live ? (int)(fid % L) + 1 : L + 1;
+    const long long ms = (long long)slot * nmode + mazim;
 
     const Layer2Lds lds(n, nn, RAD);
     double *shy = smem;                                  // shared: Y(l, iq), cmu, cwt
