@@ -28,16 +28,17 @@
 namespace sbd {
 
 struct Layer2Lds {   // doubles; per-group part + per-block shared part
-    int ld, ldh, gl, sp, sm, lu, vec, group_total, shared_y, shared_total;
+    int ld, ldh, ldq, gl, sp, sm, lu, vec, group_total, shared_y, shared_total;
     __host__ __device__ Layer2Lds(int n, int nn, bool rad)
     {
         ld = n | 1;
-        ldh = nn;                           // (unpadded: one more wave per CU beats the bank conflicts)
+        ldh = nn;                           // S+-: mostly broadcast reads, unpadded
+        ldq = nn | 1;                       // Q+-/L/C and the reduced LU matrix: walked by rows and by columns
         gl = 0;
         sp = gl + ((n + 2) & ~1);
         sm = sp + nn * ldh;
         lu = sm + nn * ldh;                 // Q+ | Q-, later the reduced UPBEAM/UPISOT matrix
-        vec = lu + 2 * nn * ldh;
+        vec = lu + 2 * nn * ldq;
         // ipvt[nn] ints; radiance mode adds zjs, z0s, z1s, psi[2n]
         group_total = (vec + (nn + 1) / 2 + 2 + (rad ? 5 * n : 0) + 1) & ~1;
         shared_y = 0;                       // Y(l, iq) l-major: [n][nn]
@@ -114,19 +115,19 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     double *gl = base + lds.gl;
     double *sp = base + lds.sp, *sm = base + lds.sm;      // S+ , S-   (nn x nn, ld = ldh)
     double *lu = base + lds.lu;
-    double *qp = lu, *qm = lu + nn * lds.ldh;             // Q+ -> L , Q- -> C (alias of lu)
+    double *qp = lu, *qm = lu + nn * lds.ldq;             // Q+ -> L , Q- -> C (alias of lu)
     int *ipvt = (int *)(base + lds.vec);
     double *vec = base + lds.vec + (nn + 1) / 2 + 2;      // radiance mode only:
     double *zjs = vec, *z0s = vec + n, *z1s = vec + 2 * n, *psi = vec + 3 * n;   // psi[2n]
-    constexpr int ldh = NN, ld = n | 1;
+    constexpr int ldh = NN, ldq = NN | 1, ld = n | 1;
     const int me = g + 1;
     const size_t lidx = (size_t)ms * L + (lc - 1);
 #define YS(l, iq) shy[(l) * nn + ((iq) - 1)]             // iq in 1..nn ; Y(l,-mu) = (-1)^(l-m) Y(l,mu)
 #define SP(i, j) sp[((j) - 1) * ldh + ((i) - 1)]
 #define SM(i, j) sm[((j) - 1) * ldh + ((i) - 1)]
-#define QP(i, j) qp[((j) - 1) * ldh + ((i) - 1)]
-#define QM(i, j) qm[((j) - 1) * ldh + ((i) - 1)]
-#define TM(i, j) lu[((j) - 1) * ldh + ((i) - 1)]       // reduced UPBEAM/UPISOT matrix (Q+- are dead by then)
+#define QP(i, j) qp[((j) - 1) * ldq + ((i) - 1)]
+#define QM(i, j) qm[((j) - 1) * ldq + ((i) - 1)]
+#define TM(i, j) lu[((j) - 1) * ldq + ((i) - 1)]       // reduced UPBEAM/UPISOT matrix (Q+- are dead by then)
 
     // ---- GL(k) (SETDIS, disort.f:2583-2585) ----
     const double oprim = sv[o.oprim() + lc - 1];
@@ -405,8 +406,8 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         const double cmu_me = (me <= nn) ? scmu[me - 1] : 1.0;
         double dv = rs - umu0 * apply_ImSW(sp, rdv / cmu_me);
         if (!(P.dbg & 2)) {
-            if (lu_factor_group(lu, ldh, nn, ipvt, g) != 0) status |= 0x02;
-            dv = lu_solve_group<G>(lu, ldh, nn, ipvt, dv, g);
+            if (lu_factor_group(lu, ldq, nn, ipvt, g) != 0) status |= 0x02;
+            dv = lu_solve_group<G>(lu, ldq, nn, ipvt, dv, g);
         }
         const double sv_ = umu0 * (rdv - apply_ImSW(sm, dv)) / cmu_me;
         const double zpl = 0.5 * (sv_ + dv), zmi = 0.5 * (sv_ - dv);     // Z(+mu_me), Z(-mu_me)
@@ -429,16 +430,16 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         if (me <= nn)
             for (int i = 1; i <= nn; ++i) TM(i, me) = ((i == me) ? 1.0 : 0.0) - SP(i, me) * scwt[me - 1];
         wave_lds_sync();
-        if (lu_factor_group(lu, ldh, nn, ipvt, g) != 0) status |= 0x04;
-        const double u = lu_solve_group<G>(lu, ldh, nn, ipvt, 1.0, g);
+        if (lu_factor_group(lu, ldq, nn, ipvt, g) != 0) status |= 0x04;
+        const double u = lu_solve_group<G>(lu, ldq, nn, ipvt, 1.0, g);
         wave_lds_sync();
         if (me <= nn)
             for (int i = 1; i <= nn; ++i) TM(i, me) = ((i == me) ? 1.0 : 0.0) - SM(i, me) * scwt[me - 1];
         wave_lds_sync();
-        if (lu_factor_group(lu, ldh, nn, ipvt, g) != 0) status |= 0x04;
+        if (lu_factor_group(lu, ldq, nn, ipvt, g) != 0) status |= 0x04;
         const double z1 = (1.0 - oprim) * xr1 * u;
         const double cmu_me = (me <= nn) ? scmu[me - 1] : 0.0;
-        const double e = lu_solve_group<G>(lu, ldh, nn, ipvt, cmu_me * z1, g);
+        const double e = lu_solve_group<G>(lu, ldq, nn, ipvt, cmu_me * z1, g);
         const double z0p = (1.0 - oprim) * xr0 * u + e, z0m = (1.0 - oprim) * xr0 * u - e;
         if (me <= nn) {
             double *p0 = P.zp0 + lidx * n, *p1 = P.zp1 + lidx * n;
