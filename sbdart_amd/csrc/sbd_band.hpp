@@ -77,7 +77,11 @@ SBD_DEVICE double dpp_max_step(double v)
     const int lo = __double2loint(v), hi = __double2hiint(v);
     const int olo = __builtin_amdgcn_update_dpp(BOUND ? 0 : lo, lo, CTRL, ROWMASK, 0xF, BOUND);
     const int ohi = __builtin_amdgcn_update_dpp(BOUND ? 0 : hi, hi, CTRL, ROWMASK, 0xF, BOUND);
-    return fmax(v, __hiloint2double(ohi, olo));
+    // v_max_f64 as written: fmax() would first canonicalise the operand it cannot prove quiet
+    double r;
+    const double o = __hiloint2double(ohi, olo);
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));
+    return r;
 }
 template <bool WIDE>
 SBD_DEVICE int wave_first_max(double vabs, int lm, double &vmax)
@@ -188,6 +192,16 @@ SBD_DEVICE void take_row(double (&a)[RW], int idx, double &t)
         constexpr int MID = (LO + HI) / 2;
         if (idx <= MID) take_row<LO, MID>(a, idx, t);
         else take_row<MID + 1, HI>(a, idx, t);
+    }
+}
+// a[0..] to LDS doubles addr[0..], two registers per ds_write2_b64 (offsets in units of 8 bytes)
+template <int J, int RW>
+SBD_DEVICE void write_pairs(unsigned addr, const double (&a)[RW])
+{
+    if constexpr (2 * J + 1 < RW) {
+        asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4"
+                     :: "v"(addr), "v"(a[2 * J]), "v"(a[2 * J + 1]), "n"(2 * J), "n"(2 * J + 1) : "memory");
+        write_pairs<J + 1>(addr, a);
     }
 }
 // a[i-1] = a[i] + t * m(i) for i <= R (lane i holds m(i) in mreg, read through SGPRs), a[i-1] = a[i] beyond
@@ -454,9 +468,10 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         auto step = [&](const int k, double &pq, unsigned long long &pm, auto fast) {
             const int lm = (ncd < N - k) ? ncd : N - k;
             // (A) pivot column -> lanes (lane t <-> row k+t)
-            if (lane == km) {
-#pragma unroll
-                for (int i = 0; i < RW; ++i) tcol[i] = a[i];
+            if (lane == km) {                            // (ds_write2_b64: any two registers per instruction)
+                const unsigned ta = lds_addr(tcol);
+                write_pairs<0>(ta, a);
+                if constexpr (RW & 1) tcol[RW - 1] = a[RW - 1];
             }
             wave_lds_sync();
             double ak = 0.0;
