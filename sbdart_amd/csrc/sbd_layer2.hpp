@@ -60,6 +60,28 @@ SBD_DEVICE double rcp_nr(double x)
     return r * (2.0 - x * r);
 }
 
+// x of lane (l ^ S) for 1 <= S <= 15 on the DPP network: quad_perm for S < 4, row_half_mirror
+// (l ^ 7) and row_mirror (l ^ 15) composed with a smaller S otherwise
+template <int CTRL>
+SBD_DEVICE double dpp_move(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int S>
+SBD_DEVICE double lane_xor(double x)
+{
+    static_assert(S >= 1 && S <= 15, "lane_xor: 1..15");
+    if constexpr (S == 1) return dpp_move<0xB1>(x);          // quad_perm [1,0,3,2]
+    else if constexpr (S == 2) return dpp_move<0x4E>(x);     // quad_perm [2,3,0,1]
+    else if constexpr (S == 3) return dpp_move<0x1B>(x);     // quad_perm [3,2,1,0]
+    else if constexpr (S == 7) return dpp_move<0x141>(x);    // row_half_mirror
+    else if constexpr (S < 7) return dpp_move<0x141>(lane_xor<(S ^ 7)>(x));
+    else if constexpr (S == 15) return dpp_move<0x140>(x);   // row_mirror
+    else return dpp_move<0x140>(lane_xor<(S ^ 15)>(x));
+}
+
 template <int NN, int G, bool RAD>
 __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 {
@@ -209,56 +231,77 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     // ---- one-sided Jacobi, round-robin pairing over the nn columns (nn even or odd) ----
     {
         constexpr int NP = (nn + 1) & ~1;               // players (a dummy when nn is odd)
+        constexpr bool XORS = (NP & (NP - 1)) == 0 && NP <= 16;   // power of two: partner = j ^ s on the DPP network
         const int j = g;                                 // player index 0..NP-1 (lanes >= NP idle)
         const double tol = 2.220446049250313e-16;
-        for (int sweep = 0; sweep < 30; ++sweep) {
-            bool rotated = false;
-            bool coarse = false;     // some pair met in this sweep with |cos(angle)| > 3e-7
-            for (int s = 0; s < NP - 1; ++s) {
-                // circle method: player 0 fixed, the others rotate
-                int pos = (j == 0) ? 0 : 1 + (j - 1 - s + 2 * (NP - 1)) % (NP - 1);
-                const int ppos = NP - 1 - pos;
-                const int partner = (ppos == 0) ? 0 : 1 + (ppos - 1 + s) % (NP - 1);
-                const bool valid = (j < nn) && (partner < nn) && (j < NP);
-                const int src = (j < NP) ? partner : j;
-                double ob[nn], ox[nn];
+        bool rotated = false, coarse = false;
+        // one meeting of this lane's column with its partner's (both lanes run it, each keeps its own)
+        auto meet = [&](const int partner, const bool valid, const double (&ob)[nn], const double (&ox)[nn]) {
+            if (valid) {
+                double aa = 0.0, bb = 0.0, gg = 0.0;
 #pragma unroll
                 for (int i = 0; i < nn; ++i) {
-                    ob[i] = __shfl(bcol[i], src, G);
-                    ox[i] = __shfl(xcol[i], src, G);
+                    aa = aa + bcol[i] * bcol[i];
+                    bb = bb + ob[i] * ob[i];
+                    gg = gg + bcol[i] * ob[i];
                 }
-                if (valid) {
-                    double aa = 0.0, bb = 0.0, gg = 0.0;
+                const double ab = aa * bb, g2 = gg * gg;
+                if (g2 > tol * tol * ab) {           // |cos(angle)| > tol
+                    rotated = true;
+                    coarse = coarse || (g2 > 1.0e-13 * ab);   // ... > 3e-7
+                    const bool lo = j < partner;
+                    // rotation defined for the ordered pair (p<q): alpha=|b_p|^2, beta=|b_q|^2
+                    const double alpha = lo ? aa : bb, beta = lo ? bb : aa;
+                    // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (beta - alpha) / (2 gg), written
+                    // without zeta: t = sign(d) 2gg / (|d| + sqrt(d^2 + 4 gg^2)); c = (1 + t^2)^-1/2.
+                    // Reciprocal (square roots) from v_rsq/v_rcp + Newton steps: an ulp or two off,
+                    // which a Jacobi rotation does not care about
+                    const double d = beta - alpha, tg = 2.0 * gg;
+                    const double h2 = d * d + tg * tg;
+                    const double h = h2 * rsqrt_nr(h2);
+                    const double t = ((d >= 0.0) ? tg : -tg) * rcp_nr(fabs(d) + h);
+                    const double c = rsqrt_nr(1.0 + t * t), sn = c * t;
+                    // p' = c p - s q ; q' = s p + c q
+                    const double mine = c, other = lo ? -sn : sn;
 #pragma unroll
                     for (int i = 0; i < nn; ++i) {
-                        aa = aa + bcol[i] * bcol[i];
-                        bb = bb + ob[i] * ob[i];
-                        gg = gg + bcol[i] * ob[i];
+                        bcol[i] = mine * bcol[i] + other * ob[i];
+                        xcol[i] = mine * xcol[i] + other * ox[i];
                     }
-                    const double ab = aa * bb, g2 = gg * gg;
-                    if (g2 > tol * tol * ab) {           // |cos(angle)| > tol
-                        rotated = true;
-                        coarse = coarse || (g2 > 1.0e-13 * ab);   // ... > 3e-7
-                        const bool lo = j < partner;
-                        // rotation defined for the ordered pair (p<q): alpha=|b_p|^2, beta=|b_q|^2
-                        const double alpha = lo ? aa : bb, beta = lo ? bb : aa;
-                        // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (beta - alpha) / (2 gg), written
-                        // without zeta: t = sign(d) 2gg / (|d| + sqrt(d^2 + 4 gg^2)); c = (1 + t^2)^-1/2.
-                        // Reciprocal (square roots) from v_rsq/v_rcp + Newton steps: an ulp or two off,
-                        // which a Jacobi rotation does not care about
-                        const double d = beta - alpha, tg = 2.0 * gg;
-                        const double h2 = d * d + tg * tg;
-                        const double h = h2 * rsqrt_nr(h2);
-                        const double t = ((d >= 0.0) ? tg : -tg) * rcp_nr(fabs(d) + h);
-                        const double c = rsqrt_nr(1.0 + t * t), sn = c * t;
-                        // p' = c p - s q ; q' = s p + c q
-                        const double mine = c, other = lo ? -sn : sn;
+                }
+            }
+        };
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            rotated = false;
+            coarse = false;          // some pair met in this sweep with |cos(angle)| > 3e-7
+            if constexpr (XORS) {
+                // every pair (j, j ^ s), s = 1..NP-1, meets once per sweep; the exchange is one or two
+                // DPP moves per dword (quad_perm / row_half_mirror / row_mirror), no LDS round trip
+                static_for<NP - 1>([&](auto ss) {
+                    constexpr int sx = decltype(ss)::value + 1;
+                    const int partner = j ^ sx;
+                    double ob[nn], ox[nn];
 #pragma unroll
-                        for (int i = 0; i < nn; ++i) {
-                            bcol[i] = mine * bcol[i] + other * ob[i];
-                            xcol[i] = mine * xcol[i] + other * ox[i];
-                        }
+                    for (int i = 0; i < nn; ++i) {
+                        ob[i] = lane_xor<sx>(bcol[i]);
+                        ox[i] = lane_xor<sx>(xcol[i]);
                     }
+                    meet(partner, (j < nn) && (partner < nn), ob, ox);
+                });
+            } else {
+                for (int s = 0; s < NP - 1; ++s) {
+                    // circle method: player 0 fixed, the others rotate
+                    int pos = (j == 0) ? 0 : 1 + (j - 1 - s + 2 * (NP - 1)) % (NP - 1);
+                    const int ppos = NP - 1 - pos;
+                    const int partner = (ppos == 0) ? 0 : 1 + (ppos - 1 + s) % (NP - 1);
+                    const int src = (j < NP) ? partner : j;
+                    double ob[nn], ox[nn];
+#pragma unroll
+                    for (int i = 0; i < nn; ++i) {
+                        ob[i] = __shfl(bcol[i], src, G);
+                        ox[i] = __shfl(xcol[i], src, G);
+                    }
+                    meet(partner, (j < nn) && (partner < nn) && (j < NP), ob, ox);
                 }
             }
             // quadratic convergence: a sweep that started below 3e-7 ends below 1e-13 (eigenvalues to
