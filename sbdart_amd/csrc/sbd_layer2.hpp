@@ -319,12 +319,15 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         for (int i = 0; i < nn; ++i) lam = lam + bcol[i] * bcol[i];
         kq = sqrt(fabs(lam));
         const double rkq = 1.0 / kq;
+        double wx[nn];                                  // W x
+#pragma unroll
+        for (int k = 0; k < nn; ++k) wx[k] = scwt[k] * xcol[k];
 #pragma unroll
         for (int i = 1; i <= nn; ++i) {
-            // AMB(i,k) = (S-(i,k) w_k - delta_ik) / mu_i
-            double s = 0.0;
+            // AMB x = M^-1 (S- W x - x)
+            double s = -xcol[i - 1];
 #pragma unroll
-            for (int k = 1; k <= nn; ++k) s = s + (SM(i, k) * scwt[k - 1] - ((i == k) ? 1.0 : 0.0)) * xcol[k - 1];
+            for (int k = 1; k <= nn; ++k) s = s + SM(i, k) * wx[k - 1];
             gp[i - 1] = s * smi[i - 1] * rkq;
         }
         double *kkout = P.kk + lidx * n;
@@ -409,11 +412,22 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     };
     // y = A x for A = I - S W (S = S+ or S-), x spread over the lanes (lane k holds x_k)
     auto apply_ImSW = [&](const double *smat, double xv) -> double {
-        double acc = 0.0;
+        const double wxv = (me <= nn) ? scwt[me - 1] * xv : 0.0;     // (W x)(me)
+        double acc = xv;
+        if constexpr (G == nn && (nn & (nn - 1)) == 0) {
+            // every lane of the group owns a row: partner k = (me-1) ^ s on the DPP network (S symmetric)
+            acc = acc - smat[(me - 1) * ldh + (me - 1)] * wxv;
+            static_for<nn - 1>([&](auto ss) {
+                constexpr int sx = decltype(ss)::value + 1;
+                const int k0 = (me - 1) ^ sx;
+                acc = acc - smat[k0 * ldh + (me - 1)] * lane_xor<sx>(wxv);
+            });
+        } else {
 #pragma unroll
-        for (int k = 1; k <= nn; ++k) {
-            const double xk = __shfl(xv, k - 1, G);
-            if (me <= nn) acc = acc + (((me == k) ? 1.0 : 0.0) - smat[(k - 1) * ldh + (me - 1)] * scwt[k - 1]) * xk;
+            for (int k = 1; k <= nn; ++k) {
+                const double wk = __shfl(wxv, k - 1, G);
+                if (me <= nn) acc = acc - smat[(k - 1) * ldh + (me - 1)] * wk;
+            }
         }
         return acc;
     };
@@ -428,11 +442,14 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 #pragma unroll
             for (int k = 1; k <= nn; ++k)
                 qv[k - 1] = (((k == me) ? 1.0 : 0.0) - SM(k, me) * scwt[me - 1]) * smi[k - 1];
-            for (int i = 1; i <= nn; ++i) {
-                double acc = 0.0;
+            double wq[nn];                              // W qv
 #pragma unroll
-                for (int k = 1; k <= nn; ++k)
-                    acc = acc + (((i == k) ? 1.0 : 0.0) - SP(i, k) * scwt[k - 1]) * qv[k - 1];
+            for (int k = 0; k < nn; ++k) wq[k] = scwt[k] * qv[k];
+#pragma unroll
+            for (int i = 1; i <= nn; ++i) {
+                double acc = qv[i - 1];                  // ((I - S+ W) qv)(i)
+#pragma unroll
+                for (int k = 1; k <= nn; ++k) acc = acc - SP(i, k) * wq[k - 1];
                 TM(i, me) = ((i == me) ? scmu[me - 1] / umu0 : 0.0) - umu0 * acc;
             }
             double se = 0.0, so = 0.0;
