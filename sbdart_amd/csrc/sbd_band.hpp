@@ -64,42 +64,44 @@ struct SolveLds {   // per-wave carve-up of the back-substitution + flux kernel 
 };
 
 // Pivot search over the low lanes of the wave with LINPACK's first-maximum tie rule, on the DPP
-// network (no LDS round trips), in two moves: the maximum magnitude by an inclusive max-scan
-// towards the higher lanes inside each row of 16 (row_shr 1,2,4,8; invalid sources read 0.0,
-// neutral for magnitudes), then row_bcast15 (and row_bcast31 when more than 32 candidates), so
-// that lane 31 / 63 holds it; then the first lane that holds it (ballot + find-first-set):
-// ISAMAX's tie rule without carrying indices through the scan.
-// v >= 0 on the candidate lanes 0..lm, anything on the others.  Returns the lane, 0 when the
-// whole column is zero (or NaN); vmax gets the magnitude.
+// network (no LDS round trips).  Magnitudes of doubles order like their bit patterns, so the
+// maximum is found on 32-bit words: an inclusive v_max_u32 scan of the leading words towards
+// the higher lanes inside each row of 16 (row_shr 1,2,4,8; invalid sources read 0), then
+// row_bcast15 (and row_bcast31 when more than 32 candidates), lane 31 / 63 holds the maximum;
+// the lanes that hold it are found by a ballot, and only if several do, the same scan settles
+// it on the trailing words.  The first such lane (find-first-set) is ISAMAX's answer; an
+// all-zero column returns lane 0 (the diagonal; the caller flags the zero pivot).
 template <int CTRL, int ROWMASK, bool BOUND>
-SBD_DEVICE double dpp_max_step(double v)
+SBD_DEVICE unsigned dpp_umax_step(unsigned v)
 {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int olo = __builtin_amdgcn_update_dpp(BOUND ? 0 : lo, lo, CTRL, ROWMASK, 0xF, BOUND);
-    const int ohi = __builtin_amdgcn_update_dpp(BOUND ? 0 : hi, hi, CTRL, ROWMASK, 0xF, BOUND);
-    // v_max_f64 as written: fmax() would first canonicalise the operand it cannot prove quiet
-    double r;
-    const double o = __hiloint2double(ohi, olo);
-    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));
-    return r;
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(BOUND ? 0 : (int)v, (int)v, CTRL, ROWMASK, 0xF, BOUND);
+    return v > o ? v : o;
 }
 template <bool WIDE>
-SBD_DEVICE int wave_first_max(double vabs, int lm, double &vmax)
+SBD_DEVICE unsigned wave_umax(unsigned v)
+{
+    v = dpp_umax_step<0x111, 0xF, true>(v);    // row_shr:1
+    v = dpp_umax_step<0x112, 0xF, true>(v);    // row_shr:2
+    v = dpp_umax_step<0x114, 0xF, true>(v);    // row_shr:4
+    v = dpp_umax_step<0x118, 0xF, true>(v);    // row_shr:8
+    v = dpp_umax_step<0x142, 0xA, false>(v);   // row_bcast:15 -> rows 1,3
+    if (WIDE) v = dpp_umax_step<0x143, 0xC, false>(v);   // row_bcast:31 -> rows 2,3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, WIDE ? 63 : 31);
+}
+template <bool WIDE>
+SBD_DEVICE int wave_first_max(double a, int lm)
 {
     const bool cand = (int)threadIdx.x <= lm;
-    double v = cand ? vabs : 0.0;
-    const double v0 = v;
-    v = dpp_max_step<0x111, 0xF, true>(v);    // row_shr:1
-    v = dpp_max_step<0x112, 0xF, true>(v);    // row_shr:2
-    v = dpp_max_step<0x114, 0xF, true>(v);    // row_shr:4
-    v = dpp_max_step<0x118, 0xF, true>(v);    // row_shr:8
-    v = dpp_max_step<0x142, 0xA, false>(v);   // row_bcast:15 -> rows 1,3
-    if (WIDE) v = dpp_max_step<0x143, 0xC, false>(v);   // row_bcast:31 -> rows 2,3
-    constexpr int SRC = WIDE ? 63 : 31;
-    vmax = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), SRC),
-                            __builtin_amdgcn_readlane(__double2loint(v), SRC));
-    const unsigned long long hit = __ballot(cand && v0 == vmax);
-    return (vmax > 0.0 && hit != 0ull) ? __ffsll((long long)hit) - 1 : 0;
+    const unsigned hi = cand ? ((unsigned)__double2hiint(a) & 0x7fffffffu) : 0u;
+    const unsigned mhi = wave_umax<WIDE>(hi);
+    unsigned long long hit = __ballot(cand && hi == mhi);
+    if (hit & (hit - 1ull)) {                       // several lanes share the leading word
+        const bool c2 = cand && hi == mhi;
+        const unsigned lo = c2 ? (unsigned)__double2loint(a) : 0u;
+        const unsigned mlo = wave_umax<WIDE>(lo);
+        hit = __ballot(c2 && lo == mlo);
+    }
+    return hit ? __ffsll((long long)hit) - 1 : 0;
 }
 
 // broadcast lane `src` (compile-time) of a double to the whole wave through SGPRs
@@ -481,8 +483,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             rk = rk * (2.0 - ak * rk);
             rk = -rk;
             // (B) ISAMAX's first-maximum rule on the DPP network
-            double vmax;
-            const int idx = wave_first_max<false>(fabs(ak), lm, vmax);
+            const int idx = wave_first_max<false>(ak, lm);
             auto pick = [&](double x, int src) {
                 return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src),
                                         __builtin_amdgcn_readlane(__double2loint(x), src));
@@ -640,8 +641,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         rk = rk * (2.0 - ak * rk);
         rk = -rk;
         // (B) pivot search over rows k..k+lm of column k (ISAMAX's first-maximum rule)
-        double vmax;                         // (an all-zero or NaN column keeps the diagonal and is flagged)
-        const int idx = wave_first_max<(RW > 32)>(fabs(ak), lm, vmax);
+        const int idx = wave_first_max<(RW > 32)>(ak, lm);   // (an all-zero column keeps the diagonal and is flagged)
         const int l = k + idx;
         // idx is wave-uniform: v_readlane with a scalar lane select instead of a bpermute
         auto pick = [&](double x, int src) {
