@@ -44,7 +44,7 @@ struct BandLds {   // per-wave carve-up of the LU kernel (doubles)
         cw = reg ? 2 * ncd + 1 : 2 * n;
         cwp = cw | 1;
         win = 0;                                                    // sliding window ...
-        bw = win + (reg ? ((rw + 1) & ~1) : (rw + kBandMargin) * cwp);   // (register variant: the pivot column only)
+        bw = win + (reg ? 32 : (rw + kBandMargin) * cwp);           // (register variant: the pivot column only, 2 x 16)
         misc = bw + (reg ? 0 : ((rw + kBandMargin + 2) & ~1));      // ... + its RHS entries
         total = (misc + 8 + n + 1) & ~1;                            // [n] surface-reflection sums
     }
@@ -206,14 +206,24 @@ SBD_DEVICE void write_pairs(unsigned addr, const double (&a)[RW])
         write_pairs<J + 1>(addr, a);
     }
 }
-// a[i-1] = a[i] + t * m(i) for i <= R (lane i holds m(i) in mreg, read through SGPRs), a[i-1] = a[i] beyond
-template <int R, int RW>
-SBD_DEVICE void update_shift(double (&a)[RW], double t, double mreg)
+// a[i-1] = a[i] + t * m(i) for i <= R, a[i-1] = a[i] beyond.  The multipliers are replicated in
+// every row of 16 lanes (lane 16r+q holds m(q) in mlo and m(16+q) in mhi), so that the DP-ALU DPP
+// form of the FMA can take them straight from a lane of its own row (row_newbcast): one
+// instruction per row of the window instead of two v_readlane and an FMA.
+template <int I>
+SBD_DEVICE void fmac_rowbcast(double &acc, double m, double t)
 {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(m), "v"(t), "n"(I & 15));
+}
+template <int R, int RW>
+SBD_DEVICE void update_shift(double (&a)[RW], double t, double mlo, double mhi)
+{
+    static_assert(RW <= 32, "two multiplier registers cover 32 window rows");
     static_for<RW - 1>([&](auto ii) {
         constexpr int i = decltype(ii)::value + 1;
-        if constexpr (i <= R) a[i - 1] = a[i] + t * bcast_lane<i>(mreg);
-        else a[i - 1] = a[i];
+        a[i - 1] = a[i];
+        if constexpr (i <= R) fmac_rowbcast<i>(a[i - 1], (i < 16) ? mlo : mhi, t);
     });
 }
 
@@ -476,8 +486,12 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
                 if constexpr (RW & 1) tcol[RW - 1] = a[RW - 1];
             }
             wave_lds_sync();
-            double ak = 0.0;
-            if (lane <= lm) ak = tcol[lane];
+            // every row of 16 lanes reads the whole column (q = lane % 16: entries q and 16+q)
+            const int q16 = lane & 15;
+            double ak_lo = 0.0, ak_hi = 0.0;
+            if (q16 <= lm) ak_lo = tcol[q16];
+            if (16 + q16 <= lm) ak_hi = tcol[16 + q16];
+            const double ak = (lane < 16) ? ak_lo : ((lane < 32) ? ak_hi : 0.0);   // lane t <-> row k+t
             double rk = __builtin_amdgcn_rcp(ak);        // -1/a for every candidate (v_rcp + 2 Newton steps)
             rk = rk * (2.0 - ak * rk);
             rk = rk * (2.0 - ak * rk);
@@ -493,8 +507,10 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             if (piv == 0.0) status |= 0x01;
             const double tinv = (piv != 0.0) ? tsel : 0.0;
             // (C) multipliers -a/pivot (after the interchange), lane t holds the one of row k+t
-            double mreg = 0.0;
-            if (lane >= 1 && lane <= lm) mreg = ((lane == idx) ? akk : ak) * tinv;
+            double mlo = 0.0, mhi = 0.0;                 // m(q), m(16+q) in every row of lanes
+            if (q16 >= 1 && q16 <= lm) mlo = ((q16 == idx) ? akk : ak_lo) * tinv;
+            if (16 + q16 <= lm) mhi = ((16 + q16 == idx) ? akk : ak_hi) * tinv;
+            const double mreg = (lane < 16) ? mlo : ((lane < 32) ? mhi : 0.0);
             // (D) pivot row out of its register, old row k into that register
             double tj;
             take_row<0, RW - 1>(a, idx, tj);
@@ -512,11 +528,11 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             const int lme = nzm ? 63 - __clzll((long long)nzm) : 0;
             {
                 constexpr int D = (2 * NN + 3) / 4;
-                if (lme > ncd - D) update_shift<ncd>(a, tj, mreg);
-                else if (lme > ncd - 2 * D) update_shift<ncd - D>(a, tj, mreg);
-                else if (lme > ncd - 3 * D) update_shift<ncd - 2 * D>(a, tj, mreg);
-                else if (lme > 0) update_shift<ncd - 3 * D>(a, tj, mreg);
-                else update_shift<0>(a, tj, mreg);
+                if (lme > ncd - D) update_shift<ncd>(a, tj, mlo, mhi);
+                else if (lme > ncd - 2 * D) update_shift<ncd - D>(a, tj, mlo, mhi);
+                else if (lme > ncd - 3 * D) update_shift<ncd - 2 * D>(a, tj, mlo, mhi);
+                else if (lme > 0) update_shift<ncd - 3 * D>(a, tj, mlo, mhi);
+                else update_shift<0>(a, tj, mlo, mhi);
             }
             // (G) the entering row takes the last register.  An explicit move: the prefetched
             //     value keeps a register of its own for the whole loop, so the only wait for its
