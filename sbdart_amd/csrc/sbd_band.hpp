@@ -470,9 +470,26 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         constexpr int U = 4;
         double pre[U];
         unsigned long long pmask[U];                     // lanes whose prefetched value is an element (else 0)
+        // steady-state form of elem_fast: the lane's column under the mapping of step k1 is carried
+        // along (it only changes when the lane is handed the next column, 63 further on)
+        int kmp = 0, colp = 0;                           // k1 mod 63 and the lane's column for the next fast load
+        auto elem_next = [&](int r, int k1, unsigned long long &vmask) -> double {
+            const int qq = r - nn - 1;
+            const int lcn = (qq / n) * n;                        // first column of the row's support - 1
+            const int d = colp - lcn;                            // 1..2n inside the row's support
+            const int lim = (k1 + CW < N + 1) ? k1 + CW : N + 1;
+            const bool valid = rhs || ((unsigned)(d - 1) < (unsigned)(2 * n) && colp < lim);
+            const int ix = qq * n - lcn - 1 + colp;              // index into the layer-lc block
+            const double *p = rhs ? yv + (r - 1) : (d <= n ? ga_ms + ix : gb_ms + (ix - n));
+            vmask = __ballot(valid);
+            const double g = *(valid ? p : yv);
+            if (lane == kmp) colp += RING;                       // this lane's column leaves at step k1
+            kmp = (kmp + 1 == RING) ? 0 : kmp + 1;
+            return g;
+        };
         auto load_row = [&](int r, double &g, unsigned long long &vm, auto fast) {   // row r enters at the end of step r - RW
             const int k1 = r - RW + 1;
-            if constexpr (decltype(fast)::value) g = elem_fast(r, k1 % RING, k1, vm);
+            if constexpr (decltype(fast)::value) g = elem_next(r, k1, vm);
             else { g = elem_for(r, k1 % RING, k1); vm = ~0ull; }
         };
 #pragma unroll
@@ -549,6 +566,13 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         // steady state: whole groups of U steps whose entering rows are all interface rows (no
         // exits and a single kind of load inside, so the loads stay in flight across steps)
         const int kfast = N - nn - RW - U;               // last step whose load is an interface row
+        {                                                // mapping of the first fast load (step 1 loads row RW+1+U)
+            const int k1 = U + 2;
+            kmp = k1 % RING;
+            int c = lane - kmp;
+            if (c < 0) c += RING;
+            colp = k1 + c;
+        }
         for (; k + U - 1 <= kfast; k += U) {
             if (((k - 1) % ZPER) == 0) {                 // clear the lanes whose column has left the window
                 int c = lane - km;
