@@ -19,8 +19,9 @@
 // out: for s = Z+ + Z-, d = Z+ - Z- the NSTR x NSTR system splits into
 //     (I - S+ W) s + (M/mu0) d = r+ + r-,     (I - S- W) d + (M/mu0) s = r+ - r-,
 // i.e. ONE NSTR/2 x NSTR/2 pivoted LU of T = M/mu0 - mu0 (I - S+ W) M^-1 (I - S- W) for the
-// beam source and two (I - S+ W, I - S- W) for the thermal one (no M/mu0 coupling there) --
-// an eighth of the elimination work and a quarter of the LDS of the full system.
+// beam source; the thermal one (no M/mu0 coupling there) needs I - S+ W and I - S- W, which are
+// R^-1 Q+- R^-1 W: two triangular solve pairs with the Cholesky factors already in LDS.
+// An eighth of the elimination work and a quarter of the LDS of the full system.
 #pragma once
 #include "sbd_common.hpp"
 #include "sbd_layer.hpp"
@@ -362,7 +363,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
             }
         }
     }
-    wave_lds_sync();      // Q+/Q- (the lu area) are dead from here on
+    wave_lds_sync();      // (L and C stay in the lu area until UPBEAM builds its matrix there)
 
     // ---- radiance mode: TERPEV from the register-resident eigenvector columns ----
     if constexpr (rad) {
@@ -431,6 +432,48 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         }
         return acc;
     };
+    // ---- UPISOT (disort.f:4309-4349) from the Cholesky factors at hand: with Q+ = L L^T,
+    //      I - S+ W = R^-1 Q+ R^-1 W, so (I - S+ W) u = b is L L^T y = R b, u = W^-1 R y (no second
+    //      factorisation, no pivoting: Q+- are positive definite here), likewise I - S- W with C.
+    //      Runs before UPBEAM, whose reduced matrix takes over the LDS of L and C. ----
+    auto chol_solve = [&](const double *fac, double bv) -> double {   // (F F^T) y = b, lane i <-> row i
+#pragma unroll
+        for (int k = 1; k <= nn; ++k) {
+            const double yk = __shfl(bv, k - 1, G) * rcp_nr(fac[(k - 1) * ldq + (k - 1)]);
+            if (me == k) bv = yk;
+            else if (me > k && me <= nn) bv = bv - fac[(k - 1) * ldq + (me - 1)] * yk;      // F(me, k)
+        }
+#pragma unroll
+        for (int k = nn; k >= 1; --k) {
+            const double yk = __shfl(bv, k - 1, G) * rcp_nr(fac[(k - 1) * ldq + (k - 1)]);
+            if (me == k) bv = yk;
+            else if (me < k) bv = bv - fac[(me - 1) * ldq + (k - 1)] * yk;                   // F(k, me)
+        }
+        return bv;
+    };
+    const bool thermal = plank && mazim == 0;
+    if (thermal) {
+        // (I - CC) Z1 = (1-w') XR1 (the same in both halves): Z1+- = (1-w') XR1 u, (I - S+ W) u = 1;
+        // (I - CC) Z0 = (1-w') XR0 + CMU Z1: Z0+- = (1-w') XR0 u +- e, (I - S- W) e = mu Z1
+        const double xr0 = sv[o.xr0() + lc - 1], xr1 = sv[o.xr1() + lc - 1];
+        const double rme = (me <= nn) ? srr[me - 1] : 0.0, rw = (me <= nn) ? srr[me - 1] * swi[me - 1] : 0.0;
+        const double cmu_me = (me <= nn) ? scmu[me - 1] : 0.0;
+        const double u = rw * chol_solve(qp, rme);
+        const double z1 = (1.0 - oprim) * xr1 * u;
+        const double e = rw * chol_solve(qm, rme * cmu_me * z1);
+        const double z0p = (1.0 - oprim) * xr0 * u + e, z0m = (1.0 - oprim) * xr0 * u - e;
+        if (me <= nn) {
+            double *p0 = P.zp0 + lidx * n, *p1 = P.zp1 + lidx * n;
+            p0[me + nn - 1] = z0p; p1[me + nn - 1] = z1;
+            p0[nn - me] = z0m;     p1[nn - me] = z1;
+            if constexpr (rad) { z0s[me - 1] = z0p; z0s[me + nn - 1] = z0m; z1s[me - 1] = z1; z1s[me + nn - 1] = z1; }
+        }
+        wave_lds_sync();
+    } else if (mazim == 0 && me <= nn) {
+        P.zp0[lidx * n + me - 1] = 0.0; P.zp0[lidx * n + me + nn - 1] = 0.0;
+        P.zp1[lidx * n + me - 1] = 0.0; P.zp1[lidx * n + me + nn - 1] = 0.0;
+    }
+
     int status = 0;
     if (fbeam > 0.0) {
         const double delm0 = (mazim == 0) ? 1.0 : 0.0;
@@ -482,37 +525,6 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         P.zz[lidx * n + me - 1] = 0.0;
         P.zz[lidx * n + me + nn - 1] = 0.0;
     }
-    const bool thermal = plank && mazim == 0;
-    if (thermal) {
-        // (I - CC) Z1 = (1-w') XR1 (the same in both halves): Z1+- = (1-w') XR1 u, (I - S+ W) u = 1;
-        // (I - CC) Z0 = (1-w') XR0 + CMU Z1: Z0+- = (1-w') XR0 u +- e, (I - S- W) e = mu Z1   (disort.f:4309-4349)
-        const double xr0 = sv[o.xr0() + lc - 1], xr1 = sv[o.xr1() + lc - 1];
-        if (me <= nn)
-            for (int i = 1; i <= nn; ++i) TM(i, me) = ((i == me) ? 1.0 : 0.0) - SP(i, me) * scwt[me - 1];
-        wave_lds_sync();
-        if (lu_factor_group(lu, ldq, nn, ipvt, g) != 0) status |= 0x04;
-        const double u = lu_solve_group<G>(lu, ldq, nn, ipvt, 1.0, g);
-        wave_lds_sync();
-        if (me <= nn)
-            for (int i = 1; i <= nn; ++i) TM(i, me) = ((i == me) ? 1.0 : 0.0) - SM(i, me) * scwt[me - 1];
-        wave_lds_sync();
-        if (lu_factor_group(lu, ldq, nn, ipvt, g) != 0) status |= 0x04;
-        const double z1 = (1.0 - oprim) * xr1 * u;
-        const double cmu_me = (me <= nn) ? scmu[me - 1] : 0.0;
-        const double e = lu_solve_group<G>(lu, ldq, nn, ipvt, cmu_me * z1, g);
-        const double z0p = (1.0 - oprim) * xr0 * u + e, z0m = (1.0 - oprim) * xr0 * u - e;
-        if (me <= nn) {
-            double *p0 = P.zp0 + lidx * n, *p1 = P.zp1 + lidx * n;
-            p0[me + nn - 1] = z0p; p1[me + nn - 1] = z1;
-            p0[nn - me] = z0m;     p1[nn - me] = z1;
-            if constexpr (rad) { z0s[me - 1] = z0p; z0s[me + nn - 1] = z0m; z1s[me - 1] = z1; z1s[me + nn - 1] = z1; }
-        }
-        wave_lds_sync();
-    } else if (mazim == 0 && me <= nn) {
-        P.zp0[lidx * n + me - 1] = 0.0; P.zp0[lidx * n + me + nn - 1] = 0.0;
-        P.zp1[lidx * n + me - 1] = 0.0; P.zp1[lidx * n + me + nn - 1] = 0.0;
-    }
-
     // ---- TERPSO (disort.f:3980-4128) ----
     if constexpr (rad) {
         const double *ylmu = P.t.ylmu + (size_t)mazim * numu * (n + 1);
