@@ -284,6 +284,13 @@ def test_lds_window_variant_matches():
     assert max(errs) < TOL, max(errs)
 
 
+def test_small_passes_match():
+    """SBD_CHUNK=5 cuts the batch into passes of five work items (workspace reuse, list reset and
+    output offsets between passes): same answers."""
+    errs = _alt_path_errors(SBD_CHUNK="5")
+    assert max(errs) < TOL, max(errs)
+
+
 def test_qr_fallback_path_matches():
     """SBD_FORCE_EIG_FALLBACK routes every layer through the QR kernel (the path taken when a
     Cholesky pivot of the symmetrised problem is not positive): same answers."""
