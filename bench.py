@@ -43,8 +43,10 @@ def algorithmic_flops_per_solve(nlyr, nstr):
 
 def cpu_baseline(sw, seconds_target=12.0):
     """Reference DISORT (oracle/_ref/disort_ref_cli, kind "reference") or the C restatement
-    (kind "port") timed on ONE host core over a bounded sample of the same workload."""
-    from sbdart_amd.records import write_records
+    (kind "port") timed on ONE host core over a bounded sample of the same workload.
+    Returns (baseline dict, reference fluxes of the sample [nsample][3][2]: rfldir, rfldn, flup at
+    TOA and surface) -- the second feeds the "flux RMSE vs CPU" half of the metric."""
+    from sbdart_amd.records import read_records, write_records
     from sbdart_amd.workload import sweep_to_records
     cli = os.path.join(ROOT, "oracle", "_ref", "disort_ref_cli")
     avg_nk = sw.nwork / sw.nwl
@@ -58,6 +60,10 @@ def cpu_baseline(sw, seconds_target=12.0):
             probe = time.time() - t0
             rep = max(1, min(20, int(seconds_target / max(probe, 1e-3))))
             out = subprocess.run([cli, "in.sbdrec", "out.sbdrec", str(rep)], cwd=d, capture_output=True, text=True)
+            ref = None
+            if os.path.exists(os.path.join(d, "out.sbdrec")):
+                ro = read_records(os.path.join(d, "out.sbdrec"))
+                ref = np.array([[[r.rfldir[0], r.rfldir[-1]], [r.rfldn[0], r.rfldn[-1]], [r.flup[0], r.flup[-1]]] for r in ro])
         for line in out.stdout.splitlines():
             if line.startswith("TIMING"):
                 _, nsolve, secs = line.split()
@@ -65,12 +71,13 @@ def cpu_baseline(sw, seconds_target=12.0):
                 return {"value": sps / avg_nk, "unit": "spectral-points/s", "cores": 1, "kind": "reference",
                         "solves_per_s": sps,
                         "sample": f"{nsample} solves of this workload x {rep} repeats, reference DISORT "
-                                  f"(amdflang -O2) on 1 host core, DISORT calls only"}
+                                  f"(amdflang -O2) on 1 host core, DISORT calls only"}, ref
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle  # baseline leg only
     nsample = min(sw.nwork, 1500)
     recs = sweep_to_records(sw, range(nsample))
-    pyoracle.disort(recs[0])
+    o0 = [pyoracle.disort(r) for r in recs]
+    ref = np.array([[[o["rfldir"][0], o["rfldir"][-1]], [o["rfldn"][0], o["rfldn"][-1]], [o["flup"][0], o["flup"][-1]]] for o in o0])
     t0 = time.time()
     n = 0
     while time.time() - t0 < seconds_target:
@@ -81,7 +88,7 @@ def cpu_baseline(sw, seconds_target=12.0):
     return {"value": n / secs / avg_nk, "unit": "spectral-points/s", "cores": 1, "kind": "port",
             "solves_per_s": n / secs,
             "sample": f"{nsample} solves of this workload repeated for {secs:.1f}s, C restatement "
-                      f"(oracle/disort_oracle.c, gcc -O2) through ctypes on 1 host core"}
+                      f"(oracle/disort_oracle.c, gcc -O2) through ctypes on 1 host core"}, ref
 
 
 def main():
@@ -212,7 +219,24 @@ def main():
                          "fp64_frac_of_vector_peak": flops * W / (phase_ms.sum() * 1e-3) / 1e12 / FP64_VEC_PEAK_TF},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(sw)
+            out["cpu_baseline"], ref = cpu_baseline(sw)
+            if ref is not None:
+                # the other half of the metric: GPU vs CPU on the sampled solves, TOA (level 0) and
+                # surface (level 1) -- per solve (fbeam = 1: fluxes per unit incident beam) and for
+                # the spectrally weighted sums of the sample (stdout1's TOPDN..BOTDIR, drt.f:1047-1054)
+                ns = ref.shape[0]
+                g = flux[:ns, :3, :].cpu().numpy()                       # [ns][rfldir, rfldn, flup][top, bot]
+                six = lambda a: np.stack([a[:, 1] + a[:, 0], a[:, 2], a[:, 0]], 1).reshape(ns, 6)   # dn, up, dir at top|bot
+                sg, sr = six(g), six(ref)
+                wgt = np.asarray(sw.weight[:ns], dtype=np.float64)[:, None]
+                out["flux_rmse_vs_cpu"] = {
+                    "per_solve_rmse": float(np.sqrt(np.mean((sg - sr) ** 2))),
+                    "per_solve_max_abs": float(np.abs(sg - sr).max()),
+                    "per_solve_max_rel_to_max": float(np.abs(sg - sr).max() / np.abs(sr).max()),
+                    "integrated_max_abs": float(np.abs(((sg - sr) * wgt).sum(0)).max()),
+                    "integrated_ref_max": float(np.abs((sr * wgt).sum(0)).max()),
+                    "quantities": "TOPDN,BOTDN,TOPUP,BOTUP,TOPDIR,BOTDIR", "solves": int(ns),
+                    "units": "fluxes per unit FBEAM (synthetic sweep has FBEAM = 1); north_star gate 1e-4 W/m2 on integrated fluxes"}
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out))
