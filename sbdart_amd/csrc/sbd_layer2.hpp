@@ -216,13 +216,18 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     // ---- B = C^T L and X0 = (M R)^-1 L : lane j <-> column j, in registers ----
     double bcol[nn], xcol[nn];
     if (me <= nn) {
+        // column me of L, its upper part read as zeros, once into registers
+        double lcol[nn];
+#pragma unroll
+        for (int k = 1; k <= nn; ++k) lcol[k - 1] = (k >= me) ? QP(k, me) : 0.0;
 #pragma unroll
         for (int i = 1; i <= nn; ++i) {
             double s = 0.0;
-            // (C^T L)(i,j) = sum_{k >= max(i,j)} C(k,i) L(k,j)
-            for (int k = (i > me ? i : me); k <= nn; ++k) s = s + QM(k, i) * QP(k, me);
+            // (C^T L)(i,j) = sum_{k >= max(i,j)} C(k,i) L(k,j): static k >= i, zeros of L below j
+#pragma unroll
+            for (int k = i; k <= nn; ++k) s = s + QM(k, i) * lcol[k - 1];
             bcol[i - 1] = s;
-            xcol[i - 1] = (i >= me) ? QP(i, me) * sxi[i - 1] : 0.0;
+            xcol[i - 1] = lcol[i - 1] * sxi[i - 1];
         }
     } else {
 #pragma unroll
