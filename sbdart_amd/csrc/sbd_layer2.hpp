@@ -168,17 +168,17 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     if (me <= nn) {
         double yj[n];   // GL(l) * Y(l, mu_j): the j-dependent factor of every term
 #pragma unroll
-        for (int l = 0; l < n; ++l) yj[l] = gl[l] * YS(l, me);
+        for (int l = 0; l < n; ++l) yj[l] = (l >= mazim) ? gl[l] * YS(l, me) : 0.0;   // the sums start at l = m
         const double rj = srr[me - 1];
+        const bool mpar = (mazim & 1) != 0;              // l - m even <=> l has m's parity
         for (int iq = 1; iq <= nn; ++iq) {
-            double se = 0.0, so = 0.0;
+            double s0 = 0.0, s1 = 0.0;                   // over even l, over odd l: plain FMAs
 #pragma unroll
-            for (int l = 0; l < n; ++l) {
-                if (l >= mazim) {
-                    const double t = YS(l, iq) * yj[l];
-                    if (((l - mazim) & 1) == 0) se = se + t; else so = so + t;
-                }
+            for (int l = 0; l < n; l += 2) {
+                s0 = s0 + YS(l, iq) * yj[l];
+                s1 = s1 + YS(l + 1, iq) * yj[l + 1];
             }
+            const double se = mpar ? s1 : s0, so = mpar ? s0 : s1;
             SP(iq, me) = se;
             SM(iq, me) = so;
             const double ri = srr[iq - 1];
