@@ -500,11 +500,14 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                 for (int k = 1; k <= nn; ++k) acc = acc - SP(i, k) * wq[k - 1];
                 TM(i, me) = ((i == me) ? scmu[me - 1] / umu0 : 0.0) - umu0 * acc;
             }
-            double se = 0.0, so = 0.0;
-            for (int k = mazim; k <= n - 1; ++k) {
-                const double t = gl[k] * YS(k, me) * ylm0[k];
-                if (((k - mazim) & 1) == 0) se = se + t; else so = so + t;
+            double s0 = 0.0, s1 = 0.0;                   // over even k, over odd k (k >= m by the mask)
+#pragma unroll
+            for (int k = 0; k < n; k += 2) {
+                s0 = s0 + ((k >= mazim) ? gl[k] * YS(k, me) : 0.0) * ylm0[k];
+                s1 = s1 + ((k + 1 >= mazim) ? gl[k + 1] * YS(k + 1, me) : 0.0) * ylm0[k + 1];
             }
+            const bool mpar = (mazim & 1) != 0;
+            const double se = mpar ? s1 : s0, so = mpar ? s0 : s1;
             const double c = (2.0 - delm0) * fbeam / (4.0 * P.pi);
             rs = 2.0 * c * se;
             rdv = 2.0 * c * so;
