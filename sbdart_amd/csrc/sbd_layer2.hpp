@@ -190,24 +190,36 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     wave_lds_sync();
 
     // ---- two Cholesky factorisations side by side (lane i <-> row i), lower factors ----
+    // (row me of both matrices lives in registers while it is being eliminated: the lower triangle
+    //  is read once, every column k crosses LDS once for the rows below it, L and C are written at the end)
     bool spd = true;
+    double rp[nn], rm[nn];
+#pragma unroll
+    for (int j = 1; j <= nn; ++j) {
+        rp[j - 1] = (me <= nn && j <= me) ? QP(me, j) : 0.0;
+        rm[j - 1] = (me <= nn && j <= me) ? QM(me, j) : 0.0;
+    }
+    wave_lds_sync();
+#pragma unroll
     for (int k = 1; k <= nn; ++k) {
-        const double dp = QP(k, k), dm = QM(k, k);
-        if (!(dp > 0.0) || !(dm > 0.0)) { spd = false; break; }
+        // pivots of step k: lane k's diagonal, to the whole group
+        const double dp = __shfl(rp[k - 1], k - 1, G), dm = __shfl(rm[k - 1], k - 1, G);
+        if (!(dp > 0.0) || !(dm > 0.0)) spd = false;
         const double rdp = rsqrt_nr(dp), rdm = rsqrt_nr(dm);      // 1/sqrt(pivot): the factors are an ulp or two off
+        if (me == k) { rp[k - 1] = dp * rdp; rm[k - 1] = dm * rdm; }
+        else if (me > k) { rp[k - 1] = rp[k - 1] * rdp; rm[k - 1] = rm[k - 1] * rdm; }
+        // column k of the factors goes through LDS (QP(j,k), QM(j,k), j >= k) for the rows below
+        if (me >= k && me <= nn) { QP(me, k) = rp[k - 1]; QM(me, k) = rm[k - 1]; }
         wave_lds_sync();
-        if (me == k) { QP(k, k) = dp * rdp; QM(k, k) = dm * rdm; }
-        if (me > k && me <= nn) { QP(me, k) = QP(me, k) * rdp; QM(me, k) = QM(me, k) * rdm; }
-        wave_lds_sync();
-        if (me > k && me <= nn) {
-            const double lp = QP(me, k), lm_ = QM(me, k);
-            for (int j = k + 1; j <= me; ++j) {
-                QP(me, j) = QP(me, j) - lp * QP(j, k);
-                QM(me, j) = QM(me, j) - lm_ * QM(j, k);
+#pragma unroll
+        for (int j = k + 1; j <= nn; ++j) {
+            if (me >= j) {
+                rp[j - 1] = rp[j - 1] - rp[k - 1] * QP(j, k);
+                rm[j - 1] = rm[j - 1] - rm[k - 1] * QM(j, k);
             }
         }
-        wave_lds_sync();
     }
+    wave_lds_sync();
     if (!spd || P.force_fallback) {   // group-uniform: hand this layer to the QR kernel
         if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;   // count, then the entries
         return;
