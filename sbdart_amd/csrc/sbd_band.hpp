@@ -393,9 +393,8 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         if (r > nn && r <= N - nn) {         // interface row: matrix-ready blocks, unit stride
             const int qq = r - nn - 1;                   // row jq = qq % n of interface lc = qq / n + 1
             const int d = col - (qq / n) * n;            // 1..2n inside the row's support
-            const int qs = (P.dbg & 8) ? n + qq % n : qq;   // profiling: always the same (cached) block
-            if (d >= 1 && d <= n) return ga_ms[(size_t)qs * n + d - 1];
-            if (d > n && d <= 2 * n) return gb_ms[(size_t)qs * n + d - n - 1];
+            if (d >= 1 && d <= n) return ga_ms[(size_t)qq * n + d - 1];
+            if (d > n && d <= 2 * n) return gb_ms[(size_t)qq * n + d - n - 1];
             return 0.0;
         }
         double g, f;                         // boundary rows
@@ -714,7 +713,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         //     row takes the physical row below the window
         double mreg = 0.0;                                   // lane t: multiplier of row k+t
         if (lane == 0) {
-            if (!(P.dbg & 4)) yv[k - 1] = bk;                  // forward-eliminated RHS, final for row k
+            yv[k - 1] = bk;                  // forward-eliminated RHS, final for row k
             bw[kq + RW] = pq.bv;
         } else if (lane <= lm) {
             const double aik = (lane == idx) ? akk : ak;     // element below the pivot after the swap
@@ -732,7 +731,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         {
             const int wmax = (UW - 1 < N - k) ? UW - 1 : N - k;
             double *urow = ufac + (size_t)(k - 1) * UW;
-            if (lane <= wmax && !(P.dbg & 4)) urow[lane] = (lane == 0) ? piv : tj;
+            if (lane <= wmax) urow[lane] = (lane == 0) ? piv : tj;
             if (two && lane + 64 <= wmax) urow[lane + 64] = tj2;
         }
         wave_lds_sync();

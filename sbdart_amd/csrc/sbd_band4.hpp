@@ -1,0 +1,277 @@
+// Band LU kernel for NSTR <= 16: FOUR boundary-value systems per wave, block form.
+//
+// Same job as sbd_band.hpp (SETMTX + SOLVE0's right-hand side + SGBFA + the forward half of
+// SGBSL, disort.f:2702-2994, 3322-3637, disutil.f:771-912, 1019-1036) and the same outputs (U
+// factor row-major 2*NSTR wide, forward-eliminated right-hand side), but the elimination walks
+// the matrix LAYER BY LAYER instead of column by column through a LINPACK-wide window:
+//
+//   unknowns x_lc (NSTR per layer); rows: NN top-boundary rows, NSTR continuity rows per
+//   interface [A_lc | B_lc+1] (the matrix-ready blocks ga/gb of the layer kernel), NN bottom rows.
+//   Layer step lc holds NN carry rows (what is left of the rows above after x_1..x_lc-1 are
+//   gone; the top-boundary rows for lc = 1) and the NSTR rows of interface lc: RW = 3 NN rows
+//   over the columns of x_lc and x_lc+1.  NSTR elimination sub-steps with partial pivoting retire
+//   NSTR rows to U and leave NN rows that only touch x_lc+1: the next carry.  These are exactly
+//   the rows and columns LINPACK's band LU touches (the rows of interface lc+1 it also scans
+//   are structurally zero in the pivot column), so pivots and factors are the same up to
+//   rounding and the order in which exactly tied candidates are taken.
+//
+// Mapping (gfx950, wave64): a system owns one ROW OF 16 LANES; lane q of the row holds column q
+// of x_lc ("slot 0"), column q of x_lc+1 ("slot 1") and a copy of the right-hand side ("slot 2")
+// for all RW window rows in registers (3 RW doubles).  One sub-step J for four systems at once:
+//   * pivot search inside lane J (the column's RW-J live rows are that lane's own registers);
+//   * the pivot row leaves its registers and the last live row takes its place (an interchange
+//     that keeps the live rows in registers 0..RW-2-J, static for the unrolled code); the row
+//     index differs per system, so this runs once per distinct index (<= 4 passes, each a
+//     computed jump into a table of six-move cases: generated inline asm, sbd_band4_take.inc);
+//   * elimination a_s[p] += a_0[p](lane J) * (t_s * (-1/pivot)): the multiplier column is read
+//     straight from lane J's registers by the DP-ALU DPP form of the FMA (row_newbcast:J) -- no
+//     transposition through LDS, no multiplier registers, no barriers, no LDS at all;
+//   * the retired row goes to U in HBM (16 lanes x 8 B per system and slot), B(k) beside it.
+// Instruction count per system and elimination step is about a quarter of the one-system-per-
+// wave kernels of sbd_band.hpp.
+#pragma once
+#include "sbd_common.hpp"
+#include "sbd_band.hpp"
+
+namespace sbd {
+
+template <int J>
+SBD_DEVICE double fmac_lane_bcast(double acc, double m, double t)   // acc + m(lane J of the row) * t
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(m), "v"(t), "n"(J));
+    return acc;
+}
+template <int J>
+SBD_DEVICE int int_lane_bcast(int x)                                // x of lane J of the row
+{
+    return __builtin_amdgcn_update_dpp(0, x, 0x150 + J, 0xF, 0xF, false);
+}
+template <int J>
+SBD_DEVICE double dbl_lane_bcast(double x)
+{
+    return __hiloint2double(int_lane_bcast<J>(__double2hiint(x)), int_lane_bcast<J>(__double2loint(x)));
+}
+
+#include "sbd_band4_take.inc"   // TakeRows<RW, LAST>: generated inline asm (tools/gen_band4_take.py)
+
+template <int NN>
+__global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
+{
+    constexpr int n = 2 * NN, nn = NN, RW = nn + n, UW = u_width(n);
+    static_assert(n <= 16, "band4_kernel: a layer's columns must fit a row of 16 lanes");
+    const int lane = threadIdx.x, q = lane & 15;
+    const int nmode = P.nmode, L = P.L;
+    const long long ms = (long long)blockIdx.x * 4 + (lane >> 4);
+    if (ms >= (long long)P.nslot * nmode) return;
+    const int mazim = (int)(ms % nmode);
+    const int slot = (int)(ms / nmode);
+    int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
+    const int st0 = svi[SBD_SVI_STATUS];
+    const double fbeam = P.fbeam[slot];
+    const bool dead = (st0 & (0x20 | 0x10 | 0x08)) != 0;
+    if (mazim > 0 && (fbeam == 0.0 || dead)) return;
+    const int nlev = P.nlev;
+    if (dead) {   // DISORT returned before computing anything: outputs stay zero (ZEROAL)
+        double *flux = P.flux + (size_t)slot * SBD_NFLUX_ * nlev;
+        for (int i = q; i < SBD_NFLUX_ * nlev; i += 16) flux[i] = 0.0;
+        return;
+    }
+    const int ncut = svi[SBD_SVI_NCUT];
+    const bool lyrcut = svi[SBD_SVI_LYRCUT] != 0;
+    const SV o(L);
+    const double *sv = P.sv + (size_t)slot * P.sv_stride;
+    const double *taucpr = sv + o.taucpr();
+    const double *expbea = sv + o.expbea();
+    const double albedo = P.albedo[slot];
+    const double delm0 = (mazim == 0) ? 1.0 : 0.0;
+    const double umu0 = P.umu0;
+    const double *cmu = P.t.cmu, *cwt = P.t.cwt;
+    const double *gc = P.gc + (size_t)ms * L * n * n;
+    const double *kk = P.kk + (size_t)ms * L * n;
+    const double *ek = P.ek + (size_t)ms * L * nn;
+    const double *zz = P.zz + (size_t)ms * L * n;
+    const double *zp0 = P.zp0 + (size_t)(ms - mazim) * L * n;     // thermal solutions: mode 0 only
+    const double *zp1 = P.zp1 + (size_t)(ms - mazim) * L * n;
+    double *yv = P.yv + (size_t)ms * L * n;
+    double *ufac = P.ufac + (size_t)ms * (size_t)(L * n) * UW;
+    const double *ga_ms = P.ga + (size_t)ms * L * n * n;
+    const double *gb_ms = P.gb + (size_t)ms * L * n * n;
+    const int N = ncut * n;
+#define GC(i, j, lc) gc[((size_t)((lc) - 1) * n + ((i) - 1)) * n + ((j) - 1)]
+#define KK(i, lc) kk[((lc) - 1) * n + ((i) - 1)]
+#define EK(i, lc) ek[((lc) - 1) * nn + ((i) - 1)]
+#define ZZ(i, lc) zz[((lc) - 1) * n + ((i) - 1)]
+#define ZP0(i, lc) zp0[((lc) - 1) * n + ((i) - 1)]
+#define ZP1(i, lc) zp1[((lc) - 1) * n + ((i) - 1)]
+    const bool refl = !(lyrcut || delm0 == 0.0);   // LAMBER: the surface couples only for m = 0 (disort.f:2925)
+    const bool col = q < n;                        // this lane carries a column
+    const int iq1 = q + 1;                         // its 1-based index inside a layer
+
+    // ---- right-hand side B (SOLVE0, disort.f:3434-3599), unknown index = (lc-1)*n + iq ----
+    {
+        const double bplank = sv[o.bplank()], tplank = sv[o.tplank()];
+        const bool beam = fbeam > 0.0;
+        for (int it = q + 1; it <= N; it += 16) {
+            double v;
+            if (it <= nn) {   // top boundary
+                const int iq = it;
+                if (mazim == 0) {
+                    if (beam) v = -ZZ(nn + 1 - iq, 1) - ZP0(nn + 1 - iq, 1) + P.fisot + tplank;
+                    else v = -ZP0(nn + 1 - iq, 1) + P.fisot + tplank;
+                } else {
+                    v = -ZZ(nn + 1 - iq, 1);
+                }
+            } else if (it > N - nn) {   // bottom boundary
+                const int iq = it - (N - nn);
+                if (mazim > 0) {
+                    v = -ZZ(iq + nn, ncut) * expbea[ncut];   // LYRCUT or Lambertian (disort.f:3441-3452)
+                } else if (lyrcut) {
+                    if (beam) v = -ZZ(iq + nn, ncut) * expbea[ncut] - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
+                    else v = -ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
+                } else {
+                    const double bdr = albedo, bem = 1.0 - albedo;
+                    double sum = 0.0;
+                    if (beam) {
+                        for (int jq = 1; jq <= nn; ++jq)
+                            sum = sum + cwt[jq - 1] * cmu[jq - 1] * bdr *
+                                            (ZZ(nn + 1 - jq, ncut) * expbea[ncut] + ZP0(nn + 1 - jq, ncut)
+                                             + ZP1(nn + 1 - jq, ncut) * taucpr[ncut]);
+                        v = 2.0 * sum + (bdr * umu0 * fbeam / P.pi - ZZ(iq + nn, ncut)) * expbea[ncut]
+                            + bem * bplank - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
+                    } else {
+                        for (int jq = 1; jq <= nn; ++jq)
+                            sum = sum + cwt[jq - 1] * cmu[jq - 1] * bdr *
+                                            (ZP0(nn + 1 - jq, ncut) + ZP1(nn + 1 - jq, ncut) * taucpr[ncut]);
+                        v = 2.0 * sum + bem * bplank - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
+                    }
+                }
+            } else {   // interface lc | lc+1
+                const int qq = it - nn - 1;
+                const int lc = qq / n + 1, iq = qq % n + 1;
+                if (mazim > 0) {
+                    v = (ZZ(iq, lc + 1) - ZZ(iq, lc)) * expbea[lc];
+                } else if (beam) {
+                    v = (ZZ(iq, lc + 1) - ZZ(iq, lc)) * expbea[lc] + ZP0(iq, lc + 1) - ZP0(iq, lc)
+                        + (ZP1(iq, lc + 1) - ZP1(iq, lc)) * taucpr[lc];
+                } else {
+                    v = ZP0(iq, lc + 1) - ZP0(iq, lc) + (ZP1(iq, lc + 1) - ZP1(iq, lc)) * taucpr[lc];
+                }
+            }
+            yv[it - 1] = v;
+        }
+        __threadfence_block();   // the rows below re-read B from HBM as they enter the window
+    }
+
+    // ---- window: RW rows x (x_lc | x_lc+1 | B) ----
+    double a0[RW], a1[RW], a2[RW];
+    // carry of the first step = the top-boundary rows (SETMTX, disort.f:2887-2915):
+    // GC(nn+1-r, j, 1) * exp(KK(j,1)*TAUCPR(1)) for j <= nn (STWJ scaling)
+    {
+        const double f = (col && iq1 <= nn) ? exp(KK(iq1, 1) * taucpr[1]) : 1.0;
+#pragma unroll
+        for (int r = 1; r <= nn; ++r) {
+            a0[r - 1] = col ? GC(nn + 1 - r, iq1, 1) * f : 0.0;
+            a1[r - 1] = 0.0;
+            a2[r - 1] = yv[r - 1];
+        }
+    }
+    int status = 0;
+    for (int lc = 1; lc <= ncut; ++lc) {
+        // ---- the rows that enter with this layer ----
+        if (lc < ncut) {          // interface lc: [ga(lc) | gb(lc+1)] and its right-hand sides
+            const double *pa = ga_ms + (size_t)(lc - 1) * n * n + q;
+            const double *pb = gb_ms + (size_t)lc * n * n + q;
+            const double *py = yv + nn + (lc - 1) * n;
+#pragma unroll
+            for (int r = 0; r < n; ++r) {
+                a0[nn + r] = col ? pa[r * n] : 0.0;
+                a1[nn + r] = col ? pb[r * n] : 0.0;
+                a2[nn + r] = py[r];
+            }
+        } else {                  // bottom boundary (disort.f:2919-2990), Lambertian reflection folded in:
+            // GC(nn+r, j, ncut) - (1 + delta_m0) * sum_k CWT(k) CMU(k) ALBEDO GC(nn+1-k, j, ncut), times
+            // EK(n+1-j) for j > nn; zero rows fill the window (they never win a pivot search)
+            double sb = 0.0;
+            if (refl && col)
+                for (int k = 1; k <= nn; ++k) sb = sb + cwt[k - 1] * cmu[k - 1] * albedo * GC(nn + 1 - k, iq1, ncut);
+            const double f = (col && iq1 > nn) ? EK(n + 1 - iq1, ncut) : 1.0;
+#pragma unroll
+            for (int r = 0; r < n; ++r) {
+                double g = 0.0, b = 0.0;
+                if (r < nn) {
+                    if (col) {
+                        g = GC(nn + 1 + r, iq1, ncut);
+                        if (refl) g = g - (1.0 + delm0) * sb;
+                        g = g * f;
+                    }
+                    b = yv[N - nn + r];
+                }
+                a0[nn + r] = g;
+                a1[nn + r] = 0.0;
+                a2[nn + r] = b;
+            }
+        }
+        double *urow0 = ufac + (size_t)(lc - 1) * n * UW;      // U rows of this layer
+        double *yrow0 = yv + (lc - 1) * n;
+        // ---- NSTR elimination sub-steps ----
+        static_for<n>([&](auto jj) {
+            constexpr int J = decltype(jj)::value;
+            constexpr int LAST = RW - 1 - J;                    // live rows: registers 0..LAST
+            // (1) pivot search in column J = lane J's own registers.  Magnitudes of doubles order like
+            //     their bit patterns: key = leading word without the sign, its last 5 bits replaced by
+            //     31 - p, so that one unsigned maximum (v_and_or_b32 + v_max3_u32) returns the largest
+            //     |a| and, among candidates that agree in the leading 27 bits, the first row.  Partial
+            //     pivoting with threshold 1 - 2^-15 (LINPACK's ISAMAX takes the exact maximum; a
+            //     pivot within 3e-5 of it bounds the multipliers by 1.00003 instead of 1)
+            unsigned kmax = 0u;
+#pragma unroll
+            for (int p = 0; p <= LAST; ++p) {
+                const unsigned key = ((unsigned)__double2hiint(a0[p]) & 0x7fffffe0u) | (unsigned)(31 - p);
+                kmax = (key > kmax) ? key : kmax;
+            }
+            const int idx = 31 - (int)(kmax & 31u);
+            const int idxb = int_lane_bcast<J>(idx);            // ... to the 16 lanes of the system
+            // (2) pivot row out of its registers, the last live row into them: one pass per
+            //     distinct row index among the systems of the wave
+            double t0, t1, t2;
+            TakeRows<RW, LAST>::run(a0, a1, a2, idxb, t0, t1, t2);
+            // (3) -1/pivot (v_rcp + two Newton steps) in lane J, a zero pivot is flagged and skipped
+            double rn = __builtin_amdgcn_rcp(t0);
+            rn = rn * (2.0 - t0 * rn);
+            rn = rn * (2.0 - t0 * rn);
+            rn = (t0 != 0.0) ? -rn : 0.0;
+            if (q == J && t0 == 0.0) status |= 0x01;
+            // (4) the retired row: U(k, k..) row-major, forward-eliminated B(k)
+            {
+                double *urow = urow0 + J * UW;
+                if (q >= J && col) urow[q - J] = t0;
+                if (col) urow[n - J + q] = t1;
+                if (q == J) yrow0[J] = t2;
+            }
+            // (5) elimination: a_s[p] += a_0[p](lane J) * (t_s * -1/pivot); columns <= J of
+            //     slot 0 are finished (their registers keep the unscaled multipliers)
+            const double rnb = dbl_lane_bcast<J>(rn);
+            const double tp1 = rnb * t1, tp2 = rnb * t2;
+            const double tp0 = (q > J) ? rnb * t0 : 0.0;
+#pragma unroll
+            for (int p = 0; p < LAST; ++p) {
+                a1[p] = fmac_lane_bcast<J>(a1[p], a0[p], tp1);
+                a2[p] = fmac_lane_bcast<J>(a2[p], a0[p], tp2);
+                a0[p] = fmac_lane_bcast<J>(a0[p], a0[p], tp0);
+            }
+        });
+        // ---- the nn rows left over only touch x_lc+1: next step's carry ----
+#pragma unroll
+        for (int p = 0; p < nn; ++p) { a0[p] = a1[p]; a1[p] = 0.0; }
+    }
+    if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
+#undef GC
+#undef KK
+#undef EK
+#undef ZZ
+#undef ZP0
+#undef ZP1
+}
+
+}  // namespace sbd

@@ -26,6 +26,7 @@
 
 namespace sbd {
 
+constexpr int SBD_NFLUX_ = 5;  // flux components per level (SBD_NFLUX of the C ABI)
 constexpr int kMaxNlyr = 65;   // params.f: mxly
 constexpr int kMaxNstr = 40;   // params.f: nstrms
 
@@ -49,7 +50,6 @@ struct Params {
     int32_t onlyfl, usrang, all_levels;
     int32_t force_fallback;  // test hook: route every layer through the QR kernel
     int32_t *eiglist;        // [1 + nslot*nmode*L] count + (item, mode, layer) indices left to the QR kernel
-    int32_t dbg;             // profiling hook (SBD_DBG_FLAGS): bit0 one Jacobi sweep, bit1 skip LU
     int32_t nslot;          // work items in this chunk
     int32_t sv_stride, svi_stride;
     int32_t cw, ncd;        // band: CW = 2*ncd+1 columns kept per U row, ncd = 3nn-1

@@ -22,13 +22,11 @@
 #include <vector>
 
 #include "sbd_common.hpp"
-namespace sbd { constexpr int SBD_NFLUX_ = SBD_NFLUX; }
-#include "sbd_setup.hpp"
-#include "sbd_layer.hpp"
-#include "sbd_layer2.hpp"
-#include "sbd_band.hpp"
-#include "sbd_solve.hpp"
-#include "sbd_usrint.hpp"
+#include "sbd_launch.hpp"
+#include "sbd_band.hpp"     // BandLds / SolveLds / u_width (host-side sizes)
+#include "sbd_layer.hpp"    // LayerLds
+#include "sbd_layer2.hpp"   // Layer2Lds
+static_assert(sbd::SBD_NFLUX_ == SBD_NFLUX, "flux component count");
 
 namespace {
 
@@ -146,19 +144,6 @@ __global__ void accum_final_kernel(int nseg, int nel, const double *partial, dou
 }  // namespace
 
 
-// (NN, G, RAD) dispatch of the fast layer kernel
-#define SBD_L2_CASES(M)                                                                        \
-    M(2, 4) M(3, 4) M(4, 4) M(5, 8) M(6, 8) M(7, 8) M(8, 8) M(9, 16) M(10, 16) M(11, 16)   \
-    M(12, 16) M(13, 16) M(14, 16) M(15, 16) M(16, 16) M(17, 32) M(18, 32) M(19, 32) M(20, 32)
-
-static int l2_group(int nn)   // lanes per layer of the fast layer kernel (the table above)
-{
-#define SBD_L2_G(NNv, Gv) if (nn == NNv) return Gv;
-    SBD_L2_CASES(SBD_L2_G)
-#undef SBD_L2_G
-    return 64;
-}
-
 struct sbd_engine {
     sbd_run_cfg cfg{};
     int n = 0, nn = 0, L = 0, nmode = 1, naz_run = 0, nlev = 0, G = 0, G2 = 0;
@@ -188,6 +173,7 @@ struct sbd_engine {
     int32_t *d_eigflag = nullptr;
     bool use_layer2 = true;
     bool band_reg = false;
+    bool band4 = false;             // four systems per wave, block form (sbd_band4.hpp), NSTR <= 16
 };
 
 extern "C" {
@@ -424,8 +410,6 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         P.dither = 100.0 * 2.220446049250313e-16;   // disort.f:442-448
         P.t = e->tab;
         P.force_fallback = 0;
-        P.dbg = 0;
-        if (const char *s2 = getenv("SBD_DBG_FLAGS")) P.dbg = atoi(s2);
         if (const char *s = getenv("SBD_FORCE_EIG_FALLBACK")) P.force_fallback = atoi(s) != 0;
     }
     // the carve above rounds every array up to 256 B: re-check against the allocation
@@ -438,51 +422,29 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->layer_lds = (int)sizeof(double) * ll.total * (64 / G);
     e->band_reg = nn <= 10;                       // register-resident LU window (sbd_band.hpp)
     if (const char *s = getenv("SBD_BAND_LDS")) e->band_reg = e->band_reg && atoi(s) == 0;
+    e->band4 = nn <= 8;
+    if (const char *s = getenv("SBD_BAND_V1")) e->band4 = e->band4 && atoi(s) == 0;
     const sbd::BandLds bl(n, nn, e->band_reg);
     e->band_lds = (int)sizeof(double) * bl.total;
     const sbd::SolveLds sl(n, nn, L);
     e->solve_lds = (int)sizeof(double) * sl.total;
     e->usr_lds = (int)sizeof(double) * (nn + 2);
-    auto set_lds = [&](const void *fn, int bytes) -> hipError_t {
-        if (bytes <= 48 * 1024) return hipSuccess;
-        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    };
     if (e->layer_lds > 160 * 1024 || e->band_lds > 160 * 1024 || e->solve_lds > 160 * 1024) {
         sbd_engine_destroy(e);
         return fail(SBD_E_UNSUPPORTED, "LDS footprint exceeds 160 KiB for this NSTR/NLYR");
     }
-    switch (G) {
-    case 4: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<4>, e->layer_lds)); break;
-    case 8: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<8>, e->layer_lds)); break;
-    case 16: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<16>, e->layer_lds)); break;
-    case 32: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<32>, e->layer_lds)); break;
-    default: CREATE_TRY(set_lds((const void *)sbd::layer_kernel<64>, e->layer_lds)); break;
-    }
-#define SBD_BAND_CASE(NNv) case NNv: CREATE_TRY(set_lds((const void *)sbd::band_kernel<NNv, false>, e->band_lds)); \
-                                 CREATE_TRY(set_lds((const void *)sbd::backsolve_kernel<NNv>, e->solve_lds)); break;
-    switch (nn) {
-        SBD_BAND_CASE(2) SBD_BAND_CASE(3) SBD_BAND_CASE(4) SBD_BAND_CASE(5) SBD_BAND_CASE(6) SBD_BAND_CASE(7)
-        SBD_BAND_CASE(8) SBD_BAND_CASE(9) SBD_BAND_CASE(10) SBD_BAND_CASE(11) SBD_BAND_CASE(12) SBD_BAND_CASE(13)
-        SBD_BAND_CASE(14) SBD_BAND_CASE(15) SBD_BAND_CASE(16) SBD_BAND_CASE(17) SBD_BAND_CASE(18) SBD_BAND_CASE(19)
-        SBD_BAND_CASE(20)
-    default: break;
-    }
-#undef SBD_BAND_CASE
+    CREATE_TRY(sbd::prepare_layer_v1(G, e->layer_lds));
+    CREATE_TRY(sbd::prepare_band_lds(nn, e->band_lds));
+    CREATE_TRY(sbd::prepare_backsolve(nn, e->solve_lds));
     {
         const sbd::Layer2Lds l2(n, nn, rad);
-        e->G2 = l2_group(nn);
+        e->G2 = sbd::l2_group(nn);
         e->layer2_lds = (int)sizeof(double) * (l2.shared_total + l2.group_total * (64 / e->G2));
         if (const char *s = getenv("SBD_LAYER_V1")) e->use_layer2 = atoi(s) == 0;
         if (e->layer2_lds > 160 * 1024) e->use_layer2 = false;
         // the list is emptied by setup_kernel, filled by layer_kernel2 and walked by the QR kernel
         CREATE_TRY(hipMemset(e->d_eigflag, 0, flag_bytes));
-#define SBD_L2_ATTR(NNv, Gv)                                                                                    \
-        if (nn == NNv) {                                                                                        \
-            if (rad) CREATE_TRY(set_lds((const void *)sbd::layer_kernel2<NNv, Gv, true>, e->layer2_lds));        \
-            else CREATE_TRY(set_lds((const void *)sbd::layer_kernel2<NNv, Gv, false>, e->layer2_lds));          \
-        }
-        SBD_L2_CASES(SBD_L2_ATTR)
-#undef SBD_L2_ATTR
+        if (e->use_layer2) CREATE_TRY(sbd::prepare_layer2(nn, rad, e->layer2_lds));
     }
     for (auto &x : e->ev) CREATE_TRY(hipEventCreate(&x));
 #undef CREATE_TRY
@@ -582,7 +544,7 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
         P.status = out->status + w0;
 
         if (timing) HIP_TRY(hipEventRecord(e->ev[0], st));
-        hipLaunchKernelGGL(sbd::setup_kernel, dim3(ns), dim3(64), 0, st, P);
+        sbd::launch_setup((unsigned)ns, st, P);
         SBD_DBG("setup");
         if (timing) HIP_TRY(hipEventRecord(e->ev[1], st));
         {
@@ -594,68 +556,30 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
                 const int gpb2 = 64 / e->G2;
                 const unsigned g2 = (unsigned)(((size_t)ns * L + gpb2 - 1) / gpb2) * (unsigned)nmode;
                 int32_t *flag = e->d_eigflag;
-#define SBD_L2_LAUNCH(NNv, Gv)                                                                                        \
-                if (e->nn == NNv) {                                                                                   \
-                    if (rad) hipLaunchKernelGGL((sbd::layer_kernel2<NNv, Gv, true>), dim3(g2), dim3(64), e->layer2_lds, st, P, flag);   \
-                    else hipLaunchKernelGGL((sbd::layer_kernel2<NNv, Gv, false>), dim3(g2), dim3(64), e->layer2_lds, st, P, flag);      \
-                }
-                SBD_L2_CASES(SBD_L2_LAUNCH)
-#undef SBD_L2_LAUNCH
+                sbd::launch_layer2(e->nn, rad, g2, e->layer2_lds, st, P, flag);
                 flt = e->d_eigflag;     // the QR kernel below only redoes the listed layers: a small
                 if (grid > 2048u) grid = 2048u;   // fixed grid walks the list (normally empty)
                 SBD_DBG("layer2");
             }
-            switch (e->G) {
-            case 4: hipLaunchKernelGGL(sbd::layer_kernel<4>, dim3(grid), dim3(64), e->layer_lds, st, P, flt); break;
-            case 8: hipLaunchKernelGGL(sbd::layer_kernel<8>, dim3(grid), dim3(64), e->layer_lds, st, P, flt); break;
-            case 16: hipLaunchKernelGGL(sbd::layer_kernel<16>, dim3(grid), dim3(64), e->layer_lds, st, P, flt); break;
-            case 32: hipLaunchKernelGGL(sbd::layer_kernel<32>, dim3(grid), dim3(64), e->layer_lds, st, P, flt); break;
-            default: hipLaunchKernelGGL(sbd::layer_kernel<64>, dim3(grid), dim3(64), e->layer_lds, st, P, flt); break;
-            }
+            sbd::launch_layer_v1(e->G, grid, e->layer_lds, st, P, flt);
         }
         SBD_DBG("layer(v1/fallback)");
         if (timing) HIP_TRY(hipEventRecord(e->ev[2], st));
         {
-            const dim3 bgrid((unsigned)((size_t)ns * nmode));
-#define SBD_BAND_CASE(NNv) case NNv: hipLaunchKernelGGL((sbd::band_kernel<NNv, false>), bgrid, dim3(64), e->band_lds, st, P); break;
-#define SBD_BANDR_CASE(NNv) case NNv: hipLaunchKernelGGL((sbd::band_kernel<NNv, true>), bgrid, dim3(64), e->band_lds, st, P); break;
-            if (e->band_reg) {
-                switch (e->nn) {
-                    SBD_BANDR_CASE(2) SBD_BANDR_CASE(3) SBD_BANDR_CASE(4) SBD_BANDR_CASE(5) SBD_BANDR_CASE(6)
-                    SBD_BANDR_CASE(7) SBD_BANDR_CASE(8) SBD_BANDR_CASE(9) SBD_BANDR_CASE(10)
-                default: break;
-                }
-            } else
-            switch (e->nn) {
-                SBD_BAND_CASE(2) SBD_BAND_CASE(3) SBD_BAND_CASE(4) SBD_BAND_CASE(5) SBD_BAND_CASE(6) SBD_BAND_CASE(7)
-                SBD_BAND_CASE(8) SBD_BAND_CASE(9) SBD_BAND_CASE(10) SBD_BAND_CASE(11) SBD_BAND_CASE(12) SBD_BAND_CASE(13)
-                SBD_BAND_CASE(14) SBD_BAND_CASE(15) SBD_BAND_CASE(16) SBD_BAND_CASE(17) SBD_BAND_CASE(18) SBD_BAND_CASE(19)
-                SBD_BAND_CASE(20)
-            default: break;
-            }
-#undef SBD_BAND_CASE
-#undef SBD_BANDR_CASE
+            const unsigned bgrid = (unsigned)((size_t)ns * nmode);
+            if (e->band4) sbd::launch_band4(e->nn, (bgrid + 3) / 4, st, P);
+            else if (e->band_reg) sbd::launch_band_reg(e->nn, bgrid, e->band_lds, st, P);
+            else sbd::launch_band_lds(e->nn, bgrid, e->band_lds, st, P);
         }
         SBD_DBG("band");
         if (timing) HIP_TRY(hipEventRecord(e->ev[3], st));
-        {
-            const dim3 bgrid((unsigned)((size_t)ns * nmode));
-#define SBD_BAND_CASE(NNv) case NNv: hipLaunchKernelGGL(sbd::backsolve_kernel<NNv>, bgrid, dim3(64), e->solve_lds, st, P); break;
-            switch (e->nn) {
-                SBD_BAND_CASE(2) SBD_BAND_CASE(3) SBD_BAND_CASE(4) SBD_BAND_CASE(5) SBD_BAND_CASE(6) SBD_BAND_CASE(7)
-                SBD_BAND_CASE(8) SBD_BAND_CASE(9) SBD_BAND_CASE(10) SBD_BAND_CASE(11) SBD_BAND_CASE(12) SBD_BAND_CASE(13)
-                SBD_BAND_CASE(14) SBD_BAND_CASE(15) SBD_BAND_CASE(16) SBD_BAND_CASE(17) SBD_BAND_CASE(18) SBD_BAND_CASE(19)
-                SBD_BAND_CASE(20)
-            default: break;
-            }
-#undef SBD_BAND_CASE
-        }
+        sbd::launch_backsolve(e->nn, (unsigned)((size_t)ns * nmode), e->solve_lds, st, P);
         SBD_DBG("backsolve");
         if (timing) HIP_TRY(hipEventRecord(e->ev[4], st));
         if (rad) {
-            hipLaunchKernelGGL(sbd::usrint_kernel, dim3((unsigned)((size_t)ns * nmode)), dim3(64), e->usr_lds, st, P);
+            sbd::launch_usrint((unsigned)((size_t)ns * nmode), e->usr_lds, st, P);
             const long long items = (long long)ns * nlev * e->P.numu;
-            hipLaunchKernelGGL(sbd::azimuth_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, P, e->naz_run);
+            sbd::launch_azimuth((unsigned)((items + 255) / 256), st, P, e->naz_run);
         }
         hipLaunchKernelGGL(finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, P);
         if (timing) HIP_TRY(hipEventRecord(e->ev[5], st));

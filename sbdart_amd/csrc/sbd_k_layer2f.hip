@@ -1,0 +1,28 @@
+// fast layer kernel (symmetrised eigenproblem, one-sided Jacobi), radiance mode = false
+#include "sbd_launch.hpp"
+#include "sbd_layer2.hpp"
+namespace sbd {
+hipError_t prepare_layer2_f(int nn, int lds)
+{
+#define SBD_C(NNv, Gv) if (nn == NNv) return raise_lds((const void *)layer_kernel2<NNv, Gv, false>, lds);
+    SBD_L2_CASES(SBD_C)
+#undef SBD_C
+    return hipSuccess;
+}
+void launch_layer2_f(int nn, unsigned grid, int lds, hipStream_t st, const Params &P, int32_t *eigflag)
+{
+#define SBD_C(NNv, Gv) if (nn == NNv) hipLaunchKernelGGL((layer_kernel2<NNv, Gv, false>), dim3(grid), dim3(64), lds, st, P, eigflag);
+    SBD_L2_CASES(SBD_C)
+#undef SBD_C
+}
+}
+namespace sbd {
+hipError_t prepare_layer2_r(int nn, int lds);
+void launch_layer2_r(int nn, unsigned grid, int lds, hipStream_t st, const Params &P, int32_t *eigflag);
+hipError_t prepare_layer2(int nn, bool rad, int lds) { return rad ? prepare_layer2_r(nn, lds) : prepare_layer2_f(nn, lds); }
+void launch_layer2(int nn, bool rad, unsigned grid, int lds, hipStream_t st, const Params &P, int32_t *eigflag)
+{
+    if (rad) launch_layer2_r(nn, grid, lds, st, P, eigflag);
+    else launch_layer2_f(nn, grid, lds, st, P, eigflag);
+}
+}

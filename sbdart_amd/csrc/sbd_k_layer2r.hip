@@ -1,0 +1,18 @@
+// fast layer kernel (symmetrised eigenproblem, one-sided Jacobi), radiance mode = true
+#include "sbd_launch.hpp"
+#include "sbd_layer2.hpp"
+namespace sbd {
+hipError_t prepare_layer2_r(int nn, int lds)
+{
+#define SBD_C(NNv, Gv) if (nn == NNv) return raise_lds((const void *)layer_kernel2<NNv, Gv, true>, lds);
+    SBD_L2_CASES(SBD_C)
+#undef SBD_C
+    return hipSuccess;
+}
+void launch_layer2_r(int nn, unsigned grid, int lds, hipStream_t st, const Params &P, int32_t *eigflag)
+{
+#define SBD_C(NNv, Gv) if (nn == NNv) hipLaunchKernelGGL((layer_kernel2<NNv, Gv, true>), dim3(grid), dim3(64), lds, st, P, eigflag);
+    SBD_L2_CASES(SBD_C)
+#undef SBD_C
+}
+}

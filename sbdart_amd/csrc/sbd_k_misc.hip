@@ -1,0 +1,9 @@
+// setup, user-angle intensities, azimuth sum
+#include "sbd_launch.hpp"
+#include "sbd_setup.hpp"
+#include "sbd_usrint.hpp"
+namespace sbd {
+void launch_setup(unsigned grid, hipStream_t st, const Params &P) { hipLaunchKernelGGL(setup_kernel, dim3(grid), dim3(64), 0, st, P); }
+void launch_usrint(unsigned grid, int lds, hipStream_t st, const Params &P) { hipLaunchKernelGGL(usrint_kernel, dim3(grid), dim3(64), lds, st, P); }
+void launch_azimuth(unsigned grid, hipStream_t st, const Params &P, int naz_run) { hipLaunchKernelGGL(azimuth_kernel, dim3(grid), dim3(256), 0, st, P, naz_run); }
+}

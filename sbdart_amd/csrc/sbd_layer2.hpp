@@ -220,7 +220,14 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         }
     }
     wave_lds_sync();
-    if (!spd || P.force_fallback) {   // group-uniform: hand this layer to the QR kernel
+    // group-uniform: hand this layer to the QR kernel when the symmetrised problem is not positive
+    // definite, and when a thermal source meets conservative scattering (SSALB = 1, dithered to
+    // 1 - 2.2e-14): there I - CC is singular to working precision, the particular solution is an O(1)
+    // quantity cancelling against the homogeneous one, and only the reference's own sequence of
+    // operations (SGECO/SGESL on the full NSTR x NSTR system) reproduces its rounding (5e-5 vs 3e-4 of
+    // the column maximum for the Cholesky-reuse solve below).  Such layers are rare.
+    const bool hard_thermal = plank && mazim == 0 && P.ssalb[(size_t)slot * L + (lc - 1)] == 1.0;
+    if (!spd || P.force_fallback || hard_thermal) {
         if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;   // count, then the entries
         return;
     }
@@ -253,9 +260,14 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         const int j = g;                                 // player index 0..NP-1 (lanes >= NP idle)
         const double tol = 2.220446049250313e-16;
         bool rotated = false, coarse = false;
+        // Convergence is decided per GROUP (the G lanes of one layer), not per wave: a group that is
+        // done stops rotating whatever its wave-mates still do, so an item's result does not depend on
+        // which other items share its wave (batch composition, pass size, L % GPB)
+        bool done = false;
+        const unsigned long long gmask = ((G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull)) << ((gi * G) & 63);
         // one meeting of this lane's column with its partner's (both lanes run it, each keeps its own)
         auto meet = [&](const int partner, const bool valid, const double (&ob)[nn], const double (&ox)[nn]) {
-            if (valid) {
+            if (valid && !done) {
                 double aa = 0.0, bb = 0.0, gg = 0.0;
 #pragma unroll
                 for (int i = 0; i < nn; ++i) {
@@ -324,7 +336,12 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
             }
             // quadratic convergence: a sweep that started below 3e-7 ends below 1e-13 (eigenvalues to
             // ~1e-26 relative, eigenvectors to ~1e-13: far inside the parity gate)
-            if (!__any(rotated) || !__any(coarse) || (P.dbg & 1)) break;
+            if ((__ballot(rotated) & gmask) == 0ull || (__ballot(coarse) & gmask) == 0ull) done = true;
+            if (!__any(!done)) break;
+        }
+        if (!done) {   // 30 sweeps without convergence: the reference-algorithm kernel redoes this layer
+            if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;
+            return;
         }
     }
 
@@ -528,10 +545,8 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         // q = (r+ + r-) - mu0 (I - S+ W) M^-1 (r+ - r-);  T d = q;  s = mu0 M^-1 ((r+ - r-) - (I - S- W) d)
         const double cmu_me = (me <= nn) ? scmu[me - 1] : 1.0;
         double dv = rs - umu0 * apply_ImSW(sp, rdv / cmu_me);
-        if (!(P.dbg & 2)) {
-            if (lu_factor_group(lu, ldq, nn, ipvt, g) != 0) status |= 0x02;
-            dv = lu_solve_group<G>(lu, ldq, nn, ipvt, dv, g);
-        }
+        if (lu_factor_group(lu, ldq, nn, ipvt, g) != 0) status |= 0x02;
+        dv = lu_solve_group<G>(lu, ldq, nn, ipvt, dv, g);
         const double sv_ = umu0 * (rdv - apply_ImSW(sm, dv)) / cmu_me;
         const double zpl = 0.5 * (sv_ + dv), zmi = 0.5 * (sv_ - dv);     // Z(+mu_me), Z(-mu_me)
         if (me <= nn) {

@@ -26,7 +26,6 @@ __global__ void __launch_bounds__(64) backsolve_kernel(Params P)
     // same early exits as the LU kernel (which zeroed the fluxes of a dead item)
     if ((st0 & (0x20 | 0x10 | 0x08)) != 0) return;
     if (mazim > 0 && fbeam == 0.0) return;
-    if (P.dbg & 32) return;
     const int nlev = P.nlev;
     double *flux = P.flux + (size_t)slot * SBD_NFLUX_ * nlev;
     const int ncut = svi[SBD_SVI_NCUT];
@@ -91,7 +90,9 @@ __global__ void __launch_bounds__(64) backsolve_kernel(Params P)
                 const int r = it * RPL + rr;
                 const int i = i0 + r;
                 v[it] = 0.0;
-                if (r < NR && i >= 1 && i <= k1 && j <= k1 && j >= i && j - i <= UB)
+                // (row i is the ((i-1) % n)-th row of its layer: its support ends with the next layer's
+                //  columns, UB - (i-1) % n places right of the diagonal; sbd_band4.hpp stores no more)
+                if (r < NR && i >= 1 && i <= k1 && j <= k1 && j >= i && j - i <= UB - (i - 1) % n)
                     v[it] = ufac[(size_t)(i - 1) * UW + (j - i)];
             }
         };

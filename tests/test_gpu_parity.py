@@ -250,16 +250,34 @@ def test_fuzz_all_stream_counts_and_layer_counts(seed):
     flux, uu, st = solve_records([r for r, _ in recs])
     # a thermal source in a conservative-scattering layer (ssalb dithered to 1-2.2e-14) makes the
     # reference's own particular solution ill-conditioned (I - CC is singular to working precision
-    # and the O(1) particular solution cancels against the homogeneous one): the reference-algorithm
-    # layer kernel (SBD_LAYER_V1=1) differs from the oracle by up to 5e-5 of the column maximum there,
-    # the fast one by up to 3e-4 (seed 323: NSTR=26, one conservative layer)
+    # and the O(1) particular solution cancels against the homogeneous one).  The engine sends such
+    # layers through the reference-algorithm layer kernel, which stays within 5e-5 of the column
+    # maximum of the oracle on them (every other record: 5e-6)
     hard = [bool(r.plank) and bool((r.ssalb == 1.0).any()) for r, _ in recs]
     easy = [i for i, h in enumerate(hard) if not h]
     _check([flux[i] for i in easy], [uu[i] for i in easy], [st[i] for i in easy],
            [recs[i][0] for i in easy], [recs[i][1] for i in easy])
     tough = [i for i, h in enumerate(hard) if h]
     _check([flux[i] for i in tough], [uu[i] for i in tough], [st[i] for i in tough],
-           [recs[i][0] for i in tough], [recs[i][1] for i in tough], tol=1e-3)
+           [recs[i][0] for i in tough], [recs[i][1] for i in tough], tol=5e-5)
+
+
+def test_result_independent_of_batch_neighbours():
+    """An item's fluxes are bitwise the same whether it is solved alone, next to other items, or
+    in passes of a different size (the Jacobi convergence vote is per layer group, the band LU
+    shares a wave between four systems without coupling them)."""
+    from sbdart_amd.engine import solve_records
+    from sbdart_amd.records import read_records
+    recs = read_records(os.path.join(GOLDEN, "cfgB_sw_nstr16.sbdrec"))[:9]
+    recs += read_records(os.path.join(GOLDEN, "cfg3_lw_nstr16_cloud.sbdrec"))[:9]
+    f_all, _, _ = solve_records(recs)
+    for i in (0, 4, 9, 13, 17):
+        f_one, _, _ = solve_records([recs[i]])
+        assert np.array_equal(f_one[0], f_all[i]), i
+    order = [17, 3, 9, 0, 12, 5, 14, 1, 8]
+    f_perm, _, _ = solve_records([recs[i] for i in order])
+    for k, i in enumerate(order):
+        assert np.array_equal(f_perm[k], f_all[i]), i
 
 
 _ALT_CODE = ("import numpy as np,sys,os,json;sys.path.insert(0,'.');"
