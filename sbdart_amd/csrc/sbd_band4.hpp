@@ -160,8 +160,30 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             }
             yv[it - 1] = v;
         }
-        __threadfence_block();   // the rows below re-read B from HBM as they enter the window
     }
+    // ---- bottom-boundary rows (disort.f:2919-2990), Lambertian reflection folded in:
+    //      GC(nn+r, j, ncut) - (1 + delta_m0) * sum_k CWT(k) CMU(k) ALBEDO GC(nn+1-k, j, ncut), times EK(n+1-j)
+    //      for j > nn.  They go where a (non-existent) interface ncut would have its x_ncut block --
+    //      ga's block of layer ncut, which nothing else reads -- padded to NSTR rows with zeros (zero
+    //      rows never win a pivot search), so that the last elimination step is a step like the others ----
+    if (col) {
+        double sb = 0.0;
+        if (refl)
+            for (int k = 1; k <= nn; ++k) sb = sb + cwt[k - 1] * cmu[k - 1] * albedo * GC(nn + 1 - k, iq1, ncut);
+        const double f = (iq1 > nn) ? EK(n + 1 - iq1, ncut) : 1.0;
+        double *bc = P.ga + (size_t)ms * L * n * n + (size_t)(ncut - 1) * n * n + q;
+#pragma unroll
+        for (int r = 0; r < n; ++r) {
+            double g = 0.0;
+            if (r < nn) {
+                g = GC(nn + 1 + r, iq1, ncut);
+                if (refl) g = g - (1.0 + delm0) * sb;
+                g = g * f;
+            }
+            bc[r * n] = g;
+        }
+    }
+    __threadfence_block();   // B and the boundary block are re-read by this wave as rows enter the window
 
     // ---- window: RW rows x (x_lc | x_lc+1 | B) ----
     double a0[RW], a1[RW], a2[RW];
@@ -177,41 +199,46 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         }
     }
     int status = 0;
-    for (int lc = 1; lc <= ncut; ++lc) {
-        // ---- the rows that enter with this layer ----
-        if (lc < ncut) {          // interface lc: [ga(lc) | gb(lc+1)] and its right-hand sides
-            const double *pa = ga_ms + (size_t)(lc - 1) * n * n + q;
-            const double *pb = gb_ms + (size_t)lc * n * n + q;
-            const double *py = yv + nn + (lc - 1) * n;
+    // The NSTR rows that enter with step lc are interface lc's [ga(lc) | gb(lc+1)] with right-hand
+    // sides B(nn + (lc-1) n + r), or for lc = ncut the boundary block above beside zeros with B(N-nn+r),
+    // r < nn.  They are fetched while step lc-1 is being eliminated: straight into the registers
+    // of rows that have been retired (sub-step J frees register RW-1-J), the last E of them --
+    // whose registers come free too late to cover the HBM latency -- through E buffer rows, the
+    // right-hand sides as one value per lane (lane r <-> row r) spread by DPP at the hand-over.
+    constexpr int E = (n < 4) ? n : 4;
+    double bufa[E], bufb[E], rhsn = 0.0;
+    auto step_rows = [&](int lci, const double *&pa, const double *&pb, const double *&py, bool &ry) {
+        const bool inner = lci < ncut, last = lci == ncut;     // (beyond ncut: valid memory, never used)
+        const int cq = col ? q : 0;
+        pa = (inner || last) ? ga_ms + (size_t)(lci - 1) * n * n + cq : yv;
+        pb = inner ? gb_ms + (size_t)lci * n * n + cq : (last ? P.t.zeros + cq : yv);
+        py = inner ? yv + nn + (lci - 1) * n : (last ? yv + (N - nn) : yv);
+        ry = inner || (last && q < nn);                         // lane r has a right-hand side for row r
+    };
+    {   // rows of step 1 (exposed once per system)
+        const double *pa, *pb, *py;
+        bool ry;
+        step_rows(1, pa, pb, py, ry);
+        const double yq0 = py[col ? q : 0];
+        const double yq = ry ? yq0 : 0.0;
 #pragma unroll
-            for (int r = 0; r < n; ++r) {
-                a0[nn + r] = col ? pa[r * n] : 0.0;
-                a1[nn + r] = col ? pb[r * n] : 0.0;
-                a2[nn + r] = py[r];
-            }
-        } else {                  // bottom boundary (disort.f:2919-2990), Lambertian reflection folded in:
-            // GC(nn+r, j, ncut) - (1 + delta_m0) * sum_k CWT(k) CMU(k) ALBEDO GC(nn+1-k, j, ncut), times
-            // EK(n+1-j) for j > nn; zero rows fill the window (they never win a pivot search)
-            double sb = 0.0;
-            if (refl && col)
-                for (int k = 1; k <= nn; ++k) sb = sb + cwt[k - 1] * cmu[k - 1] * albedo * GC(nn + 1 - k, iq1, ncut);
-            const double f = (col && iq1 > nn) ? EK(n + 1 - iq1, ncut) : 1.0;
-#pragma unroll
-            for (int r = 0; r < n; ++r) {
-                double g = 0.0, b = 0.0;
-                if (r < nn) {
-                    if (col) {
-                        g = GC(nn + 1 + r, iq1, ncut);
-                        if (refl) g = g - (1.0 + delm0) * sb;
-                        g = g * f;
-                    }
-                    b = yv[N - nn + r];
-                }
-                a0[nn + r] = g;
-                a1[nn + r] = 0.0;
-                a2[nn + r] = b;
-            }
+        for (int r = 0; r < n; ++r) {
+            const double va = pa[r * n], vb = pb[r * n];
+            a0[nn + r] = col ? va : 0.0;
+            a1[nn + r] = col ? vb : 0.0;
         }
+        static_for<n>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            a2[nn + r] = dbl_lane_bcast<r>(yq);
+        });
+    }
+    // every load so far has landed before the loop: the waits inside then only count the loop's own
+    // memory operations (vmcnt(0), expcnt/lgkmcnt unconstrained)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int lc = 1; lc <= ncut; ++lc) {
+        const double *pna, *pnb, *pny;                          // next step's rows
+        bool rny;
+        step_rows(lc + 1, pna, pnb, pny, rny);
         double *urow0 = ufac + (size_t)(lc - 1) * n * UW;      // U rows of this layer
         double *yrow0 = yv + (lc - 1) * n;
         // ---- NSTR elimination sub-steps ----
@@ -236,6 +263,21 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             //     distinct row index among the systems of the wave
             double t0, t1, t2;
             TakeRows<RW, LAST>::run(a0, a1, a2, idxb, t0, t1, t2);
+            // register LAST is free from here on: next interface's row LAST - nn moves in
+            if constexpr (LAST - nn >= E) {
+                const double va = pna[(LAST - nn) * n], vb = pnb[(LAST - nn) * n];
+                a0[LAST] = (n == 16 || col) ? va : 0.0;
+                a1[LAST] = (n == 16 || col) ? vb : 0.0;
+            }
+            if constexpr (J < E) {
+                const double va = pna[J * n], vb = pnb[J * n];
+                bufa[J] = (n == 16 || col) ? va : 0.0;
+                bufb[J] = (n == 16 || col) ? vb : 0.0;
+            }
+            if constexpr (J == 0) {                             // (a load whatever rny is: no branch, exact wait counts)
+                const double v = pny[col ? q : 0];
+                rhsn = rny ? v : 0.0;
+            }
             // (3) -1/pivot (v_rcp + two Newton steps) in lane J, a zero pivot is flagged and skipped
             double rn = __builtin_amdgcn_rcp(t0);
             rn = rn * (2.0 - t0 * rn);
@@ -245,9 +287,17 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             // (4) the retired row: U(k, k..) row-major, forward-eliminated B(k)
             {
                 double *urow = urow0 + J * UW;
-                if (q >= J && col) urow[q - J] = t0;
-                if (col) urow[n - J + q] = t1;
-                if (q == J) yrow0[J] = t2;
+                if constexpr (n == 16) {
+                    // no branches: the finished columns (q < J) put their (unread) word behind the row's
+                    // support, which is UW - J wide; B(k) is the same in the 16 lanes
+                    urow[(q - J) & (UW - 1)] = t0;
+                    urow[n - J + q] = t1;
+                    yrow0[J] = t2;
+                } else {
+                    if (q >= J && col) urow[q - J] = t0;
+                    if (col) urow[n - J + q] = t1;
+                    if (q == J) yrow0[J] = t2;
+                }
             }
             // (5) elimination: a_s[p] += a_0[p](lane J) * (t_s * -1/pivot); columns <= J of
             //     slot 0 are finished (their registers keep the unscaled multipliers)
@@ -264,6 +314,13 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         // ---- the nn rows left over only touch x_lc+1: next step's carry ----
 #pragma unroll
         for (int p = 0; p < nn; ++p) { a0[p] = a1[p]; a1[p] = 0.0; }
+        // ... and the prefetched rows of interface lc+1 complete the window
+#pragma unroll
+        for (int r = 0; r < E; ++r) { a0[nn + r] = bufa[r]; a1[nn + r] = bufb[r]; }
+        static_for<n>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            a2[nn + r] = dbl_lane_bcast<r>(rhsn);
+        });
     }
     if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
 #undef GC

@@ -40,6 +40,7 @@ struct Tables {            // per-run constants, device pointers
     const double *ylm0;    // [nmode][n+1]      YLM0(l) at -umu0
     const double *ylmu;    // [nmode][numu][n+1]
     const double *cosmphi; // [nmode][nphi]     cos(m*(phi-phi0)*rpd), row 0 = 1
+    const double *zeros;   // [n][n] of 0.0 (the x_lc+1 block of the bottom-boundary rows, sbd_band4.hpp)
     const double *temper;  // [L+1]
     const double *umu;     // [numu]
     const int32_t *level_out; // [nlev]

@@ -315,6 +315,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const size_t o_temper = push(cfg->temper, L + 1);
     double zero = 0.0;
     const size_t o_umu = numu > 0 ? push(cfg->umu, numu) : push(&zero, 1);
+    const std::vector<double> zblock((size_t)n * n, 0.0);
+    const size_t o_zero = push(zblock.data(), zblock.size());
 #define CREATE_TRY(expr)                                                                    \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
@@ -337,6 +339,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->tab.ylm0 = e->d_tab + o_ylm0;
     e->tab.ylmu = e->d_tab + o_ylmu;
     e->tab.cosmphi = e->d_tab + o_cos;
+    e->tab.zeros = e->d_tab + o_zero;
     e->tab.temper = e->d_tab + o_temper;
     e->tab.umu = e->d_tab + o_umu;
     e->tab.level_out = e->d_level;
