@@ -108,59 +108,64 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     const bool col = q < n;                        // this lane carries a column
     const int iq1 = q + 1;                         // its 1-based index inside a layer
 
-    // ---- right-hand side B (SOLVE0, disort.f:3434-3599), unknown index = (lc-1)*n + iq ----
-    {
+    // ---- right-hand side B (SOLVE0, disort.f:3434-3599), unknown index = (lc-1)*n + iq.  The 2 NN
+    //      boundary entries are computed here (lanes q < nn: top row q+1, the next nn lanes: the bottom
+    //      rows) and parked in yv; the interface entries are formed on the fly as their rows enter ----
+    const bool beam = fbeam > 0.0;
+    if (col) {
         const double bplank = sv[o.bplank()], tplank = sv[o.tplank()];
-        const bool beam = fbeam > 0.0;
-        for (int it = q + 1; it <= N; it += 16) {
-            double v;
-            if (it <= nn) {   // top boundary
-                const int iq = it;
-                if (mazim == 0) {
-                    if (beam) v = -ZZ(nn + 1 - iq, 1) - ZP0(nn + 1 - iq, 1) + P.fisot + tplank;
-                    else v = -ZP0(nn + 1 - iq, 1) + P.fisot + tplank;
+        const int it = (q < nn) ? q + 1 : N - n + q + 1;
+        double v;
+        if (q < nn) {   // top boundary
+            const int iq = it;
+            if (mazim == 0) {
+                if (beam) v = -ZZ(nn + 1 - iq, 1) - ZP0(nn + 1 - iq, 1) + P.fisot + tplank;
+                else v = -ZP0(nn + 1 - iq, 1) + P.fisot + tplank;
+            } else {
+                v = -ZZ(nn + 1 - iq, 1);
+            }
+        } else {        // bottom boundary
+            const int iq = it - (N - nn);
+            if (mazim > 0) {
+                v = -ZZ(iq + nn, ncut) * expbea[ncut];   // LYRCUT or Lambertian (disort.f:3441-3452)
+            } else if (lyrcut) {
+                if (beam) v = -ZZ(iq + nn, ncut) * expbea[ncut] - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
+                else v = -ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
+            } else {
+                const double bdr = albedo, bem = 1.0 - albedo;
+                double sum = 0.0;
+                if (beam) {
+                    for (int jq = 1; jq <= nn; ++jq)
+                        sum = sum + cwt[jq - 1] * cmu[jq - 1] * bdr *
+                                        (ZZ(nn + 1 - jq, ncut) * expbea[ncut] + ZP0(nn + 1 - jq, ncut)
+                                         + ZP1(nn + 1 - jq, ncut) * taucpr[ncut]);
+                    v = 2.0 * sum + (bdr * umu0 * fbeam / P.pi - ZZ(iq + nn, ncut)) * expbea[ncut]
+                        + bem * bplank - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
                 } else {
-                    v = -ZZ(nn + 1 - iq, 1);
-                }
-            } else if (it > N - nn) {   // bottom boundary
-                const int iq = it - (N - nn);
-                if (mazim > 0) {
-                    v = -ZZ(iq + nn, ncut) * expbea[ncut];   // LYRCUT or Lambertian (disort.f:3441-3452)
-                } else if (lyrcut) {
-                    if (beam) v = -ZZ(iq + nn, ncut) * expbea[ncut] - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
-                    else v = -ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
-                } else {
-                    const double bdr = albedo, bem = 1.0 - albedo;
-                    double sum = 0.0;
-                    if (beam) {
-                        for (int jq = 1; jq <= nn; ++jq)
-                            sum = sum + cwt[jq - 1] * cmu[jq - 1] * bdr *
-                                            (ZZ(nn + 1 - jq, ncut) * expbea[ncut] + ZP0(nn + 1 - jq, ncut)
-                                             + ZP1(nn + 1 - jq, ncut) * taucpr[ncut]);
-                        v = 2.0 * sum + (bdr * umu0 * fbeam / P.pi - ZZ(iq + nn, ncut)) * expbea[ncut]
-                            + bem * bplank - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
-                    } else {
-                        for (int jq = 1; jq <= nn; ++jq)
-                            sum = sum + cwt[jq - 1] * cmu[jq - 1] * bdr *
-                                            (ZP0(nn + 1 - jq, ncut) + ZP1(nn + 1 - jq, ncut) * taucpr[ncut]);
-                        v = 2.0 * sum + bem * bplank - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
-                    }
-                }
-            } else {   // interface lc | lc+1
-                const int qq = it - nn - 1;
-                const int lc = qq / n + 1, iq = qq % n + 1;
-                if (mazim > 0) {
-                    v = (ZZ(iq, lc + 1) - ZZ(iq, lc)) * expbea[lc];
-                } else if (beam) {
-                    v = (ZZ(iq, lc + 1) - ZZ(iq, lc)) * expbea[lc] + ZP0(iq, lc + 1) - ZP0(iq, lc)
-                        + (ZP1(iq, lc + 1) - ZP1(iq, lc)) * taucpr[lc];
-                } else {
-                    v = ZP0(iq, lc + 1) - ZP0(iq, lc) + (ZP1(iq, lc + 1) - ZP1(iq, lc)) * taucpr[lc];
+                    for (int jq = 1; jq <= nn; ++jq)
+                        sum = sum + cwt[jq - 1] * cmu[jq - 1] * bdr *
+                                        (ZP0(nn + 1 - jq, ncut) + ZP1(nn + 1 - jq, ncut) * taucpr[ncut]);
+                    v = 2.0 * sum + bem * bplank - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
                 }
             }
-            yv[it - 1] = v;
         }
+        // (ncut = 1: the bottom rows are rows nn+1..n of the same layer; top entries first, then these)
+        yv[it - 1] = v;
     }
+    // interface lci | lci+1, row iq = q+1: particular solutions of the two layers at the interface
+    struct Z3 { double zz, p0, p1; };
+    auto load_z = [&](int l) -> Z3 {                       // layer l clamped into 1..L: always a valid address
+        const int lz = (l < L) ? l : L;
+        const int ix = (lz - 1) * n + (col ? q : 0);
+        return Z3{zz[ix], zp0[ix], zp1[ix]};
+    };
+    // (SOLVE0's three source combinations in one branch-free form: without a beam ZZ is exactly zero and
+    //  the first product vanishes; modes m > 0 carry no thermal terms)
+    auto interface_rhs = [&](const Z3 &up, const Z3 &dn, double eb, double tc) -> double {
+        const double vb = (dn.zz - up.zz) * eb;
+        const double vt = vb + dn.p0 - up.p0 + (dn.p1 - up.p1) * tc;
+        return (mazim > 0) ? vb : vt;
+    };
     // ---- bottom-boundary rows (disort.f:2919-2990), Lambertian reflection folded in:
     //      GC(nn+r, j, ncut) - (1 + delta_m0) * sum_k CWT(k) CMU(k) ALBEDO GC(nn+1-k, j, ncut), times EK(n+1-j)
     //      for j > nn.  They go where a (non-existent) interface ncut would have its x_ncut block --
@@ -207,20 +212,24 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     // right-hand sides as one value per lane (lane r <-> row r) spread by DPP at the hand-over.
     constexpr int E = (n < 4) ? n : 4;
     double bufa[E], bufb[E], rhsn = 0.0;
-    auto step_rows = [&](int lci, const double *&pa, const double *&pb, const double *&py, bool &ry) {
+    auto step_rows = [&](int lci, const double *&pa, const double *&pb) {
         const bool inner = lci < ncut, last = lci == ncut;     // (beyond ncut: valid memory, never used)
         const int cq = col ? q : 0;
         pa = (inner || last) ? ga_ms + (size_t)(lci - 1) * n * n + cq : yv;
         pb = inner ? gb_ms + (size_t)lci * n * n + cq : (last ? P.t.zeros + cq : yv);
-        py = inner ? yv + nn + (lci - 1) * n : (last ? yv + (N - nn) : yv);
-        ry = inner || (last && q < nn);                         // lane r has a right-hand side for row r
     };
+    const double *pyb = yv + (N - nn) + ((q < nn) ? q : 0);    // bottom-boundary B, lane r <-> row r < nn
+    // B of the rows of step lci for lane r <-> row r: an interface (lci < ncut), the bottom boundary, nothing
+    auto step_rhs = [&](int lci, const Z3 &up, const Z3 &dn, double eb, double tc, double yb) -> double {
+        const double vi = interface_rhs(up, dn, eb, tc), vl = (lci == ncut && q < nn) ? yb : 0.0;
+        return (lci < ncut) ? vi : vl;
+    };
+    Z3 zc = load_z(2);                                         // lower layer of the interface just formed
     {   // rows of step 1 (exposed once per system)
-        const double *pa, *pb, *py;
-        bool ry;
-        step_rows(1, pa, pb, py, ry);
-        const double yq0 = py[col ? q : 0];
-        const double yq = ry ? yq0 : 0.0;
+        const double *pa, *pb;
+        step_rows(1, pa, pb);
+        const Z3 z1 = load_z(1);
+        const double yq = step_rhs(1, z1, zc, expbea[1], taucpr[1], *pyb);
 #pragma unroll
         for (int r = 0; r < n; ++r) {
             const double va = pa[r * n], vb = pb[r * n];
@@ -236,9 +245,11 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     // memory operations (vmcnt(0), expcnt/lgkmcnt unconstrained)
     __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int lc = 1; lc <= ncut; ++lc) {
-        const double *pna, *pnb, *pny;                          // next step's rows
-        bool rny;
-        step_rows(lc + 1, pna, pnb, pny, rny);
+        const double *pna, *pnb;                                // next step's rows
+        step_rows(lc + 1, pna, pnb);
+        const int lcb = (lc + 1 < L) ? lc + 1 : L;              // (a valid level index whatever ncut is)
+        Z3 zn;
+        double ebn, tcn, ybn;
         double *urow0 = ufac + (size_t)(lc - 1) * n * UW;      // U rows of this layer
         double *yrow0 = yv + (lc - 1) * n;
         // ---- NSTR elimination sub-steps ----
@@ -274,9 +285,15 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
                 bufa[J] = (n == 16 || col) ? va : 0.0;
                 bufb[J] = (n == 16 || col) ? vb : 0.0;
             }
-            if constexpr (J == 0) {                             // (a load whatever rny is: no branch, exact wait counts)
-                const double v = pny[col ? q : 0];
-                rhsn = rny ? v : 0.0;
+            if constexpr (J == 0) {                             // (loads whatever the step is: no branches,
+                zn = load_z(lc + 2);                            //  exact wait counts)
+                ebn = expbea[lcb];
+                tcn = taucpr[lcb];
+                ybn = *pyb;
+            }
+            if constexpr (J == ((n > 3) ? 3 : n - 1)) {
+                rhsn = step_rhs(lc + 1, zc, zn, ebn, tcn, ybn);
+                zc = zn;
             }
             // (3) -1/pivot (v_rcp + two Newton steps) in lane J, a zero pivot is flagged and skipped
             double rn = __builtin_amdgcn_rcp(t0);
