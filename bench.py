@@ -41,18 +41,28 @@ def algorithmic_flops_per_solve(nlyr, nstr):
     return nlyr * per_layer + band + 2 * nstr ** 2 * 3
 
 
-def cpu_baseline(sw, seconds_target=12.0):
+def sample_indices(nwork, nsample):
+    """Work items strided over the WHOLE sweep (UV ... 4 um: beam-only and thermal items alike)."""
+    return np.unique(np.linspace(0, nwork - 1, min(nsample, nwork)).astype(np.int64))
+
+
+def cpu_baseline(sw, seconds_target=10.0):
     """Reference DISORT (oracle/_ref/disort_ref_cli, kind "reference") or the C restatement
-    (kind "port") timed on ONE host core over a bounded sample of the same workload.
-    Returns (baseline dict, reference fluxes of the sample [nsample][3][2]: rfldir, rfldn, flup at
-    TOA and surface) -- the second feeds the "flux RMSE vs CPU" half of the metric."""
+    (kind "port") timed on the host cores over a bounded sample of the same workload: 1 core, then
+    one process per core (`nproc`), each on the same sample.
+    Returns (1-core dict, all-core dict or None, sample indices, reference fluxes of the sample
+    [nsample][3][2]: rfldir, rfldn, flup at TOA and surface) -- the last two feed the "flux RMSE vs
+    CPU" half of the metric."""
     from sbdart_amd.records import read_records, write_records
     from sbdart_amd.workload import sweep_to_records
     cli = os.path.join(ROOT, "oracle", "_ref", "disort_ref_cli")
     avg_nk = sw.nwork / sw.nwl
+    ncore = os.cpu_count() or 1
     if os.path.isfile(cli) and os.access(cli, os.X_OK):
-        nsample = min(sw.nwork, 2000)
-        recs = sweep_to_records(sw, range(nsample))
+        idx = sample_indices(sw.nwork, 2000)
+        nsample = len(idx)
+        recs = sweep_to_records(sw, idx)
+        nthermal = int(sum(bool(r.plank) for r in recs))
         with tempfile.TemporaryDirectory() as d:
             write_records(os.path.join(d, "in.sbdrec"), recs, with_out=False)
             t0 = time.time()
@@ -64,18 +74,40 @@ def cpu_baseline(sw, seconds_target=12.0):
             if os.path.exists(os.path.join(d, "out.sbdrec")):
                 ro = read_records(os.path.join(d, "out.sbdrec"))
                 ref = np.array([[[r.rfldir[0], r.rfldir[-1]], [r.rfldn[0], r.rfldn[-1]], [r.flup[0], r.flup[-1]]] for r in ro])
-        for line in out.stdout.splitlines():
-            if line.startswith("TIMING"):
-                _, nsolve, secs = line.split()
-                sps = float(nsolve) / float(secs)
-                return {"value": sps / avg_nk, "unit": "spectral-points/s", "cores": 1, "kind": "reference",
-                        "solves_per_s": sps,
-                        "sample": f"{nsample} solves of this workload x {rep} repeats, reference DISORT "
-                                  f"(amdflang -O2) on 1 host core, DISORT calls only"}, ref
+            one = None
+            for line in out.stdout.splitlines():
+                if line.startswith("TIMING"):
+                    _, nsolve, secs = line.split()
+                    sps = float(nsolve) / float(secs)
+                    one = {"value": sps / avg_nk, "unit": "spectral-points/s", "cores": 1, "kind": "reference",
+                           "solves_per_s": sps,
+                           "sample": f"{nsample} solves strided over the whole sweep ({nthermal} thermal) x {rep} "
+                                     f"repeats, reference DISORT (amdflang -O2) on 1 host core, DISORT calls only"}
+            allc = None
+            if one is not None and ncore > 1:
+                rep2 = max(1, rep // 2)
+                t0 = time.time()
+                procs = [subprocess.Popen([cli, "in.sbdrec", f"out{k}.sbdrec", str(rep2)], cwd=d,
+                                          stdout=subprocess.PIPE, text=True) for k in range(ncore)]
+                secs = []
+                for pr in procs:
+                    so, _ = pr.communicate()
+                    for line in so.splitlines():
+                        if line.startswith("TIMING"):
+                            secs.append(float(line.split()[2]))
+                if len(secs) == ncore:
+                    sps = ncore * nsample * rep2 / max(secs)
+                    allc = {"value": sps / avg_nk, "unit": "spectral-points/s", "cores": ncore, "nproc": ncore,
+                            "kind": "reference", "solves_per_s": sps,
+                            "sample": f"{ncore} processes x the same {nsample}-solve sample x {rep2} repeats "
+                                      f"(slowest process's DISORT time)"}
+            if one is not None:
+                return one, allc, idx, ref
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle  # baseline leg only
-    nsample = min(sw.nwork, 1500)
-    recs = sweep_to_records(sw, range(nsample))
+    idx = sample_indices(sw.nwork, 1500)
+    nsample = len(idx)
+    recs = sweep_to_records(sw, idx)
     o0 = [pyoracle.disort(r) for r in recs]
     ref = np.array([[[o["rfldir"][0], o["rfldir"][-1]], [o["rfldn"][0], o["rfldn"][-1]], [o["flup"][0], o["flup"][-1]]] for o in o0])
     t0 = time.time()
@@ -87,8 +119,12 @@ def cpu_baseline(sw, seconds_target=12.0):
     secs = time.time() - t0
     return {"value": n / secs / avg_nk, "unit": "spectral-points/s", "cores": 1, "kind": "port",
             "solves_per_s": n / secs,
-            "sample": f"{nsample} solves of this workload repeated for {secs:.1f}s, C restatement "
-                      f"(oracle/disort_oracle.c, gcc -O2) through ctypes on 1 host core"}, ref
+            "sample": f"{nsample} solves strided over the whole sweep, repeated for {secs:.1f}s, C restatement "
+                      f"(oracle/disort_oracle.c, gcc -O2) through ctypes on 1 host core"}, None, idx, ref
+
+
+DEV_SWITCHES = ("SBD_CHUNK", "SBD_WORKSPACE_MB", "SBD_BAND_LDS", "SBD_BAND_V1", "SBD_LAYER_V1",
+                "SBD_FORCE_EIG_FALLBACK", "SBD_DEBUG_SYNC", "SBD_DBG_FLAGS")
 
 
 def main():
@@ -101,6 +137,9 @@ def main():
     ap.add_argument("--nlyr", type=int, default=33)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    on = [k for k in DEV_SWITCHES if os.environ.get(k)]
+    if on:   # the headline number is the default path only
+        sys.exit(f"bench.py: developer switch(es) {on} set in the environment -- refusing to produce a bench line")
 
     import torch
     import torch.distributed as dist
@@ -173,6 +212,39 @@ def main():
     eng.enable_timing(False)
     torch.cuda.synchronize()
 
+    # ---- the same step with the inputs in (pinned) host memory: H2D of the inputs + kernels + weighted
+    #      sums + D2H of the accumulator block (SURVEY 8d's "engine phase"); never `value` ----
+    h_in = [x.cpu().pin_memory() for x in d_in]
+    h_w = d_w.cpu().pin_memory()
+    s_in = [torch.empty_like(x) for x in d_in]
+    s_w = torch.empty_like(d_w)
+
+    def step_host():
+        for dst, src in zip(s_in, h_in):
+            dst.copy_(src, non_blocking=True)
+        s_w.copy_(h_w, non_blocking=True)
+        eng.solve_device(*s_in, out=(flux, None, status), stream=stream)
+        acc.zero_()
+        rc = L.sbd_engine_accumulate_device(eng._h, W, s_w.data_ptr(), flux.data_ptr(), None,
+                                            acc.data_ptr(), None, C.c_void_p(stream))
+        assert rc == 0, rc
+        if world > 1:
+            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
+        return acc.cpu()
+
+    step_host()
+    barrier()
+    t0 = time.perf_counter()
+    nh = max(1, min(args.steps, 5))
+    for _ in range(nh):
+        step_host()
+    barrier()
+    elapsed_h = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed_h], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed_h = float(tt.item())
+
     if rank == 0:
         nwl_total = sw.nwl * world
         ms_per_step = 1e3 * elapsed / args.steps
@@ -181,16 +253,20 @@ def main():
         dom = int(np.argmax(phase_ms))
         abytes = algorithmic_bytes_per_solve(sw.nlyr, sw.nstr, eng.nlev)
         nlaunch = (W + eng.chunk - 1) // eng.chunk
+        pass_size = (W + nlaunch - 1) // nlaunch           # the engine splits a batch into equal passes
         ach = abytes * W / (phase_ms[dom] * 1e-3) / 1e9
         # HBM bytes per launch of the dominant kernel from the committed PMC passes
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/make_traffic_profile.py)
-        traffic = None
+        # HBM bytes per launch of the dominant kernel: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # separate runs, tools/make_traffic_profile.py) of this command at this launch size
+        traffic, traffic_src = None, None
         try:
-            tp = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            key = {"layer_kernel": "layer_kernel2", "band_kernel": "band_kernel"}.get(names[dom], names[dom])
-            for kname, kd in tp["kernels"].items():
-                if key in kname and (sw.nstr == 16):
-                    traffic = kd["bytes_per_solve"] * min(W, eng.chunk)
+            tp = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            key = {"layer_kernel": "layer_kernel2", "band_kernel": "band4_kernel"}.get(names[dom], names[dom])
+            if tp.get("nstr") == sw.nstr and tp.get("nlyr") == sw.nlyr and tp.get("solves_per_launch") == pass_size:
+                for kname, kd in tp["kernels"].items():
+                    if key in kname:
+                        traffic, traffic_src = kd["bytes_per_launch"], "profiles/r02_traffic.json"
         except Exception:
             traffic = None
         flops = algorithmic_flops_per_solve(sw.nlyr, sw.nstr)
@@ -206,12 +282,14 @@ def main():
                        "parallelism": f"spectral shard x{world}, 1 RCCL reduce of {5 * eng.nlev} doubles/step",
                        "chunk": eng.chunk, "workspace_bytes": eng.workspace_bytes},
             "solves_per_s": W * world * args.steps / elapsed,
+            "value_incl_h2d": nwl_total * nh / elapsed_h, "ms_per_step_incl_h2d": 1e3 * elapsed_h / nh,
+            "incl_h2d_note": "same step with the inputs in pinned host memory: H2D + kernels + sums + D2H of the sums",
             "nonzero_status": bad,
             "kernel_ms": {names[i]: float(phase_ms[i]) for i in range(5)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json)",
-                         "algorithmic_bytes_per_solve": abytes, "solves_per_launch": min(W, eng.chunk),
+                         "traffic_unit": f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
+                         "algorithmic_bytes_per_solve": abytes, "solves_per_launch": pass_size,
                          "launches": nlaunch, "avg_launch_ms": float(phase_ms[dom] / nlaunch),
                          "note": "path is fp64-VALU/LDS/latency bound by construction (SURVEY 8d); "
                                  "fp64 fraction reported beside it",
@@ -219,16 +297,18 @@ def main():
                          "fp64_frac_of_vector_peak": flops * W / (phase_ms.sum() * 1e-3) / 1e12 / FP64_VEC_PEAK_TF},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"], ref = cpu_baseline(sw)
+            out["cpu_baseline"], allc, idx, ref = cpu_baseline(sw)
+            if allc is not None:
+                out["cpu_baseline_allcore"] = allc
             if ref is not None:
                 # the other half of the metric: GPU vs CPU on the sampled solves, TOA (level 0) and
                 # surface (level 1) -- per solve (fbeam = 1: fluxes per unit incident beam) and for
                 # the spectrally weighted sums of the sample (stdout1's TOPDN..BOTDIR, drt.f:1047-1054)
                 ns = ref.shape[0]
-                g = flux[:ns, :3, :].cpu().numpy()                       # [ns][rfldir, rfldn, flup][top, bot]
+                g = flux[torch.from_numpy(idx).to(dev)][:, :3, :].cpu().numpy()   # [ns][rfldir, rfldn, flup][top, bot]
                 six = lambda a: np.stack([a[:, 1] + a[:, 0], a[:, 2], a[:, 0]], 1).reshape(ns, 6)   # dn, up, dir at top|bot
                 sg, sr = six(g), six(ref)
-                wgt = np.asarray(sw.weight[:ns], dtype=np.float64)[:, None]
+                wgt = np.asarray(sw.weight[idx], dtype=np.float64)[:, None]
                 out["flux_rmse_vs_cpu"] = {
                     "per_solve_rmse": float(np.sqrt(np.mean((sg - sr) ** 2))),
                     "per_solve_max_abs": float(np.abs(sg - sr).max()),
@@ -236,7 +316,9 @@ def main():
                     "integrated_max_abs": float(np.abs(((sg - sr) * wgt).sum(0)).max()),
                     "integrated_ref_max": float(np.abs((sr * wgt).sum(0)).max()),
                     "quantities": "TOPDN,BOTDN,TOPUP,BOTUP,TOPDIR,BOTDIR", "solves": int(ns),
-                    "units": "fluxes per unit FBEAM (synthetic sweep has FBEAM = 1); north_star gate 1e-4 W/m2 on integrated fluxes"}
+                    "thermal_solves": int(np.count_nonzero(np.asarray(sw.plank)[idx])),
+                    "units": "fluxes per unit FBEAM (synthetic sweep has FBEAM = 1; thermal items in W/m2 per band); "
+                             "north_star gate 1e-4 W/m2 on integrated fluxes"}
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out))

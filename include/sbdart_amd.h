@@ -17,6 +17,9 @@
  *     (disort.f:2645-2650, drt.f:536-555)                    SBD_E_RETRY_NSTR from create
  *   errmsg warnings 2,3,4 / fatal STOPs (disutil.f:278)     per-work-item status bits
  *   stdout1's weighted spectral sums (drt.f:964-1087)       sbd_engine_accumulate_host/_device
+ *   the same loop spread over the GPUs of a node: shards    sbd_fleet_create / sbd_fleet_solve_host
+ *     of independent (wavelength, k) items, one sum of the   (one engine per device, one RCCL
+ *     accumulators (outblk, drt.f:1-18) at the end           reduce of the accumulator block)
  *
  * The Fortran-2003 host binds these through ISO_C_BINDING
  * (sbdart_amd/fortran/sbd_engine_mod.f90); INTEGRATION.md shows the stub a
@@ -24,7 +27,11 @@
  *
  * All arithmetic is fp64.  All arrays are dense, row-major by work item
  * ("[nwork][...]"), top-down in the vertical exactly like DISORT's arguments.
- * The engine is re-entrant (no global state); one engine drives one GPU.
+ * No global state: engines are independent of one another.  ONE engine drives ONE GPU and owns
+ * one workspace, one stream and one staging area: use it from one thread at a time, and when
+ * sbd_engine_solve_device is given a caller's stream, order that stream against the engine's
+ * other uses yourself (the workspace is shared between consecutive calls).  Several GPUs of a
+ * node from one process: sbd_fleet_* below.
  */
 #ifndef SBDART_AMD_H
 #define SBDART_AMD_H
@@ -36,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SBD_ABI_VERSION 1
+#define SBD_ABI_VERSION 2
 
 /* limits of the reference (params.f:9-15) */
 #define SBD_MAX_NLYR 65   /* mxly   */
@@ -140,6 +147,27 @@ int sbd_engine_accumulate_device(sbd_engine *e, int32_t nwork, const double *wei
 int sbd_engine_accumulate_host(sbd_engine *e, int32_t nwork, const double *weight,
                                const double *flux, const double *uu,
                                double *acc_flux, double *acc_uu);
+
+/* ---- several GPUs, one process (the reference's loop has no cross-item dependence, drt.f:425-561) ----
+ * A fleet = one engine per device (devices == NULL or ndev <= 0: every visible device).  A batch is
+ * cut into contiguous shards, sbd_shard_range(nwork, nshard, rank): the first nwork % nshard shards hold
+ * one item more.  sbd_fleet_solve_host: HOST pointers; every device stages and solves its shard on its
+ * own stream; per-item outputs land in place in `out` (out->flux / out->uu may be NULL when only the
+ * sums are wanted, out->status is required).  With weight != NULL the weighted sums of the whole batch
+ * (stdout1's accumulation, same element order as sbd_engine_accumulate_*) are ADDED to acc_flux
+ * [SBD_NFLUX][nlev] and, if not NULL, acc_uu [nphi][nlev][numu]: per-device fixed-order sums, then one
+ * ncclReduce(sum, double) onto the first device (RCCL over xGMI) -- or, when a device appears twice in
+ * the list or RCCL is unavailable, a host-side sum in device order.
+ * sbd_fleet_create returns SBD_E_RETRY_NSTR like sbd_engine_create (the fleet is created). */
+typedef struct sbd_fleet sbd_fleet;
+int      sbd_fleet_create(const sbd_run_cfg *cfg, int32_t ndev, const int32_t *devices, sbd_fleet **out);
+void     sbd_fleet_destroy(sbd_fleet *f);
+int32_t  sbd_fleet_size(const sbd_fleet *f);
+sbd_engine *sbd_fleet_engine(sbd_fleet *f, int32_t i);      /* the i-th device's engine (introspection) */
+int32_t  sbd_fleet_uses_rccl(const sbd_fleet *f);           /* 1: sums are reduced by RCCL, 0: on the host */
+void     sbd_shard_range(int32_t nwork, int32_t nshard, int32_t rank, int32_t *lo, int32_t *hi);
+int      sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_out *out,
+                              const double *weight, double *acc_flux, double *acc_uu);
 
 /* ---- introspection ---- */
 int32_t     sbd_abi_version(void);

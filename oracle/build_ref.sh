@@ -7,7 +7,8 @@
 #   oracle/_ref/sbdart_ref       the unmodified reference executable (makefile:17-33 order)
 #   oracle/_ref/sbdart_capture   same objects, with DISORT/depthscl/filter call
 #                                sites routed through oracle/ref/sbd_ref_capture.f90
-#                                (symbol renames by llvm-objcopy -- no source edits)
+#                                (symbol renames by llvm-objcopy -- no source edits); also writes
+#                                the level altitudes/pressures (absint call site) beside the records
 #   oracle/_ref/disort_ref_cli   reference DISORT behind a record-file CLI
 #                                (oracle/ref/sbd_ref_cli.f90)
 #   oracle/_ref/ref_units_cli    single reference routines (QGAUSN, PLKAVG, ASYMTX,
@@ -39,7 +40,7 @@ done
 
 # --- capture build: rename the three reference definitions, link wrappers ---
 "$OBJCOPY" --redefine-sym disort_=disort_ref_     disort.o  disort_cap.o
-"$OBJCOPY" --redefine-sym depthscl_=depthscl_ref_ taugas.o  taugas_cap.o
+"$OBJCOPY" --redefine-sym depthscl_=depthscl_ref_ --redefine-sym absint_=absint_ref_ taugas.o  taugas_cap.o
 "$OBJCOPY" --redefine-sym filter_=filter_ref_     spectra.o spectra_cap.o
 "$FC" $FFLAGS -c "$HERE/ref/sbd_ref_capture.f90" -o sbd_ref_capture.o
 "$FC" $FFLAGS -o "$OUT/sbdart_capture" params.o tauaero.o taugas_cap.o spectra_cap.o \

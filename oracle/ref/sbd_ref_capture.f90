@@ -7,8 +7,12 @@
 !     disort_   -> disort_ref_     (disort.o)
 !     depthscl_ -> depthscl_ref_   (taugas.o)
 !     filter_   -> filter_ref_     (spectra.o)
+!     absint_   -> absint_ref_     (taugas.o)
 ! and links these same-named wrappers in their place, so drt.o's call sites
-! (drt.f:531-533 depthscl, drt.f:461 filter, drt.f:541-546 DISORT) land here.
+! (drt.f:531-533 depthscl, drt.f:461 filter, drt.f:541-546 DISORT, drt.f:366 absint) land here.
+! absint is the last routine that is handed the final level altitudes and pressures before the
+! wavelength loop: its wrapper writes them to "<capture file>.atm" (text: nz, then "z p" from the
+! surface upwards) -- the atmosphere file the host needs for ZOUT and the IOUT 7/11/22 formats.
 !
 ! Record layout: see sbdart_amd/records.py (the single definition of the
 ! "SBDREC1" stream format).  Inputs are written BEFORE the reference call
@@ -38,6 +42,27 @@ contains
     write(rec_unit) 'SBDREC1'//char(0), -1, 1
   end subroutine
 end module sbd_capture_state
+
+subroutine absint(uu, nz, z, p, t, wh, wo, idb)
+  use sbd_capture_state
+  implicit none
+  integer :: nz, idb, i, n, stat, u
+  real(dp) :: uu(*), z(*), p(*), t(*), wh(*), wo(*)
+  character(len=1024) :: path
+  external absint_ref
+  call get_environment_variable('SBD_CAPTURE_FILE', path, n, stat)
+  if (stat /= 0 .or. n <= 0) then
+    path = 'disort_capture.sbdrec'
+    n = len_trim(path)
+  end if
+  open(newunit=u, file=path(1:n)//'.atm', status='replace', form='formatted')
+  write(u, '(i6)') nz
+  do i = 1, nz
+    write(u, '(2es25.16)') z(i), p(i)
+  end do
+  close(u)
+  call absint_ref(uu, nz, z, p, t, wh, wo, idb)
+end subroutine absint
 
 subroutine depthscl(kdist, kd, nk, ib, nz, wl, dtaur, dtaua, &
      waer, dtauc, wcld, spowder, gwk, dtauk, dtaugc, wt, dtau, wreal, idb)

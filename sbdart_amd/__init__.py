@@ -4,6 +4,6 @@ The product is the HIP library behind include/sbdart_amd.h (sbdart_amd/csrc); th
 is its ctypes mirror (engine.py), the record format shared with the Fortran host (records.py),
 the synthetic benchmark workload (workload.py) and the spectral sharding helper (shard.py).
 """
-from .engine import DisortEngine, RetryNstr, SbdError  # noqa: F401
+from .engine import DisortEngine, DisortFleet, RetryNstr, SbdError  # noqa: F401
 
-__all__ = ["DisortEngine", "RetryNstr", "SbdError"]
+__all__ = ["DisortEngine", "DisortFleet", "RetryNstr", "SbdError"]

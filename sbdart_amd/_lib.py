@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SBDART_AMD_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get("SBDART_AMD_LIB") or os.path.join(_HERE, "lib", "libsbdart_amd.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NFLUX = 5
 RFLDIR, RFLDN, FLUP, DFDT, UAVG = range(5)
 
@@ -46,6 +46,8 @@ EXPORTS = (
     "sbd_engine_nlevel", "sbd_engine_workspace_bytes", "sbd_engine_chunk", "sbd_engine_stream",
     "sbd_engine_quadrature", "sbd_engine_last_ms", "sbd_engine_enable_timing", "sbd_strerror",
     "sbd_last_error", "sbd_engine_debug_copy",
+    "sbd_fleet_create", "sbd_fleet_destroy", "sbd_fleet_size", "sbd_fleet_engine", "sbd_fleet_uses_rccl",
+    "sbd_shard_range", "sbd_fleet_solve_host",
 )
 
 _LIB = None
@@ -93,5 +95,19 @@ def load() -> C.CDLL:
     L.sbd_last_error.restype = C.c_char_p
     L.sbd_engine_debug_copy.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.sbd_engine_debug_copy.restype = C.c_longlong
+    L.sbd_fleet_create.argtypes = [C.POINTER(RunCfg), C.c_int32, _ip, C.POINTER(vp)]
+    L.sbd_fleet_create.restype = C.c_int
+    L.sbd_fleet_destroy.argtypes = [vp]
+    L.sbd_fleet_destroy.restype = None
+    L.sbd_fleet_size.argtypes = [vp]
+    L.sbd_fleet_size.restype = C.c_int32
+    L.sbd_fleet_engine.argtypes = [vp, C.c_int32]
+    L.sbd_fleet_engine.restype = vp
+    L.sbd_fleet_uses_rccl.argtypes = [vp]
+    L.sbd_fleet_uses_rccl.restype = C.c_int32
+    L.sbd_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, _ip, _ip]
+    L.sbd_shard_range.restype = None
+    L.sbd_fleet_solve_host.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(BatchOut), vp, vp, vp]
+    L.sbd_fleet_solve_host.restype = C.c_int
     _LIB = L
     return L

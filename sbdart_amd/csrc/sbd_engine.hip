@@ -12,6 +12,7 @@
 #include "../../include/sbdart_amd.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -163,6 +164,8 @@ struct sbd_engine {
     size_t stage_bytes = 0;
     double *d_partial = nullptr;
     size_t partial_elems = 0;
+    double *d_acc = nullptr;      // [5*nlev + nphi*nlev*numu] weighted sums of the last fleet solve
+    double *d_red = nullptr;      // same size: RCCL reduce result (root)
     // timing
     bool timing = false;
     static constexpr int kPhases = 5;   // setup, layer, band LU, back-substitution + fluxes, intensities
@@ -204,6 +207,8 @@ void sbd_engine_destroy(sbd_engine *e)
     if (e->d_ws) (void)hipFree(e->d_ws);
     if (e->d_stage) (void)hipFree(e->d_stage);
     if (e->d_partial) (void)hipFree(e->d_partial);
+    if (e->d_acc) (void)hipFree(e->d_acc);
+    if (e->d_red) (void)hipFree(e->d_red);
     for (auto &x : e->ev)
         if (x) (void)hipEventDestroy(x);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -533,8 +538,12 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
     const bool dbg = getenv("SBD_DEBUG_SYNC") != nullptr;
 #define SBD_DBG(tag) do { if (dbg) { hipError_t de_ = hipStreamSynchronize(st); fprintf(stderr, "[sbd] %s: %s (eigflag=%p partial=%p ws=%p..%p)\n", tag, hipGetErrorString(de_), (void*)e->d_eigflag, (void*)e->d_partial, (void*)e->d_ws, (void*)(e->d_ws + e->ws_bytes)); } } while (0)
     float acc_ms[sbd_engine::kPhases] = {};
-    for (int w0 = 0; w0 < in->nwork; w0 += e->chunk) {
-        const int ns = (in->nwork - w0 < e->chunk) ? in->nwork - w0 : e->chunk;
+    // a batch larger than the workspace goes through in EQUAL passes (no short tail pass whose
+    // kernels cost their full launch latency for a handful of items)
+    const int npass = (in->nwork + e->chunk - 1) / e->chunk;
+    const int per_pass = (in->nwork + npass - 1) / npass;
+    for (int w0 = 0; w0 < in->nwork; w0 += per_pass) {
+        const int ns = (in->nwork - w0 < per_pass) ? in->nwork - w0 : per_pass;
         sbd::Params P = e->P;
         P.nslot = ns;
         P.dtauc = in->dtauc + (size_t)w0 * L;
@@ -615,10 +624,11 @@ static int ensure_stage(sbd_engine *e, size_t bytes)
     return SBD_OK;
 }
 
-int sbd_engine_solve_host(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out)
+// Host-pointer solve, enqueue part: H2D of the inputs, the kernel pipeline, optionally the weighted
+// sums of the batch into e->d_acc (weight != NULL), D2H of the per-item outputs the caller asked
+// for -- all on the engine's stream, no synchronisation.
+static int solve_host_enqueue(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, const double *weight)
 {
-    if (!e || !in || !out) return fail(SBD_E_INVALID, "null argument");
-    if (in->nwork <= 0) return in->nwork == 0 ? SBD_OK : fail(SBD_E_INVALID, "nwork < 0");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const size_t W = in->nwork;
     const int L = e->L, nlev = e->nlev;
@@ -627,13 +637,14 @@ int sbd_engine_solve_host(sbd_engine *e, const sbd_batch_in *in, const sbd_batch
     const size_t b_flux = sizeof(double) * W * SBD_NFLUX * nlev;
     const size_t b_uu = rad ? sizeof(double) * W * e->P.nphi * nlev * e->P.numu : 0;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t total = 2 * up(b_lay) + up(b_pm) + 4 * up(b_w) + up(W) + up(b_flux) + up(b_uu) + up(sizeof(int32_t) * W);
+    const size_t total = 2 * up(b_lay) + up(b_pm) + 5 * up(b_w) + up(W) + up(b_flux) + up(b_uu) + up(sizeof(int32_t) * W);
     int rc = ensure_stage(e, total);
     if (rc != SBD_OK) return rc;
     char *p = e->d_stage;
     auto take = [&](size_t bytes) { char *r = p; p += up(bytes); return r; };
     double *d_dt = (double *)take(b_lay), *d_ss = (double *)take(b_lay), *d_pm = (double *)take(b_pm);
     double *d_lo = (double *)take(b_w), *d_hi = (double *)take(b_w), *d_fb = (double *)take(b_w), *d_al = (double *)take(b_w);
+    double *d_wt = (double *)take(b_w);
     uint8_t *d_pl = (uint8_t *)take(W);
     double *d_flux = (double *)take(b_flux);
     double *d_uu = rad ? (double *)take(b_uu) : nullptr;
@@ -647,14 +658,35 @@ int sbd_engine_solve_host(sbd_engine *e, const sbd_batch_in *in, const sbd_batch
     HIP_TRY(hipMemcpyAsync(d_fb, in->fbeam, b_w, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_al, in->albedo, b_w, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_pl, in->plank, W, hipMemcpyHostToDevice, st));
+    if (weight) HIP_TRY(hipMemcpyAsync(d_wt, weight, b_w, hipMemcpyHostToDevice, st));
     sbd_batch_in din = {in->nwork, d_dt, d_ss, d_pm, d_lo, d_hi, d_fb, d_al, d_pl};
     sbd_batch_out dout = {d_flux, d_uu, d_st};
     rc = sbd_engine_solve_device(e, &din, &dout, st);
     if (rc != SBD_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(out->flux, d_flux, b_flux, hipMemcpyDeviceToHost, st));
+    if (weight) {
+        const size_t nel_f = (size_t)SBD_NFLUX * nlev, nel_u = rad ? (size_t)e->P.nphi * nlev * e->P.numu : 0;
+        if (!e->d_acc) {
+            HIP_TRY(hipMalloc(&e->d_acc, sizeof(double) * (nel_f + nel_u)));
+            HIP_TRY(hipMalloc(&e->d_red, sizeof(double) * (nel_f + nel_u)));
+        }
+        HIP_TRY(hipMemsetAsync(e->d_acc, 0, sizeof(double) * (nel_f + nel_u), st));
+        rc = sbd_engine_accumulate_device(e, in->nwork, d_wt, d_flux, d_uu, e->d_acc, rad ? e->d_acc + nel_f : nullptr, st);
+        if (rc != SBD_OK) return rc;
+    }
+    if (out->flux) HIP_TRY(hipMemcpyAsync(out->flux, d_flux, b_flux, hipMemcpyDeviceToHost, st));
     if (rad && out->uu) HIP_TRY(hipMemcpyAsync(out->uu, d_uu, b_uu, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out->status, d_st, sizeof(int32_t) * W, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (out->status) HIP_TRY(hipMemcpyAsync(out->status, d_st, sizeof(int32_t) * W, hipMemcpyDeviceToHost, st));
+    return SBD_OK;
+}
+
+int sbd_engine_solve_host(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out)
+{
+    if (!e || !in || !out) return fail(SBD_E_INVALID, "null argument");
+    if (in->nwork <= 0) return in->nwork == 0 ? SBD_OK : fail(SBD_E_INVALID, "nwork < 0");
+    if (!out->flux || !out->status) return fail(SBD_E_INVALID, "null output array");
+    int rc = solve_host_enqueue(e, in, out, nullptr);
+    if (rc != SBD_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return SBD_OK;
 }
 
@@ -717,6 +749,140 @@ int sbd_engine_accumulate_host(sbd_engine *e, int32_t nwork, const double *weigh
     HIP_TRY(hipMemcpyAsync(acc_flux, d_af, 8 * (size_t)nel_f, hipMemcpyDeviceToHost, st));
     if (nel_u) HIP_TRY(hipMemcpyAsync(acc_uu, d_au, 8 * (size_t)nel_u, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return SBD_OK;
+}
+
+// ===================== several GPUs from one process =====================
+// A fleet is one engine per device.  Work items are independent (drt.f:425-561), so a batch is cut
+// into contiguous shards (sbd_shard_range), every device solves its shard with no data-path
+// exchange, and the only collective is the sum of the weighted accumulator blocks (stdout1's
+// spectral sums, drt.f:1047-1054): one ncclReduce(sum, double) over xGMI when the devices are
+// distinct, a host-side sum in device order otherwise (the same engine twice: test configurations).
+struct sbd_fleet {
+    std::vector<sbd_engine *> eng;
+    std::vector<ncclComm_t> comm;     // empty: host-side sum
+    std::vector<double> hacc;         // [ndev][nel] staging of the host-side sum
+    int retry_nstr = 0;
+};
+
+void sbd_shard_range(int32_t nwork, int32_t nshard, int32_t rank, int32_t *lo, int32_t *hi)
+{
+    // contiguous blocks of ceil/floor(nwork/nshard) items, the first nwork % nshard shards one longer
+    if (nshard < 1) nshard = 1;
+    const int32_t base = nwork / nshard, extra = nwork % nshard;
+    const int32_t l = rank * base + (rank < extra ? rank : extra);
+    if (lo) *lo = l;
+    if (hi) *hi = l + base + (rank < extra ? 1 : 0);
+}
+
+void sbd_fleet_destroy(sbd_fleet *f)
+{
+    if (!f) return;
+    for (auto c : f->comm) (void)ncclCommDestroy(c);
+    for (auto e : f->eng) sbd_engine_destroy(e);
+    delete f;
+}
+
+int32_t sbd_fleet_size(const sbd_fleet *f) { return f ? (int32_t)f->eng.size() : 0; }
+sbd_engine *sbd_fleet_engine(sbd_fleet *f, int32_t i) { return (f && i >= 0 && i < (int32_t)f->eng.size()) ? f->eng[i] : nullptr; }
+int32_t sbd_fleet_uses_rccl(const sbd_fleet *f) { return f && !f->comm.empty(); }
+
+int sbd_fleet_create(const sbd_run_cfg *cfg, int32_t ndev, const int32_t *devices, sbd_fleet **out)
+{
+    if (!cfg || !out) return fail(SBD_E_INVALID, "null argument");
+    *out = nullptr;
+    int nvis = 0;
+    if (hipGetDeviceCount(&nvis) != hipSuccess || nvis <= 0) return fail(SBD_E_NO_DEVICE, "hipGetDeviceCount");
+    std::vector<int> dev;
+    if (ndev <= 0 || !devices) {
+        for (int d = 0; d < nvis; ++d) dev.push_back(d);     // every visible device
+    } else {
+        for (int i = 0; i < ndev; ++i) dev.push_back(devices[i]);
+    }
+    sbd_fleet *f = new (std::nothrow) sbd_fleet;
+    if (!f) return fail(SBD_E_NOMEM, "host allocation");
+    int rc_all = SBD_OK;
+    for (int d : dev) {
+        sbd_run_cfg c = *cfg;
+        c.device = d;
+        sbd_engine *e = nullptr;
+        const int rc = sbd_engine_create(&c, &e);
+        if (rc == SBD_E_RETRY_NSTR) { rc_all = rc; f->retry_nstr = 1; }
+        else if (rc != SBD_OK) { sbd_fleet_destroy(f); return rc; }
+        f->eng.push_back(e);
+    }
+    bool distinct = dev.size() > 1;
+    for (size_t i = 0; i < dev.size(); ++i)
+        for (size_t j = i + 1; j < dev.size(); ++j)
+            if (dev[i] == dev[j]) distinct = false;
+    if (distinct) {
+        f->comm.resize(dev.size());
+        if (ncclCommInitAll(f->comm.data(), (int)dev.size(), dev.data()) != ncclSuccess) {
+            f->comm.clear();            // no RCCL path on this system: fall back to the host-side sum
+        }
+    }
+    *out = f;
+    return rc_all;
+}
+
+int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_out *out,
+                         const double *weight, double *acc_flux, double *acc_uu)
+{
+    if (!f || !in || !out || f->eng.empty()) return fail(SBD_E_INVALID, "null argument");
+    if (in->nwork < 0) return fail(SBD_E_INVALID, "nwork < 0");
+    if (!out->status) return fail(SBD_E_INVALID, "status is NULL");
+    if (weight && !acc_flux) return fail(SBD_E_INVALID, "acc_flux is NULL");
+    const int nd = (int)f->eng.size();
+    sbd_engine *e0 = f->eng[0];
+    const int L = e0->L, nlev = e0->nlev, nmom1 = e0->cfg.nmom + 1;
+    const bool rad = !e0->cfg.onlyfl;
+    const size_t nel_f = (size_t)SBD_NFLUX * nlev, nel_u = rad ? (size_t)e0->P.nphi * nlev * e0->P.numu : 0, nel = nel_f + nel_u;
+    const size_t uu_item = rad ? (size_t)e0->P.nphi * nlev * e0->P.numu : 0;
+    std::vector<int> busy;
+    for (int r = 0; r < nd; ++r) {
+        int32_t lo, hi;
+        sbd_shard_range(in->nwork, nd, r, &lo, &hi);
+        if (hi <= lo) continue;
+        sbd_batch_in si = {hi - lo, in->dtauc + (size_t)lo * L, in->ssalb + (size_t)lo * L, in->pmom + (size_t)lo * L * nmom1,
+                           in->wvnmlo + lo, in->wvnmhi + lo, in->fbeam + lo, in->albedo + lo, in->plank + lo};
+        sbd_batch_out so = {out->flux ? out->flux + (size_t)lo * nel_f : nullptr,
+                            (rad && out->uu) ? out->uu + (size_t)lo * uu_item : nullptr, out->status + lo};
+        const int rc = solve_host_enqueue(f->eng[r], &si, &so, weight ? weight + lo : nullptr);
+        if (rc != SBD_OK) return rc;
+        busy.push_back(r);
+    }
+    if (weight) {
+        if (!f->comm.empty() && (int)busy.size() == nd) {
+            // the one collective of the path: sum of the accumulator blocks onto device 0 over xGMI
+            if (ncclGroupStart() != ncclSuccess) return fail(SBD_E_HIP, "ncclGroupStart");
+            for (int r = 0; r < nd; ++r) {
+                HIP_TRY(hipSetDevice(f->eng[r]->cfg.device));
+                if (ncclReduce(f->eng[r]->d_acc, f->eng[r]->d_red, nel, ncclDouble, ncclSum, 0, f->comm[r], f->eng[r]->stream) != ncclSuccess)
+                    return fail(SBD_E_HIP, "ncclReduce");
+            }
+            if (ncclGroupEnd() != ncclSuccess) return fail(SBD_E_HIP, "ncclGroupEnd");
+            f->hacc.assign(nel, 0.0);
+            HIP_TRY(hipSetDevice(e0->cfg.device));
+            HIP_TRY(hipMemcpyAsync(f->hacc.data(), e0->d_red, sizeof(double) * nel, hipMemcpyDeviceToHost, e0->stream));
+            for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); }
+            for (size_t i = 0; i < nel_f; ++i) acc_flux[i] += f->hacc[i];
+            if (acc_uu) for (size_t i = 0; i < nel_u; ++i) acc_uu[i] += f->hacc[nel_f + i];
+        } else {
+            f->hacc.assign((size_t)nd * nel, 0.0);
+            for (int r : busy) {
+                HIP_TRY(hipSetDevice(f->eng[r]->cfg.device));
+                HIP_TRY(hipMemcpyAsync(f->hacc.data() + (size_t)r * nel, f->eng[r]->d_acc, sizeof(double) * nel, hipMemcpyDeviceToHost, f->eng[r]->stream));
+            }
+            for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); }
+            for (int r : busy) {   // fixed order: device 0's block first
+                const double *h = f->hacc.data() + (size_t)r * nel;
+                for (size_t i = 0; i < nel_f; ++i) acc_flux[i] += h[i];
+                if (acc_uu) for (size_t i = 0; i < nel_u; ++i) acc_uu[i] += h[nel_f + i];
+            }
+        }
+    } else {
+        for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); }
+    }
     return SBD_OK;
 }
 

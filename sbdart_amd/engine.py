@@ -52,7 +52,7 @@ class DisortEngine:
         if usrang is None:
             usrang = not self.onlyfl
         self._lev = None if level_out is None else np.ascontiguousarray(level_out, dtype=np.int32)
-        cfg = RunCfg(
+        self._cfg = cfg = RunCfg(
             abi_version=_lib.ABI_VERSION, nlyr=self.nlyr, nstr=self.nstr, nmom=self.nmom,
             onlyfl=int(self.onlyfl), lamber=int(lamber), usrang=int(usrang), numu=self.numu,
             nphi=self.nphi, nlevel_out=0 if self._lev is None else len(self._lev), device=device,
@@ -62,7 +62,7 @@ class DisortEngine:
             umu=self._umu.ctypes.data_as(C.POINTER(C.c_double)) if self.numu else None,
             phi=self._phi.ctypes.data_as(C.POINTER(C.c_double)) if self.nphi else None,
             level_out=None if self._lev is None else self._lev.ctypes.data_as(C.POINTER(C.c_int32)))
-        rc = self._L.sbd_engine_create(C.byref(cfg), C.byref(self._h))
+        rc = self._create(cfg)
         self.retry_nstr = rc == _lib.E_RETRY_NSTR
         if rc == _lib.E_RETRY_NSTR and not allow_retry_nstr:
             self.close()
@@ -70,13 +70,22 @@ class DisortEngine:
         if rc not in (_lib.OK, _lib.E_RETRY_NSTR):
             self._h = C.c_void_p()
             raise SbdError(rc, "sbd_engine_create")
-        self.nlev = self._L.sbd_engine_nlevel(self._h)
+        self.nlev = self._nlevel()
         self.device = device
 
+    def _create(self, cfg) -> int:
+        return self._L.sbd_engine_create(C.byref(cfg), C.byref(self._h))
+
+    def _nlevel(self) -> int:
+        return self._L.sbd_engine_nlevel(self._h)
+
     # ---- lifecycle ----
+    def _destroy(self):
+        self._L.sbd_engine_destroy(self._h)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self._L.sbd_engine_destroy(self._h)
+            self._destroy()
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -189,6 +198,75 @@ class DisortEngine:
         if rc != _lib.OK:
             raise SbdError(rc, "sbd_engine_accumulate_host")
         return acc_flux, acc_uu
+
+
+class DisortFleet(DisortEngine):
+    """One engine per GPU of the node behind one handle (sbd_fleet_*, include/sbdart_amd.h): a
+    batch is cut into contiguous shards, every device solves its shard, and stdout1's weighted
+    sums come back reduced (RCCL over xGMI between distinct devices, host-side otherwise).
+    `devices=None` takes every visible device; a device may be listed twice (test set-ups)."""
+
+    def __init__(self, *args, devices: Optional[Sequence[int]] = None, **kw):
+        self._devices = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+        kw.pop("device", None)
+        super().__init__(*args, **kw)
+
+    def _create(self, cfg) -> int:
+        d = self._devices
+        return self._L.sbd_fleet_create(C.byref(cfg), 0 if d is None else len(d),
+                                        None if d is None else d.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        C.byref(self._h))
+
+    def _nlevel(self) -> int:
+        return self._L.sbd_engine_nlevel(self._L.sbd_fleet_engine(self._h, 0))
+
+    def _destroy(self):
+        self._L.sbd_fleet_destroy(self._h)
+
+    @property
+    def size(self) -> int:
+        return self._L.sbd_fleet_size(self._h)
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self._L.sbd_fleet_uses_rccl(self._h))
+
+    def shard_range(self, nwork: int, rank: int):
+        lo, hi = C.c_int32(), C.c_int32()
+        self._L.sbd_shard_range(nwork, self.size, rank, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, weight=None, items=True):
+        """Host (numpy) batch through every device.  Returns (flux, uu, status) and, when `weight`
+        is given, also (acc_flux[5,nlev], acc_uu or None) = sum_i weight[i] * outputs[i]."""
+        dtauc, ssalb, pmom = _f64(dtauc), _f64(ssalb), _f64(pmom)
+        W = dtauc.shape[0]
+        assert dtauc.shape == (W, self.nlyr) and ssalb.shape == (W, self.nlyr)
+        assert pmom.shape == (W, self.nlyr, self.nmom + 1)
+        lo, hi, fb, al = (_f64(np.broadcast_to(x, (W,))) for x in (wvnmlo, wvnmhi, fbeam, albedo))
+        pl = np.ascontiguousarray(np.broadcast_to(plank, (W,)), dtype=np.uint8)
+        flux = np.zeros((W, _lib.NFLUX, self.nlev)) if items else None
+        uu = None if (self.onlyfl or not items) else np.zeros((W, self.nphi, self.nlev, self.numu))
+        status = np.zeros(W, dtype=np.int32)
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        bi = BatchIn(W, vp(dtauc), vp(ssalb), vp(pmom), vp(lo), vp(hi), vp(fb), vp(al), vp(pl))
+        bo = BatchOut(vp(flux), vp(uu), vp(status))
+        acc_f = acc_u = None
+        if weight is not None:
+            weight = _f64(np.broadcast_to(weight, (W,)))
+            acc_f = np.zeros((_lib.NFLUX, self.nlev))
+            acc_u = None if self.onlyfl else np.zeros((self.nphi, self.nlev, self.numu))
+        rc = self._L.sbd_fleet_solve_host(self._h, C.byref(bi), C.byref(bo), vp(weight), vp(acc_f), vp(acc_u))
+        if rc != _lib.OK:
+            raise SbdError(rc, "sbd_fleet_solve_host")
+        if weight is None:
+            return flux, uu, status
+        return flux, uu, status, acc_f, acc_u
+
+    _solve_device = solve_device = None      # device-pointer entry points belong to single engines
+    accumulate = None
+    chunk = workspace_bytes = stream = None
+    quadrature = enable_timing = last_ms = None
 
 
 def engine_for_record(rec, level_out=None, device=0, max_batch=0, allow_retry_nstr=True):

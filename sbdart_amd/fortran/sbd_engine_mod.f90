@@ -10,11 +10,13 @@ module sbd_engine_mod
   public :: sbd_engine_create, sbd_engine_destroy, sbd_engine_solve_host, &
             sbd_engine_solve_device, sbd_engine_accumulate_host, sbd_engine_nlevel, &
             sbd_engine_chunk, sbd_strerror_f, sbd_last_error_f, sbd_abi_version
+  public :: sbd_fleet_create, sbd_fleet_destroy, sbd_fleet_size, sbd_fleet_uses_rccl, sbd_shard_range, &
+            sbd_fleet_solve_host
   public :: SBD_OK, SBD_E_RETRY_NSTR, SBD_NFLUX, SBD_ABI_VER
   public :: SBD_ST_WARN_SOLVE0, SBD_ST_WARN_UPBEAM, SBD_ST_WARN_UPISOT, SBD_ST_ERR_EIGEN, &
             SBD_ST_RETRY_NSTR, SBD_ST_ERR_INPUT, SBD_ST_WARN_PLKAVG
 
-  integer(c_int), parameter :: SBD_ABI_VER = 1, SBD_OK = 0, SBD_E_RETRY_NSTR = -2, SBD_NFLUX = 5
+  integer(c_int), parameter :: SBD_ABI_VER = 2, SBD_OK = 0, SBD_E_RETRY_NSTR = -2, SBD_NFLUX = 5
   integer(c_int), parameter :: SBD_ST_WARN_SOLVE0 = 1, SBD_ST_WARN_UPBEAM = 2, SBD_ST_WARN_UPISOT = 4, &
        SBD_ST_ERR_EIGEN = 8, SBD_ST_RETRY_NSTR = 16, SBD_ST_ERR_INPUT = 32, SBD_ST_WARN_PLKAVG = 64
 
@@ -64,6 +66,42 @@ module sbd_engine_mod
       import
       type(c_ptr), value :: eng, weight, flux, uu, acc_flux, acc_uu
       integer(c_int32_t), value :: nwork
+      integer(c_int) :: rc
+    end function
+    ! ---- several GPUs from one process: one engine per device, one reduce of the sums ----
+    function sbd_fleet_create(cfg, ndev, devices, fleet) bind(C, name='sbd_fleet_create') result(rc)
+      import
+      type(sbd_run_cfg), intent(in) :: cfg
+      integer(c_int32_t), value :: ndev
+      type(c_ptr), value :: devices            ! int32 device ordinals, or c_null_ptr: every visible device
+      type(c_ptr), intent(out) :: fleet
+      integer(c_int) :: rc
+    end function
+    subroutine sbd_fleet_destroy(fleet) bind(C, name='sbd_fleet_destroy')
+      import
+      type(c_ptr), value :: fleet
+    end subroutine
+    function sbd_fleet_size(fleet) bind(C, name='sbd_fleet_size') result(n)
+      import
+      type(c_ptr), value :: fleet
+      integer(c_int32_t) :: n
+    end function
+    function sbd_fleet_uses_rccl(fleet) bind(C, name='sbd_fleet_uses_rccl') result(n)
+      import
+      type(c_ptr), value :: fleet
+      integer(c_int32_t) :: n
+    end function
+    subroutine sbd_shard_range(nwork, nshard, rank, lo, hi) bind(C, name='sbd_shard_range')
+      import
+      integer(c_int32_t), value :: nwork, nshard, rank
+      integer(c_int32_t), intent(out) :: lo, hi
+    end subroutine
+    function sbd_fleet_solve_host(fleet, bin, bout, weight, acc_flux, acc_uu) &
+         bind(C, name='sbd_fleet_solve_host') result(rc)
+      import
+      type(c_ptr), value :: fleet, weight, acc_flux, acc_uu
+      type(sbd_batch_in), intent(in) :: bin
+      type(sbd_batch_out), intent(in) :: bout
       integer(c_int) :: rc
     end function
     function sbd_engine_nlevel(eng) bind(C, name='sbd_engine_nlevel') result(n)

@@ -1,0 +1,133 @@
+! Files around the engine: the per-work-item optical properties ("SBDREC1", the single definition of
+! the format is sbdart_amd/records.py), the optional atmosphere levels (altitude and pressure, needed by
+! the IOUT formats that print them and by ZOUT), and the reference's warning files.
+module sbd_io_mod
+  use sbd_grid_mod, only: kr
+  implicit none
+  private
+  public :: optics_t, read_optics, read_atmosphere, warn_file, fatal
+
+  type optics_t      ! one (wavelength, k-term) work item as handed to DISORT (drt.f:541-546)
+    integer :: nlyr, nstr, nmom, numu, nphi, flags, kd, nk, iwl
+    real(kr) :: wl, wt, ff, wvnmlo, wvnmhi, fbeam, umu0, phi0, albedo, btemp, ttemp, temis, fisot
+    real(kr), allocatable :: dtauc(:), ssalb(:), temper(:), pmom(:,:), umu(:), phi(:)
+  end type
+
+contains
+
+  subroutine fatal(msg)
+    character(len=*), intent(in) :: msg
+    write(0, '(a)') 'sbdart_amd: '//msg
+    stop 1
+  end subroutine
+
+  subroutine read_optics(path, recs, nrec)
+    character(len=*), intent(in) :: path
+    type(optics_t), allocatable, intent(out) :: recs(:)
+    integer, intent(out) :: nrec
+    character(len=8) :: magic
+    integer :: hdr(12), ohdr(4), has_out, nmax, ios, i, u
+    real(kr) :: sc(16)
+    real(kr), allocatable :: skip(:)
+    type(optics_t) :: r
+    type(optics_t), allocatable :: tmp(:)
+    open(newunit=u, file=path, access='stream', form='unformatted', status='old', iostat=ios)
+    if (ios /= 0) then
+      write(0, '(a)') 'sbdart_amd: cannot open optics file '//trim(path)
+      stop 2
+    end if
+    read(u) magic, nmax, has_out
+    if (magic(1:7) /= 'SBDREC1') stop 'sbdart_amd: optics file is not SBDREC1'
+    if (nmax < 0) nmax = huge(1)
+    allocate(recs(256))
+    nrec = 0
+    do i = 1, nmax
+      read(u, iostat=ios) hdr, sc
+      if (ios /= 0) exit
+      r%nlyr = hdr(1); r%nstr = hdr(2); r%nmom = hdr(3); r%numu = hdr(4); r%nphi = hdr(5)
+      r%flags = hdr(6); r%kd = hdr(7); r%nk = hdr(8); r%iwl = hdr(9)
+      r%wl = sc(1); r%wt = sc(2); r%ff = sc(3); r%wvnmlo = sc(4); r%wvnmhi = sc(5); r%fbeam = sc(6)
+      r%umu0 = sc(7); r%phi0 = sc(8); r%albedo = sc(9); r%btemp = sc(10); r%ttemp = sc(11)
+      r%temis = sc(12); r%fisot = sc(13)
+      if (allocated(r%dtauc)) deallocate(r%dtauc, r%ssalb, r%temper, r%pmom, r%umu, r%phi)
+      allocate(r%dtauc(r%nlyr), r%ssalb(r%nlyr), r%temper(0:r%nlyr), r%pmom(0:r%nmom, r%nlyr), &
+               r%umu(r%numu), r%phi(r%nphi))
+      read(u) r%dtauc, r%ssalb, r%temper, r%pmom, r%umu, r%phi
+      if (has_out /= 0) then       ! reference outputs, if present, are ignored by the host
+        read(u) ohdr
+        allocate(skip(5*ohdr(2)))
+        read(u) skip
+        deallocate(skip)
+        if (iand(r%flags, 2) == 0) then
+          allocate(skip(ohdr(3)*ohdr(2)*r%nphi))
+          read(u) skip
+          deallocate(skip)
+        end if
+      end if
+      nrec = nrec + 1
+      if (nrec > size(recs)) then
+        allocate(tmp(2*size(recs)))
+        tmp(1:nrec - 1) = recs(1:nrec - 1)
+        call move_alloc(tmp, recs)
+      end if
+      recs(nrec) = r
+    end do
+    close(u)
+  end subroutine
+
+  ! Atmosphere levels, text: first line nz, then nz lines "z[km] p[mb]" from the SURFACE upwards
+  ! (z(1) is the bottom, like the reference's profile arrays).  found = .false. when there is no file.
+  subroutine read_atmosphere(path, nz, z, p, found)
+    character(len=*), intent(in) :: path
+    integer, intent(in) :: nz
+    real(kr), intent(out) :: z(nz), p(nz)
+    logical, intent(out) :: found
+    integer :: u, ios, n, i
+    found = .false.
+    z = 0; p = 0
+    open(newunit=u, file=path, status='old', form='formatted', iostat=ios)
+    if (ios /= 0) return
+    read(u, *, iostat=ios) n
+    if (ios /= 0 .or. n /= nz) call fatal('atmosphere file '//trim(path)//' does not hold NZ levels of this run')
+    do i = 1, nz
+      read(u, *, iostat=ios) z(i), p(i)
+      if (ios /= 0) call fatal('atmosphere file '//trim(path)//' is truncated')
+    end do
+    close(u)
+    found = .true.
+  end subroutine
+
+  ! errmsg (disutil.f:278-325): message + copy of INPUT into SBDART_WARNING.NN, once per number;
+  ! number 0 is fatal
+  subroutine warn_file(msgnum, messag)
+    integer, intent(in) :: msgnum
+    character(len=*), intent(in) :: messag
+    logical, save :: issued(0:20) = .false.
+    character(len=2) :: num
+    character(len=132) :: line
+    integer :: u, v, ios
+    if (msgnum > 0) then
+      if (issued(msgnum)) return
+      line = 'WARNING >>>>>'
+    else
+      line = 'ERROR  >>>>>>'
+    end if
+    write(num, '(i2.2)') msgnum
+    open(newunit=u, file='SBDART_WARNING.'//num, status='unknown', form='formatted')
+    write(u, '(a,1x,a)') trim(line), messag
+    write(u, '(/70("#")/)')
+    open(newunit=v, file='INPUT', status='old', iostat=ios)
+    if (ios == 0) then
+      do
+        read(v, '(a)', iostat=ios) line
+        if (ios /= 0) exit
+        write(u, '(a)') trim(line)
+      end do
+      close(v)
+    end if
+    close(u)
+    if (msgnum == 0) stop
+    issued(msgnum) = .true.
+  end subroutine
+
+end module sbd_io_mod

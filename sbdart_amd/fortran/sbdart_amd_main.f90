@@ -4,9 +4,10 @@
 ! &INPUT [&DINPUT], same variable names), writes the IOUT-specific text to stdout
 ! (drt.f:892-1165), writes SBDART_WARNING.NN files (disutil.f:278-325).  The wavelength
 ! loop itself (drt.f:425-561) is restructured for the GPU: all (wavelength, k-term) work
-! items are assembled first, solved in ONE batched call through the C ABI
-! (sbd_engine_solve_host -> HIP kernels), and stdout1's accumulation then walks the
-! results in the reference's order.
+! items are assembled first and solved in ONE batched call through the C ABI
+! (sbd_fleet_solve_host: the batch is sharded over every visible GPU, HIP kernels per shard);
+! the per-run output formats take stdout1's weighted sums from the engine's reduction (one
+! RCCL reduce between GPUs), the per-wavelength formats sum the <= 3 k-terms of a point here.
 !
 ! Scope note (SURVEY.md 8f N1): the band model that turns &INPUT into per-wavelength
 ! optical depths (taugas/tauaero/taucloud/spectra/atms) is not part of this round; the
@@ -17,23 +18,25 @@
 program sbdart_amd
   use iso_c_binding
   use sbd_engine_mod
-  use sbd_host_mod
+  use sbd_grid_mod
+  use sbd_io_mod
+  use sbd_output_mod
   implicit none
   integer, parameter :: ncldz = 5, naerz = 5, naerb = 150, maxmom = 299, ndb = 20
   ! ---- &INPUT / &DINPUT (drt.f:200-215), same names, same defaults where they matter ----
   integer :: idatm = 4, isat = 0, nf = 2, iday = 0, isalb = 0, krhclr = 0, jaer(naerz) = 0, iaer = 0, &
              nothrm = -1, nosct = 0, kdist = 3, ngrid = 0, idb(ndb) = 0, iout = 10, nstr = 0, nzen = 0, &
              nphi = 0, imomc = 3, imoma = 3, ibcnd = 0, ipth = 0
-  real(kr) :: amix = zip, wlinf = real(.55, kr), wlsup = real(.55, kr), wlinc = 0, sza = 0, csza = zip, solfac = 1, &
-       time = 16, alat = real(-64.767, kr), alon = real(-64.067, kr), zpres = zip, pbar = zip, sclh2o = zip, &
-       uw = zip, uo3 = zip, o3trp = zip, ztrp = 0, xrsc = 1, xn2 = zip, xo2 = zip, xco2 = zip, xch4 = zip, &
-       xn2o = zip, xco = zip, xno2 = zip, xso2 = zip, xnh3 = zip, xno = zip, xhno3 = zip, xo4 = 1, &
+  real(kr) :: amix = unset, wlinf = real(.55, kr), wlsup = real(.55, kr), wlinc = 0, sza = 0, csza = unset, solfac = 1, &
+       time = 16, alat = real(-64.767, kr), alon = real(-64.067, kr), zpres = unset, pbar = unset, sclh2o = unset, &
+       uw = unset, uo3 = unset, o3trp = unset, ztrp = 0, xrsc = 1, xn2 = unset, xo2 = unset, xco2 = unset, xch4 = unset, &
+       xn2o = unset, xco = unset, xno2 = unset, xso2 = unset, xnh3 = unset, xno = unset, xhno3 = unset, xo4 = 1, &
        albcon = 0, sc(5) = huge(0.), zcloud(ncldz) = 0, tcloud(ncldz) = 0, lwp(ncldz) = 0, nre(ncldz) = 8, &
-       rhcld = zip, zaer(naerz) = 0, taerst(naerz) = 0, vis = zip, rhaer = zip, tbaer = zip, &
-       wlbaer(naerb) = zip, qbaer(naerb) = zip, abaer = 0, wbaer(naerb) = zip, gbaer(naerb) = zip, &
-       pmaer(naerb*maxmom) = zip, zbaer(mxly) = zip, dbaer(mxly) = zip, zgrid1 = 1, zgrid2 = 30, &
-       zout(2) = (/0._kr, 100._kr/), temis = 0, uzen(nstrms) = zip, vzen(nstrms) = 90, phi(nstrms) = zip, &
-       saza = 180, ttemp = zip, btemp = zip, phi0 = 0, fisot = 0
+       rhcld = unset, zaer(naerz) = 0, taerst(naerz) = 0, vis = unset, rhaer = unset, tbaer = unset, &
+       wlbaer(naerb) = unset, qbaer(naerb) = unset, abaer = 0, wbaer(naerb) = unset, gbaer(naerb) = unset, &
+       pmaer(naerb*maxmom) = unset, zbaer(mxly) = unset, dbaer(mxly) = unset, zgrid1 = 1, zgrid2 = 30, &
+       zout(2) = (/0._kr, 100._kr/), temis = 0, uzen(nstrms) = unset, vzen(nstrms) = 90, phi(nstrms) = unset, &
+       saza = 180, ttemp = unset, btemp = unset, phi0 = 0, fisot = 0
   logical :: prnt(7) = .false., corint = .false., spowder = .false.
   namelist /input/ idatm, amix, isat, wlinf, wlsup, wlinc, sza, csza, solfac, nf, iday, time, alat, alon, &
        zpres, pbar, sclh2o, uw, uo3, o3trp, ztrp, xrsc, xn2, xo2, xco2, xch4, xn2o, xco, xno2, xso2, xnh3, &
@@ -44,21 +47,21 @@ program sbdart_amd
   namelist /dinput/ ibcnd, phi0, prnt, ipth, fisot, temis, nstr, nzen, uzen, vzen, nphi, phi, ttemp, btemp
 
   type(optics_t), allocatable :: recs(:)
-  integer :: nrec, ios, i, j, k, nz, nwl, il, nstrsv, nmom, numu, ntry, lev_top, lev_bot, nlev, u11
-  logical :: radcalc, onlyfl, all_levels
-  character(len=1024) :: optics_path
+  type(spectral_grid) :: grid
+  type(view_geometry) :: view
+  type(iout_format) :: fmt
+  type(spectral_sums) :: sums
+  integer :: nrec, ios, i, j, nz, nmom, numu, lev_top, lev_bot, nlev, u11, ntop, nbot, i0, i1, nbeam, npart, ip
+  logical :: radcalc, known, have_atm, default_zout
+  character(len=1024) :: path
   integer :: plen, pstat
-  real(kr) :: wlinc_eff, wl, wvlo, wvhi, dwl
+  real(kr) :: wl, wvlo, wvhi, dwl
   real(kr), allocatable, target :: dtauc(:,:), ssalb(:,:), pmom(:,:,:), wvnmlo(:), wvnmhi(:), fbeam(:), &
-       albedo(:), flux(:,:,:), uu(:,:,:,:), temper(:), umu(:), phiv(:)
+       albedo(:), flux(:,:,:), uu(:,:,:,:), temper(:), umu(:), phiv(:), weight(:), acc_flux(:,:), acc_uu(:,:,:)
   integer(c_int8_t), allocatable, target :: plank(:)
   integer(c_int32_t), allocatable, target :: status(:), level_out(:)
-  real(kr), allocatable :: zlev(:), uur(:,:,:), rfldir(:), rfldn(:), flup(:)
-  type(sbd_run_cfg) :: cfg
-  type(sbd_batch_in) :: bin
-  type(sbd_batch_out) :: bout
-  type(c_ptr) :: eng
-  integer(c_int) :: rc
+  integer, allocatable :: order(:)
+  real(kr), allocatable :: zlev(:), plev(:)
   integer :: stall
 
   ! ---- read ./INPUT exactly like drt.f:220-231 ----
@@ -73,147 +76,124 @@ program sbdart_amd
     stop
   end if
 
-  radcalc = any(iout == (/5, 6, 20, 21, 22, 23/))      ! drt.f:237-247
-  onlyfl = .not. radcalc
-  if (nstr == 0) then
-    if (radcalc) then
-      nstr = min(20, nstrms)
-    else
-      nstr = 4
-    end if
-  end if
-  if (radcalc) call view_angles(nphi, phi, nzen, uzen, vzen, iout, nstr)
-  if (iout == 22) call fatal('iout=22 (radiance at every level) is not wired in this host yet')
+  fmt = find_format(iout, known)
+  if (.not. known) call fatal('this IOUT is not an output format of the hot path (1,5,6,7,10,11,20,21,22,23)')
+  radcalc = fmt%radiance /= rad_none                    ! drt.f:237-247
+  if (nstr == 0) nstr = merge(min(20, nstrms), 4, radcalc)
+  if (radcalc) view = new_view(iout, nphi, phi, nzen, uzen, vzen)
   phi0 = mod(saza - 180.0_kr + 360.0_kr, 360.0_kr)      ! drt.f:283
 
   ! ---- per-work-item optical properties (stand-in for gasset/taucloud/tauaero/rayleigh) ----
-  call get_environment_variable('SBD_OPTICS', optics_path, plen, pstat)
-  if (pstat /= 0 .or. plen <= 0) optics_path = 'OPTICS.sbdrec'
-  call read_optics(trim(optics_path), recs, nrec)
+  call get_environment_variable('SBD_OPTICS', path, plen, pstat)
+  if (pstat /= 0 .or. plen <= 0) path = 'OPTICS.sbdrec'
+  call read_optics(trim(path), recs, nrec)
   if (nrec < 1) call fatal('optics file holds no work items')
   nz = recs(1)%nlyr
   nmom = recs(1)%nmom
-  nstrsv = nstr
+  allocate(zlev(nz), plev(nz))
+  call get_environment_variable('SBD_ATMOS', path, plen, pstat)
+  if (pstat /= 0 .or. plen <= 0) path = 'ATMOS.sbdatm'
+  call read_atmosphere(trim(path), nz, zlev, plev, have_atm)
 
-  ! spectral grid size printed by stdout0 (setfilt, spectra.f:3370-3384; isat=0: wlmin=wlinf)
-  wlinc_eff = wlinc
-  nwl = grid_size(wlinf, wlsup, wlinc_eff)
-  ! cross-check the band edges of the optics against wllimits (drt.f:1657-1740)
+  ! the spectral grid of INPUT must be the one the optics were made for (wllimits, drt.f:1657-1740)
+  grid = new_grid(wlinf, wlsup, wlinc)
   do i = 1, nrec
-    il = recs(i)%iwl - 1
-    if (il < 0 .or. il >= nwl) call fatal('optics record outside the spectral grid of INPUT')
-    call wl_limits(il, nwl, wlinc_eff, wlinf, wlsup, wl, wvlo, wvhi)
+    if (recs(i)%iwl < 1 .or. recs(i)%iwl > grid%n) call fatal('optics record outside the spectral grid of INPUT')
+    call grid%band(recs(i)%iwl - 1, wl, wvlo, wvhi)
     if (abs(wl - recs(i)%wl) > 1e-12_kr*wl .or. abs(wvlo - recs(i)%wvnmlo) > 1e-9_kr*wvlo .or. &
         abs(wvhi - recs(i)%wvnmhi) > 1e-9_kr*wvhi) call fatal('optics record disagrees with the wavelength grid of INPUT')
+    if (recs(i)%nlyr /= nz .or. recs(i)%nmom /= nmom) call fatal('optics records differ in NLYR/NMOM')
   end do
 
-  ! ---- batch arrays (row-major by work item == Fortran's first index fastest) ----
-  allocate(dtauc(nz, nrec), ssalb(nz, nrec), pmom(0:nmom, nz, nrec), wvnmlo(nrec), wvnmhi(nrec), &
-           fbeam(nrec), albedo(nrec), plank(nrec), status(nrec), temper(0:nz))
+  ! ---- output levels: the computational levels nearest to ZOUT (drt.f:368-381); level 1 = top ----
+  default_zout = zout(1) == 0._kr .and. zout(2) == 100._kr
+  if (have_atm) then
+    nbot = nz - nearest_level(zlev, abs(zout(1))) + 2
+    ntop = nz - nearest_level(zlev, abs(zout(2))) + 2
+    if (ntop == 2) ntop = 1
+  else
+    if (.not. default_zout) call fatal('ZOUT needs the level altitudes: no atmosphere file (SBD_ATMOS / ATMOS.sbdatm)')
+    if (fmt%code == 7 .or. fmt%code == 11 .or. fmt%code == 22) &
+      call fatal('this IOUT prints altitudes/pressures: no atmosphere file (SBD_ATMOS / ATMOS.sbdatm)')
+    ntop = 1; nbot = nz + 1
+  end if
+  if (fmt%profile .or. fmt%radiance == rad_levels) then
+    nlev = nz + 1
+    allocate(level_out(nlev))
+    level_out = (/(i - 1, i = 1, nlev)/)
+    lev_top = ntop; lev_bot = nbot
+  else
+    nlev = 2
+    allocate(level_out(2))
+    level_out = (/ntop - 1, nbot - 1/)
+    lev_top = 1; lev_bot = 2
+  end if
+
+  numu = 0
+  if (radcalc) then                                   ! drt.f:391-403: ascending cosines, never exactly 0
+    numu = view%nzen
+    allocate(umu(numu), phiv(view%nphi))
+    do j = 1, numu
+      umu(j) = min(1._kr, max(cos(view%uzen(numu + 1 - j)*(real(3.1415926536d0, kr)/180._kr)), -1._kr))
+      if (umu(j) == 0._kr) umu(j) = merge(-real(.0001, kr), real(.0001, kr), j == numu)
+    end do
+    phiv = view%phi(1:view%nphi)
+  else
+    allocate(umu(1), phiv(1))
+  end if
+
+  ! ---- batch arrays (row-major by work item == Fortran's first index fastest).  Items the filter
+  !      function removes (ff = 0) are not solved (drt.f:461-462); items with a beam come first so
+  !      that an NSTR retry (below) re-solves one contiguous part ----
+  allocate(order(nrec))
+  nbeam = 0
   do i = 1, nrec
-    if (recs(i)%nlyr /= nz .or. recs(i)%nmom /= nmom) call fatal('optics records differ in NLYR/NMOM')
-    dtauc(:, i) = recs(i)%dtauc
-    ssalb(:, i) = recs(i)%ssalb
-    pmom(:, :, i) = recs(i)%pmom
-    wvnmlo(i) = recs(i)%wvnmlo; wvnmhi(i) = recs(i)%wvnmhi
-    fbeam(i) = recs(i)%fbeam; albedo(i) = recs(i)%albedo
-    plank(i) = int(iand(recs(i)%flags, 1), c_int8_t)
+    if (recs(i)%ff /= 0._kr .and. recs(i)%fbeam > 0._kr) then
+      nbeam = nbeam + 1
+      order(nbeam) = i
+    end if
+  end do
+  npart = nbeam
+  do i = 1, nrec
+    if (recs(i)%ff /= 0._kr .and. .not. recs(i)%fbeam > 0._kr) then
+      npart = npart + 1
+      order(npart) = i
+    end if
+  end do
+  allocate(dtauc(nz, nrec), ssalb(nz, nrec), pmom(0:nmom, nz, nrec), wvnmlo(nrec), wvnmhi(nrec), &
+           fbeam(nrec), albedo(nrec), plank(nrec), status(nrec), weight(nrec), temper(0:nz))
+  status = 0
+  do ip = 1, npart
+    i = order(ip)
+    dtauc(:, ip) = recs(i)%dtauc
+    ssalb(:, ip) = recs(i)%ssalb
+    pmom(:, :, ip) = recs(i)%pmom
+    wvnmlo(ip) = recs(i)%wvnmlo; wvnmhi(ip) = recs(i)%wvnmhi
+    fbeam(ip) = recs(i)%fbeam; albedo(ip) = recs(i)%albedo
+    plank(ip) = int(iand(recs(i)%flags, 1), c_int8_t)
+    weight(ip) = recs(i)%wt*recs(i)%ff                 ! dwt of stdout1 (drt.f:964)
   end do
   temper = recs(1)%temper
   if (btemp < 0._kr) btemp = recs(1)%btemp          ! drt.f:334-335 defaults come with the profile
   if (ttemp < 0._kr) ttemp = recs(1)%ttemp
 
-  ! output levels: ntop = 1 (TOA), nbot = nz+1 (surface) for zout = 0,100 (drt.f:376-381)
-  all_levels = (iout == 7 .or. iout == 11)
-  if (all_levels) then
-    nlev = nz + 1
-    lev_top = 1; lev_bot = nz + 1
-    allocate(level_out(nlev))
-    level_out = (/(i - 1, i = 1, nlev)/)
-  else
-    nlev = 2
-    lev_top = 1; lev_bot = 2
-    allocate(level_out(2))
-    level_out = (/0, nz/)
-  end if
-
-  numu = 0
-  if (radcalc) then                                   ! drt.f:391-403
-    numu = nzen
-    allocate(umu(numu), phiv(nphi))
-    do j = 1, numu
-      umu(j) = min(1._kr, max(cos(uzen(numu + 1 - j)*(real(3.1415926536d0, kr)/180._kr)), -1._kr))
-      if (umu(j) == 0._kr) then
-        if (j == numu) then
-          umu(j) = -real(.0001, kr)
-        else
-          umu(j) = real(.0001, kr)
-        end if
-      end if
-    end do
-    phiv = phi(1:nphi)
-    allocate(uurs(max(nzen, 1), max(nphi, 1)))
-    uurs = 0
-  else
-    allocate(umu(1), phiv(1))
-  end if
-  allocate(fxdn(nz), fxup(nz), fxdir(nz))
-  fxdn = 0; fxup = 0; fxdir = 0
-
-  ! ---- engine, with the reference's NSTR "dithering" retry (drt.f:536-555) ----
-  eng = c_null_ptr
-  do ntry = 0, 2
-    nstr = nstrsv + ntry*(3*ntry - 5)
-    if (nstr < 4) cycle
-    if (nstr > nstrms) exit
-    cfg%abi_version = SBD_ABI_VER
-    cfg%nlyr = nz; cfg%nstr = nstr; cfg%nmom = nmom
-    cfg%onlyfl = merge(1, 0, onlyfl); cfg%lamber = 1; cfg%usrang = merge(1, 0, radcalc)
-    cfg%numu = numu; cfg%nphi = merge(nphi, 0, radcalc)
-    cfg%nlevel_out = nlev; cfg%device = 0; cfg%max_batch = nrec
-    cfg%umu0 = recs(1)%umu0; cfg%phi0 = phi0; cfg%fisot = fisot
-    cfg%btemp = btemp; cfg%ttemp = ttemp; cfg%temis = temis
-    cfg%temper = c_loc(temper); cfg%umu = c_loc(umu); cfg%phi = c_loc(phiv)
-    cfg%level_out = c_loc(level_out)
-    rc = sbd_engine_create(cfg, eng)
-    if (rc == SBD_OK) exit
-    if (rc == SBD_E_RETRY_NSTR) then
-      call warn_file(1, 'SETDIS--beam angle=computational angle; change NSTR')
-      if (any(fbeam > 0._kr)) then
-        call sbd_engine_destroy(eng)
-        eng = c_null_ptr
-        cycle
-      end if
-      exit
-    end if
-    call fatal('sbd_engine_create: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
-  end do
-  if (.not. c_associated(eng)) then
-    write(*, *) 'Error --- NSTR dithering procedure failed'
-    stop
-  end if
-
-  allocate(flux(nlev, SBD_NFLUX, nrec))
+  allocate(flux(nlev, SBD_NFLUX, nrec), acc_flux(nlev, SBD_NFLUX))
   if (radcalc) then
-    allocate(uu(numu, nlev, nphi, nrec))
+    allocate(uu(numu, nlev, view%nphi, nrec), acc_uu(numu, nlev, view%nphi))
   else
-    allocate(uu(1, 1, 1, 1))
+    allocate(uu(1, 1, 1, 1), acc_uu(1, 1, 1))
   end if
-  bin%nwork = nrec
-  bin%dtauc = c_loc(dtauc); bin%ssalb = c_loc(ssalb); bin%pmom = c_loc(pmom)
-  bin%wvnmlo = c_loc(wvnmlo); bin%wvnmhi = c_loc(wvnmhi); bin%fbeam = c_loc(fbeam)
-  bin%albedo = c_loc(albedo); bin%plank = c_loc(plank)
-  bout%flux = c_loc(flux); bout%status = c_loc(status)
-  bout%uu = c_null_ptr
-  if (radcalc) bout%uu = c_loc(uu)
+  flux = 0; uu = 0; acc_flux = 0; acc_uu = 0
 
-  ! the wavelength loop, one batched call (filter ff = 0 items are solved too; their weight is 0)
-  rc = sbd_engine_solve_host(eng, bin, bout)
-  if (rc /= SBD_OK) call fatal('sbd_engine_solve_host: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
+  ! ---- the wavelength loop: the beam items with the reference's NSTR "dithering" (a beam angle that
+  !      coincides with a quadrature angle makes DISORT ask for another stream count, drt.f:536-555),
+  !      the beamless items with the stream count as given ----
+  call solve_part(1, nbeam, .true.)
+  call solve_part(nbeam + 1, npart, .false.)
 
   ! ---- warnings / fatals the reference raises through errmsg ----
   stall = 0
-  do i = 1, nrec
+  do i = 1, npart
     stall = ior(stall, status(i))
   end do
   if (iand(stall, SBD_ST_ERR_INPUT) /= 0) call warn_file(0, 'DISORT--input and/or dimension errors')
@@ -222,7 +202,7 @@ program sbdart_amd
   if (iand(stall, SBD_ST_WARN_UPBEAM) /= 0) call warn_file(3, 'UPBEAM--SGECO says matrix near singular')
   if (iand(stall, SBD_ST_WARN_UPISOT) /= 0) call warn_file(4, 'UPISOT--SGECO says matrix near singular')
   if (iand(stall, SBD_ST_WARN_PLKAVG) /= 0) call warn_file(10, 'PLKAVG--returns zero; possible underflow')
-  if (any(plank /= 0)) then                         ! CHEKIN warning 6 (disort.f:5145-5152)
+  if (any(plank(1:npart) /= 0)) then                ! CHEKIN warning 6 (disort.f:5145-5152)
     do i = 1, nz
       if (abs(temper(i) - temper(i - 1)) > 10._kr) then
         call warn_file(6, 'CHEKIN--vertical temperature step may be too large for good accuracy')
@@ -230,32 +210,127 @@ program sbdart_amd
       end if
     end do
   end if
-  if (radcalc .and. any(fbeam > 0._kr)) &          ! CHEKIN warning 7 (disort.f:5154-5158)
+  if (radcalc .and. nbeam > 0) &                    ! CHEKIN warning 7 (disort.f:5154-5158)
     call warn_file(7, 'CHEKIN--intensity correction is off; intensities may be less accurate')
 
-  ! ---- stdout0 / stdout1 / stdout2 in the reference's order ----
-  allocate(zlev(nz), rfldir(nlev), rfldn(nlev), flup(nlev))
-  zlev = 0
-  if (radcalc) then
-    allocate(uur(numu, nlev, nphi))
+  ! ---- output ----
+  call sums_init(sums, fmt, nz, view%nzen, view%nphi)
+  call write_banner(fmt, grid%n, nz)
+  if (fmt%per_point) then
+    ! one record per spectral point: the k-terms of a point are consecutive records (kd = 1..nk)
+    i0 = 1
+    do while (i0 <= nrec)
+      i1 = i0
+      do while (i1 < nrec)
+        if (recs(i1 + 1)%iwl /= recs(i0)%iwl) exit
+        i1 = i1 + 1
+      end do
+      call sums_clear(sums)
+      do i = i0, i1
+        ip = position_of(i)
+        if (ip > 0) call sums_add_item(sums, fmt, weight(ip), flux(:, 1:3, ip), lev_top, lev_bot, &
+                                       uu(:, :, :, merge(ip, 1, radcalc)), view%uzen)
+      end do
+      dwl = 10000._kr/recs(i0)%wvnmlo - 10000._kr/recs(i0)%wvnmhi      ! drt.f:438
+      sums%width_eq = dwl*recs(i1)%ff
+      sums%width_full = dwl
+      call write_point_record(sums, fmt, recs(i0)%wl, zlev, view%phi, view%uzen)
+      i0 = i1 + 1
+    end do
   else
-    allocate(uur(1, 1, 1))
+    ! one record per run: the engine's reduced sums; the equivalent width from the last k-term of each point
+    call sums_from_engine(sums, fmt, acc_flux, acc_uu, lev_top, lev_bot, view%uzen)
+    do i = 1, nrec
+      if (recs(i)%kd == recs(i)%nk) then
+        dwl = 10000._kr/recs(i)%wvnmlo - 10000._kr/recs(i)%wvnmhi
+        sums%width_eq = sums%width_eq + dwl*recs(i)%ff
+      end if
+    end do
+    call write_run_record(sums, fmt, wlinf, wlsup, zlev, plev, view%phi, view%uzen)
   end if
-  call stdout0(iout, nwl, nz)
-  do i = 1, nrec
-    dwl = 10000._kr/wvnmlo(i) - 10000._kr/wvnmhi(i)      ! drt.f:438
-    rfldir = flux(:, 1, i); rfldn = flux(:, 2, i); flup = flux(:, 3, i)
-    if (radcalc) uur = uu(:, :, :, i)
-    call stdout1(nz, zlev, lev_top, lev_bot, iout, recs(i)%wl, dwl, recs(i)%wt, rfldir, rfldn, flup, &
-                 recs(i)%ff, nphi, nzen, phi, uzen, uur, lev_top, lev_bot, recs(i)%kd, recs(i)%nk)
-  end do
-  call stdout2(iout, wlinf, wlsup, nphi, nzen, phi, uzen)
-  call sbd_engine_destroy(eng)
+  call get_environment_variable('SBD_SUMS_FILE', path, plen, pstat)   ! full-precision sums for parity tests
+  if (pstat == 0 .and. plen > 0) then
+    open(newunit=u11, file=trim(path), status='replace', form='formatted')
+    write(u11, '(6es25.16)') sums%down(1), sums%up(1), sums%direct(1), sums%down(2), sums%up(2), sums%direct(2)
+    close(u11)
+  end if
 
 contains
-  subroutine fatal(msg)
-    character(len=*), intent(in) :: msg
-    write(0, '(a)') 'sbdart_amd: '//msg
-    stop 1
+
+  ! index of the level nearest to altitude zq in the bottom-up altitudes (ties: the lower level)
+  integer function nearest_level(z, zq) result(k)
+    real(kr), intent(in) :: z(:), zq
+    integer :: m(1)
+    m = minloc(abs(z - zq))
+    k = m(1)
+  end function
+
+  integer function position_of(irec) result(ip)       ! batch position of record irec, 0 = not solved
+    integer, intent(in) :: irec
+    integer :: q
+    ip = 0
+    do q = 1, npart
+      if (order(q) == irec) then
+        ip = q
+        return
+      end if
+    end do
+  end function
+
+  ! solve batch positions p0..p1 on every visible GPU; per-run formats also get their weighted sums
+  subroutine solve_part(p0, p1, beam)
+    integer, intent(in) :: p0, p1
+    logical, intent(in) :: beam
+    type(sbd_run_cfg) :: cfg
+    type(sbd_batch_in) :: bin
+    type(sbd_batch_out) :: bout
+    type(c_ptr) :: fleet, wptr, aptr, uptr
+    integer(c_int) :: rc
+    integer :: ntry, ns
+    if (p1 < p0) return
+    fleet = c_null_ptr
+    do ntry = 0, 2
+      ns = nstr + ntry*(3*ntry - 5)                    ! nstr, nstr-2, nstr+2
+      if (ns < 4) cycle
+      if (ns > nstrms) exit
+      cfg%abi_version = SBD_ABI_VER
+      cfg%nlyr = nz; cfg%nstr = ns; cfg%nmom = nmom
+      cfg%onlyfl = merge(0, 1, radcalc); cfg%lamber = 1; cfg%usrang = merge(1, 0, radcalc)
+      cfg%numu = numu; cfg%nphi = merge(view%nphi, 0, radcalc)
+      cfg%nlevel_out = nlev; cfg%device = 0; cfg%max_batch = p1 - p0 + 1
+      cfg%umu0 = recs(1)%umu0; cfg%phi0 = phi0; cfg%fisot = fisot
+      cfg%btemp = btemp; cfg%ttemp = ttemp; cfg%temis = temis
+      cfg%temper = c_loc(temper); cfg%umu = c_loc(umu); cfg%phi = c_loc(phiv)
+      cfg%level_out = c_loc(level_out)
+      rc = sbd_fleet_create(cfg, 0, c_null_ptr, fleet)
+      if (rc == SBD_OK) exit
+      if (rc == SBD_E_RETRY_NSTR) then
+        call warn_file(1, 'SETDIS--beam angle=computational angle; change NSTR')
+        if (.not. beam) exit                           ! without a beam the angle does not matter
+        call sbd_fleet_destroy(fleet)
+        fleet = c_null_ptr
+        cycle
+      end if
+      call fatal('sbd_fleet_create: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
+    end do
+    if (.not. c_associated(fleet)) then
+      write(*, *) 'Error --- NSTR dithering procedure failed'
+      stop
+    end if
+    bin%nwork = p1 - p0 + 1
+    bin%dtauc = c_loc(dtauc(1, p0)); bin%ssalb = c_loc(ssalb(1, p0)); bin%pmom = c_loc(pmom(0, 1, p0))
+    bin%wvnmlo = c_loc(wvnmlo(p0)); bin%wvnmhi = c_loc(wvnmhi(p0)); bin%fbeam = c_loc(fbeam(p0))
+    bin%albedo = c_loc(albedo(p0)); bin%plank = c_loc(plank(p0))
+    bout%flux = c_loc(flux(1, 1, p0)); bout%status = c_loc(status(p0))
+    bout%uu = c_null_ptr
+    if (radcalc) bout%uu = c_loc(uu(1, 1, 1, p0))
+    wptr = c_null_ptr; aptr = c_null_ptr; uptr = c_null_ptr
+    if (.not. fmt%per_point) then
+      wptr = c_loc(weight(p0)); aptr = c_loc(acc_flux)
+      if (radcalc) uptr = c_loc(acc_uu)
+    end if
+    rc = sbd_fleet_solve_host(fleet, bin, bout, wptr, aptr, uptr)
+    if (rc /= SBD_OK) call fatal('sbd_fleet_solve_host: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
+    call sbd_fleet_destroy(fleet)
   end subroutine
 end program sbdart_amd

@@ -10,12 +10,13 @@ from typing import Tuple
 
 
 def shard_range(nwl: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous block [lo, hi) of spectral-point indices owned by `rank`:
-    ceil(nwl/world)-sized blocks, the last ones possibly shorter or empty."""
-    per = (nwl + world - 1) // world
-    lo = min(nwl, rank * per)
-    hi = min(nwl, lo + per)
-    return lo, hi
+    """Contiguous block [lo, hi) of spectral-point (or work-item) indices owned by `rank`:
+    balanced blocks, the first nwl % world one longer.  Same rule as the C ABI's sbd_shard_range
+    (include/sbdart_amd.h), which the fleet and the Fortran host use; tests pin the two together."""
+    world = max(1, world)
+    base, extra = divmod(nwl, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
 
 
 def reduce_accumulators(acc, dst: int = 0, group=None):

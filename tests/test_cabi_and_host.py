@@ -60,10 +60,21 @@ def test_workload_is_seeded_and_physical():
 
 
 def test_shard_range_partitions():
+    """The C ABI's sbd_shard_range (what the fleet and the Fortran host shard with; pure host code,
+    callable without a GPU) and its Python mirror: the same balanced contiguous blocks."""
+    import ctypes as C
+    from sbdart_amd import _lib
     from sbdart_amd.shard import shard_range
-    for nwl in (0, 1, 7, 751, 49152):
+    L = _lib.load()
+    lo, hi = C.c_int32(), C.c_int32()
+    for nwl in (0, 1, 7, 751, 49152, 131254):
         for world in (1, 2, 3, 8):
             parts = [shard_range(nwl, r, world) for r in range(world)]
             assert parts[0][0] == 0 and parts[-1][1] == nwl
             for (a0, a1), (b0, b1) in zip(parts, parts[1:]):
                 assert a1 == b0 and a0 <= a1
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+            for r in range(world):
+                L.sbd_shard_range(nwl, world, r, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == parts[r]

@@ -10,6 +10,7 @@ precision.
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -63,18 +64,48 @@ def _tokens(text):
     return out
 
 
-def _compare_stdout(got, want):
-    """SURVEY.md section 4 rule: equal after rounding to 5 significant digits, with an
-    absolute floor (1e-6 x the largest magnitude of the file) for analytically-zero fields."""
-    g, w = _tokens(got), _tokens(want)
+def _unit_of_last_digit(tok):
+    """Value of one unit in the last printed digit of a numeric token ('1.2345E+02' -> 1e-2)."""
+    t = tok.upper().replace("D", "E")
+    mant, _, ex = t.partition("E")
+    dec = len(mant.split(".")[1]) if "." in mant else 0
+    return 10.0 ** ((int(ex) if ex else 0) - dec)
+
+
+def _compare_stdout(got, want, max_off_by_one=None):
+    """Printed-token equality.  Every numeric token must be the SAME printed number as the
+    reference's, except (a) fields below an absolute floor (1e-6 x the largest magnitude of the
+    file: analytically-zero quantities carrying cancellation noise) and (b) at most
+    `max_off_by_one` tokens (default: 0.2 % of the file, at least 2) that differ by ONE unit in the
+    last printed digit -- a value sitting on a rounding boundary of the 5-digit print.  Returns the
+    number of such off-by-one tokens."""
+    g, w = got.split(), want.split()
     assert len(g) == len(w), (len(g), len(w))
-    nums = [abs(x) for x in w if isinstance(x, float)]
+    nums = []
+    for tok in w:
+        try:
+            nums.append(abs(float(tok)))
+        except ValueError:
+            pass
     floor = 1e-6 * max(nums)
+    off = 0
     for a, b in zip(g, w):
-        if isinstance(b, str):
-            assert a == b
-        else:
-            assert abs(a - b) <= 2e-4 * abs(b) + floor or abs(a - b) <= floor, (a, b)
+        try:
+            fb = float(b)
+        except ValueError:
+            assert a == b, (a, b)
+            continue
+        fa = float(a)
+        if fa == fb or (abs(fa) <= floor and abs(fb) <= floor):
+            continue
+        unit = _unit_of_last_digit(b)
+        if abs(fb) <= floor or abs(fa - fb) <= floor:
+            continue
+        assert abs(fa - fb) <= 1.0001 * unit, (a, b)
+        off += 1
+    limit = max(2, int(0.002 * len(nums))) if max_off_by_one is None else max_off_by_one
+    assert off <= limit, f"{off} tokens differ in the last printed digit (limit {limit} of {len(nums)})"
+    return off
 
 
 def _runs(recs):
@@ -109,4 +140,73 @@ def test_host_reproduces_reference_stdout(case, tmp_path):
         assert p.returncode == 0, p.stderr
         got += p.stdout
     want = open(os.path.join(GOLDEN, case + ".stdout")).read()
-    _compare_stdout(got, want)
+    off = _compare_stdout(got, want)
+    print(f"{case}: {off} token(s) one unit off in the last printed digit", file=sys.stderr)
+
+
+CAPTURE = os.path.join(ROOT, "oracle", "_ref", "sbdart_capture")
+needs_ref = pytest.mark.skipif(not os.access(CAPTURE, os.X_OK), reason="oracle/_ref not built")
+
+
+def run_reference_and_host(namelist, d, sums=False):
+    """In directory d: the reference (capture build: unmodified objects, DISORT call site recorded)
+    on this INPUT, then the host on the optics the reference just used.  Returns (reference stdout,
+    host stdout, path of the captured records[, host's full-precision sums])."""
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "INPUT"), "w") as f:
+        f.write("\n &INPUT\n" + namelist + "\n /\n")
+    cap = os.path.join(d, "cap.sbdrec")
+    ref = subprocess.run([CAPTURE], cwd=d, env=dict(os.environ, SBD_CAPTURE_FILE=cap), capture_output=True,
+                         text=True, check=True).stdout
+    env = dict(os.environ, SBD_OPTICS=cap, SBD_ATMOS=cap + ".atm")
+    if sums:
+        env["SBD_SUMS_FILE"] = os.path.join(d, "sums.txt")
+    p = subprocess.run([HOST], cwd=d, env=env, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    if sums:
+        return ref, p.stdout, cap, np.loadtxt(env["SBD_SUMS_FILE"])
+    return ref, p.stdout, cap
+
+
+@pytest.mark.gpu
+@needs_flang
+@needs_ref
+def test_host_reproduces_sbchk3_and_sbchk4_in_full(tmp_path):
+    """TestRuns examples 3 (thermal, three cloud cases, 161 wavelengths each) and 4 (126 single-
+    wavelength runs up to optical depth 128) replayed completely: the reference runs on the box,
+    the host gets the optics it used and must print what the reference printed -- and what
+    TestRuns/sbchk.3 holds (tests/golden/sbchk3.stdout is that file)."""
+    _build()
+    man = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+    ref_all, got_all = "", ""
+    for i, nl in enumerate(man["sbchk3"]["namelists"]):
+        ref, got, _ = run_reference_and_host(nl, str(tmp_path / f"c3_{i}"))
+        ref_all += ref
+        got_all += got
+    assert ref_all == open(os.path.join(GOLDEN, "sbchk3.stdout")).read()
+    off3 = _compare_stdout(got_all, ref_all)
+    cases4 = [f" tcloud={t}\n nre={n}\n wlinf={w}\n wlsup={w}\n idatm=1\n isat=0\n isalb=6\n iout=10\n sza=0"
+              for t in (0, 1, 2, 4, 8, 16, 32, 64, 128) for n in (2, 4, 8, 16, 32, 64, 128) for w in (".55", "2.16")]
+    ref_all, got_all = "", ""
+    for i, nl in enumerate(cases4):
+        ref, got, _ = run_reference_and_host(nl, str(tmp_path / f"c4_{i}"))
+        ref_all += ref
+        got_all += got
+    off4 = _compare_stdout(got_all, ref_all)
+    print(f"sbchk3: {off3}, sbchk4 (all 126 runs): {off4} token(s) one unit off", file=sys.stderr)
+
+
+@pytest.mark.gpu
+@needs_flang
+@needs_ref
+@pytest.mark.parametrize("iout,extra", [(7, ""), (11, ""), (22, " nstr=8 nzen=4 uzen=0,70 nphi=3 phi=0,180"),
+                                        (20, " nstr=8 nzen=5 uzen=0,80 nphi=3 phi=0,180"),
+                                        (21, " nstr=12 nzen=5 uzen=100,180 nphi=3 phi=0,180"), (23, " nstr=8 nzen=6 uzen=10,170 nphi=2 phi=0,90"),
+                                        (10, " zout=2,20")])
+def test_host_output_formats_against_reference(iout, extra, tmp_path):
+    """Every IOUT writer (per-level profiles with altitudes, heating rates, radiances at every level,
+    hemisphere split) and the ZOUT level selection against the reference on the same optics."""
+    _build()
+    nl = f" idatm=2 isat=0 wlinf=.4 wlsup=.7 wlinc=.05 sza=40 isalb=4 tcloud=3 zcloud=2 iout={iout}{extra}"
+    ref, got, _ = run_reference_and_host(nl, str(tmp_path))
+    _compare_stdout(got, ref)

@@ -1,0 +1,52 @@
+"""Several engines behind one handle (sbd_fleet_*, include/sbdart_amd.h) on the GPU box.
+
+The box has one GPU, so the fleet is built over the device list [0, 0]: two engines, two
+workspaces, two streams, the batch cut by sbd_shard_range, the weighted sums combined at the end
+(host-side here: RCCL does not take the same device twice; with distinct devices the same call
+reduces over xGMI).  Per-item outputs must equal the single engine's bit for bit, the reduced
+sums must equal stdout1's accumulation of the single engine's outputs."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(recs):
+    return (np.stack([r.dtauc for r in recs]), np.stack([r.ssalb for r in recs]), np.stack([r.pmom for r in recs]),
+            [r.wvnmlo for r in recs], [r.wvnmhi for r in recs], [r.fbeam for r in recs],
+            [r.albedo for r in recs], [r.plank for r in recs])
+
+
+@pytest.mark.parametrize("devices,name", [([0, 0], "cfgB_sw_nstr16"), ([0, 0, 0], "cfg3_lw_nstr16_cloud"), ([0], "cfgA_sw_nstr4"),
+                                          (None, "sbchk5")])
+def test_fleet_matches_single_engine(devices, name):
+    from sbdart_amd.engine import DisortFleet, engine_for_record
+    from sbdart_amd.records import read_records
+    recs = read_records(os.path.join(GOLDEN, name + ".sbdrec"))
+    r0 = recs[0]
+    recs = [r for r in recs if np.array_equal(r.temper, r0.temper) and r.umu0 == r0.umu0 and r.nstr == r0.nstr][:23]
+    args = _batch(recs)
+    w = np.array([r.wt * r.ff for r in recs])
+    lev = None if not r0.onlyfl else [0, r0.nlyr]
+    with engine_for_record(r0, level_out=lev) as one:
+        f1, u1, s1 = one.solve(*args)
+    kw = dict(nlyr=r0.nlyr, nstr=r0.nstr, nmom=r0.nmom, temper=r0.temper, umu0=r0.umu0, phi0=r0.phi0, onlyfl=r0.onlyfl,
+              usrang=r0.usrang, umu=r0.umu, phi=r0.phi, btemp=r0.btemp, ttemp=r0.ttemp, temis=r0.temis, fisot=r0.fisot,
+              level_out=lev, allow_retry_nstr=True)
+    with DisortFleet(devices=devices, **kw) as fl:
+        assert fl.size == (len(devices) if devices else 1)      # one GPU visible on the box
+        parts = [fl.shard_range(len(recs), r) for r in range(fl.size)]
+        assert parts[0][0] == 0 and parts[-1][1] == len(recs)
+        f2, u2, s2, acc_f, acc_u = fl.solve(*args, weight=w)
+        f3, u3, s3 = fl.solve(*args)                            # no sums asked for
+        _, _, s4, acc_f4, _ = fl.solve(*args, weight=w, items=False)   # sums only
+    assert np.array_equal(f1, f2) and np.array_equal(s1, s2) and np.array_equal(f1, f3)
+    if u1 is not None:
+        assert np.array_equal(u1, u2)
+        assert np.allclose(acc_u, np.einsum("i,ipln->pln", w, u1), rtol=1e-12, atol=1e-300)
+    assert np.allclose(acc_f, np.einsum("i,icl->cl", w, f1), rtol=1e-12, atol=1e-300)
+    assert np.array_equal(acc_f, acc_f4) and np.array_equal(s1, s4)

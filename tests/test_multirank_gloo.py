@@ -1,7 +1,9 @@
-"""The N>1 path on CPU: two gloo ranks shard a small sweep by spectral point, each
-integrates its shard (with the C oracle standing in for the GPU solve -- this test is
-about the sharding and the single reduce, not the kernels), and the reduced accumulators
-equal the single-process sums."""
+"""The N>1 path on CPU: two gloo ranks cut a small sweep with the product's own shard rule (the
+C ABI's sbd_shard_range, the function the fleet and the Fortran host shard with -- host code,
+callable without a GPU), each integrates its shard (the C oracle standing in for the GPU
+solve: without a GPU this test is about the sharding and the single reduce, not the kernels)
+and the reduced accumulators equal the single-process sums.  The same split with real engines
+on a GPU: tests/test_gpu_fleet.py."""
 import os
 import socket
 import sys
@@ -38,10 +40,14 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from sbdart_amd.shard import reduce_accumulators, shard_range
+    import ctypes as C
+    from sbdart_amd import _lib
+    from sbdart_amd.shard import reduce_accumulators
     from sbdart_amd.workload import sw_sweep
     sw = sw_sweep(nwl=12, nstr=8, nlyr=5, seed=99)
-    lo, hi = shard_range(sw.nwl, rank, world)
+    clo, chi = C.c_int32(), C.c_int32()
+    _lib.load().sbd_shard_range(sw.nwl, world, rank, C.byref(clo), C.byref(chi))
+    lo, hi = clo.value, chi.value
     acc = torch.from_numpy(_integrate(sw, lo, hi))
     reduce_accumulators(acc, dst=0)
     if rank == 0:

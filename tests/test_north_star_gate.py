@@ -1,0 +1,57 @@
+"""north_star's gate, literally: INPUT -> integrated fluxes within 1e-4 W/m2 of the reference.
+
+On the GPU box the reference itself runs (oracle/_ref/sbdart_capture: the unmodified reference
+objects with the DISORT call site recorded -- its stdout IS sbdart_ref's), the Fortran host
+`sbdart_amd` is handed the optical properties the reference just used, and
+
+  * the host's stdout must be the reference's stdout (printed-token equality), and
+  * the host's six spectrally integrated fluxes TOPDN, TOPUP, TOPDIR, BOTDN, BOTUP, BOTDIR (full
+    precision, SBD_SUMS_FILE) must lie within 1e-4 W/m2 of the reference's, integrated in fp64 from
+    the reference's own per-solve DISORT outputs with stdout1's weights (drt.f:964-1054) -- the
+    reference's 5-digit print cannot resolve 1e-4 W/m2 of a 1e3 W/m2 flux.
+
+Cases: BASELINE.json configs[1] (full short-wave sweep, nstr=16: 751 wavelengths, 2 009 solves, real
+solar FBEAM) and configs[2] (long-wave, cloud, thermal emission).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from test_fortran_host import _build, _compare_stdout, needs_flang, needs_ref, run_reference_and_host
+
+pytestmark = pytest.mark.gpu
+
+GATE_W_M2 = 1.0e-4
+
+CASES = {
+    "sw_nstr16": "idatm=6 isat=0 wlinf=.25 wlsup=4.0 wlinc=.005 nstr=16 iout=10",
+    "lw_cloud_nstr16": "idatm=6 wlinf=4 wlsup=80 wlinc=-.01 nstr=16 tcloud=10 zcloud=1 nre=8 sza=95 iout=10",
+}
+
+
+@needs_flang
+@needs_ref
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_integrated_fluxes_within_gate(case, tmp_path):
+    from sbdart_amd.records import read_records
+    _build()
+    ref_out, got_out, cap, sums = run_reference_and_host(CASES[case], str(tmp_path), sums=True)
+    _compare_stdout(got_out, ref_out, max_off_by_one=1)
+    recs = read_records(cap)
+    w = np.array([r.wt * r.ff for r in recs])
+    top, bot = 0, recs[0].nlyr                      # zout = 0,100: TOA and surface (drt.f:376-381)
+    ref = np.array([
+        np.sum(w * np.array([r.rfldn[top] + r.rfldir[top] for r in recs])),
+        np.sum(w * np.array([r.flup[top] for r in recs])),
+        np.sum(w * np.array([r.rfldir[top] for r in recs])),
+        np.sum(w * np.array([r.rfldn[bot] + r.rfldir[bot] for r in recs])),
+        np.sum(w * np.array([r.flup[bot] for r in recs])),
+        np.sum(w * np.array([r.rfldir[bot] for r in recs]))])
+    # the reference prints these six numbers: our fp64 re-integration of its records must print the same
+    printed = [float(t) for t in ref_out.split()[3:9]]
+    assert np.allclose(ref, printed, rtol=6e-5, atol=1e-30), (ref, printed)
+    err = np.abs(sums - ref)
+    print(f"{case}: {len(recs)} solves, |host - reference| (W/m2) = {err}, fluxes = {ref}", file=sys.stderr)
+    assert err.max() <= GATE_W_M2, (err, ref)

@@ -7,18 +7,19 @@ import csv, glob, json, sys
 from collections import defaultdict
 
 root, out, solves_per_launch = sys.argv[1], sys.argv[2], int(sys.argv[3])
+nstr, nlyr = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (16, 33)
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             acc[row["Kernel_Name"].split("(")[0].strip()][row["Counter_Name"]].append(float(row["Counter_Value"]))
-res = {"solves_per_launch": solves_per_launch, "note": "FETCH_SIZE doubled (gfx950 64B-per-128B tally); KB*1024", "kernels": {}}
+res = {"solves_per_launch": solves_per_launch, "nstr": nstr, "nlyr": nlyr, "note": "FETCH_SIZE doubled (gfx950 64B-per-128B tally); KB*1024", "kernels": {}}
 for k, d in acc.items():
     if "sbd::" not in k:
         continue
     rd = 2.0 * 1024.0 * sum(d["FETCH_SIZE"]) / max(1, len(d["FETCH_SIZE"]))
     wr = 1024.0 * sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"]))
     res["kernels"][k] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
-                         "bytes_per_solve": (rd + wr) / solves_per_launch}
+                         "bytes_per_launch": rd + wr, "bytes_per_solve": (rd + wr) / solves_per_launch}
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
