@@ -204,6 +204,9 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         }
     }
     int status = 0;
+    // smallest and largest pivot: the stand-in for SGBCO's condition estimate (errmsg 2, disort.f:3607-3610),
+    // see near_singular() in sbd_layer.hpp; lane J sees the pivot of sub-step J
+    double pmin = 1.0e300, pmax = 0.0;
     // The NSTR rows that enter with step lc are interface lc's [ga(lc) | gb(lc+1)] with right-hand
     // sides B(nn + (lc-1) n + r), or for lc = ncut the boundary block above beside zeros with B(N-nn+r),
     // r < nn.  They are fetched while step lc-1 is being eliminated: straight into the registers
@@ -224,12 +227,11 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         const double vi = interface_rhs(up, dn, eb, tc), vl = (lci == ncut && q < nn) ? yb : 0.0;
         return (lci < ncut) ? vi : vl;
     };
-    Z3 zc = load_z(2);                                         // lower layer of the interface just formed
     {   // rows of step 1 (exposed once per system)
         const double *pa, *pb;
         step_rows(1, pa, pb);
-        const Z3 z1 = load_z(1);
-        const double yq = step_rhs(1, z1, zc, expbea[1], taucpr[1], *pyb);
+        const Z3 z1 = load_z(1), z2 = load_z(2);
+        const double yq = step_rhs(1, z1, z2, expbea[1], taucpr[1], *pyb);
 #pragma unroll
         for (int r = 0; r < n; ++r) {
             const double va = pa[r * n], vb = pb[r * n];
@@ -248,9 +250,11 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         const double *pna, *pnb;                                // next step's rows
         step_rows(lc + 1, pna, pnb);
         const int lcb = (lc + 1 < L) ? lc + 1 : L;              // (a valid level index whatever ncut is)
-        Z3 zn;
+        Z3 zu, zn;                                              // the two layers at interface lc+1
         double ebn, tcn, ybn;
         double *urow0 = ufac + (size_t)(lc - 1) * n * UW;      // U rows of this layer
+        int qo = q;                                             // (opaque per step: keeps the compiler from hoisting
+        asm volatile("" : "+v"(qo));                            //  16 per-sub-step store addresses out of the loop)
         double *yrow0 = yv + (lc - 1) * n;
         // ---- NSTR elimination sub-steps ----
         static_for<n>([&](auto jj) {
@@ -286,29 +290,29 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
                 bufb[J] = (n == 16 || col) ? vb : 0.0;
             }
             if constexpr (J == 0) {                             // (loads whatever the step is: no branches,
-                zn = load_z(lc + 2);                            //  exact wait counts)
+                zu = load_z(lc + 1);                            //  exact wait counts)
+                zn = load_z(lc + 2);
                 ebn = expbea[lcb];
                 tcn = taucpr[lcb];
                 ybn = *pyb;
             }
             if constexpr (J == ((n > 3) ? 3 : n - 1)) {
-                rhsn = step_rhs(lc + 1, zc, zn, ebn, tcn, ybn);
-                zc = zn;
+                rhsn = step_rhs(lc + 1, zu, zn, ebn, tcn, ybn);
             }
             // (3) -1/pivot (v_rcp + two Newton steps) in lane J, a zero pivot is flagged and skipped
             double rn = __builtin_amdgcn_rcp(t0);
             rn = rn * (2.0 - t0 * rn);
             rn = rn * (2.0 - t0 * rn);
             rn = (t0 != 0.0) ? -rn : 0.0;
-            if (q == J && t0 == 0.0) status |= 0x01;
+            if (q == J) { pmin = fmin(pmin, fabs(t0)); pmax = fmax(pmax, fabs(t0)); }
             // (4) the retired row: U(k, k..) row-major, forward-eliminated B(k)
             {
                 double *urow = urow0 + J * UW;
                 if constexpr (n == 16) {
                     // no branches: the finished columns (q < J) put their (unread) word behind the row's
                     // support, which is UW - J wide; B(k) is the same in the 16 lanes
-                    urow[(q - J) & (UW - 1)] = t0;
-                    urow[n - J + q] = t1;
+                    urow[(qo - J) & (UW - 1)] = t0;
+                    urow[n - J + qo] = t1;
                     yrow0[J] = t2;
                 } else {
                     if (q >= J && col) urow[q - J] = t0;
@@ -338,6 +342,15 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             constexpr int r = decltype(rr)::value;
             a2[nn + r] = dbl_lane_bcast<r>(rhsn);
         });
+    }
+    {   // errmsg 2: min|pivot| <= 8 N eps max|pivot| over the N pivots of the system (a zero pivot included)
+        double am = pmax, pm = pmin;
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) {
+            am = fmax(am, __shfl_xor(am, d, 16));
+            pm = fmin(pm, __shfl_xor(pm, d, 16));
+        }
+        if (q == 0 && !(pm > 8.0 * N * 2.220446049250313e-16 * am)) status |= 0x01;
     }
     if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
 #undef GC

@@ -12,7 +12,8 @@
 #include "../../include/sbdart_amd.h"
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is dlopen()ed when a fleet needs it
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -758,6 +759,35 @@ int sbd_engine_accumulate_host(sbd_engine *e, int32_t nwork, const double *weigh
 // exchange, and the only collective is the sum of the weighted accumulator blocks (stdout1's
 // spectral sums, drt.f:1047-1054): one ncclReduce(sum, double) over xGMI when the devices are
 // distinct, a host-side sum in device order otherwise (the same engine twice: test configurations).
+// RCCL is loaded on demand (a fleet over several distinct devices), never at link time: a process that
+// drives one GPU -- or that hosts another HIP/RCCL user such as PyTorch -- does not get a second copy
+// of the collective library mapped into it.
+struct RcclApi {
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    bool ok = false;
+};
+static const RcclApi &rccl_api()
+{
+    static RcclApi api = [] {
+        RcclApi a;
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+        a.CommInitAll = (decltype(a.CommInitAll))dlsym(h, "ncclCommInitAll");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+        a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+        a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+        a.Reduce = (decltype(a.Reduce))dlsym(h, "ncclReduce");
+        a.ok = a.CommInitAll && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Reduce;
+        return a;
+    }();
+    return api;
+}
+
 struct sbd_fleet {
     std::vector<sbd_engine *> eng;
     std::vector<ncclComm_t> comm;     // empty: host-side sum
@@ -778,7 +808,7 @@ void sbd_shard_range(int32_t nwork, int32_t nshard, int32_t rank, int32_t *lo, i
 void sbd_fleet_destroy(sbd_fleet *f)
 {
     if (!f) return;
-    for (auto c : f->comm) (void)ncclCommDestroy(c);
+    for (auto c : f->comm) (void)rccl_api().CommDestroy(c);
     for (auto e : f->eng) sbd_engine_destroy(e);
     delete f;
 }
@@ -815,9 +845,9 @@ int sbd_fleet_create(const sbd_run_cfg *cfg, int32_t ndev, const int32_t *device
     for (size_t i = 0; i < dev.size(); ++i)
         for (size_t j = i + 1; j < dev.size(); ++j)
             if (dev[i] == dev[j]) distinct = false;
-    if (distinct) {
+    if (distinct && rccl_api().ok) {
         f->comm.resize(dev.size());
-        if (ncclCommInitAll(f->comm.data(), (int)dev.size(), dev.data()) != ncclSuccess) {
+        if (rccl_api().CommInitAll(f->comm.data(), (int)dev.size(), dev.data()) != ncclSuccess) {
             f->comm.clear();            // no RCCL path on this system: fall back to the host-side sum
         }
     }
@@ -854,13 +884,13 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
     if (weight) {
         if (!f->comm.empty() && (int)busy.size() == nd) {
             // the one collective of the path: sum of the accumulator blocks onto device 0 over xGMI
-            if (ncclGroupStart() != ncclSuccess) return fail(SBD_E_HIP, "ncclGroupStart");
+            if (rccl_api().GroupStart() != ncclSuccess) return fail(SBD_E_HIP, "ncclGroupStart");
             for (int r = 0; r < nd; ++r) {
                 HIP_TRY(hipSetDevice(f->eng[r]->cfg.device));
-                if (ncclReduce(f->eng[r]->d_acc, f->eng[r]->d_red, nel, ncclDouble, ncclSum, 0, f->comm[r], f->eng[r]->stream) != ncclSuccess)
+                if (rccl_api().Reduce(f->eng[r]->d_acc, f->eng[r]->d_red, nel, ncclDouble, ncclSum, 0, f->comm[r], f->eng[r]->stream) != ncclSuccess)
                     return fail(SBD_E_HIP, "ncclReduce");
             }
-            if (ncclGroupEnd() != ncclSuccess) return fail(SBD_E_HIP, "ncclGroupEnd");
+            if (rccl_api().GroupEnd() != ncclSuccess) return fail(SBD_E_HIP, "ncclGroupEnd");
             f->hacc.assign(nel, 0.0);
             HIP_TRY(hipSetDevice(e0->cfg.device));
             HIP_TRY(hipMemcpyAsync(f->hacc.data(), e0->d_red, sizeof(double) * nel, hipMemcpyDeviceToHost, e0->stream));

@@ -34,8 +34,29 @@ struct LayerLds {   // per-group carve-up (doubles)
     }
 };
 
+// Stand-in for LINPACK's condition estimate.  The reference calls SGECO/SGBCO (disutil.f:567-767,
+// 1094-1353) only to test 1 + RCOND == 1 (errmsg 2/3/4: disort.f:3607-3610, 4227, 4333), i.e. "singular
+// to working precision".  The engine stores no L factor, so it looks at the pivots instead: the matrix is
+// flagged when min|pivot| <= 8 n eps max|pivot| (eps = 2^-52).  For DISORT's systems that is where a
+// single-scattering albedo one ulp below 1 lands (the only way into these warnings with valid input: the
+// dither of disort.f:486 keeps SSALB = 1 itself 200 ulps away, 10-20 times above the threshold), and in
+// that range LINPACK's own estimate flips between warning and not from one ulp to the next.
+// pivot: this lane's |pivot|, or a negative number for lanes that hold none; G lanes per matrix.
+template <int G>
+SBD_DEVICE bool near_singular(double pivot, int n)
+{
+    double pmin = (pivot >= 0.0) ? pivot : 1.0e300, pmax = (pivot >= 0.0) ? pivot : 0.0;
+    for (int d = G / 2; d >= 1; d >>= 1) {
+        pmin = fmin(pmin, __shfl_xor(pmin, d, G));
+        pmax = fmax(pmax, __shfl_xor(pmax, d, G));
+    }
+    return !(pmin > 8.0 * n * 2.220446049250313e-16 * pmax);
+}
+
 // LU with partial pivoting of the n x n LDS matrix a (SGEFA's pivot rule: first maximal
-// |a(i,k)|, disutil.f:2060-2072).  Lane j owns column j.  Returns info (first zero pivot).
+// |a(i,k)|, disutil.f:2060-2072).  Lane j owns column j.  Returns non-zero when the matrix is singular
+// to working precision -- see near_singular() below.
+template <int G>
 SBD_DEVICE int lu_factor_group(double *a, int ld, int n, int *ipvt, int g)
 {
 #define A(i, j) a[((j) - 1) * ld + ((i) - 1)]
@@ -75,6 +96,8 @@ SBD_DEVICE int lu_factor_group(double *a, int ld, int n, int *ipvt, int g)
     if (g == 0) ipvt[n - 1] = n;
     if (A(n, n) == 0.0) info = n;
     wave_lds_sync();
+    // the pivots are U's diagonal, left in place: lane k looks at its own
+    if (near_singular<G>((me <= n) ? fabs(A(me, me)) : -1.0, n)) info = (info != 0) ? info : n;
     return info;
 }
 
@@ -276,7 +299,7 @@ __global__ void __launch_bounds__(64) layer_kernel(Params P, int32_t *only_flagg
             zj = (2.0 - delm0) * fbeam * sum / (4.0 * P.pi);
         }
         wave_lds_sync();
-        if (lu_factor_group(lu, ld, n, ipvt, g) != 0) status |= 0x02;
+        if (lu_factor_group<G>(lu, ld, n, ipvt, g) != 0) status |= 0x02;
         zj = lu_solve_group<G>(lu, ld, n, ipvt, zj, g);
         double *zzout = P.zz + ((size_t)ms * L + (lc - 1)) * n;
         if (me <= nn) zzout[me + nn - 1] = zj;
@@ -296,7 +319,7 @@ __global__ void __launch_bounds__(64) layer_kernel(Params P, int32_t *only_flagg
             z1 = (1.0 - oprim) * xr1;
         }
         wave_lds_sync();
-        if (lu_factor_group(lu, ld, n, ipvt, g) != 0) status |= 0x04;
+        if (lu_factor_group<G>(lu, ld, n, ipvt, g) != 0) status |= 0x04;
         z1 = lu_solve_group<G>(lu, ld, n, ipvt, z1, g);
         if (me <= n) z0 = (1.0 - oprim) * xr0 + cmu[me - 1] * z1;
         z0 = lu_solve_group<G>(lu, ld, n, ipvt, z0, g);

@@ -226,7 +226,9 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     // quantity cancelling against the homogeneous one, and only the reference's own sequence of
     // operations (SGECO/SGESL on the full NSTR x NSTR system) reproduces its rounding (5e-5 vs 3e-4 of
     // the column maximum for the Cholesky-reuse solve below).  Such layers are rare.
-    const bool hard_thermal = plank && mazim == 0 && P.ssalb[(size_t)slot * L + (lc - 1)] == 1.0;
+    // (within 64 ulps of 1: the dithered value and the undithered neighbours of 1, for which the full I - CC
+    //  is singular to working precision and the reference-algorithm kernel raises errmsg 4 from its pivots)
+    const bool hard_thermal = plank && mazim == 0 && P.ssalb[(size_t)slot * L + (lc - 1)] >= 1.0 - 64.0 * 1.1102230246251565e-16;
     if (!spd || P.force_fallback || hard_thermal) {
         if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;   // count, then the entries
         return;
@@ -486,6 +488,13 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         return bv;
     };
     const bool thermal = plank && mazim == 0;
+    int status = 0;
+    // errmsg 4 (UPISOT's SGECO, disort.f:4333): the Cholesky pivots of Q+ and Q- (squares of the factors'
+    // diagonals, still in LDS) stand in for the condition estimate, see near_singular() in sbd_layer.hpp
+    if (thermal) {
+        const double dl = (me <= nn) ? QP(me, me) : 0.0, dc = (me <= nn) ? QM(me, me) : 0.0;
+        if (near_singular<G>((me <= nn) ? dl * dl : -1.0, nn) || near_singular<G>((me <= nn) ? dc * dc : -1.0, nn)) status |= 0x04;
+    }
     if (thermal) {
         // (I - CC) Z1 = (1-w') XR1 (the same in both halves): Z1+- = (1-w') XR1 u, (I - S+ W) u = 1;
         // (I - CC) Z0 = (1-w') XR0 + CMU Z1: Z0+- = (1-w') XR0 u +- e, (I - S- W) e = mu Z1
@@ -508,7 +517,6 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         P.zp1[lidx * n + me - 1] = 0.0; P.zp1[lidx * n + me + nn - 1] = 0.0;
     }
 
-    int status = 0;
     if (fbeam > 0.0) {
         const double delm0 = (mazim == 0) ? 1.0 : 0.0;
         const double umu0 = P.umu0;
@@ -545,7 +553,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         // q = (r+ + r-) - mu0 (I - S+ W) M^-1 (r+ - r-);  T d = q;  s = mu0 M^-1 ((r+ - r-) - (I - S- W) d)
         const double cmu_me = (me <= nn) ? scmu[me - 1] : 1.0;
         double dv = rs - umu0 * apply_ImSW(sp, rdv / cmu_me);
-        if (lu_factor_group(lu, ldq, nn, ipvt, g) != 0) status |= 0x02;
+        if (lu_factor_group<G>(lu, ldq, nn, ipvt, g) != 0) status |= 0x02;
         dv = lu_solve_group<G>(lu, ldq, nn, ipvt, dv, g);
         const double sv_ = umu0 * (rdv - apply_ImSW(sm, dv)) / cmu_me;
         const double zpl = 0.5 * (sv_ + dv), zmi = 0.5 * (sv_ - dv);     // Z(+mu_me), Z(-mu_me)

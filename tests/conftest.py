@@ -19,6 +19,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """On a GPU box bring PyTorch's HIP runtime up FIRST.  The engine library links the system ROCm
+    runtime, PyTorch ships its own copy; when the engine's runtime opens the device first, PyTorch's
+    later initialisation in the same process reports "No HIP GPUs are available" (seen on the MI355X
+    boxes; the other order works, and bench.py / smoke() use it too)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

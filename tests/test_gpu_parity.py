@@ -27,7 +27,7 @@ FILES = sorted(glob.glob(os.path.join(GOLDEN, "*.sbdrec")))
 
 def _check(flux, uu, st, recs, outs, tol=TOL):
     for i, (r, o) in enumerate(zip(recs, outs)):
-        assert st[i] == o.get("status", 0) or (st[i] & ~0x47) == (o.get("status", 0) & ~0x47), (i, st[i], o.get("status"))
+        assert st[i] == o.get("status", 0), (i, st[i], o.get("status"))   # warnings 2/3/4/9 included
         recmax = max(max(np.abs(o[f]).max() for f in FLUX), 1e-300)
         for c, f in enumerate(FLUX):
             ref = o[f]
@@ -133,6 +133,51 @@ def test_input_error_and_retry_status():
     flux, uu, st = solve_records([r])
     assert st[0] & _lib.ST_RETRY_NSTR and np.all(flux[0] == 0.0)
     assert pyoracle.disort(r)["nstr_out"] == -8
+
+
+def _thermal_record(nstr, nlyr, tau, w_mid):
+    from sbdart_amd.records import F_LAMBER, F_ONLYFL, F_PLANK, SolveRecord
+    k = np.arange(nstr + 3)
+    ss = np.full(nlyr, 0.5)
+    ss[nlyr // 2] = w_mid
+    return SolveRecord(nlyr=nlyr, nstr=nstr, nmom=nstr + 2, flags=F_LAMBER | F_PLANK | F_ONLYFL, wvnmlo=900.0,
+                       wvnmhi=950.0, fbeam=1.0, umu0=0.6, phi0=0.0, albedo=0.3, btemp=300.0, ttemp=200.0, temis=0.5,
+                       dtauc=np.full(nlyr, tau), ssalb=ss, temper=np.linspace(220.0, 295.0, nlyr + 1),
+                       pmom=np.full(nlyr, 0.6)[:, None] ** k[None, :], umu=np.zeros(0), phi=np.zeros(0))
+
+
+def test_near_singular_systems_raise_the_reference_warnings():
+    """errmsg 2/3/4 (disort.f:3607-3610, 4227, 4333).  The reference tests 1 + RCOND == 1 with LINPACK's
+    condition estimate; the engine, which keeps no L factor, flags min|pivot| <= 8 n eps max|pivot|
+    (near_singular(), sbdart_amd/csrc/sbd_layer.hpp).  With valid input the only way into these warnings is a
+    single-scattering albedo a few ulps below 1 (it is not dithered, disort.f:486) in a layer with a
+    thermal source: I - CC is then singular to working precision and the reference returns NaN fluxes.
+    In that range LINPACK's own estimate flips from one ulp to the next (NSTR=4: warns 1..4 ulps below 1;
+    NSTR=8: 2..5; NSTR=16: 20..24 -- not at 1), so the two criteria are compared as regimes: the reference warns
+    somewhere within 32 ulps of 1 for every NSTR, the engine warns at one ulp for NSTR <= 8, and neither
+    warns at the dithered value (200 ulps) or anywhere else: every other test of this file demands EQUAL
+    status words, warnings included."""
+    import pyoracle
+    from sbdart_amd import _lib
+    from sbdart_amd.engine import solve_records
+    one_ulp = np.nextafter(1.0, 0.0)
+    for nstr in (4, 8, 16):
+        ref_warns = [k for k in range(1, 33)
+                     if pyoracle.disort(_thermal_record(nstr, 3, 1.0, 1.0 - k * 2.0 ** -53))["status"] & pyoracle.WARN_UPISOT_RCOND]
+        assert ref_warns, nstr
+        recs = [_thermal_record(nstr, nl, tau, one_ulp) for nl, tau in ((3, 0.1), (3, 1.0), (1, 10.0), (5, 50.0))]
+        _, _, st = solve_records(recs)
+        if nstr <= 8:
+            # (NSTR = 16: the rounding noise of the 16-term sums that build CC, ~n eps, is as large as
+            #  1 - SSALB itself; the pivots then stay above the threshold -- and the reference does not warn
+            #  at one ulp either.  No warning is a legitimate answer there; a false one never is.)
+            assert all(s_ & _lib.ST_WARN_UPISOT for s_ in st), (nstr, st)
+        assert all((s_ & ~_lib.ST_WARN_UPISOT) == 0 for s_ in st), (nstr, st)
+        # the dithered conservative layer (SSALB = 1 exactly) is 200 ulps away: no warning from either
+        r = _thermal_record(nstr, 3, 1.0, 1.0)
+        assert pyoracle.disort(r)["status"] == 0
+        _, _, st = solve_records([r])
+        assert st[0] == 0, (nstr, st)
 
 
 def test_level_selection_and_accumulate():
