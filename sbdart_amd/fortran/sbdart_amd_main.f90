@@ -76,6 +76,7 @@ program sbdart_amd
     stop
   end if
 
+  call check_input()
   fmt = find_format(iout, known)
   if (.not. known) call fatal('this IOUT is not an output format of the hot path (1,5,6,7,10,11,20,21,22,23)')
   radcalc = fmt%radiance /= rad_none                    ! drt.f:237-247
@@ -256,6 +257,84 @@ program sbdart_amd
   end if
 
 contains
+
+  ! The reference's input screening (chkin, drt.f:568-728): out-of-range namelist values are reported
+  ! with its messages and stop the run; two combinations only warn (errmsg 16/17).  One rule per line:
+  ! the condition that makes the value unacceptable, the name and the range text that are printed.
+  subroutine check_input()
+    integer :: nbad
+    nbad = 0
+    if (iaer == 0 .and. (vis /= unset .or. tbaer /= unset)) call warn_file(16, 'CHKIN--IAER=0, though VIS or TBAER set')
+    if (corint .and. .not. any(iout == (/5, 6, 20, 21, 22, 23/))) &
+      call warn_file(17, 'CHKIN--CORINT=t, but flux output selected')
+    call rule(idatm < -6 .or. idatm > 6, 'idatm', '[-6,6]', iv('idatm=', (/idatm/)))
+    call rule(wlinf < real(0.199, kr), 'wlinf', '[0.2,-]', rv('wlinf=', (/wlinf/)))
+    if (isat <= -2) then
+      call rule(wlsup < 0._kr .or. wlsup >= wlinf, 'wlsup', '[0,wlinf]', rv('wlsup=', (/wlsup/)))
+    else
+      call rule(wlsup < wlinf .or. wlsup > 100._kr, 'wlsup', '[wlinf,100]', rv('wlsup=', (/wlsup/)))
+    end if
+    call rule(isat < -4 .or. isat > 29, 'isat', '[-4,29]', iv('isat=', (/isat/)))
+    call rule(solfac < 0._kr, 'solfac', '[0,inf]', rv('solfac=', (/solfac/)))
+    call rule(minval(zcloud) < -100._kr .or. maxval(zcloud) > 100._kr, 'zcloud', '[-100,100]', rv('zcloud=', zcloud))
+    call rule((minval(abs(nre)) < 2._kr .or. maxval(abs(nre)) > 128._kr) .and. nre(1) /= 0._kr, 'nre', '[2,128]', rv('nre', nre))
+    if (any(tcloud == 0._kr .and. zcloud < 0._kr)) then
+      print *, 'CHKIN --- Error detected in input'
+      print *, 'TCLOUD(k)=0 when ZCLOUD(k)<0'
+      nbad = nbad + 1
+    end if
+    call rule(minval(lwp) < 0._kr, 'lwp', '[0,inf]', rv('lwp=', lwp))
+    call rule(maxval(abs(zaer)) > 100._kr, 'zaer', '[-100,100]', rv('zaer=', zaer))
+    call rule(minval(taerst) < 0._kr, 'taerst', '[0,inf]', rv('taerst', taerst))
+    call rule(minval(jaer) < 0 .or. maxval(jaer) > 4, 'jaer', '[0,4]', iv('jaer', jaer))
+    call rule(nf < -2 .or. nf > 3, 'nf', '[-2,3]', iv('nf', (/nf/)))
+    call rule(iaer < -1 .or. iaer > 5, 'iaer', '[-1,5]', iv('iaer', (/iaer/)))
+    call rule(.not. any(isalb == (/-7, -8, -9, -1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10/)), 'isalb', &
+              '[-7,-8,-9,-1,0,1,2,3,4,5,6,7,8,9,10]', iv('isalb', (/isalb/)))
+    call rule(isalb == 0 .and. albcon < 0._kr, 'albcon', '[0,inf]', rv('albedo set by albcon', (/albcon/)))
+    call rule(minval(zout) < 0._kr .or. maxval(zout) > 100._kr, 'zout', '[0,100]', rv('zout', zout))
+    call rule(.not. any(iout == (/1, 2, 5, 6, 7, 10, 11, 20, 21, 22, 23/)), 'iout', '[1,2,5,6,7,10,11,20,21,22,23]', iv('iout', (/iout/)))
+    call rule(nphi < 0 .or. nphi > nstrms, 'nphi', '[0,nstrms]', iv('nphi', (/nphi/)))
+    if (any(iout == (/20, 21, 22, 23/)) .and. nzen == 0 .and. all(uzen == unset) .and. all(vzen == 90._kr)) then
+      write(*, '(1x,a,i2,a,a)') 'iout =', iout, ' implies radiance calculation, ', 'but nzen=0 produces no radiance output'
+      nbad = nbad + 1
+    end if
+    if (zpres /= unset .and. pbar /= unset) then
+      write(*, '(1x,a)') 'set zpres or pbar but not both'
+      nbad = nbad + 1
+    end if
+    if (any(tcloud /= 0._kr) .and. any(lwp /= 0._kr)) then
+      write(*, *) 'set TCLOUD or LWP, but not both'
+      nbad = nbad + 1
+    end if
+    if (nbad > 0) stop
+  contains
+    subroutine rule(violated, name, range, echo)
+      logical, intent(in) :: violated
+      character(len=*), intent(in) :: name, range, echo
+      if (.not. violated) return
+      if (nbad == 0) print '(a)', 'CHKIN --- Errors detected in INPUT'
+      print '(/5x,4a)', 'Input parameter ', name, ' not within ', range
+      print '(a)', echo
+      nbad = nbad + 1
+    end subroutine
+    function iv(label, v) result(t)                 ! "label value(s)" as list-directed output prints it
+      character(len=*), intent(in) :: label
+      integer, intent(in) :: v(:)
+      character(len=:), allocatable :: t
+      character(len=512) :: buf
+      write(buf, *) label, v
+      t = trim(buf)
+    end function
+    function rv(label, v) result(t)
+      character(len=*), intent(in) :: label
+      real(kr), intent(in) :: v(:)
+      character(len=:), allocatable :: t
+      character(len=2048) :: buf
+      write(buf, *) label, v
+      t = trim(buf)
+    end function
+  end subroutine
 
   ! index of the level nearest to altitude zq in the bottom-up altitudes (ties: the lower level)
   integer function nearest_level(z, zq) result(k)

@@ -54,6 +54,23 @@ def test_host_prints_namelist_without_input_and_fails_without_gpu(tmp_path):
         assert r.returncode != 0 and "no usable HIP device" in r.stderr
 
 
+@needs_flang
+def test_input_screening_matches_the_reference(tmp_path):
+    """chkin (drt.f:568-728): out-of-range namelist values stop the run with the reference's report.
+    No GPU involved: the screening runs before any engine is created."""
+    _build()
+    ref = os.path.join(ROOT, "oracle", "_ref", "sbdart_ref")
+    (tmp_path / "INPUT").write_text("\n &INPUT\n idatm=9, wlinf=.1, iout=3, nf=7, isat=40, lwp=-1,0,0,0,0, nphi=99\n /\n")
+    got = subprocess.run([HOST], cwd=tmp_path, capture_output=True, text=True).stdout
+    assert "CHKIN --- Errors detected in INPUT" in got
+    for name, rng in (("idatm", "[-6,6]"), ("wlinf", "[0.2,-]"), ("isat", "[-4,29]"), ("lwp", "[0,inf]"), ("nf", "[-2,3]"),
+                      ("iout", "[1,2,5,6,7,10,11,20,21,22,23]"), ("nphi", "[0,nstrms]")):
+        assert f"Input parameter {name} not within {rng}" in got, name
+    if os.access(ref, os.X_OK):
+        want = subprocess.run([ref], cwd=tmp_path, capture_output=True, text=True).stdout
+        assert got == want
+
+
 def _tokens(text):
     out = []
     for tok in text.split():

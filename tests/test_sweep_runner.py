@@ -1,0 +1,58 @@
+"""The py3 sweep runner (sbdart_amd/sweep.py) against RunRT's documented semantics
+(GenInput.py:43-147: the worked example in CycleInput's docstring) and against the reference's
+own verified sweep outputs (shapes of RunRT/RUNS/*.sbd command blocks; token layouts of RtReader)."""
+import os
+
+import pytest
+
+from conftest import GOLDEN
+from sbdart_amd.sweep import Sweep, SweepError, parse_iout1, parse_iout10, parse_iout11
+
+
+def test_cycle_semantics_of_the_documented_example():
+    s = Sweep("TCLOUD=0;10;100\nWLINF=0.5;0.8\nWLSUP=0.5;0.8 &\nALBCON=0.5   # constant\n\nIOUT=10\n")
+    assert s.shape == (3, 2) and len(s) == 6 and s.iout == 10
+    body, lead = s.inputs(3)                      # GenInput.py:129-131: iteration 3
+    assert lead == ["TCLOUD=0", "WLINF=0.8"]
+    assert body == "TCLOUD=0\nWLINF=0.8\nWLSUP=0.8\nALBCON=0.5\nIOUT=10\n"
+    assert [s.inputs(i)[1][0] for i in range(6)] == ["TCLOUD=0", "TCLOUD=10", "TCLOUD=100"] * 2   # first cycle fastest
+    with pytest.raises(SweepError):
+        Sweep("A=1;2;3\nB=1;2 &\n")
+    with pytest.raises(IndexError):
+        s.inputs(6)
+
+
+def test_shape_of_a_reference_sweep_and_token_layouts():
+    # RunRT/RUNS/btemp_uw_iout_1.sbd's command block: 8 x 10 runs of 48 wavelengths
+    s = Sweep("BTEMP=260;270;280;290;300;310;320;330\nUW=0.5261;1.1;1.725;2.406;3.15;3.96;4.843;5.806;6.856;8\n"
+              "WLINF=6\nWLSUP=14\nWLINC=20\nIOUT=1\n")
+    assert s.shape == (8, 10) and s.iout == 1
+    assert s.inputs(79)[0].startswith("BTEMP=330\nUW=8\n")
+    one = open(os.path.join(GOLDEN, "sbchk1.stdout")).read()          # an IOUT=1 output of the reference
+    cols = parse_iout1(one)
+    assert len(cols["WL"]) == 151 and cols["WL"][0] == 0.25 and cols["WL"][-1] == 1.0
+    assert all(abs(a - (d - u)) < 1e-12 for a, d, u in zip(cols["TOPFLUX"], cols["TOPDN"], cols["TOPUP"]))
+    ten = open(os.path.join(GOLDEN, "sbchk2.stdout")).read().splitlines()[0]
+    rec = parse_iout10(ten)
+    assert rec["WLINF"] == 0.55 and rec["ABSORPTION"] == pytest.approx(rec["TOPFLUX"] - rec["BOTFLUX"])
+    prof = parse_iout11("   2  1.0000000E-01\n 1.0E+02 3.0E-04 1.8E+02 8.3E+00 1.8E+02 0.0E+00 0.0E+00\n"
+                        " 7.0E+01 7.0E-02 1.8E+02 8.3E+00 1.8E+02 3.2E-05 1.1E-01\n")
+    assert prof["Z"] == [100.0, 70.0] and prof["HEAT"][1] == 0.11 and prof["PHIDW"] == 0.1
+
+
+@pytest.mark.gpu
+def test_sweep_through_the_host_matches_the_reference(tmp_path):
+    """sbchk.2's sweep (RunRT/RUNS/sbchk2.sbd: TCLOUD x ALBCON, IOUT=10) as a command block: every
+    iteration through the reference (to make the optics) and through `sbdart_amd`."""
+    from test_fortran_host import CAPTURE, HOST, _build, _compare_stdout
+    if not os.access(CAPTURE, os.X_OK):
+        pytest.skip("oracle/_ref not built")
+    _build()
+    s = Sweep("TCLOUD=0;1;2;4;8;16;32;64\nALBCON=0;.2;.4\nIDATM=4\nISAT=0\nWLINF=.55\nWLSUP=.55\nISALB=0\nIOUT=10\nSZA=30\n")
+    assert len(s) == 24
+    ref = s.run(CAPTURE, str(tmp_path), env=dict(os.environ, SBD_CAPTURE_FILE="cap.sbdrec"))
+    got = s.run(HOST, str(tmp_path), env=dict(os.environ, SBD_OPTICS="cap.sbdrec", SBD_ATMOS="cap.sbdrec.atm"))
+    _compare_stdout("".join(got), "".join(ref))
+    want = open(os.path.join(GOLDEN, "sbchk2.stdout")).read().splitlines()
+    # sbchk.2 loops albedo outermost / cloud innermost as well: the first 24 lines are these 24 runs
+    assert [parse_iout10(r)["BOTDN"] for r in ref] == [parse_iout10(w)["BOTDN"] for w in want[:24]]
