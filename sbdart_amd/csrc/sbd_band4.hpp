@@ -95,8 +95,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     const double *zp1 = P.zp1 + (size_t)(ms - mazim) * L * n;
     double *yv = P.yv + (size_t)ms * L * n;
     double *ufac = P.ufac + (size_t)ms * (size_t)(L * n) * UW;
-    const double *ga_ms = P.ga + (size_t)ms * L * n * n;
-    const double *gb_ms = P.gb + (size_t)ms * L * n * n;
+    double *bcb = P.bcb + (size_t)ms * n * n;                  // bottom-boundary rows (below)
     const int N = ncut * n;
 #define GC(i, j, lc) gc[((size_t)((lc) - 1) * n + ((i) - 1)) * n + ((j) - 1)]
 #define KK(i, lc) kk[((lc) - 1) * n + ((i) - 1)]
@@ -168,15 +167,14 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     };
     // ---- bottom-boundary rows (disort.f:2919-2990), Lambertian reflection folded in:
     //      GC(nn+r, j, ncut) - (1 + delta_m0) * sum_k CWT(k) CMU(k) ALBEDO GC(nn+1-k, j, ncut), times EK(n+1-j)
-    //      for j > nn.  They go where a (non-existent) interface ncut would have its x_ncut block --
-    //      ga's block of layer ncut, which nothing else reads -- padded to NSTR rows with zeros (zero
-    //      rows never win a pivot search), so that the last elimination step is a step like the others ----
+    //      for j > nn.  They go to a block of their own, padded to NSTR rows with zeros (zero rows never
+    //      win a pivot search), so that the last elimination step reads its rows like the others ----
     if (col) {
         double sb = 0.0;
         if (refl)
             for (int k = 1; k <= nn; ++k) sb = sb + cwt[k - 1] * cmu[k - 1] * albedo * GC(nn + 1 - k, iq1, ncut);
         const double f = (iq1 > nn) ? EK(n + 1 - iq1, ncut) : 1.0;
-        double *bc = P.ga + (size_t)ms * L * n * n + (size_t)(ncut - 1) * n * n + q;
+        double *bc = bcb + q;
 #pragma unroll
         for (int r = 0; r < n; ++r) {
             double g = 0.0;
@@ -215,11 +213,25 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     // right-hand sides as one value per lane (lane r <-> row r) spread by DPP at the hand-over.
     constexpr int E = (n < 4) ? n : 4;
     double bufa[E], bufb[E], rhsn = 0.0;
+    // Step lci < ncut: interface lci's rows are [GC(lci) * fa | GC(lci+1) * fb] (SETMTX, disort.f:2851-2876)
+    // with the STWJ factors fa(j) = EK(n+1-j, lci) for j > nn (else 1), fb(j) = -EK(j, lci+1) for j <= nn
+    // (else -1): the layer kernels leave GC and EK, the scaling happens here when the rows are handed
+    // over.  Step ncut: the boundary block beside zeros, unscaled.  Beyond: valid memory, never used.
     auto step_rows = [&](int lci, const double *&pa, const double *&pb) {
-        const bool inner = lci < ncut, last = lci == ncut;     // (beyond ncut: valid memory, never used)
+        const bool inner = lci < ncut, last = lci == ncut;
         const int cq = col ? q : 0;
-        pa = (inner || last) ? ga_ms + (size_t)(lci - 1) * n * n + cq : yv;
-        pb = inner ? gb_ms + (size_t)lci * n * n + cq : (last ? P.t.zeros + cq : yv);
+        pa = inner ? gc + (size_t)(lci - 1) * n * n + cq : (last ? bcb + cq : yv);
+        pb = inner ? gc + (size_t)lci * n * n + cq : (last ? P.t.zeros + cq : yv);
+    };
+    auto factor_ptrs = [&](int lci, const double *&pea, const double *&peb) {   // always valid addresses
+        const int la = (lci < L) ? lci : L, lb = (lci + 1 < L) ? lci + 1 : L;
+        pea = ek + (la - 1) * nn + ((q >= nn && q < n) ? n - q - 1 : 0);
+        peb = ek + (lb - 1) * nn + ((q < nn) ? q : 0);
+    };
+    auto factors = [&](int lci, double eka, double ekb, double &fa, double &fb) {
+        const bool inner = lci < ncut;
+        fa = (inner && q >= nn) ? eka : 1.0;
+        fb = inner ? ((q < nn) ? -ekb : -1.0) : 1.0;
     };
     const double *pyb = yv + (N - nn) + ((q < nn) ? q : 0);    // bottom-boundary B, lane r <-> row r < nn
     // B of the rows of step lci for lane r <-> row r: an interface (lci < ncut), the bottom boundary, nothing
@@ -232,11 +244,15 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         step_rows(1, pa, pb);
         const Z3 z1 = load_z(1), z2 = load_z(2);
         const double yq = step_rhs(1, z1, z2, expbea[1], taucpr[1], *pyb);
+        const double *pea, *peb;
+        factor_ptrs(1, pea, peb);
+        double fa, fb;
+        factors(1, *pea, *peb, fa, fb);
 #pragma unroll
         for (int r = 0; r < n; ++r) {
             const double va = pa[r * n], vb = pb[r * n];
-            a0[nn + r] = col ? va : 0.0;
-            a1[nn + r] = col ? vb : 0.0;
+            a0[nn + r] = col ? va * fa : 0.0;
+            a1[nn + r] = col ? vb * fb : 0.0;
         }
         static_for<n>([&](auto rr) {
             constexpr int r = decltype(rr)::value;
@@ -251,7 +267,9 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         step_rows(lc + 1, pna, pnb);
         const int lcb = (lc + 1 < L) ? lc + 1 : L;              // (a valid level index whatever ncut is)
         Z3 zu, zn;                                              // the two layers at interface lc+1
-        double ebn, tcn, ybn;
+        double ebn, tcn, ybn, fan = 1.0, fbn = 1.0;
+        const double *pea, *peb;
+        factor_ptrs(lc + 1, pea, peb);
         double *urow0 = ufac + (size_t)(lc - 1) * n * UW;      // U rows of this layer
         int qo = q;                                             // (opaque per step: keeps the compiler from hoisting
         asm volatile("" : "+v"(qo));                            //  16 per-sub-step store addresses out of the loop)
@@ -295,9 +313,12 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
                 ebn = expbea[lcb];
                 tcn = taucpr[lcb];
                 ybn = *pyb;
+                fan = *pea;
+                fbn = *peb;
             }
             if constexpr (J == ((n > 3) ? 3 : n - 1)) {
                 rhsn = step_rhs(lc + 1, zu, zn, ebn, tcn, ybn);
+                factors(lc + 1, fan, fbn, fan, fbn);            // (raw EK values -> the rows' scale factors)
             }
             // (3) -1/pivot (v_rcp + two Newton steps) in lane J, a zero pivot is flagged and skipped
             double rn = __builtin_amdgcn_rcp(t0);
@@ -305,20 +326,16 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             rn = rn * (2.0 - t0 * rn);
             rn = (t0 != 0.0) ? -rn : 0.0;
             if (q == J) { pmin = fmin(pmin, fabs(t0)); pmax = fmax(pmax, fabs(t0)); }
-            // (4) the retired row: U(k, k..) row-major, forward-eliminated B(k)
+            // (4) the retired row.  U goes out by layer block: row J of the block holds x_lc's columns in
+            //     words 0..n-1 (the finished ones, q < J, carry multipliers nobody reads) and x_lc+1's in
+            //     n..2n-1 -- two aligned 128-byte lines per system, no branches; B(k) is the same in the 16 lanes
             {
                 double *urow = urow0 + J * UW;
-                if constexpr (n == 16) {
-                    // no branches: the finished columns (q < J) put their (unread) word behind the row's
-                    // support, which is UW - J wide; B(k) is the same in the 16 lanes
-                    urow[(qo - J) & (UW - 1)] = t0;
-                    urow[n - J + qo] = t1;
-                    yrow0[J] = t2;
-                } else {
-                    if (q >= J && col) urow[q - J] = t0;
-                    if (col) urow[n - J + q] = t1;
-                    if (q == J) yrow0[J] = t2;
+                if (n == 16 || col) {
+                    urow[qo] = t0;
+                    urow[n + qo] = t1;
                 }
+                if (n == 16 || q == J) yrow0[J] = t2;
             }
             // (5) elimination: a_s[p] += a_0[p](lane J) * (t_s * -1/pivot); columns <= J of
             //     slot 0 are finished (their registers keep the unscaled multipliers)
@@ -335,9 +352,11 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         // ---- the nn rows left over only touch x_lc+1: next step's carry ----
 #pragma unroll
         for (int p = 0; p < nn; ++p) { a0[p] = a1[p]; a1[p] = 0.0; }
-        // ... and the prefetched rows of interface lc+1 complete the window
+        // ... and the prefetched rows of the next step complete the window, scaled as they arrive
 #pragma unroll
-        for (int r = 0; r < E; ++r) { a0[nn + r] = bufa[r]; a1[nn + r] = bufb[r]; }
+        for (int r = 0; r < E; ++r) { a0[nn + r] = bufa[r] * fan; a1[nn + r] = bufb[r] * fbn; }
+#pragma unroll
+        for (int r = E; r < n; ++r) { a0[nn + r] = a0[nn + r] * fan; a1[nn + r] = a1[nn + r] * fbn; }
         static_for<n>([&](auto rr) {
             constexpr int r = decltype(rr)::value;
             a2[nn + r] = dbl_lane_bcast<r>(rhsn);

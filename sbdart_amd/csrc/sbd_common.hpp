@@ -54,6 +54,8 @@ struct Params {
     int32_t nslot;          // work items in this chunk
     int32_t sv_stride, svi_stride;
     int32_t cw, ncd;        // band: CW = 2*ncd+1 columns kept per U row, ncd = 3nn-1
+    int32_t ublock;         // U rows stored by layer block (sbd_band4.hpp) instead of diagonal-relative
+    int32_t gconly;         // the band kernel scales GC itself (sbd_band4.hpp): the layer kernels write no ga/gb
     double umu0, fisot, btemp, ttemp, temis;
     double pi, dither;
     Tables t;
@@ -64,7 +66,8 @@ struct Params {
     double *sv; int32_t *svi;
     double *gc, *kk, *ek, *zz, *zp0, *zp1, *ll, *ufac;
     double *yv;             // [ms][L*n] right-hand side / forward-eliminated RHS of the band system
-    double *ga, *gb;        // matrix-ready interface blocks (see sbd_band.hpp), [ms][L][n][n] each
+    double *ga, *gb;        // matrix-ready interface blocks (see sbd_band.hpp), [ms][L][n][n] each (absent when gconly)
+    double *bcb;            // [ms][n][n] bottom-boundary rows of sbd_band4.hpp (gconly)
     double *gu, *zb, *z0u, *z1u, *uum;
     // outputs (offset to the chunk)
     double *flux, *uu; int32_t *status;

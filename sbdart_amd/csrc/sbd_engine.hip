@@ -355,7 +355,11 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const sbd::SV sv(L);
     const int sv_stride = (sv.size() + 1) & ~1;
     const int svi_stride = (3 + L + 1 + 3) & ~3;
-    const size_t per_ms = sizeof(double) * ((size_t)3 * L * n * n + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * (2 * n)
+    // (band4: the band kernel reads GC and scales it itself, no ga/gb blocks -- a third of the workspace)
+    bool band4 = nn <= 8;
+    if (const char *s = getenv("SBD_BAND_V1")) band4 = band4 && atoi(s) == 0;
+    const size_t nblk = band4 ? 1 : 3;
+    const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n : 0) + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * (2 * n)
                                             + (rad ? (size_t)L * n * numu + 3 * (size_t)L * numu + (size_t)e->nlev * numu : 0));
     const size_t per_slot = per_ms * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
     size_t budget = (size_t)64 << 30;   // of 288 GB: fewer, larger passes (launch tails cost ~7 % at 16k items)
@@ -387,8 +391,14 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         P.sv = (double *)take(sizeof(double) * (size_t)chunk * sv_stride);
         P.svi = (int32_t *)take(sizeof(int32_t) * (size_t)chunk * svi_stride);
         P.gc = (double *)take(sizeof(double) * nms * L * n * n);
-        P.ga = (double *)take(sizeof(double) * nms * L * n * n);
-        P.gb = (double *)take(sizeof(double) * nms * L * n * n);
+        if (band4) {
+            P.ga = P.gb = nullptr;
+            P.bcb = (double *)take(sizeof(double) * nms * n * n);
+        } else {
+            P.ga = (double *)take(sizeof(double) * nms * L * n * n);
+            P.gb = (double *)take(sizeof(double) * nms * L * n * n);
+            P.bcb = nullptr;
+        }
         P.kk = (double *)take(sizeof(double) * nms * L * n);
         P.ek = (double *)take(sizeof(double) * nms * L * nn);
         P.zz = (double *)take(sizeof(double) * nms * L * n);
@@ -431,8 +441,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->layer_lds = (int)sizeof(double) * ll.total * (64 / G);
     e->band_reg = nn <= 10;                       // register-resident LU window (sbd_band.hpp)
     if (const char *s = getenv("SBD_BAND_LDS")) e->band_reg = e->band_reg && atoi(s) == 0;
-    e->band4 = nn <= 8;
-    if (const char *s = getenv("SBD_BAND_V1")) e->band4 = e->band4 && atoi(s) == 0;
+    e->band4 = band4;
+    e->P.ublock = e->P.gconly = band4 ? 1 : 0;
     const sbd::BandLds bl(n, nn, e->band_reg);
     e->band_lds = (int)sizeof(double) * bl.total;
     const sbd::SolveLds sl(n, nn, L);

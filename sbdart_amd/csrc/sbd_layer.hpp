@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(64) layer_kernel(Params P, int32_t *only_flagg
         }
     }
     wave_lds_sync();
-    {   // matrix-ready interface blocks for the band kernel (disort.f:2851-2876); eval[] holds k
+    if (!P.gconly) {   // matrix-ready interface blocks for the band kernel (disort.f:2851-2876); eval[] holds k
         double *gaout = P.ga + ((size_t)ms * L + (lc - 1)) * n * n, *gbout = P.gb + ((size_t)ms * L + (lc - 1)) * n * n;
         const double dtp = sv[o.dtaucp() + lc - 1];
         __threadfence_block();

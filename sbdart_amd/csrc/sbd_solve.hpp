@@ -92,8 +92,10 @@ __global__ void __launch_bounds__(64) backsolve_kernel(Params P)
                 v[it] = 0.0;
                 // (row i is the ((i-1) % n)-th row of its layer: its support ends with the next layer's
                 //  columns, UB - (i-1) % n places right of the diagonal; sbd_band4.hpp stores no more)
+                // U(i, j): diagonal-relative (sbd_band.hpp) or, from sbd_band4.hpp, relative to the first
+                // column of row i's layer (block-aligned rows: every store of that kernel is a full line)
                 if (r < NR && i >= 1 && i <= k1 && j <= k1 && j >= i && j - i <= UB - (i - 1) % n)
-                    v[it] = ufac[(size_t)(i - 1) * UW + (j - i)];
+                    v[it] = ufac[(size_t)(i - 1) * UW + (P.ublock ? j - 1 - ((i - 1) / n) * n : j - i)];
             }
         };
         double cur[NLD];
