@@ -596,7 +596,8 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
         }
         SBD_DBG("band");
         if (timing) HIP_TRY(hipEventRecord(e->ev[3], st));
-        sbd::launch_backsolve(e->nn, (unsigned)((size_t)ns * nmode), e->solve_lds, st, P);
+        if (e->band4) sbd::launch_backsolve4(e->nn, (unsigned)(((size_t)ns * nmode + 3) / 4), st, P);
+        else sbd::launch_backsolve(e->nn, (unsigned)((size_t)ns * nmode), e->solve_lds, st, P);
         SBD_DBG("backsolve");
         if (timing) HIP_TRY(hipEventRecord(e->ev[4], st));
         if (rad) {
