@@ -169,7 +169,10 @@ def main():
     flux = torch.empty((W, 5, eng.nlev), dtype=torch.float64, device=dev)
     status = torch.empty(W, dtype=torch.int32, device=dev)
     acc = torch.zeros((5, eng.nlev), dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    tstream = torch.cuda.Stream(dev)                   # an explicit stream: copies, kernels and sums of a step in order
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
     import ctypes as C
     L = eng._L
 
@@ -252,8 +255,11 @@ def main():
         names = ["setup_kernel", "layer_kernel", "band_kernel", "backsolve_kernel", "usrint+azimuth"]
         dom = int(np.argmax(phase_ms))
         abytes = algorithmic_bytes_per_solve(sw.nlyr, sw.nstr, eng.nlev)
-        nlaunch = (W + eng.chunk - 1) // eng.chunk
-        pass_size = (W + nlaunch - 1) // nlaunch           # the engine splits a batch into equal passes
+        nlaunch = (W + eng.chunk - 1) // eng.chunk          # the engine's rule (sbd_engine_solve_device): an even
+        if nlaunch == 1 and W >= 16384:                     # number of equal passes, alternating between its two
+            nlaunch = 2                                     # workspaces / streams
+        nlaunch += nlaunch > 1 and nlaunch % 2
+        pass_size = (W + nlaunch - 1) // nlaunch
         ach = abytes * W / (phase_ms[dom] * 1e-3) / 1e9
         # HBM bytes per launch of the dominant kernel from the committed PMC passes
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/make_traffic_profile.py)
@@ -279,7 +285,7 @@ def main():
                                    f"{sw.nwl} spectral points/GPU, {W} DISORT solves/GPU (avg nk {W / sw.nwl:.2f}), "
                                    f"flux at TOA+surface, seed 12345",
                        "nstr": sw.nstr, "nlyr": sw.nlyr, "nwl_per_gpu": sw.nwl, "solves_per_gpu": W,
-                       "parallelism": f"spectral shard x{world}, 1 RCCL reduce of {5 * eng.nlev} doubles/step",
+                       "parallelism": f"spectral shard x{world}, 1 RCCL reduce of {5 * eng.nlev} doubles/step; per GPU {nlaunch} passes alternating on 2 streams",
                        "chunk": eng.chunk, "workspace_bytes": eng.workspace_bytes},
             "solves_per_s": W * world * args.steps / elapsed,
             "value_incl_h2d": nwl_total * nh / elapsed_h, "ms_per_step_incl_h2d": 1e3 * elapsed_h / nh,

@@ -160,6 +160,9 @@ struct sbd_engine {
     // workspace (one allocation)
     char *d_ws = nullptr;
     sbd::Params P{};              // workspace pointers + constants; chunk fields filled per call
+    sbd::Params P2{};             // the same over the second workspace (passes alternate between the two)
+    hipStream_t aux = nullptr;    // second stream: odd passes run here, beside the even ones
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // staging for solve_host / accumulate
     char *d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -212,6 +215,9 @@ void sbd_engine_destroy(sbd_engine *e)
     if (e->d_red) (void)hipFree(e->d_red);
     for (auto &x : e->ev)
         if (x) (void)hipEventDestroy(x);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -333,6 +339,9 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         }                                                                                   \
     } while (0)
     CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     CREATE_TRY(hipMalloc(&e->d_tab, htab.size() * sizeof(double)));
     CREATE_TRY(hipMemcpy(e->d_tab, htab.data(), htab.size() * sizeof(double), hipMemcpyHostToDevice));
     std::vector<int32_t> hlev(e->nlev);
@@ -364,15 +373,18 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const size_t per_slot = per_ms * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
     size_t budget = (size_t)64 << 30;   // of 288 GB: fewer, larger passes (launch tails cost ~7 % at 16k items)
     if (const char *s = getenv("SBD_WORKSPACE_MB")) budget = (size_t)atoll(s) << 20;
-    int chunk = 131072;
+    // Two workspaces of `chunk` items each: consecutive passes of a batch alternate between them on two
+    // streams, so that the layer kernel of one pass (latency-bound arithmetic) runs beside the band LU /
+    // back-substitution of the other (HBM streaming) instead of after it.
+    int chunk = 65536;
     if (const char *s = getenv("SBD_CHUNK")) chunk = atoi(s);
     if (cfg->max_batch > 0 && cfg->max_batch < chunk) chunk = cfg->max_batch;
-    while (chunk > 1 && (size_t)chunk * per_slot > budget) chunk /= 2;
+    while (chunk > 1 && (size_t)2 * chunk * per_slot > budget) chunk /= 2;
     if (chunk < 1) chunk = 1;
     size_t flag_bytes = 0;
     for (;;) {   // a GPU that cannot spare the budget right now gets smaller passes instead of an error
         flag_bytes = sizeof(int32_t) * ((size_t)chunk * nmode * L + 4);   // count + entries
-        e->ws_bytes = (size_t)chunk * per_slot + flag_bytes + 8192;
+        e->ws_bytes = 2 * (((size_t)chunk * per_slot + flag_bytes + 8192 + 255) & ~(size_t)255);
         const hipError_t me_ = hipMalloc(&e->d_ws, e->ws_bytes);
         if (me_ == hipSuccess) break;
         e->d_ws = nullptr;
@@ -414,7 +426,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
             P.z1u = (double *)take(sizeof(double) * nms * L * numu);
             P.uum = (double *)take(sizeof(double) * nms * e->nlev * numu);
         }
-        if ((size_t)(p - e->d_ws) > e->ws_bytes + 256 * 20) {
+        if ((size_t)(p - e->d_ws) > e->ws_bytes / 2) {
             sbd_engine_destroy(e);
             return fail(SBD_E_NOMEM, "workspace carve overflow");
         }
@@ -466,6 +478,15 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         if (e->use_layer2) CREATE_TRY(sbd::prepare_layer2(nn, rad, e->layer2_lds));
     }
     for (auto &x : e->ev) CREATE_TRY(hipEventCreate(&x));
+    {   // second workspace (every field of P is final here): each workspace pointer moved by half the allocation
+        e->P2 = e->P;
+        const size_t half = e->ws_bytes / 2;
+        auto mv = [&](auto *&ptr) { if (ptr) ptr = (std::remove_reference_t<decltype(ptr)>)((char *)ptr + half); };
+        sbd::Params &Q = e->P2;
+        mv(Q.eiglist); mv(Q.sv); mv(Q.svi); mv(Q.gc); mv(Q.ga); mv(Q.gb); mv(Q.bcb); mv(Q.kk); mv(Q.ek); mv(Q.zz); mv(Q.zp0);
+        mv(Q.zp1); mv(Q.ll); mv(Q.yv); mv(Q.ufac); mv(Q.gu); mv(Q.zb); mv(Q.z0u); mv(Q.z1u); mv(Q.uum);
+        CREATE_TRY(hipMemset(Q.eiglist, 0, sizeof(int32_t) * ((size_t)e->chunk * e->nmode * e->L + 4)));
+    }
 #undef CREATE_TRY
 
     // beam angle == quadrature angle (disort.f:2643-2650): whole-run property when a beam
@@ -551,11 +572,26 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
     float acc_ms[sbd_engine::kPhases] = {};
     // a batch larger than the workspace goes through in EQUAL passes (no short tail pass whose
     // kernels cost their full launch latency for a handful of items)
-    const int npass = (in->nwork + e->chunk - 1) / e->chunk;
+    // With more than one pass, consecutive passes alternate between the two workspaces and run on two
+    // streams (the caller's and the engine's auxiliary one): an even number of equal passes, the
+    // kernels of pass i+1 beside those of pass i.  Per-kernel timing (enable_timing) keeps one stream.
+    int npass = (in->nwork + e->chunk - 1) / e->chunk;
+    if (npass == 1 && in->nwork >= 16384) npass = 2;
+    if (npass > 1 && (npass & 1)) ++npass;
+    const bool fork = !timing && !dbg && npass > 1;
     const int per_pass = (in->nwork + npass - 1) / npass;
-    for (int w0 = 0; w0 < in->nwork; w0 += per_pass) {
+    if (fork) {
+        HIP_TRY(hipEventRecord(e->ev_fork, st));                 // what the caller queued before this call ...
+        HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));      // ... is also ahead of the auxiliary stream
+    }
+    hipStream_t st_main = st;
+    int ipass = 0;
+    for (int w0 = 0; w0 < in->nwork; w0 += per_pass, ++ipass) {
         const int ns = (in->nwork - w0 < per_pass) ? in->nwork - w0 : per_pass;
-        sbd::Params P = e->P;
+        const bool second = (ipass & 1) != 0;
+        sbd::Params P = second ? e->P2 : e->P;
+        st = (fork && second) ? e->aux : st_main;
+        int32_t *const eigflag = P.eiglist;
         P.nslot = ns;
         P.dtauc = in->dtauc + (size_t)w0 * L;
         P.ssalb = in->ssalb + (size_t)w0 * L;
@@ -578,9 +614,8 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
             if (e->use_layer2) {
                 const int gpb2 = 64 / e->G2;
                 const unsigned g2 = (unsigned)(((size_t)ns * L + gpb2 - 1) / gpb2) * (unsigned)nmode;
-                int32_t *flag = e->d_eigflag;
-                sbd::launch_layer2(e->nn, rad, g2, e->layer2_lds, st, P, flag);
-                flt = e->d_eigflag;     // the QR kernel below only redoes the listed layers: a small
+                sbd::launch_layer2(e->nn, rad, g2, e->layer2_lds, st, P, eigflag);
+                flt = eigflag;          // the QR kernel below only redoes the listed layers: a small
                 if (grid > 2048u) grid = 2048u;   // fixed grid walks the list (normally empty)
                 SBD_DBG("layer2");
             }
@@ -616,6 +651,11 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
                 acc_ms[ph] += ms;
             }
         }
+    }
+    st = st_main;
+    if (fork) {
+        HIP_TRY(hipEventRecord(e->ev_join, e->aux));             // the caller's stream continues when both are done
+        HIP_TRY(hipStreamWaitEvent(st, e->ev_join, 0));
     }
     if (timing) {
         for (int ph = 0; ph < sbd_engine::kPhases; ++ph) e->ms_phase[ph] = acc_ms[ph];
