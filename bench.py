@@ -215,38 +215,32 @@ def main():
     eng.enable_timing(False)
     torch.cuda.synchronize()
 
-    # ---- the same step with the inputs in (pinned) host memory: H2D of the inputs + kernels + weighted
-    #      sums + D2H of the accumulator block (SURVEY 8d's "engine phase"); never `value` ----
-    h_in = [x.cpu().pin_memory() for x in d_in]
-    h_w = d_w.cpu().pin_memory()
-    s_in = [torch.empty_like(x) for x in d_in]
-    s_w = torch.empty_like(d_w)
+    # ---- the same step through the HOST entry point (what the Fortran host calls): inputs in pinned host
+    #      memory, every pass stages its slice H2D on its stream beside the other pass's kernels, weighted
+    #      sums on the device, D2H of the sums and the status words (SURVEY 8d's "engine phase"); never `value` ----
+    from sbdart_amd.engine import DisortFleet
+    fleet = DisortFleet(nlyr=sw.nlyr, nstr=sw.nstr, nmom=sw.nmom, temper=sw.temper, umu0=sw.umu0, btemp=sw.btemp,
+                        ttemp=sw.ttemp, temis=sw.temis, onlyfl=True, level_out=level_out, devices=[local_rank])
+    h_in = [x.cpu().pin_memory().numpy() for x in d_in]
+    h_w = d_w.cpu().pin_memory().numpy()
 
     def step_host():
-        for dst, src in zip(s_in, h_in):
-            dst.copy_(src, non_blocking=True)
-        s_w.copy_(h_w, non_blocking=True)
-        eng.solve_device(*s_in, out=(flux, None, status), stream=stream)
-        acc.zero_()
-        rc = L.sbd_engine_accumulate_device(eng._h, W, s_w.data_ptr(), flux.data_ptr(), None,
-                                            acc.data_ptr(), None, C.c_void_p(stream))
-        assert rc == 0, rc
-        if world > 1:
-            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
-        return acc.cpu()
+        return fleet.solve(*h_in, weight=h_w, items=False)[3]
 
-    step_host()
+    acc_h = step_host()
     barrier()
     t0 = time.perf_counter()
     nh = max(1, min(args.steps, 5))
     for _ in range(nh):
-        step_host()
+        acc_h = step_host()
     barrier()
     elapsed_h = time.perf_counter() - t0
+    fleet.close()
     if world > 1:
         tt = torch.tensor([elapsed_h], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed_h = float(tt.item())
+    assert np.allclose(acc_h, acc.cpu().numpy(), rtol=1e-12, atol=0) or world > 1, "host entry point disagrees with the device one"
 
     if rank == 0:
         nwl_total = sw.nwl * world
@@ -289,7 +283,7 @@ def main():
                        "chunk": eng.chunk, "workspace_bytes": eng.workspace_bytes},
             "solves_per_s": W * world * args.steps / elapsed,
             "value_incl_h2d": nwl_total * nh / elapsed_h, "ms_per_step_incl_h2d": 1e3 * elapsed_h / nh,
-            "incl_h2d_note": "same step with the inputs in pinned host memory: H2D + kernels + sums + D2H of the sums",
+            "incl_h2d_note": "same step through the host entry point (sbd_fleet_solve_host): inputs in pinned host memory, H2D per pass beside the other pass's kernels, sums on the device, D2H of sums + status",
             "nonzero_status": bad,
             "kernel_ms": {names[i]: float(phase_ms[i]) for i in range(5)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS,

@@ -553,7 +553,21 @@ long long sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t
     return (long long)bytes;
 }
 
+// Host arrays behind a device-pointer solve (sbd_engine_solve_host, fleets): every pass copies its own
+// slice in before its kernels and its outputs back after them, on the pass's stream -- the H2D of one
+// pass then runs beside the kernels of the other instead of ahead of everything.
+struct HostSide {
+    const sbd_batch_in *in;     // host inputs (NULL members never occur: checked by the callers)
+    const sbd_batch_out *out;   // host outputs; flux / uu / status may each be NULL (not wanted)
+};
+static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, void *hip_stream, const HostSide *hs);
+
 int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, void *hip_stream)
+{
+    return solve_device_impl(e, in, out, hip_stream, nullptr);
+}
+
+static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, void *hip_stream, const HostSide *hs)
 {
     if (!e || !in || !out) return fail(SBD_E_INVALID, "null argument");
     if (in->nwork < 0) return fail(SBD_E_INVALID, "nwork < 0");
@@ -592,6 +606,17 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
         sbd::Params P = second ? e->P2 : e->P;
         st = (fork && second) ? e->aux : st_main;
         int32_t *const eigflag = P.eiglist;
+        if (hs) {   // this pass's inputs, host -> staging
+            const size_t npm = (size_t)L * (e->cfg.nmom + 1);
+            HIP_TRY(hipMemcpyAsync((void *)(in->dtauc + (size_t)w0 * L), hs->in->dtauc + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync((void *)(in->ssalb + (size_t)w0 * L), hs->in->ssalb + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync((void *)(in->pmom + (size_t)w0 * npm), hs->in->pmom + (size_t)w0 * npm, sizeof(double) * ns * npm, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync((void *)(in->wvnmlo + w0), hs->in->wvnmlo + w0, sizeof(double) * ns, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync((void *)(in->wvnmhi + w0), hs->in->wvnmhi + w0, sizeof(double) * ns, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync((void *)(in->fbeam + w0), hs->in->fbeam + w0, sizeof(double) * ns, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync((void *)(in->albedo + w0), hs->in->albedo + w0, sizeof(double) * ns, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync((void *)(in->plank + w0), hs->in->plank + w0, (size_t)ns, hipMemcpyHostToDevice, st));
+        }
         P.nslot = ns;
         P.dtauc = in->dtauc + (size_t)w0 * L;
         P.ssalb = in->ssalb + (size_t)w0 * L;
@@ -616,7 +641,8 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
                 const unsigned g2 = (unsigned)(((size_t)ns * L + gpb2 - 1) / gpb2) * (unsigned)nmode;
                 sbd::launch_layer2(e->nn, rad, g2, e->layer2_lds, st, P, eigflag);
                 flt = eigflag;          // the QR kernel below only redoes the listed layers: a small
-                if (grid > 2048u) grid = 2048u;   // fixed grid walks the list (normally empty)
+                if (grid > 256u) grid = 256u;     // fixed grid (a block per CU) walks the list, normally empty:
+                                                  // its blocks ask for 30 KB of LDS each, so few of them start fast
                 SBD_DBG("layer2");
             }
             sbd::launch_layer_v1(e->G, grid, e->layer_lds, st, P, flt);
@@ -641,6 +667,12 @@ int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_bat
             sbd::launch_azimuth((unsigned)((items + 255) / 256), st, P, e->naz_run);
         }
         hipLaunchKernelGGL(finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, P);
+        if (hs) {   // this pass's outputs, staging -> host
+            const size_t nf = (size_t)SBD_NFLUX * nlev, nu = rad ? (size_t)e->P.nphi * nlev * e->P.numu : 0;
+            if (hs->out->flux) HIP_TRY(hipMemcpyAsync(hs->out->flux + (size_t)w0 * nf, P.flux, sizeof(double) * ns * nf, hipMemcpyDeviceToHost, st));
+            if (rad && hs->out->uu) HIP_TRY(hipMemcpyAsync(hs->out->uu + (size_t)w0 * nu, P.uu, sizeof(double) * ns * nu, hipMemcpyDeviceToHost, st));
+            if (hs->out->status) HIP_TRY(hipMemcpyAsync(hs->out->status + w0, P.status, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, st));
+        }
         if (timing) HIP_TRY(hipEventRecord(e->ev[5], st));
         HIP_TRY(hipGetLastError());
         if (timing) {
@@ -702,18 +734,11 @@ static int solve_host_enqueue(sbd_engine *e, const sbd_batch_in *in, const sbd_b
     double *d_uu = rad ? (double *)take(b_uu) : nullptr;
     int32_t *d_st = (int32_t *)take(sizeof(int32_t) * W);
     hipStream_t st = e->stream;
-    HIP_TRY(hipMemcpyAsync(d_dt, in->dtauc, b_lay, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_ss, in->ssalb, b_lay, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_pm, in->pmom, b_pm, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_lo, in->wvnmlo, b_w, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_hi, in->wvnmhi, b_w, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_fb, in->fbeam, b_w, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_al, in->albedo, b_w, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_pl, in->plank, W, hipMemcpyHostToDevice, st));
     if (weight) HIP_TRY(hipMemcpyAsync(d_wt, weight, b_w, hipMemcpyHostToDevice, st));
     sbd_batch_in din = {in->nwork, d_dt, d_ss, d_pm, d_lo, d_hi, d_fb, d_al, d_pl};
     sbd_batch_out dout = {d_flux, d_uu, d_st};
-    rc = sbd_engine_solve_device(e, &din, &dout, st);
+    const HostSide hs = {in, out};
+    rc = solve_device_impl(e, &din, &dout, st, &hs);   // (each pass stages its slice in and out on its own stream)
     if (rc != SBD_OK) return rc;
     if (weight) {
         const size_t nel_f = (size_t)SBD_NFLUX * nlev, nel_u = rad ? (size_t)e->P.nphi * nlev * e->P.numu : 0;
@@ -725,9 +750,6 @@ static int solve_host_enqueue(sbd_engine *e, const sbd_batch_in *in, const sbd_b
         rc = sbd_engine_accumulate_device(e, in->nwork, d_wt, d_flux, d_uu, e->d_acc, rad ? e->d_acc + nel_f : nullptr, st);
         if (rc != SBD_OK) return rc;
     }
-    if (out->flux) HIP_TRY(hipMemcpyAsync(out->flux, d_flux, b_flux, hipMemcpyDeviceToHost, st));
-    if (rad && out->uu) HIP_TRY(hipMemcpyAsync(out->uu, d_uu, b_uu, hipMemcpyDeviceToHost, st));
-    if (out->status) HIP_TRY(hipMemcpyAsync(out->status, d_st, sizeof(int32_t) * W, hipMemcpyDeviceToHost, st));
     return SBD_OK;
 }
 

@@ -10,8 +10,6 @@ sets=(
  "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_CBRANCH_TAKEN"
  "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA"
  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_IFETCH SQ_LDS_BANK_CONFLICT"
- "FETCH_SIZE"
- "WRITE_SIZE"
 )
 i=0
 for s in "${sets[@]}"; do
