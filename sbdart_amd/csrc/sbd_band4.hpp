@@ -174,7 +174,8 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         if (refl)
             for (int k = 1; k <= nn; ++k) sb = sb + cwt[k - 1] * cmu[k - 1] * albedo * GC(nn + 1 - k, iq1, ncut);
         const double f = (iq1 > nn) ? EK(n + 1 - iq1, ncut) : 1.0;
-        double *bc = bcb + q;
+        // (stored in the quarter layout the rows of every step are read in, see step_rows below)
+        double *bchi = bcb + (q / nn) * (2 * nn * nn) + (q % nn), *bclo = bchi + nn * nn;
 #pragma unroll
         for (int r = 0; r < n; ++r) {
             double g = 0.0;
@@ -183,7 +184,8 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
                 if (refl) g = g - (1.0 + delm0) * sb;
                 g = g * f;
             }
-            bc[r * n] = g;
+            if (r >= nn) bchi[(r - nn) * nn] = g;
+            else bclo[(nn - 1 - r) * nn] = g;
         }
     }
     __threadfence_block();   // B and the boundary block are re-read by this wave as rows enter the window
@@ -213,25 +215,44 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     // right-hand sides as one value per lane (lane r <-> row r) spread by DPP at the hand-over.
     constexpr int E = (n < 4) ? n : 4;
     double bufa[E], bufb[E], rhsn = 0.0;
-    // Step lci < ncut: interface lci's rows are [GC(lci) * fa | GC(lci+1) * fb] (SETMTX, disort.f:2851-2876)
-    // with the STWJ factors fa(j) = EK(n+1-j, lci) for j > nn (else 1), fb(j) = -EK(j, lci+1) for j <= nn
-    // (else -1): the layer kernels leave GC and EK, the scaling happens here when the rows are handed
-    // over.  Step ncut: the boundary block beside zeros, unscaled.  Beyond: valid memory, never used.
-    auto step_rows = [&](int lci, const double *&pa, const double *&pb) {
+    // Step lci < ncut: interface lci's rows are [GC(lci) * fa' | GC(lci+1) * fb'] (SETMTX, disort.f:2851-2876)
+    // with the STWJ factors fa'(j) = EK(n+1-j, lci) for j > nn (else 1), fb'(j) = -EK(j, lci+1) for j <= nn
+    // (else -1).  GC is read from its two independent quarters (Params::gcc: V0(iq,jq) = GC(iq+nn, jq+nn) =
+    // -GC(nn+1-iq, nn+1-jq), V1(iq,jq) = GC(nn+1-iq, jq+nn) = -GC(iq+nn, nn+1-jq), disort.f:3290-3312): a lane
+    // of the upper columns (q >= nn, jq = q-nn+1) reads V0 for the rows r >= nn (iq = r-nn+1) and V1 for the
+    // rows r < nn (iq = nn-r); a lane of the lower columns (jq = nn-q) the other way round with the sign
+    // flipped, which goes into the factor.  So a row r is one load from `hi + (r-nn) nn` or `lo + (nn-1-r) nn`
+    // with per-lane bases -- and the boundary block of step ncut is stored to be read the same way
+    // (beside zeros, unscaled).  Beyond ncut: valid memory, never used.
+    struct RowSrc { const double *hi, *lo; };
+    auto step_rows = [&](int lci, RowSrc &pa, RowSrc &pb) {
         const bool inner = lci < ncut, last = lci == ncut;
-        const int cq = col ? q : 0;
-        pa = inner ? gc + (size_t)(lci - 1) * n * n + cq : (last ? bcb + cq : yv);
-        pb = inner ? gc + (size_t)lci * n * n + cq : (last ? P.t.zeros + cq : yv);
+        const int qq = col ? q : 0;
+        const bool upper = qq >= nn;
+        const int jo = upper ? qq - nn : nn - 1 - qq;                      // jq - 1
+        const double *ca = P.gcc + ((size_t)ms * L + ((lci < L ? lci : L) - 1)) * 2 * nn * nn + jo;
+        const double *cb = P.gcc + ((size_t)ms * L + ((lci + 1 < L ? lci + 1 : L) - 1)) * 2 * nn * nn + jo;
+        const double *bc = bcb + (qq / nn) * (2 * nn * nn) + (qq % nn);
+        const double *zr = P.t.zeros + (qq % nn);
+        pa.hi = inner ? (upper ? ca : ca + nn * nn) : (last ? bc : zr);
+        pa.lo = inner ? (upper ? ca + nn * nn : ca) : (last ? bc + nn * nn : zr);
+        pb.hi = inner ? (upper ? cb : cb + nn * nn) : zr;
+        pb.lo = inner ? (upper ? cb + nn * nn : cb) : zr;
+    };
+    auto row_of = [&](const RowSrc &p, auto rr) -> double {                 // row r (compile time) of a step's block
+        constexpr int r = decltype(rr)::value;
+        if constexpr (r >= nn) return p.hi[(r - nn) * nn];
+        else return p.lo[(nn - 1 - r) * nn];
     };
     auto factor_ptrs = [&](int lci, const double *&pea, const double *&peb) {   // always valid addresses
         const int la = (lci < L) ? lci : L, lb = (lci + 1 < L) ? lci + 1 : L;
         pea = ek + (la - 1) * nn + ((q >= nn && q < n) ? n - q - 1 : 0);
         peb = ek + (lb - 1) * nn + ((q < nn) ? q : 0);
     };
-    auto factors = [&](int lci, double eka, double ekb, double &fa, double &fb) {
+    auto factors = [&](int lci, double eka, double ekb, double &fa, double &fb) {   // (quarter signs folded in)
         const bool inner = lci < ncut;
-        fa = (inner && q >= nn) ? eka : 1.0;
-        fb = inner ? ((q < nn) ? -ekb : -1.0) : 1.0;
+        fa = inner ? ((q >= nn) ? eka : -1.0) : 1.0;
+        fb = inner ? ((q < nn) ? ekb : -1.0) : 1.0;
     };
     const double *pyb = yv + (N - nn) + ((q < nn) ? q : 0);    // bottom-boundary B, lane r <-> row r < nn
     // B of the rows of step lci for lane r <-> row r: an interface (lci < ncut), the bottom boundary, nothing
@@ -240,7 +261,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         return (lci < ncut) ? vi : vl;
     };
     {   // rows of step 1 (exposed once per system)
-        const double *pa, *pb;
+        RowSrc pa, pb;
         step_rows(1, pa, pb);
         const Z3 z1 = load_z(1), z2 = load_z(2);
         const double yq = step_rhs(1, z1, z2, expbea[1], taucpr[1], *pyb);
@@ -248,14 +269,11 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         factor_ptrs(1, pea, peb);
         double fa, fb;
         factors(1, *pea, *peb, fa, fb);
-#pragma unroll
-        for (int r = 0; r < n; ++r) {
-            const double va = pa[r * n], vb = pb[r * n];
-            a0[nn + r] = col ? va * fa : 0.0;
-            a1[nn + r] = col ? vb * fb : 0.0;
-        }
         static_for<n>([&](auto rr) {
             constexpr int r = decltype(rr)::value;
+            const double va = row_of(pa, rr), vb = row_of(pb, rr);
+            a0[nn + r] = col ? va * fa : 0.0;
+            a1[nn + r] = col ? vb * fb : 0.0;
             a2[nn + r] = dbl_lane_bcast<r>(yq);
         });
     }
@@ -263,7 +281,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     // memory operations (vmcnt(0), expcnt/lgkmcnt unconstrained)
     __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int lc = 1; lc <= ncut; ++lc) {
-        const double *pna, *pnb;                                // next step's rows
+        RowSrc pna, pnb;                                        // next step's rows
         step_rows(lc + 1, pna, pnb);
         const int lcb = (lc + 1 < L) ? lc + 1 : L;              // (a valid level index whatever ncut is)
         Z3 zu, zn;                                              // the two layers at interface lc+1
@@ -298,12 +316,12 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             TakeRows<RW, LAST>::run(a0, a1, a2, idxb, t0, t1, t2);
             // register LAST is free from here on: next interface's row LAST - nn moves in
             if constexpr (LAST - nn >= E) {
-                const double va = pna[(LAST - nn) * n], vb = pnb[(LAST - nn) * n];
+                const double va = row_of(pna, std::integral_constant<int, LAST - nn>{}), vb = row_of(pnb, std::integral_constant<int, LAST - nn>{});
                 a0[LAST] = (n == 16 || col) ? va : 0.0;
                 a1[LAST] = (n == 16 || col) ? vb : 0.0;
             }
             if constexpr (J < E) {
-                const double va = pna[J * n], vb = pnb[J * n];
+                const double va = row_of(pna, std::integral_constant<int, J>{}), vb = row_of(pnb, std::integral_constant<int, J>{});
                 bufa[J] = (n == 16 || col) ? va : 0.0;
                 bufb[J] = (n == 16 || col) ? vb : 0.0;
             }
@@ -327,8 +345,9 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             rn = (t0 != 0.0) ? -rn : 0.0;
             if (q == J) { pmin = fmin(pmin, fabs(t0)); pmax = fmax(pmax, fabs(t0)); }
             // (4) the retired row.  U goes out by layer block: row J of the block holds x_lc's columns in
-            //     words 0..n-1 (the finished ones, q < J, carry multipliers nobody reads) and x_lc+1's in
-            //     n..2n-1 -- two aligned 128-byte lines per system, no branches; B(k) is the same in the 16 lanes
+            //     words 0..n-1 (the finished ones, q < J, carry multipliers nobody reads: masking them out
+            //     makes partial-line writes, measured slower) and x_lc+1's in n..2n-1 -- two aligned
+            //     128-byte lines per system, no branches; B(k) is the same in the 16 lanes
             {
                 double *urow = urow0 + J * UW;
                 if (n == 16 || col) {

@@ -68,6 +68,9 @@ struct Params {
     double *yv;             // [ms][L*n] right-hand side / forward-eliminated RHS of the band system
     double *ga, *gb;        // matrix-ready interface blocks (see sbd_band.hpp), [ms][L][n][n] each (absent when gconly)
     double *bcb;            // [ms][n][n] bottom-boundary rows of sbd_band4.hpp (gconly)
+    double *gcc;            // [ms][L][2][nn][nn] (gconly) GC's two independent quarters per layer: GC(iq+nn, jq+nn) = -GC(nn+1-iq,
+                            //   nn+1-jq) = [0][iq-1][jq-1] and GC(nn+1-iq, jq+nn) = -GC(iq+nn, nn+1-jq) = [1][iq-1][jq-1]
+                            //   (disort.f:3290-3312): what sbd_band4.hpp reads -- half the bytes of GC
     double *gu, *zb, *z0u, *z1u, *uum;
     // outputs (offset to the chunk)
     double *flux, *uu; int32_t *status;

@@ -368,7 +368,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     bool band4 = nn <= 8;
     if (const char *s = getenv("SBD_BAND_V1")) band4 = band4 && atoi(s) == 0;
     const size_t nblk = band4 ? 1 : 3;
-    const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n : 0) + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * (2 * n)
+    const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * (2 * n)
                                             + (rad ? (size_t)L * n * numu + 3 * (size_t)L * numu + (size_t)e->nlev * numu : 0));
     const size_t per_slot = per_ms * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
     size_t budget = (size_t)64 << 30;   // of 288 GB: fewer, larger passes (launch tails cost ~7 % at 16k items)
@@ -406,10 +406,12 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         if (band4) {
             P.ga = P.gb = nullptr;
             P.bcb = (double *)take(sizeof(double) * nms * n * n);
+            P.gcc = (double *)take(sizeof(double) * nms * L * 2 * nn * nn);
         } else {
             P.ga = (double *)take(sizeof(double) * nms * L * n * n);
             P.gb = (double *)take(sizeof(double) * nms * L * n * n);
             P.bcb = nullptr;
+            P.gcc = nullptr;
         }
         P.kk = (double *)take(sizeof(double) * nms * L * n);
         P.ek = (double *)take(sizeof(double) * nms * L * nn);
@@ -483,7 +485,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         const size_t half = e->ws_bytes / 2;
         auto mv = [&](auto *&ptr) { if (ptr) ptr = (std::remove_reference_t<decltype(ptr)>)((char *)ptr + half); };
         sbd::Params &Q = e->P2;
-        mv(Q.eiglist); mv(Q.sv); mv(Q.svi); mv(Q.gc); mv(Q.ga); mv(Q.gb); mv(Q.bcb); mv(Q.kk); mv(Q.ek); mv(Q.zz); mv(Q.zp0);
+        mv(Q.eiglist); mv(Q.sv); mv(Q.svi); mv(Q.gc); mv(Q.ga); mv(Q.gb); mv(Q.bcb); mv(Q.gcc); mv(Q.kk); mv(Q.ek); mv(Q.zz); mv(Q.zp0);
         mv(Q.zp1); mv(Q.ll); mv(Q.yv); mv(Q.ufac); mv(Q.gu); mv(Q.zb); mv(Q.z0u); mv(Q.z1u); mv(Q.uum);
         CREATE_TRY(hipMemset(Q.eiglist, 0, sizeof(int32_t) * ((size_t)e->chunk * e->nmode * e->L + 4)));
     }

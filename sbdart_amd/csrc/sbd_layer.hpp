@@ -264,6 +264,11 @@ __global__ void __launch_bounds__(64) layer_kernel(Params P, int32_t *only_flagg
             EVC(iq + nn, me) = e21;
             EVC(iq, me + nn) = e12;
             EVC(iq + nn, me + nn) = e22;
+            if (P.gconly) {                       // GC's two independent quarters for sbd_band4.hpp
+                double *cc = P.gcc + ((size_t)ms * L + (lc - 1)) * 2 * nn * nn + (size_t)(iq - 1) * nn + (me - 1);
+                cc[0] = e11;
+                cc[nn * nn] = e21;
+            }
             gcout[(iq + nn - 1) * n + (me + nn - 1)] = e11;
             gcout[(nn + 1 - iq - 1) * n + (me + nn - 1)] = e21;
             gcout[(iq + nn - 1) * n + (nn + 1 - me - 1)] = e12;

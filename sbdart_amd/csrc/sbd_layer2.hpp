@@ -377,8 +377,9 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         // straight from registers: this lane owns columns me+nn (k > 0) and nn+1-me (k < 0) of
         // every row, nn lanes write nn consecutive doubles per instruction.  GC itself is only
         // read back for the layers FLUXES / the boundary rows / USRINT need.
-        // (gconly: sbd_band4.hpp scales GC by the STWJ factors itself, so GC is all that leaves -- half the bytes)
-        bool need_gc = P.gconly || rad || P.all_levels || lc == 1 || lc == svi[SBD_SVI_NCUT];
+        // (gconly: sbd_band4.hpp scales GC by the STWJ factors itself and only needs GC's two independent
+        //  quarters, Params::gcc -- a quarter of the bytes of ga + gb)
+        bool need_gc = rad || P.all_levels || lc == 1 || lc == svi[SBD_SVI_NCUT];
         if (!need_gc) {
             const int32_t *layru = svi + SBD_SVI_LAYRU;
             for (int i = 0; i < P.nlev; ++i) need_gc = need_gc || layru[P.t.level_out[i]] == lc;
@@ -386,13 +387,18 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         double *gcout = P.gc + lidx * n * n;
         const int ja = me + nn - 1, jb = nn - me;          // 0-based columns
         if (P.gconly) {
+            double *cc0 = P.gcc + lidx * 2 * nn * nn + (me - 1), *cc1 = cc0 + nn * nn;
 #pragma unroll
             for (int iq = 1; iq <= nn; ++iq) {
                 const double gpp = gp[iq - 1], gmm = xcol[iq - 1];
                 const double vua = 0.5 * (gpp + gmm), vda = 0.5 * (gpp - gmm);   // rows iq+nn, nn+1-iq of column ja
-                const int ru = (iq + nn - 1) * n, rd = (nn - iq) * n;
-                gcout[ru + ja] = vua;  gcout[rd + ja] = vda;
-                gcout[ru + jb] = -vda; gcout[rd + jb] = -vua;
+                cc0[(iq - 1) * nn] = vua;
+                cc1[(iq - 1) * nn] = vda;
+                if (need_gc) {
+                    const int ru = (iq + nn - 1) * n, rd = (nn - iq) * n;
+                    gcout[ru + ja] = vua;  gcout[rd + ja] = vda;
+                    gcout[ru + jb] = -vda; gcout[rd + jb] = -vua;
+                }
             }
         } else {
             double *gaout = P.ga + lidx * n * n, *gbout = P.gb + lidx * n * n;
