@@ -203,6 +203,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     bad = int((status != 0).sum().item())
+    if not bool(torch.isfinite(flux).all().item()):
+        sys.exit("bench.py: non-finite fluxes -- refusing to report a rate for wrong answers")
 
     # ---- per-kernel timing pass (HIP events on the launch stream), outside the timed region ----
     eng.enable_timing(True)

@@ -616,11 +616,10 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     {
         const int nfirst = (N < RW) ? N : RW;
         for (int r = 1; r <= nfirst; ++r) {
-            for (int c = lane; c < CW; c += 64) {      // window columns 1..CW at start
-                double g, f;
-                entry(r, c + 1, g, f);
-                win[(r - 1) * CWP + ((c + 1) % CW)] = g * f;
-            }
+            // (row_elem, not entry(): the interface rows come from the ga/gb blocks -- GC itself is only
+            //  written for the layers the boundary rows and the output levels need)
+            for (int c = lane; c < CW; c += 64)        // window columns 1..CW at start
+                win[(r - 1) * CWP + ((c + 1) % CW)] = row_elem(r, c + 1);
         }
         wave_lds_sync();
     }

@@ -198,6 +198,28 @@ def test_level_selection_and_accumulate():
         assert np.allclose(acc, ref, rtol=1e-13, atol=0)
 
 
+@pytest.mark.parametrize("nstr", [8, 16, 20, 24, 32])
+def test_level_selection_for_every_band_kernel(nstr):
+    """Two output levels (TOA, surface: what IOUT 1/10 ask for) instead of all of them, through every band
+    LU variant (four-per-wave NSTR <= 16, register window <= 20, LDS window above): GC is then only kept
+    for the layers that need it, and the answers must not change.  (NSTR > 20 used to build its first
+    window rows from GC of layers that had not been kept.)"""
+    import pyoracle
+    from sbdart_amd.engine import solve_records
+    from sbdart_amd.workload import sw_sweep, sweep_to_records
+    sw = sw_sweep(nwl=48, nstr=nstr, nlyr=33, seed=4242)
+    recs = sweep_to_records(sw, range(0, sw.nwork, 7))
+    outs = [pyoracle.disort(r) for r in recs]
+    f_all, _, st_all = solve_records(recs)
+    f_two, _, st_two = solve_records(recs, level_out=[0, 33])
+    assert st_all == st_two == [o["status"] for o in outs]
+    for fa, ft, o in zip(f_all, f_two, outs):
+        assert np.array_equal(ft[:, 0], fa[:, 0]) and np.array_equal(ft[:, 1], fa[:, -1])
+        for c, name in enumerate(FLUX):
+            sc = max(np.abs(o[name]).max(), 1e-300)
+            assert np.abs(fa[c] - o[name]).max() <= TOL * sc, (nstr, name)
+
+
 def test_full_size_properties():
     """BASELINE.json's batch (2^17-ish solves, nstr=16, 33 layers): determinism, linearity in
     FBEAM for the non-thermal items, direct-beam closed form, and a random sample vs the oracle."""
