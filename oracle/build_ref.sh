@@ -11,6 +11,8 @@
 #                                the level altitudes/pressures (absint call site) beside the records
 #   oracle/_ref/disort_ref_cli   reference DISORT behind a record-file CLI
 #                                (oracle/ref/sbd_ref_cli.f90)
+#   oracle/_ref/libsbdart_ref.so the reference's routines as a shared library (ctypes: table extraction,
+#                                band-model unit parity)
 #   oracle/_ref/ref_units_cli    single reference routines (QGAUSN, PLKAVG, ASYMTX,
 #                                LEPOLY, SGBCO/SGBSL) behind a CLI (oracle/ref/sbd_ref_units.f90)
 #
@@ -52,4 +54,15 @@ done
 # --- individual reference routines behind a CLI (unit pinning) ---
 "$FC" $FFLAGS -c "$HERE/ref/sbd_ref_units.f90" -o sbd_ref_units.o
 "$FC" $FFLAGS -o "$OUT/ref_units_cli" sbd_ref_units.o disort.o disutil.o params.o
+# --- the reference as a shared library (position-independent objects of the same sources): single
+#     routines (atms, absint, taugas, gasset, rayleigh, solirr ...) are called through ctypes by
+#     tools/extract_tables.py and by the band-model parity tests ---
+mkdir -p "$OUT/pic"
+( cd "$OUT/pic"
+  for f in params tauaero taugas spectra taucloud atms disutil disort drt; do
+    if [ ! -f $f.o ] || [ "$REF/$f.f" -nt $f.o ]; then
+      "$FC" $FFLAGS -fPIC -ffixed-form -w -c "$REF/$f.f" -o $f.o
+    fi
+  done
+  "$FC" -shared -o "$OUT/libsbdart_ref.so" params.o tauaero.o taugas.o spectra.o taucloud.o atms.o disutil.o disort.o drt.o )
 echo "built: $(ls "$OUT" | grep -v obj | tr '\n' ' ')"

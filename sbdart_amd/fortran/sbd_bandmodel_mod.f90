@@ -1,0 +1,216 @@
+! From &INPUT to the per-(wavelength, k-term) work items of the engine: the step in front of the hot
+! path (SURVEY 8f row N1; reference drt.f:297-347, 425-533 with rayleigh spectra.f:179-247, solirr
+! spectra.f:1367-1415, normom drt.f:1366-1380, depthscl taugas.f:7512-7648).  First slice: clear sky
+! (gases + Rayleigh) over a Lambertian surface of constant albedo; what it does not cover yet is refused
+! by name (clouds, aerosols, spectral surface albedos, sensor filters, regridding, user atmosphere) and
+! still runs from an optics file the reference produced (sbd_io_mod).  Literals: see sbd_tables_mod.
+module sbd_bandmodel_mod
+  use sbd_grid_mod, only: kr, unset, spectral_grid, nstrms
+  use sbd_io_mod, only: optics_t, fatal
+  use sbd_tables_mod
+  use sbd_atmos_mod
+  use sbd_gas_mod
+  implicit none
+  private
+  public :: model_input, covered_by_band_model, build_work_items
+
+  type model_input                     ! the &INPUT variables this step reads, same names
+    integer :: idatm = 4, nf = 2, isalb = 0, kdist = 3, nothrm = -1, isat = 0, ngrid = 0, iaer = 0, nstr = 4
+    real(kr) :: amix = unset, sza = 0, solfac = 1, albcon = 0, xrsc = 1, zpres = unset, pbar = unset, &
+                sclh2o = unset, uw = unset, uo3 = unset, o3trp = unset, ztrp = 0, xgas(11) = unset, xo4 = 1, &
+                btemp = unset, ttemp = unset, temis = 0, fisot = 0, phi0 = 0
+    logical :: clouds = .false., strat_aerosol = .false., spowder = .false., radiance = .false.
+    integer :: numu = 0, nphi = 0
+  end type
+
+contains
+
+  ! .true. when every switch of the run is inside the first slice; otherwise why not
+  logical function covered_by_band_model(m, why) result(ok)
+    type(model_input), intent(in) :: m
+    character(len=*), intent(out) :: why
+    why = ''
+    if (m%idatm == 0 .or. m%amix /= unset) why = 'user atmosphere (atms.dat)'
+    if (m%ngrid /= 0) why = 'vertical regridding (ngrid)'
+    if (m%clouds) why = 'clouds'
+    if (m%iaer /= 0 .or. m%strat_aerosol) why = 'aerosols'
+    if (m%isalb /= 0) why = 'spectral / BRDF surface (isalb)'
+    if (m%isat /= 0) why = 'sensor filter functions (isat)'
+    if (m%kdist < 0) why = 'k-distribution files (kdist=-1)'
+    if (m%nf < 0) why = 'solar spectrum file (nf<0)'
+    if (m%spowder) why = 'sub-surface layer (spowder)'
+    ok = len_trim(why) == 0
+  end function
+
+  ! Rayleigh optical depth of every layer (1 = top, which is the column above the highest level taken with
+  ! a 5 km scale height); density-weighted slabs between the levels (spectra.f:179-247)
+  subroutine rayleigh_depths(wl, a, dtaur)
+    real(kr), intent(in) :: wl
+    type(atmosphere), intent(in) :: a
+    real(kr), intent(out) :: dtaur(a%nz)
+    real(kr), parameter :: fit1 = 9.38076e+18, fit2 = -1.08426e+09
+    real(kr) :: v, sig, lower, upper, dz
+    integer :: i, lev, nz
+    nz = a%nz
+    v = 10000./wl
+    sig = v**4/(fit1 + fit2*v**2)
+    dtaur(1) = sig*(a%p(nz)/pzero)/(a%t(nz)/tzero)*5.
+    do i = 2, nz
+      lev = nz - i + 1
+      lower = (a%p(lev)/pzero)/(a%t(lev)/tzero)
+      upper = (a%p(lev + 1)/pzero)/(a%t(lev + 1)/tzero)
+      dz = a%z(lev + 1) - a%z(lev)
+      if (lower == upper) then
+        dtaur(i) = .5*sig*dz*(lower + upper)
+      else
+        dtaur(i) = sig*dz*(upper - lower)/log(upper/lower)
+      end if
+    end do
+  end subroutine
+
+  ! extraterrestrial solar irradiance (W/m2/um) at wl, linear in the spectrum's own grid (spectra.f:1367-1415)
+  real(kr) function solar_irradiance(wl, nf) result(e)
+    real(kr), intent(in) :: wl
+    integer, intent(in) :: nf
+    real(kr), pointer :: w(:), s(:)
+    character(len=4) :: name
+    real(kr) :: wt
+    integer :: j
+    if (nf == 0) then
+      e = 1.
+      return
+    end if
+    write(name, '(a,i1)') 'sun', nf
+    w => tbl(name//'.wl'); s => tbl(name//'.irr')
+    j = bracket(w, wl)
+    wt = (wl - w(j))/(w(j + 1) - w(j))
+    wt = max(0._kr, min(1._kr, wt))
+    e = s(j)*(1. - wt) + s(j + 1)*wt
+  end function
+
+  ! weight that fades the slant-path correction out: with wavelength across 3.9-4.1 um (thermal emission
+  ! takes over from the sun) and with scattering optical depth above 1 (taugas.f:7625-7647)
+  pure real(kr) function correction_weight(wl, tsc) result(ramp)
+    real(kr), intent(in) :: wl, tsc
+    real(kr), parameter :: wllo = 3.9, wlhi = 4.1
+    ramp = (wlhi - wl)/(wlhi - wllo)
+    ramp = max(min(1._kr, ramp), 0._kr)
+    ramp = ramp*exp(1. - max(tsc, 1._kr))
+  end function
+
+  subroutine build_work_items(m, grid, umu, phi, recs, nrec, atm)
+    type(model_input), intent(in) :: m
+    type(spectral_grid), intent(in) :: grid
+    real(kr), intent(in) :: umu(:), phi(:)
+    type(optics_t), allocatable, intent(out) :: recs(:)
+    integer, intent(out) :: nrec
+    type(atmosphere), intent(out) :: atm
+    type(trace_gases) :: mix
+    type(gas_spectrum) :: spec
+    type(optics_t) :: r
+    real(kr), allocatable :: uu(:, :), dtaur(:), dtauk(:, :), dtaugc(:), dtaug(:), temper(:), scat(:), pm2(:)
+    real(kr) :: pbar, amu0, wl, wvlo, wvhi, dwl, flxin, rsfc, gwk(mk), wt, tsc, tglv, tgls, afac, ramp, btemp, ttemp
+    real(kr), parameter :: dtor = 3.1415926536_kr/180.
+    integer :: nz, nmom, iwl, nk, kd, i
+    logical :: plank
+
+    ! ---- once per run: profiles, rescaling, absorber amounts (drt.f:297-347) ----
+    atm = model_atmosphere(m%idatm)
+    nz = atm%nz
+    pbar = m%pbar
+    if (m%zpres /= unset) pbar = pressure_at(atm, m%zpres)
+    call rescale_profiles(atm, m%sclh2o, m%uw, m%uo3, m%o3trp, m%ztrp, pbar)
+    call set_trace_gases(mix, m%xgas, m%xo4)
+    allocate(uu(mxq, nz), dtaur(nz), dtauk(nz, 2*mk), dtaugc(nz), dtaug(nz), temper(0:nz), scat(nz), pm2(nz))
+    call absorber_columns(atm, mix, uu)
+    temper(0) = atm%t(nz)
+    do i = 1, nz
+      temper(i) = atm%t(nz + 1 - i)
+    end do
+    btemp = m%btemp; if (btemp < 0.) btemp = temper(nz)
+    ttemp = m%ttemp; if (ttemp < 0.) ttemp = temper(0)
+    nmom = min(m%nstr + 2, nstrms)
+    amu0 = cos(m%sza*dtor)
+    rsfc = max(0._kr, min(m%albcon, 1._kr))
+
+    allocate(recs(3*grid%n))
+    nrec = 0
+    do iwl = 1, grid%n
+      call grid%band(iwl - 1, wl, wvlo, wvhi)
+      spec = spectrum_at(wl, mix%xo4)
+      call gas_terms(m%kdist, spec, uu, amu0, atm%z, nz, nk, gwk, dtauk, dtaugc)
+      dwl = 10000./wvlo - 10000./wvhi
+      flxin = solar_irradiance(wl, m%nf)*dwl*m%solfac
+      if (m%nf == 0) flxin = dwl
+      if (m%sza >= 90.) then          ! no sun: from here on the gas terms are those of a vertical path
+        flxin = 0.
+        amu0 = 1.
+      end if
+      if (m%nothrm < 0) then
+        plank = wl > 2.
+      else
+        plank = m%nothrm == 0
+      end if
+      call rayleigh_depths(wl, atm, dtaur)
+      if (m%xrsc /= 1._kr) dtaur = m%xrsc*dtaur
+      ! phase-function moments of the scattering mixture; Rayleigh alone: 1, 0, 0.1 (drt.f:1366-1380)
+      scat = dtaur
+      pm2 = .1*dtaur
+      where (scat /= 0.) pm2 = pm2/scat
+
+      do kd = 1, nk
+        ! ---- gas depth of this k-term with the slant-path correction policy KDIST (depthscl) ----
+        wt = gwk(kd)
+        if (m%kdist == 0 .or. nk == 1) then
+          wt = 1.
+          tsc = 0.; tglv = 0.; tgls = 0.
+          do i = 1, nz
+            tglv = tglv + dtauk(i, 1)
+            tgls = tgls + dtauk(i, 1 + mk)
+            tsc = tsc + dtaur(i)
+            afac = 1.
+            if (tglv > .001) afac = tgls/tglv
+            ramp = correction_weight(wl, tsc)
+            afac = afac*ramp + 1. - ramp
+            dtaug(i) = dtaugc(i) + dtauk(i, 1)*afac
+          end do
+        else if (m%kdist == 1) then
+          dtaug = dtaugc + dtauk(:, kd)
+        else if (m%kdist == 2) then
+          dtaug = dtaugc + dtauk(:, kd + mk)
+        else
+          tsc = 0.
+          do i = 1, nz
+            tsc = tsc + dtaur(i)
+            ramp = correction_weight(wl, tsc)
+            dtaug(i) = dtaugc(i) + dtauk(i, kd)*(1. - ramp) + dtauk(i, kd + mk)*ramp
+          end do
+        end if
+        ! ---- the work item ----
+        r%nlyr = nz; r%nstr = m%nstr; r%nmom = nmom; r%numu = size(umu); r%nphi = size(phi)
+        r%flags = merge(1, 0, plank) + merge(0, 2, m%radiance)
+        r%kd = kd; r%nk = nk; r%iwl = iwl
+        r%wl = wl; r%wt = wt; r%ff = 1.; r%wvnmlo = wvlo; r%wvnmhi = wvhi; r%fbeam = flxin
+        r%umu0 = amu0; r%phi0 = m%phi0; r%albedo = rsfc; r%btemp = btemp; r%ttemp = ttemp
+        r%temis = m%temis; r%fisot = m%fisot
+        if (.not. allocated(r%dtauc)) allocate(r%dtauc(nz), r%ssalb(nz), r%temper(0:nz), r%pmom(0:nmom, nz), &
+                                               r%umu(size(umu)), r%phi(size(phi)))
+        r%temper = temper; r%umu = umu; r%phi = phi
+        r%pmom = 0.
+        r%pmom(0, :) = 1.
+        r%pmom(2, :) = pm2
+        do i = 1, nz
+          r%dtauc(i) = dtaug(i) + 0._kr + 0._kr + dtaur(i)
+          if (r%dtauc(i) > tiny(1._kr)) then
+            r%ssalb(i) = (0._kr + 0._kr + dtaur(i))/r%dtauc(i)
+          else
+            r%ssalb(i) = 0.
+          end if
+        end do
+        nrec = nrec + 1
+        recs(nrec) = r
+      end do
+    end do
+  end subroutine
+
+end module sbd_bandmodel_mod

@@ -5,7 +5,7 @@ module sbd_io_mod
   use sbd_grid_mod, only: kr
   implicit none
   private
-  public :: optics_t, read_optics, read_atmosphere, warn_file, fatal
+  public :: optics_t, read_optics, write_optics, read_atmosphere, warn_file, fatal
 
   type optics_t      ! one (wavelength, k-term) work item as handed to DISORT (drt.f:541-546)
     integer :: nlyr, nstr, nmom, numu, nphi, flags, kd, nk, iwl
@@ -71,6 +71,27 @@ contains
         call move_alloc(tmp, recs)
       end if
       recs(nrec) = r
+    end do
+    close(u)
+  end subroutine
+
+  ! the work items as an input-only SBDREC1 file (what read_optics reads)
+  subroutine write_optics(path, recs, nrec)
+    character(len=*), intent(in) :: path
+    type(optics_t), intent(in) :: recs(:)
+    integer, intent(in) :: nrec
+    integer :: u, i, hdr(12)
+    real(kr) :: sc(16)
+    open(newunit=u, file=path, access='stream', form='unformatted', status='replace')
+    write(u) 'SBDREC1'//achar(0), nrec, 0
+    do i = 1, nrec
+      hdr = 0; sc = 0
+      hdr(1:9) = (/recs(i)%nlyr, recs(i)%nstr, recs(i)%nmom, recs(i)%numu, recs(i)%nphi, recs(i)%flags, &
+                   recs(i)%kd, recs(i)%nk, recs(i)%iwl/)
+      sc(1:13) = (/recs(i)%wl, recs(i)%wt, recs(i)%ff, recs(i)%wvnmlo, recs(i)%wvnmhi, recs(i)%fbeam, recs(i)%umu0, &
+                   recs(i)%phi0, recs(i)%albedo, recs(i)%btemp, recs(i)%ttemp, recs(i)%temis, recs(i)%fisot/)
+      write(u) hdr, sc
+      write(u) recs(i)%dtauc, recs(i)%ssalb, recs(i)%temper, recs(i)%pmom, recs(i)%umu, recs(i)%phi
     end do
     close(u)
   end subroutine

@@ -9,18 +9,22 @@
 ! the per-run output formats take stdout1's weighted sums from the engine's reduction (one
 ! RCCL reduce between GPUs), the per-wavelength formats sum the <= 3 k-terms of a point here.
 !
-! Scope note (SURVEY.md 8f N1): the band model that turns &INPUT into per-wavelength
-! optical depths (taugas/tauaero/taucloud/spectra/atms) is not part of this round; the
-! per-work-item optical properties are read from an "SBDREC1" optics file
-! (environment SBD_OPTICS, default ./OPTICS.sbdrec) with exactly the DISORT arguments
-! drt.f:541-546 passes.  Everything downstream of that -- engine, retry of NSTR,
-! accumulation, output formats -- is this program.
+! The per-work-item optical properties (exactly the DISORT arguments drt.f:541-546 passes) come from
+! the band model of this host (sbd_bandmodel_mod: model atmospheres, LOWTRAN7 gases with the 3-term
+! k-distribution, Rayleigh, solar spectrum -- SURVEY.md 8f N1, first slice: clear sky over a surface of
+! constant albedo) or, for what that slice does not cover yet (clouds, aerosols, spectral surfaces,
+! sensor filters), from an "SBDREC1" optics file the reference produced (environment SBD_OPTICS,
+! default ./OPTICS.sbdrec; an optics file, when present, always wins).  Everything downstream of that
+! -- engine, retry of NSTR, accumulation, output formats -- is this program.
 program sbdart_amd
   use iso_c_binding
   use sbd_engine_mod
   use sbd_grid_mod
   use sbd_io_mod
   use sbd_output_mod
+  use sbd_atmos_mod, only: atmosphere
+  use sbd_bandmodel_mod
+  use sbd_tables_mod, only: tables_load
   implicit none
   integer, parameter :: ncldz = 5, naerz = 5, naerb = 150, maxmom = 299, ndb = 20
   ! ---- &INPUT / &DINPUT (drt.f:200-215), same names, same defaults where they matter ----
@@ -63,6 +67,10 @@ program sbdart_amd
   integer, allocatable :: order(:)
   real(kr), allocatable :: zlev(:), plev(:)
   integer :: stall
+  type(model_input) :: model
+  type(atmosphere) :: atm
+  logical :: have_file, ok
+  character(len=256) :: why
 
   ! ---- read ./INPUT exactly like drt.f:220-231 ----
   open(newunit=u11, file='INPUT', status='old', iostat=ios)
@@ -84,20 +92,55 @@ program sbdart_amd
   if (radcalc) view = new_view(iout, nphi, phi, nzen, uzen, vzen)
   phi0 = mod(saza - 180.0_kr + 360.0_kr, 360.0_kr)      ! drt.f:283
 
-  ! ---- per-work-item optical properties (stand-in for gasset/taucloud/tauaero/rayleigh) ----
+  ! ---- solar geometry (drt.f:275-283) ----
+  if (iday /= 0) call fatal('IDAY (solar ephemeris) is outside the hot path: give SZA')
+  if (csza /= unset) sza = acos(csza)/(real(3.1415926536d0, kr)/180.)
+  if (abs(sza - 90) < .01) sza = 95.
+  grid = new_grid(wlinf, wlsup, wlinc)
+
+  ! ---- per-work-item optical properties: optics file if there is one, else the band model ----
   call get_environment_variable('SBD_OPTICS', path, plen, pstat)
   if (pstat /= 0 .or. plen <= 0) path = 'OPTICS.sbdrec'
-  call read_optics(trim(path), recs, nrec)
-  if (nrec < 1) call fatal('optics file holds no work items')
-  nz = recs(1)%nlyr
+  inquire(file=trim(path), exist=have_file)
+  if (have_file) then
+    call read_optics(trim(path), recs, nrec)
+    if (nrec < 1) call fatal('optics file holds no work items')
+    nz = recs(1)%nlyr
+    allocate(zlev(nz), plev(nz))
+    call get_environment_variable('SBD_ATMOS', path, plen, pstat)
+    if (pstat /= 0 .or. plen <= 0) path = 'ATMOS.sbdatm'
+    call read_atmosphere(trim(path), nz, zlev, plev, have_atm)
+  else
+    model%idatm = idatm; model%nf = nf; model%isalb = isalb; model%kdist = kdist; model%nothrm = nothrm
+    model%isat = isat; model%ngrid = ngrid; model%iaer = iaer; model%nstr = nstr
+    model%amix = amix; model%sza = sza; model%solfac = solfac; model%albcon = albcon; model%xrsc = xrsc
+    model%zpres = zpres; model%pbar = pbar; model%sclh2o = sclh2o; model%uw = uw; model%uo3 = uo3
+    model%o3trp = o3trp; model%ztrp = ztrp
+    model%xgas = (/xn2, xo2, xco2, xch4, xn2o, xco, xno2, xso2, xnh3, xno, xhno3/)
+    model%xo4 = xo4; model%btemp = btemp; model%ttemp = ttemp; model%temis = temis; model%fisot = fisot
+    model%phi0 = phi0
+    model%clouds = any(tcloud /= 0._kr) .or. any(lwp /= 0._kr) .or. nre(1) == 0._kr
+    model%strat_aerosol = any(jaer /= 0)
+    model%spowder = spowder; model%radiance = radcalc
+    if (.not. covered_by_band_model(model, why)) &
+      call fatal('no optics file ('//trim(path)//') and the band model does not cover this run yet: '//trim(why))
+    call tables_load(ok, why)
+    if (.not. ok) call fatal('band-model tables not found; tried'//trim(why))
+    call viewing_cosines()
+    call build_work_items(model, grid, umu(1:numu), phiv(1:merge(view%nphi, 0, radcalc)), recs, nrec, atm)
+    nz = atm%nz
+    allocate(zlev(nz), plev(nz))
+    zlev = atm%z; plev = atm%p
+    have_atm = .true.
+  end if
   nmom = recs(1)%nmom
-  allocate(zlev(nz), plev(nz))
-  call get_environment_variable('SBD_ATMOS', path, plen, pstat)
-  if (pstat /= 0 .or. plen <= 0) path = 'ATMOS.sbdatm'
-  call read_atmosphere(trim(path), nz, zlev, plev, have_atm)
+  call get_environment_variable('SBD_DUMP_OPTICS', path, plen, pstat)      ! the work items, for inspection / tests
+  if (pstat == 0 .and. plen > 0) then
+    call write_optics(trim(path), recs, nrec)
+    stop
+  end if
 
   ! the spectral grid of INPUT must be the one the optics were made for (wllimits, drt.f:1657-1740)
-  grid = new_grid(wlinf, wlsup, wlinc)
   do i = 1, nrec
     if (recs(i)%iwl < 1 .or. recs(i)%iwl > grid%n) call fatal('optics record outside the spectral grid of INPUT')
     call grid%band(recs(i)%iwl - 1, wl, wvlo, wvhi)
@@ -130,18 +173,7 @@ program sbdart_amd
     lev_top = 1; lev_bot = 2
   end if
 
-  numu = 0
-  if (radcalc) then                                   ! drt.f:391-403: ascending cosines, never exactly 0
-    numu = view%nzen
-    allocate(umu(numu), phiv(view%nphi))
-    do j = 1, numu
-      umu(j) = min(1._kr, max(cos(view%uzen(numu + 1 - j)*(real(3.1415926536d0, kr)/180._kr)), -1._kr))
-      if (umu(j) == 0._kr) umu(j) = merge(-real(.0001, kr), real(.0001, kr), j == numu)
-    end do
-    phiv = view%phi(1:view%nphi)
-  else
-    allocate(umu(1), phiv(1))
-  end if
+  if (.not. allocated(umu)) call viewing_cosines()
 
   ! ---- batch arrays (row-major by work item == Fortran's first index fastest).  Items the filter
   !      function removes (ff = 0) are not solved (drt.f:461-462); items with a beam come first so
@@ -257,6 +289,21 @@ program sbdart_amd
   end if
 
 contains
+
+  subroutine viewing_cosines()                         ! drt.f:391-403: ascending cosines, never exactly 0
+    numu = 0
+    if (radcalc) then
+      numu = view%nzen
+      allocate(umu(numu), phiv(view%nphi))
+      do j = 1, numu
+        umu(j) = min(1._kr, max(cos(view%uzen(numu + 1 - j)*(real(3.1415926536d0, kr)/180._kr)), -1._kr))
+        if (umu(j) == 0._kr) umu(j) = merge(-real(.0001, kr), real(.0001, kr), j == numu)
+      end do
+      phiv = view%phi(1:view%nphi)
+    else
+      allocate(umu(1), phiv(1))
+    end if
+  end subroutine
 
   ! The reference's input screening (chkin, drt.f:568-728): out-of-range namelist values are reported
   ! with its messages and stop the run; two combinations only warn (errmsg 16/17).  One rule per line:
