@@ -1,8 +1,8 @@
 ! From &INPUT to the per-(wavelength, k-term) work items of the engine: the step in front of the hot
 ! path (SURVEY 8f row N1; reference drt.f:297-347, 425-533 with rayleigh spectra.f:179-247, solirr
-! spectra.f:1367-1415, normom drt.f:1366-1380, depthscl taugas.f:7512-7648).  First slice: clear sky
-! (gases + Rayleigh) over a Lambertian surface of constant albedo; what it does not cover yet is refused
-! by name (clouds, aerosols, spectral surface albedos, sensor filters, regridding, user atmosphere) and
+! spectra.f:1367-1415, normom drt.f:1366-1380, depthscl taugas.f:7512-7648).  Covered: gases, Rayleigh
+! and clouds over a Lambertian surface of constant albedo; what it does not cover yet is refused
+! by name (aerosols, spectral surface albedos, sensor filters, regridding, user atmosphere) and
 ! still runs from an optics file the reference produced (sbd_io_mod).  Literals: see sbd_tables_mod.
 module sbd_bandmodel_mod
   use sbd_grid_mod, only: kr, unset, spectral_grid, nstrms
@@ -10,6 +10,7 @@ module sbd_bandmodel_mod
   use sbd_tables_mod
   use sbd_atmos_mod
   use sbd_gas_mod
+  use sbd_cloud_mod
   implicit none
   private
   public :: model_input, covered_by_band_model, build_work_items
@@ -19,7 +20,9 @@ module sbd_bandmodel_mod
     real(kr) :: amix = unset, sza = 0, solfac = 1, albcon = 0, xrsc = 1, zpres = unset, pbar = unset, &
                 sclh2o = unset, uw = unset, uo3 = unset, o3trp = unset, ztrp = 0, xgas(11) = unset, xo4 = 1, &
                 btemp = unset, ttemp = unset, temis = 0, fisot = 0, phi0 = 0
-    logical :: clouds = .false., strat_aerosol = .false., spowder = .false., radiance = .false.
+    real(kr) :: zcloud(ncldz) = 0, tcloud(ncldz) = 0, lwp(ncldz) = 0, nre(ncldz) = 8, rhcld = unset
+    integer :: imomc = 3
+    logical :: strat_aerosol = .false., spowder = .false., radiance = .false.
     integer :: numu = 0, nphi = 0
   end type
 
@@ -32,7 +35,8 @@ contains
     why = ''
     if (m%idatm == 0 .or. m%amix /= unset) why = 'user atmosphere (atms.dat)'
     if (m%ngrid /= 0) why = 'vertical regridding (ngrid)'
-    if (m%clouds) why = 'clouds'
+    if (m%nre(1) == 0.) why = 'user cloud file (usrcld.dat, nre=0)'
+    if (m%rhcld >= 0.) why = 'water vapour saturation inside clouds (rhcld)'
     if (m%iaer /= 0 .or. m%strat_aerosol) why = 'aerosols'
     if (m%isalb /= 0) why = 'spectral / BRDF surface (isalb)'
     if (m%isat /= 0) why = 'sensor filter functions (isat)'
@@ -108,7 +112,9 @@ contains
     type(trace_gases) :: mix
     type(gas_spectrum) :: spec
     type(optics_t) :: r
-    real(kr), allocatable :: uu(:, :), dtaur(:), dtauk(:, :), dtaugc(:), dtaug(:), temper(:), scat(:), pm2(:)
+    type(cloud_deck) :: deck
+    real(kr), allocatable :: dtauc(:), wcld(:), pmom(:, :)
+    real(kr), allocatable :: uu(:, :), dtaur(:), dtauk(:, :), dtaugc(:), dtaug(:), temper(:), scat(:)
     real(kr) :: pbar, amu0, wl, wvlo, wvhi, dwl, flxin, rsfc, gwk(mk), wt, tsc, tglv, tgls, afac, ramp, btemp, ttemp
     real(kr), parameter :: dtor = 3.1415926536_kr/180.
     integer :: nz, nmom, iwl, nk, kd, i
@@ -121,7 +127,7 @@ contains
     if (m%zpres /= unset) pbar = pressure_at(atm, m%zpres)
     call rescale_profiles(atm, m%sclh2o, m%uw, m%uo3, m%o3trp, m%ztrp, pbar)
     call set_trace_gases(mix, m%xgas, m%xo4)
-    allocate(uu(mxq, nz), dtaur(nz), dtauk(nz, 2*mk), dtaugc(nz), dtaug(nz), temper(0:nz), scat(nz), pm2(nz))
+    allocate(uu(mxq, nz), dtaur(nz), dtauk(nz, 2*mk), dtaugc(nz), dtaug(nz), temper(0:nz), scat(nz))
     call absorber_columns(atm, mix, uu)
     temper(0) = atm%t(nz)
     do i = 1, nz
@@ -132,6 +138,8 @@ contains
     nmom = min(m%nstr + 2, nstrms)
     amu0 = cos(m%sza*dtor)
     rsfc = max(0._kr, min(m%albcon, 1._kr))
+    deck = new_cloud_deck(atm%z, m%zcloud, m%tcloud, m%lwp, m%nre, m%imomc)
+    allocate(dtauc(nz), wcld(nz), pmom(0:nmom, nz))
 
     allocate(recs(3*grid%n))
     nrec = 0
@@ -153,10 +161,17 @@ contains
       end if
       call rayleigh_depths(wl, atm, dtaur)
       if (m%xrsc /= 1._kr) dtaur = m%xrsc*dtaur
-      ! phase-function moments of the scattering mixture; Rayleigh alone: 1, 0, 0.1 (drt.f:1366-1380)
-      scat = dtaur
-      pm2 = .1*dtaur
-      where (scat /= 0.) pm2 = pm2/scat
+      ! clouds, then the phase-function moments of the scattering mixture: every scatterer adds moment x
+      ! scattering depth, Rayleigh 0.1 in the second moment; normalised by the total (drt.f:1366-1380)
+      pmom = 0.
+      dtauc = 0.; wcld = 0.
+      if (deck%nslot > 0) call cloud_depths(deck, wl, nz, nmom, dtauc, wcld, pmom)
+      do i = 1, nz
+        pmom(2, i) = pmom(2, i) + .1*dtaur(i)
+        scat(i) = dtauc(i)*wcld(i) + 0._kr + dtaur(i)
+        if (scat(i) /= 0.) pmom(:, i) = pmom(:, i)/scat(i)
+      end do
+      pmom(0, :) = 1.
 
       do kd = 1, nk
         ! ---- gas depth of this k-term with the slant-path correction policy KDIST (depthscl) ----
@@ -167,7 +182,7 @@ contains
           do i = 1, nz
             tglv = tglv + dtauk(i, 1)
             tgls = tgls + dtauk(i, 1 + mk)
-            tsc = tsc + dtaur(i)
+            tsc = tsc + dtaur(i) + dtauc(i) + 0._kr
             afac = 1.
             if (tglv > .001) afac = tgls/tglv
             ramp = correction_weight(wl, tsc)
@@ -181,7 +196,7 @@ contains
         else
           tsc = 0.
           do i = 1, nz
-            tsc = tsc + dtaur(i)
+            tsc = tsc + dtaur(i) + dtauc(i) + 0._kr
             ramp = correction_weight(wl, tsc)
             dtaug(i) = dtaugc(i) + dtauk(i, kd)*(1. - ramp) + dtauk(i, kd + mk)*ramp
           end do
@@ -196,13 +211,11 @@ contains
         if (.not. allocated(r%dtauc)) allocate(r%dtauc(nz), r%ssalb(nz), r%temper(0:nz), r%pmom(0:nmom, nz), &
                                                r%umu(size(umu)), r%phi(size(phi)))
         r%temper = temper; r%umu = umu; r%phi = phi
-        r%pmom = 0.
-        r%pmom(0, :) = 1.
-        r%pmom(2, :) = pm2
+        r%pmom = pmom
         do i = 1, nz
-          r%dtauc(i) = dtaug(i) + 0._kr + 0._kr + dtaur(i)
+          r%dtauc(i) = dtaug(i) + dtauc(i) + 0._kr + dtaur(i)
           if (r%dtauc(i) > tiny(1._kr)) then
-            r%ssalb(i) = (0._kr + 0._kr + dtaur(i))/r%dtauc(i)
+            r%ssalb(i) = (dtauc(i)*wcld(i) + 0._kr + dtaur(i))/r%dtauc(i)
           else
             r%ssalb(i) = 0.
           end if

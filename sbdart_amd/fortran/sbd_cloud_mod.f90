@@ -1,0 +1,197 @@
+! Cloud layers and their optical properties per wavelength (reference: zlayer drt.f:1268-1310, levrng
+! and taucloud taucloud.f:10-140, cloudpar taucloud.f:344-6768, GETMOM disutil.f:2104-2209).
+! Part of SURVEY 8f row N1.  A cloud is given by up to five slots (ZCLOUD, TCLOUD or LWP, NRE): a slot
+! with a positive altitude is a cloud in the layer that holds it; when the NEXT slot's altitude is
+! negative the cloud extends up to that altitude, effective radius interpolated geometrically and the
+! optical depth (or water path) distributed with a linear gradient.  Literals: see sbd_tables_mod.
+module sbd_cloud_mod
+  use sbd_grid_mod, only: kr
+  use sbd_tables_mod
+  implicit none
+  private
+  public :: cloud_deck, new_cloud_deck, cloud_depths, phase_moments, layers_of_altitudes, ncldz
+
+  integer, parameter :: ncldz = 5                    ! cloud slots (params.f:12)
+  real(kr), parameter :: wl55 = 0.55                 ! wavelength TCLOUD is quoted at (params.f:27)
+
+  type cloud_deck
+    integer :: nslot = 0                             ! slots in use
+    integer :: layer(ncldz) = 0                      ! layer (1 = top) of each slot, negative = "extends up to"
+    real(kr) :: tcloud(ncldz) = 0, lwp(ncldz) = 0, nre(ncldz) = 8
+    integer :: imomc = 3
+  end type
+
+contains
+
+  ! layers (1 = top; layer k lies above level nz+1-k) that hold the altitudes zz; a negative altitude
+  ! after the first marks the upper end of an extended layer and gives a negative layer number
+  subroutine layers_of_altitudes(z, zz, lz)
+    real(kr), intent(in) :: z(:), zz(:)
+    integer, intent(out) :: lz(:)
+    real(kr) :: zc
+    integer :: k, j, nz, sgn
+    nz = size(z)
+    do k = 1, size(zz)
+      sgn = 1
+      if (k == 1) then
+        zc = zz(k) + .001
+      else
+        if (zz(k) < 0.) sgn = -1
+        zc = abs(zz(k) + .001)
+      end if
+      j = nz
+      do while (j >= 1)
+        if (z(j) <= zc) exit
+        j = j - 1
+      end do
+      if (j < 1) sgn = 0
+      lz(k) = sgn*(nz - j + 1)
+    end do
+  end subroutine
+
+  function new_cloud_deck(z, zcloud, tcloud, lwp, nre, imomc) result(c)
+    real(kr), intent(in) :: z(:), zcloud(ncldz), tcloud(ncldz), lwp(ncldz), nre(ncldz)
+    integer, intent(in) :: imomc
+    type(cloud_deck) :: c
+    integer :: k
+    do k = 1, ncldz                                   ! the last slot that carries an optical depth or water path
+      if (tcloud(k) /= 0. .or. lwp(k) /= 0.) c%nslot = k
+    end do
+    c%tcloud = tcloud; c%lwp = lwp; c%nre = nre; c%imomc = imomc
+    if (c%nslot > 0) call layers_of_altitudes(z, zcloud(1:c%nslot), c%layer(1:c%nslot))
+  end function
+
+  ! extinction efficiency, single-scattering albedo and asymmetry factor of a droplet (re > 0) or ice
+  ! particle (re < 0) distribution: bilinear in ln(wavelength) x log2(radius) (taucloud.f:6726-6768)
+  subroutine mie_lookup(wl, re, qc, wc, gc)
+    real(kr), intent(in) :: wl, re
+    real(kr), intent(out) :: qc, wc, gc
+    real(kr), parameter :: wlmin = 0.29, wlmax = 333.33, eps = .000001
+    integer, parameter :: mxwv = 400, mre = 13
+    real(kr), pointer :: q(:), w(:), g(:)
+    real(kr) :: wmin, wstep, fw, fr
+    integer :: iw, ir
+    wmin = log(wlmin)
+    wstep = (log(wlmax) - wmin)/(mxwv - 1)
+    fw = 1 + (log(wl) - wmin)/wstep
+    fw = min(max(fw, 1._kr), float(mxwv) - eps)
+    iw = int(fw)
+    fw = fw - iw
+    fr = 1. + ((log(abs(re)))/log(2.) - 1.)*2
+    fr = min(max(fr, 1._kr), float(mre) - eps)
+    ir = int(fr)
+    fr = fr - ir
+    if (re < 0.) then
+      q => tbl('cloud.qi'); w => tbl('cloud.wi'); g => tbl('cloud.gi')
+    else
+      q => tbl('cloud.q'); w => tbl('cloud.w'); g => tbl('cloud.g')
+    end if
+    qc = bilinear(q); wc = bilinear(w); gc = bilinear(g)
+  contains
+    real(kr) function bilinear(t) result(v)
+      real(kr), intent(in) :: t(:)
+      integer :: k
+      k = iw + (ir - 1)*mxwv
+      v = t(k)*(1. - fw)*(1. - fr) + t(k + 1)*fw*(1. - fr) + t(k + mxwv)*(1. - fw)*fr + t(k + mxwv + 1)*fw*fr
+    end function
+  end subroutine
+
+  ! Legendre moments 0..nmom of the phase-function families of GETMOM: 1 isotropic, 2 Rayleigh,
+  ! 3 Henyey-Greenstein(gg), 4 haze L, 5 cloud C.1
+  subroutine phase_moments(iphas, gg, nmom, pm)
+    integer, intent(in) :: iphas, nmom
+    real(kr), intent(in) :: gg
+    real(kr), intent(out) :: pm(0:nmom)
+    real(kr), pointer :: t(:)
+    integer :: k
+    pm = 0.0
+    pm(0) = 1.0
+    select case (iphas)
+    case (2)
+      pm(2) = 0.1
+    case (3)
+      do k = 1, nmom
+        pm(k) = gg**k
+      end do
+    case (4)
+      t => tbl('pmom.haze_l')
+      do k = 1, min(82, nmom)
+        pm(k) = t(k)/(2*k + 1)
+      end do
+    case (5)
+      t => tbl('pmom.cloud_c1')
+      do k = 1, min(298, nmom)
+        pm(k) = t(k)/(2*k + 1)
+      end do
+    end select
+  end subroutine
+
+  ! optical depth, single-scattering albedo of the cloud in every layer at wavelength wl, and the cloud's
+  ! part of the un-normalised phase-function moments (moment x scattering optical depth) ADDED to pmom
+  subroutine cloud_depths(c, wl, nz, nmom, taucld, wcld, pmom)
+    type(cloud_deck), intent(in) :: c
+    real(kr), intent(in) :: wl
+    integer, intent(in) :: nz, nmom
+    real(kr), intent(out) :: taucld(nz), wcld(nz)
+    real(kr), intent(inout) :: pmom(0:nmom, nz)
+    real(kr), parameter :: rhoice = .917
+    real(kr) :: pm(0:nmom), reff, tcld, lwpth, wt, qc, wc, gc, q550, w550, g550
+    integer :: cnt(nz), i, j, k, lbot, ltop
+    taucld = 0.; wcld = 0.; cnt = 0
+    do i = 1, c%nslot
+      if (c%layer(i) <= 0) cycle                      ! not the base of a cloud
+      lbot = c%layer(i)
+      ltop = lbot
+      if (i /= ncldz) then
+        if (c%layer(i + 1) < 0) ltop = -c%layer(i + 1)
+      end if
+      if (c%tcloud(i) == 0. .and. c%lwp(i) == 0.) cycle
+      do j = ltop, lbot
+        if (ltop == lbot) then
+          reff = c%nre(i); tcld = c%tcloud(i); lwpth = c%lwp(i)
+        else
+          wt = float(j - ltop)/(lbot - ltop)
+          reff = c%nre(i + 1)*(c%nre(i)/c%nre(i + 1))**wt
+          tcld = spread_over(c%tcloud(i), c%tcloud(i + 1))
+          lwpth = spread_over(c%lwp(i), c%lwp(i + 1))
+        end if
+        call mie_lookup(wl, reff, qc, wc, gc)
+        call phase_moments(c%imomc, gc, nmom, pm)
+        pmom(1:nmom, j) = pm(1:nmom) + pmom(1:nmom, j)
+        wcld(j) = wc + wcld(j)
+        cnt(j) = 1 + cnt(j)
+        if (c%tcloud(i) /= 0.) then                   ! optical depth given at 0.55 um: scale with the efficiency
+          call mie_lookup(wl55, reff, q550, w550, g550)
+          taucld(j) = tcld*qc/q550 + taucld(j)
+        else if (lwpth /= 0.) then                    ! water path (g/m2) and radius (um): tau = 3 Q LWP / (4 r rho)
+          if (reff < 0.) then
+            taucld(j) = -.75*qc*lwpth/reff/rhoice + taucld(j)
+          else
+            taucld(j) = .75*qc*lwpth/reff + taucld(j)
+          end if
+        end if
+      end do
+    end do
+    do j = 1, nz
+      if (cnt(j) /= 0) then
+        wcld(j) = wcld(j)/cnt(j)
+        do k = 1, nmom
+          pmom(k, j) = taucld(j)*wcld(j)*pmom(k, j)/cnt(j)
+        end do
+      end if
+    end do
+  contains
+    ! share of layer j of a total spread over layers ltop..lbot; grad (the next slot's value) is the ratio
+    ! of the bottom layer's share to the top layer's, 0 = uniform
+    real(kr) function spread_over(total, grad) result(part)
+      real(kr), intent(in) :: total, grad
+      if (grad == 0.) then
+        part = total/(lbot - ltop + 1)
+      else
+        part = 2*total/((lbot - ltop + 1)*(1. + grad))
+        part = part + (lbot - j)*part*(grad - 1.)/(lbot - ltop)
+      end if
+    end function
+  end subroutine
+
+end module sbd_cloud_mod

@@ -119,7 +119,8 @@ program sbdart_amd
     model%xgas = (/xn2, xo2, xco2, xch4, xn2o, xco, xno2, xso2, xnh3, xno, xhno3/)
     model%xo4 = xo4; model%btemp = btemp; model%ttemp = ttemp; model%temis = temis; model%fisot = fisot
     model%phi0 = phi0
-    model%clouds = any(tcloud /= 0._kr) .or. any(lwp /= 0._kr) .or. nre(1) == 0._kr
+    model%zcloud = zcloud; model%tcloud = tcloud; model%lwp = lwp; model%nre = nre; model%rhcld = rhcld
+    model%imomc = imomc
     model%strat_aerosol = any(jaer /= 0)
     model%spowder = spowder; model%radiance = radcalc
     if (.not. covered_by_band_model(model, why)) &

@@ -1,4 +1,4 @@
-"""Band model of the Fortran host (first slice: clear sky) against the reference.
+"""Band model of the Fortran host (gases, Rayleigh, clouds) against the reference.
 
 The work items `sbdart_amd` assembles from `INPUT` alone (model atmosphere -> absorber amounts ->
 LOWTRAN7 continua + band model -> 3-term k-distribution with slant-path correction -> Rayleigh ->
@@ -9,7 +9,7 @@ solar spectrum) must be the DISORT arguments the reference passes at drt.f:541-5
 * against the reference run live (oracle/_ref/sbdart_capture -- the binary travels with the snapshot)
   over the switches of the slice: every model atmosphere, the KDIST policies, water / ozone /
   pressure rescaling, trace-gas mixing ratios, the three solar spectra, no-sun thermal runs, the three
-  kinds of spectral grid.
+  kinds of spectral grid, clouds (optical depth or water path, droplets or ice, extended layers).
 
 Bar: 1e-12 relative on every optical depth, single-scattering albedo, moment, flux and band edge
 (VERDICT item 8); measured: bit-identical.  No GPU: `SBD_DUMP_OPTICS` stops the host before the engine.
@@ -108,6 +108,15 @@ VARIANTS = [
     "idatm=1 wlinf=8 wlsup=14 wlinc=.05 nf=0 nothrm=1 sza=10 iout=1",
     "idatm=4 wlinf=.55 wlsup=.55 sza=30 albcon=.2 iout=10",
     "idatm=6 wlinf=.2 wlsup=.26 wlinc=.0005 sza=0 iout=1 xo2=150000 xn2=850000",
+    # clouds: single layer, TestRuns examples 2-3 and BASELINE configs[2]; water path; ice; extended layers
+    "tcloud=8 albcon=.2 idatm=4 isat=0 wlinf=.55 wlsup=.55 isalb=0 iout=10 sza=30",
+    "tcloud=5 zcloud=8 nre=10 idatm=4 sza=95 wlinf=4 wlsup=20 wlinc=-.01 iout=1",
+    "idatm=6 wlinf=4 wlsup=80 wlinc=-.01 nstr=16 tcloud=10 zcloud=1 nre=8 sza=95 iout=1",
+    "idatm=2 wlinf=.4 wlsup=2.4 wlinc=.05 lwp=120 zcloud=2 nre=12 sza=40 iout=1",
+    "idatm=2 wlinf=.4 wlsup=12 wlinc=-.05 tcloud=1.5 zcloud=9 nre=-40 sza=40 iout=1 imomc=4",
+    "idatm=1 wlinf=.5 wlsup=3 wlinc=.1 tcloud=12,3 zcloud=1,-4 nre=6,14 sza=20 iout=1 nstr=8",
+    "idatm=1 wlinf=.5 wlsup=3 wlinc=.1 lwp=200,50 zcloud=2,5 nre=8,-20 sza=20 iout=1 imomc=5 nstr=12",
+    "idatm=3 wlinf=.6 wlsup=1.6 wlinc=.1 tcloud=4,1,2 zcloud=1,-3,10 nre=8,10,-30 sza=55 iout=1",
 ]
 
 
@@ -124,7 +133,7 @@ def test_work_items_equal_live_reference(tmp_path, namelist):
 
 @needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
-    for namelist, word in (("tcloud=5 zcloud=1", "clouds"), ("iaer=1", "aerosols"), ("isalb=4", "surface"),
+    for namelist, word in (("tcloud=5 nre=0", "cloud"), ("iaer=1", "aerosols"), ("isalb=4", "surface"),
                            ("isat=3", "filter"), ("ngrid=50", "regridding")):
         d = str(tmp_path / word)
         os.makedirs(d)

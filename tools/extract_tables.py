@@ -115,6 +115,14 @@ def main():
     for g in ("alt", "n2", "o2", "co2", "ch4", "n2o", "co", "no2", "so2", "nh3", "no", "hno3"):
         static("mix." + g, "_QMtrcblkE" + g, "taugas.f:6834-6937")
 
+    # ---- clouds: Mie efficiency / single-scattering albedo / asymmetry on 400 log-spaced wavelengths x
+    #      13 effective radii, water and ice (cloudpar, taucloud.f:344-6768); tabulated phase-function
+    #      moments of GETMOM (disutil.f:2104-2209) ----
+    for key, sym in (("q", "qq"), ("w", "ww"), ("g", "gg"), ("qi", "qqi"), ("wi", "wwi"), ("gi", "ggi")):
+        static("cloud." + key, "_QFcloudparE" + sym, "taucloud.f:398-6725, [400 wavelengths][13 radii] column-major")
+    static("pmom.haze_l", "_QFgetmomEhazelm", "disutil.f:2109-2124")
+    static("pmom.cloud_c1", "_QFgetmomEcldmom", "disutil.f:2125-2162")
+
     # ---- model atmospheres: the reference's profile routines, called (atms.f:660-1068) ----
     dp = ctypes.POINTER(ctypes.c_double)
     for idatm, fn in enumerate(("tropic_", "midsum_", "midwin_", "subsum_", "subwin_", "us62_"), start=1):
