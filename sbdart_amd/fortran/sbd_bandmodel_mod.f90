@@ -1,12 +1,12 @@
 ! From &INPUT to the per-(wavelength, k-term) work items of the engine: the step in front of the hot
 ! path (SURVEY 8f row N1; reference drt.f:297-347, 425-533 with rayleigh spectra.f:179-247, solirr
 ! spectra.f:1367-1415, normom drt.f:1366-1380, depthscl taugas.f:7512-7648).  Covered: gases, Rayleigh
-! and clouds over a Lambertian surface of constant albedo; what it does not cover yet is refused
-! by name (aerosols, spectral surface albedos, sensor filters, regridding, user atmosphere) and
+! and clouds over a Lambertian surface (constant albedo, the six standard spectra or their mixture); what it does not cover yet is refused
+! by name (aerosols, BRDF surfaces, sensor filters, regridding, user atmosphere) and
 ! still runs from an optics file the reference produced (sbd_io_mod).  Literals: see sbd_tables_mod.
 module sbd_bandmodel_mod
   use sbd_grid_mod, only: kr, unset, spectral_grid, nstrms
-  use sbd_io_mod, only: optics_t, fatal
+  use sbd_io_mod, only: optics_t, fatal, warn_file
   use sbd_tables_mod
   use sbd_atmos_mod
   use sbd_gas_mod
@@ -22,6 +22,7 @@ module sbd_bandmodel_mod
                 btemp = unset, ttemp = unset, temis = 0, fisot = 0, phi0 = 0
     real(kr) :: zcloud(ncldz) = 0, tcloud(ncldz) = 0, lwp(ncldz) = 0, nre(ncldz) = 8, rhcld = unset
     integer :: imomc = 3
+    real(kr) :: sc(5) = (/1._kr, 0._kr, 0._kr, 0._kr, 0._kr/)   ! ISALB=10: fractions of snow, ocean, sand, vegetation
     logical :: strat_aerosol = .false., spowder = .false., radiance = .false.
     integer :: numu = 0, nphi = 0
   end type
@@ -38,7 +39,7 @@ contains
     if (m%nre(1) == 0.) why = 'user cloud file (usrcld.dat, nre=0)'
     if (m%rhcld >= 0.) why = 'water vapour saturation inside clouds (rhcld)'
     if (m%iaer /= 0 .or. m%strat_aerosol) why = 'aerosols'
-    if (m%isalb /= 0) why = 'spectral / BRDF surface (isalb)'
+    if (.not. (m%isalb >= 0 .and. m%isalb <= 6) .and. m%isalb /= 10) why = 'albedo file / BRDF surface (isalb)'
     if (m%isat /= 0) why = 'sensor filter functions (isat)'
     if (m%kdist < 0) why = 'k-distribution files (kdist=-1)'
     if (m%nf < 0) why = 'solar spectrum file (nf<0)'
@@ -92,6 +93,50 @@ contains
     e = s(j)*(1. - wt) + s(j + 1)*wt
   end function
 
+  ! albedo spectrum of the surface: ISALB 0 constant, 1-6 snow / clear water / lake water / sea water /
+  ! sand / vegetation, 10 a mixture of snow, sea water, sand and vegetation (suralb, spectra.f:61-118)
+  subroutine surface_spectrum(isalb, albcon, sc, wlalb, alb)
+    integer, intent(in) :: isalb
+    real(kr), intent(in) :: albcon, sc(5)
+    real(kr), allocatable, intent(out) :: wlalb(:), alb(:)
+    character(len=4) :: name
+    select case (isalb)
+    case (0)
+      wlalb = (/0._kr, huge(0._kr)/)
+      alb = (/albcon, albcon/)
+    case (1:6)
+      write(name, '(a,i1)') 'alb', isalb
+      wlalb = tbl(name//'.wl'); alb = tbl(name//'.r')
+    case (10)
+      wlalb = tbl('alb6.wl')
+      alb = tbl('alb1.r')*sc(1)
+      alb = tbl('alb4.r')*sc(2) + alb
+      alb = tbl('alb5.r')*sc(3) + alb
+      alb = tbl('alb6.r')*sc(4) + alb
+    end select
+  end subroutine
+
+  ! albedo at wl, linear in the spectrum's grid; outside it the end value, with the reference's warning 18
+  real(kr) function surface_albedo(wlalb, alb, wl) result(r)
+    real(kr), intent(in) :: wlalb(:), alb(:), wl
+    character(len=9) :: num
+    real(kr) :: wt
+    integer :: j, n
+    n = size(wlalb)
+    if (wl < wlalb(1)) then
+      write(num, '(f9.3)') wlalb(1)
+      call warn_file(18, 'SALBEDO--spectral range error, wlinf lt '//num)
+    end if
+    if (wl > wlalb(n)) then
+      write(num, '(f9.3)') wlalb(n)
+      call warn_file(18, 'SALBEDO--spectral range error, wlsup gt '//num)
+    end if
+    j = bracket(wlalb, wl)
+    wt = (wl - wlalb(j))/(wlalb(j + 1) - wlalb(j))
+    wt = max(0._kr, min(1._kr, wt))
+    r = alb(j)*(1. - wt) + alb(j + 1)*wt
+  end function
+
   ! weight that fades the slant-path correction out: with wavelength across 3.9-4.1 um (thermal emission
   ! takes over from the sun) and with scattering optical depth above 1 (taugas.f:7625-7647)
   pure real(kr) function correction_weight(wl, tsc) result(ramp)
@@ -113,7 +158,7 @@ contains
     type(gas_spectrum) :: spec
     type(optics_t) :: r
     type(cloud_deck) :: deck
-    real(kr), allocatable :: dtauc(:), wcld(:), pmom(:, :)
+    real(kr), allocatable :: dtauc(:), wcld(:), pmom(:, :), wlalb(:), alb(:)
     real(kr), allocatable :: uu(:, :), dtaur(:), dtauk(:, :), dtaugc(:), dtaug(:), temper(:), scat(:)
     real(kr) :: pbar, amu0, wl, wvlo, wvhi, dwl, flxin, rsfc, gwk(mk), wt, tsc, tglv, tgls, afac, ramp, btemp, ttemp
     real(kr), parameter :: dtor = 3.1415926536_kr/180.
@@ -137,7 +182,7 @@ contains
     ttemp = m%ttemp; if (ttemp < 0.) ttemp = temper(0)
     nmom = min(m%nstr + 2, nstrms)
     amu0 = cos(m%sza*dtor)
-    rsfc = max(0._kr, min(m%albcon, 1._kr))
+    call surface_spectrum(m%isalb, m%albcon, m%sc, wlalb, alb)
     deck = new_cloud_deck(atm%z, m%zcloud, m%tcloud, m%lwp, m%nre, m%imomc)
     allocate(dtauc(nz), wcld(nz), pmom(0:nmom, nz))
 
@@ -159,6 +204,7 @@ contains
       else
         plank = m%nothrm == 0
       end if
+      rsfc = max(0._kr, min(surface_albedo(wlalb, alb, wl), 1._kr))
       call rayleigh_depths(wl, atm, dtaur)
       if (m%xrsc /= 1._kr) dtaur = m%xrsc*dtaur
       ! clouds, then the phase-function moments of the scattering mixture: every scatterer adds moment x

@@ -121,6 +121,8 @@ program sbdart_amd
     model%phi0 = phi0
     model%zcloud = zcloud; model%tcloud = tcloud; model%lwp = lwp; model%nre = nre; model%rhcld = rhcld
     model%imomc = imomc
+    where (sc == huge(0.)) sc = (/1._kr, 0._kr, 0._kr, 0._kr, 0._kr/)          ! drt.f:249-262
+    model%sc = sc
     model%strat_aerosol = any(jaer /= 0)
     model%spowder = spowder; model%radiance = radcalc
     if (.not. covered_by_band_model(model, why)) &

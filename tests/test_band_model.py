@@ -116,6 +116,12 @@ VARIANTS = [
     "idatm=2 wlinf=.4 wlsup=12 wlinc=-.05 tcloud=1.5 zcloud=9 nre=-40 sza=40 iout=1 imomc=4",
     "idatm=1 wlinf=.5 wlsup=3 wlinc=.1 tcloud=12,3 zcloud=1,-4 nre=6,14 sza=20 iout=1 nstr=8",
     "idatm=1 wlinf=.5 wlsup=3 wlinc=.1 lwp=200,50 zcloud=2,5 nre=8,-20 sza=20 iout=1 imomc=5 nstr=12",
+    # surfaces: TestRuns examples 4-5 (vegetation, sea water), snow beyond its spectral range, a mixture
+    "tcloud=8 nre=16 wlinf=2.16 wlsup=2.16 idatm=1 isat=0 isalb=6 iout=10 sza=0",
+    "tcloud=5 zcloud=1 wlinf=.72 wlsup=.72 idatm=1 isalb=4 sza=60 iout=1 nstr=20",
+    "idatm=5 isalb=1 wlinf=.3 wlsup=4.6 wlinc=.1 sza=65 iout=1",
+    "idatm=2 isalb=10 sc=.1,.2,.3,.4 wlinf=.4 wlsup=2.5 wlinc=.07 sza=35 iout=1",
+    "idatm=2 isalb=5 wlinf=.4 wlsup=2.5 wlinc=.07 sza=35 iout=1",
     "idatm=3 wlinf=.6 wlsup=1.6 wlinc=.1 tcloud=4,1,2 zcloud=1,-3,10 nre=8,10,-30 sza=55 iout=1",
 ]
 
@@ -133,7 +139,7 @@ def test_work_items_equal_live_reference(tmp_path, namelist):
 
 @needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
-    for namelist, word in (("tcloud=5 nre=0", "cloud"), ("iaer=1", "aerosols"), ("isalb=4", "surface"),
+    for namelist, word in (("tcloud=5 nre=0", "cloud"), ("iaer=1", "aerosols"), ("isalb=7", "surface"),
                            ("isat=3", "filter"), ("ngrid=50", "regridding")):
         d = str(tmp_path / word)
         os.makedirs(d)

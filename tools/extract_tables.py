@@ -142,6 +142,15 @@ def main():
         tables.append(("sun%d.wl" % nf, wl[:n].copy(), "output of `%s` (spectra.f:1417-3238)" % fn))
         tables.append(("sun%d.irr" % nf, irr[:n].copy(), "output of `%s`" % fn))
 
+    # ---- spectral albedo of the six standard surfaces on their own grids (spectra.f:2899-3238) ----
+    for isalb, fn in enumerate(("snow_", "clearw_", "lakew_", "seaw_", "sand_", "vegeta_"), start=1):
+        nna = ctypes.c_int(5000)
+        wl, alb = np.zeros(8192), np.zeros(8192)
+        getattr(lib, fn)(wl.ctypes.data_as(dp), alb.ctypes.data_as(dp), ctypes.byref(nna))
+        n = nna.value
+        tables.append(("alb%d.wl" % isalb, wl[:n].copy(), "output of `%s` (spectra.f:2899-3238)" % fn))
+        tables.append(("alb%d.r" % isalb, alb[:n].copy(), "output of `%s`" % fn))
+
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "wb") as f:
         f.write(b"SBDTBL1\0")
