@@ -8,13 +8,14 @@ module sbd_atmos_mod
   implicit none
   private
   public :: atmosphere, model_atmosphere, rescale_profiles, pressure_at, trace_gases, set_trace_gases, &
-            absorber_columns, bracket, nearest_index, relative_humidity
+            absorber_columns, bracket, nearest_index, relative_humidity, regrid
 
   type atmosphere                     ! levels bottom-up: index 1 is the surface
     integer :: nz = 0
     real(kr), allocatable :: z(:), p(:), t(:), wh(:), wo(:)    ! km, mb, K, g/m3 water vapour, g/m3 ozone
   end type
 
+  integer, parameter :: mxly_levels = 65            ! most levels of a run (params.f:9)
   integer, parameter :: ngas = 11     ! n2 o2 co2 ch4 n2o co no2 so2 nh3 no hno3
   character(len=4), parameter :: gas_name(ngas) = &
     (/'n2  ', 'o2  ', 'co2 ', 'ch4 ', 'n2o ', 'co  ', 'no2 ', 'so2 ', 'nh3 ', 'no  ', 'hno3'/)
@@ -70,6 +71,60 @@ contains
     allocate(a%z(n), a%p(n), a%t(n), a%wh(n), a%wo(n))
     a%z = t(1:n); a%p = t(n + 1:2*n); a%t = t(2*n + 1:3*n); a%wh = t(3*n + 1:4*n); a%wo = t(4*n + 1:5*n)
   end function
+
+  ! NGRID /= 0: |ngrid| levels between the surface and the model top, spacing zgrid1 at the bottom,
+  ! zgrid2 at the top, stretched by a power law in between; pressure and (positive) densities
+  ! interpolated logarithmically, temperature linearly (zgrid, atms.f:505-575)
+  subroutine regrid(a, zgrid1, zgrid2, ngrid)
+    type(atmosphere), intent(inout) :: a
+    real(kr), intent(in) :: zgrid1, zgrid2
+    integer, intent(in) :: ngrid
+    real(kr), parameter :: tol = 0.99
+    type(atmosphere) :: b
+    real(kr) :: span, beta, toprat, x, ztop, fz
+    integer :: ng, i, j, jj, nz
+    nz = a%nz
+    ng = min(mxly_levels, abs(ngrid))
+    span = zgrid1*float(ng - 1)
+    ztop = a%z(nz)
+    if (span >= ztop) then
+      span = ztop
+      beta = 0.
+    else
+      span = min(span, tol*(ztop - zgrid2))
+      toprat = float(ng - 2)/(ng - 1)
+      beta = log(((ztop - zgrid2)/(toprat*span) - 1.)/(ztop/span - 1.))/log(toprat)
+    end if
+    b%nz = ng
+    allocate(b%z(ng), b%p(ng), b%t(ng), b%wh(ng), b%wo(ng))
+    j = 2
+    do i = 1, ng
+      x = float(i - 1)/float(ng - 1)
+      b%z(i) = span*x*(1. + (ztop/span - 1.)*x**beta)
+      jj = j
+      do while (jj <= nz)                    ! first old level at or above the new one, never going back down
+        if (b%z(i) <= a%z(jj)) exit
+        jj = jj + 1
+      end do
+      j = min(jj, nz)
+      fz = (b%z(i) - a%z(j - 1))/(a%z(j) - a%z(j - 1))
+      fz = min(max(fz, 0._kr), 1._kr)
+      b%p(i) = a%p(j - 1)*(a%p(j)/a%p(j - 1))**fz
+      b%t(i) = a%t(j - 1)*(1. - fz) + a%t(j)*fz
+      b%wh(i) = density_between(a%wh(j - 1), a%wh(j))
+      b%wo(i) = density_between(a%wo(j - 1), a%wo(j))
+    end do
+    a = b
+  contains
+    real(kr) function density_between(d1, d2) result(d)
+      real(kr), intent(in) :: d1, d2
+      if (min(d2, d1) > 0.) then
+        d = d1*(d2/d1)**fz
+      else
+        d = d1*(1. - fz) + d2*fz
+      end if
+    end function
+  end subroutine
 
   ! pressure at altitude zq, log-interpolated between the levels around it (drt.f:305-309)
   real(kr) function pressure_at(a, zq) result(pq)

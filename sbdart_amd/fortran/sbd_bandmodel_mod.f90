@@ -2,7 +2,7 @@
 ! path (SURVEY 8f row N1; reference drt.f:297-347, 425-533 with rayleigh spectra.f:179-247, solirr
 ! spectra.f:1367-1415, normom drt.f:1366-1380, depthscl taugas.f:7512-7648).  Covered: gases, Rayleigh
 ! and clouds over a Lambertian surface (constant albedo, the six standard spectra or their mixture); what it does not cover yet is refused
-! by name (aerosols, BRDF surfaces, sensor filters, regridding, user atmosphere) and
+! by name (aerosols, BRDF surfaces, sensor filters, user atmosphere) and
 ! still runs from an optics file the reference produced (sbd_io_mod).  Literals: see sbd_tables_mod.
 module sbd_bandmodel_mod
   use sbd_grid_mod, only: kr, unset, spectral_grid, nstrms
@@ -22,6 +22,7 @@ module sbd_bandmodel_mod
                 btemp = unset, ttemp = unset, temis = 0, fisot = 0, phi0 = 0
     real(kr) :: zcloud(ncldz) = 0, tcloud(ncldz) = 0, lwp(ncldz) = 0, nre(ncldz) = 8, rhcld = unset
     integer :: imomc = 3
+    real(kr) :: zgrid1 = 1, zgrid2 = 30
     real(kr) :: sc(5) = (/1._kr, 0._kr, 0._kr, 0._kr, 0._kr/)   ! ISALB=10: fractions of snow, ocean, sand, vegetation
     logical :: strat_aerosol = .false., spowder = .false., radiance = .false.
     integer :: numu = 0, nphi = 0
@@ -35,7 +36,6 @@ contains
     character(len=*), intent(out) :: why
     why = ''
     if (m%idatm == 0 .or. m%amix /= unset) why = 'user atmosphere (atms.dat)'
-    if (m%ngrid /= 0) why = 'vertical regridding (ngrid)'
     if (m%nre(1) == 0.) why = 'user cloud file (usrcld.dat, nre=0)'
     if (m%rhcld >= 0.) why = 'water vapour saturation inside clouds (rhcld)'
     if (m%iaer /= 0 .or. m%strat_aerosol) why = 'aerosols'
@@ -167,6 +167,7 @@ contains
 
     ! ---- once per run: profiles, rescaling, absorber amounts (drt.f:297-347) ----
     atm = model_atmosphere(m%idatm)
+    if (m%ngrid /= 0) call regrid(atm, m%zgrid1, m%zgrid2, m%ngrid)
     nz = atm%nz
     pbar = m%pbar
     if (m%zpres /= unset) pbar = pressure_at(atm, m%zpres)

@@ -123,6 +123,7 @@ program sbdart_amd
     model%imomc = imomc
     where (sc == huge(0.)) sc = (/1._kr, 0._kr, 0._kr, 0._kr, 0._kr/)          ! drt.f:249-262
     model%sc = sc
+    model%zgrid1 = zgrid1; model%zgrid2 = zgrid2
     model%strat_aerosol = any(jaer /= 0)
     model%spowder = spowder; model%radiance = radcalc
     if (.not. covered_by_band_model(model, why)) &

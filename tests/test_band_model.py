@@ -122,6 +122,10 @@ VARIANTS = [
     "idatm=5 isalb=1 wlinf=.3 wlsup=4.6 wlinc=.1 sza=65 iout=1",
     "idatm=2 isalb=10 sc=.1,.2,.3,.4 wlinf=.4 wlsup=2.5 wlinc=.07 sza=35 iout=1",
     "idatm=2 isalb=5 wlinf=.4 wlsup=2.5 wlinc=.07 sza=35 iout=1",
+    # regridded atmospheres: BASELINE configs[4] (50 layers), a coarse and a bottom-heavy grid
+    "idatm=6 wlinf=.25 wlsup=100 wlinc=20 nstr=32 ngrid=50 iout=10 sza=30",
+    "idatm=2 wlinf=.4 wlsup=4 wlinc=.2 ngrid=20 zgrid1=.25 zgrid2=20 tcloud=3 zcloud=1.5 sza=35 iout=1",
+    "idatm=4 wlinf=5 wlsup=15 wlinc=.5 ngrid=65 zgrid1=5 zgrid2=1 sza=35 iout=1",
     "idatm=3 wlinf=.6 wlsup=1.6 wlinc=.1 tcloud=4,1,2 zcloud=1,-3,10 nre=8,10,-30 sza=55 iout=1",
 ]
 
@@ -140,7 +144,7 @@ def test_work_items_equal_live_reference(tmp_path, namelist):
 @needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
     for namelist, word in (("tcloud=5 nre=0", "cloud"), ("iaer=1", "aerosols"), ("isalb=7", "surface"),
-                           ("isat=3", "filter"), ("ngrid=50", "regridding")):
+                           ("isat=3", "filter"), ("idatm=0", "atmosphere")):
         d = str(tmp_path / word)
         os.makedirs(d)
         with open(os.path.join(d, "INPUT"), "w") as f:
