@@ -165,10 +165,11 @@ CAPTURE = os.path.join(ROOT, "oracle", "_ref", "sbdart_capture")
 needs_ref = pytest.mark.skipif(not os.access(CAPTURE, os.X_OK), reason="oracle/_ref not built")
 
 
-def run_reference_and_host(namelist, d, sums=False):
+def run_reference_and_host(namelist, d, sums=False, from_input=False):
     """In directory d: the reference (capture build: unmodified objects, DISORT call site recorded)
-    on this INPUT, then the host on the optics the reference just used.  Returns (reference stdout,
-    host stdout, path of the captured records[, host's full-precision sums])."""
+    on this INPUT, then the host -- on the optics the reference just used, or (from_input) on INPUT
+    alone through its own band model.  Returns (reference stdout, host stdout, path of the captured
+    records[, host's full-precision sums])."""
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, "INPUT"), "w") as f:
         f.write("\n &INPUT\n" + namelist + "\n /\n")
@@ -176,6 +177,8 @@ def run_reference_and_host(namelist, d, sums=False):
     ref = subprocess.run([CAPTURE], cwd=d, env=dict(os.environ, SBD_CAPTURE_FILE=cap), capture_output=True,
                          text=True, check=True).stdout
     env = dict(os.environ, SBD_OPTICS=cap, SBD_ATMOS=cap + ".atm")
+    if from_input:
+        env = dict(os.environ, SBD_OPTICS=os.path.join(d, "no-optics-file"), SBD_ATMOS=os.path.join(d, "no-atm-file"))
     if sums:
         env["SBD_SUMS_FILE"] = os.path.join(d, "sums.txt")
     p = subprocess.run([HOST], cwd=d, env=env, capture_output=True, text=True)
@@ -227,3 +230,23 @@ def test_host_output_formats_against_reference(iout, extra, tmp_path):
     nl = f" idatm=2 isat=0 wlinf=.4 wlsup=.7 wlinc=.05 sza=40 isalb=4 tcloud=3 zcloud=2 iout={iout}{extra}"
     ref, got, _ = run_reference_and_host(nl, str(tmp_path))
     _compare_stdout(got, ref)
+
+
+@pytest.mark.gpu
+@needs_flang
+@needs_ref
+def test_testruns_from_input_alone(tmp_path):
+    """The five TestRuns examples with NO optics file: `sbdart_amd` reads INPUT, runs its own band model
+    (atmosphere, gases, k-distribution, Rayleigh, clouds, surface, solar spectrum), the engine and the
+    writers, and must print what the reference prints for the same INPUT (examples 2 and 4: every
+    sixth run)."""
+    _build()
+    man = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+    total = 0
+    for name, step in (("sbchk1", 1), ("sbchk2", 6), ("sbchk3", 1), ("sbchk4", 6), ("sbchk5", 1)):
+        for i, nl in enumerate(man[name]["namelists"][::step]):
+            ref, got, _ = run_reference_and_host(nl, str(tmp_path / f"{name}_{i}"), from_input=True)
+            off = _compare_stdout(got, ref)
+            total += len(ref.split())
+            print(f"{name}[{i}]: {len(ref.split())} tokens, {off} one unit off in the last printed digit", file=sys.stderr)
+    assert total > 5000

@@ -2,7 +2,8 @@
 
 On the GPU box the reference itself runs (oracle/_ref/sbdart_capture: the unmodified reference
 objects with the DISORT call site recorded -- its stdout IS sbdart_ref's), the Fortran host
-`sbdart_amd` is handed the optical properties the reference just used, and
+`sbdart_amd` is handed the optical properties the reference just used -- or nothing but INPUT
+(its own band model) -- and
 
   * the host's stdout must be the reference's stdout (printed-token equality), and
   * the host's six spectrally integrated fluxes TOPDN, TOPUP, TOPDIR, BOTDN, BOTUP, BOTDIR (full
@@ -33,11 +34,14 @@ CASES = {
 
 @needs_flang
 @needs_ref
+@pytest.mark.parametrize("from_input", [False, True], ids=["reference_optics", "input_alone"])
 @pytest.mark.parametrize("case", sorted(CASES))
-def test_integrated_fluxes_within_gate(case, tmp_path):
+def test_integrated_fluxes_within_gate(case, from_input, tmp_path):
+    """from_input: the host has no optics file and runs its own band model -- INPUT to stdout, the
+    drop-in shape of north_star."""
     from sbdart_amd.records import read_records
     _build()
-    ref_out, got_out, cap, sums = run_reference_and_host(CASES[case], str(tmp_path), sums=True)
+    ref_out, got_out, cap, sums = run_reference_and_host(CASES[case], str(tmp_path), sums=True, from_input=from_input)
     _compare_stdout(got_out, ref_out, max_off_by_one=1)
     recs = read_records(cap)
     w = np.array([r.wt * r.ff for r in recs])
