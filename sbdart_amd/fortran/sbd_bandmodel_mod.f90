@@ -1,8 +1,8 @@
 ! From &INPUT to the per-(wavelength, k-term) work items of the engine: the step in front of the hot
 ! path (SURVEY 8f row N1; reference drt.f:297-347, 425-533 with rayleigh spectra.f:179-247, solirr
-! spectra.f:1367-1415, normom drt.f:1366-1380, depthscl taugas.f:7512-7648).  Covered: gases, Rayleigh
-! and clouds over a Lambertian surface (constant albedo, the six standard spectra or their mixture); what it does not cover yet is refused
-! by name (aerosols, BRDF surfaces, sensor filters, user atmosphere) and
+! spectra.f:1367-1415, normom drt.f:1366-1380, depthscl taugas.f:7512-7648).  Covered: gases, Rayleigh,
+! clouds and aerosols over a Lambertian surface (constant albedo, the six standard spectra or their mixture); what it does not cover yet is refused
+! by name (aerosol / cloud / atmosphere files, BRDF surfaces, sensor filters, user atmosphere) and
 ! still runs from an optics file the reference produced (sbd_io_mod).  Literals: see sbd_tables_mod.
 module sbd_bandmodel_mod
   use sbd_grid_mod, only: kr, unset, spectral_grid, nstrms
@@ -11,12 +11,15 @@ module sbd_bandmodel_mod
   use sbd_atmos_mod
   use sbd_gas_mod
   use sbd_cloud_mod
+  use sbd_aerosol_mod
   implicit none
   private
-  public :: model_input, covered_by_band_model, build_work_items
+  public :: model_input, covered_by_band_model, build_work_items, aerosol_input
 
   type model_input                     ! the &INPUT variables this step reads, same names
-    integer :: idatm = 4, nf = 2, isalb = 0, kdist = 3, nothrm = -1, isat = 0, ngrid = 0, iaer = 0, nstr = 4
+    integer :: idatm = 4, nf = 2, isalb = 0, kdist = 3, nothrm = -1, isat = 0, ngrid = 0, nstr = 4
+    type(aerosol_input) :: aer
+    logical :: user_moments = .false.      ! PMAER given
     real(kr) :: amix = unset, sza = 0, solfac = 1, albcon = 0, xrsc = 1, zpres = unset, pbar = unset, &
                 sclh2o = unset, uw = unset, uo3 = unset, o3trp = unset, ztrp = 0, xgas(11) = unset, xo4 = 1, &
                 btemp = unset, ttemp = unset, temis = 0, fisot = 0, phi0 = 0
@@ -24,7 +27,7 @@ module sbd_bandmodel_mod
     integer :: imomc = 3
     real(kr) :: zgrid1 = 1, zgrid2 = 30
     real(kr) :: sc(5) = (/1._kr, 0._kr, 0._kr, 0._kr, 0._kr/)   ! ISALB=10: fractions of snow, ocean, sand, vegetation
-    logical :: strat_aerosol = .false., spowder = .false., radiance = .false.
+    logical :: spowder = .false., radiance = .false.
     integer :: numu = 0, nphi = 0
   end type
 
@@ -38,7 +41,8 @@ contains
     if (m%idatm == 0 .or. m%amix /= unset) why = 'user atmosphere (atms.dat)'
     if (m%nre(1) == 0.) why = 'user cloud file (usrcld.dat, nre=0)'
     if (m%rhcld >= 0.) why = 'water vapour saturation inside clouds (rhcld)'
-    if (m%iaer /= 0 .or. m%strat_aerosol) why = 'aerosols'
+    if (m%aer%iaer < 0) why = 'aerosol file (aerosol.dat, iaer=-1)'
+    if (m%user_moments) why = 'user aerosol phase-function moments (pmaer)'
     if (.not. (m%isalb >= 0 .and. m%isalb <= 6) .and. m%isalb /= 10) why = 'albedo file / BRDF surface (isalb)'
     if (m%isat /= 0) why = 'sensor filter functions (isat)'
     if (m%kdist < 0) why = 'k-distribution files (kdist=-1)'
@@ -158,6 +162,8 @@ contains
     type(gas_spectrum) :: spec
     type(optics_t) :: r
     type(cloud_deck) :: deck
+    type(aerosol_load) :: load
+    real(kr), allocatable :: dtaua(:), waer(:)
     real(kr), allocatable :: dtauc(:), wcld(:), pmom(:, :), wlalb(:), alb(:)
     real(kr), allocatable :: uu(:, :), dtaur(:), dtauk(:, :), dtaugc(:), dtaug(:), temper(:), scat(:)
     real(kr) :: pbar, amu0, wl, wvlo, wvhi, dwl, flxin, rsfc, gwk(mk), wt, tsc, tglv, tgls, afac, ramp, btemp, ttemp
@@ -185,7 +191,8 @@ contains
     amu0 = cos(m%sza*dtor)
     call surface_spectrum(m%isalb, m%albcon, m%sc, wlalb, alb)
     deck = new_cloud_deck(atm%z, m%zcloud, m%tcloud, m%lwp, m%nre, m%imomc)
-    allocate(dtauc(nz), wcld(nz), pmom(0:nmom, nz))
+    allocate(dtauc(nz), wcld(nz), pmom(0:nmom, nz), dtaua(nz), waer(nz))
+    load = new_aerosol_load(m%aer, atm%z, relative_humidity(atm%t(1), atm%wh(1)))
 
     allocate(recs(3*grid%n))
     nrec = 0
@@ -213,9 +220,10 @@ contains
       pmom = 0.
       dtauc = 0.; wcld = 0.
       if (deck%nslot > 0) call cloud_depths(deck, wl, nz, nmom, dtauc, wcld, pmom)
+      call aerosol_depths(load, wl, nz, nmom, dtaua, waer, pmom)
       do i = 1, nz
         pmom(2, i) = pmom(2, i) + .1*dtaur(i)
-        scat(i) = dtauc(i)*wcld(i) + 0._kr + dtaur(i)
+        scat(i) = dtauc(i)*wcld(i) + dtaua(i)*waer(i) + dtaur(i)
         if (scat(i) /= 0.) pmom(:, i) = pmom(:, i)/scat(i)
       end do
       pmom(0, :) = 1.
@@ -229,7 +237,7 @@ contains
           do i = 1, nz
             tglv = tglv + dtauk(i, 1)
             tgls = tgls + dtauk(i, 1 + mk)
-            tsc = tsc + dtaur(i) + dtauc(i) + 0._kr
+            tsc = tsc + dtaur(i) + dtauc(i) + dtaua(i)
             afac = 1.
             if (tglv > .001) afac = tgls/tglv
             ramp = correction_weight(wl, tsc)
@@ -243,7 +251,7 @@ contains
         else
           tsc = 0.
           do i = 1, nz
-            tsc = tsc + dtaur(i) + dtauc(i) + 0._kr
+            tsc = tsc + dtaur(i) + dtauc(i) + dtaua(i)
             ramp = correction_weight(wl, tsc)
             dtaug(i) = dtaugc(i) + dtauk(i, kd)*(1. - ramp) + dtauk(i, kd + mk)*ramp
           end do
@@ -260,9 +268,9 @@ contains
         r%temper = temper; r%umu = umu; r%phi = phi
         r%pmom = pmom
         do i = 1, nz
-          r%dtauc(i) = dtaug(i) + dtauc(i) + 0._kr + dtaur(i)
+          r%dtauc(i) = dtaug(i) + dtauc(i) + dtaua(i) + dtaur(i)
           if (r%dtauc(i) > tiny(1._kr)) then
-            r%ssalb(i) = (dtauc(i)*wcld(i) + 0._kr + dtaur(i))/r%dtauc(i)
+            r%ssalb(i) = (dtauc(i)*wcld(i) + dtaua(i)*waer(i) + dtaur(i))/r%dtauc(i)
           else
             r%ssalb(i) = 0.
           end if

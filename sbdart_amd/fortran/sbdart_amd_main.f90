@@ -112,7 +112,12 @@ program sbdart_amd
     call read_atmosphere(trim(path), nz, zlev, plev, have_atm)
   else
     model%idatm = idatm; model%nf = nf; model%isalb = isalb; model%kdist = kdist; model%nothrm = nothrm
-    model%isat = isat; model%ngrid = ngrid; model%iaer = iaer; model%nstr = nstr
+    model%isat = isat; model%ngrid = ngrid; model%nstr = nstr
+    model%aer%iaer = iaer; model%aer%jaer = jaer; model%aer%imoma = imoma; model%aer%nosct = nosct
+    model%aer%zaer = zaer; model%aer%taerst = taerst; model%aer%vis = vis; model%aer%tbaer = tbaer
+    model%aer%abaer = abaer; model%aer%rhaer = rhaer; model%aer%wlbaer = wlbaer; model%aer%qbaer = qbaer
+    model%aer%wbaer = wbaer; model%aer%gbaer = gbaer; model%aer%zbaer = zbaer; model%aer%dbaer = dbaer
+    model%user_moments = any(pmaer /= unset)
     model%amix = amix; model%sza = sza; model%solfac = solfac; model%albcon = albcon; model%xrsc = xrsc
     model%zpres = zpres; model%pbar = pbar; model%sclh2o = sclh2o; model%uw = uw; model%uo3 = uo3
     model%o3trp = o3trp; model%ztrp = ztrp
@@ -124,7 +129,6 @@ program sbdart_amd
     where (sc == huge(0.)) sc = (/1._kr, 0._kr, 0._kr, 0._kr, 0._kr/)          ! drt.f:249-262
     model%sc = sc
     model%zgrid1 = zgrid1; model%zgrid2 = zgrid2
-    model%strat_aerosol = any(jaer /= 0)
     model%spowder = spowder; model%radiance = radcalc
     if (.not. covered_by_band_model(model, why)) &
       call fatal('no optics file ('//trim(path)//') and the band model does not cover this run yet: '//trim(why))

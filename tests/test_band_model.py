@@ -1,4 +1,4 @@
-"""Band model of the Fortran host (gases, Rayleigh, clouds) against the reference.
+"""Band model of the Fortran host (gases, Rayleigh, clouds, aerosols, surfaces) against the reference.
 
 The work items `sbdart_amd` assembles from `INPUT` alone (model atmosphere -> absorber amounts ->
 LOWTRAN7 continua + band model -> 3-term k-distribution with slant-path correction -> Rayleigh ->
@@ -126,6 +126,17 @@ VARIANTS = [
     "idatm=6 wlinf=.25 wlsup=100 wlinc=20 nstr=32 ngrid=50 iout=10 sza=30",
     "idatm=2 wlinf=.4 wlsup=4 wlinc=.2 ngrid=20 zgrid1=.25 zgrid2=20 tcloud=3 zcloud=1.5 sza=35 iout=1",
     "idatm=4 wlinf=5 wlsup=15 wlinc=.5 ngrid=65 zgrid1=5 zgrid2=1 sza=35 iout=1",
+    # aerosols: BASELINE configs[3] (rural, radiance), the other models, optical depth instead of visibility,
+    # a user profile, a user spectrum, stratospheric layers, absorption-only
+    "idatm=6 wlinf=.5 wlsup=.9 wlinc=.2 iout=5 nstr=32 iaer=1 vis=23 nzen=20 uzen=0,85 nphi=16 phi=0,180 sza=30",
+    "idatm=2 wlinf=.3 wlsup=4.5 wlinc=.1 iaer=2 vis=8 rhaer=.75 sza=40 iout=1",
+    "idatm=1 wlinf=.3 wlsup=12 wlinc=-.05 iaer=3 tbaer=.3 sza=40 iout=1 imoma=4 nstr=8",
+    "idatm=4 wlinf=.4 wlsup=2 wlinc=.1 iaer=4 vis=40 rhaer=.95 zbaer=0,1,2,4 dbaer=10,8,2,0 sza=10 iout=1",
+    "idatm=4 wlinf=.4 wlsup=2 wlinc=.1 iaer=1 vis=15 nosct=1 sza=10 iout=1",
+    "idatm=6 wlinf=.3 wlsup=3 wlinc=.1 iaer=5 wlbaer=.4,.6,1,2 qbaer=1.2,1,.6,.2 wbaer=.95,.93,.9,.8 gbaer=.7,.68,.65,.6 tbaer=.4 sza=50 iout=1",
+    "idatm=6 wlinf=.3 wlsup=3 wlinc=.1 iaer=5 wbaer=.9 gbaer=.7 abaer=1.3 vis=20 sza=50 iout=1",
+    "idatm=5 wlinf=.3 wlsup=5 wlinc=.1 jaer=2,3 zaer=18,25 taerst=.05,.02 sza=50 iout=1",
+    "idatm=5 wlinf=.3 wlsup=5 wlinc=.1 iaer=1 vis=30 jaer=1,4 zaer=15,20 taerst=.1,.01 tcloud=2 zcloud=3 sza=50 iout=1",
     "idatm=3 wlinf=.6 wlsup=1.6 wlinc=.1 tcloud=4,1,2 zcloud=1,-3,10 nre=8,10,-30 sza=55 iout=1",
 ]
 
@@ -143,7 +154,7 @@ def test_work_items_equal_live_reference(tmp_path, namelist):
 
 @needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
-    for namelist, word in (("tcloud=5 nre=0", "cloud"), ("iaer=1", "aerosols"), ("isalb=7", "surface"),
+    for namelist, word in (("tcloud=5 nre=0", "cloud"), ("iaer=-1", "aerosol"), ("isalb=7", "surface"),
                            ("isat=3", "filter"), ("idatm=0", "atmosphere")):
         d = str(tmp_path / word)
         os.makedirs(d)

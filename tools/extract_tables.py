@@ -142,6 +142,26 @@ def main():
         tables.append(("sun%d.wl" % nf, wl[:n].copy(), "output of `%s` (spectra.f:1417-3238)" % fn))
         tables.append(("sun%d.irr" % nf, irr[:n].copy(), "output of `%s`" % fn))
 
+    # ---- aerosols (tauaero.f): wavelengths of the standard models, extinction / absorption / asymmetry of
+    #      the rural, urban, oceanic and tropospheric boundary-layer models at four relative humidities,
+    #      the four stratospheric models, and the standard vertical profile (the profile aerzstd leaves
+    #      in the module: the reference's visibility weighting always selects the 23 km profile) ----
+    static("aer.wl", "_QMaeroblkEawl", "tauaero.f:47-58")
+    static("aer.rhzone", "_QMaeroblkFstdaerErhzone", "tauaero.f:600")
+    for model, pre in (("rural", "rur"), ("urban", "urb"), ("ocean", "ocn"), ("tropo", "tro")):
+        for q in "eag":
+            static("aer.%s.%s" % (model, q), "_QMaeroblkFstdaerE%s%s" % (pre, q),
+                   "tauaero.f:610-1010, [47 wavelengths][4 humidities] column-major")
+    static("aer.strat", "_QMaeroblkFaestratEaerstr",
+           "tauaero.f:262-395, [47 wavelengths][ext, abs, asym][4 models] column-major")
+    static("aer.z", "_QMaeroblkFaerzstdEalt", "tauaero.f:93-101")
+    ctypes.c_double.in_dll(lib, "_QMaeroblkEvis").value = 23.0
+    getattr(lib, "_QMaeroblkPaerzstd")()
+    dens = np.array((ctypes.c_double * 33).in_dll(lib, "_QMaeroblkEdbaer"))
+    zchk = np.array((ctypes.c_double * 33).in_dll(lib, "_QMaeroblkEzbaer"))
+    assert np.array_equal(zchk, tables[-1][1])
+    tables.append(("aer.density", dens, "module array `dbaer` after `aerzstd` (tauaero.f:88-140)"))
+
     # ---- spectral albedo of the six standard surfaces on their own grids (spectra.f:2899-3238) ----
     for isalb, fn in enumerate(("snow_", "clearw_", "lakew_", "seaw_", "sand_", "vegeta_"), start=1):
         nna = ctypes.c_int(5000)
