@@ -70,6 +70,7 @@ program sbdart_amd
   type(model_input) :: model
   type(atmosphere) :: atm
   logical :: have_file, ok
+  integer(kind=8) :: tick0, tick1, tick2, tick_rate
   character(len=256) :: why
 
   ! ---- read ./INPUT exactly like drt.f:220-231 ----
@@ -135,7 +136,12 @@ program sbdart_amd
     call tables_load(ok, why)
     if (.not. ok) call fatal('band-model tables not found; tried'//trim(why))
     call viewing_cosines()
+    call system_clock(tick0, tick_rate)
     call build_work_items(model, grid, umu(1:numu), phiv(1:merge(view%nphi, 0, radcalc)), recs, nrec, atm)
+    call system_clock(tick1)
+    call get_environment_variable('SBD_TIMING', path, plen, pstat)
+    if (pstat == 0 .and. plen > 0) write(0, '(a,i0,a,i0,a,f9.4,a)') 'sbdart_amd: band model: ', grid%n, &
+      ' wavelengths, ', nrec, ' work items in ', real(tick1 - tick0, kr)/real(tick_rate, kr), ' s'
     nz = atm%nz
     allocate(zlev(nz), plev(nz))
     zlev = atm%z; plev = atm%p
@@ -186,6 +192,7 @@ program sbdart_amd
   ! ---- batch arrays (row-major by work item == Fortran's first index fastest).  Items the filter
   !      function removes (ff = 0) are not solved (drt.f:461-462); items with a beam come first so
   !      that an NSTR retry (below) re-solves one contiguous part ----
+  call system_clock(tick0, tick_rate)
   allocate(order(nrec))
   nbeam = 0
   do i = 1, nrec
@@ -229,8 +236,14 @@ program sbdart_amd
   ! ---- the wavelength loop: the beam items with the reference's NSTR "dithering" (a beam angle that
   !      coincides with a quadrature angle makes DISORT ask for another stream count, drt.f:536-555),
   !      the beamless items with the stream count as given ----
+  call system_clock(tick1)
   call solve_part(1, nbeam, .true.)
   call solve_part(nbeam + 1, npart, .false.)
+  call system_clock(tick2)
+  call get_environment_variable('SBD_TIMING', path, plen, pstat)
+  if (pstat == 0 .and. plen > 0) write(0, '(a,f9.4,a,i0,a,f9.4,a)') 'sbdart_amd: batch assembly ', &
+    real(tick1 - tick0, kr)/real(tick_rate, kr), ' s; engine (create + H2D + solve + D2H), ', npart, ' solves: ', &
+    real(tick2 - tick1, kr)/real(tick_rate, kr), ' s'
 
   ! ---- warnings / fatals the reference raises through errmsg ----
   stall = 0
