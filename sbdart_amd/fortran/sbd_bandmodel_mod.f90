@@ -2,7 +2,7 @@
 ! path (SURVEY 8f row N1; reference drt.f:297-347, 425-533 with rayleigh spectra.f:179-247, solirr
 ! spectra.f:1367-1415, normom drt.f:1366-1380, depthscl taugas.f:7512-7648).  Covered: gases, Rayleigh,
 ! clouds and aerosols over a Lambertian surface (constant albedo, the six standard spectra or their mixture); what it does not cover yet is refused
-! by name (aerosol / cloud / atmosphere files, BRDF surfaces, sensor filters, user atmosphere) and
+! by name (aerosol / cloud / atmosphere files, BRDF surfaces, user cloud / aerosol files) and
 ! still runs from an optics file the reference produced (sbd_io_mod).  Literals: see sbd_tables_mod.
 module sbd_bandmodel_mod
   use sbd_grid_mod, only: kr, unset, spectral_grid, nstrms
@@ -12,13 +12,14 @@ module sbd_bandmodel_mod
   use sbd_gas_mod
   use sbd_cloud_mod
   use sbd_aerosol_mod
+  use sbd_filter_mod, only: read_spectrum_file
   use omp_lib, only: omp_get_max_threads
   implicit none
   private
   public :: model_input, covered_by_band_model, build_work_items, aerosol_input
 
   type model_input                     ! the &INPUT variables this step reads, same names
-    integer :: idatm = 4, nf = 2, isalb = 0, kdist = 3, nothrm = -1, isat = 0, ngrid = 0, nstr = 4
+    integer :: idatm = 4, nf = 2, isalb = 0, kdist = 3, nothrm = -1, ngrid = 0, nstr = 4
     type(aerosol_input) :: aer
     logical :: user_moments = .false.      ! PMAER given
     real(kr) :: amix = unset, sza = 0, solfac = 1, albcon = 0, xrsc = 1, zpres = unset, pbar = unset, &
@@ -39,15 +40,13 @@ contains
     type(model_input), intent(in) :: m
     character(len=*), intent(out) :: why
     why = ''
-    if (m%idatm == 0 .or. m%amix /= unset) why = 'user atmosphere (atms.dat)'
     if (m%nre(1) == 0.) why = 'user cloud file (usrcld.dat, nre=0)'
     if (m%rhcld >= 0.) why = 'water vapour saturation inside clouds (rhcld)'
     if (m%aer%iaer < 0) why = 'aerosol file (aerosol.dat, iaer=-1)'
     if (m%user_moments) why = 'user aerosol phase-function moments (pmaer)'
-    if (.not. (m%isalb >= 0 .and. m%isalb <= 6) .and. m%isalb /= 10) why = 'albedo file / BRDF surface (isalb)'
-    if (m%isat /= 0) why = 'sensor filter functions (isat)'
+    if (.not. (m%isalb >= -1 .and. m%isalb <= 6) .and. m%isalb /= 10) why = 'BRDF surface (isalb 7, 8, 9)'
     if (m%kdist < 0) why = 'k-distribution files (kdist=-1)'
-    if (m%nf < 0) why = 'solar spectrum file (nf<0)'
+    if (m%nf == -2) why = 'solar spectrum from the k-distribution file (nf=-2)'
     if (m%spowder) why = 'sub-surface layer (spowder)'
     ok = len_trim(why) == 0
   end function
@@ -83,6 +82,7 @@ contains
     real(kr), intent(in) :: wl
     integer, intent(in) :: nf
     real(kr), pointer :: w(:), s(:)
+    real(kr), allocatable, target, save :: wfile(:), sfile(:)
     character(len=4) :: name
     real(kr) :: wt
     integer :: j
@@ -90,8 +90,13 @@ contains
       e = 1.
       return
     end if
-    write(name, '(a,i1)') 'sun', nf
-    w => tbl(name//'.wl'); s => tbl(name//'.irr')
+    if (nf == -1) then                       ! solar.dat, read once (before the threaded loop: build_work_items)
+      if (.not. allocated(wfile)) call read_spectrum_file('solar.dat', 5000, wfile, sfile)
+      w => wfile; s => sfile
+    else
+      write(name, '(a,i1)') 'sun', nf
+      w => tbl(name//'.wl'); s => tbl(name//'.irr')
+    end if
     j = bracket(w, wl)
     wt = (wl - w(j))/(w(j + 1) - w(j))
     wt = max(0._kr, min(1._kr, wt))
@@ -106,6 +111,8 @@ contains
     real(kr), allocatable, intent(out) :: wlalb(:), alb(:)
     character(len=4) :: name
     select case (isalb)
+    case (-1)
+      call read_spectrum_file('albedo.dat', 5000, wlalb, alb)
     case (0)
       wlalb = (/0._kr, huge(0._kr)/)
       alb = (/albcon, albcon/)
@@ -173,7 +180,13 @@ contains
     integer :: nthreads
 
     ! ---- once per run: profiles, rescaling, absorber amounts, clouds, aerosols, surface (drt.f:297-423) ----
-    atm = model_atmosphere(m%idatm)
+    if (m%idatm == 0) then
+      atm = user_atmosphere()
+    else
+      atm = model_atmosphere(m%idatm)
+    end if
+    if (m%amix > -1.) call mix_in(atm, m%amix)
+    if (m%nf == -1) pbar = solar_irradiance(1._kr, m%nf)       ! (reads solar.dat before the threads start)
     if (m%ngrid /= 0) call regrid(atm, m%zgrid1, m%zgrid2, m%ngrid)
     nz = atm%nz
     pbar = m%pbar

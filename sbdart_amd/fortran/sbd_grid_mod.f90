@@ -47,6 +47,12 @@ contains
     g%hi = wlsup
     g%step = wlinc
     span = wlsup - wlinf
+    if (wlinf == wlsup) then                 ! a single spectral point, 0.001 um wide (spectra.f:3280-3298)
+      g%spacing = by_wavelength
+      g%n = 1
+      g%step = real(.001, kr)
+      return
+    end if
     if (wlinc > 1._kr) then
       g%spacing = by_wavenumber
       g%n = int(((10000._kr/wlinf) - (10000._kr/wlsup))/wlinc + 1._kr)

@@ -25,6 +25,7 @@ program sbdart_amd
   use sbd_atmos_mod, only: atmosphere
   use sbd_bandmodel_mod
   use sbd_tables_mod, only: tables_load
+  use sbd_filter_mod
   implicit none
   integer, parameter :: ncldz = 5, naerz = 5, naerb = 150, maxmom = 299, ndb = 20
   ! ---- &INPUT / &DINPUT (drt.f:200-215), same names, same defaults where they matter ----
@@ -68,6 +69,7 @@ program sbdart_amd
   real(kr), allocatable :: zlev(:), plev(:)
   integer :: stall
   type(model_input) :: model
+  type(sensor_filter) :: sensor
   type(atmosphere) :: atm
   logical :: have_file, ok
   integer(kind=8) :: tick0, tick1, tick2, tick_rate
@@ -97,7 +99,12 @@ program sbdart_amd
   if (iday /= 0) call fatal('IDAY (solar ephemeris) is outside the hot path: give SZA')
   if (csza /= unset) sza = acos(csza)/(real(3.1415926536d0, kr)/180.)
   if (abs(sza - 90) < .01) sza = 95.
-  grid = new_grid(wlinf, wlsup, wlinc)
+  if (isat > 0) then
+    call tables_load(ok, why)
+    if (.not. ok) call fatal('tables not found; tried'//trim(why))
+  end if
+  sensor = new_filter(isat, wlinf, wlsup)            ! setfilt: the sensor's response and its wavelength limits
+  grid = new_grid(sensor%wlmin, sensor%wlmax, wlinc)
 
   ! ---- per-work-item optical properties: optics file if there is one, else the band model ----
   call get_environment_variable('SBD_OPTICS', path, plen, pstat)
@@ -113,7 +120,7 @@ program sbdart_amd
     call read_atmosphere(trim(path), nz, zlev, plev, have_atm)
   else
     model%idatm = idatm; model%nf = nf; model%isalb = isalb; model%kdist = kdist; model%nothrm = nothrm
-    model%isat = isat; model%ngrid = ngrid; model%nstr = nstr
+    model%ngrid = ngrid; model%nstr = nstr
     model%aer%iaer = iaer; model%aer%jaer = jaer; model%aer%imoma = imoma; model%aer%nosct = nosct
     model%aer%zaer = zaer; model%aer%taerst = taerst; model%aer%vis = vis; model%aer%tbaer = tbaer
     model%aer%abaer = abaer; model%aer%rhaer = rhaer; model%aer%wlbaer = wlbaer; model%aer%qbaer = qbaer
@@ -145,6 +152,9 @@ program sbdart_amd
     nz = atm%nz
     allocate(zlev(nz), plev(nz))
     zlev = atm%z; plev = atm%p
+    do i = 1, nrec
+      recs(i)%ff = filter_value(sensor, recs(i)%wl)       ! drt.f:461 (ewcoef = 1)
+    end do
     have_atm = .true.
   end if
   nmom = recs(1)%nmom

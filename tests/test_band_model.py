@@ -57,6 +57,7 @@ def rel(a, b):
 
 
 def compare(mine, ref, complete):
+    mine = [m for m in mine if m.ff != 0.0]          # the reference does not call DISORT where the filter is zero
     by_key = {(m.iwl, m.kd): m for m in mine}
     if complete:
         assert len(mine) == len(ref)
@@ -137,6 +138,11 @@ VARIANTS = [
     "idatm=6 wlinf=.3 wlsup=3 wlinc=.1 iaer=5 wbaer=.9 gbaer=.7 abaer=1.3 vis=20 sza=50 iout=1",
     "idatm=5 wlinf=.3 wlsup=5 wlinc=.1 jaer=2,3 zaer=18,25 taerst=.05,.02 sza=50 iout=1",
     "idatm=5 wlinf=.3 wlsup=5 wlinc=.1 iaer=1 vis=30 jaer=1,4 zaer=15,20 taerst=.1,.01 tcloud=2 zcloud=3 sza=50 iout=1",
+    # sensor response functions: built-in sensors, flat / triangular / Gaussian about a centre
+    "idatm=4 isat=1 sza=30 iout=10", "idatm=4 isat=6 wlinc=.01 sza=30 iout=1", "idatm=2 isat=11 sza=95 iout=10",
+    "idatm=2 isat=21 sza=40 iout=1", "idatm=2 isat=29 sza=40 wlinc=-.001 iout=1 nf=0",
+    "idatm=6 isat=-2 wlinf=1.6 wlsup=.1 wlinc=.005 sza=25 iout=1", "idatm=6 isat=-2 wlinf=1.6 wlsup=0 sza=25 iout=10",
+    "idatm=6 isat=-3 wlinf=.87 wlsup=.02 wlinc=.002 sza=25 iout=1", "idatm=6 isat=-4 wlinf=11 wlsup=.5 wlinc=.05 sza=25 iout=1",
     "idatm=3 wlinf=.6 wlsup=1.6 wlinc=.1 tcloud=4,1,2 zcloud=1,-3,10 nre=8,10,-30 sza=55 iout=1",
 ]
 
@@ -152,10 +158,40 @@ def test_work_items_equal_live_reference(tmp_path, namelist):
     print("%d work items, worst relative difference %.2e :: %s" % (len(ref), worst, namelist))
 
 
+USER_FILES = {
+    "atms.dat": "5\n" + "".join("%g %g %g %g %g\n" % r for r in (
+        (40, 3.0, 255.0, 1e-4, 4e-4), (20, 55.0, 217.0, 5e-4, 3e-4), (8, 360.0, 240.0, 0.2, 6e-5),
+        (2, 800.0, 275.0, 4.0, 5e-5), (0, 1010.0, 290.0, 11.0, 5e-5))),
+    "albedo.dat": "0.3 0.05\n0.7 0.1\n0.75 0.45\n2.0 0.3\n4.0 0.1\n",
+    "solar.dat": "4.0 9.0\n2.0 110.0\n1.0 720.0\n0.5 1900.0\n0.3 520.0\n",
+    "filter.dat": "0.6 0.0\n0.65 0.8\n0.7 1.0\n0.8 0.3\n0.85 0.0\n",
+}
+
+
+@needs_host
+@pytest.mark.skipif(not os.path.exists(CAPTURE), reason="oracle/_ref/sbdart_capture not built")
+@pytest.mark.parametrize("namelist", [
+    "idatm=0 wlinf=.4 wlsup=3 wlinc=.1 sza=30 iout=1",
+    "idatm=6 isalb=-1 nf=-1 wlinf=.35 wlsup=3.5 wlinc=.05 sza=30 iout=1",
+    "idatm=6 isat=-1 wlinc=.005 sza=30 iout=1",
+])
+def test_user_data_files(tmp_path, namelist):
+    """atms.dat, albedo.dat, solar.dat, filter.dat in the run directory, as the reference reads them."""
+    for d in ("ref", "mine"):
+        os.makedirs(str(tmp_path / d))
+        for name, text in USER_FILES.items():
+            (tmp_path / d / name).write_text(text)
+    ref = reference_items(str(tmp_path / "ref"), namelist)
+    assert ref
+    mine = host_items(str(tmp_path / "mine"), namelist)
+    worst = compare(mine, ref, True)
+    print("%d work items, worst relative difference %.2e :: %s" % (len(ref), worst, namelist))
+
+
 @needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
     for namelist, word in (("tcloud=5 nre=0", "cloud"), ("iaer=-1", "aerosol"), ("isalb=7", "surface"),
-                           ("isat=3", "filter"), ("idatm=0", "atmosphere")):
+                           ("rhcld=.9 tcloud=3", "saturation"), ("spowder=t", "sub-surface")):
         d = str(tmp_path / word)
         os.makedirs(d)
         with open(os.path.join(d, "INPUT"), "w") as f:

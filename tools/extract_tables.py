@@ -171,6 +171,21 @@ def main():
         tables.append(("alb%d.wl" % isalb, wl[:n].copy(), "output of `%s` (spectra.f:2899-3238)" % fn))
         tables.append(("alb%d.r" % isalb, alb[:n].copy(), "output of `%s`" % fn))
 
+    # ---- sensor response functions ISAT 1..29 on their even wavelength grids (spectra.f:3414-4380):
+    #      [wlmin, wlmax, response(1:n)] ----
+    sensors = ("meteo", "goese", "goesw", "avhr81", "avhr82", "avhr91", "avhr92", "avhr101", "avhr102", "avhr111",
+               "avhr112", "gtr1", "gtr2", "nm410", "nm936", "mfrsr1", "mfrsr2", "mfrsr3", "mfrsr4", "mfrsr5",
+               "mfrsr6", "avhr83", "avhr84", "avhr85", "setlow", "airs1", "airs2", "airs3", "airs4")
+    for isat, fn in enumerate(sensors, start=1):
+        nnf = ctypes.c_int(0)
+        wmin, wmax = ctypes.c_double(0), ctypes.c_double(0)
+        resp = np.zeros(8192)
+        getattr(lib, fn + "_")(resp.ctypes.data_as(dp), ctypes.byref(wmin), ctypes.byref(wmax), ctypes.byref(nnf))
+        n = nnf.value
+        assert 2 <= n <= 5000, (fn, n)
+        tables.append(("filter%d" % isat, np.concatenate([[wmin.value, wmax.value], resp[:n]]),
+                       "output of `%s_`: wlmin, wlmax, %d response values (spectra.f:3414-4380)" % (fn, n)))
+
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "wb") as f:
         f.write(b"SBDTBL1\0")
