@@ -8,7 +8,7 @@ module sbd_atmos_mod
   implicit none
   private
   public :: atmosphere, model_atmosphere, rescale_profiles, pressure_at, trace_gases, set_trace_gases, &
-            absorber_columns, bracket, nearest_index, relative_humidity, regrid, user_atmosphere, mix_in
+            absorber_columns, bracket, nearest_index, relative_humidity, regrid, user_atmosphere, mix_in, saturate_clouds
 
   type atmosphere                     ! levels bottom-up: index 1 is the surface
     integer :: nz = 0
@@ -400,6 +400,104 @@ contains
         end select
       end do
     end do
+  end subroutine
+
+  ! RHCLD >= 0: water vapour inside the cloud layers (and one level above each cloud top) set to relative
+  ! humidity rhcld.  KRHCLR = 1 leaves the clear levels alone (satcloud, atms.f:11-67); otherwise the clear
+  ! levels are rescaled so that the column keeps its water vapour, or, if the clouds alone hold more than
+  ! that, the cloud levels are (saturate, atms.f:70-221).  cloud_layer: layer numbers from the cloud slots
+  ! (1 = top, negative = upper end of an extended cloud, 0 = unused).
+  subroutine saturate_clouds(a, cloud_layer, rhcld, keep_clear)
+    type(atmosphere), intent(inout) :: a
+    integer, intent(in) :: cloud_layer(:)
+    real(kr), intent(in) :: rhcld
+    logical, intent(in) :: keep_clear
+    real(kr) :: column, clear, cloudy, cldfac, clrfac, after
+    logical :: in_cloud(a%nz)
+    integer :: i, j, lbot, ltop, nz, ns
+    nz = a%nz
+    ns = size(cloud_layer)
+    in_cloud = .false.
+    do i = 1, ns
+      if (cloud_layer(i) <= 0) cycle
+      lbot = cloud_layer(i)
+      ltop = lbot
+      if (i /= ns) then
+        if (cloud_layer(i + 1) < 0) ltop = -cloud_layer(i + 1)
+      end if
+      do j = max(ltop - 1, 1), lbot
+        in_cloud(nz - j + 1) = .true.
+      end do
+    end do
+    if (keep_clear) then
+      do i = 1, nz
+        if (in_cloud(i)) a%wh(i) = rhcld*saturation_density(tzero/a%t(i))
+      end do
+      return
+    end if
+    column = weighted_column(a%wh, nz, (/(.true., i = 1, nz)/))
+    if (column == 0.) then
+      print *, 'Error in saturate ---  original column water vapor is zero -- can not modify'
+      stop
+    end if
+    do i = 1, nz
+      if (in_cloud(i)) a%wh(i) = rhcld*saturation_density(tzero/a%t(i))
+    end do
+    ! (the reference tags the cloud levels by a negative density, so a clear level counts only if its
+    !  density is positive, a cloud level only if it is non-zero, and the top level counts in neither sum)
+    clear = weighted_column(a%wh, nz - 1, .not. in_cloud .and. a%wh > 0.)
+    cloudy = weighted_column(a%wh, nz - 1, in_cloud .and. a%wh /= 0.)
+    if (cloudy == 0) then
+      print *, 'Error in saturate --- water vapor density in cloud = 0 ?'
+      stop
+    end if
+    if (clear == 0) then
+      cldfac = column/cloudy
+      clrfac = 1.e-30
+    else
+      clrfac = (column - cloudy)/clear
+      cldfac = 1.
+      if (clrfac < 0) then
+        clrfac = 1.e-30
+        cldfac = column/cloudy
+      end if
+    end if
+    where (in_cloud .and. a%wh /= 0.)
+      a%wh = cldfac*a%wh
+    elsewhere
+      a%wh = clrfac*a%wh
+    end where
+    after = 0.
+    do i = 1, nz - 1
+      after = after + .1*slab_column(a%z(i + 1) - a%z(i), a%wh(i), a%wh(i + 1))
+    end do
+    a%wh = a%wh*column/after
+  contains
+    ! sum over levels 1..n of density x the height interval the level stands for (half-way to its neighbours)
+    real(kr) function weighted_column(d, n, mask) result(w)
+      real(kr), intent(in) :: d(:)
+      integer, intent(in) :: n
+      logical, intent(in) :: mask(:)
+      real(kr) :: zbot, ztop
+      integer :: k
+      w = 0.
+      zbot = a%z(1)
+      do k = 1, n
+        if (k == 1) then
+          ztop = .5*(a%z(2) + zbot)
+        else if (k == nz) then
+          ztop = a%z(nz)
+        else
+          ztop = .5*(a%z(k + 1) + a%z(k))
+        end if
+        if (mask(k)) w = w + .1*(ztop - zbot)*d(k)
+        zbot = ztop
+      end do
+    end function
+    real(kr) function saturation_density(x) result(s)
+      real(kr), intent(in) :: x
+      s = x*exp(18.916758_kr - x*(14.845878_kr + x*2.4918766_kr))
+    end function
   end subroutine
 
   ! relative humidity from temperature (K) and water-vapour density (g/m3) (tauaero.f:1499-1524)

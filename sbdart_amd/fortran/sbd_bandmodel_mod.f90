@@ -26,7 +26,7 @@ module sbd_bandmodel_mod
                 sclh2o = unset, uw = unset, uo3 = unset, o3trp = unset, ztrp = 0, xgas(11) = unset, xo4 = 1, &
                 btemp = unset, ttemp = unset, temis = 0, fisot = 0, phi0 = 0
     real(kr) :: zcloud(ncldz) = 0, tcloud(ncldz) = 0, lwp(ncldz) = 0, nre(ncldz) = 8, rhcld = unset
-    integer :: imomc = 3
+    integer :: imomc = 3, krhclr = 0
     real(kr) :: zgrid1 = 1, zgrid2 = 30
     real(kr) :: sc(5) = (/1._kr, 0._kr, 0._kr, 0._kr, 0._kr/)   ! ISALB=10: fractions of snow, ocean, sand, vegetation
     logical :: spowder = .false., radiance = .false.
@@ -41,7 +41,6 @@ contains
     character(len=*), intent(out) :: why
     why = ''
     if (m%nre(1) == 0.) why = 'user cloud file (usrcld.dat, nre=0)'
-    if (m%rhcld >= 0.) why = 'water vapour saturation inside clouds (rhcld)'
     if (m%aer%iaer < 0) why = 'aerosol file (aerosol.dat, iaer=-1)'
     if (m%user_moments) why = 'user aerosol phase-function moments (pmaer)'
     if (.not. (m%isalb >= -1 .and. m%isalb <= 6) .and. m%isalb /= 10) why = 'BRDF surface (isalb 7, 8, 9)'
@@ -174,7 +173,7 @@ contains
     type(aerosol_load) :: load
     real(kr), allocatable :: uu(:, :), temper(:), wlalb(:), alb(:)
     integer, allocatable :: nk_of(:)
-    real(kr) :: pbar, amu0, btemp, ttemp
+    real(kr) :: pbar, amu0, btemp, ttemp, rh_surface
     real(kr), parameter :: dtor = 3.1415926536_kr/180.
     integer :: nz, nmom, iwl, kd, i
     integer :: nthreads
@@ -193,6 +192,9 @@ contains
     if (m%zpres /= unset) pbar = pressure_at(atm, m%zpres)
     call rescale_profiles(atm, m%sclh2o, m%uw, m%uo3, m%o3trp, m%ztrp, pbar)
     call set_trace_gases(mix, m%xgas, m%xo4)
+    rh_surface = relative_humidity(atm%t(1), atm%wh(1))
+    deck = new_cloud_deck(atm%z, m%zcloud, m%tcloud, m%lwp, m%nre, m%imomc)
+    if (m%rhcld >= 0) call saturate_clouds(atm, deck%layer, m%rhcld, m%krhclr == 1)
     allocate(uu(mxq, nz), temper(0:nz))
     call absorber_columns(atm, mix, uu)
     temper(0) = atm%t(nz)
@@ -204,8 +206,7 @@ contains
     nmom = min(m%nstr + 2, nstrms)
     amu0 = cos(m%sza*dtor)
     call surface_spectrum(m%isalb, m%albcon, m%sc, wlalb, alb)
-    deck = new_cloud_deck(atm%z, m%zcloud, m%tcloud, m%lwp, m%nre, m%imomc)
-    load = new_aerosol_load(m%aer, atm%z, relative_humidity(atm%t(1), atm%wh(1)))
+    load = new_aerosol_load(m%aer, atm%z, rh_surface)
 
     allocate(recs(mk*grid%n), nk_of(grid%n))
     ! threads: one per 64 wavelengths, at most 16 -- every work item allocates its six arrays inside the loop,

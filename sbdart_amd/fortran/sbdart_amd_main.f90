@@ -133,7 +133,7 @@ program sbdart_amd
     model%xo4 = xo4; model%btemp = btemp; model%ttemp = ttemp; model%temis = temis; model%fisot = fisot
     model%phi0 = phi0
     model%zcloud = zcloud; model%tcloud = tcloud; model%lwp = lwp; model%nre = nre; model%rhcld = rhcld
-    model%imomc = imomc
+    model%imomc = imomc; model%krhclr = krhclr
     where (sc == huge(0.)) sc = (/1._kr, 0._kr, 0._kr, 0._kr, 0._kr/)          ! drt.f:249-262
     model%sc = sc
     model%zgrid1 = zgrid1; model%zgrid2 = zgrid2

@@ -143,6 +143,10 @@ VARIANTS = [
     "idatm=2 isat=21 sza=40 iout=1", "idatm=2 isat=29 sza=40 wlinc=-.001 iout=1 nf=0",
     "idatm=6 isat=-2 wlinf=1.6 wlsup=.1 wlinc=.005 sza=25 iout=1", "idatm=6 isat=-2 wlinf=1.6 wlsup=0 sza=25 iout=10",
     "idatm=6 isat=-3 wlinf=.87 wlsup=.02 wlinc=.002 sza=25 iout=1", "idatm=6 isat=-4 wlinf=11 wlsup=.5 wlinc=.05 sza=25 iout=1",
+    # water vapour set to a relative humidity inside the clouds (column conserved, or clear levels kept)
+    "idatm=2 wlinf=.6 wlsup=3 wlinc=.1 tcloud=6 zcloud=2 rhcld=1 sza=30 iout=1",
+    "idatm=4 wlinf=.6 wlsup=3 wlinc=.1 tcloud=6,1 zcloud=1,-4 rhcld=.9 krhclr=1 sza=30 iout=1",
+    "idatm=5 wlinf=5 wlsup=12 wlinc=.25 tcloud=3,2,2 zcloud=.5,-9,11 rhcld=1 sza=30 iout=1",
     "idatm=3 wlinf=.6 wlsup=1.6 wlinc=.1 tcloud=4,1,2 zcloud=1,-3,10 nre=8,10,-30 sza=55 iout=1",
 ]
 
@@ -191,7 +195,7 @@ def test_user_data_files(tmp_path, namelist):
 @needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
     for namelist, word in (("tcloud=5 nre=0", "cloud"), ("iaer=-1", "aerosol"), ("isalb=7", "surface"),
-                           ("rhcld=.9 tcloud=3", "saturation"), ("spowder=t", "sub-surface")):
+                           ("spowder=t", "sub-surface")):
         d = str(tmp_path / word)
         os.makedirs(d)
         with open(os.path.join(d, "INPUT"), "w") as f:
