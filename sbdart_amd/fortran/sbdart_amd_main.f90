@@ -10,11 +10,11 @@
 ! RCCL reduce between GPUs), the per-wavelength formats sum the <= 3 k-terms of a point here.
 !
 ! The per-work-item optical properties (exactly the DISORT arguments drt.f:541-546 passes) come from
-! the band model of this host (sbd_bandmodel_mod: model atmospheres, LOWTRAN7 gases with the 3-term
-! k-distribution, Rayleigh, solar spectrum -- SURVEY.md 8f N1, first slice: clear sky over a surface of
-! constant albedo) or, for what that slice does not cover yet (clouds, aerosols, spectral surfaces,
-! sensor filters), from an "SBDREC1" optics file the reference produced (environment SBD_OPTICS,
-! default ./OPTICS.sbdrec; an optics file, when present, always wins).  Everything downstream of that
+! the band model of this host (sbd_bandmodel_mod and the modules it uses: atmospheres, LOWTRAN7 gases with
+! the 3-term k-distribution, Rayleigh, clouds, aerosols, surface and solar spectra, sensor filters --
+! SURVEY.md 8f N1) or, for the few inputs it does not cover (it says which), from an "SBDREC1" optics
+! file the reference produced (environment SBD_OPTICS, default ./OPTICS.sbdrec; an optics file, when
+! present, always wins).  Everything downstream of that
 ! -- engine, retry of NSTR, accumulation, output formats -- is this program.
 program sbdart_amd
   use iso_c_binding
@@ -65,7 +65,7 @@ program sbdart_amd
        albedo(:), flux(:,:,:), uu(:,:,:,:), temper(:), umu(:), phiv(:), weight(:), acc_flux(:,:), acc_uu(:,:,:)
   integer(c_int8_t), allocatable, target :: plank(:)
   integer(c_int32_t), allocatable, target :: status(:), level_out(:)
-  integer, allocatable :: order(:)
+  integer, allocatable :: order(:), where_solved(:)
   real(kr), allocatable :: zlev(:), plev(:)
   integer :: stall
   type(model_input) :: model
@@ -203,12 +203,14 @@ program sbdart_amd
   !      function removes (ff = 0) are not solved (drt.f:461-462); items with a beam come first so
   !      that an NSTR retry (below) re-solves one contiguous part ----
   call system_clock(tick0, tick_rate)
-  allocate(order(nrec))
+  allocate(order(nrec), where_solved(nrec))
+  where_solved = 0                                   ! batch position of record i, 0 = not solved
   nbeam = 0
   do i = 1, nrec
     if (recs(i)%ff /= 0._kr .and. recs(i)%fbeam > 0._kr) then
       nbeam = nbeam + 1
       order(nbeam) = i
+      where_solved(i) = nbeam
     end if
   end do
   npart = nbeam
@@ -216,6 +218,7 @@ program sbdart_amd
     if (recs(i)%ff /= 0._kr .and. .not. recs(i)%fbeam > 0._kr) then
       npart = npart + 1
       order(npart) = i
+      where_solved(i) = npart
     end if
   end do
   allocate(dtauc(nz, nrec), ssalb(nz, nrec), pmom(0:nmom, nz, nrec), wvnmlo(nrec), wvnmhi(nrec), &
@@ -291,7 +294,7 @@ program sbdart_amd
       end do
       call sums_clear(sums)
       do i = i0, i1
-        ip = position_of(i)
+        ip = where_solved(i)
         if (ip > 0) call sums_add_item(sums, fmt, weight(ip), flux(:, 1:3, ip), lev_top, lev_bot, &
                                        uu(:, :, :, merge(ip, 1, radcalc)), view%uzen)
       end do
@@ -420,18 +423,6 @@ contains
     integer :: m(1)
     m = minloc(abs(z - zq))
     k = m(1)
-  end function
-
-  integer function position_of(irec) result(ip)       ! batch position of record irec, 0 = not solved
-    integer, intent(in) :: irec
-    integer :: q
-    ip = 0
-    do q = 1, npart
-      if (order(q) == irec) then
-        ip = q
-        return
-      end if
-    end do
   end function
 
   ! solve batch positions p0..p1 on every visible GPU; per-run formats also get their weighted sums
