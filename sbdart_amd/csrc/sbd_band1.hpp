@@ -1,0 +1,328 @@
+// Band LU kernel for 16 < NSTR <= 32: ONE boundary-value system per wave, block form, window in registers.
+//
+// Same job and the same inputs/outputs as band_kernel (sbd_band.hpp): SETMTX + SOLVE0's right-hand side
+// + SGBFA + the forward half of SGBSL (disort.f:2702-2994, 3322-3637, disutil.f:771-912, 1019-1036); the
+// interface rows come matrix-ready from the layer kernel's ga/gb blocks, U goes out row-major relative to
+// the diagonal (2 NSTR wide) for backsolve_kernel.  The elimination walks the matrix LAYER BY LAYER like
+// band4_kernel (sbd_band4.hpp, see there for why these are exactly the rows and columns LINPACK touches):
+// layer step lc holds NN carry rows and the NSTR rows of interface lc -- RW = 3 NN rows over the columns
+// of x_lc and x_lc+1 -- and retires NSTR rows to U in NSTR sub-steps with partial pivoting.
+//
+// Mapping (gfx950, wave64): lane q < 32 holds column q of x_lc, lane 32+q column q of x_lc+1, for all RW
+// window rows in registers: ONE array a[RW] per lane (96 VGPRs at NSTR = 32), against 33 KB of LDS per
+// wave in the LDS-window kernel it replaces (one wave per SIMD).  The right-hand side is a vector across
+// the lanes: lane p <-> window row p.  One sub-step J:
+//   * pivot search inside lane J (column J's live rows are that lane's registers), on 26-bit keys that
+//     carry the row index (threshold pivoting 1 - 2^-14; LINPACK takes the exact maximum);
+//   * the pivot row leaves its registers by a computed jump on the wave-uniform row index (generated
+//     inline asm, sbd_band1_take.inc) and the last live row takes its place;
+//   * elimination a[p] += a[p](lane J) * (t * -1/pivot): the multiplier travels through an SGPR pair
+//     (v_readlane) and is the scalar operand of the FMA -- 3 instructions per live row, no LDS;
+//   * the right-hand side needs column J transposed (lane p <- a[p] of lane J): lane J writes its live
+//     registers to 384 bytes of LDS (ds_write2_b64), every lane reads its row's entry: one FMA;
+//   * rows of the next interface are fetched into the registers of retired rows (+ E buffer rows) while
+//     this layer is eliminated.
+#pragma once
+#include "sbd_common.hpp"
+#include "sbd_band.hpp"
+
+namespace sbd {
+
+#include "sbd_band1_take.inc"   // TakeRow1<RW, LAST>: generated inline asm (tools/gen_band1_take.py)
+
+// a[I..CNT-1] of this lane to LDS doubles addr[I..CNT-1], two registers per ds_write2_b64
+template <int I, int CNT, int RW>
+SBD_DEVICE void write_live(unsigned addr, const double (&a)[RW])
+{
+    if constexpr (I + 1 < CNT) {
+        asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4"
+                     :: "v"(addr), "v"(a[I]), "v"(a[I + 1]), "n"(I), "n"(I + 1) : "memory");
+        write_live<I + 2, CNT>(addr, a);
+    } else if constexpr (I < CNT) {
+        asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(addr), "v"(a[I]), "n"(I * 8) : "memory");
+    }
+}
+
+SBD_DEVICE double uniform_from_lane(double x, int src)          // x of lane src (wave-uniform src), in SGPRs
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src),
+                            __builtin_amdgcn_readlane(__double2loint(x), src));
+}
+
+template <int NN>
+__global__ void __launch_bounds__(64) band1_kernel(Params P)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int n = 2 * NN, nn = NN, RW = nn + n, UW = u_width(n);
+    static_assert(n <= 32 && RW <= 64, "band1_kernel: a layer's columns must fit half a wave");
+    const int lane = threadIdx.x, q = lane & 31;
+    const bool second = lane >= 32;                // this lane carries a column of x_lc+1
+    const int nmode = P.nmode, L = P.L;
+    const long long ms = blockIdx.x;
+    const int mazim = (int)(ms % nmode);
+    const int slot = (int)(ms / nmode);
+    if (slot >= P.nslot) return;
+    int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
+    const int st0 = svi[SBD_SVI_STATUS];
+    const double fbeam = P.fbeam[slot];
+    const bool dead = (st0 & (0x20 | 0x10 | 0x08)) != 0;
+    if (mazim > 0 && (fbeam == 0.0 || dead)) return;
+    const int nlev = P.nlev;
+    if (dead) {   // DISORT returned before computing anything: outputs stay zero (ZEROAL)
+        double *flux = P.flux + (size_t)slot * SBD_NFLUX_ * nlev;
+        for (int i = lane; i < SBD_NFLUX_ * nlev; i += 64) flux[i] = 0.0;
+        return;
+    }
+    const int ncut = svi[SBD_SVI_NCUT];
+    const bool lyrcut = svi[SBD_SVI_LYRCUT] != 0;
+    const SV o(L);
+    const double *sv = P.sv + (size_t)slot * P.sv_stride;
+    const double *taucpr = sv + o.taucpr();
+    const double *expbea = sv + o.expbea();
+    const double albedo = P.albedo[slot];
+    const double delm0 = (mazim == 0) ? 1.0 : 0.0;
+    const double umu0 = P.umu0;
+    const double *cmu = P.t.cmu, *cwt = P.t.cwt;
+    const double *gc = P.gc + (size_t)ms * L * n * n;
+    const double *kk = P.kk + (size_t)ms * L * n;
+    const double *ek = P.ek + (size_t)ms * L * nn;
+    const double *zz = P.zz + (size_t)ms * L * n;
+    const double *zp0 = P.zp0 + (size_t)(ms - mazim) * L * n;     // thermal solutions: mode 0 only
+    const double *zp1 = P.zp1 + (size_t)(ms - mazim) * L * n;
+    const double *ga_ms = P.ga + (size_t)ms * L * n * n;           // interface lc: [row][column of x_lc]
+    const double *gb_ms = P.gb + (size_t)ms * L * n * n + (size_t)n * n;    // ... [row][column of x_lc+1]
+    double *yv = P.yv + (size_t)ms * L * n;
+    double *ufac = P.ufac + (size_t)ms * (size_t)(L * n) * UW;
+    double *bcb = P.bcb + (size_t)ms * n * n;                      // bottom-boundary rows (below)
+    double *mcol = smem;                                           // [RW] pivot column, for the right-hand side
+    const int N = ncut * n;
+#define GC(i, j, lc) gc[((size_t)((lc) - 1) * n + ((i) - 1)) * n + ((j) - 1)]
+#define KK(i, lc) kk[((lc) - 1) * n + ((i) - 1)]
+#define EK(i, lc) ek[((lc) - 1) * nn + ((i) - 1)]
+#define ZZ(i, lc) zz[((lc) - 1) * n + ((i) - 1)]
+#define ZP0(i, lc) zp0[((lc) - 1) * n + ((i) - 1)]
+#define ZP1(i, lc) zp1[((lc) - 1) * n + ((i) - 1)]
+    const bool refl = !(lyrcut || delm0 == 0.0);   // LAMBER: the surface couples only for m = 0 (disort.f:2925)
+    const bool col = q < n;                        // this lane carries a column
+    const int qc = col ? q : 0;
+    const int iq1 = qc + 1;
+    const bool beam = fbeam > 0.0;
+
+    // ---- right-hand side of the boundary rows (SOLVE0, disort.f:3434-3599), lane p <-> window row p:
+    //      ytop for the top rows (p < nn), ybot for the bottom rows (window rows nn..n-1 of the last step) ----
+    double ytop = 0.0, ybot = 0.0;
+    {
+        const double bplank = sv[o.bplank()], tplank = sv[o.tplank()];
+        if (lane < nn) {
+            const int iq = lane + 1;
+            if (mazim == 0) {
+                if (beam) ytop = -ZZ(nn + 1 - iq, 1) - ZP0(nn + 1 - iq, 1) + P.fisot + tplank;
+                else ytop = -ZP0(nn + 1 - iq, 1) + P.fisot + tplank;
+            } else {
+                ytop = -ZZ(nn + 1 - iq, 1);
+            }
+        }
+        if (lane >= nn && lane < n) {
+            const int iq = lane - nn + 1;
+            double v;
+            if (mazim > 0) {
+                v = -ZZ(iq + nn, ncut) * expbea[ncut];   // LYRCUT or Lambertian (disort.f:3441-3452)
+            } else if (lyrcut) {
+                if (beam) v = -ZZ(iq + nn, ncut) * expbea[ncut] - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
+                else v = -ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
+            } else {
+                const double bdr = albedo, bem = 1.0 - albedo;
+                double sum = 0.0;
+                if (beam) {
+                    for (int jq = 1; jq <= nn; ++jq)
+                        sum = sum + cwt[jq - 1] * cmu[jq - 1] * bdr *
+                                        (ZZ(nn + 1 - jq, ncut) * expbea[ncut] + ZP0(nn + 1 - jq, ncut)
+                                         + ZP1(nn + 1 - jq, ncut) * taucpr[ncut]);
+                    v = 2.0 * sum + (bdr * umu0 * fbeam / P.pi - ZZ(iq + nn, ncut)) * expbea[ncut]
+                        + bem * bplank - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
+                } else {
+                    for (int jq = 1; jq <= nn; ++jq)
+                        sum = sum + cwt[jq - 1] * cmu[jq - 1] * bdr *
+                                        (ZP0(nn + 1 - jq, ncut) + ZP1(nn + 1 - jq, ncut) * taucpr[ncut]);
+                    v = 2.0 * sum + bem * bplank - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
+                }
+            }
+            ybot = v;
+        }
+    }
+    // ---- bottom-boundary rows (disort.f:2919-2990), Lambertian reflection folded in:
+    //      GC(nn+r, j, ncut) - (1 + delta_m0) * sum_k CWT(k) CMU(k) ALBEDO GC(nn+1-k, j, ncut), times EK(n+1-j)
+    //      for j > nn; as a block [row][column] like the interface blocks, padded to NSTR rows with zeros
+    //      (zero rows never win a pivot search), so that the last step reads its rows like the others ----
+    if (!second && col) {
+        double sb = 0.0;
+        if (refl)
+            for (int k = 1; k <= nn; ++k) sb = sb + cwt[k - 1] * cmu[k - 1] * albedo * GC(nn + 1 - k, iq1, ncut);
+        const double f = (iq1 > nn) ? EK(n + 1 - iq1, ncut) : 1.0;
+        for (int r = 0; r < n; ++r) {
+            double g = 0.0;
+            if (r < nn) {
+                g = GC(nn + 1 + r, iq1, ncut);
+                if (refl) g = g - (1.0 + delm0) * sb;
+                g = g * f;
+            }
+            bcb[r * n + qc] = g;
+        }
+    }
+    __threadfence_block();   // the boundary block is re-read by this wave as its rows enter the window
+
+    // rows of step lci (r = 0..n-1) for this lane: p[r * stride]
+    struct RowSrc { const double *p; int stride; };
+    auto step_rows = [&](int lci) -> RowSrc {
+        const double *zero_row = bcb + (size_t)nn * n + qc;                 // (rows nn.. of the block are zero)
+        if (!col || lci > ncut) return RowSrc{zero_row, 0};
+        if (lci == ncut) return second ? RowSrc{zero_row, 0} : RowSrc{bcb + qc, n};
+        const size_t blk = (size_t)(lci - 1) * n * n + qc;
+        return RowSrc{(second ? gb_ms : ga_ms) + blk, n};
+    };
+    // right-hand side of row r = lane - nn of step lci: an interface, the bottom boundary, nothing
+    const int rr = (lane >= nn && lane < RW) ? lane - nn : 0;
+    struct Z3 { double zz, p0, p1; };
+    auto load_z = [&](int l) -> Z3 {                       // layer l clamped into 1..L: always a valid address
+        const int lz = (l < L) ? l : L;
+        const int ix = (lz - 1) * n + rr;
+        return Z3{zz[ix], zp0[ix], zp1[ix]};
+    };
+    auto step_rhs = [&](int lci, const Z3 &up, const Z3 &dn, double eb, double tc) -> double {
+        const double vb = (dn.zz - up.zz) * eb;
+        const double vt = vb + dn.p0 - up.p0 + (dn.p1 - up.p1) * tc;
+        const double vi = (mazim > 0) ? vb : vt;           // (without a beam ZZ is exactly zero)
+        return (lci < ncut) ? vi : ((lci == ncut) ? ybot : 0.0);
+    };
+
+    // ---- window: RW rows, one column per lane; right-hand side y: lane p <-> row p ----
+    double a[RW];
+    double y = 0.0;
+    {
+        // carry of the first step = the top-boundary rows (SETMTX, disort.f:2887-2915):
+        // GC(nn+1-r, j, 1) * exp(KK(j,1)*TAUCPR(1)) for j <= nn (STWJ scaling); no entries in x_2
+        const double f = (col && iq1 <= nn) ? exp(KK(iq1, 1) * taucpr[1]) : 1.0;
+#pragma unroll
+        for (int r = 1; r <= nn; ++r) a[r - 1] = (col && !second) ? GC(nn + 1 - r, iq1, 1) * f : 0.0;
+        const RowSrc s1 = step_rows(1);
+#pragma unroll
+        for (int r = 0; r < n; ++r) {
+            const double v = s1.p[r * s1.stride];
+            a[nn + r] = col ? v : 0.0;
+        }
+        const Z3 z1 = load_z(1), z2 = load_z(2);
+        const double y1 = step_rhs(1, z1, z2, expbea[1], taucpr[1]);
+        y = (lane < nn) ? ytop : ((lane < RW) ? y1 : 0.0);
+    }
+    int status = 0;
+    double pmin = 1.0e300, pmax = 0.0;         // see near_singular() in sbd_layer.hpp; lane J sees the pivot of sub-step J
+    constexpr int E = 4;
+    double buf[E], ynext = 0.0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);         // every load so far has landed: the waits inside count the loop's own
+    for (int lc = 1; lc <= ncut; ++lc) {
+        const RowSrc nx = step_rows(lc + 1);                   // next step's rows
+        const int lcb = (lc + 1 < L) ? lc + 1 : L;
+        Z3 zu, zn;
+        double ebn = 0.0, tcn = 0.0;
+        const int k0 = (lc - 1) * n;                            // rows k0+1 .. k0+n retire in this step
+        double *urow0 = ufac + (size_t)k0 * UW;
+        double *yrow0 = yv + k0;
+        int qo = q;                                             // (opaque per step: keeps the compiler from hoisting
+        asm volatile("" : "+v"(qo));                            //  per-sub-step store addresses out of the loop)
+        const bool tail = lc == ncut;                           // the last layer has no x_lc+1
+        static_for<n>([&](auto jj) {
+            constexpr int J = decltype(jj)::value;
+            constexpr int LAST = RW - 1 - J;                    // live rows: registers 0..LAST
+            // (1) pivot search in column J = lane J's own registers: key = leading word of |a| with its
+            //     last 6 bits replaced by 63 - p (largest magnitude, first row among near-ties)
+            unsigned kmax = 0u;
+#pragma unroll
+            for (int p = 0; p <= LAST; ++p) {
+                const unsigned key = ((unsigned)__double2hiint(a[p]) & 0x7fffffc0u) | (unsigned)(63 - p);
+                kmax = (key > kmax) ? key : kmax;
+            }
+            const int idx = __builtin_amdgcn_readlane(63 - (int)(kmax & 63u), J);    // wave-uniform
+            // (2) pivot row out of its registers, the last live row into them; the same for y
+            double t;
+            TakeRow1<RW, LAST>::run(a, idx, t);
+            const double ypiv = uniform_from_lane(y, idx);
+            {
+                const double ylast = uniform_from_lane(y, LAST);
+                y = (lane == idx) ? ylast : y;
+            }
+            // column J of the live rows (after the interchange) -> LDS, for the right-hand side
+            if (lane == J) write_live<0, LAST>(lds_addr(mcol), a);      // (only live registers: the others may be loads in flight)
+            // register LAST is free from here on: next interface's row LAST - nn moves in
+            if constexpr (LAST - nn >= E) a[LAST] = nx.p[(LAST - nn) * nx.stride];
+            if constexpr (J < E) buf[J] = nx.p[J * nx.stride];
+            if constexpr (J == 0) {
+                zu = load_z(lc + 1);
+                zn = load_z(lc + 2);
+                ebn = expbea[lcb];
+                tcn = taucpr[lcb];
+            }
+            if constexpr (J == 3) ynext = step_rhs(lc + 1, zu, zn, ebn, tcn);
+            // (3) -1/pivot (v_rcp + two Newton steps) from lane J, a zero pivot is flagged and skipped
+            double rn = __builtin_amdgcn_rcp(t);
+            rn = rn * (2.0 - t * rn);
+            rn = rn * (2.0 - t * rn);
+            rn = (t != 0.0) ? -rn : 0.0;
+            const double rns = uniform_from_lane(rn, J);
+            if (lane == J) { pmin = fmin(pmin, fabs(t)); pmax = fmax(pmax, fabs(t)); }
+            // (4) the retired row: U(k, k..k+2n-1-J) relative to the diagonal, B(k)
+            {
+                double *urow = urow0 + J * UW;
+                if (!second) {
+                    if (q >= J && col) urow[qo - J] = t;
+                } else {
+                    if (col && !tail) urow[n - J + qo] = t;
+                }
+                if (lane == 0) yrow0[J] = ypiv;
+            }
+            // (5) elimination: a[p] += a[p](lane J) * (t * -1/pivot); columns <= J of x_lc are finished
+            //     (their registers keep the unscaled multipliers)
+            const double tp = (second || q > J) ? rns * t : 0.0;
+#pragma unroll
+            for (int p = 0; p < LAST; ++p) {
+                const double m = uniform_from_lane(a[p], J);
+                a[p] = a[p] + m * tp;
+            }
+            // right-hand side: y(p) += a[p](lane J) * (y_pivot * -1/pivot) for the live rows
+            wave_lds_sync();
+            {
+                const double mv = mcol[(lane < LAST) ? lane : 0];
+                const double yt = ypiv * rns;
+                y = (lane < LAST) ? y + mv * yt : y;
+            }
+            wave_lds_sync();
+        });
+        // ---- the nn rows left over only touch x_lc+1: next step's carry (their entries move to the
+        //      first half of the wave); the prefetched rows of the next step complete the window ----
+#pragma unroll
+        for (int p = 0; p < nn; ++p) {
+            const double up = __shfl(a[p], lane + 32);
+            a[p] = second ? 0.0 : up;
+        }
+#pragma unroll
+        for (int r = 0; r < E; ++r) a[nn + r] = buf[r];
+        y = (lane < nn) ? y : ((lane < RW) ? ynext : 0.0);
+    }
+    {   // errmsg 2: min|pivot| <= 8 N eps max|pivot| over the N pivots of the system (a zero pivot included)
+        double am = pmax, pm = pmin;
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+            am = fmax(am, __shfl_xor(am, d, 32));
+            pm = fmin(pm, __shfl_xor(pm, d, 32));
+        }
+        if (lane == 0 && !(pm > 8.0 * N * 2.220446049250313e-16 * am)) status |= 0x01;
+    }
+    if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
+#undef GC
+#undef KK
+#undef EK
+#undef ZZ
+#undef ZP0
+#undef ZP1
+}
+
+}  // namespace sbd

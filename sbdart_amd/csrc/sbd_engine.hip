@@ -181,6 +181,7 @@ struct sbd_engine {
     bool use_layer2 = true;
     bool band_reg = false;
     bool band4 = false;             // four systems per wave, block form (sbd_band4.hpp), NSTR <= 16
+    bool band1 = false;             // one system per wave, block form in registers (sbd_band1.hpp), 16 < NSTR <= 32
 };
 
 extern "C" {
@@ -366,9 +367,10 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const int svi_stride = (3 + L + 1 + 3) & ~3;
     // (band4: the band kernel reads GC and scales it itself, no ga/gb blocks -- a third of the workspace)
     bool band4 = nn <= 8;
-    if (const char *s = getenv("SBD_BAND_V1")) band4 = band4 && atoi(s) == 0;
+    bool band1 = nn >= 9 && nn <= 16;
+    if (const char *s = getenv("SBD_BAND_V1")) { band4 = band4 && atoi(s) == 0; band1 = band1 && atoi(s) == 0; }
     const size_t nblk = band4 ? 1 : 3;
-    const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * (2 * n)
+    const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)n * n : 0) + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * (2 * n)
                                             + (rad ? (size_t)L * n * numu + 3 * (size_t)L * numu + (size_t)e->nlev * numu : 0));
     const size_t per_slot = per_ms * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
     size_t budget = (size_t)64 << 30;   // of 288 GB: fewer, larger passes (launch tails cost ~7 % at 16k items)
@@ -410,7 +412,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         } else {
             P.ga = (double *)take(sizeof(double) * nms * L * n * n);
             P.gb = (double *)take(sizeof(double) * nms * L * n * n);
-            P.bcb = nullptr;
+            P.bcb = band1 ? (double *)take(sizeof(double) * nms * n * n) : nullptr;
             P.gcc = nullptr;
         }
         P.kk = (double *)take(sizeof(double) * nms * L * n);
@@ -456,6 +458,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->band_reg = nn <= 10;                       // register-resident LU window (sbd_band.hpp)
     if (const char *s = getenv("SBD_BAND_LDS")) e->band_reg = e->band_reg && atoi(s) == 0;
     e->band4 = band4;
+    e->band1 = band1;
     e->P.ublock = e->P.gconly = band4 ? 1 : 0;
     const sbd::BandLds bl(n, nn, e->band_reg);
     e->band_lds = (int)sizeof(double) * bl.total;
@@ -654,6 +657,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         {
             const unsigned bgrid = (unsigned)((size_t)ns * nmode);
             if (e->band4) sbd::launch_band4(e->nn, (bgrid + 3) / 4, st, P);
+            else if (e->band1) sbd::launch_band1(e->nn, bgrid, st, P);
             else if (e->band_reg) sbd::launch_band_reg(e->nn, bgrid, e->band_lds, st, P);
             else sbd::launch_band_lds(e->nn, bgrid, e->band_lds, st, P);
         }
