@@ -12,14 +12,14 @@
 // window rows in registers: ONE array a[RW] per lane (96 VGPRs at NSTR = 32), against 33 KB of LDS per
 // wave in the LDS-window kernel it replaces (one wave per SIMD).  The right-hand side is a vector across
 // the lanes: lane p <-> window row p.  One sub-step J:
-//   * pivot search inside lane J (column J's live rows are that lane's registers), on 26-bit keys that
-//     carry the row index (threshold pivoting 1 - 2^-14; LINPACK takes the exact maximum);
+//   * column J of the live rows (lane J's registers) crosses to the lanes through 384 bytes of LDS: lane J
+//     writes (ds_write2_b64), every lane reads its row's entry and the entries of rows 16k + lane%16;
+//   * pivot search over the lanes on the DPP network, LINPACK's first-maximum rule exactly;
 //   * the pivot row leaves its registers by a computed jump on the wave-uniform row index (generated
 //     inline asm, sbd_band1_take.inc) and the last live row takes its place;
-//   * elimination a[p] += a[p](lane J) * (t * -1/pivot): the multiplier travels through an SGPR pair
-//     (v_readlane) and is the scalar operand of the FMA -- 3 instructions per live row, no LDS;
-//   * the right-hand side needs column J transposed (lane p <- a[p] of lane J): lane J writes its live
-//     registers to 384 bytes of LDS (ds_write2_b64), every lane reads its row's entry: one FMA;
+//   * elimination a[p] += a[p](lane J) * (t * -1/pivot): the multipliers, replicated in every row of 16
+//     lanes, are read by the DP-ALU DPP form of the FMA (row_newbcast): ONE instruction per live row;
+//   * the right-hand side takes its multipliers lane-wise from the same column: one FMA;
 //   * rows of the next interface are fetched into the registers of retired rows (+ E buffer rows) while
 //     this layer is eliminated.
 #pragma once
@@ -43,14 +43,38 @@ SBD_DEVICE void write_live(unsigned addr, const double (&a)[RW])
     }
 }
 
+template <int I>
+SBD_DEVICE double fmac_row16(double acc, double m, double t)        // acc + m(lane I of the lane's row of 16) * t
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(m), "v"(t), "n"(I));
+    return acc;
+}
+
 SBD_DEVICE double uniform_from_lane(double x, int src)          // x of lane src (wave-uniform src), in SGPRs
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src),
                             __builtin_amdgcn_readlane(__double2loint(x), src));
 }
 
+// ISAMAX's first-maximum rule over lanes 0..lm (wave_first_max with the lane number passed in)
+SBD_DEVICE int wave_first_max_of(double a, int lane, int lm)
+{
+    const bool cand = lane <= lm;
+    const unsigned hi = cand ? ((unsigned)__double2hiint(a) & 0x7fffffffu) : 0u;
+    const unsigned mhi = wave_umax<true>(hi);
+    unsigned long long hit = __ballot(cand && hi == mhi);
+    if (hit & (hit - 1ull)) {                       // several lanes share the leading word
+        const bool c2 = cand && hi == mhi;
+        const unsigned lo = c2 ? (unsigned)__double2loint(a) : 0u;
+        const unsigned mlo = wave_umax<true>(lo);
+        hit = __ballot(c2 && lo == mlo);
+    }
+    return hit ? __ffsll((long long)hit) - 1 : 0;
+}
+
 template <int NN>
-__global__ void __launch_bounds__(64) band1_kernel(Params P)
+__global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int n = 2 * NN, nn = NN, RW = nn + n, UW = u_width(n);
@@ -93,7 +117,7 @@ __global__ void __launch_bounds__(64) band1_kernel(Params P)
     const double *gb_ms = P.gb + (size_t)ms * L * n * n + (size_t)n * n;    // ... [row][column of x_lc+1]
     double *yv = P.yv + (size_t)ms * L * n;
     double *ufac = P.ufac + (size_t)ms * (size_t)(L * n) * UW;
-    double *bcb = P.bcb + (size_t)ms * n * n;                      // bottom-boundary rows (below)
+    double *bcb = P.bcb + (size_t)ms * 2 * n * n;                  // bottom-boundary rows + a block of zeros (below)
     double *mcol = smem;                                           // [RW] pivot column, for the right-hand side
     const int N = ncut * n;
 #define GC(i, j, lc) gc[((size_t)((lc) - 1) * n + ((i) - 1)) * n + ((j) - 1)]
@@ -167,18 +191,20 @@ __global__ void __launch_bounds__(64) band1_kernel(Params P)
                 g = g * f;
             }
             bcb[r * n + qc] = g;
+            bcb[(n + r) * n + qc] = 0.0;
         }
     }
     __threadfence_block();   // the boundary block is re-read by this wave as its rows enter the window
 
-    // rows of step lci (r = 0..n-1) for this lane: p[r * stride]
-    struct RowSrc { const double *p; int stride; };
+    // rows of step lci (r = 0..n-1) for this lane: p[r * n] -- an interface block, the boundary block, or
+    // the block of zeros behind it (compile-time stride: immediate offsets, no per-row address registers)
+    struct RowSrc { const double *p; };
     auto step_rows = [&](int lci) -> RowSrc {
-        const double *zero_row = bcb + (size_t)nn * n + qc;                 // (rows nn.. of the block are zero)
-        if (!col || lci > ncut) return RowSrc{zero_row, 0};
-        if (lci == ncut) return second ? RowSrc{zero_row, 0} : RowSrc{bcb + qc, n};
+        const double *zeros = bcb + (size_t)n * n + qc;
+        if (!col || lci > ncut) return RowSrc{zeros};
+        if (lci == ncut) return second ? RowSrc{zeros} : RowSrc{bcb + qc};
         const size_t blk = (size_t)(lci - 1) * n * n + qc;
-        return RowSrc{(second ? gb_ms : ga_ms) + blk, n};
+        return RowSrc{(second ? gb_ms : ga_ms) + blk};
     };
     // right-hand side of row r = lane - nn of step lci: an interface, the bottom boundary, nothing
     const int rr = (lane >= nn && lane < RW) ? lane - nn : 0;
@@ -207,7 +233,7 @@ __global__ void __launch_bounds__(64) band1_kernel(Params P)
         const RowSrc s1 = step_rows(1);
 #pragma unroll
         for (int r = 0; r < n; ++r) {
-            const double v = s1.p[r * s1.stride];
+            const double v = s1.p[r * n];
             a[nn + r] = col ? v : 0.0;
         }
         const Z3 z1 = load_z(1), z2 = load_z(2);
@@ -227,34 +253,43 @@ __global__ void __launch_bounds__(64) band1_kernel(Params P)
         const int k0 = (lc - 1) * n;                            // rows k0+1 .. k0+n retire in this step
         double *urow0 = ufac + (size_t)k0 * UW;
         double *yrow0 = yv + k0;
-        int qo = q;                                             // (opaque per step: keeps the compiler from hoisting
-        asm volatile("" : "+v"(qo));                            //  per-sub-step store addresses out of the loop)
         const bool tail = lc == ncut;                           // the last layer has no x_lc+1
         static_for<n>([&](auto jj) {
             constexpr int J = decltype(jj)::value;
             constexpr int LAST = RW - 1 - J;                    // live rows: registers 0..LAST
-            // (1) pivot search in column J = lane J's own registers: key = leading word of |a| with its
-            //     last 6 bits replaced by 63 - p (largest magnitude, first row among near-ties)
-            unsigned kmax = 0u;
-#pragma unroll
-            for (int p = 0; p <= LAST; ++p) {
-                const unsigned key = ((unsigned)__double2hiint(a[p]) & 0x7fffffc0u) | (unsigned)(63 - p);
-                kmax = (key > kmax) ? key : kmax;
-            }
-            const int idx = __builtin_amdgcn_readlane(63 - (int)(kmax & 63u), J);    // wave-uniform
-            // (2) pivot row out of its registers, the last live row into them; the same for y
+            // (the lane number is made opaque per sub-step: otherwise the compiler keeps the 32 x ~6 lane
+            //  predicates and addresses of the unrolled sub-steps alive across the whole layer loop)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int lq = ln & 31, l16 = ln & 15;
+            const bool second = ln >= 32, col = lq < n;
+            // (1) column J of the live rows crosses to the lanes through LDS: lane J writes its registers,
+            //     every lane reads row `lane`'s entry (v: pivot search, right-hand side) and the entries of
+            //     rows 16k + lane%16 (m0..m2: the multipliers, replicated in each row of 16 lanes for the
+            //     DPP form of the elimination FMA)
+            if (ln == J) write_live<0, LAST + 1>(lds_addr(mcol), a);   // (only live registers: the others may be loads in flight)
+            wave_lds_sync();
+            double v = mcol[ln];                                 // (lanes beyond the live rows: never used)
+            double m0 = mcol[l16], m1 = mcol[16 + l16], m2 = mcol[32 + l16];
+            wave_lds_sync();
+            // (2) ISAMAX's first-maximum rule on the DPP network; the pivot row leaves its registers, the
+            //     last live row takes its place -- in the window, in y and in the column just read
+            const int idx = wave_first_max_of(v, ln, LAST);
             double t;
             TakeRow1<RW, LAST>::run(a, idx, t);
             const double ypiv = uniform_from_lane(y, idx);
             {
-                const double ylast = uniform_from_lane(y, LAST);
-                y = (lane == idx) ? ylast : y;
+                const double ylast = uniform_from_lane(y, LAST), vlast = uniform_from_lane(v, LAST);
+                y = (ln == idx) ? ylast : y;
+                v = (ln == idx) ? vlast : v;
+                const bool mine = l16 == (idx & 15);
+                m0 = (mine && (idx >> 4) == 0) ? vlast : m0;
+                m1 = (mine && (idx >> 4) == 1) ? vlast : m1;
+                m2 = (mine && (idx >> 4) == 2) ? vlast : m2;
             }
-            // column J of the live rows (after the interchange) -> LDS, for the right-hand side
-            if (lane == J) write_live<0, LAST>(lds_addr(mcol), a);      // (only live registers: the others may be loads in flight)
             // register LAST is free from here on: next interface's row LAST - nn moves in
-            if constexpr (LAST - nn >= E) a[LAST] = nx.p[(LAST - nn) * nx.stride];
-            if constexpr (J < E) buf[J] = nx.p[J * nx.stride];
+            if constexpr (LAST - nn >= E) a[LAST] = nx.p[(LAST - nn) * n];
+            if constexpr (J < E) buf[J] = nx.p[J * n];
             if constexpr (J == 0) {
                 zu = load_z(lc + 1);
                 zn = load_z(lc + 2);
@@ -268,33 +303,29 @@ __global__ void __launch_bounds__(64) band1_kernel(Params P)
             rn = rn * (2.0 - t * rn);
             rn = (t != 0.0) ? -rn : 0.0;
             const double rns = uniform_from_lane(rn, J);
-            if (lane == J) { pmin = fmin(pmin, fabs(t)); pmax = fmax(pmax, fabs(t)); }
+            if (ln == J) { pmin = fmin(pmin, fabs(t)); pmax = fmax(pmax, fabs(t)); }
             // (4) the retired row: U(k, k..k+2n-1-J) relative to the diagonal, B(k)
             {
                 double *urow = urow0 + J * UW;
                 if (!second) {
-                    if (q >= J && col) urow[qo - J] = t;
+                    if (lq >= J && col) urow[lq - J] = t;
                 } else {
-                    if (col && !tail) urow[n - J + qo] = t;
+                    if (col && !tail) urow[n - J + lq] = t;
                 }
-                if (lane == 0) yrow0[J] = ypiv;
+                if (ln == 0) yrow0[J] = ypiv;
             }
-            // (5) elimination: a[p] += a[p](lane J) * (t * -1/pivot); columns <= J of x_lc are finished
-            //     (their registers keep the unscaled multipliers)
-            const double tp = (second || q > J) ? rns * t : 0.0;
-#pragma unroll
-            for (int p = 0; p < LAST; ++p) {
-                const double m = uniform_from_lane(a[p], J);
-                a[p] = a[p] + m * tp;
-            }
+            // (5) elimination: a[p] += a[p](lane J) * (t * -1/pivot), the multiplier from lane p%16 of the
+            //     lane's own row of 16 (v_fmac_f64_dpp row_newbcast); columns <= J of x_lc are finished
+            const double tp = (second || lq > J) ? rns * t : 0.0;
+            static_for<LAST>([&](auto pp) {
+                constexpr int p = decltype(pp)::value;
+                a[p] = fmac_row16<p & 15>(a[p], (p < 16) ? m0 : ((p < 32) ? m1 : m2), tp);
+            });
             // right-hand side: y(p) += a[p](lane J) * (y_pivot * -1/pivot) for the live rows
-            wave_lds_sync();
             {
-                const double mv = mcol[(lane < LAST) ? lane : 0];
                 const double yt = ypiv * rns;
-                y = (lane < LAST) ? y + mv * yt : y;
+                y = (ln < LAST) ? y + v * yt : y;
             }
-            wave_lds_sync();
         });
         // ---- the nn rows left over only touch x_lc+1: next step's carry (their entries move to the
         //      first half of the wave); the prefetched rows of the next step complete the window ----

@@ -370,7 +370,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     bool band1 = nn >= 9 && nn <= 16;
     if (const char *s = getenv("SBD_BAND_V1")) { band4 = band4 && atoi(s) == 0; band1 = band1 && atoi(s) == 0; }
     const size_t nblk = band4 ? 1 : 3;
-    const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)n * n : 0) + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * (2 * n)
+    const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)2 * n * n : 0) + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * (2 * n)
                                             + (rad ? (size_t)L * n * numu + 3 * (size_t)L * numu + (size_t)e->nlev * numu : 0));
     const size_t per_slot = per_ms * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
     size_t budget = (size_t)64 << 30;   // of 288 GB: fewer, larger passes (launch tails cost ~7 % at 16k items)
@@ -412,7 +412,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         } else {
             P.ga = (double *)take(sizeof(double) * nms * L * n * n);
             P.gb = (double *)take(sizeof(double) * nms * L * n * n);
-            P.bcb = band1 ? (double *)take(sizeof(double) * nms * n * n) : nullptr;
+            P.bcb = band1 ? (double *)take(sizeof(double) * nms * 2 * n * n) : nullptr;
             P.gcc = nullptr;
         }
         P.kk = (double *)take(sizeof(double) * nms * L * n);
