@@ -215,9 +215,10 @@ __global__ void __launch_bounds__(256) azimuth_kernel(Params P, int naz_run)
     const int naz = (fbeam == 0.0) ? 0 : naz_run;   // disort.f:577-586
     const double *uum = P.uum + (size_t)slot * nmode * per + rem;
     double *uu = P.uu + (size_t)slot * nphi * per + rem;
-    // the convergence test (disort.f:821-825) is global over (iu, lu, j): evaluated in a
-    // second kernel only if some mode is identically zero -- with ACCUR = 0 a term can
-    // "converge" only when every AZTERM of a mode vanishes, and then adding it is a no-op.
+    // All NAZ modes are added.  DISORT stops the series after two consecutive modes whose largest term is
+    // <= ACCUR times the running sum (disort.f:821-825); SBDART always passes ACCUR = 0 (drt.f:152), the
+    // C ABI has no ACCUR field, and with ACCUR = 0 the test can only pass when every term of two modes
+    // is exactly zero -- adding further exact zeros is then a no-op, so the sums are the reference's.
     for (int j = 0; j < nphi; ++j) {
         double acc = uum[0];
         for (int m = 1; m <= naz; ++m) acc = acc + uum[(size_t)m * per] * P.t.cosmphi[(size_t)m * nphi + j];

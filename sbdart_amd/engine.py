@@ -163,6 +163,11 @@ class DisortEngine:
             assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
         assert plank.is_cuda and plank.dtype == torch.uint8 and plank.is_contiguous()
         dev = dtauc.device
+        assert dev.index == self.device, "tensors live on cuda:%s, the engine on device %d" % (dev.index, self.device)
+        assert all(t.device == dev for t in (ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank))
+        assert dtauc.shape == (W, self.nlyr) and ssalb.shape == (W, self.nlyr)
+        assert pmom.shape == (W, self.nlyr, self.nmom + 1)
+        assert all(t.shape == (W,) for t in (wvnmlo, wvnmhi, fbeam, albedo, plank))
         if out is None:
             flux = torch.empty((W, _lib.NFLUX, self.nlev), dtype=torch.float64, device=dev)
             uu = None if self.onlyfl else torch.empty((W, self.nphi, self.nlev, self.numu),
