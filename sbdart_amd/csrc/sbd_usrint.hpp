@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) azimuth_kernel(Params P, int naz_run)
     const double *uum = P.uum + (size_t)slot * nmode * per + rem;
     double *uu = P.uu + (size_t)slot * nphi * per + rem;
     // All NAZ modes are added.  DISORT stops the series after two consecutive modes whose largest term is
-    // <= ACCUR times the running sum (disort.f:821-825); SBDART always passes ACCUR = 0 (drt.f:152), the
+    // <= ACCUR times the running sum (disort.f:821-825); SBDART always passes ACCUR = 0 (drt.f:142), the
     // C ABI has no ACCUR field, and with ACCUR = 0 the test can only pass when every term of two modes
     // is exactly zero -- adding further exact zeros is then a no-op, so the sums are the reference's.
     for (int j = 0; j < nphi; ++j) {
