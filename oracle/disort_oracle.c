@@ -1436,6 +1436,89 @@ static double *carve(double **p, size_t nelem)
     return r;
 }
 
+
+/* ---- Nakajima/Tanaka intensity corrections (CORINT): XIFUNC disort.f:4795-4862, SINSCA
+ *      disort.f:2996-3097, SECSCA disort.f:2299-2452, INTCOR disort.f:2044-2297 ---- */
+static double xifunc(double umu1, double umu2, double umu3, double tau)
+{
+    const double x1 = 1.0 / umu1 - 1.0 / umu2;
+    const double x2 = 1.0 / umu1 - 1.0 / umu3;
+    const double exp1 = exp(-tau / umu1);
+    if (umu2 == umu3 && umu1 == umu2) return tau * tau * exp1 / (2.0 * umu1 * umu2);
+    if (umu2 == umu3 && umu1 != umu2) return ((tau - 1.0 / x1) * exp(-tau / umu2) + exp1 / x1) / (x1 * umu1 * umu2);
+    if (umu2 != umu3 && umu1 == umu2) return ((exp(-tau / umu3) - exp1) / x2 - tau * exp1) / (x2 * umu1 * umu2);
+    if (umu2 != umu3 && umu1 == umu3) return ((exp(-tau / umu2) - exp1) / x1 - tau * exp1) / (x1 * umu1 * umu2);
+    return ((exp(-tau / umu3) - exp1) / x2 - (exp(-tau / umu2) - exp1) / x1) / (x2 * umu1 * umu2);
+}
+
+/* phase/omega 1-based over layers (index lc-1), tau 0-based over levels */
+static double sinsca(double dither, int layru, int nlyr, const double *phase, const double *omega,
+                     const double *tau, double umu, double umu0, double utau, double fbeam, double pi)
+{
+    double s = 0.0;
+    double exp0 = exp(-utau / umu0);
+    if (fabs(umu + umu0) <= dither) {
+        for (int lyr = 1; lyr <= layru - 1; ++lyr)
+            s = s + omega[lyr - 1] * phase[lyr - 1] * (tau[lyr] - tau[lyr - 1]);
+        return fbeam / (4.0 * pi * umu0) * exp0 * (s + omega[layru - 1] * phase[layru - 1] * (utau - tau[layru - 1]));
+    }
+    if (umu > 0.0) {
+        for (int lyr = layru; lyr <= nlyr; ++lyr) {
+            const double exp1 = exp(-((tau[lyr] - utau) / umu + tau[lyr] / umu0));
+            s = s + omega[lyr - 1] * phase[lyr - 1] * (exp0 - exp1);
+            exp0 = exp1;
+        }
+    } else {
+        for (int lyr = layru; lyr >= 1; --lyr) {
+            const double exp1 = exp(-((tau[lyr - 1] - utau) / umu + tau[lyr - 1] / umu0));
+            s = s + omega[lyr - 1] * phase[lyr - 1] * (exp0 - exp1);
+            exp0 = exp1;
+        }
+    }
+    return fbeam / (4.0 * pi * (1.0 + umu / umu0)) * s;
+}
+
+static double secsca(double ctheta, const double *flyr, int layru, int nmom, int nstr, const double *pmom,
+                     const double *ssalb, const double *dtauc, const double *tauc, double umu, double umu0,
+                     double utau, double fbeam, double pi)
+{
+    const double zero = f32(1e-4f);
+    double dtau = utau - tauc[layru - 1];
+    double wbar = ssalb[layru - 1] * dtau;
+    double fbar = flyr[layru - 1] * wbar;
+    double stau = dtau;
+    for (int lyr = 1; lyr <= layru - 1; ++lyr) {
+        wbar = wbar + ssalb[lyr - 1] * dtauc[lyr - 1];
+        fbar = fbar + ssalb[lyr - 1] * dtauc[lyr - 1] * flyr[lyr - 1];
+        stau = stau + dtauc[lyr - 1];
+    }
+    if (wbar <= zero || fbar <= zero || stau <= zero || fbeam <= zero) return 0.0;
+    fbar = fbar / wbar;
+    wbar = wbar / stau;
+    double pspike = 1.0, gbar = 1.0, plm1 = 1.0, plm2 = 0.0;
+    for (int k = 1; k <= nstr - 1; ++k) {
+        const double pl = ((double)(2 * k - 1) * ctheta * plm1 - (double)(k - 1) * plm2) / (double)k;
+        plm2 = plm1;
+        plm1 = pl;
+        pspike = pspike + (2.0 * gbar - gbar * gbar) * (double)(2 * k + 1) * pl;
+    }
+    for (int k = nstr; k <= nmom; ++k) {
+        const double pl = ((double)(2 * k - 1) * ctheta * plm1 - (double)(k - 1) * plm2) / (double)k;
+        plm2 = plm1;
+        plm1 = pl;
+        dtau = utau - tauc[layru - 1];
+        gbar = pmom[(size_t)(layru - 1) * (nmom + 1) + k] * ssalb[layru - 1] * dtau;
+        for (int lyr = 1; lyr <= layru - 1; ++lyr)
+            gbar = gbar + pmom[(size_t)(lyr - 1) * (nmom + 1) + k] * ssalb[lyr - 1] * dtauc[lyr - 1];
+        if (fbar * wbar * stau <= zero) gbar = 0.0;
+        else gbar = gbar / (fbar * wbar * stau);
+        pspike = pspike + (2.0 * gbar - gbar * gbar) * (double)(2 * k + 1) * pl;
+    }
+    const double umu0p = umu0 / (1.0 - fbar * wbar);
+    return fbeam / (4.0 * pi) * ((fbar * wbar) * (fbar * wbar)) / (1.0 - fbar * wbar) * pspike
+           * xifunc(-umu, umu0p, umu0p, utau);
+}
+
 int sbdo_disort(const sbdo_in *in, sbdo_out *out)
 {
     const int n0 = in->nstr;
@@ -1748,6 +1831,64 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
             if (kconv >= 2) break;
         }
 #undef UU
+    }
+
+    /* ---- INTCOR (disort.f:831-842, 2044-2297); CORINT is switched off without a beam, without
+     *      scattering and in flux-only runs (disort.f:2695-2696) ---- */
+    if (in->corint && !in->onlyfl && in->fbeam != 0.0 && yessct != 0.0) {
+        const int nmom = in->nmom;
+        double *phasa = (double *)calloc((size_t)3 * L, sizeof(double));
+        double *phast = phasa + L, *phasm = phast + L;
+        const double dtheta = 10.0;
+        double theta0 = 0.0, thetap = 0.0;   /* (SAVEd locals of the reference: set when UMU < 0) */
+#define UU(iu, lu, j) out->uu[((size_t)((j) - 1) * ntau + (size_t)((lu) - 1)) * numu + (size_t)((iu) - 1)]
+        for (int iu = 1; iu <= numu; ++iu) {
+            if (umu[iu - 1] < 0.0) {
+                theta0 = acos(-in->umu0) / rpd;
+                thetap = acos(umu[iu - 1]) / rpd;
+            }
+            for (int jp = 1; jp <= nphi; ++jp) {
+                const double ctheta = -in->umu0 * umu[iu - 1]
+                    + sqrt((1.0 - in->umu0 * in->umu0) * (1.0 - umu[iu - 1] * umu[iu - 1])) * cos(phirad[jp - 1]);
+                for (int lc = 1; lc <= ncut; ++lc) { phasa[lc - 1] = 1.0; phasm[lc - 1] = 1.0; }
+                double plm1 = 1.0, plm2 = 0.0;
+                for (int k = 1; k <= nmom; ++k) {
+                    const double pl = ((double)(2 * k - 1) * ctheta * plm1 - (double)(k - 1) * plm2) / (double)k;
+                    plm2 = plm1;
+                    plm1 = pl;
+                    for (int lc = 1; lc <= ncut; ++lc)
+                        phasa[lc - 1] = phasa[lc - 1] + (double)(2 * k + 1) * pl * in->pmom[(size_t)(lc - 1) * (nmom + 1) + k];
+                    if (k <= n - 1)
+                        for (int lc = 1; lc <= ncut; ++lc)
+                            phasm[lc - 1] = phasm[lc - 1] + (double)(2 * k + 1) * pl
+                                * (in->pmom[(size_t)(lc - 1) * (nmom + 1) + k] - w->flyr[lc - 1]) / (1.0 - w->flyr[lc - 1]);
+                }
+                for (int lc = 1; lc <= ncut; ++lc)
+                    phast[lc - 1] = phasa[lc - 1] / (1.0 - w->flyr[lc - 1] * ssalb[lc - 1]);
+                for (int lu = 1; lu <= ntau; ++lu) {
+                    if (!lyrcut || layru[lu - 1] < ncut) {
+                        const double ussndm = sinsca(dither, layru[lu - 1], ncut, phast, ssalb, w->taucpr,
+                                                     umu[iu - 1], in->umu0, utaupr[lu - 1], in->fbeam, pi);
+                        const double ussp = sinsca(dither, layru[lu - 1], ncut, phasm, w->oprim, w->taucpr,
+                                                   umu[iu - 1], in->umu0, utaupr[lu - 1], in->fbeam, pi);
+                        UU(iu, lu, jp) = UU(iu, lu, jp) + ussndm - ussp;
+                    }
+                }
+                if (umu[iu - 1] < 0.0 && fabs(theta0 - thetap) <= dtheta) {
+                    int ltau = 1;
+                    if (utau[0] <= dither) ltau = 2;
+                    for (int lu = ltau; lu <= ntau; ++lu) {
+                        if (!lyrcut || layru[lu - 1] < ncut) {
+                            const double duims = secsca(ctheta, w->flyr, layru[lu - 1], nmom, n, in->pmom, ssalb,
+                                                        dtauc, tauc, umu[iu - 1], in->umu0, utau[lu - 1], in->fbeam, pi);
+                            UU(iu, lu, jp) = UU(iu, lu, jp) - duims;
+                        }
+                    }
+                }
+            }
+        }
+#undef UU
+        free(phasa);
     }
 
 done:

@@ -35,6 +35,7 @@ typedef struct {
     int usrtau, ntau;           /* usrtau=0 in SBDART; kept for SLFTST */
     double wvnmlo, wvnmhi, fbeam, umu0, phi0, fisot, albedo, btemp, ttemp, temis;
     double accur;               /* azimuth-series convergence; SBDART passes 0 (drt.f:142) */
+    int corint;                 /* Nakajima/Tanaka intensity corrections (INTCOR, disort.f:2044) */
     const double *dtauc;        /* [nlyr]            top-down */
     const double *ssalb;        /* [nlyr]                     */
     const double *temper;       /* [nlyr+1]  levels 0..nlyr   */

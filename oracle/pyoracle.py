@@ -28,6 +28,7 @@ class _In(C.Structure):
                [(k, C.c_double) for k in
                 ("wvnmlo", "wvnmhi", "fbeam", "umu0", "phi0", "fisot", "albedo", "btemp",
                  "ttemp", "temis", "accur")] + \
+               [("corint", C.c_int)] + \
                [(k, _dp) for k in ("dtauc", "ssalb", "temper", "pmom", "umu", "phi", "utau")]
 
 
@@ -87,7 +88,7 @@ def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False, debug_mod
             usrang=int(rec.usrang), usrtau=int(usrtau), ntau=ntau,
             wvnmlo=rec.wvnmlo, wvnmhi=rec.wvnmhi, fbeam=rec.fbeam, umu0=rec.umu0,
             phi0=rec.phi0, fisot=rec.fisot, albedo=rec.albedo, btemp=rec.btemp,
-            ttemp=rec.ttemp, temis=rec.temis, accur=accur,
+            ttemp=rec.ttemp, temis=rec.temis, accur=accur, corint=int(getattr(rec, 'corint', False)),
             dtauc=_p(dtauc), ssalb=_p(ssalb), temper=_p(temper), pmom=_p(pmom),
             umu=_p(umu), phi=_p(phi), utau=_p(ut))
     flx = np.zeros((5, ntau))

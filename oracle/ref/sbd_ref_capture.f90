@@ -125,6 +125,7 @@ subroutine disort(nlyr, dtauc, ssalb, corint, nmom, pmom, temper, &
   if (onlyfl) flags = flags + 2
   if (lamber) flags = flags + 4
   if (usrang) flags = flags + 8
+  if (corint) flags = flags + 16
   numu_in = 0
   nphi_in = 0
   if (usrang) numu_in = numu

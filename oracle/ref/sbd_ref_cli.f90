@@ -116,7 +116,7 @@ program sbd_ref_cli
       onlyfl = iand(flags, 2) /= 0
       lamber = iand(flags, 4) /= 0
       usrang = iand(flags, 8) /= 0
-      corint = .false.
+      corint = iand(flags, 16) /= 0
       mxumu = max(numu, abs(nstr), 1)
       mxphi = max(nphi, 1)
       allocate(dtauc(nlyr), ssalb(nlyr), temper(0:nlyr), pmom(0:nmom, nlyr), &

@@ -10,7 +10,7 @@ All little-endian, no padding::
                   int32 has_out
     per record  : int32 hdr[12] = nlyr, nstr, nmom, numu, nphi, flags, kd, nk,
                                   iwl, ibcnd, 0, 0
-                  flags: bit0 PLANK, bit1 ONLYFL, bit2 LAMBER, bit3 USRANG
+                  flags: bit0 PLANK, bit1 ONLYFL, bit2 LAMBER, bit3 USRANG, bit4 CORINT
                   float64 sc[16] = wl, wt, ff, wvnmlo, wvnmhi, fbeam, umu0,
                                    phi0, albedo, btemp, ttemp, temis, fisot,
                                    accur, 0, 0
@@ -37,7 +37,7 @@ import numpy as np
 
 MAGIC = b"SBDREC1\0"
 
-F_PLANK, F_ONLYFL, F_LAMBER, F_USRANG = 1, 2, 4, 8
+F_PLANK, F_ONLYFL, F_LAMBER, F_USRANG, F_CORINT = 1, 2, 4, 8, 16
 
 
 @dataclasses.dataclass
@@ -94,6 +94,10 @@ class SolveRecord:
     @property
     def usrang(self) -> bool:
         return bool(self.flags & F_USRANG)
+
+    @property
+    def corint(self) -> bool:
+        return bool(self.flags & F_CORINT)
 
     @property
     def numu(self) -> int:

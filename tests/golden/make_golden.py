@@ -46,7 +46,13 @@ def every_nth_wl(recs, n, offset=0):
 def main():
     manifest = {}
 
+    only = set(sys.argv[1:])                      # names to (re)generate; none given = all
+    if only and os.path.exists(os.path.join(HERE, "MANIFEST.json")):
+        manifest.update(json.load(open(os.path.join(HERE, "MANIFEST.json"))))
+
     def emit(name, namelists, pick, keep_stdout=True, full_inputs=False):
+        if only and name not in only:
+            return None
         allrec, stdout, allw = [], "", []
         for nl in namelists:
             out, recs, warns = run_case(nl)
@@ -105,6 +111,15 @@ def main():
     emit("cfgD_nstr32_50ly",
          ["idatm=6 wlinf=.25 wlsup=100 wlinc=20 nstr=32 ngrid=50 iout=10 sza=30"],
          lambda r: every_nth_wl(r, 250, 7), keep_stdout=False)
+
+    # --- intensity corrections (CORINT = true: 299 phase-function moments per layer), one record each:
+    #     a cloud seen from below and above incl. the solar aureole (IMS term, viewing angles within 10
+    #     degrees of the beam), rural aerosol, and a thermal + solar point over a bright surface
+    emit("corint_nstr8",
+         ["idatm=6 wlinf=.55 wlsup=.55 iout=20 nstr=8 corint=t tcloud=3 zcloud=2 nzen=8 uzen=0,175 nphi=3 phi=0,180 sza=40",
+          "idatm=2 wlinf=.45 wlsup=.45 iout=20 nstr=8 corint=t iaer=1 vis=10 nzen=6 uzen=100,170 nphi=2 phi=0,90 sza=25 imoma=4",
+          "idatm=4 wlinf=3.8 wlsup=3.8 iout=20 nstr=8 corint=t tcloud=1 zcloud=4 nre=-30 albcon=.6 nzen=5 uzen=10,80 nphi=2 phi=30,150 sza=60"],
+         lambda r: r[-1:], keep_stdout=False)
 
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

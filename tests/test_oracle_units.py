@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 import pyoracle
-from sbdart_amd.records import F_LAMBER, F_PLANK, F_USRANG, SolveRecord
+from sbdart_amd.records import F_LAMBER, F_PLANK, F_USRANG, SolveRecord, F_CORINT
 
 from conftest import REF_DIR, have_ref
 
@@ -42,8 +42,13 @@ def test_slftst_known_answers():
     assert abs(o["rfldir"][0] / 1.527286 - 1) < 3e-7
     assert abs(o["rfldn"][0] / 28.372225 - 1) < 3e-7
     assert abs(o["flup"][0] / 152.585284 - 1) < 3e-7
-    # without CORINT the intensity sits 1.2e-4 below the corrected 47.865571
+    # without CORINT the intensity sits 1.2e-4 below the corrected 47.865571 ...
     assert abs(o["uu"][0, 0, 0] / 47.865571 - 1) < 2e-4
+    # ... and SLFTST runs with the intensity corrections on (disort.f:6373-6392): the fourth known answer
+    r = slftst_record()
+    r.flags |= F_CORINT
+    o = pyoracle.disort(r, utau=[0.5], accur=f32(1e-4))
+    assert abs(o["uu"][0, 0, 0] / 47.865571 - 1) < 3e-7
 
 
 def test_constants():
