@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SBD_ABI_VERSION 2
+#define SBD_ABI_VERSION 3
 
 /* limits of the reference (params.f:9-15) */
 #define SBD_MAX_NLYR 65   /* mxly   */
@@ -58,7 +58,7 @@ extern "C" {
                                    without a beam (FBEAM = 0) can still be solved with it */
 #define SBD_E_NO_DEVICE     -3
 #define SBD_E_HIP           -4  /* a HIP runtime call failed; see sbd_last_error() */
-#define SBD_E_UNSUPPORTED   -5  /* BRDF surface, IBCND=1, CORINT */
+#define SBD_E_UNSUPPORTED   -5  /* BRDF surface, IBCND=1 */
 #define SBD_E_NOMEM         -6
 
 /* ---- per-work-item status bits ---- */
@@ -95,6 +95,10 @@ typedef struct {
     int32_t device;        /* HIP device ordinal */
     int32_t max_batch;     /* largest nwork of one solve call (workspace is sized for
                               min(max_batch, chunk)); 0 = default */
+    int32_t corint;        /* CORINT: Nakajima/Tanaka intensity corrections (INTCOR, disort.f:2044-2297) on the
+                              radiances of every item with a beam and scattering (disort.f:2695-2696);
+                              SBDART then supplies nmom = 299 moments (drt.f:490-491); ignored when onlyfl */
+    int32_t reserved0;     /* 0 */
     double umu0;           /* cosine of solar zenith (amu0, drt.f:421,456-459) */
     double phi0;           /* solar azimuth, degrees */
     double fisot;          /* isotropic top illumination (0 in SBDART) */

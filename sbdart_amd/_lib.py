@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SBDART_AMD_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get("SBDART_AMD_LIB") or os.path.join(_HERE, "lib", "libsbdart_amd.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NFLUX = 5
 RFLDIR, RFLDN, FLUP, DFDT, UAVG = range(5)
 
@@ -25,7 +25,7 @@ _bp = C.POINTER(C.c_uint8)
 class RunCfg(C.Structure):
     _fields_ = [(k, C.c_int32) for k in
                 ("abi_version", "nlyr", "nstr", "nmom", "onlyfl", "lamber", "usrang", "numu",
-                 "nphi", "nlevel_out", "device", "max_batch")] + \
+                 "nphi", "nlevel_out", "device", "max_batch", "corint", "reserved0")] + \
                [(k, C.c_double) for k in ("umu0", "phi0", "fisot", "btemp", "ttemp", "temis")] + \
                [("temper", _dp), ("umu", _dp), ("phi", _dp), ("level_out", _ip)]
 

@@ -182,6 +182,7 @@ struct sbd_engine {
     bool band_reg = false;
     bool band4 = false;             // four systems per wave, block form (sbd_band4.hpp), NSTR <= 16
     bool band1 = false;             // one system per wave, block form in registers (sbd_band1.hpp), 16 < NSTR <= 32
+    bool corint = false;            // intensity corrections after the azimuth series (sbd_intcor.hpp)
 };
 
 extern "C" {
@@ -198,7 +199,7 @@ const char *sbd_strerror(int code)
     case SBD_E_RETRY_NSTR: return "beam angle equals a quadrature angle: change NSTR (disort.f:2645-2650)";
     case SBD_E_NO_DEVICE: return "no usable HIP device";
     case SBD_E_HIP: return "HIP runtime error";
-    case SBD_E_UNSUPPORTED: return "feature outside the hot-path scope (BRDF / IBCND=1 / CORINT)";
+    case SBD_E_UNSUPPORTED: return "feature outside the hot-path scope (BRDF / IBCND=1)";
     case SBD_E_NOMEM: return "out of device memory";
     default: return "unknown error";
     }
@@ -459,6 +460,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     if (const char *s = getenv("SBD_BAND_LDS")) e->band_reg = e->band_reg && atoi(s) == 0;
     e->band4 = band4;
     e->band1 = band1;
+    e->corint = rad && cfg->corint != 0;
     e->P.ublock = e->P.gconly = band4 ? 1 : 0;
     const sbd::BandLds bl(n, nn, e->band_reg);
     e->band_lds = (int)sizeof(double) * bl.total;
@@ -671,6 +673,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             sbd::launch_usrint((unsigned)((size_t)ns * nmode), e->usr_lds, st, P);
             const long long items = (long long)ns * nlev * e->P.numu;
             sbd::launch_azimuth((unsigned)((items + 255) / 256), st, P, e->naz_run);
+            if (e->corint) sbd::launch_intcor((unsigned)ns, st, P, e->naz_run);
         }
         hipLaunchKernelGGL(finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, P);
         if (hs) {   // this pass's outputs, staging -> host

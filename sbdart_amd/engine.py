@@ -39,7 +39,7 @@ class DisortEngine:
                  umu: Optional[Sequence[float]] = None, phi: Optional[Sequence[float]] = None,
                  btemp: float = 0.0, ttemp: float = 0.0, temis: float = 0.0, fisot: float = 0.0,
                  lamber: bool = True, level_out: Optional[Sequence[int]] = None, device: int = 0,
-                 max_batch: int = 0, allow_retry_nstr: bool = False):
+                 max_batch: int = 0, allow_retry_nstr: bool = False, corint: bool = False):
         self._L = _lib.load()
         self._h = C.c_void_p()
         self.nlyr, self.nstr, self.nmom = int(nlyr), int(nstr), int(nmom)
@@ -56,7 +56,7 @@ class DisortEngine:
             abi_version=_lib.ABI_VERSION, nlyr=self.nlyr, nstr=self.nstr, nmom=self.nmom,
             onlyfl=int(self.onlyfl), lamber=int(lamber), usrang=int(usrang), numu=self.numu,
             nphi=self.nphi, nlevel_out=0 if self._lev is None else len(self._lev), device=device,
-            max_batch=max_batch, umu0=umu0, phi0=phi0, fisot=fisot, btemp=btemp, ttemp=ttemp,
+            max_batch=max_batch, corint=int(bool(corint)), reserved0=0, umu0=umu0, phi0=phi0, fisot=fisot, btemp=btemp, ttemp=ttemp,
             temis=temis,
             temper=self._temper.ctypes.data_as(C.POINTER(C.c_double)),
             umu=self._umu.ctypes.data_as(C.POINTER(C.c_double)) if self.numu else None,
@@ -280,7 +280,8 @@ def engine_for_record(rec, level_out=None, device=0, max_batch=0, allow_retry_ns
         nlyr=rec.nlyr, nstr=rec.nstr, nmom=rec.nmom, temper=rec.temper, umu0=rec.umu0,
         phi0=rec.phi0, onlyfl=rec.onlyfl, usrang=rec.usrang, umu=rec.umu, phi=rec.phi,
         btemp=rec.btemp, ttemp=rec.ttemp, temis=rec.temis, fisot=rec.fisot, lamber=rec.lamber,
-        level_out=level_out, device=device, max_batch=max_batch, allow_retry_nstr=allow_retry_nstr)
+        level_out=level_out, device=device, max_batch=max_batch, allow_retry_nstr=allow_retry_nstr,
+        corint=getattr(rec, "corint", False))
 
 
 def run_key(rec):

@@ -17,6 +17,7 @@ module sbd_bandmodel_mod
   implicit none
   private
   public :: model_input, covered_by_band_model, build_work_items, aerosol_input
+  integer, parameter :: maxmom_all = 299               ! params.f:10
 
   type model_input                     ! the &INPUT variables this step reads, same names
     integer :: idatm = 4, nf = 2, isalb = 0, kdist = 3, nothrm = -1, ngrid = 0, nstr = 4
@@ -30,6 +31,7 @@ module sbd_bandmodel_mod
     real(kr) :: zgrid1 = 1, zgrid2 = 30
     real(kr) :: sc(5) = (/1._kr, 0._kr, 0._kr, 0._kr, 0._kr/)   ! ISALB=10: fractions of snow, ocean, sand, vegetation
     logical :: spowder = .false., radiance = .false.
+    logical :: corint = .false.            ! with radiances: all 299 phase-function moments go to the engine (drt.f:490-494)
     integer :: numu = 0, nphi = 0
   end type
 
@@ -203,7 +205,8 @@ contains
     end do
     btemp = m%btemp; if (btemp < 0.) btemp = temper(nz)
     ttemp = m%ttemp; if (ttemp < 0.) ttemp = temper(0)
-    nmom = min(m%nstr + 2, nstrms)
+    nmom = min(m%nstr + 2, nstrms)                          ! (two more than NSTR: room for the NSTR retry)
+    if (m%radiance .and. m%corint) nmom = maxmom_all
     amu0 = cos(m%sza*dtor)
     call surface_spectrum(m%isalb, m%albcon, m%sc, wlalb, alb)
     load = new_aerosol_load(m%aer, atm%z, rh_surface)

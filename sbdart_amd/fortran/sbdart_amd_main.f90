@@ -137,7 +137,7 @@ program sbdart_amd
     where (sc == huge(0.)) sc = (/1._kr, 0._kr, 0._kr, 0._kr, 0._kr/)          ! drt.f:249-262
     model%sc = sc
     model%zgrid1 = zgrid1; model%zgrid2 = zgrid2
-    model%spowder = spowder; model%radiance = radcalc
+    model%spowder = spowder; model%radiance = radcalc; model%corint = corint
     if (.not. covered_by_band_model(model, why)) &
       call fatal('no optics file ('//trim(path)//') and the band model does not cover this run yet: '//trim(why))
     call tables_load(ok, why)
@@ -277,7 +277,11 @@ program sbdart_amd
       end if
     end do
   end if
-  if (radcalc .and. nbeam > 0) &                    ! CHEKIN warning 7 (disort.f:5154-5158)
+  if (corint .and. nmom > 10 .and. npart > 0) then       ! CHEKIN warning 5 (disort.f:4939-4941)
+    if (any(pmom(nmom, :, 1:npart) > real(1.e-3, kr))) &
+      call warn_file(5, 'CHEKIN-- phase function not sufficiently resolved for use with corint=.true.')
+  end if
+  if (radcalc .and. nbeam > 0 .and. .not. corint) & ! CHEKIN warning 7 (disort.f:5154-5158)
     call warn_file(7, 'CHEKIN--intensity correction is off; intensities may be less accurate')
 
   ! ---- output ----
@@ -446,6 +450,7 @@ contains
       cfg%onlyfl = merge(0, 1, radcalc); cfg%lamber = 1; cfg%usrang = merge(1, 0, radcalc)
       cfg%numu = numu; cfg%nphi = merge(view%nphi, 0, radcalc)
       cfg%nlevel_out = nlev; cfg%device = 0; cfg%max_batch = p1 - p0 + 1
+      cfg%corint = merge(1, 0, corint .and. radcalc .and. beam)      ! (off without a beam, disort.f:2695)
       cfg%umu0 = recs(1)%umu0; cfg%phi0 = phi0; cfg%fisot = fisot
       cfg%btemp = btemp; cfg%ttemp = ttemp; cfg%temis = temis
       cfg%temper = c_loc(temper); cfg%umu = c_loc(umu); cfg%phi = c_loc(phiv)

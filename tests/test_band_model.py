@@ -147,6 +147,8 @@ VARIANTS = [
     "idatm=2 wlinf=.6 wlsup=3 wlinc=.1 tcloud=6 zcloud=2 rhcld=1 sza=30 iout=1",
     "idatm=4 wlinf=.6 wlsup=3 wlinc=.1 tcloud=6,1 zcloud=1,-4 rhcld=.9 krhclr=1 sza=30 iout=1",
     "idatm=5 wlinf=5 wlsup=12 wlinc=.25 tcloud=3,2,2 zcloud=.5,-9,11 rhcld=1 sza=30 iout=1",
+    # intensity corrections: all 299 moments of clouds and aerosols are handed over
+    "idatm=6 wlinf=.5 wlsup=.7 wlinc=.1 iout=20 nstr=8 corint=t tcloud=3 zcloud=2 iaer=1 vis=15 nzen=4 uzen=0,85 nphi=2 phi=0,180 sza=40 imomc=5",
     "idatm=3 wlinf=.6 wlsup=1.6 wlinc=.1 tcloud=4,1,2 zcloud=1,-3,10 nre=8,10,-30 sza=55 iout=1",
 ]
 

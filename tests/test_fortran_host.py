@@ -250,3 +250,19 @@ def test_testruns_from_input_alone(tmp_path):
             total += len(ref.split())
             print(f"{name}[{i}]: {len(ref.split())} tokens, {off} one unit off in the last printed digit", file=sys.stderr)
     assert total > 5000
+
+
+@pytest.mark.gpu
+@needs_flang
+@needs_ref
+@pytest.mark.parametrize("namelist", [
+    "idatm=6 wlinf=.5 wlsup=.7 wlinc=.1 iout=20 nstr=8 corint=t tcloud=3 zcloud=2 nzen=8 uzen=0,175 nphi=3 phi=0,180 sza=40",
+    "idatm=2 wlinf=.45 wlsup=.45 iout=21 nstr=16 corint=t iaer=1 vis=10 nzen=6 uzen=100,170 nphi=2 phi=0,90 sza=25",
+])
+def test_intensity_corrections_from_input_alone(tmp_path, namelist):
+    """CORINT = true through the whole host: 299 phase-function moments from the band model, the engine's
+    INTCOR kernel, the radiance writers -- against the reference's stdout for the same INPUT."""
+    _build()
+    ref, got, _ = run_reference_and_host(namelist, str(tmp_path), from_input=True)
+    off = _compare_stdout(got, ref)
+    print(f"{len(ref.split())} tokens, {off} one unit off in the last printed digit", file=sys.stderr)

@@ -383,3 +383,37 @@ def test_qr_fallback_path_matches():
     Cholesky pivot of the symmetrised problem is not positive): same answers."""
     errs = _alt_path_errors(SBD_FORCE_EIG_FALLBACK="1")
     assert max(errs) < TOL, max(errs)
+
+
+def test_intensity_corrections_against_oracle():
+    """CORINT = true (INTCOR, disort.f:2044-2297): random cloudy/hazy columns with 60-299 moments, viewing
+    angles on both sides of the horizon incl. the aureole of the beam (second-order term) and a column thick
+    enough for LYRCUT; the committed reference records with CORINT are part of
+    test_engine_matches_reference_records."""
+    import dataclasses
+    import pyoracle
+    from sbdart_amd.engine import solve_records
+    from sbdart_amd.records import F_CORINT, F_LAMBER, F_USRANG, SolveRecord
+    rng = np.random.default_rng(77)
+    recs = []
+    for case in range(12):
+        nstr = (4, 8, 16, 32)[case % 4]
+        L = int(rng.integers(2, 9))
+        nmom = (60, 120, 299)[case % 3]
+        g = rng.uniform(0.5, 0.9, L)
+        k = np.arange(nmom + 1)
+        pm = g[:, None] ** k[None, :]
+        dt = rng.uniform(0.05, 2.0, L) * (8.0 if case == 7 else 1.0)
+        w = rng.uniform(0.3, 0.999, L) * (0.5 if case == 7 else 1.0)
+        umu0 = float(rng.uniform(0.3, 0.95))
+        umu = np.sort(np.concatenate([-np.array([umu0 * 0.98, umu0 * 1.03]).clip(0.05, 0.99), [-0.2, 0.15, 0.7]]))
+        recs.append(SolveRecord(nlyr=L, nstr=nstr, nmom=nmom, flags=F_LAMBER | F_USRANG | F_CORINT,
+                                wvnmlo=10000.0, wvnmhi=10100.0, fbeam=float(rng.uniform(0.5, 3.0)), umu0=umu0,
+                                phi0=10.0, albedo=float(rng.uniform(0, 0.8)), btemp=290.0, ttemp=0.0, temis=0.0,
+                                dtauc=dt, ssalb=w, temper=np.linspace(220.0, 290.0, L + 1), pmom=pm,
+                                umu=umu, phi=np.array([10.0, 70.0, 190.0])))
+    outs = [pyoracle.disort(r) for r in recs]
+    plain = [pyoracle.disort(dataclasses.replace(r, flags=r.flags & ~F_CORINT)) for r in recs]
+    assert max(np.abs(o["uu"] - p["uu"]).max() / np.abs(o["uu"]).max() for o, p in zip(outs, plain)) > 1e-3
+    flux, uu, st = solve_records(recs)
+    _check(flux, uu, st, recs, outs)
