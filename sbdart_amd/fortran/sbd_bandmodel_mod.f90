@@ -48,7 +48,6 @@ contains
     if (.not. (m%isalb >= -1 .and. m%isalb <= 6) .and. m%isalb /= 10) why = 'BRDF surface (isalb 7, 8, 9)'
     if (m%kdist < 0) why = 'k-distribution files (kdist=-1)'
     if (m%nf == -2) why = 'solar spectrum from the k-distribution file (nf=-2)'
-    if (m%spowder) why = 'sub-surface layer (spowder)'
     ok = len_trim(why) == 0
   end function
 
@@ -195,16 +194,35 @@ contains
     call rescale_profiles(atm, m%sclh2o, m%uw, m%uo3, m%o3trp, m%ztrp, pbar)
     call set_trace_gases(mix, m%xgas, m%xo4)
     rh_surface = relative_humidity(atm%t(1), atm%wh(1))
-    deck = new_cloud_deck(atm%z, m%zcloud, m%tcloud, m%lwp, m%nre, m%imomc)
-    if (m%rhcld >= 0) call saturate_clouds(atm, deck%layer, m%rhcld, m%krhclr == 1)
-    allocate(uu(mxq, nz), temper(0:nz))
-    call absorber_columns(atm, mix, uu)
+    ! level temperatures top-down and the default boundary temperatures (drt.f:330-335) -- taken BEFORE the
+    ! sub-surface layer is added, as the reference does (the extra bottom level keeps temperature zero)
+    allocate(temper(0:nz + merge(1, 0, m%spowder)))
+    temper = 0.
     temper(0) = atm%t(nz)
     do i = 1, nz
       temper(i) = atm%t(nz + 1 - i)
     end do
     btemp = m%btemp; if (btemp < 0.) btemp = temper(nz)
     ttemp = m%ttemp; if (ttemp < 0.) ttemp = temper(0)
+    ! SPOWDER: one more layer under the surface, 1 km thick, without gases or Rayleigh scattering; what
+    ! scatters in it is the cloud the user puts there (drt.f:337-347, taugas.f:7557-7560)
+    if (m%spowder) then
+      if (nz >= 65) then
+        print *, 'Error --- nz < mxly is required with spowder option'
+        stop
+      end if
+      atm%z = (/-1._kr, atm%z/)
+      atm%p = (/1.1*atm%p(1), atm%p/)
+      atm%t = (/btemp, atm%t/)
+      atm%wh = (/0._kr, atm%wh/)
+      atm%wo = (/0._kr, atm%wo/)
+      nz = nz + 1
+      atm%nz = nz
+    end if
+    deck = new_cloud_deck(atm%z, m%zcloud, m%tcloud, m%lwp, m%nre, m%imomc)
+    if (m%rhcld >= 0) call saturate_clouds(atm, deck%layer, m%rhcld, m%krhclr == 1)
+    allocate(uu(mxq, nz))
+    call absorber_columns(atm, mix, uu)
     nmom = min(m%nstr + 2, nstrms)                          ! (two more than NSTR: room for the NSTR retry)
     if (m%radiance .and. m%corint) nmom = maxmom_all
     amu0 = cos(m%sza*dtor)
@@ -293,6 +311,7 @@ contains
       pmom(0, :) = 1.
 
       nk_of(iw) = nk
+      if (m%spowder) dtaur(nz) = 0.                                  ! (depthscl does this at every k-term)
       do k = 1, nk
         ! ---- gas depth of this k-term with the slant-path correction policy KDIST (depthscl) ----
         wt = gwk(k)
@@ -321,6 +340,7 @@ contains
             dtaug(l) = dtaugc(l) + dtauk(l, k)*(1. - ramp) + dtauk(l, k + mk)*ramp
           end do
         end if
+        if (m%spowder) dtaug(nz) = 0.
         ! ---- the work item ----
         associate (r => recs(mk*(iw - 1) + k))
         r%nlyr = nz; r%nstr = m%nstr; r%nmom = nmom; r%numu = size(umu); r%nphi = size(phi)

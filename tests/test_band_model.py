@@ -149,6 +149,9 @@ VARIANTS = [
     "idatm=5 wlinf=5 wlsup=12 wlinc=.25 tcloud=3,2,2 zcloud=.5,-9,11 rhcld=1 sza=30 iout=1",
     # intensity corrections: all 299 moments of clouds and aerosols are handed over
     "idatm=6 wlinf=.5 wlsup=.7 wlinc=.1 iout=20 nstr=8 corint=t tcloud=3 zcloud=2 iaer=1 vis=15 nzen=4 uzen=0,85 nphi=2 phi=0,180 sza=40 imomc=5",
+    # a scattering layer under the surface (snow or soil as a thick "cloud")
+    "idatm=4 wlinf=.4 wlsup=2.4 wlinc=.2 spowder=t tcloud=50 zcloud=-1 nre=60 albcon=.1 sza=50 iout=1",
+    "idatm=5 wlinf=3 wlsup=12 wlinc=1 spowder=t tcloud=20 zcloud=-1 nre=-100 btemp=260 sza=70 iout=1 nstr=8",
     "idatm=3 wlinf=.6 wlsup=1.6 wlinc=.1 tcloud=4,1,2 zcloud=1,-3,10 nre=8,10,-30 sza=55 iout=1",
 ]
 
@@ -197,7 +200,7 @@ def test_user_data_files(tmp_path, namelist):
 @needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
     for namelist, word in (("tcloud=5 nre=0", "cloud"), ("iaer=-1", "aerosol"), ("isalb=7", "surface"),
-                           ("spowder=t", "sub-surface")):
+                           ("kdist=-1", "k-distribution")):
         d = str(tmp_path / word)
         os.makedirs(d)
         with open(os.path.join(d, "INPUT"), "w") as f:

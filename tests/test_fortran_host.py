@@ -266,3 +266,29 @@ def test_intensity_corrections_from_input_alone(tmp_path, namelist):
     ref, got, _ = run_reference_and_host(namelist, str(tmp_path), from_input=True)
     off = _compare_stdout(got, ref)
     print(f"{len(ref.split())} tokens, {off} one unit off in the last printed digit", file=sys.stderr)
+
+
+DIVERSE = [
+    "idatm=6 wlinf=.5 wlsup=.9 wlinc=.2 iout=5 nstr=32 iaer=1 vis=23 nzen=20 uzen=0,85 nphi=16 phi=0,180 sza=30",   # BASELINE configs[3]
+    "idatm=6 wlinf=.25 wlsup=100 wlinc=20 nstr=32 ngrid=50 iout=10 sza=30",                                          # BASELINE configs[4]
+    "idatm=4 isat=6 sza=30 iout=10 isalb=6",
+    "idatm=2 wlinf=8 wlsup=13 wlinc=.25 sza=95 iout=11 tcloud=2 zcloud=6 nre=-40 rhcld=1",
+    "idatm=4 wlinf=.4 wlsup=2.4 wlinc=.1 spowder=t tcloud=50 zcloud=-1 nre=60 albcon=.1 sza=50 iout=1",
+    "idatm=5 wlinf=.3 wlsup=3 wlinc=.05 iaer=3 tbaer=.3 jaer=2 zaer=20 taerst=.05 uw=1.5 uo3=.3 sza=65 iout=7 zout=0,30",
+    "idatm=1 wlinf=.4 wlsup=1 wlinc=.1 isalb=10 sc=.2,.3,.1,.4 xco2=560 sza=20 iout=22 nstr=8 nzen=3 uzen=20,70 nphi=2 phi=0,120",
+]
+
+
+@pytest.mark.gpu
+@needs_flang
+@needs_ref
+@pytest.mark.parametrize("namelist", DIVERSE)
+def test_diverse_inputs_from_input_alone(tmp_path, namelist):
+    """INPUT -> stdout with no optics file over the band model's features (aerosols with radiances, the
+    regridded 50-layer atmosphere, a sensor filter over vegetation, a saturated ice cloud in the thermal with
+    heating rates, a sub-surface layer, trace-gas and column rescaling with output at altitude, a surface
+    mixture with radiances at every level): what the reference prints for the same INPUT."""
+    _build()
+    ref, got, _ = run_reference_and_host(namelist, str(tmp_path), from_input=True)
+    off = _compare_stdout(got, ref)
+    print(f"{len(ref.split())} tokens, {off} one unit off in the last printed digit", file=sys.stderr)
