@@ -317,7 +317,7 @@ program sbdart_amd
         sums%width_eq = sums%width_eq + dwl*recs(i)%ff
       end if
     end do
-    call write_run_record(sums, fmt, wlinf, wlsup, zlev, plev, view%phi, view%uzen)
+    call write_run_record(sums, fmt, sensor%wlmin, sensor%wlmax, zlev, plev, view%phi, view%uzen)   ! (wl1, wl2 of setfilt)
   end if
   call get_environment_variable('SBD_SUMS_FILE', path, plen, pstat)   ! full-precision sums for parity tests
   if (pstat == 0 .and. plen > 0) then
