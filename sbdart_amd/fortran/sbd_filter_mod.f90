@@ -7,7 +7,7 @@ module sbd_filter_mod
   use sbd_tables_mod, only: tbl
   implicit none
   private
-  public :: sensor_filter, new_filter, filter_value, read_spectrum_file
+  public :: sensor_filter, new_filter, filter_value, read_spectrum_file, solar_position
 
   type sensor_filter
     integer :: n = 0                          ! 0: flat response
@@ -16,6 +16,42 @@ module sbd_filter_mod
   end type
 
 contains
+
+  ! Solar zenith and azimuth angle (degrees) and the Earth-Sun distance factor 1/r^2 for day of year iday, UTC
+  ! hours `time`, latitude and longitude in degrees: equation of time and declination interpolated in a table of
+  ! five-day values, spherical triangle pole-observer-subsolar point (zensun, spectra.f:4440-4556)
+  subroutine solar_position(iday, time, alat, alon, zenith, azimuth, solfac)
+    integer, intent(in) :: iday
+    real(kr), intent(in) :: time, alat, alon
+    real(kr), intent(out) :: zenith, azimuth, solfac
+    real(kr), parameter :: pi = 3.1415926536_kr, degpday = 360./365.242, eccen = 0.01671, dayph = 2.
+    real(kr), pointer :: eqt(:), dec(:)
+    real(kr) :: dtor, dd, frac, eqtime, decang, sunlon, t0, t1, p0, p1, zz, xx, yy, rsun
+    integer :: i, d0, d1
+    eqt => tbl('sun.eqt'); dec => tbl('sun.dec')
+    dtor = pi/180.
+    dd = mod(iday - 1, 365) + 1
+    i = 2                                            ! table days 1, 6, 11, ... 366: the first one beyond dd
+    do while (1 + 5*(i - 1) <= dd .and. i < 74)
+      i = i + 1
+    end do
+    d0 = 1 + 5*(i - 2); d1 = 1 + 5*(i - 1)
+    frac = (dd - d0)/(d1 - d0)
+    eqtime = eqt(i - 1)*(1. - frac) + frac*eqt(i)
+    decang = dec(i - 1)*(1. - frac) + frac*dec(i)
+    sunlon = -15.*(time - 12. + eqtime/60.)
+    t0 = (90. - alat)*dtor
+    t1 = (90. - decang)*dtor
+    p0 = alon*dtor
+    p1 = sunlon*dtor
+    zz = cos(t0)*cos(t1) + sin(t0)*sin(t1)*cos(p1 - p0)
+    xx = sin(t1)*sin(p1 - p0)
+    yy = sin(t0)*cos(t1) - cos(t0)*sin(t1)*cos(p1 - p0)
+    azimuth = atan2(xx, yy)/dtor
+    zenith = acos(zz)/dtor
+    rsun = 1. - eccen*cos(degpday*(dd - dayph)*dtor)
+    solfac = 1./rsun**2
+  end subroutine
 
   ! two-column text file "wavelength value", at most nmax lines, returned in ascending wavelength
   subroutine read_spectrum_file(file, nmax, wl, r)

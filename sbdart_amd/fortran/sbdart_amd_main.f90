@@ -93,15 +93,33 @@ program sbdart_amd
   radcalc = fmt%radiance /= rad_none                    ! drt.f:237-247
   if (nstr == 0) nstr = merge(min(20, nstrms), 4, radcalc)
   if (radcalc) view = new_view(iout, nphi, phi, nzen, uzen, vzen)
-  phi0 = mod(saza - 180.0_kr + 360.0_kr, 360.0_kr)      ! drt.f:283
 
   ! ---- solar geometry (drt.f:275-283) ----
-  if (iday /= 0) call fatal('IDAY (solar ephemeris) is outside the hot path: give SZA')
-  if (csza /= unset) sza = acos(csza)/(real(3.1415926536d0, kr)/180.)
-  if (abs(sza - 90) < .01) sza = 95.
-  if (isat > 0) then
+  if (iday /= 0 .or. isat > 0) then
     call tables_load(ok, why)
     if (.not. ok) call fatal('tables not found; tried'//trim(why))
+  end if
+  if (iday /= 0) then
+    call solar_position(abs(iday), time, alat, alon, sza, saza, solfac)
+  else if (csza /= unset) then
+    sza = acos(csza)/(real(3.1415926536d0, kr)/180.)
+  end if
+  if (abs(sza - 90) < .01) sza = 95.
+  phi0 = mod(saza - 180.0_kr + 360.0_kr, 360.0_kr)      ! drt.f:283
+  if (iday < 0) then                                     ! drt.f:285-299: report the solar geometry and stop
+    print '(a5,6a9)', 'day', 'time', 'lat', 'lon', 'sza', 'azm', 'solfac'
+    print '(i5,6f9.3)', abs(iday), time, alat, alon, sza, saza, solfac
+    if (radcalc) then
+      print '(2a9)', 'phi', 'rel_az'
+      do i = 1, view%nphi
+        if (phi0 > 180. .and. view%phi(view%nphi) + phi0 > 360) then
+          print '(2f9.3)', view%phi(i), view%phi(i) + phi0 - 360.
+        else
+          print '(2f9.3)', view%phi(i), view%phi(i) + phi0
+        end if
+      end do
+    end if
+    stop
   end if
   sensor = new_filter(isat, wlinf, wlsup)            ! setfilt: the sensor's response and its wavelength limits
   grid = new_grid(sensor%wlmin, sensor%wlmax, wlinc)

@@ -152,6 +152,9 @@ VARIANTS = [
     # a scattering layer under the surface (snow or soil as a thick "cloud")
     "idatm=4 wlinf=.4 wlsup=2.4 wlinc=.2 spowder=t tcloud=50 zcloud=-1 nre=60 albcon=.1 sza=50 iout=1",
     "idatm=5 wlinf=3 wlsup=12 wlinc=1 spowder=t tcloud=20 zcloud=-1 nre=-100 btemp=260 sza=70 iout=1 nstr=8",
+    # solar geometry from day, time and place
+    "idatm=2 iday=172 time=18.5 alat=34.4 alon=-119.8 wlinf=.3 wlsup=3 wlinc=.1 iout=1",
+    "idatm=5 iday=400 time=3 alat=-70 alon=40 wlinf=.3 wlsup=3 wlinc=.3 iout=5 nzen=3 uzen=10,60 nphi=2 phi=0,90",
     "idatm=3 wlinf=.6 wlsup=1.6 wlinc=.1 tcloud=4,1,2 zcloud=1,-3,10 nre=8,10,-30 sza=55 iout=1",
 ]
 
@@ -208,3 +211,20 @@ def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
         p = subprocess.run([HOST], cwd=d, env=dict(os.environ, SBD_OPTICS=os.path.join(d, "none")),
                            capture_output=True, text=True)
         assert p.returncode != 0 and word in p.stderr, (namelist, p.stderr)
+
+
+@needs_host
+@pytest.mark.skipif(not os.path.exists(CAPTURE), reason="oracle/_ref/sbdart_capture not built")
+def test_solar_geometry_report(tmp_path):
+    """IDAY < 0: print day, time, place, solar zenith/azimuth, distance factor (and the relative azimuths
+    of a radiance run) and stop -- the reference's text (drt.f:285-299)."""
+    for k, nl in enumerate(("iday=-80 time=20.25 alat=19.8 alon=-155.5",
+                            "iday=-300 time=11 alat=52 alon=5 iout=20 nzen=2 uzen=10,40 nphi=3 phi=0,90")):
+        d = str(tmp_path / str(k))
+        os.makedirs(d)
+        with open(os.path.join(d, "INPUT"), "w") as f:
+            f.write("\n &INPUT\n" + nl + "\n /\n")
+        ref = subprocess.run([CAPTURE], cwd=d, capture_output=True, text=True).stdout
+        got = subprocess.run([HOST], cwd=d, env=dict(os.environ, SBD_OPTICS=os.path.join(d, "none")),
+                             capture_output=True, text=True).stdout
+        assert ref.split() and got.split() == ref.split(), (got, ref)

@@ -171,6 +171,10 @@ def main():
         tables.append(("alb%d.wl" % isalb, wl[:n].copy(), "output of `%s` (spectra.f:2899-3238)" % fn))
         tables.append(("alb%d.r" % isalb, alb[:n].copy(), "output of `%s`" % fn))
 
+    # ---- equation of time (minutes) and solar declination (degrees) every five days (zensun, spectra.f:4440-4556)
+    static("sun.eqt", "_QFzensunEeqt", "spectra.f:4467-4477")
+    static("sun.dec", "_QFzensunEdec", "spectra.f:4478-4488")
+
     # ---- sensor response functions ISAT 1..29 on their even wavelength grids (spectra.f:3414-4380):
     #      [wlmin, wlmax, response(1:n)] ----
     sensors = ("meteo", "goese", "goesw", "avhr81", "avhr82", "avhr91", "avhr92", "avhr101", "avhr102", "avhr111",
