@@ -38,6 +38,8 @@ module sbd_aerosol_mod
     real(kr) :: taerst(naerz) = 0
   end type
 
+  real(kr), pointer, save :: t_awl(:) => null(), t_strat(:) => null()
+
 contains
 
   integer function last_set(v) result(n)              ! largest index whose value is not "unset"
@@ -90,7 +92,7 @@ contains
     real(kr), pointer :: awl(:), t(:)
     real(kr) :: wt, absorp
     integer :: l
-    awl => tbl('aer.wl'); t => tbl('aer.strat')
+    awl => t_awl; t => t_strat
     wa = 0.
     l = bracket(awl, wl)
     if (wl <= awl(1)) then
@@ -127,6 +129,7 @@ contains
     integer :: nz, nzb, ndb, i, j, lev, nq, nw, ng, ne
     character(len=80) :: errmes(10)
     nz = size(z)
+    t_awl => tbl('aer.wl'); t_strat => tbl('aer.strat')       ! (resolved once per run)
     a%iaer = in%iaer; a%imoma = in%imoma; a%nosct = in%nosct; a%abaer = in%abaer
     a%jaer = in%jaer; a%taerst = in%taerst
     ! ---- stratospheric layers: the layer that holds each altitude ----

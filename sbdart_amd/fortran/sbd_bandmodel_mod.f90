@@ -78,30 +78,36 @@ contains
   end subroutine
 
   ! extraterrestrial solar irradiance (W/m2/um) at wl, linear in the spectrum's own grid (spectra.f:1367-1415)
-  real(kr) function solar_irradiance(wl, nf) result(e)
-    real(kr), intent(in) :: wl
+  real(kr) function solar_irradiance(wl, nf, w, s) result(e)
+    real(kr), intent(in) :: wl, w(:), s(:)               ! the spectrum (solar_spectrum): wavelengths, irradiance
     integer, intent(in) :: nf
-    real(kr), pointer :: w(:), s(:)
-    real(kr), allocatable, target, save :: wfile(:), sfile(:)
-    character(len=4) :: name
     real(kr) :: wt
     integer :: j
     if (nf == 0) then
       e = 1.
       return
     end if
-    if (nf == -1) then                       ! solar.dat, read once (before the threaded loop: build_work_items)
-      if (.not. allocated(wfile)) call read_spectrum_file('solar.dat', 5000, wfile, sfile)
-      w => wfile; s => sfile
-    else
-      write(name, '(a,i1)') 'sun', nf
-      w => tbl(name//'.wl'); s => tbl(name//'.irr')
-    end if
     j = bracket(w, wl)
     wt = (wl - w(j))/(w(j + 1) - w(j))
     wt = max(0._kr, min(1._kr, wt))
     e = s(j)*(1. - wt) + s(j + 1)*wt
   end function
+
+  ! NF: 1 5S, 2 LOWTRAN7, 3 MODTRAN3 (tables), -1 the file solar.dat, 0 none (unit irradiance)
+  subroutine solar_spectrum(nf, w, s)
+    integer, intent(in) :: nf
+    real(kr), allocatable, intent(out) :: w(:), s(:)
+    character(len=4) :: name
+    select case (nf)
+    case (-1)
+      call read_spectrum_file('solar.dat', 5000, w, s)
+    case (1:3)
+      write(name, '(a,i1)') 'sun', nf
+      w = tbl(name//'.wl'); s = tbl(name//'.irr')
+    case default
+      w = (/0._kr, 1._kr/); s = (/1._kr, 1._kr/)
+    end select
+  end subroutine
 
   ! albedo spectrum of the surface: ISALB 0 constant, 1-6 snow / clear water / lake water / sea water /
   ! sand / vegetation, 10 a mixture of snow, sea water, sand and vegetation (suralb, spectra.f:61-118)
@@ -159,21 +165,26 @@ contains
     ramp = ramp*exp(1. - max(tsc, 1._kr))
   end function
 
-  ! The work items of a run, ordered by wavelength then k-term.  The wavelengths are independent of each
-  ! other (the reference's saved state is replaced by values prepared once per run), so the loop over them is
-  ! an OpenMP parallel loop: every wavelength fills its own three slots, which are then closed up.
-  subroutine build_work_items(m, grid, umu, phi, recs, nrec, atm)
+  ! The work items of a run, ordered by wavelength then k-term: the scalars of every item in recs (no arrays
+  ! allocated there), the layer arrays in contiguous batch arrays -- the engine's input layout.  The wavelengths
+  ! are independent of each other (the reference's saved state is replaced by values prepared once per run), so
+  ! the loop over them is an OpenMP parallel loop: every wavelength fills its own MK slots, a second parallel
+  ! loop closes the slots up.  No allocation inside the loops.
+  subroutine build_work_items(m, grid, umu, phi, recs, nrec, atm, bdtauc, bssalb, bpmom, btemper)
     type(model_input), intent(in) :: m
     type(spectral_grid), intent(in) :: grid
     real(kr), intent(in) :: umu(:), phi(:)
     type(optics_t), allocatable, intent(out) :: recs(:)
     integer, intent(out) :: nrec
     type(atmosphere), intent(out) :: atm
+    real(kr), allocatable, intent(out) :: bdtauc(:, :), bssalb(:, :), bpmom(:, :, :), btemper(:)
     type(trace_gases) :: mix
     type(cloud_deck) :: deck
     type(aerosol_load) :: load
-    real(kr), allocatable :: uu(:, :), temper(:), wlalb(:), alb(:)
-    integer, allocatable :: nk_of(:)
+    real(kr), allocatable :: uu(:, :), temper(:), wlalb(:), alb(:), wsun(:), ssun(:)
+    real(kr), allocatable :: sd(:, :), ss(:, :), sp(:, :, :), swt(:, :), swl(:), slo(:), shi(:), sfb(:), salb(:)
+    logical, allocatable :: splank(:)
+    integer, allocatable :: nk_of(:), first(:)
     real(kr) :: pbar, amu0, btemp, ttemp, rh_surface
     real(kr), parameter :: dtor = 3.1415926536_kr/180.
     integer :: nz, nmom, iwl, kd, i
@@ -186,7 +197,6 @@ contains
       atm = model_atmosphere(m%idatm)
     end if
     if (m%amix > -1.) call mix_in(atm, m%amix)
-    if (m%nf == -1) pbar = solar_irradiance(1._kr, m%nf)       ! (reads solar.dat before the threads start)
     if (m%ngrid /= 0) call regrid(atm, m%zgrid1, m%zgrid2, m%ngrid)
     nz = atm%nz
     pbar = m%pbar
@@ -227,12 +237,16 @@ contains
     if (m%radiance .and. m%corint) nmom = maxmom_all
     amu0 = cos(m%sza*dtor)
     call surface_spectrum(m%isalb, m%albcon, m%sc, wlalb, alb)
+    call solar_spectrum(m%nf, wsun, ssun)
+    call gas_tables_init()
+    call cloud_tables_init()
     load = new_aerosol_load(m%aer, atm%z, rh_surface)
 
-    allocate(recs(mk*grid%n), nk_of(grid%n))
-    ! threads: one per 64 wavelengths, at most 16 -- every work item allocates its six arrays inside the loop,
-    ! and beyond ~16 threads the allocator, not the arithmetic, sets the pace (measured on the 256-core GPU box,
-    ! 75 001 wavelengths: 1.7 s with 1 thread, 0.4-0.5 s with 16, 2.0 s with 64, 3.5 s with 128)
+    allocate(nk_of(grid%n), first(grid%n), sd(nz, mk*grid%n), ss(nz, mk*grid%n), sp(0:nmom, nz, mk*grid%n), &
+             swt(mk, grid%n), swl(grid%n), slo(grid%n), shi(grid%n), sfb(grid%n), salb(grid%n), splank(grid%n))
+    ! threads: one per 64 wavelengths, at most 16 (measured on the 256-core GPU box, 75 001 wavelengths: 1.2 s
+    ! with 1 thread, 0.25-0.31 s with 16, 0.46-0.5 s with 64: first-touch page faults of the 2.5 GB of slot
+    ! and batch arrays, not arithmetic, set the pace beyond that)
     nthreads = max(1, min(omp_get_max_threads(), grid%n/64, 16))
     !$omp parallel do schedule(dynamic, 16) num_threads(nthreads) proc_bind(spread)
     do iwl = 1, grid%n
@@ -241,25 +255,30 @@ contains
     !$omp end parallel do
     nrec = 0
     do iwl = 1, grid%n
+      first(iwl) = nrec + 1
+      nrec = nrec + nk_of(iwl)
+    end do
+    allocate(recs(nrec), bdtauc(nz, nrec), bssalb(nz, nrec), bpmom(0:nmom, nz, nrec), btemper(0:nz))
+    btemper = temper
+    !$omp parallel do schedule(static) num_threads(nthreads) private(kd, i)
+    do iwl = 1, grid%n
       do kd = 1, nk_of(iwl)
-        nrec = nrec + 1
-        if (nrec /= mk*(iwl - 1) + kd) call move_item(recs(mk*(iwl - 1) + kd), recs(nrec))
+        i = first(iwl) + kd - 1
+        bdtauc(:, i) = sd(:, mk*(iwl - 1) + kd)
+        bssalb(:, i) = ss(:, mk*(iwl - 1) + kd)
+        bpmom(:, :, i) = sp(:, :, mk*(iwl - 1) + kd)
+        recs(i)%nlyr = nz; recs(i)%nstr = m%nstr; recs(i)%nmom = nmom; recs(i)%numu = size(umu); recs(i)%nphi = size(phi)
+        recs(i)%flags = merge(1, 0, splank(iwl)) + merge(0, 2, m%radiance) + merge(16, 0, m%radiance .and. m%corint)
+        recs(i)%kd = kd; recs(i)%nk = nk_of(iwl); recs(i)%iwl = iwl
+        recs(i)%wl = swl(iwl); recs(i)%wt = swt(kd, iwl); recs(i)%ff = 1.
+        recs(i)%wvnmlo = slo(iwl); recs(i)%wvnmhi = shi(iwl); recs(i)%fbeam = sfb(iwl)
+        recs(i)%umu0 = merge(1._kr, amu0, m%sza >= 90.); recs(i)%phi0 = m%phi0; recs(i)%albedo = salb(iwl)
+        recs(i)%btemp = btemp; recs(i)%ttemp = ttemp; recs(i)%temis = m%temis; recs(i)%fisot = m%fisot
       end do
     end do
+    !$omp end parallel do
 
   contains
-
-    subroutine move_item(from, to)
-      type(optics_t), intent(inout) :: from, to
-      to%nlyr = from%nlyr; to%nstr = from%nstr; to%nmom = from%nmom; to%numu = from%numu; to%nphi = from%nphi
-      to%flags = from%flags; to%kd = from%kd; to%nk = from%nk; to%iwl = from%iwl
-      to%wl = from%wl; to%wt = from%wt; to%ff = from%ff; to%wvnmlo = from%wvnmlo; to%wvnmhi = from%wvnmhi
-      to%fbeam = from%fbeam; to%umu0 = from%umu0; to%phi0 = from%phi0; to%albedo = from%albedo
-      to%btemp = from%btemp; to%ttemp = from%ttemp; to%temis = from%temis; to%fisot = from%fisot
-      call move_alloc(from%dtauc, to%dtauc); call move_alloc(from%ssalb, to%ssalb)
-      call move_alloc(from%temper, to%temper); call move_alloc(from%pmom, to%pmom)
-      call move_alloc(from%umu, to%umu); call move_alloc(from%phi, to%phi)
-    end subroutine
 
     subroutine one_wavelength(iw)
       integer, intent(in) :: iw
@@ -280,7 +299,7 @@ contains
       spec = spectrum_at(wl, mix%xo4)
       call gas_terms(m%kdist, spec, uu, amu_gas, atm%z, nz, nk, gwk, dtauk, dtaugc)
       dwl = 10000./wvlo - 10000./wvhi
-      flxin = solar_irradiance(wl, m%nf)*dwl*m%solfac
+      flxin = solar_irradiance(wl, m%nf, wsun, ssun)*dwl*m%solfac
       if (m%nf == 0) flxin = dwl
       if (m%sza >= 90.) flxin = 0.
       if (m%nothrm < 0) then
@@ -311,6 +330,7 @@ contains
       pmom(0, :) = 1.
 
       nk_of(iw) = nk
+      swl(iw) = wl; slo(iw) = wvlo; shi(iw) = wvhi; sfb(iw) = flxin; salb(iw) = rsfc; splank(iw) = plank
       if (m%spowder) dtaur(nz) = 0.                                  ! (depthscl does this at every k-term)
       do k = 1, nk
         ! ---- gas depth of this k-term with the slant-path correction policy KDIST (depthscl) ----
@@ -341,27 +361,17 @@ contains
           end do
         end if
         if (m%spowder) dtaug(nz) = 0.
-        ! ---- the work item ----
-        associate (r => recs(mk*(iw - 1) + k))
-        r%nlyr = nz; r%nstr = m%nstr; r%nmom = nmom; r%numu = size(umu); r%nphi = size(phi)
-        r%flags = merge(1, 0, plank) + merge(0, 2, m%radiance)
-        r%kd = k; r%nk = nk; r%iwl = iw
-        r%wl = wl; r%wt = wt; r%ff = 1.; r%wvnmlo = wvlo; r%wvnmhi = wvhi; r%fbeam = flxin
-        r%umu0 = amu_sun; r%phi0 = m%phi0; r%albedo = rsfc; r%btemp = btemp; r%ttemp = ttemp
-        r%temis = m%temis; r%fisot = m%fisot
-        if (.not. allocated(r%dtauc)) allocate(r%dtauc(nz), r%ssalb(nz), r%temper(0:nz), r%pmom(0:nmom, nz), &
-                                               r%umu(size(umu)), r%phi(size(phi)))
-        r%temper = temper; r%umu = umu; r%phi = phi
-        r%pmom = pmom
+        ! ---- the work item's layer arrays ----
+        swt(k, iw) = wt
+        sp(:, :, mk*(iw - 1) + k) = pmom
         do l = 1, nz
-          r%dtauc(l) = dtaug(l) + dtauc(l) + dtaua(l) + dtaur(l)
-          if (r%dtauc(l) > tiny(1._kr)) then
-            r%ssalb(l) = (dtauc(l)*wcld(l) + dtaua(l)*waer(l) + dtaur(l))/r%dtauc(l)
+          sd(l, mk*(iw - 1) + k) = dtaug(l) + dtauc(l) + dtaua(l) + dtaur(l)
+          if (sd(l, mk*(iw - 1) + k) > tiny(1._kr)) then
+            ss(l, mk*(iw - 1) + k) = (dtauc(l)*wcld(l) + dtaua(l)*waer(l) + dtaur(l))/sd(l, mk*(iw - 1) + k)
           else
-            r%ssalb(l) = 0.
+            ss(l, mk*(iw - 1) + k) = 0.
           end if
         end do
-        end associate
       end do
     end subroutine
   end subroutine

@@ -9,7 +9,7 @@ module sbd_cloud_mod
   use sbd_tables_mod
   implicit none
   private
-  public :: cloud_deck, new_cloud_deck, cloud_depths, phase_moments, layers_of_altitudes, ncldz
+  public :: cloud_deck, new_cloud_deck, cloud_depths, phase_moments, layers_of_altitudes, ncldz, cloud_tables_init
 
   integer, parameter :: ncldz = 5                    ! cloud slots (params.f:12)
   real(kr), parameter :: wl55 = 0.55                 ! wavelength TCLOUD is quoted at (params.f:27)
@@ -21,7 +21,16 @@ module sbd_cloud_mod
     integer :: imomc = 3
   end type
 
+  real(kr), pointer, save :: t_q(:) => null(), t_w(:) => null(), t_g(:) => null(), t_qi(:) => null(), &
+                             t_wi(:) => null(), t_gi(:) => null(), t_haze(:) => null(), t_c1(:) => null()
+
 contains
+
+  subroutine cloud_tables_init()       ! once per run: no name look-ups in the wavelength loop
+    t_q => tbl('cloud.q'); t_w => tbl('cloud.w'); t_g => tbl('cloud.g')
+    t_qi => tbl('cloud.qi'); t_wi => tbl('cloud.wi'); t_gi => tbl('cloud.gi')
+    t_haze => tbl('pmom.haze_l'); t_c1 => tbl('pmom.cloud_c1')
+  end subroutine
 
   ! layers (1 = top; layer k lies above level nz+1-k) that hold the altitudes zz; a negative altitude
   ! after the first marks the upper end of an extended layer and gives a negative layer number
@@ -82,9 +91,9 @@ contains
     ir = int(fr)
     fr = fr - ir
     if (re < 0.) then
-      q => tbl('cloud.qi'); w => tbl('cloud.wi'); g => tbl('cloud.gi')
+      q => t_qi; w => t_wi; g => t_gi
     else
-      q => tbl('cloud.q'); w => tbl('cloud.w'); g => tbl('cloud.g')
+      q => t_q; w => t_w; g => t_g
     end if
     qc = bilinear(q); wc = bilinear(w); gc = bilinear(g)
   contains
@@ -114,12 +123,12 @@ contains
         pm(k) = gg**k
       end do
     case (4)
-      t => tbl('pmom.haze_l')
+      t => t_haze
       do k = 1, min(82, nmom)
         pm(k) = t(k)/(2*k + 1)
       end do
     case (5)
-      t => tbl('pmom.cloud_c1')
+      t => t_c1
       do k = 1, min(298, nmom)
         pm(k) = t(k)/(2*k + 1)
       end do

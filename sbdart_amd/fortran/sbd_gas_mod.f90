@@ -11,7 +11,7 @@ module sbd_gas_mod
   use sbd_tables_mod
   implicit none
   private
-  public :: gas_spectrum, spectrum_at, path_depths, gas_terms, nmol, mk
+  public :: gas_spectrum, spectrum_at, path_depths, gas_terms, nmol, mk, gas_tables_init
 
   integer, parameter :: nmol = 11          ! h2o co2 o3 n2o co ch4 o2 no so2 no2 nh3
   integer, parameter :: mk = 3             ! k-distribution terms
@@ -36,6 +36,17 @@ module sbd_gas_mod
     10, 1515, 1695, 55,   10, 2800, 2970, 55,   9, 0, 185, 56,   9, 400, 650, 57,   9, 950, 1460, 57, &
     9, 2415, 2580, 57 /), (/4, nrange/))
 
+  ! the tables, resolved once per run by gas_tables_init (no name look-ups in the wavelength loop)
+  type rtab
+    real(kr), pointer :: p(:) => null()
+  end type
+  type itab
+    integer, pointer :: p(:) => null()
+  end type
+  type(rtab), save :: t_self296, t_self260, t_foreign, t_n2, t_h1, t_h2, t_h3, t_o2s0, t_o2a, t_o2b, t_o4, t_o3uv, &
+                      t_hh0, t_hh1, t_hh2, t_chap, t_schrun, t_cp(nmol), t_bs(nmol), t_ba(nmol), t_bb(nmol), t_bc(nmol)
+  type(itab), save :: t_lo(nmol), t_hi(nmol)
+
   type gas_spectrum
     real(kr) :: v = 0                       ! wavenumber 1e4/wl
     ! continua (per unit of the absorber amounts of sbd_atmos_mod)
@@ -49,6 +60,21 @@ module sbd_gas_mod
   end type
 
 contains
+
+  subroutine gas_tables_init()
+    integer :: m
+    t_self296%p => tbl('h2o.self296'); t_self260%p => tbl('h2o.self260'); t_foreign%p => tbl('h2o.foreign')
+    t_n2%p => tbl('n2.cont'); t_h1%p => tbl('hno3.h1'); t_h2%p => tbl('hno3.h2'); t_h3%p => tbl('hno3.h3')
+    t_o2s0%p => tbl('o2.s0'); t_o2a%p => tbl('o2.a'); t_o2b%p => tbl('o2.b'); t_o4%p => tbl('o4.sig')
+    t_o3uv%p => tbl('o3.uv'); t_hh0%p => tbl('o3.hh0'); t_hh1%p => tbl('o3.hh1'); t_hh2%p => tbl('o3.hh2')
+    t_chap%p => tbl('o3.chappuis'); t_schrun%p => tbl('o2.schrun')
+    do m = 1, nmol
+      t_cp(m)%p => tbl('cp.'//trim(mol_name(m)))
+      t_lo(m)%p => tbl_int('iwl.'//trim(mol_name(m))); t_hi(m)%p => tbl_int('iwh.'//trim(mol_name(m)))
+      t_bs(m)%p => tbl('bs.'//trim(mol_name(m))); t_ba(m)%p => tbl('ba.'//trim(mol_name(m)))
+      t_bb(m)%p => tbl('bb.'//trim(mol_name(m))); t_bc(m)%p => tbl('bc.'//trim(mol_name(m)))
+    end do
+  end subroutine
 
   ! value of a 10 cm-1 table that starts at v1: the entry at v, or the mean of the two around it when v
   ! is not a multiple of 10 (the reference's rule, taugas.f:3854-3871)
@@ -64,13 +90,13 @@ contains
 
   ! band-model coefficient of one molecule at wavenumber v (5 cm-1 table over the molecule's spectral
   ! regions iwl..iwh, stored back to back); -20 outside every region (taugas.f:6416-6456)
-  real(kr) function band_coefficient(mol, v) result(c)
-    character(len=*), intent(in) :: mol
+  real(kr) function band_coefficient(m, v) result(c)
+    integer, intent(in) :: m
     real(kr), intent(in) :: v
     integer, pointer :: lo(:), hi(:)
     real(kr), pointer :: cp(:)
     integer :: iv, r, before
-    lo => tbl_int('iwl.'//mol); hi => tbl_int('iwh.'//mol); cp => tbl('cp.'//mol)
+    lo => t_lo(m)%p; hi => t_hi(m)%p; cp => t_cp(m)%p
     iv = v
     c = -20.0
     before = 0
@@ -95,9 +121,9 @@ contains
     iv5 = 5*(int(10000.0/wl)/5)
     s%v = v
     ! ---- water-vapour continuum: self at 296 K and 260 K, foreign; radiation field factors ----
-    s%self296 = ten_wavenumber_table(tbl('h2o.self296'), -20._kr, v)
-    s%self260 = ten_wavenumber_table(tbl('h2o.self260'), -20._kr, v)
-    s%foreign = ten_wavenumber_table(tbl('h2o.foreign'), -20._kr, v)
+    s%self296 = ten_wavenumber_table(t_self296%p, -20._kr, v)
+    s%self260 = ten_wavenumber_table(t_self260%p, -20._kr, v)
+    s%foreign = ten_wavenumber_table(t_foreign%p, -20._kr, v)
     if (s%self296 > 0.) then
       alpha2 = 200.**2
       xh2o = (1. - 0.2333*(alpha2/((v - 1050.)**2 + alpha2)))
@@ -118,17 +144,17 @@ contains
     s%far_wing = 1./(ya + yb)
     ! ---- nitrogen continuum, 2080-2740 cm-1 ----
     if (v >= 2080. .and. v <= 2740.) then
-      t => tbl('n2.cont')
+      t => t_n2%p
       i = v
       s%n2 = t((i - 2080)/5 + 1)
     end if
     ! ---- nitric acid, three windows ----
     if (v >= 850.0 .and. v <= 920.0) then
-      t => tbl('hno3.h1'); i = (v - 845.)/5.; s%hno3 = t(i)
+      t => t_h1%p; i = (v - 845.)/5.; s%hno3 = t(i)
     else if (v >= 1275.0 .and. v <= 1350.0) then
-      t => tbl('hno3.h2'); i = (v - 1270.)/5.; s%hno3 = t(i)
+      t => t_h2%p; i = (v - 1270.)/5.; s%hno3 = t(i)
     else if (v >= 1675.0 .and. v <= 1735.0) then
-      t => tbl('hno3.h3'); i = (v - 1670.)/5.; s%hno3 = t(i)
+      t => t_h3%p; i = (v - 1670.)/5.; s%hno3 = t(i)
     end if
     ! ---- oxygen: Herzberg continuum (analytic), 1395-1760 cm-1 collision-induced band ----
     if (v > 36000.00) then
@@ -141,10 +167,10 @@ contains
     if (.not. (v < 1395 .or. v > 1760)) then
       i = (v - 1395.0_kr)/5.0_kr + 1.00001
       a = 0.; b = 0.; c = 0.
-      t => tbl('o2.s0')
+      t => t_o2s0%p
       if (i >= 1 .and. i <= size(t)) then
         c = t(i)
-        t1 => tbl('o2.a'); t2 => tbl('o2.b')
+        t1 => t_o2a%p; t2 => t_o2b%p
         a = t1(i); b = t2(i)
       end if
       s%o2_a = a
@@ -157,14 +183,14 @@ contains
     f = wnm - inm
     inm = inm - 335 + 1
     if (inm >= 1 .and. inm <= 1015) then
-      t => tbl('o4.sig')
+      t => t_o4%p
       factor = fraco2**2
       if (wl > 1.2) factor = fraco2*(fraco2 + effn2*fracn2)
       s%o4 = xo4*factor*(t(inm)*(1. - f) + t(inm + 1)*f)
     end if
     ! ---- ozone: Hartley (UV), Hartley-Huggins with temperature terms, Chappuis ----
     if (v > 40800) then
-      t => tbl('o3.uv')
+      t => t_o3uv%p
       n = size(t)
       c = 0.
       i = (v - 40800._kr)/100._kr + 1.00001
@@ -181,28 +207,28 @@ contains
       end if
       s%oz(1) = .269*c
     else if (v > 24370) then
-      t => tbl('o3.hh0')
+      t => t_hh0%p
       i = (v - 27370._kr)/5._kr + 1.00001
       if (i >= 1 .and. i <= size(t)) then
-        t1 => tbl('o3.hh1'); t2 => tbl('o3.hh2')
+        t1 => t_hh1%p; t2 => t_hh2%p
         s%oz(1) = .269*t(i)
         s%oz(2) = t(i)*t1(i)
         s%oz(3) = t(i)*t2(i)
       end if
     else if (v >= 13000. .and. v <= 24200) then
-      t => tbl('o3.chappuis')
+      t => t_chap%p
       xi = (v - 13000.0)/200.0 + 1.
       n = xi + 1.001
       s%oz(1) = t(n) + (xi - float(n))*(t(n) - t(n - 1))
     end if
     ! ---- band model: coefficient, band and band parameters of every molecule ----
     do m = 1, nmol
-      s%cp(m) = band_coefficient(trim(mol_name(m)), v)
+      s%cp(m) = band_coefficient(m, v)
     end do
     call assign_bands(band_range, nrange)
     if (iv5 >= 49600 .and. iv5 <= 52710) s%bs(7) = .4704          ! Schumann-Runge: its own band-model exponent
     if (v > 49600) then                                           ! ... and coefficients
-      t => tbl('o2.schrun')
+      t => t_schrun%p
       s%cp(7) = -20.
       i = (v - 49600._kr)/5._kr + 1.0001
       if (i >= 1 .and. i <= size(t)) s%cp(7) = t(i)
@@ -210,17 +236,16 @@ contains
   contains
     subroutine assign_bands(ranges, nr)
       integer, intent(in) :: nr, ranges(4, nr)
-      real(kr), pointer :: p(:)
       integer :: band
       do k = 1, nr
         if (iv5 < ranges(2, k) .or. iv5 > ranges(3, k)) cycle
         m = ranges(1, k)
         s%slot(m) = ranges(4, k)
         band = ranges(4, k) - slot_base(m)
-        p => tbl('bs.'//trim(mol_name(m))); s%bs(m) = p(band)
-        p => tbl('ba.'//trim(mol_name(m))); s%ba(m) = p(band)
-        p => tbl('bb.'//trim(mol_name(m))); s%bb(m) = p(band)
-        p => tbl('bc.'//trim(mol_name(m))); s%bc(m) = p(band)
+        s%bs(m) = t_bs(m)%p(band)
+        s%ba(m) = t_ba(m)%p(band)
+        s%bb(m) = t_bb(m)%p(band)
+        s%bc(m) = t_bc(m)%p(band)
       end do
     end subroutine
   end function

@@ -76,10 +76,12 @@ contains
   end subroutine
 
   ! the work items as an input-only SBDREC1 file (what read_optics reads)
-  subroutine write_optics(path, recs, nrec)
+  ! (the layer arrays either inside the records or, when the band model made them, in its batch arrays)
+  subroutine write_optics(path, recs, nrec, bdtauc, bssalb, bpmom, btemper, umu, phi)
     character(len=*), intent(in) :: path
     type(optics_t), intent(in) :: recs(:)
     integer, intent(in) :: nrec
+    real(kr), intent(in), optional :: bdtauc(:, :), bssalb(:, :), bpmom(:, :, :), btemper(:), umu(:), phi(:)
     integer :: u, i, hdr(12)
     real(kr) :: sc(16)
     open(newunit=u, file=path, access='stream', form='unformatted', status='replace')
@@ -91,7 +93,11 @@ contains
       sc(1:13) = (/recs(i)%wl, recs(i)%wt, recs(i)%ff, recs(i)%wvnmlo, recs(i)%wvnmhi, recs(i)%fbeam, recs(i)%umu0, &
                    recs(i)%phi0, recs(i)%albedo, recs(i)%btemp, recs(i)%ttemp, recs(i)%temis, recs(i)%fisot/)
       write(u) hdr, sc
-      write(u) recs(i)%dtauc, recs(i)%ssalb, recs(i)%temper, recs(i)%pmom, recs(i)%umu, recs(i)%phi
+      if (present(bdtauc)) then
+        write(u) bdtauc(:, i), bssalb(:, i), btemper, bpmom(:, :, i), umu, phi
+      else
+        write(u) recs(i)%dtauc, recs(i)%ssalb, recs(i)%temper, recs(i)%pmom, recs(i)%umu, recs(i)%phi
+      end if
     end do
     close(u)
   end subroutine

@@ -71,7 +71,9 @@ program sbdart_amd
   type(model_input) :: model
   type(sensor_filter) :: sensor
   type(atmosphere) :: atm
-  logical :: have_file, ok
+  logical :: have_file, ok, from_model = .false., in_place
+  real(kr), allocatable, target :: bdtauc(:, :), bssalb(:, :), bpmom(:, :, :)
+  real(kr), allocatable :: btemper(:)
   integer(kind=8) :: tick0, tick1, tick2, tick_rate
   character(len=256) :: why
 
@@ -162,7 +164,9 @@ program sbdart_amd
     if (.not. ok) call fatal('band-model tables not found; tried'//trim(why))
     call viewing_cosines()
     call system_clock(tick0, tick_rate)
-    call build_work_items(model, grid, umu(1:numu), phiv(1:merge(view%nphi, 0, radcalc)), recs, nrec, atm)
+    call build_work_items(model, grid, umu(1:numu), phiv(1:merge(view%nphi, 0, radcalc)), recs, nrec, atm, &
+                          bdtauc, bssalb, bpmom, btemper)
+    from_model = .true.
     call system_clock(tick1)
     call get_environment_variable('SBD_TIMING', path, plen, pstat)
     if (pstat == 0 .and. plen > 0) write(0, '(a,i0,a,i0,a,f9.4,a)') 'sbdart_amd: band model: ', grid%n, &
@@ -178,7 +182,12 @@ program sbdart_amd
   nmom = recs(1)%nmom
   call get_environment_variable('SBD_DUMP_OPTICS', path, plen, pstat)      ! the work items, for inspection / tests
   if (pstat == 0 .and. plen > 0) then
-    call write_optics(trim(path), recs, nrec)
+    if (from_model) then
+      call write_optics(trim(path), recs, nrec, bdtauc, bssalb, bpmom, btemper, umu(1:numu), &
+                        phiv(1:merge(view%nphi, 0, radcalc)))
+    else
+      call write_optics(trim(path), recs, nrec)
+    end if
     stop
   end if
 
@@ -239,20 +248,34 @@ program sbdart_amd
       where_solved(i) = npart
     end if
   end do
-  allocate(dtauc(nz, nrec), ssalb(nz, nrec), pmom(0:nmom, nz, nrec), wvnmlo(nrec), wvnmhi(nrec), &
-           fbeam(nrec), albedo(nrec), plank(nrec), status(nrec), weight(nrec), temper(0:nz))
+  ! (the band model's arrays are already the batch when every item is solved and all or none have a beam)
+  in_place = from_model .and. npart == nrec .and. (nbeam == nrec .or. nbeam == 0)
+  allocate(wvnmlo(nrec), wvnmhi(nrec), fbeam(nrec), albedo(nrec), plank(nrec), status(nrec), weight(nrec), temper(0:nz))
+  if (in_place) then
+    call move_alloc(bdtauc, dtauc); call move_alloc(bssalb, ssalb); call move_alloc(bpmom, pmom)
+  else
+    allocate(dtauc(nz, nrec), ssalb(nz, nrec), pmom(0:nmom, nz, nrec))
+  end if
   status = 0
   do ip = 1, npart
     i = order(ip)
-    dtauc(:, ip) = recs(i)%dtauc
-    ssalb(:, ip) = recs(i)%ssalb
-    pmom(:, :, ip) = recs(i)%pmom
+    if (.not. in_place) then
+      if (from_model) then
+        dtauc(:, ip) = bdtauc(:, i); ssalb(:, ip) = bssalb(:, i); pmom(:, :, ip) = bpmom(:, :, i)
+      else
+        dtauc(:, ip) = recs(i)%dtauc; ssalb(:, ip) = recs(i)%ssalb; pmom(:, :, ip) = recs(i)%pmom
+      end if
+    end if
     wvnmlo(ip) = recs(i)%wvnmlo; wvnmhi(ip) = recs(i)%wvnmhi
     fbeam(ip) = recs(i)%fbeam; albedo(ip) = recs(i)%albedo
     plank(ip) = int(iand(recs(i)%flags, 1), c_int8_t)
     weight(ip) = recs(i)%wt*recs(i)%ff                 ! dwt of stdout1 (drt.f:964)
   end do
-  temper = recs(1)%temper
+  if (from_model) then
+    temper = btemper
+  else
+    temper = recs(1)%temper
+  end if
   if (btemp < 0._kr) btemp = recs(1)%btemp          ! drt.f:334-335 defaults come with the profile
   if (ttemp < 0._kr) ttemp = recs(1)%ttemp
 
