@@ -16,7 +16,7 @@ module sbd_bandmodel_mod
   use omp_lib, only: omp_get_max_threads
   implicit none
   private
-  public :: model_input, covered_by_band_model, build_work_items, aerosol_input
+  public :: model_input, covered_by_band_model, build_work_items, aerosol_input, gas_depth_report
   integer, parameter :: maxmom_all = 299               ! params.f:10
 
   type model_input                     ! the &INPUT variables this step reads, same names
@@ -164,6 +164,49 @@ contains
     ramp = max(min(1._kr, ramp), 0._kr)
     ramp = ramp*exp(1. - max(tsc, 1._kr))
   end function
+
+  ! IOUT = 2: no radiative transfer, one line per wavelength with the gas optical depth of the slant path to the
+  ! surface by absorber (water lines + continuum, CO2, O3, N2O, CO, CH4, O2 + N2, trace gases, total)
+  ! (drt.f:440-445 with taugas' diagnostic print, taugas.f:2497-2500).  An absorber without a band at a
+  ! wavelength shows the value of the last wavelength where it had one, as in the reference.
+  subroutine gas_depth_report(m, grid)
+    type(model_input), intent(in) :: m
+    type(spectral_grid), intent(in) :: grid
+    type(atmosphere) :: atm
+    type(trace_gases) :: mix
+    type(cloud_deck) :: deck
+    type(gas_spectrum) :: spec
+    real(kr), allocatable :: uu(:, :), dc(:), dl(:)
+    real(kr) :: pbar, amu0, wl, wvlo, wvhi, col(9), carry(nmol)
+    real(kr), parameter :: dtor = 3.1415926536_kr/180.
+    integer :: nz, iwl
+    carry = 0.
+    if (m%idatm == 0) then
+      atm = user_atmosphere()
+    else
+      atm = model_atmosphere(m%idatm)
+    end if
+    if (m%amix > -1.) call mix_in(atm, m%amix)
+    if (m%ngrid /= 0) call regrid(atm, m%zgrid1, m%zgrid2, m%ngrid)
+    pbar = m%pbar
+    if (m%zpres /= unset) pbar = pressure_at(atm, m%zpres)
+    call rescale_profiles(atm, m%sclh2o, m%uw, m%uo3, m%o3trp, m%ztrp, pbar)
+    call set_trace_gases(mix, m%xgas, m%xo4)
+    nz = atm%nz
+    deck = new_cloud_deck(atm%z, m%zcloud, m%tcloud, m%lwp, m%nre, m%imomc)
+    if (m%rhcld >= 0) call saturate_clouds(atm, deck%layer, m%rhcld, m%krhclr == 1)
+    allocate(uu(mxq, nz), dc(nz), dl(nz))
+    call absorber_columns(atm, mix, uu)
+    call gas_tables_init()
+    amu0 = cos(m%sza*dtor)
+    print *, 'nwl', grid%n
+    do iwl = 1, grid%n
+      call grid%band(iwl - 1, wl, wvlo, wvhi)
+      spec = spectrum_at(wl, mix%xo4)
+      call path_depths(spec, uu, amu0, atm%z, nz, dc, dl, col, carry)
+      print '(f11.4,9es11.3)', wl, col(1) + col(2), col(3:9), sum(col)
+    end do
+  end subroutine
 
   ! The work items of a run, ordered by wavelength then k-term: the scalars of every item in recs (no arrays
   ! allocated there), the layer arrays in contiguous batch arrays -- the engine's input layout.  The wavelengths

@@ -252,11 +252,18 @@ contains
 
   ! Continuum and band-model ("line") optical depth of every layer for a path whose zenith cosine at the
   ! ground is amu0 (spherical-shell air mass per layer); layer 1 is the top (taugas.f:2236-2534)
-  subroutine path_depths(s, uu, amu0, z, nz, dtau_cont, dtau_line)
+  subroutine path_depths(s, uu, amu0, z, nz, dtau_cont, dtau_line, column, carry)
     type(gas_spectrum), intent(in) :: s
     integer, intent(in) :: nz
     real(kr), intent(in) :: uu(mxq, nz), amu0, z(nz)
     real(kr), intent(out) :: dtau_cont(nz), dtau_line(nz)
+    ! whole-path optical depth by absorber (IOUT 2): water lines, water continuum, CO2, O3, N2O, CO, CH4,
+    ! O2 + N2 (lines and continua), trace gases (NO, SO2, NO2, NH3 lines)
+    real(kr), intent(out), optional :: column(9)
+    ! (the reference's report shows, for a molecule without a band at this wavelength, the value its work array
+    !  still holds from an earlier wavelength -- and adds it to the total; `carry` reproduces that)
+    real(kr), intent(inout), optional :: carry(nmol)
+    real(kr) :: tau(nmol)
     real(kr), parameter :: awlmax = 20., wfac = 1.e-20
     real(kr) :: w(mxq), cum_c(nz), cum_l(nz), zi, zim, zbar, uniform, h2o, ozone, trace, awl
     integer :: i, im, k, ib
@@ -278,16 +285,23 @@ contains
       ozone = s%oz(1)*w(8) + s%oz(2)*w(59) + s%oz(3)*w(60)
       trace = s%hno3*w(11)
       cum_c(im) = uniform + h2o + ozone + trace
+      tau = 0.
+      if (present(carry)) tau = carry
       do k = 1, nmol
         ib = s%slot(k)
         if (ib > 0) then
+          tau(k) = 0.
           if (s%cp(k) > -awlmax .and. w(ib) > 1.e-20) then
             awl = s%bs(k)*(s%cp(k) + log10(w(ib)))
             awl = min(awl, awlmax)
-            cum_l(im) = cum_l(im) + 10.**awl
+            tau(k) = 10.**awl
+            cum_l(im) = cum_l(im) + tau(k)
           end if
         end if
       end do
+      if (present(carry)) carry = tau
+      if (present(column) .and. i == 1) column = (/tau(1), h2o, tau(2), tau(3) + ozone, tau(4), tau(5), tau(6), &
+                                                    tau(7) + uniform, tau(8) + tau(9) + tau(10) + tau(11)/)
     end do
     dtau_cont(1) = cum_c(1)
     dtau_line(1) = cum_l(1)

@@ -90,9 +90,11 @@ program sbdart_amd
   end if
 
   call check_input()
-  fmt = find_format(iout, known)
-  if (.not. known) call fatal('this IOUT is not an output format of the hot path (1,5,6,7,10,11,20,21,22,23)')
-  radcalc = fmt%radiance /= rad_none                    ! drt.f:237-247
+  if (iout /= 2) fmt = find_format(iout, known)
+  if (iout == 2) known = .true.
+  if (.not. known) call fatal('this IOUT is not an output format of the hot path (1,2,5,6,7,10,11,20,21,22,23)')
+  radcalc = .false.
+  if (iout /= 2) radcalc = fmt%radiance /= rad_none     ! drt.f:237-247
   if (nstr == 0) nstr = merge(min(20, nstrms), 4, radcalc)
   if (radcalc) view = new_view(iout, nphi, phi, nzen, uzen, vzen)
 
@@ -126,6 +128,15 @@ program sbdart_amd
   sensor = new_filter(isat, wlinf, wlsup)            ! setfilt: the sensor's response and its wavelength limits
   grid = new_grid(sensor%wlmin, sensor%wlmax, wlinc)
 
+  if (iout == 2) then                                   ! gas optical depths only: no radiative transfer
+    call fill_model()
+    if (.not. covered_by_band_model(model, why)) call fatal('IOUT=2: the band model does not cover this run: '//trim(why))
+    call tables_load(ok, why)
+    if (.not. ok) call fatal('band-model tables not found; tried'//trim(why))
+    call gas_depth_report(model, grid)
+    stop
+  end if
+
   ! ---- per-work-item optical properties: optics file if there is one, else the band model ----
   call get_environment_variable('SBD_OPTICS', path, plen, pstat)
   if (pstat /= 0 .or. plen <= 0) path = 'OPTICS.sbdrec'
@@ -139,25 +150,7 @@ program sbdart_amd
     if (pstat /= 0 .or. plen <= 0) path = 'ATMOS.sbdatm'
     call read_atmosphere(trim(path), nz, zlev, plev, have_atm)
   else
-    model%idatm = idatm; model%nf = nf; model%isalb = isalb; model%kdist = kdist; model%nothrm = nothrm
-    model%ngrid = ngrid; model%nstr = nstr
-    model%aer%iaer = iaer; model%aer%jaer = jaer; model%aer%imoma = imoma; model%aer%nosct = nosct
-    model%aer%zaer = zaer; model%aer%taerst = taerst; model%aer%vis = vis; model%aer%tbaer = tbaer
-    model%aer%abaer = abaer; model%aer%rhaer = rhaer; model%aer%wlbaer = wlbaer; model%aer%qbaer = qbaer
-    model%aer%wbaer = wbaer; model%aer%gbaer = gbaer; model%aer%zbaer = zbaer; model%aer%dbaer = dbaer
-    model%user_moments = any(pmaer /= unset)
-    model%amix = amix; model%sza = sza; model%solfac = solfac; model%albcon = albcon; model%xrsc = xrsc
-    model%zpres = zpres; model%pbar = pbar; model%sclh2o = sclh2o; model%uw = uw; model%uo3 = uo3
-    model%o3trp = o3trp; model%ztrp = ztrp
-    model%xgas = (/xn2, xo2, xco2, xch4, xn2o, xco, xno2, xso2, xnh3, xno, xhno3/)
-    model%xo4 = xo4; model%btemp = btemp; model%ttemp = ttemp; model%temis = temis; model%fisot = fisot
-    model%phi0 = phi0
-    model%zcloud = zcloud; model%tcloud = tcloud; model%lwp = lwp; model%nre = nre; model%rhcld = rhcld
-    model%imomc = imomc; model%krhclr = krhclr
-    where (sc == huge(0.)) sc = (/1._kr, 0._kr, 0._kr, 0._kr, 0._kr/)          ! drt.f:249-262
-    model%sc = sc
-    model%zgrid1 = zgrid1; model%zgrid2 = zgrid2
-    model%spowder = spowder; model%radiance = radcalc; model%corint = corint
+    call fill_model()
     if (.not. covered_by_band_model(model, why)) &
       call fatal('no optics file ('//trim(path)//') and the band model does not cover this run yet: '//trim(why))
     call tables_load(ok, why)
@@ -368,6 +361,28 @@ program sbdart_amd
   end if
 
 contains
+
+  subroutine fill_model()                              ! the &INPUT variables the band model reads
+    model%idatm = idatm; model%nf = nf; model%isalb = isalb; model%kdist = kdist; model%nothrm = nothrm
+    model%ngrid = ngrid; model%nstr = nstr
+    model%aer%iaer = iaer; model%aer%jaer = jaer; model%aer%imoma = imoma; model%aer%nosct = nosct
+    model%aer%zaer = zaer; model%aer%taerst = taerst; model%aer%vis = vis; model%aer%tbaer = tbaer
+    model%aer%abaer = abaer; model%aer%rhaer = rhaer; model%aer%wlbaer = wlbaer; model%aer%qbaer = qbaer
+    model%aer%wbaer = wbaer; model%aer%gbaer = gbaer; model%aer%zbaer = zbaer; model%aer%dbaer = dbaer
+    model%user_moments = any(pmaer /= unset)
+    model%amix = amix; model%sza = sza; model%solfac = solfac; model%albcon = albcon; model%xrsc = xrsc
+    model%zpres = zpres; model%pbar = pbar; model%sclh2o = sclh2o; model%uw = uw; model%uo3 = uo3
+    model%o3trp = o3trp; model%ztrp = ztrp
+    model%xgas = (/xn2, xo2, xco2, xch4, xn2o, xco, xno2, xso2, xnh3, xno, xhno3/)
+    model%xo4 = xo4; model%btemp = btemp; model%ttemp = ttemp; model%temis = temis; model%fisot = fisot
+    model%phi0 = phi0
+    model%zcloud = zcloud; model%tcloud = tcloud; model%lwp = lwp; model%nre = nre; model%rhcld = rhcld
+    model%imomc = imomc; model%krhclr = krhclr
+    where (sc == huge(0.)) sc = (/1._kr, 0._kr, 0._kr, 0._kr, 0._kr/)          ! drt.f:249-262
+    model%sc = sc
+    model%zgrid1 = zgrid1; model%zgrid2 = zgrid2
+    model%spowder = spowder; model%radiance = radcalc; model%corint = corint
+  end subroutine
 
   subroutine viewing_cosines()                         ! drt.f:391-403: ascending cosines, never exactly 0
     numu = 0
