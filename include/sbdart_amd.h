@@ -186,6 +186,10 @@ int         sbd_engine_quadrature(const sbd_engine *e, double *cmu, double *cwt)
  * 3 back-substitution + fluxes, 4 intensities, -1 total.  Synchronises the stream. */
 double      sbd_engine_last_ms(sbd_engine *e, int phase);
 void        sbd_engine_enable_timing(sbd_engine *e, int on);
+/* timing mode: number of (item, mode, layer) eigenproblems of the last solve that the fast layer kernel handed
+ * to the reference-algorithm kernel (not positive definite after symmetrisation, no Jacobi convergence, thermal
+ * source in a conservative layer); -1 without timing */
+int64_t     sbd_engine_last_fallback_layers(sbd_engine *e);
 /* Test hook: copy one workspace array of the LAST chunk solved to the host.
  * which: 0 gc, 1 kk, 2 ek, 3 zz, 4 zp0, 5 zp1, 6 ll, 7 sv, 8 svi(int32).  Returns bytes copied
  * (<= nbytes) or a negative error. */

@@ -44,7 +44,8 @@ EXPORTS = (
     "sbd_engine_create", "sbd_engine_destroy", "sbd_engine_solve_device", "sbd_engine_solve_host",
     "sbd_engine_accumulate_device", "sbd_engine_accumulate_host", "sbd_abi_version",
     "sbd_engine_nlevel", "sbd_engine_workspace_bytes", "sbd_engine_chunk", "sbd_engine_stream",
-    "sbd_engine_quadrature", "sbd_engine_last_ms", "sbd_engine_enable_timing", "sbd_strerror",
+    "sbd_engine_quadrature", "sbd_engine_last_ms", "sbd_engine_enable_timing", "sbd_engine_last_fallback_layers",
+    "sbd_strerror",
     "sbd_last_error", "sbd_engine_debug_copy",
     "sbd_fleet_create", "sbd_fleet_destroy", "sbd_fleet_size", "sbd_fleet_engine", "sbd_fleet_uses_rccl",
     "sbd_shard_range", "sbd_fleet_solve_host",
@@ -90,6 +91,8 @@ def load() -> C.CDLL:
     L.sbd_engine_last_ms.restype = C.c_double
     L.sbd_engine_enable_timing.argtypes = [vp, C.c_int]
     L.sbd_engine_enable_timing.restype = None
+    L.sbd_engine_last_fallback_layers.argtypes = [vp]
+    L.sbd_engine_last_fallback_layers.restype = C.c_int64
     L.sbd_strerror.argtypes = [C.c_int]
     L.sbd_strerror.restype = C.c_char_p
     L.sbd_last_error.restype = C.c_char_p

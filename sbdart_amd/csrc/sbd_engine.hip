@@ -183,6 +183,7 @@ struct sbd_engine {
     bool band4 = false;             // four systems per wave, block form (sbd_band4.hpp), NSTR <= 16
     bool band1 = false;             // one system per wave, block form in registers (sbd_band1.hpp), 16 < NSTR <= 32
     bool corint = false;            // intensity corrections after the azimuth series (sbd_intcor.hpp)
+    int64_t fallback_layers = 0;    // timing mode: (item, mode, layer) problems of the last solve left to the QR kernel
 };
 
 extern "C" {
@@ -519,6 +520,8 @@ int sbd_engine_quadrature(const sbd_engine *e, double *cmu, double *cwt)
     return SBD_OK;
 }
 
+int64_t sbd_engine_last_fallback_layers(sbd_engine *e) { return (e && e->have_times) ? e->fallback_layers : -1; }
+
 double sbd_engine_last_ms(sbd_engine *e, int phase)
 {
     if (!e || !e->have_times) return -1.0;
@@ -591,6 +594,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
     const bool dbg = getenv("SBD_DEBUG_SYNC") != nullptr;
 #define SBD_DBG(tag) do { if (dbg) { hipError_t de_ = hipStreamSynchronize(st); fprintf(stderr, "[sbd] %s: %s (eigflag=%p partial=%p ws=%p..%p)\n", tag, hipGetErrorString(de_), (void*)e->d_eigflag, (void*)e->d_partial, (void*)e->d_ws, (void*)(e->d_ws + e->ws_bytes)); } } while (0)
     float acc_ms[sbd_engine::kPhases] = {};
+    int64_t nfallback = 0;
     // a batch larger than the workspace goes through in EQUAL passes (no short tail pass whose
     // kernels cost their full launch latency for a handful of items)
     // With more than one pass, consecutive passes alternate between the two workspaces and run on two
@@ -686,6 +690,11 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         HIP_TRY(hipGetLastError());
         if (timing) {
             HIP_TRY(hipEventSynchronize(e->ev[sbd_engine::kPhases]));
+            if (e->use_layer2) {                         // layers the fast layer kernel handed to the reference-algorithm one
+                int32_t cnt = 0;
+                HIP_TRY(hipMemcpy(&cnt, eigflag, sizeof(cnt), hipMemcpyDeviceToHost));
+                nfallback += cnt;
+            }
             for (int ph = 0; ph < sbd_engine::kPhases; ++ph) {
                 float ms = 0.f;
                 HIP_TRY(hipEventElapsedTime(&ms, e->ev[ph], e->ev[ph + 1]));
@@ -700,6 +709,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
     }
     if (timing) {
         for (int ph = 0; ph < sbd_engine::kPhases; ++ph) e->ms_phase[ph] = acc_ms[ph];
+        e->fallback_layers = nfallback;
         e->have_times = true;
     }
     return SBD_OK;

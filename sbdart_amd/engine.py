@@ -126,6 +126,9 @@ class DisortEngine:
     def last_ms(self, phase: int = -1) -> float:
         return self._L.sbd_engine_last_ms(self._h, phase)
 
+    def last_fallback_layers(self) -> int:
+        return int(self._L.sbd_engine_last_fallback_layers(self._h))
+
     # ---- the hot path ----
     def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank):
         """Solve a batch.  Shapes: dtauc/ssalb [W, nlyr]; pmom [W, nlyr, nmom+1];
