@@ -7,7 +7,7 @@
 !                    ZBAER / DBAER
 !   stratosphere:    up to five layers ZAER with 0.55 um optical depth TAERST of model JAER 1-4
 ! An aerosol_load is prepared once per run; aerosol_depths evaluates it at a wavelength.  Not covered:
-! IAER=-1 (aerosol.dat) and user phase-function moments PMAER.  Literals: see sbd_tables_mod.
+! IAER=-1 (aerosol.dat).  Literals: see sbd_tables_mod.
 module sbd_aerosol_mod
   use sbd_grid_mod, only: kr, unset
   use sbd_tables_mod
@@ -25,6 +25,7 @@ module sbd_aerosol_mod
     real(kr) :: zaer(naerz) = 0, taerst(naerz) = 0, vis = unset, tbaer = unset, abaer = 0, rhaer = unset
     real(kr) :: wlbaer(naerb) = unset, qbaer(naerb) = unset, wbaer(naerb) = unset, gbaer(naerb) = unset
     real(kr) :: zbaer(65) = unset, dbaer(65) = unset
+    real(kr) :: pmaer(naerb*299) = unset   ! IAER 5: phase-function moments 1.. per wavelength, wavelength index fastest
   end type
 
   type aerosol_load
@@ -33,6 +34,8 @@ module sbd_aerosol_mod
     integer :: nwl = 0                                  ! boundary-layer spectrum: wavelengths, extinction,
     real(kr), allocatable :: wl(:), ext(:), absb(:), asym(:)   ! absorption, asymmetry factor
     real(kr), allocatable :: column(:)                  ! per layer (1 = top): 0.55 um optical depth / ext(0.55)
+    integer :: npm = 0                                  ! user phase-function moments per wavelength (then imoma = 0)
+    real(kr), allocatable :: pm(:)                      ! [npm][nwl], wavelength index fastest
     integer :: nstrat = 0
     integer :: strat_layer(naerz) = 0, jaer(naerz) = 0
     real(kr) :: taerst(naerz) = 0
@@ -250,9 +253,11 @@ contains
     subroutine user_spectrum(q55)                        ! IAER=5 (usraer)
       real(kr), intent(out) :: q55
       real(kr) :: wlb(naerb), qb(naerb), wb(naerb), gb(naerb)
-      integer :: nwlb, k
+      real(kr), allocatable :: pmu(:)
+      integer :: nwlb, k, npm
       wlb = in%wlbaer; qb = in%qbaer; wb = in%wbaer; gb = in%gbaer
       nwlb = last_set(wlb); nq = last_set(qb); nw = last_set(wb); ng = last_set(gb)
+      npm = last_set(in%pmaer)
       ne = 0
       if (nwlb == 0) then
         qb(1) = 1.; nq = 1
@@ -268,16 +273,24 @@ contains
         if (nwlb /= nq) call complain('number of elements must match: wlbaer, qbaer')
         if (nwlb /= nw) call complain('number of elements must match: wlbaer, wbaer')
         if (ng == 0) then
-          call complain('must specify either gbaer or pmaer')
+          if (npm >= 1) then
+            if (mod(npm, nwlb) /= 0) then
+              call complain('incorrect number of phase function moments')
+            else
+              npm = npm/nwlb
+            end if
+          else
+            call complain('must specify either gbaer or pmaer')
+          end if
         else if (ng /= nw) then
           call complain('number of elements must match: wlbaer, gbaer')
         end if
       end if
-      if (ng == 0 .and. in%imoma == 3) call complain('must specify either gbaer or pmaer, not both')
+      if (((ng == 0) .eqv. (npm == 0)) .and. in%imoma == 3) call complain('must specify either gbaer or pmaer, not both')
       if (ne > 0) then
         write(*, *) 'Error in user specified aerosols (iaer=5)'
         write(*, '(/,1x,5a8)') 'nwlbaer', 'nqbaer', 'nwbaer', 'ngbaer', 'npmaer'
-        write(*, '(5i8,/)') nwlb, nq, nw, ng, 0
+        write(*, '(5i8,/)') nwlb, nq, nw, ng, npm
         do k = 1, ne
           write(*, '(2a)') 'Error in USRAER -- ', errmes(k)
         end do
@@ -290,6 +303,18 @@ contains
         qb(2) = qb(1)*(wlb(1)/wlb(2))**in%abaer
         wb(2) = wb(1)
         gb(2) = gb(1)
+        if (npm > 0) then                                ! the same moments at both points
+          allocate(pmu(2*npm))
+          pmu(1:2*npm - 1:2) = in%pmaer(1:npm)
+          pmu(2:2*npm:2) = in%pmaer(1:npm)
+        end if
+      else if (npm > 0) then
+        pmu = in%pmaer(1:npm*nwlb)
+      end if
+      if (npm > 0) then
+        a%npm = npm
+        a%imoma = 0
+        call move_alloc(pmu, a%pm)
       end if
       a%nwl = nwlb
       allocate(a%wl(nwlb), a%ext(nwlb), a%absb(nwlb), a%asym(nwlb))
@@ -322,8 +347,8 @@ contains
     integer, intent(in) :: nz, nmom
     real(kr), intent(out) :: dtaua(nz), waer(nz)
     real(kr), intent(inout) :: pmom(0:nmom, nz)
-    real(kr) :: pm(0:nmom), extinc, wa, ga, dt
-    integer :: i, j, nl
+    real(kr) :: pm(0:nmom), extinc, wa, ga, dt, wt
+    integer :: i, j, nl, namom, l
     dtaua = 0.; waer = 0.
     if (a%iaer /= 0) then
       call boundary_layer_at(a, wl, extinc, wa, ga)
@@ -332,11 +357,22 @@ contains
       if (a%nosct /= 0) then
         wa = 0.; ga = 0.
       end if
-      call phase_moments(a%imoma, ga, nmom, pm)
+      if (a%imoma > 0) then
+        namom = nmom
+        call phase_moments(a%imoma, ga, nmom, pm)
+      else                                               ! the user's moments, linear in wavelength, end values outside
+        namom = min(a%npm, nmom)
+        l = bracket(a%wl(1:a%nwl), wl)
+        wt = (wl - a%wl(l))/(a%wl(l + 1) - a%wl(l))
+        wt = max(0._kr, min(wt, 1._kr))
+        do j = 1, namom
+          pm(j) = a%pm(l + (j - 1)*a%nwl)*(1. - wt) + a%pm(l + 1 + (j - 1)*a%nwl)*wt
+        end do
+      end if
       do i = 1, nz
         dtaua(i) = extinc*a%column(i)
         waer(i) = wa
-        do j = 1, nmom
+        do j = 1, namom
           pmom(j, i) = pmom(j, i) + pm(j)*dtaua(i)*waer(i)
         end do
       end do

@@ -22,7 +22,6 @@ module sbd_bandmodel_mod
   type model_input                     ! the &INPUT variables this step reads, same names
     integer :: idatm = 4, nf = 2, isalb = 0, kdist = 3, nothrm = -1, ngrid = 0, nstr = 4
     type(aerosol_input) :: aer
-    logical :: user_moments = .false.      ! PMAER given
     real(kr) :: amix = unset, sza = 0, solfac = 1, albcon = 0, xrsc = 1, zpres = unset, pbar = unset, &
                 sclh2o = unset, uw = unset, uo3 = unset, o3trp = unset, ztrp = 0, xgas(11) = unset, xo4 = 1, &
                 btemp = unset, ttemp = unset, temis = 0, fisot = 0, phi0 = 0
@@ -42,9 +41,7 @@ contains
     type(model_input), intent(in) :: m
     character(len=*), intent(out) :: why
     why = ''
-    if (m%nre(1) == 0.) why = 'user cloud file (usrcld.dat, nre=0)'
     if (m%aer%iaer < 0) why = 'aerosol file (aerosol.dat, iaer=-1)'
-    if (m%user_moments) why = 'user aerosol phase-function moments (pmaer)'
     if (.not. (m%isalb >= -1 .and. m%isalb <= 6) .and. m%isalb /= 10) why = 'BRDF surface (isalb 7, 8, 9)'
     if (m%kdist < 0) why = 'k-distribution files (kdist=-1)'
     if (m%nf == -2) why = 'solar spectrum from the k-distribution file (nf=-2)'
@@ -224,6 +221,7 @@ contains
     type(trace_gases) :: mix
     type(cloud_deck) :: deck
     type(aerosol_load) :: load
+    type(layer_clouds) :: lcloud
     real(kr), allocatable :: uu(:, :), temper(:), wlalb(:), alb(:), wsun(:), ssun(:)
     real(kr), allocatable :: sd(:, :), ss(:, :), sp(:, :, :), swt(:, :), swl(:), slo(:), shi(:), sfb(:), salb(:)
     logical, allocatable :: splank(:)
@@ -283,6 +281,7 @@ contains
     call solar_spectrum(m%nf, wsun, ssun)
     call gas_tables_init()
     call cloud_tables_init()
+    if (deck%nslot == 0 .and. m%nre(1) == 0.) lcloud = read_layer_clouds(nz)      ! drt.f:501-502
     load = new_aerosol_load(m%aer, atm%z, rh_surface)
 
     allocate(nk_of(grid%n), first(grid%n), sd(nz, mk*grid%n), ss(nz, mk*grid%n), sp(0:nmom, nz, mk*grid%n), &
@@ -363,7 +362,11 @@ contains
       ! moment x scattering depth, Rayleigh 0.1 in the second moment; normalised by the total (drt.f:1366-1380)
       pmom = 0.
       dtauc = 0.; wcld = 0.
-      if (deck%nslot > 0) call cloud_depths(deck, wl, nz, nmom, dtauc, wcld, pmom)
+      if (deck%nslot > 0) then
+        call cloud_depths(deck, wl, nz, nmom, dtauc, wcld, pmom)
+      else if (lcloud%given) then
+        call layer_cloud_depths(lcloud, m%imomc, wl, nz, nmom, dtauc, wcld, pmom)
+      end if
       call aerosol_depths(load, wl, nz, nmom, dtaua, waer, pmom)
       do l = 1, nz
         pmom(2, l) = pmom(2, l) + .1*dtaur(l)

@@ -9,7 +9,8 @@ module sbd_cloud_mod
   use sbd_tables_mod
   implicit none
   private
-  public :: cloud_deck, new_cloud_deck, cloud_depths, phase_moments, layers_of_altitudes, ncldz, cloud_tables_init
+  public :: cloud_deck, new_cloud_deck, cloud_depths, phase_moments, layers_of_altitudes, ncldz, cloud_tables_init, &
+            layer_clouds, read_layer_clouds, layer_cloud_depths
 
   integer, parameter :: ncldz = 5                    ! cloud slots (params.f:12)
   real(kr), parameter :: wl55 = 0.55                 ! wavelength TCLOUD is quoted at (params.f:27)
@@ -21,6 +22,11 @@ module sbd_cloud_mod
     integer :: imomc = 3
   end type
 
+  type layer_clouds                    ! usrcld.dat: liquid water path (g/m2), effective radius (um), cloud fraction per layer
+    logical :: given = .false.
+    real(kr), allocatable :: lwp(:), reff(:), frac(:)      ! layer 1 = top
+  end type
+
   real(kr), pointer, save :: t_q(:) => null(), t_w(:) => null(), t_g(:) => null(), t_qi(:) => null(), &
                              t_wi(:) => null(), t_gi(:) => null(), t_haze(:) => null(), t_c1(:) => null()
 
@@ -30,6 +36,65 @@ contains
     t_q => tbl('cloud.q'); t_w => tbl('cloud.w'); t_g => tbl('cloud.g')
     t_qi => tbl('cloud.qi'); t_wi => tbl('cloud.wi'); t_gi => tbl('cloud.gi')
     t_haze => tbl('pmom.haze_l'); t_c1 => tbl('pmom.cloud_c1')
+  end subroutine
+
+  ! NRE(1) = 0 without TCLOUD/LWP: clouds layer by layer from usrcld.dat -- one record per layer from the BOTTOM
+  ! layer upwards, "lwp reff fwp reice cldfrac" (missing layers: no cloud) (usrcloud, taucloud.f:142-274).  Frozen
+  ! water (fwp /= 0) is refused: the reference divides by an ice density it declared INTEGER (= 0).
+  function read_layer_clouds(nz) result(c)
+    integer, intent(in) :: nz
+    type(layer_clouds) :: c
+    real(kr) :: fwp, reice
+    integer :: u, ios, i
+    allocate(c%lwp(nz), c%reff(nz), c%frac(nz))
+    c%lwp = 0.; c%reff = 8.; c%frac = 1.
+    c%given = .true.
+    open(newunit=u, file='usrcld.dat', status='old', form='formatted', iostat=ios)
+    if (ios /= 0) then
+      write(0, '(a)') 'sbdart_amd: cannot open usrcld.dat'
+      stop 2
+    end if
+    do i = nz, 1, -1
+      fwp = 0.; reice = -1.
+      read(u, *, iostat=ios) c%lwp(i), c%reff(i), fwp, reice, c%frac(i)
+      if (ios /= 0) exit
+      if (fwp /= 0.) then
+        write(0, '(a)') 'sbdart_amd: usrcld.dat: ice water (fwp /= 0) is not supported'
+        stop 2
+      end if
+    end do
+    close(u)
+  end function
+
+  subroutine layer_cloud_depths(c, imomc, wl, nz, nmom, taucld, wcld, pmom)
+    type(layer_clouds), intent(in) :: c
+    integer, intent(in) :: imomc, nz, nmom
+    real(kr), intent(in) :: wl
+    real(kr), intent(out) :: taucld(nz), wcld(nz)
+    real(kr), intent(inout) :: pmom(0:nmom, nz)
+    real(kr) :: qw, ww, gw, tauw
+    integer :: i, j
+    if (imomc < 0) then
+      print *, 'imomc < 0 not allowed with usrcld.dat option'
+      stop
+    end if
+    taucld = 0.; wcld = 0.
+    do i = 1, nz
+      tauw = 0.
+      if (c%lwp(i) > 0.) then
+        call mie_lookup(wl, c%reff(i), qw, ww, gw)
+        tauw = .75*qw*c%lwp(i)/c%reff(i)
+      end if
+      taucld(i) = tauw
+      if (taucld(i) /= 0.) then
+        wcld(i) = (tauw*ww)/taucld(i)
+        call phase_moments(imomc, (tauw*gw)/taucld(i), nmom, pmom(:, i))
+      end if
+      taucld(i) = taucld(i)*c%frac(i)**1.5
+      do j = 1, nmom
+        pmom(j, i) = taucld(i)*wcld(i)*pmom(j, i)
+      end do
+    end do
   end subroutine
 
   ! layers (1 = top; layer k lies above level nz+1-k) that hold the altitudes zz; a negative altitude

@@ -369,7 +369,7 @@ contains
     model%aer%zaer = zaer; model%aer%taerst = taerst; model%aer%vis = vis; model%aer%tbaer = tbaer
     model%aer%abaer = abaer; model%aer%rhaer = rhaer; model%aer%wlbaer = wlbaer; model%aer%qbaer = qbaer
     model%aer%wbaer = wbaer; model%aer%gbaer = gbaer; model%aer%zbaer = zbaer; model%aer%dbaer = dbaer
-    model%user_moments = any(pmaer /= unset)
+    model%aer%pmaer = pmaer
     model%amix = amix; model%sza = sza; model%solfac = solfac; model%albcon = albcon; model%xrsc = xrsc
     model%zpres = zpres; model%pbar = pbar; model%sclh2o = sclh2o; model%uw = uw; model%uo3 = uo3
     model%o3trp = o3trp; model%ztrp = ztrp

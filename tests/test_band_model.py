@@ -136,6 +136,8 @@ VARIANTS = [
     "idatm=4 wlinf=.4 wlsup=2 wlinc=.1 iaer=1 vis=15 nosct=1 sza=10 iout=1",
     "idatm=6 wlinf=.3 wlsup=3 wlinc=.1 iaer=5 wlbaer=.4,.6,1,2 qbaer=1.2,1,.6,.2 wbaer=.95,.93,.9,.8 gbaer=.7,.68,.65,.6 tbaer=.4 sza=50 iout=1",
     "idatm=6 wlinf=.3 wlsup=3 wlinc=.1 iaer=5 wbaer=.9 gbaer=.7 abaer=1.3 vis=20 sza=50 iout=1",
+    "idatm=6 wlinf=.3 wlsup=3 wlinc=.1 iaer=5 wlbaer=.4,1,2 qbaer=1.2,.6,.2 wbaer=.95,.9,.8 pmaer=.7,.65,.6,.5,.42,.36,.35,.27,.2,.2,.1,.05 tbaer=.4 sza=50 iout=1 nstr=8",
+    "idatm=6 wlinf=.3 wlsup=3 wlinc=.1 iaer=5 wbaer=.9 pmaer=.7,.5,.35,.2,.1 abaer=1.1 vis=20 sza=50 iout=1",
     "idatm=5 wlinf=.3 wlsup=5 wlinc=.1 jaer=2,3 zaer=18,25 taerst=.05,.02 sza=50 iout=1",
     "idatm=5 wlinf=.3 wlsup=5 wlinc=.1 iaer=1 vis=30 jaer=1,4 zaer=15,20 taerst=.1,.01 tcloud=2 zcloud=3 sza=50 iout=1",
     # sensor response functions: built-in sensors, flat / triangular / Gaussian about a centre
@@ -177,6 +179,7 @@ USER_FILES = {
     "albedo.dat": "0.3 0.05\n0.7 0.1\n0.75 0.45\n2.0 0.3\n4.0 0.1\n",
     "solar.dat": "4.0 9.0\n2.0 110.0\n1.0 720.0\n0.5 1900.0\n0.3 520.0\n",
     "filter.dat": "0.6 0.0\n0.65 0.8\n0.7 1.0\n0.8 0.3\n0.85 0.0\n",
+    "usrcld.dat": "0 8 0 -1 1\n40 6 0 -1 1\n120 9 0 -1 .6\n0 8 0 -1 1\n15 14 0 -1 1\n",
 }
 
 
@@ -186,6 +189,8 @@ USER_FILES = {
     "idatm=0 wlinf=.4 wlsup=3 wlinc=.1 sza=30 iout=1",
     "idatm=6 isalb=-1 nf=-1 wlinf=.35 wlsup=3.5 wlinc=.05 sza=30 iout=1",
     "idatm=6 isat=-1 wlinc=.005 sza=30 iout=1",
+    "idatm=4 nre=0 wlinf=.4 wlsup=3.4 wlinc=.1 sza=30 iout=1 imomc=3",
+    "idatm=2 nre=0 wlinf=8 wlsup=12 wlinc=.5 sza=30 iout=1 imomc=5 nstr=8",
 ])
 def test_user_data_files(tmp_path, namelist):
     """atms.dat, albedo.dat, solar.dat, filter.dat in the run directory, as the reference reads them."""
@@ -202,7 +207,7 @@ def test_user_data_files(tmp_path, namelist):
 
 @needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
-    for namelist, word in (("tcloud=5 nre=0", "cloud"), ("iaer=-1", "aerosol"), ("isalb=7", "surface"),
+    for namelist, word in (("iaer=-1", "aerosol"), ("isalb=7", "surface"),
                            ("kdist=-1", "k-distribution")):
         d = str(tmp_path / word)
         os.makedirs(d)
