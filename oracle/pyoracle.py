@@ -14,6 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB: Optional[C.CDLL] = None
+_LIB_FMA: Optional[C.CDLL] = None
 
 WARN_SOLVE0_RCOND, WARN_UPBEAM_RCOND, WARN_UPISOT_RCOND = 1, 2, 4
 ERR_ASYMTX, RETRY_NSTR, ERR_INPUT, WARN_PLKAVG = 8, 16, 32, 64
@@ -68,13 +69,29 @@ def lib() -> C.CDLL:
     return _LIB
 
 
+def lib_fma() -> C.CDLL:
+    """The same restatement compiled with fused multiply-adds: a rounding-perturbed twin (see oracle/Makefile)."""
+    global _LIB_FMA
+    if _LIB_FMA is None:
+        so = os.path.join(_HERE, "liboracle_fma.so")
+        src = os.path.join(_HERE, "disort_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle_fma.so"])
+        L = C.CDLL(so)
+        L.sbdo_disort.argtypes = [C.POINTER(_In), C.POINTER(_Out)]
+        L.sbdo_disort.restype = C.c_int
+        _LIB_FMA = L
+    return _LIB_FMA
+
+
 def _p(a: np.ndarray):
     return a.ctypes.data_as(_dp)
 
 
-def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False, debug_mode=None):
-    """Solve one record (sbdart_amd.records.SolveRecord-like). Returns a dict."""
-    L = lib()
+def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False, debug_mode=None, perturbed: bool = False):
+    """Solve one record (sbdart_amd.records.SolveRecord-like). Returns a dict.  perturbed: through the
+    FMA-contracted twin of the library (rounding sensitivity of the record, never a reference answer)."""
+    L = lib_fma() if perturbed else lib()
     f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
     dtauc, ssalb, temper, pmom = f(rec.dtauc), f(rec.ssalb), f(rec.temper), f(rec.pmom)
     umu = f(rec.umu) if len(rec.umu) else np.zeros(1)

@@ -121,6 +121,15 @@ def main():
           "idatm=4 wlinf=3.8 wlsup=3.8 iout=20 nstr=8 corint=t tcloud=1 zcloud=4 nre=-30 albcon=.6 nzen=5 uzen=10,80 nphi=2 phi=30,150 sza=60"],
          lambda r: r[-1:], keep_stdout=False)
 
+    # --- ill-conditioned on purpose (kept apart from the 5e-6 parity files): the thermal window on a 65-level
+    #     regridded atmosphere -- dozens of layers of optical depth ~1e-6 make the boundary-value system so
+    #     nearly singular that the reference's own answer moves by 3e-5 when its arithmetic is merely contracted
+    #     to fused multiply-adds (tests/test_gpu_parity.py::test_ill_conditioned_records)
+    emit("illcond/thin65_thermal",
+         ["idatm=4 wlinf=8 wlsup=9.6 wlinc=4.16667 iday=200 time=0 alat=35 alon=-120 nf=2 uo3=0.35 ngrid=65 "
+          "zgrid1=2 zgrid2=10 iout=1 nstr=16"],
+         lambda r: [x for x in r if x.kd == 3][::9][:6], keep_stdout=False)
+
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("total bytes", sum(e["bytes"] for e in manifest.values()))
