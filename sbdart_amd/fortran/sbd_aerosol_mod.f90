@@ -6,8 +6,10 @@
 !                    visibility VIS or the 0.55 um optical depth TBAER; vertical profile standard or
 !                    ZBAER / DBAER
 !   stratosphere:    up to five layers ZAER with 0.55 um optical depth TAERST of model JAER 1-4
-! An aerosol_load is prepared once per run; aerosol_depths evaluates it at a wavelength.  Not covered:
-! IAER=-1 (aerosol.dat).  Literals: see sbd_tables_mod.
+!   aerosol.dat:    IAER -1, per-layer optical depth, single-scattering albedo and moments at the file's
+!                    wavelengths (aeread 1526-1713)
+! An aerosol_load is prepared once per run; aerosol_depths evaluates it at a wavelength.  Literals: see
+! sbd_tables_mod.
 module sbd_aerosol_mod
   use sbd_grid_mod, only: kr, unset
   use sbd_tables_mod
@@ -15,7 +17,7 @@ module sbd_aerosol_mod
   use sbd_cloud_mod, only: phase_moments, layers_of_altitudes
   implicit none
   private
-  public :: aerosol_input, aerosol_load, new_aerosol_load, aerosol_depths, naerz, naerb
+  public :: aerosol_input, aerosol_load, new_aerosol_load, aerosol_depths, naerz, naerb, plan_aerosol_file
 
   integer, parameter :: naerz = 5, naerb = 150, naerw = 47
   real(kr), parameter :: wl55 = 0.55
@@ -28,7 +30,20 @@ module sbd_aerosol_mod
     real(kr) :: pmaer(naerb*299) = unset   ! IAER 5: phase-function moments 1.. per wavelength, wavelength index fastest
   end type
 
+  ! aerosol.dat in full: "nn nmom", then per wavelength the wavelength and nn layer records (depth, albedo, moments)
+  type aerosol_file
+    integer :: nn = 0, nmom = 0
+    integer :: nset = 0                                 ! wavelength headers in the file
+    integer :: short = 0                                ! the set whose layer records ran out (0: none)
+    real(kr), allocatable :: wl(:), tau(:, :), ssa(:, :), pm(:, :, :)    ! [set], [nn, set], [nmom, nn, set]
+    ! per wavelength of the run (plan_aerosol_file): the two sets aeread would hold and the wavelengths it
+    ! would carry for them: (1, :) the set read last, (2, :) the one before
+    integer, allocatable :: pair(:, :)
+    real(kr), allocatable :: pair_wl(:, :)
+  end type
+
   type aerosol_load
+    type(aerosol_file) :: file
     integer :: iaer = 0, imoma = 3, nosct = 0
     real(kr) :: abaer = 0
     integer :: nwl = 0                                  ! boundary-layer spectrum: wavelengths, extinction,
@@ -143,6 +158,10 @@ contains
       if (a%nstrat > 0) call layers_of_altitudes(z, in%zaer(1:a%nstrat), a%strat_layer(1:a%nstrat))
     end if
     if (in%iaer == 0) return
+    if (in%iaer == -1) then
+      a%file = read_aerosol_file(nz)
+      return
+    end if
 
     ! ---- vertical profile of the boundary-layer aerosol: user's or standard ----
     nzb = last_set(in%zbaer); ndb = last_set(in%dbaer)
@@ -341,16 +360,160 @@ contains
 
   ! aerosol optical depth and single-scattering albedo of every layer (1 = top) at wl; the aerosols' part of
   ! the un-normalised phase-function moments (moment x scattering depth) is ADDED to pmom
-  subroutine aerosol_depths(a, wl, nz, nmom, dtaua, waer, pmom)
+  ! aerosol.dat, every record of it (aeread reads it as the wavelength loop advances: same list-directed reads,
+  ! one record per "nn nmom", per wavelength and per layer)
+  function read_aerosol_file(nz) result(f)
+    integer, intent(in) :: nz
+    type(aerosol_file) :: f
+    real(kr) :: w
+    real(kr), allocatable :: row(:)
+    integer :: u, ios, i, pass, n
+    open(newunit=u, file='aerosol.dat', form='formatted', status='old', iostat=ios)
+    if (ios /= 0) then
+      write(*, *) 'iaer=-1: aerosol.dat not found in the run directory'
+      stop 1
+    end if
+    read(u, *, iostat=ios) f%nn, f%nmom
+    if (ios /= 0) then
+      write(*, *) 'no data found in aerosol.dat'
+      stop 1
+    end if
+    if (nz - f%nn + 1 <= 0) then
+      write(*, *) 'nz  nn ', nz, f%nn
+      write(*, *) 'too many layers specified in aerosol.dat'
+      stop 1
+    end if
+    allocate(row(2 + f%nmom))
+    do pass = 1, 2                                       ! count the sets, then keep them
+      n = 0
+      sets: do
+        read(u, *, iostat=ios) w
+        if (ios /= 0) exit
+        n = n + 1
+        if (pass == 2) f%wl(n) = w
+        do i = 1, f%nn
+          read(u, *, iostat=ios) row
+          if (ios /= 0) then
+            f%short = n
+            exit sets
+          end if
+          if (pass == 2) then
+            f%tau(i, n) = row(1); f%ssa(i, n) = row(2); f%pm(:, i, n) = row(3:)
+          end if
+        end do
+      end do sets
+      if (pass == 1) then
+        f%nset = n
+        allocate(f%wl(n), f%tau(f%nn, n), f%ssa(f%nn, n), f%pm(f%nmom, f%nn, n))
+        f%tau = 0.; f%ssa = 0.; f%pm = 0.
+        rewind u
+        read(u, *)
+      end if
+    end do
+    close(u)
+    if (f%nset == 0) then
+      write(*, *) 'no data found in aerosol.dat'
+      stop 1
+    end if
+  end function
+
+  ! Which two sets of aerosol.dat serve each wavelength of the run.  aeread (tauaero.f:1607-1672) keeps two
+  ! slots and reads forward while the wavelength is beyond both; what it holds at a call depends on the calls
+  ! before it (a first wavelength at or below the file's first makes the first set spectrally uniform, carried
+  ! at half and twice THAT wavelength until the run passes twice it), so the wavelengths are walked in order,
+  ! once, ahead of the parallel loop.
+  subroutine plan_aerosol_file(a, wls)
+    type(aerosol_load), intent(inout) :: a
+    real(kr), intent(in) :: wls(:)
+    real(kr) :: w(2), wl0, wl
+    integer :: d(2), ind, more, next, iw
+    logical :: at_end
+    if (a%iaer /= -1) return
+    associate (f => a%file)
+      allocate(f%pair(2, size(wls)), f%pair_wl(2, size(wls)))
+      w = 0.; d = 0; ind = 1; more = 1; wl0 = 0.; next = 1
+      do iw = 1, size(wls)
+        wl = wls(iw)
+        if (w(1) == 0.) then
+          call take(1, 1)
+          wl0 = w(1); ind = 1; next = 2
+        else if (wl < minval(w) .and. wl > wl0) then     ! back to the first set
+          call take(1, 1)
+          w(2) = 0.; ind = 1; more = 1; next = 2
+        end if
+        if (more == 1) then
+          at_end = .false.
+          do while (wl > maxval(w))
+            more = 0
+            if (next > f%nset) then
+              at_end = .true.
+              exit
+            end if
+            ind = 3 - ind
+            call take(ind, next)
+            next = next + 1
+          end do
+          if (.not. at_end) more = 1
+        end if
+        if (w(2) == 0.) then                             ! one set so far: spectrally uniform
+          w(1) = .5*wl; w(2) = 2*wl
+          d(2) = d(1)
+          wl0 = 0.
+        end if
+        f%pair(:, iw) = [d(ind), d(3 - ind)]
+        f%pair_wl(:, iw) = [w(ind), w(3 - ind)]
+      end do
+    end associate
+  contains
+    subroutine take(slot, set)
+      integer, intent(in) :: slot, set
+      if (a%file%short == set) then
+        write(*, *) 'not enough aerosol records'
+        write(*, *) 'need ', a%file%nn, ' records'
+        stop 1
+      end if
+      d(slot) = set; w(slot) = a%file%wl(set)
+    end subroutine
+  end subroutine
+
+  subroutine aerosol_depths(a, wl, nz, nmom, dtaua, waer, pmom, iw)
     type(aerosol_load), intent(in) :: a
     real(kr), intent(in) :: wl
     integer, intent(in) :: nz, nmom
     real(kr), intent(out) :: dtaua(nz), waer(nz)
     real(kr), intent(inout) :: pmom(0:nmom, nz)
-    real(kr) :: pm(0:nmom), extinc, wa, ga, dt, wt
-    integer :: i, j, nl, namom, l
+    integer, intent(in), optional :: iw                  ! index of wl among the run's wavelengths (aerosol.dat)
+    real(kr) :: pm(0:nmom), extinc, wa, ga, dt, wt, ta, tb, gg
+    integer :: i, j, nl, namom, l, ia, ib, k
     dtaua = 0.; waer = 0.
-    if (a%iaer /= 0) then
+    if (a%iaer == -1) then
+      ! layers nz-nn+1 .. nz from the file (the layers above them: nothing; the reference leaves them unset);
+      ! depth log-log between the two sets where both are positive, everything else linear in the weight
+      associate (f => a%file)
+        ia = f%pair(1, iw); ib = f%pair(2, iw)
+        wt = log(wl/f%pair_wl(1, iw))/log(f%pair_wl(2, iw)/f%pair_wl(1, iw))
+        wt = max(0._kr, min(wt, 1._kr))
+        do k = 1, f%nn
+          i = nz - f%nn + k
+          ta = f%tau(k, ia); tb = f%tau(k, ib)
+          if (min(ta, tb) > 0.) then
+            dtaua(i) = ta*(tb/ta)**wt
+          else
+            dtaua(i) = ta*(1. - wt) + tb*wt
+          end if
+          waer(i) = f%ssa(k, ia)*(1. - wt) + f%ssa(k, ib)*wt
+          if (f%nmom == 1) then
+            namom = nmom
+            gg = f%pm(1, k, ia)*(1. - wt) + f%pm(1, k, ib)*wt
+            call phase_moments(a%imoma, gg, nmom, pm)
+          else
+            namom = min(f%nmom, nmom)
+            pm(1:namom) = f%pm(1:namom, k, ia)*(1. - wt) + f%pm(1:namom, k, ib)*wt
+          end if
+          pmom(1:namom, i) = pmom(1:namom, i) + pm(1:namom)*dtaua(i)*waer(i)
+        end do
+      end associate
+    else if (a%iaer /= 0) then
       call boundary_layer_at(a, wl, extinc, wa, ga)
       if (a%nosct == 1) extinc = extinc*(1. - wa)
       if (a%nosct == 3) extinc = extinc*(1. - wa*ga)

@@ -2,7 +2,7 @@
 ! path (SURVEY 8f row N1; reference drt.f:297-347, 425-533 with rayleigh spectra.f:179-247, solirr
 ! spectra.f:1367-1415, normom drt.f:1366-1380, depthscl taugas.f:7512-7648).  Covered: gases, Rayleigh,
 ! clouds and aerosols over a Lambertian surface (constant albedo, the six standard spectra or their mixture); what it does not cover yet is refused
-! by name (aerosol / cloud / atmosphere files, BRDF surfaces, user cloud / aerosol files) and
+! by name (BRDF surfaces, CKTAU files, ice water in usrcld.dat) and
 ! still runs from an optics file the reference produced (sbd_io_mod).  Literals: see sbd_tables_mod.
 module sbd_bandmodel_mod
   use sbd_grid_mod, only: kr, unset, spectral_grid, nstrms
@@ -41,7 +41,6 @@ contains
     type(model_input), intent(in) :: m
     character(len=*), intent(out) :: why
     why = ''
-    if (m%aer%iaer < 0) why = 'aerosol file (aerosol.dat, iaer=-1)'
     if (.not. (m%isalb >= -1 .and. m%isalb <= 6) .and. m%isalb /= 10) why = 'BRDF surface (isalb 7, 8, 9)'
     if (m%kdist < 0) why = 'k-distribution files (kdist=-1)'
     if (m%nf == -2) why = 'solar spectrum from the k-distribution file (nf=-2)'
@@ -226,7 +225,8 @@ contains
     real(kr), allocatable :: sd(:, :), ss(:, :), sp(:, :, :), swt(:, :), swl(:), slo(:), shi(:), sfb(:), salb(:)
     logical, allocatable :: splank(:)
     integer, allocatable :: nk_of(:), first(:)
-    real(kr) :: pbar, amu0, btemp, ttemp, rh_surface
+    real(kr) :: pbar, amu0, btemp, ttemp, rh_surface, wv1, wv2
+    real(kr), allocatable :: run_wl(:)
     real(kr), parameter :: dtor = 3.1415926536_kr/180.
     integer :: nz, nmom, iwl, kd, i
     integer :: nthreads
@@ -283,6 +283,13 @@ contains
     call cloud_tables_init()
     if (deck%nslot == 0 .and. m%nre(1) == 0.) lcloud = read_layer_clouds(nz)      ! drt.f:501-502
     load = new_aerosol_load(m%aer, atm%z, rh_surface)
+    if (m%aer%iaer == -1) then                              ! aerosol.dat is read in wavelength order: walk it first
+      allocate(run_wl(grid%n))
+      do iwl = 1, grid%n
+        call grid%band(iwl - 1, run_wl(iwl), wv1, wv2)
+      end do
+      call plan_aerosol_file(load, run_wl)
+    end if
 
     allocate(nk_of(grid%n), first(grid%n), sd(nz, mk*grid%n), ss(nz, mk*grid%n), sp(0:nmom, nz, mk*grid%n), &
              swt(mk, grid%n), swl(grid%n), slo(grid%n), shi(grid%n), sfb(grid%n), salb(grid%n), splank(grid%n))
@@ -367,7 +374,7 @@ contains
       else if (lcloud%given) then
         call layer_cloud_depths(lcloud, m%imomc, wl, nz, nmom, dtauc, wcld, pmom)
       end if
-      call aerosol_depths(load, wl, nz, nmom, dtaua, waer, pmom)
+      call aerosol_depths(load, wl, nz, nmom, dtaua, waer, pmom, iw)
       do l = 1, nz
         pmom(2, l) = pmom(2, l) + .1*dtaur(l)
         scat(l) = dtauc(l)*wcld(l) + dtaua(l)*waer(l) + dtaur(l)

@@ -205,9 +205,74 @@ def test_user_data_files(tmp_path, namelist):
     print("%d work items, worst relative difference %.2e :: %s" % (len(ref), worst, namelist))
 
 
+def aerosol_file(wls, nn, nmom, seed):
+    """aerosol.dat: nn layers (the lowest of the atmosphere), nmom moments per layer, one set per wavelength."""
+    rng = np.random.default_rng(seed)
+    out = ["%d %d" % (nn, nmom)]
+    for w in wls:
+        out.append("%g" % w)
+        for i in range(nn):
+            g = rng.uniform(.5, .8)
+            tau = 0.0 if (i == 1 and w == wls[0]) else rng.uniform(.01, .2)/w       # a zero depth: the linear branch
+            moms = [g] if nmom == 1 else [g**k for k in range(1, nmom + 1)]
+            out.append(" ".join("%.6g" % v for v in [tau, rng.uniform(.8, 1.0)] + moms))
+    return "\n".join(out) + "\n"
+
+
+@needs_host
+@pytest.mark.skipif(not os.path.exists(CAPTURE), reason="oracle/_ref/sbdart_capture not built")
+@pytest.mark.parametrize("namelist,wls,nn,nmom", [
+    ("idatm=4 iaer=-1 wlinf=.3 wlsup=3 wlinc=.05 sza=30 iout=1", (.4, .55, .9, 1.6, 2.2), 33, 1),
+    ("idatm=4 iaer=-1 imoma=4 wlinf=.5 wlsup=4 wlinc=.1 sza=30 iout=1 nstr=8", (.4, .55, .9, 1.6), 33, 1),
+    ("idatm=2 iaer=-1 wlinf=.3 wlsup=3 wlinc=.05 sza=50 iout=1 nstr=8", (.25, .55, 1.0, 2.5, 3.5), 33, 10),
+    ("idatm=2 iaer=-1 wlinf=.3 wlsup=3 wlinc=.05 sza=50 iout=1 nstr=16", (.25, .55, 1.0), 33, 4),
+    ("idatm=6 iaer=-1 wlinf=.3 wlsup=3 wlinc=.1 sza=10 iout=1", (.55,), 33, 1),
+    ("idatm=6 iaer=-1 wlinf=.3 wlsup=3 wlinc=.02 sza=10 iout=1", (.5, .7, 1.0, 1.1, 2.0), 33, 3),   # first wavelength below the file
+    ("idatm=6 iaer=-1 wlinf=1 wlsup=3 wlinc=.1 sza=10 iout=1 jaer=1,3 zaer=15,22 taerst=.05,.1 tcloud=3 zcloud=1",
+     (.5, .7, 1.5, 2.0), 33, 1),
+    ("idatm=1 iaer=-1 wlinf=8 wlsup=12 wlinc=.25 sza=95 iout=1", (.5, 9.0, 10.0), 33, 2),
+])
+def test_aerosol_file(tmp_path, namelist, wls, nn, nmom):
+    """IAER=-1: aerosol.dat, read as the wavelength loop advances (tauaero.f:1526-1713), including what the
+    reference makes of a run that starts below the file's first wavelength."""
+    text = aerosol_file(wls, nn, nmom, seed=len(namelist))
+    for d in ("ref", "mine"):
+        os.makedirs(str(tmp_path / d))
+        (tmp_path / d / "aerosol.dat").write_text(text)
+    ref = reference_items(str(tmp_path / "ref"), namelist)
+    assert ref
+    mine = host_items(str(tmp_path / "mine"), namelist)
+    worst = compare(mine, ref, True)
+    print("%d work items, worst relative difference %.2e :: %s" % (len(ref), worst, namelist))
+
+
+@needs_host
+@pytest.mark.skipif(not os.path.exists(CAPTURE), reason="oracle/_ref/sbdart_capture not built")
+def test_aerosol_file_for_the_lowest_layers_only(tmp_path):
+    """aerosol.dat with fewer layers than the atmosphere: the reference fills the lowest layers and leaves the
+    aerosol depth of the others unset (tauaero.f:1219 `dtauab`, a local array: whatever the stack held -- its
+    work items then differ from run to run and layer to layer).  Here the other layers carry no aerosol: the
+    work items are those the reference builds from the same file padded with empty layers at the top."""
+    namelist = "idatm=6 wlinf=.3 wlsup=3 wlinc=.1 sza=10 iout=1 iaer=-1"
+    wls, nn, nz = (.4, .9, 2.0), 5, 33
+    lines = aerosol_file(wls, nn, 1, seed=3).splitlines()
+    padded = ["%d 1" % nz]
+    for k in range(len(wls)):
+        padded += [lines[1 + k*(nn + 1)]] + ["0 0 0"]*(nz - nn) + lines[2 + k*(nn + 1):2 + k*(nn + 1) + nn]
+    os.makedirs(str(tmp_path / "ref"))
+    os.makedirs(str(tmp_path / "mine"))
+    (tmp_path / "ref" / "aerosol.dat").write_text("\n".join(padded) + "\n")
+    (tmp_path / "mine" / "aerosol.dat").write_text("\n".join(lines) + "\n")
+    ref = reference_items(str(tmp_path / "ref"), namelist)
+    mine = host_items(str(tmp_path / "mine"), namelist)
+    assert ref and ref[0].nlyr == nz
+    worst = compare(mine, ref, True)
+    print("%d work items, worst relative difference %.2e" % (len(ref), worst))
+
+
 @needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
-    for namelist, word in (("iaer=-1", "aerosol"), ("isalb=7", "surface"),
+    for namelist, word in (("isalb=7", "surface"),
                            ("kdist=-1", "k-distribution")):
         d = str(tmp_path / word)
         os.makedirs(d)
