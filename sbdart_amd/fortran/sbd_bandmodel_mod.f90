@@ -16,7 +16,7 @@ module sbd_bandmodel_mod
   use omp_lib, only: omp_get_max_threads
   implicit none
   private
-  public :: model_input, covered_by_band_model, build_work_items, aerosol_input, gas_depth_report
+  public :: model_input, covered_by_band_model, build_work_items, aerosol_input, gas_depth_report, corint_history
   integer, parameter :: maxmom_all = 299               ! params.f:10
 
   type model_input                     ! the &INPUT variables this step reads, same names
@@ -201,6 +201,31 @@ contains
       spec = spectrum_at(wl, mix%xo4)
       call path_depths(spec, uu, amu0, atm%z, nz, dc, dl, col, carry)
       print '(f11.4,9es11.3)', wl, col(1) + col(2), col(3:9), sum(col)
+    end do
+  end subroutine
+
+  ! DISORT switches its CORINT argument off IN PLACE when a call has no beam or no scattering (disort.f:2695-2696)
+  ! and the reference passes its namelist variable (drt.f:541): every LATER call of the run goes without the
+  ! intensity corrections, and from the next wavelength on only NSTR+2 moments are prepared (drt.f:490-494).
+  ! The items are walked in call order (those the sensor filter removes are not calls, drt.f:461-462); flag 16
+  ! of an item = corrections still requested when its call is made.
+  subroutine corint_history(recs, nrec, ssalb)
+    type(optics_t), intent(inout) :: recs(:)
+    integer, intent(in) :: nrec
+    real(kr), intent(in) :: ssalb(:, :)
+    logical :: live
+    integer :: i, full, nm
+    if (nrec == 0) return
+    if (iand(recs(1)%flags, 16) == 0) return
+    live = .true.
+    full = recs(1)%nmom; nm = full
+    do i = 1, nrec
+      if (i > 1) then
+        if (recs(i)%iwl /= recs(i - 1)%iwl) nm = merge(full, min(recs(i)%nstr + 2, nstrms), live)
+      end if
+      recs(i)%nmom = nm
+      if (.not. live) recs(i)%flags = recs(i)%flags - iand(recs(i)%flags, 16)
+      if (recs(i)%ff /= 0._kr .and. (recs(i)%fbeam == 0._kr .or. sum(ssalb(:, i)) == 0._kr)) live = .false.
     end do
   end subroutine
 

@@ -94,7 +94,7 @@ contains
                    recs(i)%phi0, recs(i)%albedo, recs(i)%btemp, recs(i)%ttemp, recs(i)%temis, recs(i)%fisot/)
       write(u) hdr, sc
       if (present(bdtauc)) then
-        write(u) bdtauc(:, i), bssalb(:, i), btemper, bpmom(:, :, i), umu, phi
+        write(u) bdtauc(:, i), bssalb(:, i), btemper, bpmom(:recs(i)%nmom + lbound(bpmom, 1), :, i), umu, phi
       else
         write(u) recs(i)%dtauc, recs(i)%ssalb, recs(i)%temper, recs(i)%pmom, recs(i)%umu, recs(i)%phi
       end if

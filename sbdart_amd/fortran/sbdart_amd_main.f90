@@ -56,7 +56,7 @@ program sbdart_amd
   type(view_geometry) :: view
   type(iout_format) :: fmt
   type(spectral_sums) :: sums
-  integer :: nrec, ios, i, j, nz, nmom, numu, lev_top, lev_bot, nlev, u11, ntop, nbot, i0, i1, nbeam, npart, ip
+  integer :: nrec, ios, i, j, nz, nmom, numu, lev_top, lev_bot, nlev, u11, ntop, nbot, i0, i1, nbeam, npart, ip, pass, ncorr
   logical :: radcalc, known, have_atm, default_zout
   character(len=1024) :: path
   integer :: plen, pstat
@@ -170,9 +170,10 @@ program sbdart_amd
     do i = 1, nrec
       recs(i)%ff = filter_value(sensor, recs(i)%wl)       ! drt.f:461 (ewcoef = 1)
     end do
+    call corint_history(recs, nrec, bssalb)
     have_atm = .true.
   end if
-  nmom = recs(1)%nmom
+  nmom = maxval(recs(1:nrec)%nmom)
   call get_environment_variable('SBD_DUMP_OPTICS', path, plen, pstat)      ! the work items, for inspection / tests
   if (pstat == 0 .and. plen > 0) then
     if (from_model) then
@@ -190,7 +191,8 @@ program sbdart_amd
     call grid%band(recs(i)%iwl - 1, wl, wvlo, wvhi)
     if (abs(wl - recs(i)%wl) > 1e-12_kr*wl .or. abs(wvlo - recs(i)%wvnmlo) > 1e-9_kr*wvlo .or. &
         abs(wvhi - recs(i)%wvnmhi) > 1e-9_kr*wvhi) call fatal('optics record disagrees with the wavelength grid of INPUT')
-    if (recs(i)%nlyr /= nz .or. recs(i)%nmom /= nmom) call fatal('optics records differ in NLYR/NMOM')
+    if (recs(i)%nlyr /= nz .or. recs(i)%nmom > nmom .or. recs(i)%nmom < min(recs(i)%nstr, nmom)) &
+      call fatal('optics records differ in NLYR/NMOM')        ! (fewer moments: after CORINT went off, corint_history)
   end do
 
   ! ---- output levels: the computational levels nearest to ZOUT (drt.f:368-381); level 1 = top ----
@@ -221,28 +223,31 @@ program sbdart_amd
 
   ! ---- batch arrays (row-major by work item == Fortran's first index fastest).  Items the filter
   !      function removes (ff = 0) are not solved (drt.f:461-462); items with a beam come first so
-  !      that an NSTR retry (below) re-solves one contiguous part ----
+  !      that an NSTR retry (below) re-solves one contiguous part, and among them first those whose call
+  !      still asks for the intensity corrections (flag 16: corint_history) ----
   call system_clock(tick0, tick_rate)
   allocate(order(nrec), where_solved(nrec))
   where_solved = 0                                   ! batch position of record i, 0 = not solved
-  nbeam = 0
-  do i = 1, nrec
-    if (recs(i)%ff /= 0._kr .and. recs(i)%fbeam > 0._kr) then
-      nbeam = nbeam + 1
-      order(nbeam) = i
-      where_solved(i) = nbeam
-    end if
-  end do
-  npart = nbeam
-  do i = 1, nrec
-    if (recs(i)%ff /= 0._kr .and. .not. recs(i)%fbeam > 0._kr) then
+  npart = 0
+  do pass = 1, 3
+    do i = 1, nrec
+      if (recs(i)%ff == 0._kr) cycle
+      if (.not. recs(i)%fbeam > 0._kr) then
+        if (pass /= 3) cycle
+      else if (corint .and. radcalc .and. iand(recs(i)%flags, 16) == 0) then
+        if (pass /= 2) cycle
+      else
+        if (pass /= 1) cycle
+      end if
       npart = npart + 1
       order(npart) = i
       where_solved(i) = npart
-    end if
+    end do
+    if (pass == 1) ncorr = npart
+    if (pass == 2) nbeam = npart
   end do
-  ! (the band model's arrays are already the batch when every item is solved and all or none have a beam)
-  in_place = from_model .and. npart == nrec .and. (nbeam == nrec .or. nbeam == 0)
+  ! (the band model's arrays are already the batch when every item is solved and all are of one kind)
+  in_place = from_model .and. npart == nrec .and. (ncorr == nrec .or. nbeam - ncorr == nrec .or. nbeam == 0)
   allocate(wvnmlo(nrec), wvnmhi(nrec), fbeam(nrec), albedo(nrec), plank(nrec), status(nrec), weight(nrec), temper(0:nz))
   if (in_place) then
     call move_alloc(bdtauc, dtauc); call move_alloc(bssalb, ssalb); call move_alloc(bpmom, pmom)
@@ -256,7 +261,9 @@ program sbdart_amd
       if (from_model) then
         dtauc(:, ip) = bdtauc(:, i); ssalb(:, ip) = bssalb(:, i); pmom(:, :, ip) = bpmom(:, :, i)
       else
-        dtauc(:, ip) = recs(i)%dtauc; ssalb(:, ip) = recs(i)%ssalb; pmom(:, :, ip) = recs(i)%pmom
+        dtauc(:, ip) = recs(i)%dtauc; ssalb(:, ip) = recs(i)%ssalb
+        pmom(:, :, ip) = 0                             ! (a run whose CORINT went off holds shorter moment arrays later)
+        pmom(0:recs(i)%nmom, :, ip) = recs(i)%pmom
       end if
     end if
     wvnmlo(ip) = recs(i)%wvnmlo; wvnmhi(ip) = recs(i)%wvnmhi
@@ -284,8 +291,9 @@ program sbdart_amd
   !      coincides with a quadrature angle makes DISORT ask for another stream count, drt.f:536-555),
   !      the beamless items with the stream count as given ----
   call system_clock(tick1)
-  call solve_part(1, nbeam, .true.)
-  call solve_part(nbeam + 1, npart, .false.)
+  call solve_part(1, ncorr, .true., corint)
+  call solve_part(ncorr + 1, nbeam, .true., .false.)
+  call solve_part(nbeam + 1, npart, .false., .false.)
   call system_clock(tick2)
   call get_environment_variable('SBD_TIMING', path, plen, pstat)
   if (pstat == 0 .and. plen > 0) write(0, '(a,f9.4,a,i0,a,f9.4,a)') 'sbdart_amd: batch assembly ', &
@@ -486,9 +494,9 @@ contains
   end function
 
   ! solve batch positions p0..p1 on every visible GPU; per-run formats also get their weighted sums
-  subroutine solve_part(p0, p1, beam)
+  subroutine solve_part(p0, p1, beam, corrections)
     integer, intent(in) :: p0, p1
-    logical, intent(in) :: beam
+    logical, intent(in) :: beam, corrections
     type(sbd_run_cfg) :: cfg
     type(sbd_batch_in) :: bin
     type(sbd_batch_out) :: bout
@@ -506,7 +514,7 @@ contains
       cfg%onlyfl = merge(0, 1, radcalc); cfg%lamber = 1; cfg%usrang = merge(1, 0, radcalc)
       cfg%numu = numu; cfg%nphi = merge(view%nphi, 0, radcalc)
       cfg%nlevel_out = nlev; cfg%device = 0; cfg%max_batch = p1 - p0 + 1
-      cfg%corint = merge(1, 0, corint .and. radcalc .and. beam)      ! (off without a beam, disort.f:2695)
+      cfg%corint = merge(1, 0, corrections .and. radcalc .and. beam) ! (off without a beam, disort.f:2695)
       cfg%umu0 = recs(1)%umu0; cfg%phi0 = phi0; cfg%fisot = fisot
       cfg%btemp = btemp; cfg%ttemp = ttemp; cfg%temis = temis
       cfg%temper = c_loc(temper); cfg%umu = c_loc(umu); cfg%phi = c_loc(phiv)

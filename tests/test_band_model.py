@@ -271,6 +271,24 @@ def test_aerosol_file_for_the_lowest_layers_only(tmp_path):
 
 
 @needs_host
+@pytest.mark.skipif(not os.path.exists(CAPTURE), reason="oracle/_ref/sbdart_capture not built")
+def test_corint_history(tmp_path):
+    """The first call without a beam ends the intensity corrections of the run (disort.f:2695-2696 writes the
+    caller's variable): flag 16 and the moment count of every later item follow the reference's."""
+    namelist = ("idatm=4 wlinf=0.2 wlsup=0.3 wlinc=.01 sza=30 nf=-1 iout=5 nstr=8 nzen=2 uzen=100,175 nphi=2 "
+                "phi=0,90 corint=t")
+    for d in ("ref", "mine"):
+        os.makedirs(str(tmp_path / d))
+        (tmp_path / d / "solar.dat").write_text("0.5 1900.0\n0.4 1500\n0.3 520.0\n0.25 100\n0.24 0\n.1 0\n")
+    ref = reference_items(str(tmp_path / "ref"), namelist)
+    mine = host_items(str(tmp_path / "mine"), namelist)
+    compare(mine, ref, True)
+    assert [m.flags & 16 for m in mine] == [r.flags & 16 for r in ref]
+    assert [m.nmom for m in mine] == [r.nmom for r in ref] == [299]*3 + [10]*(len(ref) - 3)
+    assert mine[0].flags & 16 and not any(m.flags & 16 for m in mine[1:]) and mine[-1].fbeam > 0
+
+
+@needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
     for namelist, word in (("isalb=7", "surface"),
                            ("kdist=-1", "k-distribution")):

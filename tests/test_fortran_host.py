@@ -165,7 +165,7 @@ CAPTURE = os.path.join(ROOT, "oracle", "_ref", "sbdart_capture")
 needs_ref = pytest.mark.skipif(not os.access(CAPTURE, os.X_OK), reason="oracle/_ref not built")
 
 
-def run_reference_and_host(namelist, d, sums=False, from_input=False):
+def run_reference_and_host(namelist, d, sums=False, from_input=False, files=None):
     """In directory d: the reference (capture build: unmodified objects, DISORT call site recorded)
     on this INPUT, then the host -- on the optics the reference just used, or (from_input) on INPUT
     alone through its own band model.  Returns (reference stdout, host stdout, path of the captured
@@ -173,6 +173,9 @@ def run_reference_and_host(namelist, d, sums=False, from_input=False):
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, "INPUT"), "w") as f:
         f.write("\n &INPUT\n" + namelist + "\n /\n")
+    for name, text in (files or {}).items():           # user data files: both executables run in d
+        with open(os.path.join(d, name), "w") as f:
+            f.write(text)
     cap = os.path.join(d, "cap.sbdrec")
     ref = subprocess.run([CAPTURE], cwd=d, env=dict(os.environ, SBD_CAPTURE_FILE=cap), capture_output=True,
                          text=True, check=True).stdout
@@ -264,6 +267,58 @@ def test_intensity_corrections_from_input_alone(tmp_path, namelist):
     INTCOR kernel, the radiance writers -- against the reference's stdout for the same INPUT."""
     _build()
     ref, got, _ = run_reference_and_host(namelist, str(tmp_path), from_input=True)
+    off = _compare_stdout(got, ref)
+    print(f"{len(ref.split())} tokens, {off} one unit off in the last printed digit", file=sys.stderr)
+
+
+DARK_START = "0.5 1900.0\n0.4 1500\n0.3 520.0\n0.25 100\n0.24 0\n.1 0\n"     # solar.dat: no sun below 0.24 um
+
+
+@pytest.mark.gpu
+@needs_flang
+@needs_ref
+@pytest.mark.parametrize("from_input", [False, True], ids=["reference_optics", "input_alone"])
+def test_intensity_corrections_end_with_the_first_beamless_call(tmp_path, from_input):
+    """DISORT switches CORINT off in its caller's variable when a call has no beam (disort.f:2695-2696):
+    a run whose first wavelengths have no sun prints uncorrected radiances for ALL later ones.  The host
+    follows the history of the calls (corint_history), from the reference's optics and from INPUT alone."""
+    from sbdart_amd import records
+    _build()
+    nl = ("idatm=4 wlinf=.2 wlsup=.3 wlinc=.01 sza=30 nf=-1 iout=5 nstr=8 nzen=4 uzen=100,175 nphi=2 phi=0,90 "
+          "corint=t iaer=1 vis=15")
+    ref, got, cap = run_reference_and_host(nl, str(tmp_path), from_input=from_input, files={"solar.dat": DARK_START})
+    recs = records.read_records(cap)
+    lit = [r for r in recs if r.fbeam > 0]
+    assert recs[0].fbeam == 0 and recs[0].corint and lit and not any(r.corint for r in lit)
+    off = _compare_stdout(got, ref)
+    print(f"{len(ref.split())} tokens, {off} one unit off in the last printed digit", file=sys.stderr)
+
+
+def _aerosol_dat(wls, nn, nmom):
+    rng = np.random.default_rng(11)
+    out = ["%d %d" % (nn, nmom)]
+    for w in wls:
+        out.append("%g" % w)
+        for _ in range(nn):
+            g = rng.uniform(.55, .8)
+            out.append(" ".join("%.6g" % v for v in [rng.uniform(.005, .05)/w, rng.uniform(.85, 1.0)]
+                                + ([g] if nmom == 1 else [g**k for k in range(1, nmom + 1)])))
+    return "\n".join(out) + "\n"
+
+
+@pytest.mark.gpu
+@needs_flang
+@needs_ref
+@pytest.mark.parametrize("namelist,wls,nmom", [
+    ("idatm=4 iaer=-1 wlinf=.3 wlsup=2.3 wlinc=.1 sza=35 iout=10", (.4, .55, .9, 1.6), 1),
+    ("idatm=2 iaer=-1 wlinf=.45 wlsup=.85 wlinc=.2 sza=35 iout=20 nstr=16 nzen=5 uzen=0,175 nphi=2 phi=0,180 corint=t",
+     (.4, .55, .9), 40),
+])
+def test_aerosol_file_from_input_alone(tmp_path, namelist, wls, nmom):
+    """IAER=-1: aerosol.dat through band model, engine and writers, against the reference's stdout."""
+    _build()
+    ref, got, _ = run_reference_and_host(namelist, str(tmp_path), from_input=True,
+                                         files={"aerosol.dat": _aerosol_dat(wls, 33, nmom)})
     off = _compare_stdout(got, ref)
     print(f"{len(ref.split())} tokens, {off} one unit off in the last printed digit", file=sys.stderr)
 

@@ -4,7 +4,7 @@ python tools/fuzz_band_model.py SEED COUNT -- every switch of the band model dra
 compared with the reference DISORT arguments (bar 1e-12, see tests/test_band_model.py).  Build-container tool."""
 import sys, os, random, subprocess, tempfile, numpy as np
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,ROOT+'/tests')
-from test_band_model import host_items, reference_items, compare
+from test_band_model import host_items, reference_items, compare, aerosol_file
 random.seed(int(sys.argv[1]) if len(sys.argv)>1 else 1)
 def pick(*a): return random.choice(a)
 bad=0
@@ -33,12 +33,17 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
         p.append(c)
         if random.random()<.3: p.append("rhcld=%g krhclr=%d"%(pick(.8,1.),pick(0,1)))
         if random.random()<.3: p.append("imomc=%d"%pick(3,4,5))
-    if random.random()<.4:
+    aerfile=None
+    if random.random()<.12:                      # aerosol.dat: a full column (33 layers) at 1-5 wavelengths
+        p.append("iaer=-1 imoma=%d"%pick(1,3,4))
+        ws=sorted(random.sample([.2,.35,.5,.7,1.,1.6,2.5,4.,9.,20.],pick(1,2,3,5)))
+        aerfile=aerosol_file(tuple(ws),33,pick(1,1,3,12),seed=it)
+    elif random.random()<.4:
         p.append(pick("iaer=%d vis=%g"%(pick(1,2,3,4),pick(5,23,60)), "iaer=%d tbaer=%g rhaer=%g"%(pick(1,2,3,4),pick(.05,.5),pick(.3,.75,.9,.99))))
         if random.random()<.3: p.append("nosct=%d"%pick(1,3))
     if random.random()<.2: p.append("jaer=%d zaer=%g taerst=%g"%(pick(1,2,3,4),pick(15,22),pick(.01,.1)))
     if random.random()<.5: p.append(pick("albcon=%g"%pick(0,.3,.9),"isalb=%d"%pick(1,2,3,4,5,6),"isalb=10 sc=.25,.25,.25,.25"))
-    if random.random()<.25: p.append("ngrid=%d zgrid1=%g zgrid2=%g"%(pick(20,40,65),pick(.5,1,2),pick(10,30)))
+    if aerfile is None and random.random()<.25: p.append("ngrid=%d zgrid1=%g zgrid2=%g"%(pick(20,40,65),pick(.5,1,2),pick(10,30)))
     if random.random()<.2: p.append("nothrm=%d"%pick(0,1))
     if random.random()<.2: p.append("xrsc=%g"%pick(0,.5,2))
     rad=random.random()<.3
@@ -50,6 +55,9 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
     if random.random()<.15: p.append("isat=%d"%pick(1,4,9,13,17,22,26))
     nl=" ".join(p)
     with tempfile.TemporaryDirectory() as d:
+        if aerfile:
+            for sub in ("/r","/m"):
+                os.makedirs(d+sub); open(d+sub+"/aerosol.dat","w").write(aerfile)
         try:
             ref=reference_items(d+"/r",nl)
         except Exception as e:
