@@ -26,3 +26,14 @@ void launch_layer2(int nn, bool rad, unsigned grid, int lds, hipStream_t st, con
     else launch_layer2_f(nn, grid, lds, st, P, eigflag);
 }
 }
+#ifdef SBD_PHASE_TICKS
+extern "C" int sbd_debug_layer2_ticks(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sbd::layer2_ticks), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sbd::layer2_ticks), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

@@ -8,9 +8,10 @@
 //   phase functions), ARRAY is similar to Q- Q+.  Cholesky Q+ = L L^T, Q- = C C^T gives
 //   Q- Q+ ~ B^T B with B = C^T L, so the eigenvalues k^2 are the squared singular values of B
 //   and the eigenvectors of ARRAY are x = (M R)^-1 L v for the right singular vectors v.
-//   B's SVD is computed by ONE-SIDED JACOBI: lane j keeps column j of B and of X in registers,
+//   B's SVD is computed by ONE-SIDED JACOBI: lane j keeps column j of B in registers,
 //   column pairs meet by wave shuffles in a round-robin tournament, every rotation is local
-//   to the two lanes -- no LDS traffic, no barriers, NSTR/2 lanes busy per matrix.
+//   to the two lanes -- no LDS traffic, no barriers, NSTR/2 lanes busy per matrix.  The converged
+//   column b' = B v gives the eigenvector through C alone (x = (M R)^-1 C^-T b'), see below.
 //
 // When a Cholesky pivot is not positive (non-physical moments) the group raises a flag and
 // the QR kernel of sbd_layer.hpp redoes that layer (same outputs, reference algorithm).
@@ -83,6 +84,13 @@ SBD_DEVICE double lane_xor(double x)
     else return dpp_move<0x140>(lane_xor<(S ^ 15)>(x));
 }
 
+#ifdef SBD_PHASE_TICKS   // developer build: shader-clock ticks per phase, summed over waves (tools/layer_phases.py)
+static __device__ unsigned long long layer2_ticks[16];
+#define SBD_TICK(i) const unsigned long long tick##i = __builtin_readcyclecounter();
+#else
+#define SBD_TICK(i)
+#endif
+
 template <int NN, int G, bool RAD>
 __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 {
@@ -105,34 +113,74 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     const Layer2Lds lds(n, nn, RAD);
     double *shy = smem;                                  // shared: Y(l, iq), cmu, cwt
     double *scmu = smem + n * nn, *scwt = scmu + n;
-    const double *ylmc = P.t.ylmc + (size_t)mazim * n * (n + 1);
-    for (int e = lane; e < n * nn; e += 64) {
-        const int l = e / nn, iq = e % nn;
-        shy[e] = ylmc[iq * (n + 1) + l];
-    }
     double *srr = scwt + n, *sxi = srr + nn, *swi = sxi + nn, *smi = swi + nn;   // R = (W/M)^1/2, 1/(M R), 1/W, 1/M
-    if (lane < n) { scmu[lane] = P.t.cmu[lane]; scwt[lane] = P.t.cwt[lane]; }
+    constexpr bool rad = RAD;
+    const int me = g + 1;
+    const SV o(L);
+
+    // ---- everything the wave reads from global memory is asked for HERE, in one batch: the block's tables,
+    //      the layer's scalars, its moments, the beam's Ylm row.  A load in the middle of the kernel costs a
+    //      full memory round trip with nothing to hide it behind (two waves per SIMD), and one issued after
+    //      the output stores waits for those as well.  (Partial last block: the idle lanes read slot 0, layer 1.) ----
+    const int lcl = live ? lc : 1;
+    const int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
+    const double *sv = P.sv + (size_t)slot * P.sv_stride;
+    const double *ylmc = P.t.ylmc + (size_t)mazim * n * (n + 1);
+    constexpr int NYE = (n * nn + 63) / 64;
+    double yent[NYE];
+#pragma unroll
+    for (int t = 0; t < NYE; ++t) {
+        const int e = lane + 64 * t, l = e / nn, iq = e % nn;
+        yent[t] = (e < n * nn) ? ylmc[iq * (n + 1) + l] : 0.0;
+    }
+    const double tcmu = (lane < n) ? P.t.cmu[lane] : 1.0, tcwt = (lane < n) ? P.t.cwt[lane] : 1.0;
+    const int st0 = svi[SBD_SVI_STATUS];
+    const int ncut = svi[SBD_SVI_NCUT];
+    const double fbeam = P.fbeam[slot];
+    const bool plank = P.plank[slot] != 0;
+    const double oprim = sv[o.oprim() + lcl - 1];
+    const double f = sv[o.flyr() + lcl - 1];
+    const double dtaucp_lc = sv[o.dtaucp() + lcl - 1];
+    const double ssalb_lc = P.ssalb[(size_t)slot * L + (lcl - 1)];
+    const double xr0 = sv[o.xr0() + lcl - 1], xr1 = sv[o.xr1() + lcl - 1];
+    constexpr int NPK = (n + G - 1) / G;
+    double pkv[NPK];
+    {
+        const double *pm = P.pmom + ((size_t)slot * L + (lcl - 1)) * (P.nmom + 1);
+#pragma unroll
+        for (int t = 0; t < NPK; ++t) {
+            const int k = g + t * G;
+            pkv[t] = (k == 0) ? 1.0 : ((k < n && k <= P.nmom) ? pm[k] : 0.0);
+        }
+    }
+    const double *ylm0 = P.t.ylm0 + (size_t)mazim * (n + 1);
+    double y0[n];
+#pragma unroll
+    for (int k = 0; k < n; ++k) y0[k] = ylm0[k];
+    // GC itself is only read back for the layers FLUXES / the boundary rows / USRINT need: the layers of the
+    // first two output levels are fetched with the batch, further ones (rare) where the answer is needed
+    const int32_t *layru = svi + SBD_SVI_LAYRU;
+    const int lay0 = (P.nlev > 0) ? layru[P.t.level_out[0]] : 0;
+    const int lay1 = (P.nlev > 1) ? layru[P.t.level_out[1]] : 0;
+
+#pragma unroll
+    for (int t = 0; t < NYE; ++t) {
+        const int e = lane + 64 * t;
+        if (e < n * nn) shy[e] = yent[t];
+    }
+    if (lane < n) { scmu[lane] = tcmu; scwt[lane] = tcwt; }
     if (lane < nn) {
-        const double w = P.t.cwt[lane], mu = P.t.cmu[lane];
-        const double r = sqrt(w / mu);
+        const double r = sqrt(tcwt / tcmu);
         srr[lane] = r;
-        sxi[lane] = 1.0 / (mu * r);
-        swi[lane] = 1.0 / w;
-        smi[lane] = 1.0 / mu;
+        sxi[lane] = 1.0 / (tcmu * r);
+        swi[lane] = 1.0 / tcwt;
+        smi[lane] = 1.0 / tcmu;
     }
     __syncthreads();
     if (lc > L) return;
-
-    const int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
-    const int st0 = svi[SBD_SVI_STATUS];
     if (st0 & (0x20 | 0x10)) return;
-    if (lc > svi[SBD_SVI_NCUT]) return;
-    const double fbeam = P.fbeam[slot];
+    if (lc > ncut) return;
     if (mazim > 0 && fbeam == 0.0) return;
-    const bool plank = P.plank[slot] != 0;
-    constexpr bool rad = RAD;
-    const SV o(L);
-    const double *sv = P.sv + (size_t)slot * P.sv_stride;
 
     double *base = smem + lds.shared_total + (size_t)gi * lds.group_total;
     double *gl = base + lds.gl;
@@ -143,7 +191,6 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     double *vec = base + lds.vec + (nn + 1) / 2 + 2;      // radiance mode only:
     double *zjs = vec, *z0s = vec + n, *z1s = vec + 2 * n, *psi = vec + 3 * n;   // psi[2n]
     constexpr int ldh = NN, ldq = NN | 1, ld = n | 1;
-    const int me = g + 1;
     const size_t lidx = (size_t)ms * L + (lc - 1);
 #define YS(l, iq) shy[(l) * nn + ((iq) - 1)]             // iq in 1..nn ; Y(l,-mu) = (-1)^(l-m) Y(l,mu)
 #define SP(i, j) sp[((j) - 1) * ldh + ((i) - 1)]
@@ -152,17 +199,30 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 #define QM(i, j) qm[((j) - 1) * ldq + ((i) - 1)]
 #define TM(i, j) lu[((j) - 1) * ldq + ((i) - 1)]       // reduced UPBEAM/UPISOT matrix (Q+- are dead by then)
 
+    SBD_TICK(0)
     // ---- GL(k) (SETDIS, disort.f:2583-2585) ----
-    const double oprim = sv[o.oprim() + lc - 1];
-    const double f = sv[o.flyr() + lc - 1];
-    {
-        const double *pm = P.pmom + ((size_t)slot * L + (lc - 1)) * (P.nmom + 1);
-        for (int k = g; k < n; k += G) {
-            const double pk = (k == 0) ? 1.0 : ((k <= P.nmom) ? pm[k] : 0.0);
-            gl[k] = (double)(2 * k + 1) * oprim * (pk - f) / (1.0 - f);
-        }
+#pragma unroll
+    for (int t = 0; t < NPK; ++t) {
+        const int k = g + t * G;
+        if (k < n) gl[k] = (double)(2 * k + 1) * oprim * (pkv[t] - f) / (1.0 - f);
     }
     wave_lds_sync();
+
+    // ---- the beam source's two halves, r+ + r- and r+ - r- (disort.f:4208-4216): nothing but GL and Ylm ----
+    double rs = 0.0, rdv = 0.0;
+    if (fbeam > 0.0 && me <= nn) {
+        double s0 = 0.0, s1 = 0.0;                       // over even k, over odd k (k >= m by the mask)
+#pragma unroll
+        for (int k = 0; k < n; k += 2) {
+            s0 = s0 + ((k >= mazim) ? gl[k] * YS(k, me) : 0.0) * y0[k];
+            s1 = s1 + ((k + 1 >= mazim) ? gl[k + 1] * YS(k + 1, me) : 0.0) * y0[k + 1];
+        }
+        const bool mpar = (mazim & 1) != 0;
+        const double se = mpar ? s1 : s0, so = mpar ? s0 : s1;
+        const double c = ((mazim == 0) ? 1.0 : 2.0) * fbeam / (4.0 * P.pi);
+        rs = 2.0 * c * se;
+        rdv = 2.0 * c * so;
+    }
 
     // ---- S+ / S- (even / odd l-m parts), lane j <-> column j; then Q+-, all symmetric ----
     if (me <= nn) {
@@ -189,6 +249,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     }
     wave_lds_sync();
 
+    SBD_TICK(1)
     // ---- two Cholesky factorisations side by side (lane i <-> row i), lower factors ----
     // (row me of both matrices lives in registers while it is being eliminated: the lower triangle
     //  is read once, every column k crosses LDS once for the rows below it, L and C are written at the end)
@@ -228,14 +289,15 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     // the column maximum for the Cholesky-reuse solve below).  Such layers are rare.
     // (within 64 ulps of 1: the dithered value and the undithered neighbours of 1, for which the full I - CC
     //  is singular to working precision and the reference-algorithm kernel raises errmsg 4 from its pivots)
-    const bool hard_thermal = plank && mazim == 0 && P.ssalb[(size_t)slot * L + (lc - 1)] >= 1.0 - 64.0 * 1.1102230246251565e-16;
+    const bool hard_thermal = plank && mazim == 0 && ssalb_lc >= 1.0 - 64.0 * 1.1102230246251565e-16;
     if (!spd || P.force_fallback || hard_thermal) {
         if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;   // count, then the entries
         return;
     }
 
-    // ---- B = C^T L and X0 = (M R)^-1 L : lane j <-> column j, in registers ----
-    double bcol[nn], xcol[nn];
+    SBD_TICK(2)
+    // ---- B = C^T L : lane j <-> column j, in registers ----
+    double bcol[nn];
     if (me <= nn) {
         // column me of L, its upper part read as zeros, once into registers
         double lcol[nn];
@@ -248,13 +310,16 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 #pragma unroll
             for (int k = i; k <= nn; ++k) s = s + QM(k, i) * lcol[k - 1];
             bcol[i - 1] = s;
-            xcol[i - 1] = lcol[i - 1] * sxi[i - 1];
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < nn; ++i) { bcol[i] = 0.0; xcol[i] = 0.0; }
+        for (int i = 0; i < nn; ++i) bcol[i] = 0.0;
     }
 
+    SBD_TICK(3)
+#ifdef SBD_PHASE_TICKS
+    int nsweep = 0;
+#endif
     // ---- one-sided Jacobi, round-robin pairing over the nn columns (nn even or odd) ----
     {
         constexpr int NP = (nn + 1) & ~1;               // players (a dummy when nn is odd)
@@ -268,7 +333,8 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         bool done = false;
         const unsigned long long gmask = ((G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull)) << ((gi * G) & 63);
         // one meeting of this lane's column with its partner's (both lanes run it, each keeps its own)
-        auto meet = [&](const int partner, const bool valid, const double (&ob)[nn], const double (&ox)[nn]) {
+        // (only B's columns rotate: the eigenvectors follow from the converged columns and C afterwards)
+        auto meet = [&](const int partner, const bool valid, const double (&ob)[nn]) {
             if (valid && !done) {
                 double aa = 0.0, bb = 0.0, gg = 0.0;
 #pragma unroll
@@ -296,10 +362,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                     // p' = c p - s q ; q' = s p + c q
                     const double mine = c, other = lo ? -sn : sn;
 #pragma unroll
-                    for (int i = 0; i < nn; ++i) {
-                        bcol[i] = mine * bcol[i] + other * ob[i];
-                        xcol[i] = mine * xcol[i] + other * ox[i];
-                    }
+                    for (int i = 0; i < nn; ++i) bcol[i] = mine * bcol[i] + other * ob[i];
                 }
             }
         };
@@ -312,13 +375,10 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                 static_for<NP - 1>([&](auto ss) {
                     constexpr int sx = decltype(ss)::value + 1;
                     const int partner = j ^ sx;
-                    double ob[nn], ox[nn];
+                    double ob[nn];
 #pragma unroll
-                    for (int i = 0; i < nn; ++i) {
-                        ob[i] = lane_xor<sx>(bcol[i]);
-                        ox[i] = lane_xor<sx>(xcol[i]);
-                    }
-                    meet(partner, (j < nn) && (partner < nn), ob, ox);
+                    for (int i = 0; i < nn; ++i) ob[i] = lane_xor<sx>(bcol[i]);
+                    meet(partner, (j < nn) && (partner < nn), ob);
                 });
             } else {
                 for (int s = 0; s < NP - 1; ++s) {
@@ -327,18 +387,18 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                     const int ppos = NP - 1 - pos;
                     const int partner = (ppos == 0) ? 0 : 1 + (ppos - 1 + s) % (NP - 1);
                     const int src = (j < NP) ? partner : j;
-                    double ob[nn], ox[nn];
+                    double ob[nn];
 #pragma unroll
-                    for (int i = 0; i < nn; ++i) {
-                        ob[i] = __shfl(bcol[i], src, G);
-                        ox[i] = __shfl(xcol[i], src, G);
-                    }
-                    meet(partner, (j < nn) && (partner < nn) && (j < NP), ob, ox);
+                    for (int i = 0; i < nn; ++i) ob[i] = __shfl(bcol[i], src, G);
+                    meet(partner, (j < nn) && (partner < nn) && (j < NP), ob);
                 }
             }
             // quadratic convergence: a sweep that started below 3e-7 ends below 1e-13 (eigenvalues to
             // ~1e-26 relative, eigenvectors to ~1e-13: far inside the parity gate)
             if ((__ballot(rotated) & gmask) == 0ull || (__ballot(coarse) & gmask) == 0ull) done = true;
+#ifdef SBD_PHASE_TICKS
+            ++nsweep;
+#endif
             if (!__any(!done)) break;
         }
         if (!done) {   // 30 sweeps without convergence: the reference-algorithm kernel redoes this layer
@@ -347,31 +407,49 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         }
     }
 
-    // ---- eigenvalues, (G+)+(G-) = AMB x / k (disort.f:3264-3286), outputs ----
-    double kq = 0.0;
-    double gp[nn];
+    SBD_TICK(4)
+    // ---- eigenvalues, eigenvectors, (G+)+(G-) = AMB x / k (disort.f:3264-3286), outputs ----
+    // The converged column is b' = B v = C^T L v (|b'| = k).  With y = L v = C^-T b':
+    //   x = (M R)^-1 y                                   (G+)-(G-), one back-substitution with C^T;
+    //   AMB x = -M^-1 (I - S- W) x = -(M R)^-1 Q- (R^-1 W x), and R^-1 W x = W/(M R^2) y = y, Q- y = C C^T y = C b':
+    //   (G+)+(G-) = -(M R)^-1 (C b') / k                  one product with C.
+    // C is in LDS since the factorisation; nothing but B's columns went through the rotations.
+    double kq = 0.0, lam = 1.0;
+    double gp[nn], xcol[nn];
+    double yv[nn], cb[nn];                               // y = L v and C b' = Q- y: UPISOT / UPBEAM below reuse them
+#pragma unroll
+    for (int i = 0; i < nn; ++i) { yv[i] = 0.0; cb[i] = 0.0; }
     if (me <= nn) {
-        double lam = 0.0;
+        lam = 0.0;
 #pragma unroll
         for (int i = 0; i < nn; ++i) lam = lam + bcol[i] * bcol[i];
         kq = sqrt(fabs(lam));
         const double rkq = 1.0 / kq;
-        double wx[nn];                                  // W x
+        double rc[nn];
 #pragma unroll
-        for (int k = 0; k < nn; ++k) wx[k] = scwt[k] * xcol[k];
+        for (int i = 1; i <= nn; ++i) rc[i - 1] = rcp_nr(QM(i, i));
+#pragma unroll
+        for (int i = nn; i >= 1; --i) {                  // C^T y = b'
+            double s = bcol[i - 1];
+#pragma unroll
+            for (int k = i + 1; k <= nn; ++k) s = s - QM(k, i) * yv[k - 1];
+            yv[i - 1] = s * rc[i - 1];
+        }
 #pragma unroll
         for (int i = 1; i <= nn; ++i) {
-            // AMB x = M^-1 (S- W x - x)
-            double s = -xcol[i - 1];
+            double s = 0.0;                              // (C b')(i)
 #pragma unroll
-            for (int k = 1; k <= nn; ++k) s = s + SM(i, k) * wx[k - 1];
-            gp[i - 1] = s * smi[i - 1] * rkq;
+            for (int k = 1; k <= i; ++k) s = s + QM(i, k) * bcol[k - 1];
+            cb[i - 1] = s;
+            gp[i - 1] = -(s * sxi[i - 1]) * rkq;
         }
+#pragma unroll
+        for (int i = 0; i < nn; ++i) xcol[i] = yv[i] * sxi[i];
         double *kkout = P.kk + lidx * n;
         double *ekout = P.ek + lidx * nn;
         kkout[me + nn - 1] = kq;
         kkout[nn + 1 - me - 1] = -kq;
-        const double ekv = exp(-kq * sv[o.dtaucp() + lc - 1]);
+        const double ekv = exp(-kq * dtaucp_lc);
         ekout[nn + 1 - me - 1] = ekv;
         // GC (disort.f:3290-3312) and the matrix-ready interface blocks (disort.f:2851-2876)
         // straight from registers: this lane owns columns me+nn (k > 0) and nn+1-me (k < 0) of
@@ -379,10 +457,9 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         // read back for the layers FLUXES / the boundary rows / USRINT need.
         // (gconly: sbd_band4.hpp scales GC by the STWJ factors itself and only needs GC's two independent
         //  quarters, Params::gcc -- a quarter of the bytes of ga + gb)
-        bool need_gc = rad || P.all_levels || lc == 1 || lc == svi[SBD_SVI_NCUT];
+        bool need_gc = rad || P.all_levels || lc == 1 || lc == ncut || lay0 == lc || lay1 == lc;
         if (!need_gc) {
-            const int32_t *layru = svi + SBD_SVI_LAYRU;
-            for (int i = 0; i < P.nlev; ++i) need_gc = need_gc || layru[P.t.level_out[i]] == lc;
+            for (int i = 2; i < P.nlev; ++i) need_gc = need_gc || layru[P.t.level_out[i]] == lc;
         }
         double *gcout = P.gc + lidx * n * n;
         const int ja = me + nn - 1, jb = nn - me;          // 0-based columns
@@ -419,6 +496,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         }
     }
     wave_lds_sync();      // (L and C stay in the lu area until UPBEAM builds its matrix there)
+    SBD_TICK(5)
 
     // ---- radiance mode: TERPEV from the register-resident eigenvector columns ----
     if constexpr (rad) {
@@ -461,7 +539,6 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     }
 
     // ---- UPBEAM / UPISOT on the +-mu-reduced systems (see the header): lane i <-> mu_i ----
-    const double *ylm0 = P.t.ylm0 + (size_t)mazim * (n + 1);
     auto ylmc_full = [&](int l, int iq) -> double {   // YLMC(l, iq) including the mirrored half
         if (iq <= nn) return YS(l, iq);
         return ((((l - mazim) & 1) == 0) ? 1.0 : -1.0) * YS(l, iq - nn);
@@ -508,6 +585,47 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     };
     const bool thermal = plank && mazim == 0;
     int status = 0;
+    // ---- the same solves from the singular vectors at hand.  With Y = [y_j] (y_j = L v_j) and K = diag(k_j):
+    //        Y Y^T = Q+,  Y^T Q- Y = K^2   =>   Q+^-1 = (C B') K^-4 (C B')^T,   Q-^-1 = Y K^-2 Y^T,
+    //        Q+ Q- = Y K^2 Y^-1,  Y^-1 = K^-2 (C B')^T,
+    //      and with M = R^-2 W:  T = R^-1 (I/mu0 - mu0 Q+ Q-) R^-1 W, so
+    //        T^-1 q = W^-1 R  sum_j y_j (cb_j . R q) / (k_j^2 (1/mu0 - mu0 k_j^2)).
+    //      Every solve is a projection on the columns (lane j <-> column j) and a recombination, two LDS
+    //      round trips each, instead of NSTR/2 dependent elimination steps.  Taken when no k_j is so small
+    //      that b'_j (absolute accuracy eps |B|) has lost its relative accuracy, and -- for the beam -- no
+    //      k_j sits next to 1/mu0; otherwise the factorisations below do the work. ----
+    double *scr = lu;                                    // [nn][ldq] products, then nn doubles of a spread vector
+    double *spread = lu + nn * ldq;                      // (L and C are dead on this path)
+    auto project = [&](const double (&a)[nn], const double vi) -> double {    // sum_i a_j[i] v_i, v over the lanes
+        if (me <= nn) spread[me - 1] = vi;
+        wave_lds_sync();
+        double d = 0.0;
+#pragma unroll
+        for (int i = 0; i < nn; ++i) d = d + a[i] * spread[i];
+        return d;
+    };
+    auto combine = [&](const double (&a)[nn], const double tj) -> double {    // sum_j a_j[i] t_j, to lane i
+        if (me <= nn) {
+#pragma unroll
+            for (int i = 0; i < nn; ++i) scr[i * ldq + (me - 1)] = a[i] * tj;
+        }
+        wave_lds_sync();
+        double r = 0.0;
+        if (me <= nn) {
+#pragma unroll
+            for (int m = 0; m < nn; ++m) r = r + scr[(me - 1) * ldq + m];
+        }
+        wave_lds_sync();
+        return r;
+    };
+    const double umu0 = P.umu0;
+    bool by_vectors;
+    {
+        const double gap = fabs(1.0 - umu0 * umu0 * lam);
+        const bool bad = (me <= nn) && (!(lam > 1.0e-8) || (fbeam > 0.0 && !(gap > 1.0e-6)));
+        const unsigned long long gmask = ((G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull)) << ((gi * G) & 63);
+        by_vectors = (__ballot(bad) & gmask) == 0ull;
+    }
     // errmsg 4 (UPISOT's SGECO, disort.f:4333): the Cholesky pivots of Q+ and Q- (squares of the factors'
     // diagonals, still in LDS) stand in for the condition estimate, see near_singular() in sbd_layer.hpp
     if (thermal) {
@@ -517,12 +635,24 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     if (thermal) {
         // (I - CC) Z1 = (1-w') XR1 (the same in both halves): Z1+- = (1-w') XR1 u, (I - S+ W) u = 1;
         // (I - CC) Z0 = (1-w') XR0 + CMU Z1: Z0+- = (1-w') XR0 u +- e, (I - S- W) e = mu Z1
-        const double xr0 = sv[o.xr0() + lc - 1], xr1 = sv[o.xr1() + lc - 1];
         const double rme = (me <= nn) ? srr[me - 1] : 0.0, rw = (me <= nn) ? srr[me - 1] * swi[me - 1] : 0.0;
         const double cmu_me = (me <= nn) ? scmu[me - 1] : 0.0;
-        const double u = rw * chol_solve(qp, rme);
-        const double z1 = (1.0 - oprim) * xr1 * u;
-        const double e = rw * chol_solve(qm, rme * cmu_me * z1);
+        double u, e, z1;
+        if (by_vectors) {
+            wave_lds_sync();                             // (the pivots above were read from the area that now turns scratch)
+            const double rk2 = 1.0 / lam;
+            double d1 = 0.0;                             // (C b')_j . (R 1)
+#pragma unroll
+            for (int i = 0; i < nn; ++i) d1 = d1 + cb[i] * srr[i];
+            u = rw * combine(cb, d1 * rk2 * rk2);
+            z1 = (1.0 - oprim) * xr1 * u;
+            const double d2 = project(yv, rme * cmu_me * z1);
+            e = rw * combine(yv, d2 * rk2);
+        } else {
+            u = rw * chol_solve(qp, rme);
+            z1 = (1.0 - oprim) * xr1 * u;
+            e = rw * chol_solve(qm, rme * cmu_me * z1);
+        }
         const double z0p = (1.0 - oprim) * xr0 * u + e, z0m = (1.0 - oprim) * xr0 * u - e;
         if (me <= nn) {
             double *p0 = P.zp0 + lidx * n, *p1 = P.zp1 + lidx * n;
@@ -536,44 +666,39 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         P.zp1[lidx * n + me - 1] = 0.0; P.zp1[lidx * n + me + nn - 1] = 0.0;
     }
 
+    SBD_TICK(6)
     if (fbeam > 0.0) {
-        const double delm0 = (mazim == 0) ? 1.0 : 0.0;
-        const double umu0 = P.umu0;
-        double rs = 0.0, rdv = 0.0;                      // r+ + r-, r+ - r-  (disort.f:4208-4216)
         if (me <= nn) {
-            // column me of T = M/mu0 - mu0 (I - S+ W) M^-1 (I - S- W)
-            double qv[nn];
+            if (!by_vectors) {
+                // column me of T = M/mu0 - mu0 (I - S+ W) M^-1 (I - S- W)
+                double qv[nn];
 #pragma unroll
-            for (int k = 1; k <= nn; ++k)
-                qv[k - 1] = (((k == me) ? 1.0 : 0.0) - SM(k, me) * scwt[me - 1]) * smi[k - 1];
-            double wq[nn];                              // W qv
+                for (int k = 1; k <= nn; ++k)
+                    qv[k - 1] = (((k == me) ? 1.0 : 0.0) - SM(k, me) * scwt[me - 1]) * smi[k - 1];
+                double wq[nn];                              // W qv
 #pragma unroll
-            for (int k = 0; k < nn; ++k) wq[k] = scwt[k] * qv[k];
+                for (int k = 0; k < nn; ++k) wq[k] = scwt[k] * qv[k];
 #pragma unroll
-            for (int i = 1; i <= nn; ++i) {
-                double acc = qv[i - 1];                  // ((I - S+ W) qv)(i)
+                for (int i = 1; i <= nn; ++i) {
+                    double acc = qv[i - 1];                  // ((I - S+ W) qv)(i)
 #pragma unroll
-                for (int k = 1; k <= nn; ++k) acc = acc - SP(i, k) * wq[k - 1];
-                TM(i, me) = ((i == me) ? scmu[me - 1] / umu0 : 0.0) - umu0 * acc;
+                    for (int k = 1; k <= nn; ++k) acc = acc - SP(i, k) * wq[k - 1];
+                    TM(i, me) = ((i == me) ? scmu[me - 1] / umu0 : 0.0) - umu0 * acc;
+                }
             }
-            double s0 = 0.0, s1 = 0.0;                   // over even k, over odd k (k >= m by the mask)
-#pragma unroll
-            for (int k = 0; k < n; k += 2) {
-                s0 = s0 + ((k >= mazim) ? gl[k] * YS(k, me) : 0.0) * ylm0[k];
-                s1 = s1 + ((k + 1 >= mazim) ? gl[k + 1] * YS(k + 1, me) : 0.0) * ylm0[k + 1];
-            }
-            const bool mpar = (mazim & 1) != 0;
-            const double se = mpar ? s1 : s0, so = mpar ? s0 : s1;
-            const double c = (2.0 - delm0) * fbeam / (4.0 * P.pi);
-            rs = 2.0 * c * se;
-            rdv = 2.0 * c * so;
         }
         wave_lds_sync();
         // q = (r+ + r-) - mu0 (I - S+ W) M^-1 (r+ - r-);  T d = q;  s = mu0 M^-1 ((r+ - r-) - (I - S- W) d)
         const double cmu_me = (me <= nn) ? scmu[me - 1] : 1.0;
         double dv = rs - umu0 * apply_ImSW(sp, rdv / cmu_me);
-        if (lu_factor_group<G>(lu, ldq, nn, ipvt, g) != 0) status |= 0x02;
-        dv = lu_solve_group<G>(lu, ldq, nn, ipvt, dv, g);
+        if (by_vectors) {
+            const double rme = (me <= nn) ? srr[me - 1] : 0.0, rw = (me <= nn) ? srr[me - 1] * swi[me - 1] : 0.0;
+            const double d3 = project(cb, rme * dv);
+            dv = rw * combine(yv, d3 / (lam * (1.0 / umu0 - umu0 * lam)));
+        } else {
+            if (lu_factor_group<G>(lu, ldq, nn, ipvt, g) != 0) status |= 0x02;
+            dv = lu_solve_group<G>(lu, ldq, nn, ipvt, dv, g);
+        }
         const double sv_ = umu0 * (rdv - apply_ImSW(sm, dv)) / cmu_me;
         const double zpl = 0.5 * (sv_ + dv), zmi = 0.5 * (sv_ - dv);     // Z(+mu_me), Z(-mu_me)
         if (me <= nn) {
@@ -613,7 +738,6 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
             for (int iu = me; iu <= numu; iu += G) zbout[iu - 1] = 0.0;
         }
         if (thermal) {
-            const double xr0 = sv[o.xr0() + lc - 1], xr1 = sv[o.xr1() + lc - 1];
             for (int l = g; l <= n - 1; l += G) {
                 double psum0 = 0.0, psum1 = 0.0;
                 for (int jq = 1; jq <= n; ++jq) {
@@ -640,6 +764,18 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         }
     }
     if (status && g == 0) atomicOr(&P.svi[(size_t)slot * P.svi_stride + SBD_SVI_STATUS], status);
+#ifdef SBD_PHASE_TICKS
+    {
+        const unsigned long long tick7 = __builtin_readcyclecounter();
+        if (lane == 0) {
+            atomicAdd(&layer2_ticks[0], tick1 - tick0); atomicAdd(&layer2_ticks[1], tick2 - tick1);
+            atomicAdd(&layer2_ticks[2], tick3 - tick2); atomicAdd(&layer2_ticks[3], tick4 - tick3);
+            atomicAdd(&layer2_ticks[4], tick5 - tick4); atomicAdd(&layer2_ticks[5], tick6 - tick5);
+            atomicAdd(&layer2_ticks[6], tick7 - tick6); atomicAdd(&layer2_ticks[7], 1ull);
+            atomicAdd(&layer2_ticks[8], (unsigned long long)nsweep);
+        }
+    }
+#endif
 #undef YS
 #undef SP
 #undef SM
