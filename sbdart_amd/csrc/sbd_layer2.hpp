@@ -13,16 +13,16 @@
 //   to the two lanes -- no LDS traffic, no barriers, NSTR/2 lanes busy per matrix.  The converged
 //   column b' = B v gives the eigenvector through C alone (x = (M R)^-1 C^-T b'), see below.
 //
-// When a Cholesky pivot is not positive (non-physical moments) the group raises a flag and
-// the QR kernel of sbd_layer.hpp redoes that layer (same outputs, reference algorithm).
+// When a Cholesky pivot is not positive (non-physical moments) or some k sits next to 1/mu0, the group
+// raises a flag and the QR kernel of sbd_layer.hpp redoes that layer (same outputs, reference algorithm).
 //
 // UPBEAM/UPISOT (disort.f:4130-4353) solve (D - CC) Z = rhs with the same +-mu symmetry taken
 // out: for s = Z+ + Z-, d = Z+ - Z- the NSTR x NSTR system splits into
 //     (I - S+ W) s + (M/mu0) d = r+ + r-,     (I - S- W) d + (M/mu0) s = r+ - r-,
-// i.e. ONE NSTR/2 x NSTR/2 pivoted LU of T = M/mu0 - mu0 (I - S+ W) M^-1 (I - S- W) for the
-// beam source; the thermal one (no M/mu0 coupling there) needs I - S+ W and I - S- W, which are
-// R^-1 Q+- R^-1 W: two triangular solve pairs with the Cholesky factors already in LDS.
-// An eighth of the elimination work and a quarter of the LDS of the full system.
+// i.e. one NSTR/2 x NSTR/2 system T d = q, T = M/mu0 - mu0 (I - S+ W) M^-1 (I - S- W), for the beam
+// source; the thermal one (no M/mu0 coupling there) needs (I - S+ W)^-1 and (I - S- W)^-1.  All three
+// inverses are diagonal in the basis of the singular vectors just computed (formulas at the code), so
+// no second factorisation is made: each solve is a projection on the columns and a recombination.
 #pragma once
 #include "sbd_common.hpp"
 #include "sbd_layer.hpp"
@@ -30,19 +30,16 @@
 namespace sbd {
 
 struct Layer2Lds {   // doubles; per-group part + per-block shared part
-    int ld, ldh, ldq, gl, sp, sm, lu, vec, group_total, shared_y, shared_total;
+    int ld, ldq, gl, lu, vec, group_total, shared_y, shared_total;
     __host__ __device__ Layer2Lds(int n, int nn, bool rad)
     {
         ld = n | 1;
-        ldh = nn;                           // S+-: mostly broadcast reads, unpadded
-        ldq = nn | 1;                       // Q+-/L/C and the reduced LU matrix: walked by rows and by columns
+        ldq = nn | 1;                       // Q+-/L/C, later two scratch blocks: walked by rows and by columns
         gl = 0;
-        sp = gl + ((n + 2) & ~1);
-        sm = sp + nn * ldh;
-        lu = sm + nn * ldh;                 // Q+ | Q-, later the reduced UPBEAM/UPISOT matrix
+        lu = gl + ((n + 2) & ~1);           // Q+ | Q-
         vec = lu + 2 * nn * ldq;
-        // ipvt[nn] ints; radiance mode adds zjs, z0s, z1s, psi[2n]
-        group_total = (vec + (nn + 1) / 2 + 2 + (rad ? 5 * n : 0) + 1) & ~1;
+        // radiance mode adds zjs, z0s, z1s, psi[2n]
+        group_total = (vec + (rad ? 5 * n : 0) + 1) & ~1;
         shared_y = 0;                       // Y(l, iq) l-major: [n][nn]
         shared_total = (n * nn + 2 * n + 4 * nn + 1) & ~1;   // + R, 1/(M R), 1/W, 1/M tables
     }
@@ -184,20 +181,15 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 
     double *base = smem + lds.shared_total + (size_t)gi * lds.group_total;
     double *gl = base + lds.gl;
-    double *sp = base + lds.sp, *sm = base + lds.sm;      // S+ , S-   (nn x nn, ld = ldh)
     double *lu = base + lds.lu;
     double *qp = lu, *qm = lu + nn * lds.ldq;             // Q+ -> L , Q- -> C (alias of lu)
-    int *ipvt = (int *)(base + lds.vec);
-    double *vec = base + lds.vec + (nn + 1) / 2 + 2;      // radiance mode only:
+    double *vec = base + lds.vec;                         // radiance mode only:
     double *zjs = vec, *z0s = vec + n, *z1s = vec + 2 * n, *psi = vec + 3 * n;   // psi[2n]
-    constexpr int ldh = NN, ldq = NN | 1, ld = n | 1;
+    constexpr int ldq = NN | 1;
     const size_t lidx = (size_t)ms * L + (lc - 1);
 #define YS(l, iq) shy[(l) * nn + ((iq) - 1)]             // iq in 1..nn ; Y(l,-mu) = (-1)^(l-m) Y(l,mu)
-#define SP(i, j) sp[((j) - 1) * ldh + ((i) - 1)]
-#define SM(i, j) sm[((j) - 1) * ldh + ((i) - 1)]
 #define QP(i, j) qp[((j) - 1) * ldq + ((i) - 1)]
 #define QM(i, j) qm[((j) - 1) * ldq + ((i) - 1)]
-#define TM(i, j) lu[((j) - 1) * ldq + ((i) - 1)]       // reduced UPBEAM/UPISOT matrix (Q+- are dead by then)
 
     SBD_TICK(0)
     // ---- GL(k) (SETDIS, disort.f:2583-2585) ----
@@ -239,8 +231,6 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                 s1 = s1 + YS(l + 1, iq) * yj[l + 1];
             }
             const double se = mpar ? s1 : s0, so = mpar ? s0 : s1;
-            SP(iq, me) = se;
-            SM(iq, me) = so;
             const double ri = srr[iq - 1];
             const double dg = (iq == me) ? swi[me - 1] : 0.0;
             QP(iq, me) = ri * rj * (dg - se);
@@ -423,6 +413,23 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         lam = 0.0;
 #pragma unroll
         for (int i = 0; i < nn; ++i) lam = lam + bcol[i] * bcol[i];
+    }
+    // The particular solutions below come from these singular vectors.  With a beam, a k_j next to 1/mu0 makes
+    // the system UPBEAM solves singular (disort.f:4227): the reference-algorithm kernel redoes such a layer.
+    // (A tiny k_j -- conservative scattering, SSALB dithered to 1 - 2.2e-14, k ~ 2e-7 -- is served here: its
+    //  column b'_j carries the absolute accuracy eps |B| of the rotations, i.e. ~1e-9 relative, in the
+    //  eigenvector as in the particular solution; the reference's own k for that mode is good to ~1e-3.)
+    const double umu0 = P.umu0;
+    {
+        const double gap = fabs(1.0 - umu0 * umu0 * lam);
+        const bool bad = (me <= nn) && (!(lam > 0.0) || (fbeam > 0.0 && !(gap > 1.0e-6)));
+        const unsigned long long gmask = ((G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull)) << ((gi * G) & 63);
+        if ((__ballot(bad) & gmask) != 0ull) {
+            if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;
+            return;
+        }
+    }
+    if (me <= nn) {
         kq = sqrt(fabs(lam));
         const double rkq = 1.0 / kq;
         double rc[nn];
@@ -538,121 +545,64 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         }
     }
 
-    // ---- UPBEAM / UPISOT on the +-mu-reduced systems (see the header): lane i <-> mu_i ----
+    // ---- UPBEAM / UPISOT on the +-mu-reduced systems (see the header), from the singular vectors at hand.
+    //      With Y = [y_j] (y_j = L v_j), CB' = [C b'_j] = Q- Y and K = diag(k_j):
+    //        Y Y^T = Q+,   Y^T (CB') = K^2,   Q+^-1 = (CB') K^-4 (CB')^T,   Q- = (CB') K^-2 (CB')^T,
+    //        I - S+ W = R^-1 Q+ R^-1 W,   I - S- W = R^-1 Q- R^-1 W,   M = R^-2 W,
+    //        T = R^-1 (I/mu0 - mu0 Q+ Q-) R^-1 W,   Q+ Q- = Y K^2 Y^-1,   Y^-1 = K^-2 (CB')^T.
+    //      Every solve is a projection on the columns (lane j <-> column j) and a recombination -- two LDS
+    //      round trips -- instead of NSTR/2 dependent elimination steps; S+ and S- themselves are not kept. ----
     auto ylmc_full = [&](int l, int iq) -> double {   // YLMC(l, iq) including the mirrored half
         if (iq <= nn) return YS(l, iq);
         return ((((l - mazim) & 1) == 0) ? 1.0 : -1.0) * YS(l, iq - nn);
     };
-    // y = A x for A = I - S W (S = S+ or S-), x spread over the lanes (lane k holds x_k)
-    auto apply_ImSW = [&](const double *smat, double xv) -> double {
-        const double wxv = (me <= nn) ? scwt[me - 1] * xv : 0.0;     // (W x)(me)
-        double acc = xv;
-        if constexpr (G == nn && (nn & (nn - 1)) == 0) {
-            // every lane of the group owns a row: partner k = (me-1) ^ s on the DPP network (S symmetric)
-            acc = acc - smat[(me - 1) * ldh + (me - 1)] * wxv;
-            static_for<nn - 1>([&](auto ss) {
-                constexpr int sx = decltype(ss)::value + 1;
-                const int k0 = (me - 1) ^ sx;
-                acc = acc - smat[k0 * ldh + (me - 1)] * lane_xor<sx>(wxv);
-            });
-        } else {
+    double *scra = lu, *scrb = lu + nn * ldq;            // L and C are dead from here on
+    // (sum_j y_j[i] t_j, sum_j cb_j[i] t_j) delivered to lane i
+    auto combine2 = [&](const double tj, double &ry, double &rc_) {
+        if (me <= nn) {
 #pragma unroll
-            for (int k = 1; k <= nn; ++k) {
-                const double wk = __shfl(wxv, k - 1, G);
-                if (me <= nn) acc = acc - smat[(k - 1) * ldh + (me - 1)] * wk;
+            for (int i = 0; i < nn; ++i) {
+                scra[i * ldq + (me - 1)] = yv[i] * tj;
+                scrb[i * ldq + (me - 1)] = cb[i] * tj;
             }
         }
-        return acc;
-    };
-    // ---- UPISOT (disort.f:4309-4349) from the Cholesky factors at hand: with Q+ = L L^T,
-    //      I - S+ W = R^-1 Q+ R^-1 W, so (I - S+ W) u = b is L L^T y = R b, u = W^-1 R y (no second
-    //      factorisation, no pivoting: Q+- are positive definite here), likewise I - S- W with C.
-    //      Runs before UPBEAM, whose reduced matrix takes over the LDS of L and C. ----
-    auto chol_solve = [&](const double *fac, double bv) -> double {   // (F F^T) y = b, lane i <-> row i
+        wave_lds_sync();
+        ry = 0.0; rc_ = 0.0;
+        if (me <= nn) {
 #pragma unroll
-        for (int k = 1; k <= nn; ++k) {
-            const double yk = __shfl(bv, k - 1, G) * rcp_nr(fac[(k - 1) * ldq + (k - 1)]);
-            if (me == k) bv = yk;
-            else if (me > k && me <= nn) bv = bv - fac[(k - 1) * ldq + (me - 1)] * yk;      // F(me, k)
+            for (int m = 0; m < nn; ++m) {
+                ry = ry + scra[(me - 1) * ldq + m];
+                rc_ = rc_ + scrb[(me - 1) * ldq + m];
+            }
         }
-#pragma unroll
-        for (int k = nn; k >= 1; --k) {
-            const double yk = __shfl(bv, k - 1, G) * rcp_nr(fac[(k - 1) * ldq + (k - 1)]);
-            if (me == k) bv = yk;
-            else if (me < k) bv = bv - fac[(me - 1) * ldq + (k - 1)] * yk;                   // F(k, me)
-        }
-        return bv;
+        wave_lds_sync();
     };
     const bool thermal = plank && mazim == 0;
     int status = 0;
-    // ---- the same solves from the singular vectors at hand.  With Y = [y_j] (y_j = L v_j) and K = diag(k_j):
-    //        Y Y^T = Q+,  Y^T Q- Y = K^2   =>   Q+^-1 = (C B') K^-4 (C B')^T,   Q-^-1 = Y K^-2 Y^T,
-    //        Q+ Q- = Y K^2 Y^-1,  Y^-1 = K^-2 (C B')^T,
-    //      and with M = R^-2 W:  T = R^-1 (I/mu0 - mu0 Q+ Q-) R^-1 W, so
-    //        T^-1 q = W^-1 R  sum_j y_j (cb_j . R q) / (k_j^2 (1/mu0 - mu0 k_j^2)).
-    //      Every solve is a projection on the columns (lane j <-> column j) and a recombination, two LDS
-    //      round trips each, instead of NSTR/2 dependent elimination steps.  Taken when no k_j is so small
-    //      that b'_j (absolute accuracy eps |B|) has lost its relative accuracy, and -- for the beam -- no
-    //      k_j sits next to 1/mu0; otherwise the factorisations below do the work. ----
-    double *scr = lu;                                    // [nn][ldq] products, then nn doubles of a spread vector
-    double *spread = lu + nn * ldq;                      // (L and C are dead on this path)
-    auto project = [&](const double (&a)[nn], const double vi) -> double {    // sum_i a_j[i] v_i, v over the lanes
-        if (me <= nn) spread[me - 1] = vi;
-        wave_lds_sync();
-        double d = 0.0;
-#pragma unroll
-        for (int i = 0; i < nn; ++i) d = d + a[i] * spread[i];
-        return d;
-    };
-    auto combine = [&](const double (&a)[nn], const double tj) -> double {    // sum_j a_j[i] t_j, to lane i
-        if (me <= nn) {
-#pragma unroll
-            for (int i = 0; i < nn; ++i) scr[i * ldq + (me - 1)] = a[i] * tj;
-        }
-        wave_lds_sync();
-        double r = 0.0;
-        if (me <= nn) {
-#pragma unroll
-            for (int m = 0; m < nn; ++m) r = r + scr[(me - 1) * ldq + m];
-        }
-        wave_lds_sync();
-        return r;
-    };
-    const double umu0 = P.umu0;
-    bool by_vectors;
-    {
-        const double gap = fabs(1.0 - umu0 * umu0 * lam);
-        const bool bad = (me <= nn) && (!(lam > 1.0e-8) || (fbeam > 0.0 && !(gap > 1.0e-6)));
-        const unsigned long long gmask = ((G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull)) << ((gi * G) & 63);
-        by_vectors = (__ballot(bad) & gmask) == 0ull;
-    }
     // errmsg 4 (UPISOT's SGECO, disort.f:4333): the Cholesky pivots of Q+ and Q- (squares of the factors'
     // diagonals, still in LDS) stand in for the condition estimate, see near_singular() in sbd_layer.hpp
     if (thermal) {
         const double dl = (me <= nn) ? QP(me, me) : 0.0, dc = (me <= nn) ? QM(me, me) : 0.0;
         if (near_singular<G>((me <= nn) ? dl * dl : -1.0, nn) || near_singular<G>((me <= nn) ? dc * dc : -1.0, nn)) status |= 0x04;
+        wave_lds_sync();                                 // (the pivots were read from the area that now turns scratch)
     }
+    const double rme = (me <= nn) ? srr[me - 1] : 1.0, rw = (me <= nn) ? srr[me - 1] * swi[me - 1] : 0.0;
+    const double cmu_me = (me <= nn) ? scmu[me - 1] : 1.0;
+    const double rk2 = 1.0 / lam;
     if (thermal) {
-        // (I - CC) Z1 = (1-w') XR1 (the same in both halves): Z1+- = (1-w') XR1 u, (I - S+ W) u = 1;
-        // (I - CC) Z0 = (1-w') XR0 + CMU Z1: Z0+- = (1-w') XR0 u +- e, (I - S- W) e = mu Z1
-        const double rme = (me <= nn) ? srr[me - 1] : 0.0, rw = (me <= nn) ? srr[me - 1] * swi[me - 1] : 0.0;
-        const double cmu_me = (me <= nn) ? scmu[me - 1] : 0.0;
-        double u, e, z1;
-        if (by_vectors) {
-            wave_lds_sync();                             // (the pivots above were read from the area that now turns scratch)
-            const double rk2 = 1.0 / lam;
-            double d1 = 0.0;                             // (C b')_j . (R 1)
+        // UPISOT (disort.f:4309-4349).  (I - CC) Z1 = (1-w') XR1 (the same in both halves): Z1+- = (1-w') XR1 u,
+        // (I - S+ W) u = 1;  (I - CC) Z0 = (1-w') XR0 + CMU Z1: Z0+- = (1-w') XR0 u +- e, (I - S- W) e = mu Z1.
+        //   u = W^-1 R Q+^-1 (R 1) = W^-1 R sum_j cb_j t_j,  t_j = (cb_j . R 1) / k_j^4
+        //   e = W^-1 R Q-^-1 (R M Z1); R M Z1 = (1-w') XR1 R M W^-1 R Q+^-1 (R 1) = (1-w') XR1 Q+^-1 (R 1)  (R^2 M = W), and
+        //   Q-^-1 = Y K^-2 Y^T, Y^T (CB') = K^2:   e = (1-w') XR1 W^-1 R sum_j y_j t_j   -- the same coefficients
+        double d1 = 0.0;
 #pragma unroll
-            for (int i = 0; i < nn; ++i) d1 = d1 + cb[i] * srr[i];
-            u = rw * combine(cb, d1 * rk2 * rk2);
-            z1 = (1.0 - oprim) * xr1 * u;
-            const double d2 = project(yv, rme * cmu_me * z1);
-            e = rw * combine(yv, d2 * rk2);
-        } else {
-            u = rw * chol_solve(qp, rme);
-            z1 = (1.0 - oprim) * xr1 * u;
-            e = rw * chol_solve(qm, rme * cmu_me * z1);
-        }
+        for (int i = 0; i < nn; ++i) d1 = d1 + cb[i] * srr[i];
+        double vy, vc;
+        combine2(d1 * rk2 * rk2, vy, vc);
+        const double u = rw * vc;
+        const double z1 = (1.0 - oprim) * xr1 * u;
+        const double e = (1.0 - oprim) * xr1 * rw * vy;
         const double z0p = (1.0 - oprim) * xr0 * u + e, z0m = (1.0 - oprim) * xr0 * u - e;
         if (me <= nn) {
             double *p0 = P.zp0 + lidx * n, *p1 = P.zp1 + lidx * n;
@@ -660,7 +610,6 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
             p0[nn - me] = z0m;     p1[nn - me] = z1;
             if constexpr (rad) { z0s[me - 1] = z0p; z0s[me + nn - 1] = z0m; z1s[me - 1] = z1; z1s[me + nn - 1] = z1; }
         }
-        wave_lds_sync();
     } else if (mazim == 0 && me <= nn) {
         P.zp0[lidx * n + me - 1] = 0.0; P.zp0[lidx * n + me + nn - 1] = 0.0;
         P.zp1[lidx * n + me - 1] = 0.0; P.zp1[lidx * n + me + nn - 1] = 0.0;
@@ -668,38 +617,29 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 
     SBD_TICK(6)
     if (fbeam > 0.0) {
+        // UPBEAM (disort.f:4130-4244) for s = Z+ + Z-, d = Z+ - Z-:
+        //   q = (r+ + r-) - mu0 (I - S+ W) M^-1 (r+ - r-);  T d = q;  s = mu0 M^-1 ((r+ - r-) - (I - S- W) d).
+        // With p = R^-1 W M^-1 (r+ - r-) and a = R (r+ + r-):  (CB')^T R q = (CB')^T a - mu0 K^2 Y^T p, so
+        //   c_j = (cb_j . a - mu0 k_j^2 y_j . p) / (k_j^2 (1/mu0 - mu0 k_j^2)),
+        //   d = W^-1 R sum_j y_j c_j,   (I - S- W) d = R^-1 (CB') K^-2 (CB')^T Y c = R^-1 sum_j cb_j c_j.
+        double *spa = scra, *spp = scra + nn;            // the two spread vectors, read before the products land
         if (me <= nn) {
-            if (!by_vectors) {
-                // column me of T = M/mu0 - mu0 (I - S+ W) M^-1 (I - S- W)
-                double qv[nn];
-#pragma unroll
-                for (int k = 1; k <= nn; ++k)
-                    qv[k - 1] = (((k == me) ? 1.0 : 0.0) - SM(k, me) * scwt[me - 1]) * smi[k - 1];
-                double wq[nn];                              // W qv
-#pragma unroll
-                for (int k = 0; k < nn; ++k) wq[k] = scwt[k] * qv[k];
-#pragma unroll
-                for (int i = 1; i <= nn; ++i) {
-                    double acc = qv[i - 1];                  // ((I - S+ W) qv)(i)
-#pragma unroll
-                    for (int k = 1; k <= nn; ++k) acc = acc - SP(i, k) * wq[k - 1];
-                    TM(i, me) = ((i == me) ? scmu[me - 1] / umu0 : 0.0) - umu0 * acc;
-                }
-            }
+            spa[me - 1] = rme * rs;
+            spp[me - 1] = (scwt[me - 1] / rme) * (rdv / cmu_me);
         }
         wave_lds_sync();
-        // q = (r+ + r-) - mu0 (I - S+ W) M^-1 (r+ - r-);  T d = q;  s = mu0 M^-1 ((r+ - r-) - (I - S- W) d)
-        const double cmu_me = (me <= nn) ? scmu[me - 1] : 1.0;
-        double dv = rs - umu0 * apply_ImSW(sp, rdv / cmu_me);
-        if (by_vectors) {
-            const double rme = (me <= nn) ? srr[me - 1] : 0.0, rw = (me <= nn) ? srr[me - 1] * swi[me - 1] : 0.0;
-            const double d3 = project(cb, rme * dv);
-            dv = rw * combine(yv, d3 / (lam * (1.0 / umu0 - umu0 * lam)));
-        } else {
-            if (lu_factor_group<G>(lu, ldq, nn, ipvt, g) != 0) status |= 0x02;
-            dv = lu_solve_group<G>(lu, ldq, nn, ipvt, dv, g);
+        double pa = 0.0, pp = 0.0;
+#pragma unroll
+        for (int i = 0; i < nn; ++i) {
+            pa = pa + cb[i] * spa[i];
+            pp = pp + yv[i] * spp[i];
         }
-        const double sv_ = umu0 * (rdv - apply_ImSW(sm, dv)) / cmu_me;
+        wave_lds_sync();
+        const double cj = (pa - umu0 * lam * pp) / (lam * (1.0 / umu0 - umu0 * lam));
+        double vy, vc;
+        combine2(cj, vy, vc);
+        const double dv = rw * vy;
+        const double sv_ = umu0 * (rdv - vc / rme) / cmu_me;
         const double zpl = 0.5 * (sv_ + dv), zmi = 0.5 * (sv_ - dv);     // Z(+mu_me), Z(-mu_me)
         if (me <= nn) {
             double *zzout = P.zz + lidx * n;
@@ -777,11 +717,8 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     }
 #endif
 #undef YS
-#undef SP
-#undef SM
 #undef QP
 #undef QM
-#undef TM
 }
 
 }  // namespace sbd
