@@ -29,10 +29,14 @@ void launch_layer2(int nn, bool rad, unsigned grid, int lds, hipStream_t st, con
 #ifdef SBD_PHASE_TICKS
 extern "C" int sbd_debug_layer2_ticks(unsigned long long *out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sbd::layer2_ticks), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    static unsigned long long h[1024 * 16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(sbd::layer2_ticks), sizeof h) != hipSuccess) return 1;
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+    for (int b = 0; b < 1024; ++b)
+        for (int i = 0; i < 16; ++i) out[i] += h[b * 16 + i];
     if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(sbd::layer2_ticks), z, sizeof z) != hipSuccess) return 1;
+        for (auto &x : h) x = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(sbd::layer2_ticks), h, sizeof h) != hipSuccess) return 1;
     }
     return 0;
 }

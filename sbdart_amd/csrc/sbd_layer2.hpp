@@ -52,6 +52,17 @@ SBD_DEVICE double rsqrt_nr(double x)
     y = y * (1.5 - 0.5 * x * y * y);
     return y * (1.5 - 0.5 * x * y * y);
 }
+// ... and with one Newton step: where only the speed of convergence depends on the value (a Jacobi angle)
+SBD_DEVICE double rsqrt_n1(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    return y * (1.5 - 0.5 * x * y * y);
+}
+SBD_DEVICE double rcp_n1(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return r * (2.0 - x * r);
+}
 SBD_DEVICE double rcp_nr(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
@@ -82,11 +93,46 @@ SBD_DEVICE double lane_xor(double x)
 }
 
 #ifdef SBD_PHASE_TICKS   // developer build: shader-clock ticks per phase, summed over waves (tools/layer_phases.py)
-static __device__ unsigned long long layer2_ticks[16];
-#define SBD_TICK(i) const unsigned long long tick##i = __builtin_readcyclecounter();
+static __device__ unsigned long long layer2_ticks[1024 * 16];   // [block % 1024][counter]: spread, or the atomics are the kernel
+#define SBD_TICK(i) tick##i = __builtin_readcyclecounter();
 #else
 #define SBD_TICK(i)
 #endif
+
+// acc + m(lane K of the 16-lane row) * t: the DP-ALU DPP form of the FMA, lanes outside BANKS (one bit per
+// four lanes of the row) keep acc
+template <int K, int BANKS = 0xF>
+SBD_DEVICE double row_fmac(double acc, double m, double t)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:%4"
+                 : "+v"(acc) : "v"(m), "v"(t), "n"(K), "n"(BANKS));
+    return acc;
+}
+// acc + m(lane K of this lane's GROUP of G lanes) * t, G = 8 or 16: a row of 16 lanes holds 16 / G groups
+template <int K, int G>
+SBD_DEVICE double group_fmac(double acc, double m, double t)
+{
+    static_assert(G == 8 || G == 16, "group_fmac: 8 or 16 lanes per group");
+    if constexpr (G == 16) return row_fmac<K>(acc, m, t);
+    else return row_fmac<K + 8, 0xC>(row_fmac<K, 0x3>(acc, m, t), m, t);
+}
+// x of lane K of this lane's group
+template <int K, int G>
+SBD_DEVICE double group_bcast(double x)
+{
+    static_assert(G == 8 || G == 16, "group_bcast: 8 or 16 lanes per group");
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    if constexpr (G == 16) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xF, 0xF, false);
+    } else {
+        const int l0 = __builtin_amdgcn_update_dpp(0, lo, 0x150 + K, 0xF, 0x3, false);
+        const int h0 = __builtin_amdgcn_update_dpp(0, hi, 0x150 + K, 0xF, 0x3, false);
+        lo = __builtin_amdgcn_update_dpp(l0, lo, 0x150 + K + 8, 0xF, 0xC, false);
+        hi = __builtin_amdgcn_update_dpp(h0, hi, 0x150 + K + 8, 0xF, 0xC, false);
+    }
+    return __hiloint2double(hi, lo);
+}
 
 template <int NN, int G, bool RAD>
 __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
@@ -191,6 +237,9 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 #define QP(i, j) qp[((j) - 1) * ldq + ((i) - 1)]
 #define QM(i, j) qm[((j) - 1) * ldq + ((i) - 1)]
 
+#ifdef SBD_PHASE_TICKS
+    unsigned long long tick0 = 0, tick1 = 0, tick2 = 0, tick3 = 0, tick4 = 0, tick5 = 0, tick6 = 0;
+#endif
     SBD_TICK(0)
     // ---- GL(k) (SETDIS, disort.f:2583-2585) ----
 #pragma unroll
@@ -216,15 +265,23 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         rdv = 2.0 * c * so;
     }
 
-    // ---- S+ / S- (even / odd l-m parts), lane j <-> column j; then Q+-, all symmetric ----
-    if (me <= nn) {
-        double yj[n];   // GL(l) * Y(l, mu_j): the j-dependent factor of every term
+    // ---- S+ / S- (even / odd l-m parts), then Q+-, all symmetric; two Cholesky factorisations side by
+    //      side, lower factors, lane i <-> row i ----
+    bool spd = true;
+    double rp[nn], rm[nn];
+    if constexpr (G == 8 || G == 16) {
+        // Lane j forms column j = row j of S+- (symmetric); the row stays in registers for the factorisation,
+        // whose column k travels by DPP inside the group.  L and C go to LDS once, at the end.
+        // (The Ylm table is read from LDS, not from the neighbours' registers: a DPP source lane whose group
+        //  has left the kernel -- a layer below the LYRCUT level -- delivers nothing.)
+        double yj[n];
 #pragma unroll
-        for (int l = 0; l < n; ++l) yj[l] = (l >= mazim) ? gl[l] * YS(l, me) : 0.0;   // the sums start at l = m
-        const double rj = srr[me - 1];
+        for (int l = 0; l < n; ++l) yj[l] = (l >= mazim && me <= nn) ? gl[l] * YS(l, me) : 0.0;   // the sums start at l = m
+        const double rj = (me <= nn) ? srr[me - 1] : 0.0;
         const bool mpar = (mazim & 1) != 0;              // l - m even <=> l has m's parity
-        for (int iq = 1; iq <= nn; ++iq) {
-            double s0 = 0.0, s1 = 0.0;                   // over even l, over odd l: plain FMAs
+        static_for<nn>([&](auto qq) {
+            constexpr int iq = decltype(qq)::value + 1;
+            double s0 = 0.0, s1 = 0.0;                   // over even l, over odd l
 #pragma unroll
             for (int l = 0; l < n; l += 2) {
                 s0 = s0 + YS(l, iq) * yj[l];
@@ -232,41 +289,80 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
             }
             const double se = mpar ? s1 : s0, so = mpar ? s0 : s1;
             const double ri = srr[iq - 1];
-            const double dg = (iq == me) ? swi[me - 1] : 0.0;
-            QP(iq, me) = ri * rj * (dg - se);
-            QM(iq, me) = ri * rj * (dg - so);
+            const double dg = (iq == me) ? swi[iq - 1] : 0.0;
+            const bool low = iq <= me && me <= nn;
+            rp[iq - 1] = low ? ri * rj * (dg - se) : 0.0;
+            rm[iq - 1] = low ? ri * rj * (dg - so) : 0.0;
+        });
+        SBD_TICK(1)
+        static_for<nn>([&](auto kk_) {
+            constexpr int k = decltype(kk_)::value + 1;
+            // pivots of step k: lane k's diagonal, to the whole group
+            const double dp = group_bcast<k - 1, G>(rp[k - 1]), dm = group_bcast<k - 1, G>(rm[k - 1]);
+            if (!(dp > 0.0) || !(dm > 0.0)) spd = false;
+            const double rdp = rsqrt_nr(dp), rdm = rsqrt_nr(dm);      // 1/sqrt(pivot): the factors are an ulp or two off
+            if (me == k) { rp[k - 1] = dp * rdp; rm[k - 1] = dm * rdm; }
+            else if (me > k) { rp[k - 1] = rp[k - 1] * rdp; rm[k - 1] = rm[k - 1] * rdm; }
+            // row me, column j > k: minus L(me,k) L(j,k), L(j,k) = lane j's entry k (the lanes above row j
+            // compute on their unused upper part)
+            const double np = -rp[k - 1], nm = -rm[k - 1];
+            static_for<nn - k>([&](auto jj_) {
+                constexpr int j = k + 1 + decltype(jj_)::value;
+                rp[j - 1] = group_fmac<j - 1, G>(rp[j - 1], rp[k - 1], np);
+                rm[j - 1] = group_fmac<j - 1, G>(rm[j - 1], rm[k - 1], nm);
+            });
+        });
+        if (me <= nn) {
+#pragma unroll
+            for (int k = 1; k <= nn; ++k)
+                if (k <= me) { QP(me, k) = rp[k - 1]; QM(me, k) = rm[k - 1]; }
         }
-    }
-    wave_lds_sync();
-
-    SBD_TICK(1)
-    // ---- two Cholesky factorisations side by side (lane i <-> row i), lower factors ----
-    // (row me of both matrices lives in registers while it is being eliminated: the lower triangle
-    //  is read once, every column k crosses LDS once for the rows below it, L and C are written at the end)
-    bool spd = true;
-    double rp[nn], rm[nn];
+    } else {
+        if (me <= nn) {
+            double yj[n];   // GL(l) * Y(l, mu_j): the j-dependent factor of every term
 #pragma unroll
-    for (int j = 1; j <= nn; ++j) {
-        rp[j - 1] = (me <= nn && j <= me) ? QP(me, j) : 0.0;
-        rm[j - 1] = (me <= nn && j <= me) ? QM(me, j) : 0.0;
-    }
-    wave_lds_sync();
+            for (int l = 0; l < n; ++l) yj[l] = (l >= mazim) ? gl[l] * YS(l, me) : 0.0;   // the sums start at l = m
+            const double rj = srr[me - 1];
+            const bool mpar = (mazim & 1) != 0;              // l - m even <=> l has m's parity
+            for (int iq = 1; iq <= nn; ++iq) {
+                double s0 = 0.0, s1 = 0.0;                   // over even l, over odd l: plain FMAs
 #pragma unroll
-    for (int k = 1; k <= nn; ++k) {
-        // pivots of step k: lane k's diagonal, to the whole group
-        const double dp = __shfl(rp[k - 1], k - 1, G), dm = __shfl(rm[k - 1], k - 1, G);
-        if (!(dp > 0.0) || !(dm > 0.0)) spd = false;
-        const double rdp = rsqrt_nr(dp), rdm = rsqrt_nr(dm);      // 1/sqrt(pivot): the factors are an ulp or two off
-        if (me == k) { rp[k - 1] = dp * rdp; rm[k - 1] = dm * rdm; }
-        else if (me > k) { rp[k - 1] = rp[k - 1] * rdp; rm[k - 1] = rm[k - 1] * rdm; }
-        // column k of the factors goes through LDS (QP(j,k), QM(j,k), j >= k) for the rows below
-        if (me >= k && me <= nn) { QP(me, k) = rp[k - 1]; QM(me, k) = rm[k - 1]; }
+                for (int l = 0; l < n; l += 2) {
+                    s0 = s0 + YS(l, iq) * yj[l];
+                    s1 = s1 + YS(l + 1, iq) * yj[l + 1];
+                }
+                const double se = mpar ? s1 : s0, so = mpar ? s0 : s1;
+                const double ri = srr[iq - 1];
+                const double dg = (iq == me) ? swi[me - 1] : 0.0;
+                QP(iq, me) = ri * rj * (dg - se);
+                QM(iq, me) = ri * rj * (dg - so);
+            }
+        }
+        wave_lds_sync();
+        SBD_TICK(1)
+        // (row me of both matrices lives in registers while it is being eliminated: the lower triangle
+        //  is read once, every column k crosses LDS once for the rows below it)
+#pragma unroll
+        for (int j = 1; j <= nn; ++j) {
+            rp[j - 1] = (me <= nn && j <= me) ? QP(me, j) : 0.0;
+            rm[j - 1] = (me <= nn && j <= me) ? QM(me, j) : 0.0;
+        }
         wave_lds_sync();
 #pragma unroll
-        for (int j = k + 1; j <= nn; ++j) {
-            if (me >= j) {
-                rp[j - 1] = rp[j - 1] - rp[k - 1] * QP(j, k);
-                rm[j - 1] = rm[j - 1] - rm[k - 1] * QM(j, k);
+        for (int k = 1; k <= nn; ++k) {
+            const double dp = __shfl(rp[k - 1], k - 1, G), dm = __shfl(rm[k - 1], k - 1, G);
+            if (!(dp > 0.0) || !(dm > 0.0)) spd = false;
+            const double rdp = rsqrt_nr(dp), rdm = rsqrt_nr(dm);
+            if (me == k) { rp[k - 1] = dp * rdp; rm[k - 1] = dm * rdm; }
+            else if (me > k) { rp[k - 1] = rp[k - 1] * rdp; rm[k - 1] = rm[k - 1] * rdm; }
+            if (me >= k && me <= nn) { QP(me, k) = rp[k - 1]; QM(me, k) = rm[k - 1]; }
+            wave_lds_sync();
+#pragma unroll
+            for (int j = k + 1; j <= nn; ++j) {
+                if (me >= j) {
+                    rp[j - 1] = rp[j - 1] - rp[k - 1] * QP(j, k);
+                    rm[j - 1] = rm[j - 1] - rm[k - 1] * QM(j, k);
+                }
             }
         }
     }
@@ -324,15 +420,15 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         const unsigned long long gmask = ((G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull)) << ((gi * G) & 63);
         // one meeting of this lane's column with its partner's (both lanes run it, each keeps its own)
         // (only B's columns rotate: the eigenvectors follow from the converged columns and C afterwards)
-        auto meet = [&](const int partner, const bool valid, const double (&ob)[nn]) {
+        // |b_j|^2 of this lane's column, exact at the start of every sweep, carried through the rotations
+        // (alpha' = alpha - t gamma, beta' = beta + t gamma): a meeting costs one inner product, not three
+        double nrm = 0.0;
+        auto meet = [&](const int partner, const bool valid, const double (&ob)[nn], const double bb) {
             if (valid && !done) {
-                double aa = 0.0, bb = 0.0, gg = 0.0;
+                const double aa = nrm;
+                double gg = 0.0;
 #pragma unroll
-                for (int i = 0; i < nn; ++i) {
-                    aa = aa + bcol[i] * bcol[i];
-                    bb = bb + ob[i] * ob[i];
-                    gg = gg + bcol[i] * ob[i];
-                }
+                for (int i = 0; i < nn; ++i) gg = gg + bcol[i] * ob[i];
                 const double ab = aa * bb, g2 = gg * gg;
                 if (g2 > tol * tol * ab) {           // |cos(angle)| > tol
                     rotated = true;
@@ -342,23 +438,28 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                     const double alpha = lo ? aa : bb, beta = lo ? bb : aa;
                     // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (beta - alpha) / (2 gg), written
                     // without zeta: t = sign(d) 2gg / (|d| + sqrt(d^2 + 4 gg^2)); c = (1 + t^2)^-1/2.
-                    // Reciprocal (square roots) from v_rsq/v_rcp + Newton steps: an ulp or two off,
-                    // which a Jacobi rotation does not care about
+                    // t only has to be close (one Newton step on the hardware seeds: the pair comes out
+                    // orthogonal to ~1e-8 of what it was, the next sweep sees to the rest); c and s = c t
+                    // must make a rotation to working precision (two steps)
                     const double d = beta - alpha, tg = 2.0 * gg;
                     const double h2 = d * d + tg * tg;
-                    const double h = h2 * rsqrt_nr(h2);
-                    const double t = ((d >= 0.0) ? tg : -tg) * rcp_nr(fabs(d) + h);
+                    const double h = h2 * rsqrt_n1(h2);
+                    const double t = ((d >= 0.0) ? tg : -tg) * rcp_n1(fabs(d) + h);
                     const double c = rsqrt_nr(1.0 + t * t), sn = c * t;
                     // p' = c p - s q ; q' = s p + c q
                     const double mine = c, other = lo ? -sn : sn;
 #pragma unroll
                     for (int i = 0; i < nn; ++i) bcol[i] = mine * bcol[i] + other * ob[i];
+                    nrm = lo ? aa - t * gg : aa + t * gg;
                 }
             }
         };
         for (int sweep = 0; sweep < 30; ++sweep) {
             rotated = false;
             coarse = false;          // some pair met in this sweep with |cos(angle)| > 3e-7
+            nrm = 0.0;
+#pragma unroll
+            for (int i = 0; i < nn; ++i) nrm = nrm + bcol[i] * bcol[i];
             if constexpr (XORS) {
                 // every pair (j, j ^ s), s = 1..NP-1, meets once per sweep; the exchange is one or two
                 // DPP moves per dword (quad_perm / row_half_mirror / row_mirror), no LDS round trip
@@ -368,7 +469,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                     double ob[nn];
 #pragma unroll
                     for (int i = 0; i < nn; ++i) ob[i] = lane_xor<sx>(bcol[i]);
-                    meet(partner, (j < nn) && (partner < nn), ob);
+                    meet(partner, (j < nn) && (partner < nn), ob, lane_xor<sx>(nrm));
                 });
             } else {
                 for (int s = 0; s < NP - 1; ++s) {
@@ -380,7 +481,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
                     double ob[nn];
 #pragma unroll
                     for (int i = 0; i < nn; ++i) ob[i] = __shfl(bcol[i], src, G);
-                    meet(partner, (j < nn) && (partner < nn) && (j < NP), ob);
+                    meet(partner, (j < nn) && (partner < nn) && (j < NP), ob, __shfl(nrm, src, G));
                 }
             }
             // quadratic convergence: a sweep that started below 3e-7 ends below 1e-13 (eigenvalues to
@@ -708,11 +809,12 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     {
         const unsigned long long tick7 = __builtin_readcyclecounter();
         if (lane == 0) {
-            atomicAdd(&layer2_ticks[0], tick1 - tick0); atomicAdd(&layer2_ticks[1], tick2 - tick1);
-            atomicAdd(&layer2_ticks[2], tick3 - tick2); atomicAdd(&layer2_ticks[3], tick4 - tick3);
-            atomicAdd(&layer2_ticks[4], tick5 - tick4); atomicAdd(&layer2_ticks[5], tick6 - tick5);
-            atomicAdd(&layer2_ticks[6], tick7 - tick6); atomicAdd(&layer2_ticks[7], 1ull);
-            atomicAdd(&layer2_ticks[8], (unsigned long long)nsweep);
+            unsigned long long *tk = layer2_ticks + (blockIdx.x & 1023u) * 16;
+            atomicAdd(&tk[0], tick1 - tick0); atomicAdd(&tk[1], tick2 - tick1);
+            atomicAdd(&tk[2], tick3 - tick2); atomicAdd(&tk[3], tick4 - tick3);
+            atomicAdd(&tk[4], tick5 - tick4); atomicAdd(&tk[5], tick6 - tick5);
+            atomicAdd(&tk[6], tick7 - tick6); atomicAdd(&tk[7], 1ull);
+            atomicAdd(&tk[8], (unsigned long long)nsweep);
         }
     }
 #endif
