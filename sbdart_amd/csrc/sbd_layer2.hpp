@@ -34,10 +34,12 @@ struct Layer2Lds {   // doubles; per-group part + per-block shared part
     __host__ __device__ Layer2Lds(int n, int nn, bool rad)
     {
         ld = n | 1;
-        ldq = nn | 1;                       // Q+-/L/C, later two scratch blocks: walked by rows and by columns
+        ldq = nn | 1;                       // Q+-/L/C, later a scratch block: walked by rows and by columns
         gl = 0;
-        lu = gl + ((n + 2) & ~1);           // Q+ | Q-
-        vec = lu + 2 * nn * ldq;
+        lu = gl + ((n + 2) & ~1);
+        // groups of 8 or 16 lanes (nn > 4) keep L in the lower triangle of ONE block, C transposed in its upper
+        // triangle and C's diagonal behind it; the groups of 4 keep Q+ | Q- side by side
+        vec = lu + ((nn > 4) ? nn * ldq + nn : 2 * nn * ldq);
         // radiance mode adds zjs, z0s, z1s, psi[2n]
         group_total = (vec + (rad ? 5 * n : 0) + 1) & ~1;
         shared_y = 0;                       // Y(l, iq) l-major: [n][nn]
@@ -228,14 +230,19 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     double *base = smem + lds.shared_total + (size_t)gi * lds.group_total;
     double *gl = base + lds.gl;
     double *lu = base + lds.lu;
-    double *qp = lu, *qm = lu + nn * lds.ldq;             // Q+ -> L , Q- -> C (alias of lu)
+    constexpr bool PACKED = (G == 8 || G == 16);          // (see Layer2Lds)
+    double *qp = lu, *qm = lu + nn * lds.ldq;             // Q+ -> L , Q- -> C; packed: qm = C's diagonal
     double *vec = base + lds.vec;                         // radiance mode only:
     double *zjs = vec, *z0s = vec + n, *z1s = vec + 2 * n, *psi = vec + 3 * n;   // psi[2n]
     constexpr int ldq = NN | 1;
     const size_t lidx = (size_t)ms * L + (lc - 1);
 #define YS(l, iq) shy[(l) * nn + ((iq) - 1)]             // iq in 1..nn ; Y(l,-mu) = (-1)^(l-m) Y(l,mu)
 #define QP(i, j) qp[((j) - 1) * ldq + ((i) - 1)]
-#define QM(i, j) qm[((j) - 1) * ldq + ((i) - 1)]
+    auto qm_at = [&](const int i, const int j) -> double & {   // C(i, j), i >= j
+        if constexpr (PACKED) return (i == j) ? qm[i - 1] : lu[(i - 1) * ldq + (j - 1)];
+        else return qm[(j - 1) * ldq + (i - 1)];
+    };
+#define QM(i, j) qm_at((i), (j))
 
 #ifdef SBD_PHASE_TICKS
     unsigned long long tick0 = 0, tick1 = 0, tick2 = 0, tick3 = 0, tick4 = 0, tick5 = 0, tick6 = 0;
@@ -506,7 +513,8 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
     //   (G+)+(G-) = -(M R)^-1 (C b') / k                  one product with C.
     // C is in LDS since the factorisation; nothing but B's columns went through the rotations.
     double kq = 0.0, lam = 1.0;
-    double gp[nn], xcol[nn];
+    double gp[rad ? nn : 1], xcol[rad ? nn : 1];         // radiance mode (TERPEV) walks them many times
+    double rkq_me = 0.0;
     double yv[nn], cb[nn];                               // y = L v and C b' = Q- y: UPISOT / UPBEAM below reuse them
 #pragma unroll
     for (int i = 0; i < nn; ++i) { yv[i] = 0.0; cb[i] = 0.0; }
@@ -549,10 +557,13 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
 #pragma unroll
             for (int k = 1; k <= i; ++k) s = s + QM(i, k) * bcol[k - 1];
             cb[i - 1] = s;
-            gp[i - 1] = -(s * sxi[i - 1]) * rkq;
+            if constexpr (rad) gp[i - 1] = -(s * sxi[i - 1]) * rkq;
         }
+        if constexpr (rad) {
 #pragma unroll
-        for (int i = 0; i < nn; ++i) xcol[i] = yv[i] * sxi[i];
+            for (int i = 0; i < nn; ++i) xcol[i] = yv[i] * sxi[i];
+        }
+        rkq_me = rkq;
         double *kkout = P.kk + lidx * n;
         double *ekout = P.ek + lidx * nn;
         kkout[me + nn - 1] = kq;
@@ -575,7 +586,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
             double *cc0 = P.gcc + lidx * 2 * nn * nn + (me - 1), *cc1 = cc0 + nn * nn;
 #pragma unroll
             for (int iq = 1; iq <= nn; ++iq) {
-                const double gpp = gp[iq - 1], gmm = xcol[iq - 1];
+                const double gpp = -(cb[iq - 1] * sxi[iq - 1]) * rkq_me, gmm = yv[iq - 1] * sxi[iq - 1];
                 const double vua = 0.5 * (gpp + gmm), vda = 0.5 * (gpp - gmm);   // rows iq+nn, nn+1-iq of column ja
                 cc0[(iq - 1) * nn] = vua;
                 cc1[(iq - 1) * nn] = vda;
@@ -589,7 +600,7 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
             double *gaout = P.ga + lidx * n * n, *gbout = P.gb + lidx * n * n;
 #pragma unroll
             for (int iq = 1; iq <= nn; ++iq) {
-                const double gpp = gp[iq - 1], gmm = xcol[iq - 1];
+                const double gpp = -(cb[iq - 1] * sxi[iq - 1]) * rkq_me, gmm = yv[iq - 1] * sxi[iq - 1];
                 const double vua = 0.5 * (gpp + gmm), vda = 0.5 * (gpp - gmm);   // rows iq+nn, nn+1-iq of column ja
                 const int ru = (iq + nn - 1) * n, rd = (nn - iq) * n;
                 gaout[ru + ja] = vua * ekv;  gbout[ru + ja] = -vua;
@@ -657,26 +668,25 @@ __global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
         if (iq <= nn) return YS(l, iq);
         return ((((l - mazim) & 1) == 0) ? 1.0 : -1.0) * YS(l, iq - nn);
     };
-    double *scra = lu, *scrb = lu + nn * ldq;            // L and C are dead from here on
+    double *scra = lu;                                   // L and C are dead from here on
     // (sum_j y_j[i] t_j, sum_j cb_j[i] t_j) delivered to lane i
+    auto combine1 = [&](const double (&a)[nn], const double tj) -> double {
+        if (me <= nn) {
+#pragma unroll
+            for (int i = 0; i < nn; ++i) scra[i * ldq + (me - 1)] = a[i] * tj;
+        }
+        wave_lds_sync();
+        double r = 0.0;
+        if (me <= nn) {
+#pragma unroll
+            for (int m = 0; m < nn; ++m) r = r + scra[(me - 1) * ldq + m];
+        }
+        wave_lds_sync();
+        return r;
+    };
     auto combine2 = [&](const double tj, double &ry, double &rc_) {
-        if (me <= nn) {
-#pragma unroll
-            for (int i = 0; i < nn; ++i) {
-                scra[i * ldq + (me - 1)] = yv[i] * tj;
-                scrb[i * ldq + (me - 1)] = cb[i] * tj;
-            }
-        }
-        wave_lds_sync();
-        ry = 0.0; rc_ = 0.0;
-        if (me <= nn) {
-#pragma unroll
-            for (int m = 0; m < nn; ++m) {
-                ry = ry + scra[(me - 1) * ldq + m];
-                rc_ = rc_ + scrb[(me - 1) * ldq + m];
-            }
-        }
-        wave_lds_sync();
+        ry = combine1(yv, tj);
+        rc_ = combine1(cb, tj);
     };
     const bool thermal = plank && mazim == 0;
     int status = 0;
