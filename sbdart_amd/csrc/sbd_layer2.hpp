@@ -137,7 +137,7 @@ SBD_DEVICE double group_bcast(double x)
 }
 
 template <int NN, int G, bool RAD>
-__global__ void __launch_bounds__(64) layer_kernel2(Params P, int32_t *eigflag)
+__global__ void __launch_bounds__(64, (NN > 12) ? 2 : 1) layer_kernel2(Params P, int32_t *eigflag)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int n = 2 * NN, nn = NN, GPB = 64 / G;
