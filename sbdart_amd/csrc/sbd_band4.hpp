@@ -190,6 +190,11 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     }
     __threadfence_block();   // B and the boundary block are re-read by this wave as rows enter the window
 
+    // raw GC words of the layer below the current interface: lane (system, q) keeps its 2 NN words of GC(lc+1)
+    // from the step in which they were slot 1 to the step in which they are slot 0 (own words only: no
+    // exchange between lanes, LDS operations of a wave run in order -- no fence)
+    __shared__ double gc_next[n * 64];
+    double *keep = gc_next + lane;
     // ---- window: RW rows x (x_lc | x_lc+1 | B) ----
     double a0[RW], a1[RW], a2[RW];
     // carry of the first step = the top-boundary rows (SETMTX, disort.f:2887-2915):
@@ -225,7 +230,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     // with per-lane bases -- and the boundary block of step ncut is stored to be read the same way
     // (beside zeros, unscaled).  Beyond ncut: valid memory, never used.
     struct RowSrc { const double *hi, *lo; };
-    auto step_rows = [&](int lci, RowSrc &pa, RowSrc &pb) {
+    auto step_rows = [&](int lci, RowSrc &pa, RowSrc &pb, const bool first = false) {
         const bool inner = lci < ncut, last = lci == ncut;
         const int qq = col ? q : 0;
         const bool upper = qq >= nn;
@@ -234,8 +239,12 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         const double *cb = P.gcc + ((size_t)ms * L + ((lci + 1 < L ? lci + 1 : L) - 1)) * 2 * nn * nn + jo;
         const double *bc = bcb + (qq / nn) * (2 * nn * nn) + (qq % nn);
         const double *zr = P.t.zeros + (qq % nn);
-        pa.hi = inner ? (upper ? ca : ca + nn * nn) : (last ? bc : zr);
-        pa.lo = inner ? (upper ? ca + nn * nn : ca) : (last ? bc + nn * nn : zr);
+        // (slot 0 of an inner step is GC(lci): the same words that were slot 1 of the step before -- kept in LDS
+        //  across the step, not read from HBM a second time; only the first step fetches them, `first`.  The
+        //  loads of the other inner steps stay in the code, branch-free, and hit the zeros table)
+        const bool fetch_a = inner && first;
+        pa.hi = fetch_a ? (upper ? ca : ca + nn * nn) : (last ? bc : zr);
+        pa.lo = fetch_a ? (upper ? ca + nn * nn : ca) : (last ? bc + nn * nn : zr);
         pb.hi = inner ? (upper ? cb : cb + nn * nn) : zr;
         pb.lo = inner ? (upper ? cb + nn * nn : cb) : zr;
     };
@@ -262,7 +271,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     };
     {   // rows of step 1 (exposed once per system)
         RowSrc pa, pb;
-        step_rows(1, pa, pb);
+        step_rows(1, pa, pb, true);
         const Z3 z1 = load_z(1), z2 = load_z(2);
         const double yq = step_rhs(1, z1, z2, expbea[1], taucpr[1], *pyb);
         const double *pea, *peb;
@@ -272,6 +281,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         static_for<n>([&](auto rr) {
             constexpr int r = decltype(rr)::value;
             const double va = row_of(pa, rr), vb = row_of(pb, rr);
+            keep[r * 64] = vb;
             a0[nn + r] = col ? va * fa : 0.0;
             a1[nn + r] = col ? vb * fb : 0.0;
             a2[nn + r] = dbl_lane_bcast<r>(yq);
@@ -372,10 +382,21 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
 #pragma unroll
         for (int p = 0; p < nn; ++p) { a0[p] = a1[p]; a1[p] = 0.0; }
         // ... and the prefetched rows of the next step complete the window, scaled as they arrive
+        const bool inner_next = lc + 1 < ncut;              // slot 0 of the next step: GC(lc+1) from LDS, else what was loaded
 #pragma unroll
-        for (int r = 0; r < E; ++r) { a0[nn + r] = bufa[r] * fan; a1[nn + r] = bufb[r] * fbn; }
+        for (int r = 0; r < E; ++r) {
+            const double ga_ = keep[r * 64];
+            keep[r * 64] = bufb[r];
+            a0[nn + r] = (inner_next ? ((n == 16 || col) ? ga_ : 0.0) : bufa[r]) * fan;
+            a1[nn + r] = bufb[r] * fbn;
+        }
 #pragma unroll
-        for (int r = E; r < n; ++r) { a0[nn + r] = a0[nn + r] * fan; a1[nn + r] = a1[nn + r] * fbn; }
+        for (int r = E; r < n; ++r) {
+            const double ga_ = keep[r * 64];
+            keep[r * 64] = a1[nn + r];
+            a0[nn + r] = (inner_next ? ((n == 16 || col) ? ga_ : 0.0) : a0[nn + r]) * fan;
+            a1[nn + r] = a1[nn + r] * fbn;
+        }
         static_for<n>([&](auto rr) {
             constexpr int r = decltype(rr)::value;
             a2[nn + r] = dbl_lane_bcast<r>(rhsn);
