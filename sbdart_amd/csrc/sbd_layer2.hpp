@@ -137,7 +137,7 @@ SBD_DEVICE double group_bcast(double x)
 }
 
 template <int NN, int G, bool RAD>
-__global__ void __launch_bounds__(64, (NN > 12) ? 2 : 1) layer_kernel2(Params P, int32_t *eigflag)
+__global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(Params P, int32_t *eigflag)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int n = 2 * NN, nn = NN, GPB = 64 / G;
@@ -541,23 +541,26 @@ __global__ void __launch_bounds__(64, (NN > 12) ? 2 : 1) layer_kernel2(Params P,
     if (me <= nn) {
         kq = sqrt(fabs(lam));
         const double rkq = 1.0 / kq;
-        double rc[nn];
-#pragma unroll
-        for (int i = 1; i <= nn; ++i) rc[i - 1] = rcp_nr(QM(i, i));
-#pragma unroll
-        for (int i = nn; i >= 1; --i) {                  // C^T y = b'
+        // one walk over C, column by column from the last: entry C(k,i) serves the back-substitution
+        // C^T y = b' (row i) and the product C b' (row k) -- read once, and never more than a column in flight
+        static_for<nn>([&](auto ii) {
+            constexpr int i = nn - decltype(ii)::value;
             double s = bcol[i - 1];
+            const double bi = bcol[i - 1];
+            const double cii = QM(i, i);
 #pragma unroll
-            for (int k = i + 1; k <= nn; ++k) s = s - QM(k, i) * yv[k - 1];
-            yv[i - 1] = s * rc[i - 1];
-        }
+            for (int k = i + 1; k <= nn; ++k) {
+                const double c = QM(k, i);
+                s = s - c * yv[k - 1];
+                cb[k - 1] = cb[k - 1] + c * bi;
+            }
+            cb[i - 1] = cb[i - 1] + cii * bi;
+            yv[i - 1] = s * rcp_nr(cii);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (rad) {
 #pragma unroll
-        for (int i = 1; i <= nn; ++i) {
-            double s = 0.0;                              // (C b')(i)
-#pragma unroll
-            for (int k = 1; k <= i; ++k) s = s + QM(i, k) * bcol[k - 1];
-            cb[i - 1] = s;
-            if constexpr (rad) gp[i - 1] = -(s * sxi[i - 1]) * rkq;
+            for (int i = 0; i < nn; ++i) gp[i] = -(cb[i] * sxi[i]) * rkq;
         }
         if constexpr (rad) {
 #pragma unroll
