@@ -285,7 +285,7 @@ def main():
                        "chunk": eng.chunk, "workspace_bytes": eng.workspace_bytes},
             "solves_per_s": W * world * args.steps / elapsed,
             "value_incl_h2d": nwl_total * nh / elapsed_h, "ms_per_step_incl_h2d": 1e3 * elapsed_h / nh,
-            "incl_h2d_note": "same step through the host entry point (sbd_fleet_solve_host): inputs in pinned host memory, H2D per pass beside the other pass's kernels, sums on the device, D2H of sums + status",
+            "incl_h2d_note": "same step through the host entry point (sbd_fleet_solve_host): inputs in pinned host memory, the passes' H2D back to back on a copy stream beside the kernels, sums on the device, D2H of sums + status",
             "nonzero_status": bad,
             "kernel_ms": {names[i]: float(phase_ms[i]) for i in range(5)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS,

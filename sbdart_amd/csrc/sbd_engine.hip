@@ -163,9 +163,21 @@ struct sbd_engine {
     sbd::Params P2{};             // the same over the second workspace (passes alternate between the two)
     hipStream_t aux = nullptr;    // second stream: odd passes run here, beside the even ones
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // host-pointer solves: ONE stream carries the H2D copies of all passes, back to back, each followed by
+    // an event its pass waits for -- the inputs of pass i+1 cross PCIe while pass i computes (with the copies
+    // on the passes' own two streams both streams copied, then both computed: nothing overlapped)
+    hipStream_t copy = nullptr;
+    std::vector<hipEvent_t> ev_h2d;
     // staging for solve_host / accumulate
     char *d_stage = nullptr;
     size_t stage_bytes = 0;
+    // Outputs of a host-pointer solve land in a pinned buffer of the engine and move to the caller's arrays
+    // after the stream has drained: a D2H copy into pageable memory is staged by the runtime and blocks the
+    // enqueueing thread until the pass has finished -- which serialises the passes (H2D of pass i+1 would wait).
+    char *h_pin = nullptr;
+    size_t h_pin_bytes = 0;
+    struct PendingOut { void *dst; const void *src; size_t bytes; };
+    std::vector<PendingOut> pending_out;
     double *d_partial = nullptr;
     size_t partial_elems = 0;
     double *d_acc = nullptr;      // [5*nlev + nphi*nlev*numu] weighted sums of the last fleet solve
@@ -213,6 +225,7 @@ void sbd_engine_destroy(sbd_engine *e)
     if (e->d_level) (void)hipFree(e->d_level);
     if (e->d_ws) (void)hipFree(e->d_ws);
     if (e->d_stage) (void)hipFree(e->d_stage);
+    if (e->h_pin) (void)hipHostFree(e->h_pin);
     if (e->d_partial) (void)hipFree(e->d_partial);
     if (e->d_acc) (void)hipFree(e->d_acc);
     if (e->d_red) (void)hipFree(e->d_red);
@@ -221,6 +234,8 @@ void sbd_engine_destroy(sbd_engine *e)
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->aux) (void)hipStreamDestroy(e->aux);
+    for (auto &x : e->ev_h2d) if (x) (void)hipEventDestroy(x);
+    if (e->copy) (void)hipStreamDestroy(e->copy);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -343,6 +358,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     } while (0)
     CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     CREATE_TRY(hipMalloc(&e->d_tab, htab.size() * sizeof(double)));
@@ -610,6 +626,38 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));      // ... is also ahead of the auxiliary stream
     }
     hipStream_t st_main = st;
+    // inputs of pass ip, host -> staging, on the copy stream (see sbd_engine::copy).  Pass 0 goes first, pass
+    // i+1 right after the kernels of pass i have been queued: with pinned host arrays nothing here waits; with
+    // pageable ones (the runtime stages those and returns when the copy is done) the calling thread copies
+    // while the GPU computes the pass before
+    auto copy_pass = [&](const int ip) -> int {
+        const int w0 = ip * per_pass;
+        if (!hs || w0 >= in->nwork) return SBD_OK;
+        const size_t npm = (size_t)L * (e->cfg.nmom + 1);
+        const int ns = (in->nwork - w0 < per_pass) ? in->nwork - w0 : per_pass;
+        hipStream_t cs = e->copy;
+        HIP_TRY(hipMemcpyAsync((void *)(in->dtauc + (size_t)w0 * L), hs->in->dtauc + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipMemcpyAsync((void *)(in->ssalb + (size_t)w0 * L), hs->in->ssalb + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipMemcpyAsync((void *)(in->pmom + (size_t)w0 * npm), hs->in->pmom + (size_t)w0 * npm, sizeof(double) * ns * npm, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipMemcpyAsync((void *)(in->wvnmlo + w0), hs->in->wvnmlo + w0, sizeof(double) * ns, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipMemcpyAsync((void *)(in->wvnmhi + w0), hs->in->wvnmhi + w0, sizeof(double) * ns, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipMemcpyAsync((void *)(in->fbeam + w0), hs->in->fbeam + w0, sizeof(double) * ns, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipMemcpyAsync((void *)(in->albedo + w0), hs->in->albedo + w0, sizeof(double) * ns, hipMemcpyHostToDevice, cs));
+        HIP_TRY(hipMemcpyAsync((void *)(in->plank + w0), hs->in->plank + w0, (size_t)ns, hipMemcpyHostToDevice, cs));
+        if ((int)e->ev_h2d.size() <= ip) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e->ev_h2d.push_back(ev);
+        }
+        HIP_TRY(hipEventRecord(e->ev_h2d[ip], cs));
+        return SBD_OK;
+    };
+    if (hs) {
+        HIP_TRY(hipEventRecord(e->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(e->copy, e->ev_fork, 0));
+        const int rc0 = copy_pass(0);
+        if (rc0 != SBD_OK) return rc0;
+    }
     int ipass = 0;
     for (int w0 = 0; w0 < in->nwork; w0 += per_pass, ++ipass) {
         const int ns = (in->nwork - w0 < per_pass) ? in->nwork - w0 : per_pass;
@@ -617,17 +665,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         sbd::Params P = second ? e->P2 : e->P;
         st = (fork && second) ? e->aux : st_main;
         int32_t *const eigflag = P.eiglist;
-        if (hs) {   // this pass's inputs, host -> staging
-            const size_t npm = (size_t)L * (e->cfg.nmom + 1);
-            HIP_TRY(hipMemcpyAsync((void *)(in->dtauc + (size_t)w0 * L), hs->in->dtauc + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync((void *)(in->ssalb + (size_t)w0 * L), hs->in->ssalb + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync((void *)(in->pmom + (size_t)w0 * npm), hs->in->pmom + (size_t)w0 * npm, sizeof(double) * ns * npm, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync((void *)(in->wvnmlo + w0), hs->in->wvnmlo + w0, sizeof(double) * ns, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync((void *)(in->wvnmhi + w0), hs->in->wvnmhi + w0, sizeof(double) * ns, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync((void *)(in->fbeam + w0), hs->in->fbeam + w0, sizeof(double) * ns, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync((void *)(in->albedo + w0), hs->in->albedo + w0, sizeof(double) * ns, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync((void *)(in->plank + w0), hs->in->plank + w0, (size_t)ns, hipMemcpyHostToDevice, st));
-        }
+        if (hs) HIP_TRY(hipStreamWaitEvent(st, e->ev_h2d[ipass], 0));   // this pass's inputs have landed
         P.nslot = ns;
         P.dtauc = in->dtauc + (size_t)w0 * L;
         P.ssalb = in->ssalb + (size_t)w0 * L;
@@ -688,6 +726,10 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         }
         if (timing) HIP_TRY(hipEventRecord(e->ev[5], st));
         HIP_TRY(hipGetLastError());
+        {
+            const int rcn = copy_pass(ipass + 1);
+            if (rcn != SBD_OK) return rcn;
+        }
         if (timing) {
             HIP_TRY(hipEventSynchronize(e->ev[sbd_engine::kPhases]));
             if (e->use_layer2) {                         // layers the fast layer kernel handed to the reference-algorithm one
@@ -719,6 +761,7 @@ static int ensure_stage(sbd_engine *e, size_t bytes)
 {
     if (bytes <= e->stage_bytes) return SBD_OK;
     if (e->d_stage) (void)hipFree(e->d_stage);
+    if (e->h_pin) (void)hipHostFree(e->h_pin);
     e->d_stage = nullptr;
     e->stage_bytes = 0;
     hipError_t err = hipMalloc(&e->d_stage, bytes);
@@ -756,7 +799,22 @@ static int solve_host_enqueue(sbd_engine *e, const sbd_batch_in *in, const sbd_b
     if (weight) HIP_TRY(hipMemcpyAsync(d_wt, weight, b_w, hipMemcpyHostToDevice, st));
     sbd_batch_in din = {in->nwork, d_dt, d_ss, d_pm, d_lo, d_hi, d_fb, d_al, d_pl};
     sbd_batch_out dout = {d_flux, d_uu, d_st};
-    const HostSide hs = {in, out};
+    // pinned landing area for the outputs the caller wants (see sbd_engine::h_pin)
+    const size_t w_flux = out->flux ? up(b_flux) : 0, w_uu = (rad && out->uu) ? up(b_uu) : 0, w_st = out->status ? up(sizeof(int32_t) * W) : 0;
+    if (w_flux + w_uu + w_st > e->h_pin_bytes) {
+        if (e->h_pin) (void)hipHostFree(e->h_pin);
+        e->h_pin = nullptr;
+        e->h_pin_bytes = 0;
+        if (hipHostMalloc(&e->h_pin, w_flux + w_uu + w_st, hipHostMallocDefault) != hipSuccess) return fail(SBD_E_NOMEM, "hipHostMalloc(outputs)");
+        e->h_pin_bytes = w_flux + w_uu + w_st;
+    }
+    char *hp = e->h_pin;
+    sbd_batch_out pout = {nullptr, nullptr, nullptr};
+    e->pending_out.clear();
+    if (w_flux) { pout.flux = (double *)hp; e->pending_out.push_back({out->flux, hp, b_flux}); hp += w_flux; }
+    if (w_uu) { pout.uu = (double *)hp; e->pending_out.push_back({out->uu, hp, b_uu}); hp += w_uu; }
+    if (w_st) { pout.status = (int32_t *)hp; e->pending_out.push_back({out->status, hp, sizeof(int32_t) * W}); hp += w_st; }
+    const HostSide hs = {in, &pout};
     rc = solve_device_impl(e, &din, &dout, st, &hs);   // (each pass stages its slice in and out on its own stream)
     if (rc != SBD_OK) return rc;
     if (weight) {
@@ -772,6 +830,13 @@ static int solve_host_enqueue(sbd_engine *e, const sbd_batch_in *in, const sbd_b
     return SBD_OK;
 }
 
+// after the engine's stream has drained: the outputs of the last host-pointer solve, pinned buffer -> caller
+static void deliver_host_outputs(sbd_engine *e)
+{
+    for (const auto &po : e->pending_out) memcpy(po.dst, po.src, po.bytes);
+    e->pending_out.clear();
+}
+
 int sbd_engine_solve_host(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out)
 {
     if (!e || !in || !out) return fail(SBD_E_INVALID, "null argument");
@@ -780,6 +845,7 @@ int sbd_engine_solve_host(sbd_engine *e, const sbd_batch_in *in, const sbd_batch
     int rc = solve_host_enqueue(e, in, out, nullptr);
     if (rc != SBD_OK) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
+    deliver_host_outputs(e);
     return SBD_OK;
 }
 
@@ -986,7 +1052,7 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
             f->hacc.assign(nel, 0.0);
             HIP_TRY(hipSetDevice(e0->cfg.device));
             HIP_TRY(hipMemcpyAsync(f->hacc.data(), e0->d_red, sizeof(double) * nel, hipMemcpyDeviceToHost, e0->stream));
-            for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); }
+            for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); deliver_host_outputs(f->eng[r]); }
             for (size_t i = 0; i < nel_f; ++i) acc_flux[i] += f->hacc[i];
             if (acc_uu) for (size_t i = 0; i < nel_u; ++i) acc_uu[i] += f->hacc[nel_f + i];
         } else {
@@ -995,7 +1061,7 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
                 HIP_TRY(hipSetDevice(f->eng[r]->cfg.device));
                 HIP_TRY(hipMemcpyAsync(f->hacc.data() + (size_t)r * nel, f->eng[r]->d_acc, sizeof(double) * nel, hipMemcpyDeviceToHost, f->eng[r]->stream));
             }
-            for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); }
+            for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); deliver_host_outputs(f->eng[r]); }
             for (int r : busy) {   // fixed order: device 0's block first
                 const double *h = f->hacc.data() + (size_t)r * nel;
                 for (size_t i = 0; i < nel_f; ++i) acc_flux[i] += h[i];
@@ -1003,7 +1069,7 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
             }
         }
     } else {
-        for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); }
+        for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); deliver_host_outputs(f->eng[r]); }
     }
     return SBD_OK;
 }
