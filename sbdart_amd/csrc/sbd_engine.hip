@@ -396,7 +396,10 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     // Two workspaces of `chunk` items each: consecutive passes of a batch alternate between them on two
     // streams, so that the layer kernel of one pass (latency-bound arithmetic) runs beside the band LU /
     // back-substitution of the other (HBM streaming) instead of after it.
-    int chunk = 65536;
+    // (measured on the 131 254-solve sweep, tools/bench_chunks.py, twice: 6 passes of 21 876 items 14.95 ms,
+    //  4 passes of 32 814 15.3 ms, 10 passes of 13 126 15.05 ms -- more boundaries where a tail of one stream
+    //  overlaps the other's kernels, until launch tails take it back)
+    int chunk = 32768;
     if (const char *s = getenv("SBD_CHUNK")) chunk = atoi(s);
     if (cfg->max_batch > 0 && cfg->max_batch < chunk) chunk = cfg->max_batch;
     while (chunk > 1 && (size_t)2 * chunk * per_slot > budget) chunk /= 2;
