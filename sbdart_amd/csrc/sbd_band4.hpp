@@ -302,6 +302,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         int qo = q;                                             // (opaque per step: keeps the compiler from hoisting
         asm volatile("" : "+v"(qo));                            //  16 per-sub-step store addresses out of the loop)
         double *yrow0 = yv + (lc - 1) * n;
+        double tpair = 0.0;
         // ---- NSTR elimination sub-steps ----
         static_for<n>([&](auto jj) {
             constexpr int J = decltype(jj)::value;
@@ -358,13 +359,27 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             //     words 0..n-1 (the finished ones, q < J, carry multipliers nobody reads: masking them out
             //     makes partial-line writes, measured slower) and x_lc+1's in n..2n-1 -- two aligned
             //     128-byte lines per system, no branches; B(k) is the same in the 16 lanes
-            {
+            if constexpr (n == 16) {
+                // 16-column layers: the block is 28 lines of 16 words -- U1's rows (0..15), U0's rows 0..7, and
+                // the live halves (columns 8..15) of U0's rows 8..15 two to a line: rows 8+2k | 9+2k.  The
+                // even row of a pair waits one sub-step in `tpair`; its words move to lanes 0..7 (row_ror:8)
+                // and leave with the odd row as one full line.
+                urow0[J * 16 + qo] = t1;
+                if constexpr (J < 8) urow0[(16 + J) * 16 + qo] = t0;
+                else if constexpr ((J & 1) == 0) tpair = t0;
+                else {
+                    const double lo8 = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(tpair), 0x128, 0xF, 0xF, false),
+                                                        __builtin_amdgcn_update_dpp(0, __double2loint(tpair), 0x128, 0xF, 0xF, false));
+                    urow0[(24 + (J - 8) / 2) * 16 + qo] = (q < 8) ? lo8 : t0;
+                }
+                yrow0[J] = t2;
+            } else {
                 double *urow = urow0 + J * UW;
-                if (n == 16 || col) {
+                if (col) {
                     urow[qo] = t0;
                     urow[n + qo] = t1;
                 }
-                if (n == 16 || q == J) yrow0[J] = t2;
+                if (q == J) yrow0[J] = t2;
             }
             // (5) elimination: a_s[p] += a_0[p](lane J) * (t_s * -1/pivot); columns <= J of
             //     slot 0 are finished (their registers keep the unscaled multipliers)

@@ -84,13 +84,24 @@ __global__ void __launch_bounds__(64, 2) backsolve4_kernel(Params P)
 
     // rows of the layer being solved: u0[J] = U0(J, q), u1[J] = U1(J, q)
     double u0[n], u1[n];
-    auto row_ptr = [&](int lc, int J) { return ufac + ((size_t)(lc - 1) * n + J) * UW + cq; };
+    // (16-column layers: sbd_band4.hpp's 28-line block -- U1's rows, U0's rows 0..7, the live halves of U0's
+    //  rows 8..15 two to a line; otherwise rows of 2n words)
+    auto load_row = [&](int lc, auto jj, double &w0, double &w1) {
+        constexpr int J = decltype(jj)::value;
+        const double *blk = ufac + (size_t)(lc - 1) * n * UW;
+        if constexpr (n == 16) {
+            w1 = blk[J * 16 + cq];
+            if constexpr (J < 8) w0 = blk[(16 + J) * 16 + cq];
+            else if (q >= 8) w0 = blk[(24 + (J - 8) / 2) * 16 + (J & 1) * 8 + (cq - 8)];   // (lanes 0..7: columns long finished)
+        } else {
+            const double *p = blk + (size_t)J * UW + cq;
+            w0 = p[0];                              // (raw words: lanes left of the diagonal hold multipliers and
+            w1 = p[n];                              //  are masked where they are used, not where they are loaded)
+        }
+    };
 #pragma unroll
-    for (int J = 0; J < n; ++J) {
-        const double *p = row_ptr(ncut, J);
-        u0[J] = p[0];                               // (raw words: lanes left of the diagonal hold multipliers and
-        u1[J] = p[n];                               //  are masked where they are used, not where they are loaded)
-    }
+    for (int J = 0; J < n; ++J) { u0[J] = 1.0; u1[J] = 0.0; }
+    static_for<n>([&](auto jj) { load_row(ncut, jj, u0[decltype(jj)::value], u1[decltype(jj)::value]); });
     double yq = yv[(ncut - 1) * n + cq];
     double xn = 0.0;                                 // x of the layer below (none below the last)
     for (int lc = ncut; lc >= 1; --lc) {
@@ -114,11 +125,7 @@ __global__ void __launch_bounds__(64, 2) backsolve4_kernel(Params P)
             const double xk = q0 + (bk - q0 * d) * r;
             xq = (q == J) ? xk : xq;
             // this row is done: fetch the same row of the layer above into its registers
-            {
-                const double *p2 = row_ptr(lcp, J);        // (no use of the values here: the loads stay in flight)
-                u0[J] = p2[0];
-                u1[J] = p2[n];
-            }
+            load_row(lcp, std::integral_constant<int, J>{}, u0[J], u1[J]);   // (no use of the values here: the loads stay in flight)
             if constexpr (J == n - 1) yqn = yv[(lcp - 1) * n + cq];
         });
         if (col) ll[(lc - 1) * n + q] = xq;           // LL(j, lc) = B((lc-1)*n + j) (disort.f:3624-3633)
