@@ -764,7 +764,6 @@ static int ensure_stage(sbd_engine *e, size_t bytes)
 {
     if (bytes <= e->stage_bytes) return SBD_OK;
     if (e->d_stage) (void)hipFree(e->d_stage);
-    if (e->h_pin) (void)hipHostFree(e->h_pin);
     e->d_stage = nullptr;
     e->stage_bytes = 0;
     hipError_t err = hipMalloc(&e->d_stage, bytes);

@@ -50,3 +50,24 @@ def test_fleet_matches_single_engine(devices, name):
         assert np.allclose(acc_u, np.einsum("i,ipln->pln", w, u1), rtol=1e-12, atol=1e-300)
     assert np.allclose(acc_f, np.einsum("i,icl->cl", w, f1), rtol=1e-12, atol=1e-300)
     assert np.array_equal(acc_f, acc_f4) and np.array_equal(s1, s4)
+
+
+def test_host_entry_point_with_growing_batches():
+    """The host-pointer solve keeps a device staging area and a pinned landing buffer for the outputs, both
+    grown on demand: a small batch, a larger one, the small one again -- each must equal the device-pointer
+    results of the same items (several passes in the large one: the copy stream and its events)."""
+    import torch
+    from sbdart_amd.engine import DisortEngine
+    from sbdart_amd.workload import sw_sweep
+    sw = sw_sweep(nwl=1536, nstr=8, nlyr=20, seed=99, shard=0)
+    ins = (sw.dtauc, sw.ssalb, sw.pmom, sw.wvnmlo, sw.wvnmhi, sw.fbeam, sw.albedo, sw.plank)
+    cut = lambda n: tuple(a[:n] for a in ins)
+    with DisortEngine(nlyr=sw.nlyr, nstr=sw.nstr, nmom=sw.nmom, temper=sw.temper, umu0=sw.umu0, btemp=sw.btemp,
+                      ttemp=sw.ttemp, temis=sw.temis, onlyfl=True, level_out=[0, sw.nlyr], device=0, max_batch=512) as eng:
+        f_small, _, s_small = eng.solve(*cut(37))
+        f_big, _, s_big = eng.solve(*ins)                      # several passes of <= 512 items
+        f_again, _, s_again = eng.solve(*cut(37))
+    assert sw.nwork > 2048
+    assert np.isfinite(f_big).all() and (s_big == 0).all()
+    assert np.array_equal(f_small, f_big[:37]) and np.array_equal(f_again, f_small)
+    assert np.array_equal(s_small, s_big[:37]) and np.array_equal(s_again, s_small)
