@@ -573,6 +573,8 @@ long long sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t
     case 10: src = e->P.zb; bytes = 8 * nms * L * e->P.numu; break;
     case 11: src = e->P.z0u; bytes = 8 * nms * L * e->P.numu; break;
     case 12: src = e->P.z1u; bytes = 8 * nms * L * e->P.numu; break;
+    case 13: src = e->P.eiglist; bytes = 4 * 64; break;     // count + first entries of the fallback list (first workspace)
+    case 14: src = e->P2.eiglist; bytes = 4 * 64; break;    // ... second workspace
     default: return SBD_E_INVALID;
     }
     if (bytes > nbytes) bytes = nbytes;

@@ -524,14 +524,18 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
         for (int i = 0; i < nn; ++i) lam = lam + bcol[i] * bcol[i];
     }
     // The particular solutions below come from these singular vectors.  With a beam, a k_j next to 1/mu0 makes
-    // the system UPBEAM solves singular (disort.f:4227): the reference-algorithm kernel redoes such a layer.
+    // the system UPBEAM solves singular (disort.f:4227): the reference-algorithm kernel redoes such a layer
+    // (and raises the reference's warning from its pivots).  "Next to" is 1e-10 relative: the expansion below
+    // and the reference's LU lose the same eps / gap there, and a wider window costs real time -- among the
+    // 4 M layers of a 131 k-solve sweep a few eigenvalues fall within 1e-6 of 1/mu0 every time, and ONE layer
+    // in the reference-algorithm kernel holds its pass's stream for 0.9 ms.
     // (A tiny k_j -- conservative scattering, SSALB dithered to 1 - 2.2e-14, k ~ 2e-7 -- is served here: its
     //  column b'_j carries the absolute accuracy eps |B| of the rotations, i.e. ~1e-9 relative, in the
     //  eigenvector as in the particular solution; the reference's own k for that mode is good to ~1e-3.)
     const double umu0 = P.umu0;
     {
         const double gap = fabs(1.0 - umu0 * umu0 * lam);
-        const bool bad = (me <= nn) && (!(lam > 0.0) || (fbeam > 0.0 && !(gap > 1.0e-6)));
+        const bool bad = (me <= nn) && (!(lam > 0.0) || (fbeam > 0.0 && !(gap > 1.0e-10)));
         const unsigned long long gmask = ((G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull)) << ((gi * G) & 63);
         if ((__ballot(bad) & gmask) != 0ull) {
             if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;
