@@ -179,18 +179,21 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
         sv[o.utau() + lev] = ut;
         sv[o.utaupr() + lev] = s_taucpr[lc - 1] + (1.0 - s_w[lc - 1] * s_f[lc - 1]) * (ut - s_tauc[lc - 1]);
         svi[SBD_SVI_LAYRU + lev] = lc;
-        const double pk = plank ? plkavg(wlo, whi, P.t.temper[lev], P.pi, pw) : 0.0;   // disort.f:564-569
-        s_pk[lev] = pk;
-        sv[o.pkag() + lev] = pk;
     }
-    if (lane == 0) {
-        double bpl = 0.0, tpl = 0.0;
-        if (plank) {
-            tpl = P.temis * plkavg(wlo, whi, P.ttemp, P.pi, pw);   // disort.f:556-557
-            bpl = plkavg(wlo, whi, P.btemp, P.pi, pw);
+    // band-integrated Planck function at every level (disort.f:564-569) and at the two boundary temperatures
+    // (disort.f:556-557): L + 3 evaluations of the same routine, one per lane in ONE pass (the boundary two used
+    // to follow on lane 0 alone, each as long as the whole pass)
+    for (int lev = lane; lev <= L + 2; lev += 64) {
+        const double tk = (lev <= L) ? P.t.temper[lev] : ((lev == L + 1) ? P.ttemp : P.btemp);
+        const double pk = plank ? plkavg(wlo, whi, tk, P.pi, pw) : 0.0;
+        if (lev <= L) {
+            s_pk[lev] = pk;
+            sv[o.pkag() + lev] = pk;
+        } else if (lev == L + 1) {
+            sv[o.tplank()] = P.temis * pk;
+        } else {
+            sv[o.bplank()] = pk;
         }
-        sv[o.bplank()] = bpl;
-        sv[o.tplank()] = tpl;
     }
     if (pw) atomicOr(&s_pw, 1);
     __syncthreads();
