@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool: where the fast layer kernel spends its shader-clock ticks, phase by phase.
-Needs the library built with -DSBD_PHASE_TICKS (make -C sbdart_amd/csrc clean; make ... EXTRA=-DSBD_PHASE_TICKS):
+Needs the layer kernel built with -DSBD_PHASE_TICKS:
+   rm sbdart_amd/csrc/build/sbd_k_layer2f.o; make -C sbdart_amd/csrc HIPFLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -DSBD_PHASE_TICKS"
+(and rebuilt without it afterwards: the tick atomics cost time)
    python tools/layer_phases.py NSTR NLYR NWL"""
 import ctypes, os, sys
 nstr, nlyr, nwl = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
