@@ -53,13 +53,39 @@ SBD_DEVICE double dbl_lane_bcast(double x)
     return __hiloint2double(int_lane_bcast<J>(__double2hiint(x)), int_lane_bcast<J>(__double2loint(x)));
 }
 
+// sum over the 16 lanes of a row, result in every lane
+SBD_DEVICE double row_sum16(double v)
+{
+    auto dpp = [](double x, auto ctrl) {
+        constexpr int C = decltype(ctrl)::value;
+        return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), C, 0xF, 0xF, false),
+                                __builtin_amdgcn_update_dpp(0, __double2loint(x), C, 0xF, 0xF, false));
+    };
+    v = v + dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v = v + dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v = v + dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v = v + dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    return v;
+}
+
 #include "sbd_band4_take.inc"   // TakeRows<RW, LAST>: generated inline asm (tools/gen_band4_take.py)
 
-template <int NN>
+// FUSED (flux-only runs that ask for the fluxes at the top of the first layer and at the surface only: IOUT 1 / 10
+// with the default ZOUT, drt.f:376-381): no factor leaves the kernel.  FLUXES' three angular sums at a level are
+// linear functionals c^T x of that layer's integration constants (c = weights^T GC diag(E), disort.f:1945-1994);
+// a functional is carried through the elimination as one more row of the augmented system [A b; c^T 0] that is
+// never a pivot candidate -- when every unknown is gone its right-hand side holds -c^T A^-1 b.  The three rows of
+// the top level live in registers of their own (F0/F1/F2), the three of the surface level ride in the zero rows
+// that pad the bottom-boundary block, scaled by 2^-300 (exact, and they never win a pivot search) and marked by a
+// tag in their unused x_lc+1 slot.  The U factor, the eliminated right-hand side, LL and the whole back-substitution
+// kernel (two thirds of the pipeline's HBM bytes) do not exist in this mode.
+template <int NN, bool FUSED = false>
 __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
 {
     constexpr int n = 2 * NN, nn = NN, RW = nn + n, UW = u_width(n);
     static_assert(n <= 16, "band4_kernel: a layer's columns must fit a row of 16 lanes");
+    static_assert(!FUSED || NN >= 3, "band4_kernel: the fused variant needs three padding rows in the bottom block");
+    constexpr double kTiny = 4.909093465297727e-91, kHuge = 2.037035976334486e+90;   // 2^-300, 2^300
     const int lane = threadIdx.x, q = lane & 15;
     const int nmode = P.nmode, L = P.L;
     const long long ms = (long long)blockIdx.x * 4 + (lane >> 4);
@@ -94,7 +120,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     const double *zp0 = P.zp0 + (size_t)(ms - mazim) * L * n;     // thermal solutions: mode 0 only
     const double *zp1 = P.zp1 + (size_t)(ms - mazim) * L * n;
     double *yv = P.yv + (size_t)ms * L * n;
-    double *ufac = P.ufac + (size_t)ms * (size_t)(L * n) * UW;
+    double *ufac = FUSED ? nullptr : P.ufac + (size_t)ms * (size_t)(L * n) * UW;
     double *bcb = P.bcb + (size_t)ms * n * n;                  // bottom-boundary rows (below)
     const int N = ncut * n;
 #define GC(i, j, lc) gc[((size_t)((lc) - 1) * n + ((i) - 1)) * n + ((j) - 1)]
@@ -176,6 +202,25 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         const double f = (iq1 > nn) ? EK(n + 1 - iq1, ncut) : 1.0;
         // (stored in the quarter layout the rows of every step are read in, see step_rows below)
         double *bchi = bcb + (q / nn) * (2 * nn * nn) + (q % nn), *bclo = bchi + nn * nn;
+        double cb[3] = {0.0, 0.0, 0.0};
+        if constexpr (FUSED) {   // the surface level's functionals (only a level inside layer ncut has any)
+            const int levb = P.t.level_out[1];
+            if (svi[SBD_SVI_LAYRU + levb] == ncut) {
+                const double upb = sv[o.utaupr() + levb];
+                const double refb = (q < nn) ? taucpr[ncut] : taucpr[ncut - 1];
+                const double eb = exp(-KK(iq1, ncut) * (upb - refb)) * kTiny;
+                double sa = 0.0, sd = 0.0, su = 0.0;
+#pragma unroll
+                for (int i = 0; i < n; ++i) {
+                    const int iw = (i < nn) ? nn - 1 - i : i - nn;
+                    const double g = GC(i + 1, iq1, ncut), w = cwt[iw];
+                    sa = sa + w * g;
+                    if (i < nn) sd = sd + (w * cmu[iw]) * g;
+                    else su = su + (w * cmu[iw]) * g;
+                }
+                cb[0] = sa * eb; cb[1] = sd * eb; cb[2] = su * eb;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < n; ++r) {
             double g = 0.0;
@@ -184,6 +229,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
                 if (refl) g = g - (1.0 + delm0) * sb;
                 g = g * f;
             }
+            if constexpr (FUSED) { if (r >= nn && r < nn + 3) g = cb[r - nn]; }
             if (r >= nn) bchi[(r - nn) * nn] = g;
             else bclo[(nn - 1 - r) * nn] = g;
         }
@@ -206,6 +252,27 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             a0[r - 1] = col ? GC(nn + 1 - r, iq1, 1) * f : 0.0;
             a1[r - 1] = 0.0;
             a2[r - 1] = yv[r - 1];
+        }
+    }
+    // FUSED: the top level's three functional rows (mean intensity, downward and upward flux sums) over
+    // (x_lc | x_lc+1 | B); they enter with the first step: the level lies in layer 1
+    double F0[3] = {0.0, 0.0, 0.0}, F1[3] = {0.0, 0.0, 0.0}, F2[3] = {0.0, 0.0, 0.0};
+    if constexpr (FUSED) {
+        if (col) {
+            const int levt = P.t.level_out[0];
+            const double upt = sv[o.utaupr() + levt];
+            const double reft = (q < nn) ? taucpr[1] : taucpr[0];
+            const double et = exp(-KK(iq1, 1) * (upt - reft));
+            double sa = 0.0, sd = 0.0, su = 0.0;
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+                const int iw = (i < nn) ? nn - 1 - i : i - nn;
+                const double g = GC(i + 1, iq1, 1), w = cwt[iw];
+                sa = sa + w * g;
+                if (i < nn) sd = sd + (w * cmu[iw]) * g;
+                else su = su + (w * cmu[iw]) * g;
+            }
+            F0[0] = sa * et; F0[1] = sd * et; F0[2] = su * et;
         }
     }
     int status = 0;
@@ -239,13 +306,14 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         const double *cb = P.gcc + ((size_t)ms * L + ((lci + 1 < L ? lci + 1 : L) - 1)) * 2 * nn * nn + jo;
         const double *bc = bcb + (qq / nn) * (2 * nn * nn) + (qq % nn);
         const double *zr = P.t.zeros + (qq % nn);
+        const double *tg = FUSED ? P.t.tags + (qq % nn) : zr;              // (rows nn..nn+2 of the last step: 1, 2, 3)
         // (slot 0 of an inner step is GC(lci): the same words that were slot 1 of the step before -- kept in LDS
         //  across the step, not read from HBM a second time; only the first step fetches them, `first`.  The
         //  loads of the other inner steps stay in the code, branch-free, and hit the zeros table)
         const bool fetch_a = inner && first;
         pa.hi = fetch_a ? (upper ? ca : ca + nn * nn) : (last ? bc : zr);
         pa.lo = fetch_a ? (upper ? ca + nn * nn : ca) : (last ? bc + nn * nn : zr);
-        pb.hi = inner ? (upper ? cb : cb + nn * nn) : zr;
+        pb.hi = inner ? (upper ? cb : cb + nn * nn) : tg;
         pb.lo = inner ? (upper ? cb + nn * nn : cb) : zr;
     };
     auto row_of = [&](const RowSrc &p, auto rr) -> double {                 // row r (compile time) of a step's block
@@ -298,7 +366,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         double ebn, tcn, ybn, fan = 1.0, fbn = 1.0;
         const double *pea, *peb;
         factor_ptrs(lc + 1, pea, peb);
-        double *urow0 = ufac + (size_t)(lc - 1) * n * UW;      // U rows of this layer
+        double *urow0 = FUSED ? nullptr : ufac + (size_t)(lc - 1) * n * UW;      // U rows of this layer
         int qo = q;                                             // (opaque per step: keeps the compiler from hoisting
         asm volatile("" : "+v"(qo));                            //  16 per-sub-step store addresses out of the loop)
         double *yrow0 = yv + (lc - 1) * n;
@@ -359,7 +427,9 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             //     words 0..n-1 (the finished ones, q < J, carry multipliers nobody reads: masking them out
             //     makes partial-line writes, measured slower) and x_lc+1's in n..2n-1 -- two aligned
             //     128-byte lines per system, no branches; B(k) is the same in the 16 lanes
-            if constexpr (n == 16) {
+            if constexpr (FUSED) {
+                // nothing is stored: the functional rows below take the place of the back-substitution
+            } else if constexpr (n == 16) {
                 // 16-column layers: the block is 28 lines of 16 words -- U1's rows (0..15), U0's rows 0..7, and
                 // the live halves (columns 8..15) of U0's rows 8..15 two to a line: rows 8+2k | 9+2k.  The
                 // even row of a pair waits one sub-step in `tpair`; its words move to lanes 0..7 (row_ror:8)
@@ -392,10 +462,22 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
                 a2[p] = fmac_lane_bcast<J>(a2[p], a0[p], tp2);
                 a0[p] = fmac_lane_bcast<J>(a0[p], a0[p], tp0);
             }
+            if constexpr (FUSED) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    F1[k] = fmac_lane_bcast<J>(F1[k], F0[k], tp1);
+                    F2[k] = fmac_lane_bcast<J>(F2[k], F0[k], tp2);
+                    F0[k] = fmac_lane_bcast<J>(F0[k], F0[k], tp0);
+                }
+            }
         });
         // ---- the nn rows left over only touch x_lc+1: next step's carry ----
 #pragma unroll
         for (int p = 0; p < nn; ++p) { a0[p] = a1[p]; a1[p] = 0.0; }
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { F0[k] = F1[k]; F1[k] = 0.0; }
+        }
         // ... and the prefetched rows of the next step complete the window, scaled as they arrive
         const bool inner_next = lc + 1 < ncut;              // slot 0 of the next step: GC(lc+1) from LDS, else what was loaded
 #pragma unroll
@@ -427,6 +509,64 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         if (q == 0 && !(pm > 8.0 * N * 2.220446049250313e-16 * am)) status |= 0x01;
     }
     if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
+    if constexpr (FUSED) {
+        // ---- FLUXES (disort.f:1780-2042) at the two levels from the functionals ----
+        // top level: the right-hand sides of the rows F; surface level: the nn rows left over by the last step are the
+        // padding rows, three of them tagged 1..3 in what was their x_lc+1 slot (moved to slot 0 by the hand-over)
+        double fs[2][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            fs[0][k] = -F2[k];
+            double v = 0.0;
+#pragma unroll
+            for (int p = 0; p < nn; ++p) v = (a0[p] == (double)(k + 1)) ? a2[p] : v;
+            fs[1][k] = -v * kHuge;
+        }
+        const int cq = col ? q : 0;
+        const int iqw = (cq < nn) ? nn - 1 - cq : cq - nn;
+        const double wq = col ? cwt[iqw] : 0.0, wmq = col ? cwt[iqw] * cmu[iqw] : 0.0;
+        const double pi = P.pi;
+        const int32_t *layru = svi + SBD_SVI_LAYRU;
+        const double *utau = sv + o.utau(), *utaupr = sv + o.utaupr(), *ssalbv = sv + o.ssalb();
+        const double *xr0 = sv + o.xr0(), *xr1 = sv + o.xr1();
+        double *flux = P.flux + (size_t)slot * SBD_NFLUX_ * nlev;
+#pragma unroll
+        for (int ol = 0; ol < 2; ++ol) {
+            const int lev = P.t.level_out[ol];
+            const int lc = layru[lev];
+            double rfldir = 0.0, rfldn = 0.0, flup = 0.0, dfdt = 0.0, uavg = 0.0;
+            if (lc <= ncut) {       // (levels below a cut-off layer stay zero, disort.f:1907-1916)
+                const double up = utaupr[lev];
+                // particular solutions' share of U0C(iq): ZZ e^{-tau'/mu0} + ZPLK0 + ZPLK1 tau' (disort.f:1945-1960)
+                double part = zp0[(lc - 1) * n + cq] + zp1[(lc - 1) * n + cq] * up;
+                if (beam) part = zz[(lc - 1) * n + cq] * exp(-up / umu0) + part;
+                const double uavg_s = fs[ol][0] + row_sum16(wq * part);
+                const double fldn_s = fs[ol][1] + row_sum16((q < nn) ? wmq * part : 0.0);
+                const double flup_s = fs[ol][2] + row_sum16((q >= nn) ? wmq * part : 0.0);
+                double dirint = 0.0, fldir = 0.0;
+                if (beam) {
+                    const double fact = exp(-up / umu0);
+                    dirint = fbeam * fact;
+                    fldir = umu0 * (fbeam * fact);
+                    rfldir = umu0 * fbeam * exp(-utau[lev] / umu0);
+                }
+                flup = 2.0 * pi * flup_s;
+                const double fldn = 2.0 * pi * fldn_s;
+                const double fdntot = fldn + fldir;
+                rfldn = fdntot - rfldir;
+                uavg = (2.0 * pi * uavg_s + dirint) / (4.0 * pi);
+                const double plsorc = xr0[lc - 1] + xr1[lc - 1] * up;
+                dfdt = (1.0 - ssalbv[lc - 1]) * 4.0 * pi * (uavg - plsorc);
+            }
+            if (q == 0) {
+                flux[0 * nlev + ol] = rfldir;
+                flux[1 * nlev + ol] = rfldn;
+                flux[2 * nlev + ol] = flup;
+                flux[3 * nlev + ol] = dfdt;
+                flux[4 * nlev + ol] = uavg;
+            }
+        }
+    }
 #undef GC
 #undef KK
 #undef EK

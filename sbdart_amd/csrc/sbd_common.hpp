@@ -41,6 +41,7 @@ struct Tables {            // per-run constants, device pointers
     const double *ylmu;    // [nmode][numu][n+1]
     const double *cosmphi; // [nmode][nphi]     cos(m*(phi-phi0)*rpd), row 0 = 1
     const double *zeros;   // [n][n] of 0.0 (the x_lc+1 block of the bottom-boundary rows, sbd_band4.hpp)
+    const double *tags;    // [nn][nn]: rows 0..2 hold 1, 2, 3 -- marks of the fused band kernel's functional rows
     const double *temper;  // [L+1]
     const double *umu;     // [numu]
     const int32_t *level_out; // [nlev]

@@ -194,6 +194,8 @@ struct sbd_engine {
     bool band_reg = false;
     bool band4 = false;             // four systems per wave, block form (sbd_band4.hpp), NSTR <= 16
     bool band1 = false;             // one system per wave, block form in registers (sbd_band1.hpp), 16 < NSTR <= 32
+    bool fused = false;             // band4, flux-only, levels = {top of layer 1, surface}: the band kernel carries FLUXES'
+                                    // functionals through the elimination -- no U factor, no back-substitution kernel
     bool corint = false;            // intensity corrections after the azimuth series (sbd_intcor.hpp)
     int64_t fallback_layers = 0;    // timing mode: (item, mode, layer) problems of the last solve left to the QR kernel
 };
@@ -347,6 +349,10 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const size_t o_umu = numu > 0 ? push(cfg->umu, numu) : push(&zero, 1);
     const std::vector<double> zblock((size_t)n * n, 0.0);
     const size_t o_zero = push(zblock.data(), zblock.size());
+    std::vector<double> tagblock((size_t)nn * nn, 0.0);
+    for (int k = 0; k < 3 && k < nn; ++k)
+        for (int c = 0; c < nn; ++c) tagblock[(size_t)k * nn + c] = (double)(k + 1);
+    const size_t o_tags = push(tagblock.data(), tagblock.size());
 #define CREATE_TRY(expr)                                                                    \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
@@ -374,6 +380,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->tab.ylmu = e->d_tab + o_ylmu;
     e->tab.cosmphi = e->d_tab + o_cos;
     e->tab.zeros = e->d_tab + o_zero;
+    e->tab.tags = e->d_tab + o_tags;
     e->tab.temper = e->d_tab + o_temper;
     e->tab.umu = e->d_tab + o_umu;
     e->tab.level_out = e->d_level;
@@ -387,8 +394,11 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     bool band4 = nn <= 8;
     bool band1 = nn >= 9 && nn <= 16;
     if (const char *s = getenv("SBD_BAND_V1")) { band4 = band4 && atoi(s) == 0; band1 = band1 && atoi(s) == 0; }
+    // fluxes at the top of the first layer and at the surface only (IOUT 1 / 10 with the default ZOUT): fused band kernel
+    bool fused = band4 && nn >= 3 && cfg->onlyfl && cfg->nlevel_out == 2 && cfg->level_out[0] == 0 && cfg->level_out[1] == L;
+    if (const char *s = getenv("SBD_NO_FUSE")) fused = fused && atoi(s) == 0;
     const size_t nblk = band4 ? 1 : 3;
-    const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)2 * n * n : 0) + (size_t)L * n * 6 + (size_t)L * nn + (size_t)L * n * (2 * n)
+    const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)2 * n * n : 0) + (size_t)L * n * 6 + (size_t)L * nn + (fused ? 0 : (size_t)L * n * (2 * n))
                                             + (rad ? (size_t)L * n * numu + 3 * (size_t)L * numu + (size_t)e->nlev * numu : 0));
     const size_t per_slot = per_ms * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
     size_t budget = (size_t)64 << 30;   // of 288 GB: fewer, larger passes (launch tails cost ~7 % at 16k items)
@@ -443,7 +453,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         P.zp1 = (double *)take(sizeof(double) * nms * L * n);
         P.ll = (double *)take(sizeof(double) * nms * L * n);
         P.yv = (double *)take(sizeof(double) * nms * L * n);
-        P.ufac = (double *)take(sizeof(double) * nms * L * n * (2 * n));   // sbd::u_width(n)
+        P.ufac = fused ? nullptr : (double *)take(sizeof(double) * nms * L * n * (2 * n));   // sbd::u_width(n)
         if (rad) {
             P.gu = (double *)take(sizeof(double) * nms * L * n * numu);
             P.zb = (double *)take(sizeof(double) * nms * L * numu);
@@ -480,6 +490,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     if (const char *s = getenv("SBD_BAND_LDS")) e->band_reg = e->band_reg && atoi(s) == 0;
     e->band4 = band4;
     e->band1 = band1;
+    e->fused = fused;
     e->corint = rad && cfg->corint != 0;
     e->P.ublock = e->P.gconly = band4 ? 1 : 0;
     const sbd::BandLds bl(n, nn, e->band_reg);
@@ -705,14 +716,15 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         if (timing) HIP_TRY(hipEventRecord(e->ev[2], st));
         {
             const unsigned bgrid = (unsigned)((size_t)ns * nmode);
-            if (e->band4) sbd::launch_band4(e->nn, (bgrid + 3) / 4, st, P);
+            if (e->band4) sbd::launch_band4(e->nn, (bgrid + 3) / 4, st, P, e->fused);
             else if (e->band1) sbd::launch_band1(e->nn, bgrid, st, P);
             else if (e->band_reg) sbd::launch_band_reg(e->nn, bgrid, e->band_lds, st, P);
             else sbd::launch_band_lds(e->nn, bgrid, e->band_lds, st, P);
         }
         SBD_DBG("band");
         if (timing) HIP_TRY(hipEventRecord(e->ev[3], st));
-        if (e->band4) sbd::launch_backsolve4(e->nn, (unsigned)(((size_t)ns * nmode + 3) / 4), st, P);
+        if (e->fused) { /* the band kernel has written the fluxes */ }
+        else if (e->band4) sbd::launch_backsolve4(e->nn, (unsigned)(((size_t)ns * nmode + 3) / 4), st, P);
         else sbd::launch_backsolve(e->nn, (unsigned)((size_t)ns * nmode), e->solve_lds, st, P);
         SBD_DBG("backsolve");
         if (timing) HIP_TRY(hipEventRecord(e->ev[4], st));

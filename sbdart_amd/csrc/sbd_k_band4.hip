@@ -5,9 +5,15 @@ namespace sbd {
 #ifndef SBD_BAND4_CASES
 #define SBD_BAND4_CASES(M) M(2) M(3) M(4) M(5) M(6) M(7) M(8)
 #endif
-void launch_band4(int nn, unsigned grid, hipStream_t st, const Params &P)
+void launch_band4(int nn, unsigned grid, hipStream_t st, const Params &P, bool fused)
 {
-#define SBD_C(NNv) if (nn == NNv) hipLaunchKernelGGL((band4_kernel<NNv>), dim3(grid), dim3(64), 0, st, P);
+    if (fused) {   // fluxes at the top and at the surface only: nothing stored, no back-substitution kernel
+#define SBD_C(NNv) if constexpr (NNv >= 3) { if (nn == NNv) hipLaunchKernelGGL((band4_kernel<NNv, true>), dim3(grid), dim3(64), 0, st, P); }
+        SBD_BAND4_CASES(SBD_C)
+#undef SBD_C
+        return;
+    }
+#define SBD_C(NNv) if (nn == NNv) hipLaunchKernelGGL((band4_kernel<NNv, false>), dim3(grid), dim3(64), 0, st, P);
     SBD_BAND4_CASES(SBD_C)
 #undef SBD_C
 }

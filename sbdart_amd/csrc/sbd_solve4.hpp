@@ -22,21 +22,6 @@
 
 namespace sbd {
 
-// sum over the 16 lanes of a row, result in every lane
-SBD_DEVICE double row_sum16(double v)
-{
-    auto dpp = [](double x, auto ctrl) {
-        constexpr int C = decltype(ctrl)::value;
-        return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), C, 0xF, 0xF, false),
-                                __builtin_amdgcn_update_dpp(0, __double2loint(x), C, 0xF, 0xF, false));
-    };
-    v = v + dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
-    v = v + dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
-    v = v + dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
-    v = v + dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
-    return v;
-}
-
 template <int NN>
 __global__ void __launch_bounds__(64, 2) backsolve4_kernel(Params P)
 {

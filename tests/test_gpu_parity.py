@@ -191,7 +191,12 @@ def test_level_selection_and_accumulate():
     with engine_for_record(r0) as e_all, engine_for_record(r0, level_out=[0, r0.nlyr]) as e_two:
         f_all, _, _ = e_all.solve(*args)
         f_two, _, _ = e_two.solve(*args)
-        assert np.array_equal(f_two[:, :, 0], f_all[:, :, 0]) and np.array_equal(f_two[:, :, 1], f_all[:, :, -1])
+        # (two levels = the fused band kernel for NSTR <= 16: FLUXES' sums carried through the elimination instead of
+        #  a back-substitution -- the same factors, another association; measured 1e-16 .. 2e-10 of the record's maximum)
+        sc = np.abs(f_all).max(axis=(1, 2), keepdims=True)
+        assert np.abs(f_two[:, :, 0:1] - f_all[:, :, 0:1]).max() <= 1e-8 * sc.max()
+        assert (np.abs(f_two[:, :, 0] - f_all[:, :, 0]) <= 1e-8 * sc[:, :, 0]).all()
+        assert (np.abs(f_two[:, :, 1] - f_all[:, :, -1]) <= 1e-8 * sc[:, :, 0]).all()
         w = np.array([r.wt * r.ff for r in recs])
         acc, _ = e_two.accumulate(w, f_two)
         ref = np.einsum("i,icl->cl", w, f_two)
@@ -214,10 +219,54 @@ def test_level_selection_for_every_band_kernel(nstr):
     f_two, _, st_two = solve_records(recs, level_out=[0, 33])
     assert st_all == st_two == [o["status"] for o in outs]
     for fa, ft, o in zip(f_all, f_two, outs):
-        assert np.array_equal(ft[:, 0], fa[:, 0]) and np.array_equal(ft[:, 1], fa[:, -1])
+        if nstr > 16:   # (the stored-factor kernels: the very same arithmetic whatever the levels)
+            assert np.array_equal(ft[:, 0], fa[:, 0]) and np.array_equal(ft[:, 1], fa[:, -1])
+        recmax = max(np.abs(o[name]).max() for name in FLUX)
         for c, name in enumerate(FLUX):
             sc = max(np.abs(o[name]).max(), 1e-300)
             assert np.abs(fa[c] - o[name]).max() <= TOL * sc, (nstr, name)
+            assert np.abs(ft[c] - o[name][[0, -1]]).max() <= TOL * sc + 1e-12 * recmax, (nstr, name, "two levels")
+            assert np.abs(ft[c] - fa[c][[0, -1]]).max() <= 1e-8 * recmax, (nstr, name, "two levels vs all")
+
+
+@pytest.mark.parametrize("path", [f for f in FILES if "rad" not in f and "corint" not in f and "sbchk5" not in f],
+                         ids=lambda f: os.path.basename(f))
+def test_two_level_fused_path_matches_reference_records(path):
+    """IOUT 1 / 10's level pair (top, surface) sends NSTR <= 16 flux runs through the fused band kernel (no stored
+    factor, no back-substitution: FLUXES' functionals ride through the elimination).  Every captured flux record
+    of the reference at those two levels, same gate as the all-level path; SBD_NO_FUSE=1 (stored factors, two
+    levels) must reproduce the all-level path bit for bit."""
+    from sbdart_amd.engine import solve_records
+    from sbdart_amd.records import read_records
+    recs = [r for r in read_records(path) if r.onlyfl]
+    if not recs:
+        pytest.skip("no flux-only record in this file")
+    L = recs[0].nlyr
+    flux, _, st = solve_records(recs, level_out=[0, L])
+    worst = 0.0
+    for i, r in enumerate(recs):
+        assert st[i] == 0
+        recmax = max(max(np.abs(getattr(r, f)).max() for f in FLUX), 1e-300)
+        for c, f in enumerate(FLUX):
+            ref = getattr(r, f)
+            scale = np.abs(ref).max()
+            err = np.abs(flux[i][c] - ref[[0, -1]]).max()
+            worst = max(worst, err / max(scale, 1e-300) if scale > 1e-9 * recmax else 0.0)
+            assert err <= TOL * scale + 1e-12 * recmax, (i, f, err, scale)
+    print(f"{os.path.basename(path)}: worst two-level error {worst:.2e} of the column maximum")
+
+
+def test_stored_factor_path_is_level_independent():
+    """SBD_NO_FUSE=1: two output levels through the stored-factor kernels are bitwise the all-level answers."""
+    import subprocess, sys, json
+    from conftest import ROOT
+    code = ("import numpy as np,json;from sbdart_amd.engine import solve_records;from sbdart_amd.records import read_records;"
+            "r=read_records('tests/golden/cfgB_sw_nstr16.sbdrec')+read_records('tests/golden/cfg3_lw_nstr16_cloud.sbdrec')[:40];"
+            "r=[x for x in r if x.nlyr==r[0].nlyr];"
+            "fa,_,sa=solve_records(r);ft,_,st=solve_records(r,level_out=[0,r[0].nlyr]);"
+            "print(json.dumps([bool(np.array_equal(a[:,[0,-1]],t)) for a,t in zip(fa,ft)]+[sa==st]))")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, SBD_NO_FUSE="1"), text=True)
+    assert all(json.loads(out.strip().splitlines()[-1]))
 
 
 def test_full_size_properties():
