@@ -57,7 +57,7 @@ def cpu_baseline(sw, seconds_target=10.0):
     from sbdart_amd.workload import sweep_to_records
     cli = os.path.join(ROOT, "oracle", "_ref", "disort_ref_cli")
     avg_nk = sw.nwork / sw.nwl
-    ncore = os.cpu_count() or 1
+    ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     if os.path.isfile(cli) and os.access(cli, os.X_OK):
         idx = sample_indices(sw.nwork, 2000)
         nsample = len(idx)
@@ -68,7 +68,7 @@ def cpu_baseline(sw, seconds_target=10.0):
             t0 = time.time()
             out = subprocess.run([cli, "in.sbdrec", "out.sbdrec", "1"], cwd=d, capture_output=True, text=True)
             probe = time.time() - t0
-            rep = max(1, min(20, int(seconds_target / max(probe, 1e-3))))
+            rep = max(1, min(12, int(seconds_target / max(probe, 1e-3))))
             out = subprocess.run([cli, "in.sbdrec", "out.sbdrec", str(rep)], cwd=d, capture_output=True, text=True)
             ref = None
             if os.path.exists(os.path.join(d, "out.sbdrec")):
@@ -85,22 +85,35 @@ def cpu_baseline(sw, seconds_target=10.0):
                                      f"repeats, reference DISORT (amdflang -O2) on 1 host core, DISORT calls only"}
             allc = None
             if one is not None and ncore > 1:
-                rep2 = max(1, rep // 2)
+                # one process per core the scheduler gives this process, each ONE pass over a sub-sample sized from
+                # the 1-core rate (the reference's 3.7 MB of memsets per call make 256 copies memory-bound: round 2's
+                # leg took 565 s), and a wall cap after which the leg is dropped rather than waited for
+                nsub = max(50, min(nsample, int(one["solves_per_s"] * 0.35)))
+                write_records(os.path.join(d, "sub.sbdrec"), recs[:: max(1, nsample // nsub)][:nsub], with_out=False)
+                nsub = len(recs[:: max(1, nsample // nsub)][:nsub])
                 t0 = time.time()
-                procs = [subprocess.Popen([cli, "in.sbdrec", f"out{k}.sbdrec", str(rep2)], cwd=d,
+                procs = [subprocess.Popen([cli, "sub.sbdrec", f"out{k}.sbdrec", "1"], cwd=d,
                                           stdout=subprocess.PIPE, text=True) for k in range(ncore)]
-                secs = []
+                secs, cap = [], 60.0
                 for pr in procs:
-                    so, _ = pr.communicate()
+                    try:
+                        so, _ = pr.communicate(timeout=max(0.1, cap - (time.time() - t0)))
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        pr.communicate()
+                        continue
                     for line in so.splitlines():
                         if line.startswith("TIMING"):
                             secs.append(float(line.split()[2]))
                 if len(secs) == ncore:
-                    sps = ncore * nsample * rep2 / max(secs)
+                    sps = ncore * nsub / max(secs)
                     allc = {"value": sps / avg_nk, "unit": "spectral-points/s", "cores": ncore, "nproc": ncore,
-                            "kind": "reference", "solves_per_s": sps,
-                            "sample": f"{ncore} processes x the same {nsample}-solve sample x {rep2} repeats "
-                                      f"(slowest process's DISORT time)"}
+                            "kind": "reference", "solves_per_s": sps, "wall_s": time.time() - t0,
+                            "sample": f"{ncore} processes (sched_getaffinity) x {nsub} solves of the same sample, one "
+                                      f"pass (slowest process's DISORT time), capped at {cap:.0f} s"}
+                else:
+                    allc = {"value": None, "cores": ncore, "kind": "reference",
+                            "sample": f"dropped: {ncore - len(secs)} of {ncore} processes exceeded the {cap:.0f} s cap"}
             if one is not None:
                 return one, allc, idx, ref
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -123,8 +136,117 @@ def cpu_baseline(sw, seconds_target=10.0):
                       f"(oracle/disort_oracle.c, gcc -O2) through ctypes on 1 host core"}, None, idx, ref
 
 
+MI355X_SIMDS = 256 * 4         # CUs x SIMDs
+MI355X_CLOCK_HZ = 2.4e9        # peak engine clock (MI355X_MICROARCH.md)
+
+
+def valu_issue(W, step_s, nstr, nlyr):
+    """Executed-instruction occupancy of the vector ALUs over the timed step: VALU wave-instructions per solve
+    (rocprofv3 --pmc SQ_INSTS_VALU of this command, committed under profiles/ like the traffic figures) x the
+    step's solves x 4 issue cycles per wave64 instruction / (1 024 SIMDs x 2.4 GHz x the step's time)."""
+    try:
+        vp = json.load(open(os.path.join(ROOT, "profiles", "r03_valu.json")))
+        if vp.get("nstr") != nstr or vp.get("nlyr") != nlyr:
+            return None
+        per_solve = sum(k["valu_wave_insts_per_solve"] for k in vp["kernels"].values())
+        frac = per_solve * W * 4.0 / (MI355X_SIMDS * MI355X_CLOCK_HZ * step_s)
+        return {"valu_wave_insts_per_solve": per_solve, "issue_cycles_per_inst": 4,
+                "frac_of_step": frac, "source": "profiles/r03_valu.json (SQ_INSTS_VALU, separate PMC pass)",
+                "per_kernel": {k: v["valu_wave_insts_per_solve"] for k, v in vp["kernels"].items()}}
+    except Exception:
+        return None
+
+
+def latency_case(device):
+    """The drop-in case at its real size: BASELINE configs[1] (0.25-4.0 um, wlinc 0.005, NSTR 16: 751 wavelengths,
+    2 009 solves).  The Fortran host's band model writes the work items (SBD_DUMP_OPTICS stops it before the
+    engine), the host entry point sbd_fleet_solve_host solves them from pageable arrays -- create excluded."""
+    from sbdart_amd.engine import DisortFleet
+    from sbdart_amd.records import read_records
+    host = os.path.join(ROOT, "sbdart_amd", "bin", "sbdart_amd")
+    if not os.path.exists(host):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "INPUT"), "w") as f:
+            f.write("\n &INPUT\n idatm=6 isat=0 wlinf=.25 wlsup=4.0 wlinc=.005 nstr=16 iout=10\n /\n")
+        out = os.path.join(d, "items.sbdrec")
+        subprocess.run([host], cwd=d, env=dict(os.environ, SBD_DUMP_OPTICS=out, SBD_OPTICS=os.path.join(d, "none")),
+                       capture_output=True, text=True)
+        if not os.path.exists(out):
+            return None
+        recs = [r for r in read_records(out) if r.ff != 0.0]
+    r0 = recs[0]
+    nwl = len({r.iwl for r in recs})
+    arrs = [np.stack([r.dtauc for r in recs]), np.stack([r.ssalb for r in recs]), np.stack([r.pmom for r in recs]),
+            np.array([r.wvnmlo for r in recs]), np.array([r.wvnmhi for r in recs]), np.array([r.fbeam for r in recs]),
+            np.array([r.albedo for r in recs]), np.array([r.plank for r in recs], dtype=np.uint8)]
+    w = np.array([r.wt * r.ff for r in recs])
+    t0 = time.perf_counter()
+    fleet = DisortFleet(nlyr=r0.nlyr, nstr=r0.nstr, nmom=r0.nmom, temper=r0.temper, umu0=r0.umu0, btemp=r0.btemp,
+                        ttemp=r0.ttemp, temis=r0.temis, onlyfl=True, level_out=[0, r0.nlyr], devices=[device],
+                        max_batch=len(recs))
+    create_s = time.perf_counter() - t0
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        res = fleet.solve(*arrs, weight=w, items=False)
+        ts.append(time.perf_counter() - t0)
+    st = res[2]
+    fleet.close()
+    ts = sorted(ts[1:])
+    med = ts[len(ts) // 2]
+    return {"workload": "BASELINE configs[1] from INPUT: band model (Fortran host) -> sbd_fleet_solve_host, pageable arrays",
+            "nwl": nwl, "solves": len(recs), "ms_median": 1e3 * med, "ms_min": 1e3 * ts[0], "ms_max": 1e3 * ts[-1],
+            "spectral_points_per_s": nwl / med, "create_s_excluded": create_s,
+            "nonzero_status": int(np.count_nonzero(st)), "repeats": len(ts)}
+
+
+def other_shapes(dev):
+    """One-step lines for the other BASELINE shapes (parity-test cases, not the headline): configs[4]'s
+    NSTR 32 x 50 layers in flux mode and configs[3]'s radiance shape (NSTR 32, 20 x 16 angles, 32 azimuth modes)."""
+    import torch
+    from sbdart_amd.engine import DisortEngine
+    from sbdart_amd.workload import sw_sweep
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    out = {}
+    for name, kw, nwl in (("cfgD_nstr32_50layers_flux", dict(nstr=32, nlyr=50), 6144),
+                          ("cfgC_nstr32_radiance_20x16", dict(nstr=32, nlyr=33, thermal_above_um=99.0), 384)):
+        try:
+            sw = sw_sweep(nwl=nwl, seed=12345, **kw)
+            rad = "radiance" in name
+            ekw = dict(onlyfl=True)
+            if rad:
+                ekw = dict(onlyfl=False, umu=np.cos(np.deg2rad(np.linspace(0, 85, 20)[::-1])), phi=np.linspace(0, 180, 16))
+            eng = DisortEngine(nlyr=sw.nlyr, nstr=sw.nstr, nmom=sw.nmom, temper=sw.temper, umu0=sw.umu0, btemp=sw.btemp,
+                               ttemp=sw.ttemp, temis=0.0 if rad else sw.temis, level_out=[0, sw.nlyr],
+                               device=dev.index or 0, **ekw)
+            ins = [t(sw.dtauc), t(sw.ssalb), t(sw.pmom), t(sw.wvnmlo), t(sw.wvnmhi), t(sw.fbeam), t(sw.albedo), t(sw.plank)]
+            eng.solve(*ins)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nrep = 2
+            for _ in range(nrep):
+                flux, uu, st = eng.solve(*ins)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / nrep
+            eng.enable_timing(True)
+            eng.solve(*ins)
+            torch.cuda.synchronize()
+            kms = [eng.last_ms(p) for p in range(5)]
+            fb = eng.last_fallback_layers()
+            finite = bool(torch.isfinite(flux).all().item()) and (uu is None or bool(torch.isfinite(uu).all().item()))
+            out[name] = {"value": sw.nwl / dt if finite else None, "unit": "spectral-points/s", "ms_per_step": 1e3 * dt,
+                         "nwl": sw.nwl, "solves": sw.nwork, "nstr": sw.nstr, "nlyr": sw.nlyr,
+                         "kernel_ms": dict(zip(["setup", "layer", "band", "backsolve", "usrint+azimuth"], map(float, kms))),
+                         "nonzero_status": int((st != 0).sum().item()), "fallback_layers": int(fb), "finite": finite}
+            eng.close()
+        except Exception as ex:   # a side line must not take the headline down
+            out[name] = {"value": None, "error": repr(ex)}
+    return out
+
+
 DEV_SWITCHES = ("SBD_CHUNK", "SBD_WORKSPACE_MB", "SBD_BAND_LDS", "SBD_BAND_V1", "SBD_LAYER_V1",
-                "SBD_FORCE_EIG_FALLBACK", "SBD_DEBUG_SYNC", "SBD_DBG_FLAGS")
+                "SBD_FORCE_EIG_FALLBACK", "SBD_DEBUG_SYNC", "SBD_DBG_FLAGS", "SBD_NO_FUSE")
 
 
 def main():
@@ -136,6 +258,7 @@ def main():
     ap.add_argument("--nstr", type=int, default=16)
     ap.add_argument("--nlyr", type=int, default=33)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-lines", action="store_true", help="skip the latency case and the other BASELINE shapes")
     args = ap.parse_args()
     on = [k for k in DEV_SWITCHES if os.environ.get(k)]
     if on:   # the headline number is the default path only
@@ -214,6 +337,7 @@ def main():
         eng.solve_device(*d_in, out=(flux, None, status), stream=stream)
         phase_ms += [eng.last_ms(p) for p in range(5)]
     phase_ms /= nrep
+    fallback_layers = int(eng.last_fallback_layers())
     eng.enable_timing(False)
     torch.cuda.synchronize()
 
@@ -263,12 +387,12 @@ def main():
         # separate runs, tools/make_traffic_profile.py) of this command at this launch size
         traffic, traffic_src = None, None
         try:
-            tp = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            tp = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
             key = {"layer_kernel": "layer_kernel2", "band_kernel": "band4_kernel"}.get(names[dom], names[dom])
             if tp.get("nstr") == sw.nstr and tp.get("nlyr") == sw.nlyr and tp.get("solves_per_launch") == pass_size:
                 for kname, kd in tp["kernels"].items():
                     if key in kname:
-                        traffic, traffic_src = kd["bytes_per_launch"], "profiles/r02_traffic.json"
+                        traffic, traffic_src = kd["bytes_per_launch"], "profiles/r03_traffic.json"
         except Exception:
             traffic = None
         flops = algorithmic_flops_per_solve(sw.nlyr, sw.nstr)
@@ -286,18 +410,24 @@ def main():
             "solves_per_s": W * world * args.steps / elapsed,
             "value_incl_h2d": nwl_total * nh / elapsed_h, "ms_per_step_incl_h2d": 1e3 * elapsed_h / nh,
             "incl_h2d_note": "same step through the host entry point (sbd_fleet_solve_host): inputs in pinned host memory, the passes' H2D back to back on a copy stream beside the kernels, sums on the device, D2H of sums + status",
-            "nonzero_status": bad,
+            "nonzero_status": bad, "fallback_layers": fallback_layers,
             "kernel_ms": {names[i]: float(phase_ms[i]) for i in range(5)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
                          "algorithmic_bytes_per_solve": abytes, "solves_per_launch": pass_size,
                          "launches": nlaunch, "avg_launch_ms": float(phase_ms[dom] / nlaunch),
-                         "note": "path is fp64-VALU/LDS/latency bound by construction (SURVEY 8d); "
-                                 "fp64 fraction reported beside it",
-                         "fp64_achieved_tflops": flops * W / (phase_ms.sum() * 1e-3) / 1e12,
-                         "fp64_frac_of_vector_peak": flops * W / (phase_ms.sum() * 1e-3) / 1e12 / FP64_VEC_PEAK_TF},
+                         "note": "latency/issue bound by construction (SURVEY 8d): ~5 KB of inputs per 2.5 MFLOP of "
+                                 "pivoted fp64; the binding figure is valu_issue (executed VALU occupancy), beside it"},
         }
+        out["valu_issue"] = valu_issue(W, elapsed / args.steps, sw.nstr, sw.nlyr)
+        flux_h = flux.cpu().numpy()
+        if world == 1 and not args.no_side_lines:
+            eng.close()
+            del d_in, flux, status
+            torch.cuda.empty_cache()
+            out["latency_case"] = latency_case(local_rank)
+            out["other_shapes"] = other_shapes(dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], allc, idx, ref = cpu_baseline(sw)
             if allc is not None:
@@ -307,7 +437,7 @@ def main():
                 # surface (level 1) -- per solve (fbeam = 1: fluxes per unit incident beam) and for
                 # the spectrally weighted sums of the sample (stdout1's TOPDN..BOTDIR, drt.f:1047-1054)
                 ns = ref.shape[0]
-                g = flux[torch.from_numpy(idx).to(dev)][:, :3, :].cpu().numpy()   # [ns][rfldir, rfldn, flup][top, bot]
+                g = flux_h[idx][:, :3, :]   # [ns][rfldir, rfldn, flup][top, bot]
                 six = lambda a: np.stack([a[:, 1] + a[:, 0], a[:, 2], a[:, 0]], 1).reshape(ns, 6)   # dn, up, dir at top|bot
                 sg, sr = six(g), six(ref)
                 wgt = np.asarray(sw.weight[idx], dtype=np.float64)[:, None]

@@ -278,7 +278,8 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     int status = 0;
     // smallest and largest pivot: the stand-in for SGBCO's condition estimate (errmsg 2, disort.f:3607-3610),
     // see near_singular() in sbd_layer.hpp; lane J sees the pivot of sub-step J
-    double pmin = 1.0e300, pmax = 0.0;
+    // (kept as leading words: lane J remembers the pivot of sub-step J, one select per sub-step; min / max once per step)
+    unsigned pkey = 0u, kpmin = 0x7fffffffu, kpmax = 0u;
     // The NSTR rows that enter with step lc are interface lc's [ga(lc) | gb(lc+1)] with right-hand
     // sides B(nn + (lc-1) n + r), or for lc = ncut the boundary block above beside zeros with B(N-nn+r),
     // r < nn.  They are fetched while step lc-1 is being eliminated: straight into the registers
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     // whose registers come free too late to cover the HBM latency -- through E buffer rows, the
     // right-hand sides as one value per lane (lane r <-> row r) spread by DPP at the hand-over.
     constexpr int E = (n < 4) ? n : 4;
-    double bufa[E], bufb[E], rhsn = 0.0;
+    double bufb[E], rhsn = 0.0;
     // Step lci < ncut: interface lci's rows are [GC(lci) * fa' | GC(lci+1) * fb'] (SETMTX, disort.f:2851-2876)
     // with the STWJ factors fa'(j) = EK(n+1-j, lci) for j > nn (else 1), fb'(j) = -EK(j, lci+1) for j <= nn
     // (else -1).  GC is read from its two independent quarters (Params::gcc: V0(iq,jq) = GC(iq+nn, jq+nn) =
@@ -394,14 +395,14 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             double t0, t1, t2;
             TakeRows<RW, LAST>::run(a0, a1, a2, idxb, t0, t1, t2);
             // register LAST is free from here on: next interface's row LAST - nn moves in
+            // (slot 1 only: slot 0 of an inner step waits in LDS, the bottom-boundary block of the last step is
+            //  read at the hand-over -- once per system, not worth registers in every step)
             if constexpr (LAST - nn >= E) {
-                const double va = row_of(pna, std::integral_constant<int, LAST - nn>{}), vb = row_of(pnb, std::integral_constant<int, LAST - nn>{});
-                a0[LAST] = (n == 16 || col) ? va : 0.0;
+                const double vb = row_of(pnb, std::integral_constant<int, LAST - nn>{});
                 a1[LAST] = (n == 16 || col) ? vb : 0.0;
             }
             if constexpr (J < E) {
-                const double va = row_of(pna, std::integral_constant<int, J>{}), vb = row_of(pnb, std::integral_constant<int, J>{});
-                bufa[J] = (n == 16 || col) ? va : 0.0;
+                const double vb = row_of(pnb, std::integral_constant<int, J>{});
                 bufb[J] = (n == 16 || col) ? vb : 0.0;
             }
             if constexpr (J == 0) {                             // (loads whatever the step is: no branches,
@@ -422,7 +423,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             rn = rn * (2.0 - t0 * rn);
             rn = rn * (2.0 - t0 * rn);
             rn = (t0 != 0.0) ? -rn : 0.0;
-            if (q == J) { pmin = fmin(pmin, fabs(t0)); pmax = fmax(pmax, fabs(t0)); }
+            pkey = (q == J) ? (unsigned)__double2hiint(t0) : pkey;
             // (4) the retired row.  U goes out by layer block: row J of the block holds x_lc's columns in
             //     words 0..n-1 (the finished ones, q < J, carry multipliers nobody reads: masking them out
             //     makes partial-line writes, measured slower) and x_lc+1's in n..2n-1 -- two aligned
@@ -455,7 +456,9 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             //     slot 0 are finished (their registers keep the unscaled multipliers)
             const double rnb = dbl_lane_bcast<J>(rn);
             const double tp1 = rnb * t1, tp2 = rnb * t2;
-            const double tp0 = (q > J) ? rnb * t0 : 0.0;
+            // (no mask on slot 0: the finished columns q <= J then collect garbage instead of keeping the multipliers --
+            //  nobody reads them again; the lanes left of the diagonal are skipped where U is used)
+            const double tp0 = rnb * t0;
 #pragma unroll
             for (int p = 0; p < LAST; ++p) {
                 a1[p] = fmac_lane_bcast<J>(a1[p], a0[p], tp1);
@@ -471,6 +474,11 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
                 }
             }
         });
+        if (col) {
+            const unsigned h = pkey & 0x7fffffffu;
+            kpmin = (h < kpmin) ? h : kpmin;
+            kpmax = (h > kpmax) ? h : kpmax;
+        }
         // ---- the nn rows left over only touch x_lc+1: next step's carry ----
 #pragma unroll
         for (int p = 0; p < nn; ++p) { a0[p] = a1[p]; a1[p] = 0.0; }
@@ -479,20 +487,29 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             for (int k = 0; k < 3; ++k) { F0[k] = F1[k]; F1[k] = 0.0; }
         }
         // ... and the prefetched rows of the next step complete the window, scaled as they arrive
-        const bool inner_next = lc + 1 < ncut;              // slot 0 of the next step: GC(lc+1) from LDS, else what was loaded
+        // slot 0 of the next step: GC(lc+1) from LDS (inner step), the bottom-boundary block (last step, below)
 #pragma unroll
         for (int r = 0; r < E; ++r) {
             const double ga_ = keep[r * 64];
             keep[r * 64] = bufb[r];
-            a0[nn + r] = (inner_next ? ((n == 16 || col) ? ga_ : 0.0) : bufa[r]) * fan;
+            a0[nn + r] = ((n == 16 || col) ? ga_ : 0.0) * fan;
             a1[nn + r] = bufb[r] * fbn;
         }
 #pragma unroll
         for (int r = E; r < n; ++r) {
             const double ga_ = keep[r * 64];
             keep[r * 64] = a1[nn + r];
-            a0[nn + r] = (inner_next ? ((n == 16 || col) ? ga_ : 0.0) : a0[nn + r]) * fan;
+            a0[nn + r] = ((n == 16 || col) ? ga_ : 0.0) * fan;
             a1[nn + r] = a1[nn + r] * fbn;
+        }
+        if (lc + 1 == ncut) {
+            const int qq = col ? q : 0;
+            const RowSrc pbot = {bcb + (qq / nn) * (2 * nn * nn) + (qq % nn), bcb + (qq / nn) * (2 * nn * nn) + (qq % nn) + nn * nn};
+            static_for<n>([&](auto rr) {
+                constexpr int r = decltype(rr)::value;
+                const double va = row_of(pbot, rr);
+                a0[nn + r] = (n == 16 || col) ? va : 0.0;
+            });
         }
         static_for<n>([&](auto rr) {
             constexpr int r = decltype(rr)::value;
@@ -500,12 +517,14 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         });
     }
     {   // errmsg 2: min|pivot| <= 8 N eps max|pivot| over the N pivots of the system (a zero pivot included)
-        double am = pmax, pm = pmin;
+        unsigned ka = kpmax, kp = kpmin;
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) {
-            am = fmax(am, __shfl_xor(am, d, 16));
-            pm = fmin(pm, __shfl_xor(pm, d, 16));
+            const unsigned oa = (unsigned)__shfl_xor((int)ka, d, 16), op = (unsigned)__shfl_xor((int)kp, d, 16);
+            ka = (oa > ka) ? oa : ka;
+            kp = (op < kp) ? op : kp;
         }
+        const double am = __hiloint2double((int)ka, 0), pm = __hiloint2double((int)kp, 0);   // (leading words: 2^-20 relative)
         if (q == 0 && !(pm > 8.0 * N * 2.220446049250313e-16 * am)) status |= 0x01;
     }
     if (status) atomicOr(&svi[SBD_SVI_STATUS], status);

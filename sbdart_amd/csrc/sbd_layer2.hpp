@@ -42,6 +42,13 @@ struct Layer2Lds {   // doubles; per-group part + per-block shared part
         vec = lu + ((nn > 4) ? nn * ldq + nn : 2 * nn * ldq);
         // radiance mode adds zjs, z0s, z1s, psi[2n]
         group_total = (vec + (rad ? 5 * n : 0) + 1) & ~1;
+        // Lane g of a group reads word g of a row: G consecutive doubles.  ds_read_b64 serves 32 lanes per LDS cycle over
+        // 64 dword banks, so the 32 / G groups of a half wave are conflict-free when their bases are 2G dwords apart
+        // (mod 64): group_total = G (mod 32) doubles.  (At 98 doubles -- NSTR 16 -- the four groups of a half wave
+        // overlapped in 12 of their 16 banks: SQ_LDS_BANK_CONFLICT was 56 % of the LDS-active cycles.)
+        int G = 4;
+        while (G < nn) G <<= 1;
+        if (G <= 16) group_total += ((G - group_total) % 32 + 32) % 32;
         shared_y = 0;                       // Y(l, iq) l-major: [n][nn]
         shared_total = (n * nn + 2 * n + 4 * nn + 1) & ~1;   // + R, 1/(M R), 1/W, 1/M tables
     }

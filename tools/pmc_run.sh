@@ -2,7 +2,7 @@
 # rocprofv3 PMC passes (one run per counter set, no tracing) over a short bench run.
 # usage: tools/pmc_run.sh OUTDIR [bench args...]; summary: python tools/pmc_summary.py OUTDIR
 out=${1:-gpurun_out/pmc}; shift
-args=${@:---steps 1 --warmup 0 --nwl 6144 --no-cpu-baseline}
+args=${@:---steps 1 --warmup 0 --nwl 6144 --no-cpu-baseline --no-side-lines}
 cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
 mkdir -p $out
 sets=(
