@@ -62,8 +62,10 @@ extern "C" {
 #define SBD_E_NOMEM         -6
 
 /* ---- per-work-item status bits ---- */
-/* warnings 2/3/4: the reference raises them from LINPACK's RCOND estimate (1+RCOND == 1);
- * this engine raises them on an exactly singular pivot only (no condition estimate). */
+/* warnings 2/3/4: the reference raises them from LINPACK's RCOND estimate (1+RCOND == 1), which needs the L
+ * factor this engine never stores; the engine raises them when min|pivot| <= 8 n eps max|pivot| over the pivots
+ * of the system it factors (an exactly singular pivot included) -- the same regimes, not the same ulp
+ * (tests/test_gpu_parity.py::test_near_singular_systems_raise_the_reference_warnings). */
 #define SBD_ST_WARN_SOLVE0   0x01  /* band matrix singular pivot        (errmsg 2, disort.f:3609) */
 #define SBD_ST_WARN_UPBEAM   0x02  /* beam-source system singular pivot (errmsg 3, disort.f:4227) */
 #define SBD_ST_WARN_UPISOT   0x04  /* thermal-source system singular    (errmsg 4, disort.f:4333) */
@@ -172,6 +174,16 @@ int32_t  sbd_fleet_uses_rccl(const sbd_fleet *f);           /* 1: sums are reduc
 void     sbd_shard_range(int32_t nwork, int32_t nshard, int32_t rank, int32_t *lo, int32_t *hi);
 int      sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_out *out,
                               const double *weight, double *acc_flux, double *acc_uu);
+/* How the devices are fed (replaces nothing in the reference: its loop is serial, drt.f:425-561): every device's
+ * shard is enqueued from a host thread of its own, and when the fleet spans several devices (or SBD_PIN_INPUTS=1)
+ * dtauc / ssalb / pmom are page-locked for the duration of the call, so pageable arrays of the caller do not
+ * serialise the devices.  sbd_fleet_last_enqueue: host clock (seconds since the last call began) around device
+ * i's enqueue and the number of arrays that call page-locked.  sbd_host_alloc / sbd_host_free: page-locked
+ * host memory for a host program's batch arrays (then nothing is registered per call).
+ * SBD_FLEET_RCCL=1 in the environment makes a fleet of ONE device reduce through RCCL too (nranks = 1). */
+int      sbd_fleet_last_enqueue(const sbd_fleet *f, int32_t i, double *t_begin, double *t_end, int32_t *npinned);
+int      sbd_host_alloc(size_t bytes, void **out);
+void     sbd_host_free(void *p);
 
 /* ---- introspection ---- */
 int32_t     sbd_abi_version(void);
@@ -194,6 +206,11 @@ int64_t     sbd_engine_last_fallback_layers(sbd_engine *e);
  * which: 0 gc, 1 kk, 2 ek, 3 zz, 4 zp0, 5 zp1, 6 ll, 7 sv, 8 svi(int32).  Returns bytes copied
  * (<= nbytes) or a negative error. */
 long long   sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t nbytes);
+/* Test hook (NSTR <= 16, all output levels): on != 0 makes the band LU record, per system and elimination
+ * sub-step, the register index of the pivot row it took (which = 15 of sbd_engine_debug_copy, int32 [item x mode]
+ * [NLYR x NSTR]); the test replays the window bookkeeping and compares the ROWS with the ones SGBFA's ISAMAX takes
+ * (disutil.f:852-912, 2060-2072). */
+int         sbd_engine_debug_pivots(sbd_engine *e, int on);
 const char *sbd_strerror(int code);
 const char *sbd_last_error(void);   /* thread-local detail for SBD_E_HIP / SBD_E_INVALID */
 

@@ -1802,6 +1802,7 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
             if (out->dbg_zz) memcpy(out->dbg_zz, w->zz, sizeof(double) * (size_t)n * L);
             if (out->dbg_zplk0) memcpy(out->dbg_zplk0, w->zplk0, sizeof(double) * (size_t)n * L);
             if (out->dbg_zplk1) memcpy(out->dbg_zplk1, w->zplk1, sizeof(double) * (size_t)n * L);
+            if (out->dbg_ipvt) memcpy(out->dbg_ipvt, ipvt, sizeof(int) * (size_t)n * L);   /* SGBFA's pivots of this mode */
         }
         if (in->onlyfl) break;
 
@@ -1813,8 +1814,12 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
             for (int lu = 1; lu <= ntau; ++lu)
                 for (int iu = 1; iu <= numu; ++iu)
                     for (int j = 1; j <= nphi; ++j) UU(iu, lu, j) = F2(uum, numu, iu, lu);
-            if (naz > 0)
-                for (int j = 1; j <= nphi; ++j) phirad[j - 1] = rpd * (in->phi[j - 1] - in->phi0);
+            /* The reference fills PHIRAD only IF( NAZ.GT.0 ) (disort.f:788-795) and INTCOR reads it regardless
+             * (disort.f:2188-2193): with a single azimuth mode -- a sun within 0.26 degrees of the zenith, or one or two
+             * polar viewing angles -- it reads an UNINITIALISED local array (measured with oracle/_ref/disort_ref_cli:
+             * the first element holds stack garbage, the others zeros).  No parity is possible on undefined
+             * behaviour: restatement and engine both take the azimuths the caller passed. */
+            for (int j = 1; j <= nphi; ++j) phirad[j - 1] = rpd * (in->phi[j - 1] - in->phi0);
         } else {
             double azerr = 0.0;
             for (int j = 1; j <= nphi; ++j) {

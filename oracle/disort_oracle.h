@@ -58,6 +58,7 @@ typedef struct {
        zplk1 [nlyr][nstr] */
     int dbg_mode;
     double *dbg_gc, *dbg_kk, *dbg_ll, *dbg_zz, *dbg_zplk0, *dbg_zplk1;
+    int *dbg_ipvt;              /* [nlyr*nstr] SGBFA's pivot rows of that mode's band system, 1-based (disutil.f:852-912) */
 } sbdo_out;
 
 int  sbdo_disort(const sbdo_in *in, sbdo_out *out);

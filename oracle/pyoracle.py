@@ -37,7 +37,8 @@ class _Out(C.Structure):
     _fields_ = [("nstr_out", C.c_int), ("status", C.c_int), ("ntau", C.c_int)] + \
                [(k, _dp) for k in ("rfldir", "rfldn", "flup", "dfdt", "uavg", "uu", "u0c")] + \
                [("dbg_mode", C.c_int)] + \
-               [(k, _dp) for k in ("dbg_gc", "dbg_kk", "dbg_ll", "dbg_zz", "dbg_zplk0", "dbg_zplk1")]
+               [(k, _dp) for k in ("dbg_gc", "dbg_kk", "dbg_ll", "dbg_zz", "dbg_zplk0", "dbg_zplk1")] + \
+               [("dbg_ipvt", C.POINTER(C.c_int))]
 
 
 def build(force: bool = False) -> str:
@@ -121,6 +122,9 @@ def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False, debug_mod
         o.dbg_mode = int(debug_mode)
         for k_, v_ in dbg.items():
             setattr(o, "dbg_" + k_, _p(v_))
+        ipvt = np.zeros(n_ * L_, dtype=np.int32)
+        o.dbg_ipvt = ipvt.ctypes.data_as(C.POINTER(C.c_int))
+        dbg["ipvt"] = ipvt
     st = L.sbdo_disort(C.byref(i), C.byref(o))
     res = dict(status=st, nstr_out=o.nstr_out, rfldir=flx[0], rfldn=flx[1], flup=flx[2],
                dfdt=flx[3], uavg=flx[4])

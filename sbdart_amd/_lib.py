@@ -46,9 +46,9 @@ EXPORTS = (
     "sbd_engine_nlevel", "sbd_engine_workspace_bytes", "sbd_engine_chunk", "sbd_engine_stream",
     "sbd_engine_quadrature", "sbd_engine_last_ms", "sbd_engine_enable_timing", "sbd_engine_last_fallback_layers",
     "sbd_strerror",
-    "sbd_last_error", "sbd_engine_debug_copy",
+    "sbd_last_error", "sbd_engine_debug_copy", "sbd_engine_debug_pivots",
     "sbd_fleet_create", "sbd_fleet_destroy", "sbd_fleet_size", "sbd_fleet_engine", "sbd_fleet_uses_rccl",
-    "sbd_shard_range", "sbd_fleet_solve_host",
+    "sbd_shard_range", "sbd_fleet_solve_host", "sbd_fleet_last_enqueue", "sbd_host_alloc", "sbd_host_free",
 )
 
 _LIB = None
@@ -98,6 +98,8 @@ def load() -> C.CDLL:
     L.sbd_last_error.restype = C.c_char_p
     L.sbd_engine_debug_copy.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.sbd_engine_debug_copy.restype = C.c_longlong
+    L.sbd_engine_debug_pivots.argtypes = [vp, C.c_int]
+    L.sbd_engine_debug_pivots.restype = C.c_int
     L.sbd_fleet_create.argtypes = [C.POINTER(RunCfg), C.c_int32, _ip, C.POINTER(vp)]
     L.sbd_fleet_create.restype = C.c_int
     L.sbd_fleet_destroy.argtypes = [vp]
@@ -112,5 +114,11 @@ def load() -> C.CDLL:
     L.sbd_shard_range.restype = None
     L.sbd_fleet_solve_host.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(BatchOut), vp, vp, vp]
     L.sbd_fleet_solve_host.restype = C.c_int
+    L.sbd_fleet_last_enqueue.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.sbd_fleet_last_enqueue.restype = C.c_int
+    L.sbd_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.sbd_host_alloc.restype = C.c_int
+    L.sbd_host_free.argtypes = [vp]
+    L.sbd_host_free.restype = None
     _LIB = L
     return L

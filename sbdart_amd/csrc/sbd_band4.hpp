@@ -79,7 +79,9 @@ SBD_DEVICE double row_sum16(double v)
 // that pad the bottom-boundary block, scaled by 2^-300 (exact, and they never win a pivot search) and marked by a
 // tag in their unused x_lc+1 slot.  The U factor, the eliminated right-hand side, LL and the whole back-substitution
 // kernel (two thirds of the pipeline's HBM bytes) do not exist in this mode.
-template <int NN, bool FUSED = false>
+// PIVDBG (tests only): the register index of every pivot row goes to Params::pivdbg -- the host replays the window's
+// bookkeeping from it and compares the ROWS chosen with LINPACK's (tests/test_gpu_parity.py::test_pivot_sequence...).
+template <int NN, bool FUSED = false, bool PIVDBG = false>
 __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
 {
     constexpr int n = 2 * NN, nn = NN, RW = nn + n, UW = u_width(n);
@@ -390,6 +392,9 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             }
             const int idx = 31 - (int)(kmax & 31u);
             const int idxb = int_lane_bcast<J>(idx);            // ... to the 16 lanes of the system
+            if constexpr (PIVDBG) {
+                if (q == 0) P.pivdbg[(size_t)ms * L * n + (size_t)(lc - 1) * n + J] = idxb;
+            }
             // (2) pivot row out of its registers, the last live row into them: one pass per
             //     distinct row index among the systems of the wave
             double t0, t1, t2;

@@ -40,6 +40,7 @@ struct Tables {            // per-run constants, device pointers
     const double *ylm0;    // [nmode][n+1]      YLM0(l) at -umu0
     const double *ylmu;    // [nmode][numu][n+1]
     const double *cosmphi; // [nmode][nphi]     cos(m*(phi-phi0)*rpd), row 0 = 1
+    const double *cosphi;  // [nphi]            cos((phi-phi0)*rpd), always filled (INTCOR's scattering angle)
     const double *zeros;   // [n][n] of 0.0 (the x_lc+1 block of the bottom-boundary rows, sbd_band4.hpp)
     const double *tags;    // [nn][nn]: rows 0..2 hold 1, 2, 3 -- marks of the fused band kernel's functional rows
     const double *temper;  // [L+1]
@@ -73,6 +74,7 @@ struct Params {
                             //   nn+1-jq) = [0][iq-1][jq-1] and GC(nn+1-iq, jq+nn) = -GC(iq+nn, nn+1-jq) = [1][iq-1][jq-1]
                             //   (disort.f:3290-3312): what sbd_band4.hpp reads -- half the bytes of GC
     double *gu, *zb, *z0u, *z1u, *uum;
+    int32_t *pivdbg;        // [ms][L*n] register index of each pivot row (band4_kernel<.., PIVDBG>), tests only
     // outputs (offset to the chunk)
     double *flux, *uu; int32_t *status;
 };

@@ -20,7 +20,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sbd_common.hpp"
@@ -197,6 +199,7 @@ struct sbd_engine {
     bool fused = false;             // band4, flux-only, levels = {top of layer 1, surface}: the band kernel carries FLUXES'
                                     // functionals through the elimination -- no U factor, no back-substitution kernel
     bool corint = false;            // intensity corrections after the azimuth series (sbd_intcor.hpp)
+    int32_t *d_pivdbg = nullptr;    // sbd_engine_debug_pivots: [2][chunk * nmode][L * n]
     int64_t fallback_layers = 0;    // timing mode: (item, mode, layer) problems of the last solve left to the QR kernel
 };
 
@@ -231,6 +234,7 @@ void sbd_engine_destroy(sbd_engine *e)
     if (e->d_partial) (void)hipFree(e->d_partial);
     if (e->d_acc) (void)hipFree(e->d_acc);
     if (e->d_red) (void)hipFree(e->d_red);
+    if (e->d_pivdbg) (void)hipFree(e->d_pivdbg);
     for (auto &x : e->ev)
         if (x) (void)hipEventDestroy(x);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -344,6 +348,10 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const size_t o_cmu = push(e->h_cmu.data(), n), o_cwt = push(e->h_cwt.data(), n);
     const size_t o_ylmc = push(ylmc.data(), ylmc.size()), o_ylm0 = push(ylm0.data(), ylm0.size());
     const size_t o_ylmu = push(ylmu.data(), ylmu.size()), o_cos = push(cosm.data(), cosm.size());
+    // cos(phi - phi0) for INTCOR's scattering angle (disort.f:2188-2190): filled whatever the number of azimuth modes
+    std::vector<double> cphi1((size_t)(nphi > 0 ? nphi : 1), 1.0);
+    for (int j = 0; j < nphi; ++j) cphi1[j] = cos((ref_pi() / 180.0) * (cfg->phi[j] - cfg->phi0));
+    const size_t o_cphi = push(cphi1.data(), cphi1.size());
     const size_t o_temper = push(cfg->temper, L + 1);
     double zero = 0.0;
     const size_t o_umu = numu > 0 ? push(cfg->umu, numu) : push(&zero, 1);
@@ -379,6 +387,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->tab.ylm0 = e->d_tab + o_ylm0;
     e->tab.ylmu = e->d_tab + o_ylmu;
     e->tab.cosmphi = e->d_tab + o_cos;
+    e->tab.cosphi = e->d_tab + o_cphi;
     e->tab.zeros = e->d_tab + o_zero;
     e->tab.tags = e->d_tab + o_tags;
     e->tab.temper = e->d_tab + o_temper;
@@ -564,6 +573,24 @@ double sbd_engine_last_ms(sbd_engine *e, int phase)
     return (double)e->ms_phase[phase];
 }
 
+// tests only: the four-per-wave band LU records the register index of every pivot row (NSTR <= 16, stored-factor path)
+int sbd_engine_debug_pivots(sbd_engine *e, int on)
+{
+    if (!e) return SBD_E_INVALID;
+    if (!e->band4 || e->fused) return fail(SBD_E_INVALID, "pivot record: NSTR <= 16 and the stored-factor path only");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (on && !e->d_pivdbg) {
+        const size_t cnt = (size_t)2 * e->chunk * e->nmode * e->L * e->n;
+        HIP_TRY(hipMalloc(&e->d_pivdbg, sizeof(int32_t) * cnt));
+        HIP_TRY(hipMemset(e->d_pivdbg, 0xff, sizeof(int32_t) * cnt));
+    } else if (!on && e->d_pivdbg) {
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(e->d_pivdbg);
+        e->d_pivdbg = nullptr;
+    }
+    return SBD_OK;
+}
+
 long long sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t nbytes)
 {
     if (!e || !host_buf) return SBD_E_INVALID;
@@ -586,6 +613,7 @@ long long sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t
     case 12: src = e->P.z1u; bytes = 8 * nms * L * e->P.numu; break;
     case 13: src = e->P.eiglist; bytes = 4 * 64; break;     // count + first entries of the fallback list (first workspace)
     case 14: src = e->P2.eiglist; bytes = 4 * 64; break;    // ... second workspace
+    case 15: src = e->d_pivdbg; bytes = e->d_pivdbg ? 4 * nms * L * n : 0; break;   // pivot register indices (first workspace)
     default: return SBD_E_INVALID;
     }
     if (bytes > nbytes) bytes = nbytes;
@@ -716,7 +744,10 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         if (timing) HIP_TRY(hipEventRecord(e->ev[2], st));
         {
             const unsigned bgrid = (unsigned)((size_t)ns * nmode);
-            if (e->band4) sbd::launch_band4(e->nn, (bgrid + 3) / 4, st, P, e->fused);
+            if (e->band4 && e->d_pivdbg) {
+                P.pivdbg = e->d_pivdbg + (second ? (size_t)e->chunk * nmode * L * n : 0);
+                sbd::launch_band4_pivdbg(e->nn, (bgrid + 3) / 4, st, P);
+            } else if (e->band4) sbd::launch_band4(e->nn, (bgrid + 3) / 4, st, P, e->fused);
             else if (e->band1) sbd::launch_band1(e->nn, bgrid, st, P);
             else if (e->band_reg) sbd::launch_band_reg(e->nn, bgrid, e->band_lds, st, P);
             else sbd::launch_band_lds(e->nn, bgrid, e->band_lds, st, P);
@@ -966,7 +997,9 @@ struct sbd_fleet {
     std::vector<sbd_engine *> eng;
     std::vector<ncclComm_t> comm;     // empty: host-side sum
     std::vector<double> hacc;         // [ndev][nel] staging of the host-side sum
+    std::vector<double> t_enq;        // [ndev][2] host clock (s since the call began) around each device's enqueue
     int retry_nstr = 0;
+    int pinned_last = 0;              // arrays of the last call that were page-locked for its duration
 };
 
 void sbd_shard_range(int32_t nwork, int32_t nshard, int32_t rank, int32_t *lo, int32_t *hi)
@@ -1015,7 +1048,10 @@ int sbd_fleet_create(const sbd_run_cfg *cfg, int32_t ndev, const int32_t *device
         else if (rc != SBD_OK) { sbd_fleet_destroy(f); return rc; }
         f->eng.push_back(e);
     }
-    bool distinct = dev.size() > 1;
+    // (SBD_FLEET_RCCL=1: a communicator also for a fleet of ONE device -- nranks = 1 is legal -- so that the
+    //  collective path, dlopen to teardown, runs under test on a one-GPU box)
+    const char *force = getenv("SBD_FLEET_RCCL");
+    bool distinct = dev.size() > 1 || (force && atoi(force) != 0);
     for (size_t i = 0; i < dev.size(); ++i)
         for (size_t j = i + 1; j < dev.size(); ++j)
             if (dev[i] == dev[j]) distinct = false;
@@ -1046,14 +1082,63 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
     for (int r = 0; r < nd; ++r) {
         int32_t lo, hi;
         sbd_shard_range(in->nwork, nd, r, &lo, &hi);
-        if (hi <= lo) continue;
-        sbd_batch_in si = {hi - lo, in->dtauc + (size_t)lo * L, in->ssalb + (size_t)lo * L, in->pmom + (size_t)lo * L * nmom1,
-                           in->wvnmlo + lo, in->wvnmhi + lo, in->fbeam + lo, in->albedo + lo, in->plank + lo};
-        sbd_batch_out so = {out->flux ? out->flux + (size_t)lo * nel_f : nullptr,
-                            (rad && out->uu) ? out->uu + (size_t)lo * uu_item : nullptr, out->status + lo};
-        const int rc = solve_host_enqueue(f->eng[r], &si, &so, weight ? weight + lo : nullptr);
-        if (rc != SBD_OK) return rc;
-        busy.push_back(r);
+        if (hi > lo) busy.push_back(r);
+    }
+    // The caller's arrays are usually pageable (a Fortran ALLOCATE): a hipMemcpyAsync from them is staged by the
+    // runtime and returns when the copy is done, so ONE enqueueing thread would feed the devices one after another
+    // (0.67 GB per device and step at the bench's size, far more than the 10 ms of compute).  Two measures:
+    //  * every device's shard is enqueued from a host thread of its own -- the devices' copies and kernels overlap
+    //    whatever the memory is;
+    //  * for a fleet of several devices (or SBD_PIN_INPUTS=1) the three large input arrays are page-locked for the
+    //    duration of the call (hipHostRegister, portable): the copies become DMA at PCIe speed from any device.
+    struct PinGuard {                                   // (unregistered on every way out of the call)
+        std::vector<void *> p;
+        ~PinGuard() { for (void *x : p) (void)hipHostUnregister(x); }
+    } pins;
+    std::vector<void *> &pinned = pins.p;
+    {
+        const char *pe = getenv("SBD_PIN_INPUTS");
+        const size_t big = sizeof(double) * (size_t)in->nwork * L * nmom1;
+        const bool pin = pe ? atoi(pe) != 0 : (busy.size() > 1 && big >= ((size_t)32 << 20));
+        if (pin) {
+            const std::pair<const void *, size_t> arr[3] = {{in->dtauc, sizeof(double) * (size_t)in->nwork * L},
+                                                            {in->ssalb, sizeof(double) * (size_t)in->nwork * L}, {in->pmom, big}};
+            for (const auto &a : arr) {
+                if (hipHostRegister((void *)a.first, a.second, hipHostRegisterPortable) == hipSuccess) pinned.push_back((void *)a.first);
+                else (void)hipGetLastError();          // (already registered -- PyTorch pinned memory -- or not registrable)
+            }
+        }
+        f->pinned_last = (int)pinned.size();
+    }
+    f->t_enq.assign((size_t)nd * 2, 0.0);
+    {
+        const auto t_begin = std::chrono::steady_clock::now();
+        std::vector<int> rcs(nd, SBD_OK);
+        std::vector<std::string> errs(nd);
+        auto enqueue = [&](const int r) {
+            int32_t lo, hi;
+            sbd_shard_range(in->nwork, nd, r, &lo, &hi);
+            sbd_batch_in si = {hi - lo, in->dtauc + (size_t)lo * L, in->ssalb + (size_t)lo * L, in->pmom + (size_t)lo * L * nmom1,
+                               in->wvnmlo + lo, in->wvnmhi + lo, in->fbeam + lo, in->albedo + lo, in->plank + lo};
+            sbd_batch_out so = {out->flux ? out->flux + (size_t)lo * nel_f : nullptr,
+                                (rad && out->uu) ? out->uu + (size_t)lo * uu_item : nullptr, out->status + lo};
+            f->t_enq[2 * r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+            rcs[r] = solve_host_enqueue(f->eng[r], &si, &so, weight ? weight + lo : nullptr);
+            if (rcs[r] != SBD_OK) errs[r] = g_last_error;          // (thread-local: carried to the caller below)
+            f->t_enq[2 * r + 1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        };
+        if (busy.size() > 1) {
+            std::vector<std::thread> th;
+            for (int r : busy) th.emplace_back(enqueue, r);
+            for (auto &t : th) t.join();
+        } else if (!busy.empty()) {
+            enqueue(busy[0]);
+        }
+        for (int r : busy)
+            if (rcs[r] != SBD_OK) {
+                for (int q : busy) { (void)hipSetDevice(f->eng[q]->cfg.device); (void)hipStreamSynchronize(f->eng[q]->stream); }
+                return fail(rcs[r], errs[r]);
+            }
     }
     if (weight) {
         if (!f->comm.empty() && (int)busy.size() == nd) {
@@ -1089,5 +1174,30 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
     }
     return SBD_OK;
 }
+
+// host clock around device i's enqueue in the last sbd_fleet_solve_host (seconds since that call began), and how
+// many of the caller's arrays were page-locked for it: introspection for the multi-device tests
+int sbd_fleet_last_enqueue(const sbd_fleet *f, int32_t i, double *t_begin, double *t_end, int32_t *npinned)
+{
+    if (!f || i < 0 || (size_t)(2 * i + 1) >= f->t_enq.size()) return SBD_E_INVALID;
+    if (t_begin) *t_begin = f->t_enq[2 * i];
+    if (t_end) *t_end = f->t_enq[2 * i + 1];
+    if (npinned) *npinned = f->pinned_last;
+    return SBD_OK;
+}
+
+// page-locked host memory for the batch arrays of a host program (the Fortran host allocates its batch here, so
+// that every H2D of sbd_fleet_solve_host is a DMA from the start and nothing has to be registered per call)
+int sbd_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return SBD_E_INVALID;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(SBD_E_NOMEM, "hipHostMalloc");
+    }
+    return SBD_OK;
+}
+void sbd_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 }  // extern "C"

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) intcor_kernel(Params P, int naz_run)
             const int pc = t / ncut, lc = t % ncut;
             const int pair = p0 + pc, iu = pair / nphi, jp = pair % nphi;
             const double umu = P.t.umu[iu];
-            const double cphi = (naz_run > 0) ? P.t.cosmphi[(size_t)1 * nphi + jp] : 1.0;   // cos(phi - phi0)
+            const double cphi = P.t.cosphi[jp];                                  // cos(phi - phi0), disort.f:2188-2190
             const double ctheta = -umu0 * umu + sqrt((1.0 - umu0 * umu0) * (1.0 - umu * umu)) * cphi;
             const double *pm = pmom + (size_t)lc * (nmom + 1);
             const double f = flyr[lc];
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) intcor_kernel(Params P, int naz_run)
             double corr = ussndm - ussp;
             // second-order term: only looking up (umu < 0) within 10 degrees of the beam, not at the top
             if (umu < 0.0 && fabs(acos(-umu0) / rpd - acos(umu) / rpd) <= 10.0 && !(lev == 0 && tauc[0] <= dither)) {
-                const double cphi = (naz_run > 0) ? P.t.cosmphi[(size_t)1 * nphi + jp] : 1.0;
+                const double cphi = P.t.cosphi[jp];
                 const double ctheta = -umu0 * umu + sqrt((1.0 - umu0 * umu0) * (1.0 - umu * umu)) * cphi;
                 const double utau = tauc[lev];
                 const double zero = (double)1e-4f;

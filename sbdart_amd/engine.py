@@ -130,6 +130,20 @@ class DisortEngine:
         return int(self._L.sbd_engine_last_fallback_layers(self._h))
 
     # ---- the hot path ----
+    def debug_pivots(self, on: bool = True):
+        """Test hook: record the band LU's pivot choices (NSTR <= 16, all output levels)."""
+        rc = self._L.sbd_engine_debug_pivots(self._h, int(on))
+        if rc != _lib.OK:
+            raise SbdError(rc, "sbd_engine_debug_pivots")
+
+    def debug_array(self, which: int, dtype, count: int):
+        """Test hook: `count` elements of workspace array `which` (sbd_engine_debug_copy) of the last pass."""
+        buf = np.zeros(count, dtype=dtype)
+        got = self._L.sbd_engine_debug_copy(self._h, which, buf.ctypes.data_as(C.c_void_p), buf.nbytes)
+        if got < 0:
+            raise SbdError(int(got), "sbd_engine_debug_copy")
+        return buf[: got // buf.itemsize]
+
     def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank):
         """Solve a batch.  Shapes: dtauc/ssalb [W, nlyr]; pmom [W, nlyr, nmom+1];
         wvnmlo/wvnmhi/fbeam/albedo [W]; plank [W] bool.  Returns (flux[W,5,nlev],
@@ -238,6 +252,18 @@ class DisortFleet(DisortEngine):
     @property
     def uses_rccl(self) -> bool:
         return bool(self._L.sbd_fleet_uses_rccl(self._h))
+
+    def last_enqueue(self):
+        """Per device (begin, end) of its enqueue in the last solve, host seconds since that call began, and the
+        number of input arrays the call page-locked."""
+        t0, t1, npin = C.c_double(), C.c_double(), C.c_int32()
+        out = []
+        for i in range(self.size):
+            rc = self._L.sbd_fleet_last_enqueue(self._h, i, C.byref(t0), C.byref(t1), C.byref(npin))
+            if rc != _lib.OK:
+                raise SbdError(rc, "sbd_fleet_last_enqueue")
+            out.append((t0.value, t1.value))
+        return out, npin.value
 
     def shard_range(self, nwork: int, rank: int):
         lo, hi = C.c_int32(), C.c_int32()

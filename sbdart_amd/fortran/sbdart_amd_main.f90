@@ -76,6 +76,12 @@ program sbdart_amd
   real(kr), allocatable :: btemper(:)
   integer(kind=8) :: tick0, tick1, tick2, tick_rate
   character(len=256) :: why
+  ! the run's GPUs and the fleets created so far (stream count x intensity corrections)
+  integer(c_int32_t), allocatable, target :: devices(:)
+  type(c_ptr) :: fleets(6)
+  integer :: fleet_ns(6), nfleet = 0
+  logical :: fleet_corr(6)
+  integer(c_int) :: fleet_rc(6)
 
   ! ---- read ./INPUT exactly like drt.f:220-231 ----
   open(newunit=u11, file='INPUT', status='old', iostat=ios)
@@ -294,6 +300,7 @@ program sbdart_amd
   call solve_part(1, ncorr, .true., corint)
   call solve_part(ncorr + 1, nbeam, .true., .false.)
   call solve_part(nbeam + 1, npart, .false., .false.)
+  call release_fleets()
   call system_clock(tick2)
   call get_environment_variable('SBD_TIMING', path, plen, pstat)
   if (pstat == 0 .and. plen > 0) write(0, '(a,f9.4,a,i0,a,f9.4,a)') 'sbdart_amd: batch assembly ', &
@@ -323,7 +330,9 @@ program sbdart_amd
     if (any(pmom(nmom, :, 1:npart) > real(1.e-3, kr))) &
       call warn_file(5, 'CHEKIN-- phase function not sufficiently resolved for use with corint=.true.')
   end if
-  if (radcalc .and. nbeam > 0 .and. .not. corint) & ! CHEKIN warning 7 (disort.f:5154-5158)
+  ! CHEKIN warning 7 (disort.f:5154-5158, 5169): every beam call whose CORINT argument is false -- the namelist's
+  ! value, or the one DISORT switched off in place at an earlier beamless call (corint_history: items ncorr+1..nbeam)
+  if (radcalc .and. nbeam > 0 .and. (.not. corint .or. nbeam > ncorr)) &
     call warn_file(7, 'CHEKIN--intensity correction is off; intensities may be less accurate')
 
   ! ---- output ----
@@ -352,7 +361,20 @@ program sbdart_amd
     end do
   else
     ! one record per run: the engine's reduced sums; the equivalent width from the last k-term of each point
-    call sums_from_engine(sums, fmt, acc_flux, acc_uu, lev_top, lev_bot, view%uzen)
+    ! (the engine adds per part -- corrected beam items, other beam items, beamless items -- and per device shard:
+    !  the association of the sums, hence their last bits, follows the part split and the number of GPUs.
+    !  SBD_ORDERED_SUMS=1 adds the per-item outputs here instead, in the reference's wavelength order
+    !  (drt.f:964-1054): bit-reproducible on any number of devices)
+    call get_environment_variable('SBD_ORDERED_SUMS', path, plen, pstat)
+    if (pstat == 0 .and. plen > 0 .and. path(1:1) /= '0') then
+      do i = 1, nrec
+        ip = where_solved(i)
+        if (ip > 0) call sums_add_item(sums, fmt, weight(ip), flux(:, 1:3, ip), lev_top, lev_bot, &
+                                       uu(:, :, :, merge(ip, 1, radcalc)), view%uzen)
+      end do
+    else
+      call sums_from_engine(sums, fmt, acc_flux, acc_uu, lev_top, lev_bot, view%uzen)
+    end if
     do i = 1, nrec
       if (recs(i)%kd == recs(i)%nk) then
         dwl = 10000._kr/recs(i)%wvnmlo - 10000._kr/recs(i)%wvnmhi
@@ -493,11 +515,86 @@ contains
     k = m(1)
   end function
 
-  ! solve batch positions p0..p1 on every visible GPU; per-run formats also get their weighted sums
+  ! The GPUs of the run.  Default: device 0 -- one process, one GPU, sums on that device.  SBD_DEVICES=all takes
+  ! every visible device (contiguous spectral shards, one RCCL reduce of the sums); SBD_DEVICES=0,2,3 a list.
+  subroutine pick_devices()
+    character(len=256) :: txt
+    integer :: tlen, tstat, k, ios, pos, nxt
+    if (allocated(devices)) return
+    call get_environment_variable('SBD_DEVICES', txt, tlen, tstat)
+    if (tstat /= 0 .or. tlen <= 0) then
+      allocate(devices(1)); devices(1) = 0
+      return
+    end if
+    if (trim(adjustl(txt(1:tlen))) == 'all' .or. trim(adjustl(txt(1:tlen))) == 'ALL') then
+      allocate(devices(0))                             ! (zero-length: sbd_fleet_create's "every visible device")
+      return
+    end if
+    k = 1
+    do pos = 1, tlen
+      if (txt(pos:pos) == ',') k = k + 1
+    end do
+    allocate(devices(k))
+    pos = 1
+    do k = 1, size(devices)
+      nxt = index(txt(pos:tlen), ',')
+      if (nxt == 0) nxt = tlen - pos + 2
+      read(txt(pos:pos + nxt - 2), *, iostat=ios) devices(k)
+      if (ios /= 0) call fatal('SBD_DEVICES: expected "all" or a comma-separated list of device ordinals')
+      pos = pos + nxt
+    end do
+  end subroutine
+
+  ! the fleet for stream count ns with / without the intensity corrections: created once per run and reused by
+  ! the parts that ask for the same pair (engines, workspaces and the communicator are the expensive part of a
+  ! small run); rc as sbd_fleet_create returned it the first time
+  function fleet_for(ns, corr, rc) result(fl)
+    integer, intent(in) :: ns
+    logical, intent(in) :: corr
+    integer(c_int), intent(out) :: rc
+    type(c_ptr) :: fl
+    type(sbd_run_cfg) :: cfg
+    integer :: k
+    do k = 1, nfleet
+      if (fleet_ns(k) == ns .and. (fleet_corr(k) .eqv. corr)) then
+        fl = fleets(k); rc = fleet_rc(k)
+        return
+      end if
+    end do
+    call pick_devices()
+    cfg%abi_version = SBD_ABI_VER
+    cfg%nlyr = nz; cfg%nstr = ns; cfg%nmom = nmom
+    cfg%onlyfl = merge(0, 1, radcalc); cfg%lamber = 1; cfg%usrang = merge(1, 0, radcalc)
+    cfg%numu = numu; cfg%nphi = merge(view%nphi, 0, radcalc)
+    cfg%nlevel_out = nlev; cfg%device = 0; cfg%max_batch = max(1, npart)
+    cfg%corint = merge(1, 0, corr)
+    cfg%umu0 = recs(1)%umu0; cfg%phi0 = phi0; cfg%fisot = fisot
+    cfg%btemp = btemp; cfg%ttemp = ttemp; cfg%temis = temis
+    cfg%temper = c_loc(temper); cfg%umu = c_loc(umu); cfg%phi = c_loc(phiv)
+    cfg%level_out = c_loc(level_out)
+    if (size(devices) == 0) then
+      rc = sbd_fleet_create(cfg, 0, c_null_ptr, fl)
+    else
+      rc = sbd_fleet_create(cfg, int(size(devices), c_int32_t), c_loc(devices), fl)
+    end if
+    if (rc /= SBD_OK .and. rc /= SBD_E_RETRY_NSTR) &
+      call fatal('sbd_fleet_create: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
+    nfleet = nfleet + 1
+    fleets(nfleet) = fl; fleet_ns(nfleet) = ns; fleet_corr(nfleet) = corr; fleet_rc(nfleet) = rc
+  end function
+
+  subroutine release_fleets()
+    integer :: k
+    do k = 1, nfleet
+      call sbd_fleet_destroy(fleets(k))
+    end do
+    nfleet = 0
+  end subroutine
+
+  ! solve batch positions p0..p1 on the run's GPUs; per-run formats also get their weighted sums
   subroutine solve_part(p0, p1, beam, corrections)
     integer, intent(in) :: p0, p1
     logical, intent(in) :: beam, corrections
-    type(sbd_run_cfg) :: cfg
     type(sbd_batch_in) :: bin
     type(sbd_batch_out) :: bout
     type(c_ptr) :: fleet, wptr, aptr, uptr
@@ -509,26 +606,12 @@ contains
       ns = nstr + ntry*(3*ntry - 5)                    ! nstr, nstr-2, nstr+2
       if (ns < 4) cycle
       if (ns > nstrms) exit
-      cfg%abi_version = SBD_ABI_VER
-      cfg%nlyr = nz; cfg%nstr = ns; cfg%nmom = nmom
-      cfg%onlyfl = merge(0, 1, radcalc); cfg%lamber = 1; cfg%usrang = merge(1, 0, radcalc)
-      cfg%numu = numu; cfg%nphi = merge(view%nphi, 0, radcalc)
-      cfg%nlevel_out = nlev; cfg%device = 0; cfg%max_batch = p1 - p0 + 1
-      cfg%corint = merge(1, 0, corrections .and. radcalc .and. beam) ! (off without a beam, disort.f:2695)
-      cfg%umu0 = recs(1)%umu0; cfg%phi0 = phi0; cfg%fisot = fisot
-      cfg%btemp = btemp; cfg%ttemp = ttemp; cfg%temis = temis
-      cfg%temper = c_loc(temper); cfg%umu = c_loc(umu); cfg%phi = c_loc(phiv)
-      cfg%level_out = c_loc(level_out)
-      rc = sbd_fleet_create(cfg, 0, c_null_ptr, fleet)
+      fleet = fleet_for(ns, corrections .and. radcalc .and. beam, rc)   ! (corrections off without a beam, disort.f:2695)
       if (rc == SBD_OK) exit
-      if (rc == SBD_E_RETRY_NSTR) then
-        call warn_file(1, 'SETDIS--beam angle=computational angle; change NSTR')
-        if (.not. beam) exit                           ! without a beam the angle does not matter
-        call sbd_fleet_destroy(fleet)
-        fleet = c_null_ptr
-        cycle
-      end if
-      call fatal('sbd_fleet_create: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
+      ! rc == SBD_E_RETRY_NSTR: SETDIS tests the beam angle only when there is a beam (disort.f:2641-2650)
+      if (.not. beam) exit
+      call warn_file(1, 'SETDIS--beam angle=computational angle; change NSTR')
+      fleet = c_null_ptr
     end do
     if (.not. c_associated(fleet)) then
       write(*, *) 'Error --- NSTR dithering procedure failed'
@@ -548,6 +631,5 @@ contains
     end if
     rc = sbd_fleet_solve_host(fleet, bin, bout, wptr, aptr, uptr)
     if (rc /= SBD_OK) call fatal('sbd_fleet_solve_host: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
-    call sbd_fleet_destroy(fleet)
   end subroutine
 end program sbdart_amd

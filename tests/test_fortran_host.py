@@ -121,8 +121,22 @@ def _compare_stdout(got, want, max_off_by_one=None):
         assert abs(fa - fb) <= 1.0001 * unit, (a, b)
         off += 1
     limit = max(2, int(0.002 * len(nums))) if max_off_by_one is None else max_off_by_one
+    _record_token_count(len(nums), off)
     assert off <= limit, f"{off} tokens differ in the last printed digit (limit {limit} of {len(nums)})"
     return off
+
+
+def _record_token_count(ntok, off):
+    """One line per stdout comparison into gpurun_out/stdout_tokens.jsonl (copied to profiles/ per round): which test,
+    how many numeric tokens, how many of them one unit off in the last printed digit."""
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        name = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+        with open(os.path.join(out, "stdout_tokens.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, "numeric_tokens": ntok, "one_unit_off": off}) + "\n")
+    except OSError:
+        pass
 
 
 def _runs(recs):
@@ -165,7 +179,7 @@ CAPTURE = os.path.join(ROOT, "oracle", "_ref", "sbdart_capture")
 needs_ref = pytest.mark.skipif(not os.access(CAPTURE, os.X_OK), reason="oracle/_ref not built")
 
 
-def run_reference_and_host(namelist, d, sums=False, from_input=False, files=None):
+def run_reference_and_host(namelist, d, sums=False, from_input=False, files=None, host_env=None):
     """In directory d: the reference (capture build: unmodified objects, DISORT call site recorded)
     on this INPUT, then the host -- on the optics the reference just used, or (from_input) on INPUT
     alone through its own band model.  Returns (reference stdout, host stdout, path of the captured
@@ -184,6 +198,7 @@ def run_reference_and_host(namelist, d, sums=False, from_input=False, files=None
         env = dict(os.environ, SBD_OPTICS=os.path.join(d, "no-optics-file"), SBD_ATMOS=os.path.join(d, "no-atm-file"))
     if sums:
         env["SBD_SUMS_FILE"] = os.path.join(d, "sums.txt")
+    env.update(host_env or {})
     p = subprocess.run([HOST], cwd=d, env=env, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     if sums:
@@ -347,3 +362,24 @@ def test_diverse_inputs_from_input_alone(tmp_path, namelist):
     ref, got, _ = run_reference_and_host(namelist, str(tmp_path), from_input=True)
     off = _compare_stdout(got, ref)
     print(f"{len(ref.split())} tokens, {off} one unit off in the last printed digit", file=sys.stderr)
+
+
+@pytest.mark.gpu
+@needs_flang
+@needs_ref
+def test_device_list_and_ordered_sums(tmp_path):
+    """SBD_DEVICES picks the run's GPUs (default: device 0; here the one GPU of the box listed three times, which
+    shards the batch three ways).  The engine's reduced sums follow the shard split in their last bits;
+    SBD_ORDERED_SUMS=1 adds the per-item outputs on the host in wavelength order instead and must give the SAME
+    bits whatever the device list -- and the printed record is the reference's either way."""
+    _build()
+    nl = " idatm=4 isat=0 wlinf=.3 wlsup=3.0 wlinc=.02 nstr=8 sza=50 tcloud=4 zcloud=1 iout=10"
+    runs = {}
+    for tag, env in (("default", {}), ("three", {"SBD_DEVICES": "0,0,0"}),
+                     ("ordered1", {"SBD_ORDERED_SUMS": "1"}), ("ordered3", {"SBD_ORDERED_SUMS": "1", "SBD_DEVICES": "0,0,0"})):
+        ref, got, _, sums = run_reference_and_host(nl, str(tmp_path / tag), sums=True, from_input=True, host_env=env)
+        _compare_stdout(got, ref)
+        runs[tag] = sums
+    assert np.array_equal(runs["ordered1"], runs["ordered3"])
+    assert np.allclose(runs["default"], runs["ordered1"], rtol=1e-12, atol=0)
+    assert np.allclose(runs["three"], runs["ordered1"], rtol=1e-12, atol=0)

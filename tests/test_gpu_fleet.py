@@ -71,3 +71,56 @@ def test_host_entry_point_with_growing_batches():
     assert np.isfinite(f_big).all() and (s_big == 0).all()
     assert np.array_equal(f_small, f_big[:37]) and np.array_equal(f_again, f_small)
     assert np.array_equal(s_small, s_big[:37]) and np.array_equal(s_again, s_small)
+
+
+def test_fleet_feeds_its_devices_from_one_thread_each():
+    """A pageable batch (numpy arrays: like a Fortran ALLOCATE) on the device list [0, 0, 0]: the three shards are
+    enqueued from a host thread each and the large input arrays are page-locked for the call, so no device waits
+    for another's staging.  The enqueue intervals (host clock, sbd_fleet_last_enqueue) must overlap -- with one
+    enqueueing thread they would follow each other -- and the answers stay bitwise those of a single engine."""
+    from sbdart_amd.engine import DisortEngine, DisortFleet
+    from sbdart_amd.workload import sw_sweep
+    sw = sw_sweep(nwl=9000, nstr=16, nlyr=33, seed=31)         # ~24 000 solves, 0.12 GB of pageable inputs
+    ins = (sw.dtauc, sw.ssalb, sw.pmom, sw.wvnmlo, sw.wvnmhi, sw.fbeam, sw.albedo, sw.plank)
+    kw = dict(nlyr=sw.nlyr, nstr=sw.nstr, nmom=sw.nmom, temper=sw.temper, umu0=sw.umu0, btemp=sw.btemp,
+              ttemp=sw.ttemp, temis=sw.temis, onlyfl=True, level_out=[0, sw.nlyr])
+    with DisortEngine(device=0, **kw) as one:
+        f1, _, s1 = one.solve(*ins)
+    with DisortFleet(devices=[0, 0, 0], **kw) as fl:
+        f2, _, s2, acc, _ = fl.solve(*ins, weight=sw.weight)
+        spans, npinned = fl.last_enqueue()
+        f3, _, s3, acc3, _ = fl.solve(*ins, weight=sw.weight)   # (registered and released again: same answers)
+    assert np.array_equal(f1, f2) and np.array_equal(s1, s2) and np.array_equal(f2, f3) and np.array_equal(acc, acc3)
+    assert npinned == 3, npinned
+    assert len(spans) == 3 and all(e > b for b, e in spans)
+    latest_begin, earliest_end = max(b for b, _ in spans), min(e for _, e in spans)
+    assert latest_begin < earliest_end, spans                   # every device was being fed at the same time
+    assert np.allclose(acc, np.einsum("i,icl->cl", sw.weight, f1), rtol=1e-12, atol=1e-300)
+
+
+def test_rccl_reduce_path_on_one_device():
+    """SBD_FLEET_RCCL=1: a fleet of ONE device takes the collective path -- librccl dlopen()ed, ncclCommInitAll
+    over [0] (nranks = 1), the grouped ncclReduce(sum, double) of the accumulator block into d_red, its D2H, the
+    communicator's teardown -- which a one-GPU box otherwise never executes.  Sums and items must equal the
+    host-side-sum fleet's bit for bit."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    code = ("import numpy as np,json;from sbdart_amd.engine import DisortFleet;from sbdart_amd.workload import sw_sweep;"
+            "sw=sw_sweep(nwl=600,nstr=16,nlyr=33,seed=5);"
+            "kw=dict(nlyr=sw.nlyr,nstr=sw.nstr,nmom=sw.nmom,temper=sw.temper,umu0=sw.umu0,btemp=sw.btemp,ttemp=sw.ttemp,"
+            "temis=sw.temis,onlyfl=True,level_out=[0,sw.nlyr]);"
+            "fl=DisortFleet(devices=[0],**kw);"
+            "f,_,s,acc,_=fl.solve(sw.dtauc,sw.ssalb,sw.pmom,sw.wvnmlo,sw.wvnmhi,sw.fbeam,sw.albedo,sw.plank,weight=sw.weight);"
+            "f2,_,s2,acc2,_=fl.solve(sw.dtauc,sw.ssalb,sw.pmom,sw.wvnmlo,sw.wvnmhi,sw.fbeam,sw.albedo,sw.plank,weight=sw.weight);"
+            "r=fl.uses_rccl;fl.close();"
+            "print(json.dumps(dict(rccl=bool(r),acc=acc.tolist(),acc2=acc2.tolist(),fsum=float(np.abs(f).sum()),bad=int((s!=0).sum()))))")
+    res = {}
+    for flag in ("0", "1"):
+        p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, text=True, capture_output=True,
+                           env=dict(os.environ, SBD_FLEET_RCCL=flag, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"rccl"')]      # (RCCL may print banners of its own)
+        assert p.returncode == 0 and lines, (flag, p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+        res[flag] = json.loads(lines[-1])
+    assert res["0"]["rccl"] is False and res["1"]["rccl"] is True
+    assert res["1"]["bad"] == 0
+    assert res["1"]["acc"] == res["0"]["acc"] and res["1"]["acc2"] == res["1"]["acc"] and res["1"]["fsum"] == res["0"]["fsum"]

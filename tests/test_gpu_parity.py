@@ -376,7 +376,7 @@ def test_fuzz_all_stream_counts_and_layer_counts(seed):
            [recs[i][0] for i in easy], [recs[i][1] for i in easy])
     tough = [i for i, h in enumerate(hard) if h]
     _check([flux[i] for i in tough], [uu[i] for i in tough], [st[i] for i in tough],
-           [recs[i][0] for i in tough], [recs[i][1] for i in tough], tol=1e-4)
+           [recs[i][0] for i in tough], [recs[i][1] for i in tough], tol=8e-5)   # (measured <= 5.1e-5)
 
 
 def test_result_independent_of_batch_neighbours():
@@ -462,11 +462,200 @@ def test_intensity_corrections_against_oracle():
                                 phi0=10.0, albedo=float(rng.uniform(0, 0.8)), btemp=290.0, ttemp=0.0, temis=0.0,
                                 dtauc=dt, ssalb=w, temper=np.linspace(220.0, 290.0, L + 1), pmom=pm,
                                 umu=umu, phi=np.array([10.0, 70.0, 190.0])))
+    # a sun 0.2 degrees off the zenith: |1 - umu0| < 1e-5 leaves one azimuth mode (disort.f:577-586), yet INTCOR's
+    # scattering angle keeps its cos(phi - phi0) term, sqrt(1 - umu0^2) = 3.5e-3 (a forward peak of 299 moments sees it)
+    for phis in ([10.0, 70.0, 190.0], [100.0]):
+        g = np.array([0.85, 0.9, 0.8])
+        recs.append(SolveRecord(nlyr=3, nstr=8, nmom=299, flags=F_LAMBER | F_USRANG | F_CORINT,
+                                wvnmlo=10000.0, wvnmhi=10100.0, fbeam=2.0, umu0=float(np.cos(np.deg2rad(0.2))),
+                                phi0=10.0, albedo=0.1, btemp=290.0, ttemp=0.0, temis=0.0,
+                                dtauc=np.array([0.3, 1.0, 0.2]), ssalb=np.array([0.9, 0.99, 0.5]),
+                                temper=np.linspace(220.0, 290.0, 4), pmom=g[:, None] ** np.arange(300)[None, :],
+                                umu=np.array([-0.9999, -0.995, -0.6, 0.3, 0.99]), phi=np.array(phis)))
+    assert abs(1.0 - recs[-1].umu0) < 1e-5
     outs = [pyoracle.disort(r) for r in recs]
     plain = [pyoracle.disort(dataclasses.replace(r, flags=r.flags & ~F_CORINT)) for r in recs]
     assert max(np.abs(o["uu"] - p["uu"]).max() / np.abs(o["uu"]).max() for o, p in zip(outs, plain)) > 1e-3
     flux, uu, st = solve_records(recs)
     _check(flux, uu, st, recs, outs)
+
+
+def _linpack_rows(ipvt, N):
+    """Original row taken as pivot of column k by SGBFA, from its IPVT (1-based positions; the interchange puts the
+    row that sat at position k where the pivot row was, disutil.f:866-876)."""
+    perm = list(range(N))
+    rows = []
+    for k in range(N):
+        l = int(ipvt[k]) - 1
+        rows.append(perm[l])
+        perm[l], perm[k] = perm[k], perm[l]
+    return rows
+
+
+def _engine_rows(idx, n, ncut):
+    """The same from band4_kernel's record of register indices: registers 0..nn-1 hold the carry rows (the top
+    boundary rows at first), nn..nn+n-1 the rows of the step's interface (the bottom rows + padding in the last
+    step); the pivot's register takes the last live register's row (sbd_band4.hpp)."""
+    nn, RW, N = n // 2, n // 2 + n, n * ncut
+    regs = list(range(nn)) + [None] * n
+    rows = []
+    for lc in range(1, ncut + 1):
+        for r in range(n):
+            if lc < ncut:
+                regs[nn + r] = nn + (lc - 1) * n + r
+            else:
+                regs[nn + r] = N - nn + r if r < nn else -1
+        for J in range(n):
+            last = RW - 1 - J
+            i = int(idx[(lc - 1) * n + J])
+            assert 0 <= i <= last, (lc, J, i)
+            rows.append(regs[i])
+            regs[i] = regs[last]
+    return rows
+
+
+def _band_matrix(gc, kk, ek, cmu, cwt, albedo, ncut, L):
+    """SETMTX's matrix (disort.f:2702-2994) in LINPACK band storage from a system's GC [L][n][n] (row-major GC(i,j)),
+    KK [L][n] and STWJ factors EK [L][nn] -- the ENGINE's own arrays: eigenvectors are only defined up to order and
+    scale, so the pivot rule can only be compared on the matrix the engine actually factors."""
+    n = gc.shape[1]
+    nn, N, ncd = n // 2, n * ncut, 3 * (n // 2) - 1
+    M = np.zeros((N, N))
+    top = gc[0][nn - 1::-1, :].copy()
+    top[:, :nn] *= ek[0][None, :]
+    M[:nn, :n] = top
+    for lc in range(ncut - 1):
+        fa, fb = np.ones(n), np.ones(n)
+        fa[nn:] = ek[lc][::-1]
+        fb[:nn] = ek[lc + 1]
+        r0 = nn + lc * n
+        M[r0:r0 + n, lc * n:(lc + 1) * n] = gc[lc] * fa[None, :]
+        M[r0:r0 + n, (lc + 1) * n:(lc + 2) * n] = -gc[lc + 1] * fb[None, :]
+    g = gc[ncut - 1]
+    sb = np.zeros(n)
+    if ncut == L:                                      # (no surface below a LYRCUT level)
+        for k in range(nn):
+            sb = sb + cwt[k] * cmu[k] * albedo * g[nn - 1 - k, :]
+    fbot = np.ones(n)
+    fbot[nn:] = ek[ncut - 1][::-1]
+    M[N - nn:, N - n:] = (g[nn:, :] - 2.0 * sb[None, :]) * fbot[None, :]
+    m, lda = 2 * ncd + 1, 3 * ncd + 1
+    abd = np.zeros((N, lda))                           # column-major ABD(lda, N): abd[j][i - j + m - 1] = A(i, j)
+    for j in range(N):
+        i0, i1 = max(0, j - ncd), min(N - 1, j + ncd)
+        abd[j, i0 - j + m - 1:i1 - j + m] = M[i0:i1 + 1, j]
+    return abd, ncd
+
+
+@pytest.mark.parametrize("name", ["cfgB_sw_nstr16", "cfg3_lw_nstr16_cloud", "sbchk1", "sbchk3", "corint_nstr8"])
+def test_pivot_sequence_against_linpack(name):
+    """The band LU's pivot ROWS against the ones LINPACK's SGBFA takes (ISAMAX: first exact maximum,
+    disutil.f:852-912, 2060-2072) -- on the engine's own band matrix, assembled on the host from the GC / KK / EK the
+    layer kernel left (the reference's matrix has its layers' columns in ASYMTX's eigenvalue order, the engine's in
+    its Jacobi order: different but equivalent systems whose pivot rows cannot be matched one to one).  The engine
+    searches on the leading 27 bits of |a| (threshold 1 - 2^-15, equal keys in register order); an exact search
+    costs 1 to 1.5 more instructions per live row and sub-step (+12 % of the kernel), so the threshold stays and
+    THIS is its measured price: the fraction of pivots whose row differs from SGBFA's."""
+    import ctypes as C
+    import pyoracle
+    from sbdart_amd.engine import engine_for_record
+    from sbdart_amd.records import read_records
+    recs = [r for r in read_records(os.path.join(GOLDEN, name + ".sbdrec"))]
+    r0 = recs[0]
+    recs = [r for r in recs if np.array_equal(r.temper, r0.temper) and r.umu0 == r0.umu0 and r.nstr == r0.nstr
+            and r.nlyr == r0.nlyr][:48]
+    n, L = r0.nstr, r0.nlyr
+    nn = n // 2
+    args = (np.stack([r.dtauc for r in recs]), np.stack([r.ssalb for r in recs]), np.stack([r.pmom for r in recs]),
+            [r.wvnmlo for r in recs], [r.wvnmhi for r in recs], [r.fbeam for r in recs],
+            [r.albedo for r in recs], [r.plank for r in recs])
+    with engine_for_record(r0, max_batch=len(recs)) as eng:
+        eng.debug_pivots(True)
+        flux, uu, st = eng.solve(*args)
+        cmu, cwt = eng.quadrature()
+        svi = eng.debug_array(8, np.int32, 1 << 22)
+        piv = eng.debug_array(15, np.int32, 1 << 24)
+        nmode = len(piv) // (len(recs) * L * n)
+        gc = eng.debug_array(0, np.float64, len(recs) * nmode * L * n * n).reshape(len(recs), nmode, L, n, n)
+        kk = eng.debug_array(1, np.float64, len(recs) * nmode * L * n).reshape(len(recs), nmode, L, n)
+        ek = eng.debug_array(2, np.float64, len(recs) * nmode * L * nn).reshape(len(recs), nmode, L, nn)
+        eng.debug_pivots(False)
+    piv = piv.reshape(len(recs), nmode, L * n)
+    svi_stride = (3 + L + 1 + 3) & ~3
+    lib = pyoracle.lib()
+    total = differ = items_differ = 0
+    for i, r in enumerate(recs):
+        if st[i] & 0x38:                                # (no system was factored for this item)
+            continue
+        ncut, N = int(svi[i * svi_stride]), n * int(svi[i * svi_stride])
+        abd, ncd = _band_matrix(gc[i, 0], kk[i, 0], ek[i, 0], cmu, cwt, r.albedo, ncut, L)
+        ipvt, info = np.zeros(N, dtype=np.int32), C.c_int(0)
+        lib.sbdo_sgbfa(pyoracle._p(abd), 3 * ncd + 1, N, ncd, ncd, ipvt.ctypes.data_as(C.POINTER(C.c_int)), C.byref(info))
+        want = _linpack_rows(ipvt, N)
+        got = _engine_rows(piv[i, 0], n, ncut)
+        bad = sum(1 for a, b in zip(got, want) if a != b)
+        total += len(want)
+        differ += bad
+        items_differ += bad > 0
+    assert total > 0
+    frac = differ / total
+    print(f"{name}: {total} pivots of {len(recs)} systems, {differ} rows differ from SGBFA's ({frac:.2e}), "
+          f"{items_differ} systems affected")
+    try:
+        import json
+        with open(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "pivot_rows.jsonl"), "a") as f:
+            f.write(json.dumps({"records": name, "pivots": total, "rows_differ": differ, "systems": len(recs),
+                                "systems_affected": items_differ}) + "\n")
+    except OSError:
+        pass
+    assert frac <= 5e-3, frac
+
+
+@pytest.mark.parametrize("delta", [1e-5, 1e-7, 1e-8, 1e-9, 3e-10, -1e-8, 1e-11])
+def test_eigenvalue_next_to_the_beam(delta):
+    """UPBEAM's system is singular when a layer's eigenvalue k equals 1/umu0 (disort.f:4130-4245): the fast layer
+    kernel solves it in the basis of the singular vectors (a division by 1 - umu0^2 k^2) and hands the layer to the
+    reference-algorithm kernel only inside |1 - umu0 k| < 1e-10.  Layers whose eigenvalue sits 1e-5 ... 3e-10 from
+    1/umu0 -- 1e4 x more amplification than the fuzz ever sees -- and one inside the window, against the oracle
+    (status words included: errmsg 3 where LINPACK's estimate raises it)."""
+    import dataclasses
+    import pyoracle
+    from sbdart_amd.engine import solve_records
+    from sbdart_amd.records import F_LAMBER, F_ONLYFL, SolveRecord
+    recs = []
+    for nstr in (8, 16):
+        nmom = nstr + 2
+        g = np.array([0.7, 0.8, 0.6])
+        base = SolveRecord(nlyr=3, nstr=nstr, nmom=nmom, flags=F_LAMBER | F_ONLYFL, wvnmlo=10000.0, wvnmhi=10100.0,
+                           fbeam=1.0, umu0=0.5, phi0=0.0, albedo=0.2, btemp=290.0, ttemp=0.0, temis=0.0,
+                           dtauc=np.array([0.2, 0.7, 0.4]), ssalb=np.array([0.6, 0.9, 0.8]),
+                           temper=np.linspace(220.0, 290.0, 4), pmom=g[:, None] ** np.arange(nmom + 1)[None, :],
+                           umu=np.zeros(0), phi=np.zeros(0))
+        kk = pyoracle.disort(base, debug_mode=0)["dbg"]["kk"]          # eigenvalues do not depend on the beam
+        for lc in range(3):
+            for k in kk[lc][nstr // 2:]:                                 # the positive half, every stream
+                if 1.02 < k < 20.0:                                      # 1/k a possible cosine of the beam
+                    recs.append(dataclasses.replace(base, umu0=float(1.0 / (k * (1.0 + delta)))))
+    assert len(recs) >= 8
+    outs = [pyoracle.disort(r) for r in recs]
+    keep = [i for i, o in enumerate(outs) if not (o["status"] & (pyoracle.RETRY_NSTR | pyoracle.ERR_INPUT))]
+    recs, outs = [recs[i] for i in keep], [outs[i] for i in keep]
+    # the reference's own rounding sensitivity grows like eps / |delta| (its LU of the nearly singular system loses
+    # the same digits): measured with the FMA-contracted twin of the oracle, as in test_ill_conditioned_records
+    twins = [pyoracle.disort(r, perturbed=True) for r in recs]
+    flux, uu, st = solve_records(recs)
+    worst, worst_sens = 0.0, 0.0
+    for i, (r, o, t) in enumerate(zip(recs, outs, twins)):
+        assert st[i] == o["status"], (i, st[i], o["status"])
+        recmax = max(max(np.abs(o[f]).max() for f in FLUX), 1e-300)
+        for c, f in enumerate(FLUX):
+            scale = np.abs(o[f]).max()
+            sens = np.abs(t[f] - o[f]).max() / max(scale, 1e-300)
+            err = np.abs(flux[i][c] - o[f]).max()
+            worst, worst_sens = max(worst, err / max(scale, 1e-9 * recmax)), max(worst_sens, sens)
+            assert err <= max(TOL, 8.0 * sens) * scale + 1e-12 * recmax, (i, f, err / max(scale, 1e-300), sens, r.umu0)
+    print(f"delta {delta:g}: {len(recs)} records, worst error {worst:.2e} of the column maximum "
+          f"(the reference's own FMA sensitivity: {worst_sens:.2e})")
 
 
 def test_ill_conditioned_records():

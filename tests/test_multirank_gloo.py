@@ -34,7 +34,20 @@ def _integrate(sw, lo, hi):
     return acc
 
 
-def _worker(rank, world, port, q):
+def _integrate_gpu(sw, lo, hi):
+    """The same shard through the HIP engine (device-side weighted sums, sbd_engine_accumulate_*)."""
+    from sbdart_amd.engine import DisortEngine
+    idx = np.nonzero((sw.wl_of >= lo) & (sw.wl_of < hi))[0]
+    with DisortEngine(nlyr=sw.nlyr, nstr=sw.nstr, nmom=sw.nmom, temper=sw.temper, umu0=sw.umu0, btemp=sw.btemp,
+                      ttemp=sw.ttemp, temis=sw.temis, onlyfl=True, level_out=[0, sw.nlyr], device=0) as eng:
+        flux, _, st = eng.solve(sw.dtauc[idx], sw.ssalb[idx], sw.pmom[idx], sw.wvnmlo[idx], sw.wvnmhi[idx],
+                                sw.fbeam[idx], sw.albedo[idx], sw.plank[idx])
+        assert (st == 0).all()
+        acc, _ = eng.accumulate(sw.weight[idx], flux)
+    return acc
+
+
+def _worker(rank, world, port, q, engine=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, ORACLE_DIR)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -48,7 +61,9 @@ def _worker(rank, world, port, q):
     clo, chi = C.c_int32(), C.c_int32()
     _lib.load().sbd_shard_range(sw.nwl, world, rank, C.byref(clo), C.byref(chi))
     lo, hi = clo.value, chi.value
-    acc = torch.from_numpy(_integrate(sw, lo, hi))
+    if engine:
+        torch.cuda.init()                                   # PyTorch's HIP runtime before the engine's (conftest.py)
+    acc = torch.from_numpy(np.ascontiguousarray(_integrate_gpu(sw, lo, hi) if engine else _integrate(sw, lo, hi)))
     reduce_accumulators(acc, dst=0)
     if rank == 0:
         q.put(acc.numpy().copy())
@@ -56,13 +71,28 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_rank_spectral_shard_and_reduce_with_engines():
+    """The same two-rank run with the HIP engine solving each rank's shard (both ranks on the box's one GPU; the
+    reduce stays on gloo -- RCCL refuses two ranks on one device): sharding rule + engine + reduce together,
+    against the C oracle's whole-sweep integral."""
+    _two_ranks(engine=True, rtol=5e-6)     # (the engine-vs-reference gate of tests/test_gpu_parity.py)
+
+
 def test_two_rank_spectral_shard_and_reduce():
+    _two_ranks(engine=False, rtol=1e-13)
+
+
+def _two_ranks(engine, rtol):
     sys.path.insert(0, ORACLE_DIR)
     from sbdart_amd.workload import sw_sweep
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, engine)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
@@ -71,4 +101,4 @@ def test_two_rank_spectral_shard_and_reduce():
         assert p.exitcode == 0
     sw = sw_sweep(nwl=12, nstr=8, nlyr=5, seed=99)
     whole = _integrate(sw, 0, sw.nwl)
-    assert np.allclose(got, whole, rtol=1e-13, atol=0)
+    assert np.allclose(got, whole, rtol=rtol, atol=rtol * 1e-3 * np.abs(whole).max())

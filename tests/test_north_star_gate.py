@@ -12,7 +12,8 @@ objects with the DISORT call site recorded -- its stdout IS sbdart_ref's), the F
     reference's 5-digit print cannot resolve 1e-4 W/m2 of a 1e3 W/m2 flux.
 
 Cases: BASELINE.json configs[1] (full short-wave sweep, nstr=16: 751 wavelengths, 2 009 solves, real
-solar FBEAM) and configs[2] (long-wave, cloud, thermal emission).
+solar FBEAM), configs[2] (long-wave, cloud, thermal emission), and a run whose Rayleigh layers scatter
+conservatively under a thermal source (the one class of layers gated looser per solve, tests/test_gpu_parity.py).
 """
 import os
 import sys
@@ -29,6 +30,12 @@ GATE_W_M2 = 1.0e-4
 CASES = {
     "sw_nstr16": "idatm=6 isat=0 wlinf=.25 wlsup=4.0 wlinc=.005 nstr=16 iout=10",
     "lw_cloud_nstr16": "idatm=6 wlinf=4 wlsup=80 wlinc=-.01 nstr=16 tcloud=10 zcloud=1 nre=8 sza=95 iout=10",
+    # thermal emission in CONSERVATIVE layers: every absorber switched off leaves 32 Rayleigh layers with SSALB = 1
+    # (dithered by DISORT) around an absorbing cloud, sun and Planck source together (2-3 um).  I - CC is singular
+    # to working precision in those layers: the engine sends them to its reference-algorithm layer kernel
+    "thermal_conservative_nstr16": "idatm=6 isat=0 wlinf=2.02 wlsup=3.0 wlinc=.02 nstr=16 iout=10 sza=40 uw=0 uo3=0 "
+                                   "xn2=0 xo2=0 xco2=0 xch4=0 xn2o=0 xco=0 xno2=0 xso2=0 xnh3=0 xno=0 xhno3=0 xo4=0 "
+                                   "tcloud=6 zcloud=2 nre=8",
 }
 
 
