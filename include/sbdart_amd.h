@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SBD_ABI_VERSION 3
+#define SBD_ABI_VERSION 4
 
 /* limits of the reference (params.f:9-15) */
 #define SBD_MAX_NLYR 65   /* mxly   */
@@ -58,7 +58,7 @@ extern "C" {
                                    without a beam (FBEAM = 0) can still be solved with it */
 #define SBD_E_NO_DEVICE     -3
 #define SBD_E_HIP           -4  /* a HIP runtime call failed; see sbd_last_error() */
-#define SBD_E_UNSUPPORTED   -5  /* BRDF surface, IBCND=1 */
+#define SBD_E_UNSUPPORTED   -5  /* IBCND=1, intensities at the quadrature angles */
 #define SBD_E_NOMEM         -6
 
 /* ---- per-work-item status bits ---- */
@@ -88,7 +88,8 @@ typedef struct {
     int32_t nmom;          /* highest Legendre moment supplied; PMOM row stride = nmom+1;
                               drt.f:490-494 uses min(nstr+2, 40) */
     int32_t onlyfl;        /* ONLYFL: 1 = fluxes only (iout not in 5,6,20..23) */
-    int32_t lamber;        /* must be 1 (Lambertian; BRDF is out of scope) */
+    int32_t lamber;        /* LAMBER: 1 = Lambertian surface with the work item's ALBEDO; 0 = bidirectional surface
+                              `ibdrf` (SURFAC's quadrature of BDREF, disort.f:3765-3912; spectra.f:249-296) */
     int32_t usrang;        /* USRANG: radiances at umu[] (required when onlyfl=0) */
     int32_t numu;          /* number of user polar angles (radiance mode) */
     int32_t nphi;          /* number of user azimuths     (radiance mode) */
@@ -100,7 +101,8 @@ typedef struct {
     int32_t corint;        /* CORINT: Nakajima/Tanaka intensity corrections (INTCOR, disort.f:2044-2297) on the
                               radiances of every item with a beam and scattering (disort.f:2695-2696);
                               SBDART then supplies nmom = 299 moments (drt.f:490-491); ignored when onlyfl */
-    int32_t reserved0;     /* 0 */
+    int32_t ibdrf;         /* with lamber = 0: 1 ocean (seabdrf, isalb 7), 2 Hapke (isalb 8), 3 Ross-thick / Li-sparse
+                              (isalb 9); parameters in bpar; 0 with lamber = 1 */
     double umu0;           /* cosine of solar zenith (amu0, drt.f:421,456-459) */
     double phi0;           /* solar azimuth, degrees */
     double fisot;          /* isotropic top illumination (0 in SBDART) */
@@ -109,6 +111,11 @@ typedef struct {
     const double *umu;     /* [numu] ascending cosines (drt.f:393-403) or NULL */
     const double *phi;     /* [nphi] degrees or NULL */
     const int32_t *level_out; /* [nlevel_out] 0-based level indices (0 = TOA, nlyr = surface) */
+    double bpar[8];        /* surface model parameters (albblk, spectra.f:15-26; suralb, spectra.f:61-177):
+                              ocean   : wind speed (m/s), foam cover 2.951e-6 wndspd^3.52, foam reflectance 0.22 x cover
+                                        (seabdrf, spectra.f:441-451), pigment concentration, salinity
+                              Hapke   : single-scattering albedo, asymmetry, hot-spot amplitude, hot-spot width
+                              Ross-Li : isotropic, volumetric, geometric coefficients, hot-spot magnitude, width */
 } sbd_run_cfg;
 
 /* One batch of (wavelength, k-term) work items: the per-call DISORT arguments. */
@@ -122,6 +129,9 @@ typedef struct {
     const double *fbeam;    /* [nwork]                  FBEAM (flxin, drt.f:448)  */
     const double *albedo;   /* [nwork]                  ALBEDO (rsfc, drt.f:469)  */
     const uint8_t *plank;   /* [nwork]                  PLANK (wl>2 um, drt.f:463)*/
+    const double *bitem;    /* [nwork][4] ocean surface only (ibdrf = 1), else NULL: refractive index nr, ni of
+                               the water and its sub-surface reflectance rsw at the item's wavelength (indwat,
+                               morcasiwat: spectra.f:446-449), one spare */
 } sbd_batch_in;
 
 typedef struct {

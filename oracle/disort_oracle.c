@@ -898,6 +898,148 @@ typedef struct {
 #define CMU(i) w->cmu[(i) - 1]
 #define CWT(i) w->cwt[(i) - 1]
 
+/* ===================== bidirectional surface reflectance (BDREF, spectra.f:249-296) =====================
+ * Un-suffixed literals of the reference are REAL*4 widened; params.f:29 has pi = 3.1415926536_kr. */
+#define SBDO_F32(x) ((double)(x##f))
+static const double kPiParams = 3.1415926536;
+
+/* Fresnel reflection coefficient of the water facet (fresnel, spectra.f:1320-1356) */
+static double fresnel(double nr, double ni, double coschi, double sinchi)
+{
+    double a1 = fabs(nr * nr - ni * ni - sinchi * sinchi);
+    double t = nr * nr - ni * ni - sinchi * sinchi;
+    double a2 = sqrt(pow(t, 2.0) + 4.0 * nr * nr * ni * ni);
+    double u = sqrt(0.5 * (a1 + a2));
+    double v = sqrt(0.5 * (-a1 + a2));
+    double rr2 = ((coschi - u) * (coschi - u) + v * v) / ((coschi + u) * (coschi + u) + v * v);
+    double b1 = (nr * nr - ni * ni) * coschi;
+    double b2 = 2.0 * nr * ni * coschi;
+    double rl2 = ((b1 - u) * (b1 - u) + (b2 + v) * (b2 + v)) / ((b1 + u) * (b1 + u) + (b2 - v) * (b2 - v));
+    return (rr2 + rl2) / 2.0;
+}
+
+/* sun glint of a wind-roughened sea, slope distribution averaged over the wind direction (sunglint,
+ * spectra.f:1224-1318) */
+static double sunglint(double wndspd, double nr, double ni, double csin, double cvin, double phi)
+{
+    const double pi = kPiParams;
+    double cs = fmax(csin, 0.05), cv = fmax(cvin, 0.05);
+    double ss = sqrt(1.0 - cs * cs), sv = sqrt(1.0 - cv * cv);
+    double zx = -sv * sin(pi - phi) / (cs + cv);
+    double zy = (ss + sv * cos(pi - phi)) / (cs + cv);
+    double tantilt = sqrt(zx * zx + zy * zy);
+    double tilt = atan(tantilt);
+    double sigmac = SBDO_F32(0.003) + SBDO_F32(0.00192) * wndspd;
+    double sigmau = SBDO_F32(0.00316) * wndspd;
+    const double c40 = SBDO_F32(0.40), c22 = SBDO_F32(0.12), c04 = SBDO_F32(0.23);
+    double zx2 = zx * zx, zy2 = zy * zy, zx4 = zx2 * zx2, zy4 = zy2 * zy2;
+    double axe2 = 0.5 * (zx2 + zy2) / sigmac;
+    double axn2 = 0.5 * (zx2 + zy2) / sigmau;
+    double axe4 = (3.0 * zx4 + 6.0 * zx2 * zy2 + 3.0 * zy4) / (8.0 * (sigmac * sigmac));
+    double axn4 = (3.0 * zx4 + 6.0 * zx2 * zy2 + 3.0 * zy4) / (8.0 * (sigmau * sigmau));
+    double axe2xn2 = (zx4 + 10.0 * zx2 * zy2 + zy4) / (8.0 * sigmau * sigmac);
+    double coef = 1.0;
+    coef = coef + c40 / 24.0 * (axe4 - 6.0 * axe2 + 3.0);
+    coef = coef + c04 / 24.0 * (axn4 - 6.0 * axn2 + 3.0);
+    coef = coef + c22 / 4.0 * (axe2xn2 - axn2 - axe2 + 1.0);
+    coef = coef / (2.0 * pi * sqrt(sigmau) * sqrt(sigmac));
+    double proba = coef * exp(-(axe2 + axn2) / 2.0);
+    double cos2chi = cv * cs + sv * ss * cos(pi - phi);
+    if (cos2chi > 1.0) cos2chi = SBDO_F32(0.99999999999);
+    if (cos2chi < -1.0) cos2chi = -SBDO_F32(0.99999999999);
+    double coschi = sqrt(0.5 * (1.0 + cos2chi));
+    double sinchi = sqrt(0.5 * (1.0 - cos2chi));
+    double r1 = fresnel(nr, ni, coschi, sinchi);
+    double ct = cos(tilt);
+    return pi * r1 * proba / (4.0 * cs * cv * ((ct * ct) * (ct * ct)));
+}
+
+/* Hapke's soil model (hapkbdrf, spectra.f:298-348) */
+static double hapke(const double *bp, double ui, double ur, double phir)
+{
+    const double pi = kPiParams, hssa = bp[0], hasym = bp[1], hotspt = bp[2], hotwdth = bp[3];
+    double coss = ui * ur + sqrt(1.0 - ur * ur) * sqrt(1.0 - ui * ui) * cos(pi - phir);
+    double s = acos(coss);
+    double pfun = (1.0 - hasym * hasym) / pow(1.0 + hasym * hasym + 2.0 * hasym * coss, 1.5);
+    double pfun0 = (1.0 - hasym * hasym) / ((1.0 + hasym) * (1.0 + hasym) * (1.0 + hasym));
+    double b0 = hotspt / (hssa * pfun0);
+    double bfun = b0 / (1.0 + tan(s / 2.0) / hotwdth);
+    double hfunr = (1.0 + 2.0 * ur) / (1.0 + 2.0 * ur * sqrt(1.0 - hssa));
+    double hfuni = (1.0 + 2.0 * ui) / (1.0 + 2.0 * ui * sqrt(1.0 - hssa));
+    double bdrf = (1.0 + bfun) * pfun + hfunr * hfuni - 1.0;
+    return 0.25 * hssa * bdrf / (ur + ui);
+}
+
+/* Ross-thick / Li-sparse kernels (rtlsbdrf, spectra.f:350-419) */
+static double rosslisparse(const double *bp, double mui, double mur, double phir)
+{
+    const double pi = kPiParams, rliso = bp[0], rlvol = bp[1], rlgeo = bp[2], rlhot = bp[3], rlwdth = bp[4];
+    double ui = fmax(mui, 0.01), ur = fmax(mur, 0.01);
+    double cosra = cos(pi - phir);
+    double coss = ui * ur + sqrt(1.0 - ur * ur) * sqrt(1.0 - ui * ui) * cosra;
+    coss = fmax(-1.0, fmin(coss, 1.0));
+    double s = acos(coss), sins = sin(s);
+    double f1 = (pi / 2.0 - s) * coss + sins;
+    f1 = f1 / (ui + ur) - pi / 4.0;
+    double vza = acos(ur), sza = acos(ui);
+    double tanvzap = rlwdth * tan(vza), tanszap = rlwdth * tan(sza);
+    double vzap, szap;
+    if (rlwdth == 1.0) { vzap = vza; szap = sza; }
+    else { vzap = atan(tanvzap); szap = atan(tanszap); }
+    double cossp = cos(szap) * cos(vzap) + sin(szap) * sin(vzap) * cosra;
+    cossp = fmax(-1.0, fmin(cossp, 1.0));
+    double dd = tanszap * tanszap + tanvzap * tanvzap - 2.0 * tanszap * tanvzap * cosra;
+    double secsum = 1.0 / cos(szap) + 1.0 / cos(vzap);
+    double tt = tanszap * tanvzap * sin(pi - phir);
+    double cost = rlhot * sqrt(dd + tt * tt);
+    cost = cost / secsum;
+    cost = fmax(-1.0, fmin(cost, 1.0));
+    double t = acos(cost);
+    double f2 = (t - sin(t) * cost) * secsum / pi;
+    f2 = f2 - 1.0 / cos(vzap) + 0.5 * (1.0 + cossp) / (cos(szap) * cos(vzap));
+    return rliso + rlvol * f1 + rlgeo * f2;
+}
+
+/* BDREF(WVNMLO, WVNMHI, MUR, MUI, PHIR) (spectra.f:249-296): reflection cosine first */
+static double bdref(const sbdo_in *in, double mur, double mui, double phir)
+{
+    switch (in->ibdrf) {
+    case 1: {   /* seabdrf(wl, mus = mui, muv = mur, phir), spectra.f:421-465 */
+        const double wndspd = in->bpar[0], wndwt = in->bpar[1], rfoam = in->bpar[2];
+        const double rgl = sunglint(wndspd, in->bitem[0], in->bitem[1], mui, mur, phir);
+        return rfoam + (1.0 - wndwt) * rgl + (1.0 - rfoam) * in->bitem[2];
+    }
+    case 2: return hapke(in->bpar, mui, mur, phir);
+    case 3: return rosslisparse(in->bpar, mui, mur, phir);
+    default: return 0.0;
+    }
+}
+
+/* directional-hemispherical integral with the REFLECTION cosine fixed (SURFAC's emissivity, disort.f:3795-3818, 3880-3903) */
+static double dref_at(const sbdo_in *in, const double *gmu, const double *gwt, double pi, double mur)
+{
+    double d = 0.0;
+    for (int jg = 1; jg <= 50; ++jg) {
+        double sum = 0.0;
+        for (int k = 1; k <= 25; ++k) sum = sum + gwt[k - 1] * gmu[k - 1] * bdref(in, mur, gmu[k - 1], pi * gmu[jg - 1]);
+        d = d + gwt[jg - 1] * sum;
+    }
+    return d;
+}
+
+/* flux albedo of the surface for incident cosine mu (DREF, disort.f:5178-5284) */
+static double dref(const sbdo_in *in, const double *gmu, const double *gwt, double pi, double mu)
+{
+    double d = 0.0;
+    for (int jg = 1; jg <= 50; ++jg) {
+        double sum = 0.0;
+        for (int k = 1; k <= 25; ++k) sum = sum + gwt[k - 1] * gmu[k - 1] * bdref(in, gmu[k - 1], mu, pi * gmu[jg - 1]);
+        d = d + gwt[jg - 1] * sum;
+    }
+    return d;
+}
+
+
 /* SOLEIG (disort.f:3099-3320).  cc, evecc are (n x n); amb, apb, array are
  * (nn x nn); eval [nn]; wkd [n]. Returns IER from ASYMTX. */
 static int soleig(work_t *w, int lc, int mazim, double *amb, double *apb, double *array,
@@ -1599,8 +1741,19 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
     if (in->fbeam > 0.0 && (in->umu0 <= 0.0 || in->umu0 > 1.0)) inperr = 1;
     if (in->fbeam > 0.0 && (in->phi0 < 0.0 || in->phi0 > 360.0)) inperr = 1;
     if (in->fisot < 0.0) inperr = 1;
-    if (!in->lamber) inperr = 1; /* BRDF surfaces: out of scope */
-    if (in->albedo < 0.0 || in->albedo > 1.0) inperr = 1;
+    /* quadrature of SURFAC / DREF over the azimuth and the incident cosine: QGAUSN(25) mirrored (disort.f:3707-3716) */
+    double gmu50[50], gwt50[50];
+    if (!in->lamber) {
+        sbdo_qgausn(25, gmu50, gwt50);
+        for (int k = 0; k < 25; ++k) { gmu50[k + 25] = -gmu50[k]; gwt50[k + 25] = gwt50[k]; }
+        if (in->ibdrf < 1 || in->ibdrf > 3) inperr = 1;
+        else
+            for (int irmu = 0; irmu <= 100; ++irmu) {   /* CHEKIN: flux albedo in [0,1] (disort.f:5080-5096) */
+                const double rmu = (double)((float)irmu * 0.01f);
+                const double flxalb = dref(in, gmu50, gwt50, pi, rmu);
+                if (flxalb < 0.0 || flxalb > 1.0) inperr = 1;
+            }
+    } else if (in->albedo < 0.0 || in->albedo > 1.0) inperr = 1;
     if (in->plank) {
         if (in->wvnmlo < 0.0 || in->wvnmhi <= in->wvnmlo) inperr = 1;
         if (in->temis < 0.0 || in->temis > 1.0) inperr = 1;
@@ -1751,8 +1904,48 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
             sgn = -sgn;
             for (int iq = nn + 1; iq <= n; ++iq) YLMC(l, iq) = sgn * YLMC(l, iq - nn);
         }
-        /* SURFAC, Lambertian branch (disort.f:3746-3763, 3843-3849) */
-        if (!lyrcut) {
+        /* SURFAC (disort.f:3639-3918): Lambertian branch, or the Fourier components of the bidirectional reflectance */
+        if (!lyrcut && !in->lamber) {
+            const double fac = 0.5 * (2.0 - delm0);
+            for (int i = 0; i < nn * (nn + 1); ++i) w->bdr[i] = 0.0;
+            for (int i = 0; i < nn; ++i) w->bem[i] = 0.0;
+            for (int iq = 1; iq <= nn; ++iq) {
+                for (int jq = 1; jq <= nn; ++jq) {
+                    double sum = 0.0;
+                    for (int k = 0; k < 50; ++k)
+                        sum = sum + gwt50[k] * bdref(in, CMU(iq), CMU(jq), pi * gmu50[k]) * cos((double)mazim * pi * gmu50[k]);
+                    BDR(iq, jq) = fac * sum;
+                }
+                if (in->fbeam > 0.0) {
+                    double sum = 0.0;
+                    for (int k = 0; k < 50; ++k)
+                        sum = sum + gwt50[k] * bdref(in, CMU(iq), in->umu0, pi * gmu50[k]) * cos((double)mazim * pi * gmu50[k]);
+                    BDR(iq, 0) = fac * sum;
+                }
+            }
+            if (mazim == 0)
+                for (int iq = 1; iq <= nn; ++iq) w->bem[iq - 1] = 1.0 - dref_at(in, gmu50, gwt50, pi, CMU(iq));
+            if (!in->onlyfl && in->usrang) {
+                for (int i = 0; i < numu; ++i) w->emu[i] = 0.0;
+                for (int i = 0; i < numu * (nn + 1); ++i) w->rmu[i] = 0.0;
+                for (int iu = 1; iu <= numu; ++iu) {
+                    if (!(umu[iu - 1] > 0.0)) continue;
+                    for (int iq = 1; iq <= nn; ++iq) {
+                        double sum = 0.0;
+                        for (int k = 0; k < 50; ++k)
+                            sum = sum + gwt50[k] * bdref(in, umu[iu - 1], CMU(iq), pi * gmu50[k]) * cos((double)mazim * pi * gmu50[k]);
+                        RMU(iu, iq) = fac * sum;
+                    }
+                    if (in->fbeam > 0.0) {
+                        double sum = 0.0;
+                        for (int k = 0; k < 50; ++k)
+                            sum = sum + gwt50[k] * bdref(in, umu[iu - 1], in->umu0, pi * gmu50[k]) * cos((double)mazim * pi * gmu50[k]);
+                        RMU(iu, 0) = fac * sum;
+                    }
+                    if (mazim == 0) w->emu[iu - 1] = 1.0 - dref_at(in, gmu50, gwt50, pi, umu[iu - 1]);
+                }
+            }
+        } else if (!lyrcut) {
             for (int i = 0; i < nn * (nn + 1); ++i) w->bdr[i] = 0.0;
             for (int i = 0; i < nn; ++i) w->bem[i] = 0.0;
             if (mazim == 0) {

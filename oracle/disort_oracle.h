@@ -43,6 +43,11 @@ typedef struct {
     const double *umu;          /* [numu] ascending           */
     const double *phi;          /* [nphi] degrees             */
     const double *utau;         /* [ntau] if usrtau           */
+    /* bidirectional surface (LAMBER off), spectra.f:249-296: 0 none, 1 ocean (seabdrf), 2 Hapke, 3 Ross-Li.
+       bpar: the model's run parameters, bitem: the ocean's per-wavelength constants nr, ni, rsw
+       (layout: sbdart_amd/records.py) */
+    int ibdrf;
+    double bpar[8], bitem[4];
 } sbdo_in;
 
 typedef struct {

@@ -30,7 +30,8 @@ class _In(C.Structure):
                 ("wvnmlo", "wvnmhi", "fbeam", "umu0", "phi0", "fisot", "albedo", "btemp",
                  "ttemp", "temis", "accur")] + \
                [("corint", C.c_int)] + \
-               [(k, _dp) for k in ("dtauc", "ssalb", "temper", "pmom", "umu", "phi", "utau")]
+               [(k, _dp) for k in ("dtauc", "ssalb", "temper", "pmom", "umu", "phi", "utau")] + \
+               [("ibdrf", C.c_int), ("bpar", C.c_double * 8), ("bitem", C.c_double * 4)]
 
 
 class _Out(C.Structure):
@@ -108,7 +109,11 @@ def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False, debug_mod
             phi0=rec.phi0, fisot=rec.fisot, albedo=rec.albedo, btemp=rec.btemp,
             ttemp=rec.ttemp, temis=rec.temis, accur=accur, corint=int(getattr(rec, 'corint', False)),
             dtauc=_p(dtauc), ssalb=_p(ssalb), temper=_p(temper), pmom=_p(pmom),
-            umu=_p(umu), phi=_p(phi), utau=_p(ut))
+            umu=_p(umu), phi=_p(phi), utau=_p(ut), ibdrf=int(getattr(rec, "ibdrf", 0)))
+    for k_ in range(8):
+        i.bpar[k_] = float(getattr(rec, "bpar", np.zeros(8))[k_])
+    for k_ in range(4):
+        i.bitem[k_] = float(getattr(rec, "bitem", np.zeros(4))[k_])
     flx = np.zeros((5, ntau))
     uu = np.zeros((max(nphi, 1), ntau, max(numu, 1)))
     u0c = np.zeros((ntau, rec.nstr))

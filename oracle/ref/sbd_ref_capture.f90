@@ -101,6 +101,7 @@ subroutine disort(nlyr, dtauc, ssalb, corint, nmom, pmom, temper, &
      maxcly, maxulv, maxumu, maxphi, maxmom, rfldir, rfldn, flup, &
      dfdt, uavg, uu, albmed, trnmed)
   use sbd_capture_state
+  use albblk, only: ibdrf, wndspd, chlor, salin, hssa, hasym, hotspt, hotwdth, rliso, rlvol, rlgeo, rlhot, rlwdth
   implicit none
   character header*127
   logical :: lamber, onlyfl, plank, usrang, usrtau, corint
@@ -116,7 +117,9 @@ subroutine disort(nlyr, dtauc, ssalb, corint, nmom, pmom, temper, &
   external disort_ref
   integer :: flags, lc, k, j, lu, iu, numu_in, nphi_in
   integer :: hdr(12), ohdr(4)
-  real(dp) :: sc(16)
+  real(dp) :: sc(16), bpar(8), bitem(4), wlb
+  ! (seabdrf's foam constants, spectra.f:441-444; same types, same compiler: the same bits)
+  real(dp), parameter :: wndc1 = 2.951e-6, wndc2 = 3.52, rfco = 0.22
 
   call capture_open()
 
@@ -134,6 +137,7 @@ subroutine disort(nlyr, dtauc, ssalb, corint, nmom, pmom, temper, &
   hdr(1) = nlyr;  hdr(2) = nstr;  hdr(3) = nmom;  hdr(4) = numu_in
   hdr(5) = nphi_in; hdr(6) = flags; hdr(7) = cur_kd; hdr(8) = cur_nk
   hdr(9) = cur_iwl; hdr(10) = ibcnd
+  if (.not. lamber) hdr(11) = ibdrf
   sc = 0
   sc(1) = cur_wl;  sc(2) = cur_wt;  sc(3) = cur_ff
   sc(4) = wvnmlo;  sc(5) = wvnmhi;  sc(6) = fbeam;  sc(7) = umu0
@@ -143,6 +147,24 @@ subroutine disort(nlyr, dtauc, ssalb, corint, nmom, pmom, temper, &
   write(rec_unit) (dtauc(lc), lc=1,nlyr), (ssalb(lc), lc=1,nlyr), &
        (temper(lc), lc=0,nlyr), ((pmom(k,lc), k=0,nmom), lc=1,nlyr), &
        (umu(iu), iu=1,numu_in), (phi(j), j=1,nphi_in)
+  if (.not. lamber) then
+    ! the surface model's parameters (albblk, spectra.f:15-26) and, for the ocean, what seabdrf derives from the
+    ! wavelength alone (spectra.f:446-453): the water's refractive index and sub-surface reflectance
+    bpar = 0; bitem = 0
+    select case (ibdrf)
+    case (1)
+      bpar(1) = wndspd; bpar(2) = wndc1*wndspd**wndc2; bpar(3) = bpar(2)*rfco; bpar(4) = chlor; bpar(5) = salin
+      wlb = 20000./(wvnmhi + wvnmlo)
+      call indwat(wlb, chlor, bitem(1), bitem(2))
+      call morcasiwat(wlb, chlor, bitem(3))
+      if (chlor == 0.) bitem(3) = 0.
+    case (2)
+      bpar(1) = hssa; bpar(2) = hasym; bpar(3) = hotspt; bpar(4) = hotwdth
+    case (3)
+      bpar(1) = rliso; bpar(2) = rlvol; bpar(3) = rlgeo; bpar(4) = rlhot; bpar(5) = rlwdth
+    end select
+    write(rec_unit) bpar, bitem
+  end if
 
   call disort_ref(nlyr, dtauc, ssalb, corint, nmom, pmom, temper, &
        wvnmlo, wvnmhi, usrtau, ntau, utau, nstr, usrang, numu, umu, &

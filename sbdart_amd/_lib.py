@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SBDART_AMD_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get("SBDART_AMD_LIB") or os.path.join(_HERE, "lib", "libsbdart_amd.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NFLUX = 5
 RFLDIR, RFLDN, FLUP, DFDT, UAVG = range(5)
 
@@ -25,15 +25,15 @@ _bp = C.POINTER(C.c_uint8)
 class RunCfg(C.Structure):
     _fields_ = [(k, C.c_int32) for k in
                 ("abi_version", "nlyr", "nstr", "nmom", "onlyfl", "lamber", "usrang", "numu",
-                 "nphi", "nlevel_out", "device", "max_batch", "corint", "reserved0")] + \
+                 "nphi", "nlevel_out", "device", "max_batch", "corint", "ibdrf")] + \
                [(k, C.c_double) for k in ("umu0", "phi0", "fisot", "btemp", "ttemp", "temis")] + \
-               [("temper", _dp), ("umu", _dp), ("phi", _dp), ("level_out", _ip)]
+               [("temper", _dp), ("umu", _dp), ("phi", _dp), ("level_out", _ip), ("bpar", C.c_double * 8)]
 
 
 class BatchIn(C.Structure):
     _fields_ = [("nwork", C.c_int32), ("dtauc", C.c_void_p), ("ssalb", C.c_void_p),
                 ("pmom", C.c_void_p), ("wvnmlo", C.c_void_p), ("wvnmhi", C.c_void_p),
-                ("fbeam", C.c_void_p), ("albedo", C.c_void_p), ("plank", C.c_void_p)]
+                ("fbeam", C.c_void_p), ("albedo", C.c_void_p), ("plank", C.c_void_p), ("bitem", C.c_void_p)]
 
 
 class BatchOut(C.Structure):

@@ -25,6 +25,7 @@
 // up to FMA contraction and the last bit of the reciprocal.
 #pragma once
 #include "sbd_common.hpp"
+#include "sbd_surface.hpp"
 
 namespace sbd {
 
@@ -289,12 +290,16 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
 #define ZP1(i, lc) zp1[((lc) - 1) * n + ((i) - 1)]
 #define WIN(s, j) win[(s) * CWP + ((j) % CW)]
 
-    const bool refl = !(lyrcut || delm0 == 0.0);   // LAMBER: surface couples only for m = 0 (2925)
+    // the surface: Lambertian (couples only for m = 0, disort.f:2925) or bidirectional (SURFAC's tables of this mode)
+    const bool brdf = P.ibdrf != 0;
+    const size_t sidx = surf_index(P, slot, mazim);
+    const double *bdrt = brdf ? surf_bdr(P, sidx) : nullptr, *bemt = brdf ? surf_bem(P, sidx) : nullptr;
+    const bool refl = !lyrcut && (brdf || delm0 != 0.0);
     // ---- bottom-boundary reflection sums: S(IQ) = sum_k CWT(k) CMU(k) BDR GC(nn+1-k, IQ, ncut),
     //      Lambertian BDR = albedo for every pair (SURFAC, disort.f:3746-3763) ----
     if (lane < n) {
         double s = 0.0;
-        if (refl)
+        if (refl && !brdf)
             for (int k = 1; k <= nn; ++k) s = s + cwt[k - 1] * cmu[k - 1] * albedo * GC(nn + 1 - k, lane + 1, ncut);
         sbot[lane] = s;
     }
@@ -314,27 +319,14 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             }
         } else if (it > N - nn) {   // bottom boundary
             const int iq = it - (N - nn);
-            if (mazim > 0) {
-                v = -ZZ(iq + nn, ncut) * expbea[ncut];   // LYRCUT or Lambertian (disort.f:3441-3452)
-            } else if (lyrcut) {
-                if (beam) v = -ZZ(iq + nn, ncut) * expbea[ncut] - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
+            if (lyrcut) {                                  // nothing comes back from below the cut (disort.f:3441-3452)
+                if (mazim > 0) v = -ZZ(iq + nn, ncut) * expbea[ncut];
+                else if (beam) v = -ZZ(iq + nn, ncut) * expbea[ncut] - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
                 else v = -ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
             } else {
-                const double bdr = albedo, bem = 1.0 - albedo;
-                double sum = 0.0;
-                if (beam) {
-                    for (int jq = 1; jq <= nn; ++jq)
-                        sum = sum + cwt[jq - 1] * cmu[jq - 1] * bdr *
-                                        (ZZ(nn + 1 - jq, ncut) * expbea[ncut] + ZP0(nn + 1 - jq, ncut)
-                                         + ZP1(nn + 1 - jq, ncut) * taucpr[ncut]);
-                    v = 2.0 * sum + (bdr * umu0 * fbeam / P.pi - ZZ(iq + nn, ncut)) * expbea[ncut]
-                        + bem * bplank - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
-                } else {
-                    for (int jq = 1; jq <= nn; ++jq)
-                        sum = sum + cwt[jq - 1] * cmu[jq - 1] * bdr *
-                                        (ZP0(nn + 1 - jq, ncut) + ZP1(nn + 1 - jq, ncut) * taucpr[ncut]);
-                    v = 2.0 * sum + bem * bplank - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
-                }
+                v = surf_bottom_rhs(iq, mazim, beam, fbeam, umu0, P.pi, albedo, bdrt, bemt, nn, cwt, cmu,
+                                    zz + (ncut - 1) * n, zp0 + (ncut - 1) * n, zp1 + (ncut - 1) * n,
+                                    expbea[ncut], taucpr[ncut], bplank);
             }
         } else {   // interface lc | lc+1
             const int q = it - nn - 1;
@@ -369,7 +361,12 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             const int iq = col - (N - n);
             if (iq >= 1) {
                 g = GC(nn + (r - (N - nn)), iq, ncut);
-                if (refl) g = g - (1.0 + delm0) * sbot[iq - 1];
+                if (refl && brdf) {                        // row r - (N - nn) of BDR meets the downward streams (disort.f:2946-2952)
+                    double sr = 0.0;
+                    for (int k = 1; k <= nn; ++k)
+                        sr = sr + cwt[k - 1] * cmu[k - 1] * SBD_BDR(bdrt, r - (N - nn), k) * GC(nn + 1 - k, iq, ncut);
+                    g = g - (1.0 + delm0) * sr;
+                } else if (refl) g = g - (1.0 + delm0) * sbot[iq - 1];
                 if (iq > nn) f = EK(n + 1 - iq, ncut);
             }
         } else {                             // continuity between layers lc and lc+1

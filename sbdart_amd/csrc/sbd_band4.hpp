@@ -32,6 +32,7 @@
 #pragma once
 #include "sbd_common.hpp"
 #include "sbd_band.hpp"
+#include "sbd_surface.hpp"
 
 namespace sbd {
 
@@ -131,7 +132,11 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
 #define ZZ(i, lc) zz[((lc) - 1) * n + ((i) - 1)]
 #define ZP0(i, lc) zp0[((lc) - 1) * n + ((i) - 1)]
 #define ZP1(i, lc) zp1[((lc) - 1) * n + ((i) - 1)]
-    const bool refl = !(lyrcut || delm0 == 0.0);   // LAMBER: the surface couples only for m = 0 (disort.f:2925)
+    // the surface: Lambertian (couples only for m = 0, disort.f:2925) or bidirectional (SURFAC's tables of this mode)
+    const bool brdf = P.ibdrf != 0;
+    const size_t sidx = surf_index(P, slot, mazim);
+    const double *bdrt = brdf ? surf_bdr(P, sidx) : nullptr, *bemt = brdf ? surf_bem(P, sidx) : nullptr;
+    const bool refl = !lyrcut && (brdf || delm0 != 0.0);
     const bool col = q < n;                        // this lane carries a column
     const int iq1 = q + 1;                         // its 1-based index inside a layer
 
@@ -153,27 +158,14 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             }
         } else {        // bottom boundary
             const int iq = it - (N - nn);
-            if (mazim > 0) {
-                v = -ZZ(iq + nn, ncut) * expbea[ncut];   // LYRCUT or Lambertian (disort.f:3441-3452)
-            } else if (lyrcut) {
-                if (beam) v = -ZZ(iq + nn, ncut) * expbea[ncut] - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
+            if (lyrcut) {                                  // nothing comes back from below the cut (disort.f:3441-3452)
+                if (mazim > 0) v = -ZZ(iq + nn, ncut) * expbea[ncut];
+                else if (beam) v = -ZZ(iq + nn, ncut) * expbea[ncut] - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
                 else v = -ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
             } else {
-                const double bdr = albedo, bem = 1.0 - albedo;
-                double sum = 0.0;
-                if (beam) {
-                    for (int jq = 1; jq <= nn; ++jq)
-                        sum = sum + cwt[jq - 1] * cmu[jq - 1] * bdr *
-                                        (ZZ(nn + 1 - jq, ncut) * expbea[ncut] + ZP0(nn + 1 - jq, ncut)
-                                         + ZP1(nn + 1 - jq, ncut) * taucpr[ncut]);
-                    v = 2.0 * sum + (bdr * umu0 * fbeam / P.pi - ZZ(iq + nn, ncut)) * expbea[ncut]
-                        + bem * bplank - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
-                } else {
-                    for (int jq = 1; jq <= nn; ++jq)
-                        sum = sum + cwt[jq - 1] * cmu[jq - 1] * bdr *
-                                        (ZP0(nn + 1 - jq, ncut) + ZP1(nn + 1 - jq, ncut) * taucpr[ncut]);
-                    v = 2.0 * sum + bem * bplank - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
-                }
+                v = surf_bottom_rhs(iq, mazim, beam, fbeam, umu0, P.pi, albedo, bdrt, bemt, nn, cwt, cmu,
+                                    zz + (ncut - 1) * n, zp0 + (ncut - 1) * n, zp1 + (ncut - 1) * n,
+                                    expbea[ncut], taucpr[ncut], bplank);
             }
         }
         // (ncut = 1: the bottom rows are rows nn+1..n of the same layer; top entries first, then these)
@@ -199,7 +191,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     //      win a pivot search), so that the last elimination step reads its rows like the others ----
     if (col) {
         double sb = 0.0;
-        if (refl)
+        if (refl && !brdf)
             for (int k = 1; k <= nn; ++k) sb = sb + cwt[k - 1] * cmu[k - 1] * albedo * GC(nn + 1 - k, iq1, ncut);
         const double f = (iq1 > nn) ? EK(n + 1 - iq1, ncut) : 1.0;
         // (stored in the quarter layout the rows of every step are read in, see step_rows below)
@@ -228,7 +220,11 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             double g = 0.0;
             if (r < nn) {
                 g = GC(nn + 1 + r, iq1, ncut);
-                if (refl) g = g - (1.0 + delm0) * sb;
+                if (refl && brdf) {                        // row r+1 of BDR meets the downward streams (disort.f:2946-2952)
+                    double s = 0.0;
+                    for (int k = 1; k <= nn; ++k) s = s + cwt[k - 1] * cmu[k - 1] * SBD_BDR(bdrt, r + 1, k) * GC(nn + 1 - k, iq1, ncut);
+                    g = g - (1.0 + delm0) * s;
+                } else if (refl) g = g - (1.0 + delm0) * sb;
                 g = g * f;
             }
             if constexpr (FUSED) { if (r >= nn && r < nn + 3) g = cb[r - nn]; }

@@ -43,6 +43,8 @@ struct Tables {            // per-run constants, device pointers
     const double *cosphi;  // [nphi]            cos((phi-phi0)*rpd), always filled (INTCOR's scattering angle)
     const double *zeros;   // [n][n] of 0.0 (the x_lc+1 block of the bottom-boundary rows, sbd_band4.hpp)
     const double *tags;    // [nn][nn]: rows 0..2 hold 1, 2, 3 -- marks of the fused band kernel's functional rows
+    const double *gmu50;   // [50] SURFAC's azimuth / incidence quadrature: QGAUSN(25) and its mirror image (disort.f:3707-3716)
+    const double *gwt50;   // [50]
     const double *temper;  // [L+1]
     const double *umu;     // [numu]
     const int32_t *level_out; // [nlev]
@@ -74,6 +76,12 @@ struct Params {
                             //   nn+1-jq) = [0][iq-1][jq-1] and GC(nn+1-iq, jq+nn) = -GC(iq+nn, nn+1-jq) = [1][iq-1][jq-1]
                             //   (disort.f:3290-3312): what sbd_band4.hpp reads -- half the bytes of GC
     double *gu, *zb, *z0u, *z1u, *uum;
+    // bidirectional surface (sbd_surface.hpp): model 1..3 (0 = Lambertian), its run parameters, per-item ocean
+    // constants [nslot][4], and SURFAC's tables per (item or run, mode)
+    int32_t ibdrf, brdf_shared, brdf_bad;   // brdf_bad: CHEKIN rejected the (wavelength-independent) model
+    double bpar[8];
+    const double *bitem;
+    double *bdr, *bem, *rmu, *emu;
     int32_t *pivdbg;        // [ms][L*n] register index of each pivot row (band4_kernel<.., PIVDBG>), tests only
     // outputs (offset to the chunk)
     double *flux, *uu; int32_t *status;

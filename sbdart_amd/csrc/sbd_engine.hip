@@ -30,6 +30,7 @@
 #include "sbd_band.hpp"     // BandLds / SolveLds / u_width (host-side sizes)
 #include "sbd_layer.hpp"    // LayerLds
 #include "sbd_layer2.hpp"   // Layer2Lds
+#include "sbd_surface.hpp"  // bidirectional surfaces: surfac_kernel, host-side check of the model
 static_assert(sbd::SBD_NFLUX_ == SBD_NFLUX, "flux component count");
 
 namespace {
@@ -196,6 +197,9 @@ struct sbd_engine {
     bool band_reg = false;
     bool band4 = false;             // four systems per wave, block form (sbd_band4.hpp), NSTR <= 16
     bool band1 = false;             // one system per wave, block form in registers (sbd_band1.hpp), 16 < NSTR <= 32
+    int32_t *d_surf_flag = nullptr; // shared surface tables: CHEKIN's verdict on the model (sbd_surface.hpp)
+    double *d_surf = nullptr;       // shared surface tables (Hapke / Ross-Li: one set per run)
+    bool brdf_bad = false;          // ... the model's flux albedo leaves [0,1]: every item gets SBD_ST_ERR_INPUT
     bool fused = false;             // band4, flux-only, levels = {top of layer 1, surface}: the band kernel carries FLUXES'
                                     // functionals through the elimination -- no U factor, no back-substitution kernel
     bool corint = false;            // intensity corrections after the azimuth series (sbd_intcor.hpp)
@@ -235,6 +239,8 @@ void sbd_engine_destroy(sbd_engine *e)
     if (e->d_acc) (void)hipFree(e->d_acc);
     if (e->d_red) (void)hipFree(e->d_red);
     if (e->d_pivdbg) (void)hipFree(e->d_pivdbg);
+    if (e->d_surf) (void)hipFree(e->d_surf);
+    if (e->d_surf_flag) (void)hipFree(e->d_surf_flag);
     for (auto &x : e->ev)
         if (x) (void)hipEventDestroy(x);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -256,7 +262,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     if (n < 4 || n > SBD_MAX_NSTR || (n & 1)) return fail(SBD_E_INVALID, "NSTR must be even, 4..40");
     if (L < 1 || L > SBD_MAX_NLYR) return fail(SBD_E_INVALID, "NLYR out of range");
     if (cfg->nmom < 0) return fail(SBD_E_INVALID, "NMOM < 0");
-    if (!cfg->lamber) return fail(SBD_E_UNSUPPORTED, "non-Lambertian surface");
+    if (!cfg->lamber && (cfg->ibdrf < 1 || cfg->ibdrf > 3)) return fail(SBD_E_INVALID, "lamber = 0 needs ibdrf = 1, 2 or 3");
+    if (cfg->lamber && cfg->ibdrf != 0) return fail(SBD_E_INVALID, "ibdrf set with lamber = 1");
     if (!cfg->temper) return fail(SBD_E_INVALID, "temper is NULL");
     const bool rad = !cfg->onlyfl;
     if (rad) {
@@ -352,6 +359,13 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     std::vector<double> cphi1((size_t)(nphi > 0 ? nphi : 1), 1.0);
     for (int j = 0; j < nphi; ++j) cphi1[j] = cos((ref_pi() / 180.0) * (cfg->phi[j] - cfg->phi0));
     const size_t o_cphi = push(cphi1.data(), cphi1.size());
+    std::vector<double> g50(2 * sbd::kSurfGauss, 0.0);
+    gauss01(sbd::kSurfGauss / 2, g50.data(), g50.data() + sbd::kSurfGauss);
+    for (int k = 0; k < sbd::kSurfGauss / 2; ++k) {
+        g50[k + sbd::kSurfGauss / 2] = -g50[k];
+        g50[sbd::kSurfGauss + k + sbd::kSurfGauss / 2] = g50[sbd::kSurfGauss + k];
+    }
+    const size_t o_g50 = push(g50.data(), g50.size());
     const size_t o_temper = push(cfg->temper, L + 1);
     double zero = 0.0;
     const size_t o_umu = numu > 0 ? push(cfg->umu, numu) : push(&zero, 1);
@@ -388,6 +402,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->tab.ylmu = e->d_tab + o_ylmu;
     e->tab.cosmphi = e->d_tab + o_cos;
     e->tab.cosphi = e->d_tab + o_cphi;
+    e->tab.gmu50 = e->d_tab + o_g50;
+    e->tab.gwt50 = e->d_tab + o_g50 + sbd::kSurfGauss;
     e->tab.zeros = e->d_tab + o_zero;
     e->tab.tags = e->d_tab + o_tags;
     e->tab.temper = e->d_tab + o_temper;
@@ -409,7 +425,9 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const size_t nblk = band4 ? 1 : 3;
     const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)2 * n * n : 0) + (size_t)L * n * 6 + (size_t)L * nn + (fused ? 0 : (size_t)L * n * (2 * n))
                                             + (rad ? (size_t)L * n * numu + 3 * (size_t)L * numu + (size_t)e->nlev * numu : 0));
-    const size_t per_slot = per_ms * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
+    const bool brdf = !cfg->lamber, brdf_item = brdf && cfg->ibdrf == 1;      // (the ocean's tables follow the wavelength)
+    const size_t surf_per_ms = sizeof(double) * ((size_t)nn * (nn + 1) + nn + (size_t)numu * (nn + 1) + numu + 4);
+    const size_t per_slot = (per_ms + (brdf_item ? surf_per_ms : 0)) * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
     size_t budget = (size_t)64 << 30;   // of 288 GB: fewer, larger passes (launch tails cost ~7 % at 16k items)
     if (const char *s = getenv("SBD_WORKSPACE_MB")) budget = (size_t)atoll(s) << 20;
     // Two workspaces of `chunk` items each: consecutive passes of a batch alternate between them on two
@@ -469,6 +487,17 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
             P.z0u = (double *)take(sizeof(double) * nms * L * numu);
             P.z1u = (double *)take(sizeof(double) * nms * L * numu);
             P.uum = (double *)take(sizeof(double) * nms * e->nlev * numu);
+        }
+        P.ibdrf = brdf ? cfg->ibdrf : 0;
+        P.brdf_shared = (brdf && !brdf_item) ? 1 : 0;
+        for (int k = 0; k < 8; ++k) P.bpar[k] = brdf ? cfg->bpar[k] : 0.0;
+        P.bitem = nullptr;
+        P.bdr = P.bem = P.rmu = P.emu = nullptr;
+        if (brdf_item) {
+            P.bdr = (double *)take(sizeof(double) * nms * nn * (nn + 1));
+            P.bem = (double *)take(sizeof(double) * nms * nn);
+            P.rmu = (double *)take(sizeof(double) * nms * (numu > 0 ? numu : 1) * (nn + 1));
+            P.emu = (double *)take(sizeof(double) * nms * (numu > 0 ? numu : 1));
         }
         if ((size_t)(p - e->d_ws) > e->ws_bytes / 2) {
             sbd_engine_destroy(e);
@@ -532,7 +561,32 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         sbd::Params &Q = e->P2;
         mv(Q.eiglist); mv(Q.sv); mv(Q.svi); mv(Q.gc); mv(Q.ga); mv(Q.gb); mv(Q.bcb); mv(Q.gcc); mv(Q.kk); mv(Q.ek); mv(Q.zz); mv(Q.zp0);
         mv(Q.zp1); mv(Q.ll); mv(Q.yv); mv(Q.ufac); mv(Q.gu); mv(Q.zb); mv(Q.z0u); mv(Q.z1u); mv(Q.uum);
+        if (brdf_item) { mv(Q.bdr); mv(Q.bem); mv(Q.rmu); mv(Q.emu); }
         CREATE_TRY(hipMemset(Q.eiglist, 0, sizeof(int32_t) * ((size_t)e->chunk * e->nmode * e->L + 4)));
+    }
+    if (brdf && !brdf_item) {
+        // Hapke / Ross-Li do not depend on the wavelength: SURFAC's tables and CHEKIN's test of the model are made
+        // once, here, for every azimuth mode (the beam column included: it only ever meets FBEAM > 0)
+        const size_t cnt = (size_t)nmode * ((size_t)nn * (nn + 1) + nn + (size_t)(numu > 0 ? numu : 1) * (nn + 2));
+        CREATE_TRY(hipMalloc(&e->d_surf, sizeof(double) * cnt));
+        CREATE_TRY(hipMemset(e->d_surf, 0, sizeof(double) * cnt));
+        CREATE_TRY(hipMalloc(&e->d_surf_flag, sizeof(int32_t)));
+        CREATE_TRY(hipMemset(e->d_surf_flag, 0, sizeof(int32_t)));
+        double *q = e->d_surf;
+        for (sbd::Params *PP : {&e->P, &e->P2}) {
+            PP->bdr = q;
+            PP->bem = q + (size_t)nmode * nn * (nn + 1);
+            PP->rmu = PP->bem + (size_t)nmode * nn;
+            PP->emu = PP->rmu + (size_t)nmode * (numu > 0 ? numu : 1) * (nn + 1);
+        }
+        sbd::Params Ps = e->P;
+        Ps.nslot = 1;
+        hipLaunchKernelGGL(sbd::surfac_kernel, dim3((unsigned)nmode), dim3(256), sizeof(double) * sbd::surf_lds_doubles(nn, numu),
+                           e->stream, Ps, e->d_surf_flag);
+        int32_t flag = 0;
+        CREATE_TRY(hipMemcpyAsync(&flag, e->d_surf_flag, sizeof(flag), hipMemcpyDeviceToHost, e->stream));
+        CREATE_TRY(hipStreamSynchronize(e->stream));
+        e->brdf_bad = flag != 0;
     }
 #undef CREATE_TRY
 
@@ -644,6 +698,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
     if (in->nwork == 0) return SBD_OK;
     if (!in->dtauc || !in->ssalb || !in->pmom || !in->wvnmlo || !in->wvnmhi || !in->fbeam || !in->albedo || !in->plank)
         return fail(SBD_E_INVALID, "null input array");
+    if (e->P.ibdrf == 1 && !in->bitem) return fail(SBD_E_INVALID, "ocean surface (ibdrf = 1): bitem is NULL");
     if (!out->flux || !out->status) return fail(SBD_E_INVALID, "null output array");
     const bool rad = !e->cfg.onlyfl;
     if (rad && !out->uu) return fail(SBD_E_INVALID, "uu is NULL in radiance mode");
@@ -688,6 +743,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         HIP_TRY(hipMemcpyAsync((void *)(in->fbeam + w0), hs->in->fbeam + w0, sizeof(double) * ns, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipMemcpyAsync((void *)(in->albedo + w0), hs->in->albedo + w0, sizeof(double) * ns, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipMemcpyAsync((void *)(in->plank + w0), hs->in->plank + w0, (size_t)ns, hipMemcpyHostToDevice, cs));
+        if (in->bitem) HIP_TRY(hipMemcpyAsync((void *)(in->bitem + (size_t)w0 * 4), hs->in->bitem + (size_t)w0 * 4, sizeof(double) * 4 * ns, hipMemcpyHostToDevice, cs));
         if ((int)e->ev_h2d.size() <= ip) {
             hipEvent_t ev = nullptr;
             HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -716,12 +772,17 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         P.pmom = in->pmom + (size_t)w0 * L * (e->cfg.nmom + 1);
         P.wvnmlo = in->wvnmlo + w0; P.wvnmhi = in->wvnmhi + w0;
         P.fbeam = in->fbeam + w0; P.albedo = in->albedo + w0; P.plank = in->plank + w0;
+        P.bitem = in->bitem ? in->bitem + (size_t)w0 * 4 : nullptr;
+        P.brdf_bad = e->brdf_bad ? 1 : 0;
         P.flux = out->flux + (size_t)w0 * SBD_NFLUX * nlev;
         P.uu = rad ? out->uu + (size_t)w0 * e->P.nphi * nlev * e->P.numu : nullptr;
         P.status = out->status + w0;
 
         if (timing) HIP_TRY(hipEventRecord(e->ev[0], st));
         sbd::launch_setup((unsigned)ns, st, P);
+        if (P.ibdrf && !P.brdf_shared)      // the ocean's SURFAC tables and CHEKIN's test of them, per item and mode
+            hipLaunchKernelGGL(sbd::surfac_kernel, dim3((unsigned)((size_t)ns * nmode)), dim3(256),
+                               sizeof(double) * sbd::surf_lds_doubles(e->nn, e->P.numu), st, P, (int32_t *)nullptr);
         SBD_DBG("setup");
         if (timing) HIP_TRY(hipEventRecord(e->ev[1], st));
         {
@@ -830,7 +891,10 @@ static int solve_host_enqueue(sbd_engine *e, const sbd_batch_in *in, const sbd_b
     const size_t b_flux = sizeof(double) * W * SBD_NFLUX * nlev;
     const size_t b_uu = rad ? sizeof(double) * W * e->P.nphi * nlev * e->P.numu : 0;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t total = 2 * up(b_lay) + up(b_pm) + 5 * up(b_w) + up(W) + up(b_flux) + up(b_uu) + up(sizeof(int32_t) * W);
+    const bool ocean = e->P.ibdrf == 1;
+    if (ocean && !in->bitem) return fail(SBD_E_INVALID, "ocean surface (ibdrf = 1): bitem is NULL");
+    const size_t total = 2 * up(b_lay) + up(b_pm) + 5 * up(b_w) + up(W) + up(b_flux) + up(b_uu) + up(sizeof(int32_t) * W)
+                         + (ocean ? up(4 * b_w) : 0);
     int rc = ensure_stage(e, total);
     if (rc != SBD_OK) return rc;
     char *p = e->d_stage;
@@ -842,9 +906,10 @@ static int solve_host_enqueue(sbd_engine *e, const sbd_batch_in *in, const sbd_b
     double *d_flux = (double *)take(b_flux);
     double *d_uu = rad ? (double *)take(b_uu) : nullptr;
     int32_t *d_st = (int32_t *)take(sizeof(int32_t) * W);
+    double *d_bi = ocean ? (double *)take(4 * b_w) : nullptr;
     hipStream_t st = e->stream;
     if (weight) HIP_TRY(hipMemcpyAsync(d_wt, weight, b_w, hipMemcpyHostToDevice, st));
-    sbd_batch_in din = {in->nwork, d_dt, d_ss, d_pm, d_lo, d_hi, d_fb, d_al, d_pl};
+    sbd_batch_in din = {in->nwork, d_dt, d_ss, d_pm, d_lo, d_hi, d_fb, d_al, d_pl, d_bi};
     sbd_batch_out dout = {d_flux, d_uu, d_st};
     // pinned landing area for the outputs the caller wants (see sbd_engine::h_pin)
     const size_t w_flux = out->flux ? up(b_flux) : 0, w_uu = (rad && out->uu) ? up(b_uu) : 0, w_st = out->status ? up(sizeof(int32_t) * W) : 0;
@@ -1119,7 +1184,8 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
             int32_t lo, hi;
             sbd_shard_range(in->nwork, nd, r, &lo, &hi);
             sbd_batch_in si = {hi - lo, in->dtauc + (size_t)lo * L, in->ssalb + (size_t)lo * L, in->pmom + (size_t)lo * L * nmom1,
-                               in->wvnmlo + lo, in->wvnmhi + lo, in->fbeam + lo, in->albedo + lo, in->plank + lo};
+                               in->wvnmlo + lo, in->wvnmhi + lo, in->fbeam + lo, in->albedo + lo, in->plank + lo,
+                               in->bitem ? in->bitem + (size_t)lo * 4 : nullptr};
             sbd_batch_out so = {out->flux ? out->flux + (size_t)lo * nel_f : nullptr,
                                 (rad && out->uu) ? out->uu + (size_t)lo * uu_item : nullptr, out->status + lo};
             f->t_enq[2 * r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

@@ -118,10 +118,10 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
         if (pm < -1.0 || pm > 1.0) err = 1;
     }
     if (fbeam < 0.0 || (fbeam > 0.0 && (umu0 <= 0.0 || umu0 > 1.0))) err = 1;
-    {
-        const double alb = P.albedo[slot];
+    if (P.ibdrf == 0) {                  // LAMBER: ALBEDO in [0,1] (disort.f:5075-5078); a bidirectional surface is
+        const double alb = P.albedo[slot];   // tested through its flux albedo (sbd_surface.hpp; brdf_bad: once per run)
         if (alb < 0.0 || alb > 1.0) err = 1;
-    }
+    } else if (P.brdf_bad) err = 1;
     if (plank && (wlo < 0.0 || whi <= wlo)) err = 1;
     if (err) atomicOr(&s_err, 1);
     __syncthreads();

@@ -12,6 +12,7 @@
 // in SBDART, drt.f:142), one lane per (level, angle), modes summed in order.
 #pragma once
 #include "sbd_common.hpp"
+#include "sbd_surface.hpp"
 
 namespace sbd {
 
@@ -76,9 +77,14 @@ __global__ void __launch_bounds__(64) usrint_kernel(Params P)
     // ---- surface term, identical for every user angle (Lambertian RMU = albedo,
     //      disort.f:4736-4781): bnddfu = sum_{iq=nn..1} (1+delm0) albedo CMU CWT DFUINT(iq) ----
     double bndsrf = 0.0;   // BNDDFU + BNDDIR + DELM0*EMU*BPLANK
-    const bool has_surface = !(lyrcut || mazim > 0);
+    // (a bidirectional surface reflects in every azimuth mode, and differently into every user angle: RMU, EMU of
+    //  SURFAC, sbd_surface.hpp -- the sum over the downward streams is then formed per angle, below)
+    const bool brdf = P.ibdrf != 0;
+    const size_t sidx = surf_index(P, slot, mazim);
+    const double *rmut = brdf ? surf_rmu(P, sidx) : nullptr, *emut = brdf ? surf_emu(P, sidx) : nullptr;
+    const bool has_surface = !lyrcut && (brdf || mazim == 0);
+    double *dfu = smem;   // [nn]
     if (has_surface) {
-        double *dfu = smem;   // [nn]
         if (lane < nn) {
             const int iq = lane + 1;
             double dfuint = 0.0;
@@ -184,7 +190,14 @@ __global__ void __launch_bounds__(64) usrint_kernel(Params P)
             }
             double bndint = 0.0;
             if (negumu && mazim == 0) bndint = (P.fisot + tplank) * exp(up / um);
-            else if (!negumu && has_surface) bndint = bndsrf * exp((up - taucpr[L]) / um);
+            else if (!negumu && has_surface && brdf) {
+                double bnddfu = 0.0;
+                for (int iq = nn; iq >= 1; --iq)
+                    bnddfu = bnddfu + (1.0 + delm0) * SBD_RMU(rmut, iu, nn + 1 - iq) * cmu[nn - iq] * cwt[nn - iq] * dfu[iq - 1];
+                double bnddir = 0.0;
+                if (beam) bnddir = umu0 * fbeam / pi * SBD_RMU(rmut, iu, 0) * expbea[L];
+                bndint = (bnddfu + bnddir + delm0 * emut[iu - 1] * bplank) * exp((up - taucpr[L]) / um);
+            } else if (!negumu && has_surface) bndint = bndsrf * exp((up - taucpr[L]) / um);
             result = palint + plkint + bndint;
         }
         uum[(size_t)li * numu + (iu - 1)] = result;

@@ -39,7 +39,8 @@ class DisortEngine:
                  umu: Optional[Sequence[float]] = None, phi: Optional[Sequence[float]] = None,
                  btemp: float = 0.0, ttemp: float = 0.0, temis: float = 0.0, fisot: float = 0.0,
                  lamber: bool = True, level_out: Optional[Sequence[int]] = None, device: int = 0,
-                 max_batch: int = 0, allow_retry_nstr: bool = False, corint: bool = False):
+                 max_batch: int = 0, allow_retry_nstr: bool = False, corint: bool = False,
+                 ibdrf: int = 0, bpar: Optional[Sequence[float]] = None):
         self._L = _lib.load()
         self._h = C.c_void_p()
         self.nlyr, self.nstr, self.nmom = int(nlyr), int(nstr), int(nmom)
@@ -56,12 +57,15 @@ class DisortEngine:
             abi_version=_lib.ABI_VERSION, nlyr=self.nlyr, nstr=self.nstr, nmom=self.nmom,
             onlyfl=int(self.onlyfl), lamber=int(lamber), usrang=int(usrang), numu=self.numu,
             nphi=self.nphi, nlevel_out=0 if self._lev is None else len(self._lev), device=device,
-            max_batch=max_batch, corint=int(bool(corint)), reserved0=0, umu0=umu0, phi0=phi0, fisot=fisot, btemp=btemp, ttemp=ttemp,
+            max_batch=max_batch, corint=int(bool(corint)), ibdrf=0 if lamber else int(ibdrf), umu0=umu0, phi0=phi0, fisot=fisot, btemp=btemp, ttemp=ttemp,
             temis=temis,
             temper=self._temper.ctypes.data_as(C.POINTER(C.c_double)),
             umu=self._umu.ctypes.data_as(C.POINTER(C.c_double)) if self.numu else None,
             phi=self._phi.ctypes.data_as(C.POINTER(C.c_double)) if self.nphi else None,
             level_out=None if self._lev is None else self._lev.ctypes.data_as(C.POINTER(C.c_int32)))
+        self.ibdrf = 0 if lamber else int(ibdrf)
+        for k_, v_ in enumerate(list(bpar if bpar is not None else [])[:8]):
+            cfg.bpar[k_] = float(v_)
         rc = self._create(cfg)
         self.retry_nstr = rc == _lib.E_RETRY_NSTR
         if rc == _lib.E_RETRY_NSTR and not allow_retry_nstr:
@@ -144,17 +148,17 @@ class DisortEngine:
             raise SbdError(int(got), "sbd_engine_debug_copy")
         return buf[: got // buf.itemsize]
 
-    def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank):
+    def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, bitem=None):
         """Solve a batch.  Shapes: dtauc/ssalb [W, nlyr]; pmom [W, nlyr, nmom+1];
-        wvnmlo/wvnmhi/fbeam/albedo [W]; plank [W] bool.  Returns (flux[W,5,nlev],
-        uu[W,nphi,nlev,numu] or None, status[W])."""
+        wvnmlo/wvnmhi/fbeam/albedo [W]; plank [W] bool; bitem [W, 4] with the ocean surface (ibdrf = 1) only.
+        Returns (flux[W,5,nlev], uu[W,nphi,nlev,numu] or None, status[W])."""
         try:
             import torch
             is_t = isinstance(dtauc, torch.Tensor)
         except Exception:  # torch is plumbing only
             is_t = False
         if is_t:
-            return self._solve_device(dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank)
+            return self._solve_device(dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, bitem=bitem)
         dtauc, ssalb, pmom = _f64(dtauc), _f64(ssalb), _f64(pmom)
         W = dtauc.shape[0]
         assert dtauc.shape == (W, self.nlyr) and ssalb.shape == (W, self.nlyr)
@@ -165,7 +169,8 @@ class DisortEngine:
         uu = None if self.onlyfl else np.zeros((W, self.nphi, self.nlev, self.numu))
         status = np.zeros(W, dtype=np.int32)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        bi = BatchIn(W, vp(dtauc), vp(ssalb), vp(pmom), vp(lo), vp(hi), vp(fb), vp(al), vp(pl))
+        bt = None if bitem is None else _f64(bitem).reshape(W, 4)
+        bi = BatchIn(W, vp(dtauc), vp(ssalb), vp(pmom), vp(lo), vp(hi), vp(fb), vp(al), vp(pl), None if bt is None else vp(bt))
         bo = BatchOut(vp(flux), None if uu is None else vp(uu), vp(status))
         rc = self._L.sbd_engine_solve_host(self._h, C.byref(bi), C.byref(bo))
         if rc != _lib.OK:
@@ -173,7 +178,7 @@ class DisortEngine:
         return flux, uu, status
 
     def _solve_device(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank,
-                      out=None, stream: Optional[int] = None):
+                      out=None, stream: Optional[int] = None, bitem=None):
         import torch
         W = dtauc.shape[0]
         for t in (dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo):
@@ -195,7 +200,8 @@ class DisortEngine:
         if stream is None:
             stream = torch.cuda.current_stream(dev).cuda_stream
         bi = BatchIn(W, dtauc.data_ptr(), ssalb.data_ptr(), pmom.data_ptr(), wvnmlo.data_ptr(),
-                     wvnmhi.data_ptr(), fbeam.data_ptr(), albedo.data_ptr(), plank.data_ptr())
+                     wvnmhi.data_ptr(), fbeam.data_ptr(), albedo.data_ptr(), plank.data_ptr(),
+                     None if bitem is None else bitem.data_ptr())
         bo = BatchOut(flux.data_ptr(), 0 if uu is None else uu.data_ptr(), status.data_ptr())
         rc = self._L.sbd_engine_solve_device(self._h, C.byref(bi), C.byref(bo), C.c_void_p(stream))
         if rc != _lib.OK:
@@ -270,7 +276,7 @@ class DisortFleet(DisortEngine):
         self._L.sbd_shard_range(nwork, self.size, rank, C.byref(lo), C.byref(hi))
         return lo.value, hi.value
 
-    def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, weight=None, items=True):
+    def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, weight=None, items=True, bitem=None):
         """Host (numpy) batch through every device.  Returns (flux, uu, status) and, when `weight`
         is given, also (acc_flux[5,nlev], acc_uu or None) = sum_i weight[i] * outputs[i]."""
         dtauc, ssalb, pmom = _f64(dtauc), _f64(ssalb), _f64(pmom)
@@ -283,7 +289,8 @@ class DisortFleet(DisortEngine):
         uu = None if (self.onlyfl or not items) else np.zeros((W, self.nphi, self.nlev, self.numu))
         status = np.zeros(W, dtype=np.int32)
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
-        bi = BatchIn(W, vp(dtauc), vp(ssalb), vp(pmom), vp(lo), vp(hi), vp(fb), vp(al), vp(pl))
+        bt = None if bitem is None else _f64(bitem).reshape(W, 4)
+        bi = BatchIn(W, vp(dtauc), vp(ssalb), vp(pmom), vp(lo), vp(hi), vp(fb), vp(al), vp(pl), vp(bt))
         bo = BatchOut(vp(flux), vp(uu), vp(status))
         acc_f = acc_u = None
         if weight is not None:
@@ -310,12 +317,13 @@ def engine_for_record(rec, level_out=None, device=0, max_batch=0, allow_retry_ns
         phi0=rec.phi0, onlyfl=rec.onlyfl, usrang=rec.usrang, umu=rec.umu, phi=rec.phi,
         btemp=rec.btemp, ttemp=rec.ttemp, temis=rec.temis, fisot=rec.fisot, lamber=rec.lamber,
         level_out=level_out, device=device, max_batch=max_batch, allow_retry_nstr=allow_retry_nstr,
-        corint=getattr(rec, "corint", False))
+        corint=getattr(rec, "corint", False), ibdrf=getattr(rec, "ibdrf", 0), bpar=getattr(rec, "bpar", None))
 
 
 def run_key(rec):
     return (rec.nlyr, rec.nstr, rec.nmom, rec.flags & ~1, rec.umu0, rec.phi0, rec.btemp, rec.ttemp,
-            rec.temis, rec.fisot, rec.temper.tobytes(), rec.umu.tobytes(), rec.phi.tobytes())
+            rec.temis, rec.fisot, rec.temper.tobytes(), rec.umu.tobytes(), rec.phi.tobytes(),
+            getattr(rec, "ibdrf", 0), np.asarray(getattr(rec, "bpar", np.zeros(8))).tobytes())
 
 
 def solve_records(recs, level_out=None, device=0):
@@ -332,7 +340,8 @@ def solve_records(recs, level_out=None, device=0):
                 np.stack([recs[i].dtauc for i in idx]), np.stack([recs[i].ssalb for i in idx]),
                 np.stack([recs[i].pmom for i in idx]), [recs[i].wvnmlo for i in idx],
                 [recs[i].wvnmhi for i in idx], [recs[i].fbeam for i in idx],
-                [recs[i].albedo for i in idx], [recs[i].plank for i in idx])
+                [recs[i].albedo for i in idx], [recs[i].plank for i in idx],
+                bitem=np.stack([recs[i].bitem for i in idx]) if getattr(r0, "ibdrf", 0) == 1 else None)
         for k, i in enumerate(idx):
             flux_out[i], st_out[i] = flux[k], int(st[k])
             if uu is not None:

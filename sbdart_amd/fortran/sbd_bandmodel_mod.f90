@@ -13,6 +13,7 @@ module sbd_bandmodel_mod
   use sbd_cloud_mod
   use sbd_aerosol_mod
   use sbd_filter_mod, only: read_spectrum_file
+  use sbd_surface_mod
   use omp_lib, only: omp_get_max_threads
   implicit none
   private
@@ -41,7 +42,7 @@ contains
     type(model_input), intent(in) :: m
     character(len=*), intent(out) :: why
     why = ''
-    if (.not. (m%isalb >= -1 .and. m%isalb <= 6) .and. m%isalb /= 10) why = 'BRDF surface (isalb 7, 8, 9)'
+    if (m%isalb <= -7) why = 'Lambertian surface with the flux albedo of a BRDF model (isalb -7, -8, -9)'
     if (m%kdist < 0) why = 'k-distribution files (kdist=-1)'
     if (m%nf == -2) why = 'solar spectrum from the k-distribution file (nf=-2)'
     ok = len_trim(why) == 0
@@ -247,7 +248,8 @@ contains
     type(aerosol_load) :: load
     type(layer_clouds) :: lcloud
     real(kr), allocatable :: uu(:, :), temper(:), wlalb(:), alb(:), wsun(:), ssun(:)
-    real(kr), allocatable :: sd(:, :), ss(:, :), sp(:, :, :), swt(:, :), swl(:), slo(:), shi(:), sfb(:), salb(:)
+    real(kr), allocatable :: sd(:, :), ss(:, :), sp(:, :, :), swt(:, :), swl(:), slo(:), shi(:), sfb(:), salb(:), sbit(:, :)
+    type(surface_model) :: surf
     logical, allocatable :: splank(:)
     integer, allocatable :: nk_of(:), first(:)
     real(kr) :: pbar, amu0, btemp, ttemp, rh_surface, wv1, wv2
@@ -302,7 +304,8 @@ contains
     nmom = min(m%nstr + 2, nstrms)                          ! (two more than NSTR: room for the NSTR retry)
     if (m%radiance .and. m%corint) nmom = maxmom_all
     amu0 = cos(m%sza*dtor)
-    call surface_spectrum(m%isalb, m%albcon, m%sc, wlalb, alb)
+    surf = new_surface_model(m%isalb, m%sc)                 ! (ISALB 7, 8, 9: a bidirectional surface, no albedo spectrum)
+    if (surf%ibdrf == 0) call surface_spectrum(m%isalb, m%albcon, m%sc, wlalb, alb)
     call solar_spectrum(m%nf, wsun, ssun)
     call gas_tables_init()
     call cloud_tables_init()
@@ -317,7 +320,9 @@ contains
     end if
 
     allocate(nk_of(grid%n), first(grid%n), sd(nz, mk*grid%n), ss(nz, mk*grid%n), sp(0:nmom, nz, mk*grid%n), &
-             swt(mk, grid%n), swl(grid%n), slo(grid%n), shi(grid%n), sfb(grid%n), salb(grid%n), splank(grid%n))
+             swt(mk, grid%n), swl(grid%n), slo(grid%n), shi(grid%n), sfb(grid%n), salb(grid%n), splank(grid%n), &
+             sbit(4, grid%n))
+    sbit = 0
     ! threads: one per 64 wavelengths, at most 16 (measured on the 256-core GPU box, 75 001 wavelengths: 1.2 s
     ! with 1 thread, 0.25-0.31 s with 16, 0.46-0.5 s with 64: first-touch page faults of the 2.5 GB of slot
     ! and batch arrays, not arithmetic, set the pace beyond that)
@@ -348,6 +353,7 @@ contains
         recs(i)%wvnmlo = slo(iwl); recs(i)%wvnmhi = shi(iwl); recs(i)%fbeam = sfb(iwl)
         recs(i)%umu0 = merge(1._kr, amu0, m%sza >= 90.); recs(i)%phi0 = m%phi0; recs(i)%albedo = salb(iwl)
         recs(i)%btemp = btemp; recs(i)%ttemp = ttemp; recs(i)%temis = m%temis; recs(i)%fisot = m%fisot
+        recs(i)%ibdrf = surf%ibdrf; recs(i)%bpar = surf%par; recs(i)%bitem = sbit(:, iwl)
       end do
     end do
     !$omp end parallel do
@@ -381,7 +387,11 @@ contains
       else
         plank = m%nothrm == 0
       end if
-      if (wl < wlalb(1) .or. wl > wlalb(size(wlalb))) then       ! (writes the reference's warning file: one at a time)
+      if (surf%ibdrf /= 0) then
+        rsfc = 0.                                                 ! (LAMBER off: DISORT never reads ALBEDO)
+        ! the ocean's water constants at BDREF's wavelength, the middle of the band in wavenumber (spectra.f:284)
+        if (surf%ibdrf == 1) call ocean_constants(surf, 20000./(wvhi + wvlo), sbit(1, iw), sbit(2, iw), sbit(3, iw))
+      else if (wl < wlalb(1) .or. wl > wlalb(size(wlalb))) then   ! (writes the reference's warning file: one at a time)
         !$omp critical (sbd_surface_warning)
         rsfc = max(0._kr, min(surface_albedo(wlalb, alb, wl), 1._kr))
         !$omp end critical (sbd_surface_warning)

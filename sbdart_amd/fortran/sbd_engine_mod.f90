@@ -16,20 +16,22 @@ module sbd_engine_mod
   public :: SBD_ST_WARN_SOLVE0, SBD_ST_WARN_UPBEAM, SBD_ST_WARN_UPISOT, SBD_ST_ERR_EIGEN, &
             SBD_ST_RETRY_NSTR, SBD_ST_ERR_INPUT, SBD_ST_WARN_PLKAVG
 
-  integer(c_int), parameter :: SBD_ABI_VER = 3, SBD_OK = 0, SBD_E_RETRY_NSTR = -2, SBD_NFLUX = 5
+  integer(c_int), parameter :: SBD_ABI_VER = 4, SBD_OK = 0, SBD_E_RETRY_NSTR = -2, SBD_NFLUX = 5
   integer(c_int), parameter :: SBD_ST_WARN_SOLVE0 = 1, SBD_ST_WARN_UPBEAM = 2, SBD_ST_WARN_UPISOT = 4, &
        SBD_ST_ERR_EIGEN = 8, SBD_ST_RETRY_NSTR = 16, SBD_ST_ERR_INPUT = 32, SBD_ST_WARN_PLKAVG = 64
 
   type, bind(C) :: sbd_run_cfg
     integer(c_int32_t) :: abi_version, nlyr, nstr, nmom, onlyfl, lamber, usrang, numu, nphi, &
-                          nlevel_out, device, max_batch, corint = 0, reserved0 = 0
+                          nlevel_out, device, max_batch, corint = 0, ibdrf = 0
     real(c_double) :: umu0, phi0, fisot, btemp, ttemp, temis
     type(c_ptr) :: temper, umu, phi, level_out
+    real(c_double) :: bpar(8) = 0        ! bidirectional surface parameters (lamber = 0)
   end type
 
   type, bind(C) :: sbd_batch_in
     integer(c_int32_t) :: nwork
     type(c_ptr) :: dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank
+    type(c_ptr) :: bitem = c_null_ptr    ! [4, nwork] ocean surface constants, else null
   end type
 
   type, bind(C) :: sbd_batch_out

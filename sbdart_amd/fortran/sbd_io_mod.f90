@@ -11,6 +11,10 @@ module sbd_io_mod
     integer :: nlyr, nstr, nmom, numu, nphi, flags, kd, nk, iwl
     real(kr) :: wl, wt, ff, wvnmlo, wvnmhi, fbeam, umu0, phi0, albedo, btemp, ttemp, temis, fisot
     real(kr), allocatable :: dtauc(:), ssalb(:), temper(:), pmom(:,:), umu(:), phi(:)
+    ! bidirectional surface (LAMBER flag off): model 1 ocean, 2 Hapke, 3 Ross-Li, its run parameters, and the
+    ! ocean's per-wavelength constants nr, ni, rsw (records.py: the block behind PHI when hdr(11) /= 0)
+    integer :: ibdrf = 0
+    real(kr) :: bpar(8) = 0, bitem(4) = 0
   end type
 
 contains
@@ -53,6 +57,8 @@ contains
       allocate(r%dtauc(r%nlyr), r%ssalb(r%nlyr), r%temper(0:r%nlyr), r%pmom(0:r%nmom, r%nlyr), &
                r%umu(r%numu), r%phi(r%nphi))
       read(u) r%dtauc, r%ssalb, r%temper, r%pmom, r%umu, r%phi
+      r%ibdrf = hdr(11); r%bpar = 0; r%bitem = 0
+      if (r%ibdrf /= 0) read(u) r%bpar, r%bitem
       if (has_out /= 0) then       ! reference outputs, if present, are ignored by the host
         read(u) ohdr
         allocate(skip(5*ohdr(2)))
@@ -90,6 +96,7 @@ contains
       hdr = 0; sc = 0
       hdr(1:9) = (/recs(i)%nlyr, recs(i)%nstr, recs(i)%nmom, recs(i)%numu, recs(i)%nphi, recs(i)%flags, &
                    recs(i)%kd, recs(i)%nk, recs(i)%iwl/)
+      hdr(11) = recs(i)%ibdrf
       sc(1:13) = (/recs(i)%wl, recs(i)%wt, recs(i)%ff, recs(i)%wvnmlo, recs(i)%wvnmhi, recs(i)%fbeam, recs(i)%umu0, &
                    recs(i)%phi0, recs(i)%albedo, recs(i)%btemp, recs(i)%ttemp, recs(i)%temis, recs(i)%fisot/)
       write(u) hdr, sc
@@ -98,6 +105,7 @@ contains
       else
         write(u) recs(i)%dtauc, recs(i)%ssalb, recs(i)%temper, recs(i)%pmom, recs(i)%umu, recs(i)%phi
       end if
+      if (recs(i)%ibdrf /= 0) write(u) recs(i)%bpar, recs(i)%bitem
     end do
     close(u)
   end subroutine

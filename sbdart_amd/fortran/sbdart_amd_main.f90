@@ -64,6 +64,7 @@ program sbdart_amd
   real(kr), allocatable, target :: dtauc(:,:), ssalb(:,:), pmom(:,:,:), wvnmlo(:), wvnmhi(:), fbeam(:), &
        albedo(:), flux(:,:,:), uu(:,:,:,:), temper(:), umu(:), phiv(:), weight(:), acc_flux(:,:), acc_uu(:,:,:)
   integer(c_int8_t), allocatable, target :: plank(:)
+  real(kr), allocatable, target :: bitem(:, :)        ! ocean surface: nr, ni, rsw per work item
   integer(c_int32_t), allocatable, target :: status(:), level_out(:)
   integer, allocatable :: order(:), where_solved(:)
   real(kr), allocatable :: zlev(:), plev(:)
@@ -255,6 +256,7 @@ program sbdart_amd
   ! (the band model's arrays are already the batch when every item is solved and all are of one kind)
   in_place = from_model .and. npart == nrec .and. (ncorr == nrec .or. nbeam - ncorr == nrec .or. nbeam == 0)
   allocate(wvnmlo(nrec), wvnmhi(nrec), fbeam(nrec), albedo(nrec), plank(nrec), status(nrec), weight(nrec), temper(0:nz))
+  allocate(bitem(4, nrec))
   if (in_place) then
     call move_alloc(bdtauc, dtauc); call move_alloc(bssalb, ssalb); call move_alloc(bpmom, pmom)
   else
@@ -275,6 +277,7 @@ program sbdart_amd
     wvnmlo(ip) = recs(i)%wvnmlo; wvnmhi(ip) = recs(i)%wvnmhi
     fbeam(ip) = recs(i)%fbeam; albedo(ip) = recs(i)%albedo
     plank(ip) = int(iand(recs(i)%flags, 1), c_int8_t)
+    bitem(:, ip) = recs(i)%bitem
     weight(ip) = recs(i)%wt*recs(i)%ff                 ! dwt of stdout1 (drt.f:964)
   end do
   if (from_model) then
@@ -564,7 +567,9 @@ contains
     call pick_devices()
     cfg%abi_version = SBD_ABI_VER
     cfg%nlyr = nz; cfg%nstr = ns; cfg%nmom = nmom
-    cfg%onlyfl = merge(0, 1, radcalc); cfg%lamber = 1; cfg%usrang = merge(1, 0, radcalc)
+    cfg%onlyfl = merge(0, 1, radcalc); cfg%usrang = merge(1, 0, radcalc)
+    cfg%lamber = merge(1, 0, recs(1)%ibdrf == 0)       ! a bidirectional surface: ISALB 7, 8, 9 (drt.f:468-470)
+    cfg%ibdrf = recs(1)%ibdrf; cfg%bpar = recs(1)%bpar
     cfg%numu = numu; cfg%nphi = merge(view%nphi, 0, radcalc)
     cfg%nlevel_out = nlev; cfg%device = 0; cfg%max_batch = max(1, npart)
     cfg%corint = merge(1, 0, corr)
@@ -621,6 +626,8 @@ contains
     bin%dtauc = c_loc(dtauc(1, p0)); bin%ssalb = c_loc(ssalb(1, p0)); bin%pmom = c_loc(pmom(0, 1, p0))
     bin%wvnmlo = c_loc(wvnmlo(p0)); bin%wvnmhi = c_loc(wvnmhi(p0)); bin%fbeam = c_loc(fbeam(p0))
     bin%albedo = c_loc(albedo(p0)); bin%plank = c_loc(plank(p0))
+    bin%bitem = c_null_ptr
+    if (recs(1)%ibdrf == 1) bin%bitem = c_loc(bitem(1, p0))
     bout%flux = c_loc(flux(1, 1, p0)); bout%status = c_loc(status(p0))
     bout%uu = c_null_ptr
     if (radcalc) bout%uu = c_loc(uu(1, 1, 1, p0))

@@ -16,6 +16,12 @@ All little-endian, no padding::
                                    accur, 0, 0
                   float64 dtauc[nlyr], ssalb[nlyr], temper[nlyr+1],
                           pmom[nlyr][nmom+1], umu[numu], phi[nphi]
+      if ibdrf != 0 (LAMBER off: a bidirectional surface, spectra.f:249-296; 1 ocean, 2 Hapke, 3 Ross-Li):
+                  float64 bpar[8]  = the model's run parameters (albblk, spectra.f:15-26):
+                                     1: wndspd, foam cover, foam reflectance, chlor, salin
+                                     2: hssa, hasym, hotspt, hotwdth     3: rliso, rlvol, rlgeo, rlhot, rlwdth
+                  float64 bitem[4] = per-item constants of the ocean model: refractive index nr, ni of the
+                                     water and its sub-surface reflectance rsw at this wavelength
       if has_out: int32 ohdr[4] = nstr_out (<0: "retry with another NSTR",
                                   disort.f:2645-2650), ntau, numu, 0
                   float64 rfldir[ntau], rfldn[ntau], flup[ntau], dfdt[ntau],
@@ -70,6 +76,9 @@ class SolveRecord:
     nk: int = 1
     iwl: int = 0
     ibcnd: int = 0
+    ibdrf: int = 0                       # 0 Lambertian, 1 ocean, 2 Hapke, 3 Ross-Li (LAMBER flag off)
+    bpar: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(8))
+    bitem: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(4))
     # outputs (None when the record carries inputs only)
     nstr_out: Optional[int] = None
     rfldir: Optional[np.ndarray] = None
@@ -143,12 +152,16 @@ def read_records(path: str) -> List[SolveRecord]:
             pmom = _rd(f, "<f8", nlyr * (nmom + 1)).reshape(nlyr, nmom + 1)
             umu = _rd(f, "<f8", numu)
             phi = _rd(f, "<f8", nphi)
+            ibdrf = int(hdr[10])
+            bpar = _rd(f, "<f8", 8) if ibdrf else np.zeros(8)
+            bitem = _rd(f, "<f8", 4) if ibdrf else np.zeros(4)
             r = SolveRecord(
                 nlyr=nlyr, nstr=nstr, nmom=nmom, flags=flags,
                 wvnmlo=sc[3], wvnmhi=sc[4], fbeam=sc[5], umu0=sc[6], phi0=sc[7],
                 albedo=sc[8], btemp=sc[9], ttemp=sc[10], temis=sc[11],
                 fisot=sc[12], accur=sc[13], wl=sc[0], wt=sc[1], ff=sc[2],
                 kd=int(hdr[6]), nk=int(hdr[7]), iwl=int(hdr[8]), ibcnd=int(hdr[9]),
+                ibdrf=ibdrf, bpar=bpar, bitem=bitem,
                 dtauc=dtauc, ssalb=ssalb, temper=temper, pmom=pmom, umu=umu, phi=phi)
             if has_out:
                 ohdr = _rd(f, "<i4", 4)
@@ -171,8 +184,8 @@ def write_records(path: str, recs: Iterable[SolveRecord], with_out: Optional[boo
         f.write(struct.pack("<ii", len(recs), 1 if with_out else 0))
         for r in recs:
             hdr = np.zeros(12, "<i4")
-            hdr[:10] = [r.nlyr, r.nstr, r.nmom, r.numu, r.nphi, r.flags, r.kd, r.nk,
-                        r.iwl, r.ibcnd]
+            hdr[:11] = [r.nlyr, r.nstr, r.nmom, r.numu, r.nphi, r.flags, r.kd, r.nk,
+                        r.iwl, r.ibcnd, r.ibdrf]
             sc = np.zeros(16, "<f8")
             sc[:14] = [r.wl, r.wt, r.ff, r.wvnmlo, r.wvnmhi, r.fbeam, r.umu0, r.phi0,
                        r.albedo, r.btemp, r.ttemp, r.temis, r.fisot, r.accur]
@@ -184,6 +197,9 @@ def write_records(path: str, recs: Iterable[SolveRecord], with_out: Optional[boo
                 a = np.ascontiguousarray(a, dtype="<f8")
                 assert a.shape == shape, (a.shape, shape)
                 f.write(a.tobytes())
+            if r.ibdrf:
+                f.write(np.ascontiguousarray(r.bpar, dtype="<f8").tobytes())
+                f.write(np.ascontiguousarray(r.bitem, dtype="<f8").tobytes())
             if with_out:
                 ntau = len(r.rfldir)
                 f.write(np.array([r.nstr_out, ntau, r.numu, 0], "<i4").tobytes())

@@ -121,6 +121,19 @@ def main():
           "idatm=4 wlinf=3.8 wlsup=3.8 iout=20 nstr=8 corint=t tcloud=1 zcloud=4 nre=-30 albcon=.6 nzen=5 uzen=10,80 nphi=2 phi=30,150 sza=60"],
          lambda r: r[-1:], keep_stdout=False)
 
+    # --- bidirectional surfaces (LAMBER off; BDREF spectra.f:249-296, SURFAC's quadrature disort.f:3765-3912): the
+    #     ocean model (wind 5 m/s, pigment 0.1 mg/m3), Hapke's soil, Ross-thick / Li-sparse; radiances up and down +
+    #     fluxes, a thermal + solar wavelength over the ocean, a flux-only NSTR 16 run.  The records carry the model
+    #     parameters and, for the ocean, the water's refractive index and sub-surface reflectance at the wavelength
+    emit("brdf_surfaces",
+         ["idatm=4 isat=0 wlinf=.5 wlsup=.9 wlinc=.2 isalb=7 sc=0.1,5,34.3,0 nstr=8 iout=20 nzen=5 uzen=0,80 nphi=3 phi=0,180 sza=40",
+          "idatm=4 isat=0 wlinf=.5 wlsup=.9 wlinc=.2 isalb=8 sc=0.6,0.3,0.4,0.1 nstr=8 iout=21 nzen=5 uzen=100,180 nphi=3 phi=0,180 sza=40",
+          "idatm=4 isat=0 wlinf=.5 wlsup=.9 wlinc=.2 isalb=9 sc=0.08,0.03,0.0005,1.0,2.0 nstr=8 iout=20 nzen=5 uzen=0,80 nphi=3 phi=0,180 sza=40",
+          "idatm=2 isat=0 wlinf=3.7 wlsup=3.9 wlinc=.1 isalb=7 sc=1.0,10,34.3,0 nstr=12 iout=20 nzen=4 uzen=0,75 nphi=2 phi=20,160 sza=55 tcloud=1 zcloud=3",
+          "idatm=4 isat=0 wlinf=.4 wlsup=1.0 wlinc=.3 isalb=8 sc=0.7,0.2,0.3,0.2 nstr=16 iout=10 sza=30",
+          "idatm=4 isat=0 wlinf=.6 wlsup=.6 isalb=9 sc=0.08,0.03,0.0005,1.0,2.0 nstr=4 iout=10 sza=70"],
+         lambda r: r[::2], keep_stdout=False)
+
     # --- ill-conditioned on purpose (kept apart from the 5e-6 parity files): the thermal window on a 65-level
     #     regridded atmosphere -- dozens of layers of optical depth ~1e-6 make the boundary-value system so
     #     nearly singular that the reference's own answer moves by 3e-5 when its arithmetic is merely contracted

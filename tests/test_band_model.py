@@ -66,7 +66,10 @@ def compare(mine, ref, complete):
         m = by_key.get((g.iwl, g.kd))
         assert m is not None, "work item (%d, %d) missing" % (g.iwl, g.kd)
         assert (m.nk, m.nlyr, m.nmom, m.flags & 1) == (g.nk, g.nlyr, g.nmom, g.flags & 1), (g.iwl, g.wl)
-        for f in ("wl", "wt", "ff", "wvnmlo", "wvnmhi", "fbeam", "umu0", "albedo", "btemp", "ttemp", "temis"):
+        assert m.ibdrf == g.ibdrf, (g.iwl, m.ibdrf, g.ibdrf)
+        for f in ("wl", "wt", "ff", "wvnmlo", "wvnmhi", "fbeam", "umu0", "albedo", "btemp", "ttemp", "temis", "bpar", "bitem"):
+            if f == "albedo" and g.ibdrf:            # (LAMBER off: the reference hands DISORT an unset ALBEDO)
+                continue
             e = rel(getattr(m, f), getattr(g, f))
             assert e <= TOL, (f, g.iwl, g.kd, getattr(m, f), getattr(g, f))
             worst = max(worst, e)
@@ -158,6 +161,12 @@ VARIANTS = [
     "idatm=2 iday=172 time=18.5 alat=34.4 alon=-119.8 wlinf=.3 wlsup=3 wlinc=.1 iout=1",
     "idatm=5 iday=400 time=3 alat=-70 alon=40 wlinf=.3 wlsup=3 wlinc=.3 iout=5 nzen=3 uzen=10,60 nphi=2 phi=0,90",
     "idatm=3 wlinf=.6 wlsup=1.6 wlinc=.1 tcloud=4,1,2 zcloud=1,-3,10 nre=8,10,-30 sza=55 iout=1",
+    # bidirectional surfaces: the model's parameters and, for the ocean, the water's refractive index and the
+    # sub-surface reflectance per wavelength (inside and outside Morel's 400-700 nm, with and without pigment)
+    "idatm=4 isat=0 wlinf=.35 wlsup=.9 wlinc=.05 isalb=7 sc=0.5,7,34.3,0 nstr=8 iout=20 nzen=5 uzen=0,80 nphi=3 phi=0,180 sza=40",
+    "idatm=2 isat=0 wlinf=.3 wlsup=4.2 wlinc=.3 isalb=7 sc=0,12,30,0 nstr=8 iout=10 sza=60",
+    "idatm=4 isat=0 wlinf=.5 wlsup=.9 wlinc=.2 isalb=8 sc=0.6,0.3,0.4,0.1 nstr=8 iout=21 nzen=5 uzen=100,180 nphi=3 phi=0,180 sza=40",
+    "idatm=4 isat=0 wlinf=.6 wlsup=.6 isalb=9 sc=0.08,0.03,0.0005,1.0,2.0 nstr=4 iout=10 sza=70",
 ]
 
 
@@ -290,7 +299,7 @@ def test_corint_history(tmp_path):
 
 @needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
-    for namelist, word in (("isalb=7", "surface"),
+    for namelist, word in (("isalb=-8 sc=.6,.3,.4,.1", "surface"),
                            ("kdist=-1", "k-distribution")):
         d = str(tmp_path / word)
         os.makedirs(d)

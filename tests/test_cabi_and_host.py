@@ -30,7 +30,11 @@ def test_create_fails_loudly_without_gpu_or_with_bad_config():
         DisortEngine(nlyr=2, nstr=5, nmom=6, temper=[250, 260, 270], umu0=0.5)   # odd NSTR
     assert ei.value.code == _lib.E_INVALID
     with pytest.raises(SbdError) as ei:
-        DisortEngine(nlyr=2, nstr=8, nmom=10, temper=[250, 260, 270], umu0=0.5, lamber=False)
+        DisortEngine(nlyr=2, nstr=8, nmom=10, temper=[250, 260, 270], umu0=0.5, lamber=False)   # no surface model named
+    assert ei.value.code == _lib.E_INVALID
+    with pytest.raises(SbdError) as ei:
+        DisortEngine(nlyr=2, nstr=8, nmom=10, temper=[250, 260, 270], umu0=0.5, onlyfl=False, usrang=False,
+                     umu=[0.5], phi=[0.0])                                                   # intensities at the quadrature angles
     assert ei.value.code == _lib.E_UNSUPPORTED
     if not torch.cuda.is_available():
         with pytest.raises(SbdError) as ei:

@@ -480,6 +480,58 @@ def test_intensity_corrections_against_oracle():
     _check(flux, uu, st, recs, outs)
 
 
+@pytest.mark.parametrize("nstr", [4, 8, 16, 20, 32, 36])
+def test_bidirectional_surfaces_against_oracle(nstr):
+    """LAMBER off (BDREF, spectra.f:249-296; SURFAC's quadrature, disort.f:3765-3912; the BRDF branches of SETMTX,
+    SOLVE0 and USRINT): the three surface models through every band-kernel family (four systems per wave, one per
+    wave, LDS window), fluxes and radiances on both sides of the horizon, with a thermal source (directional
+    emissivities), a LYRCUT column (no surface at all), a beamless item, and a model whose flux albedo leaves [0,1]
+    (CHEKIN's test of the surface, disort.f:5080-5096: SBD_ST_ERR_INPUT from both)."""
+    import pyoracle
+    from sbdart_amd.engine import solve_records
+    from sbdart_amd.records import F_ONLYFL, F_PLANK, F_USRANG, SolveRecord
+    rng = np.random.default_rng(1000 + nstr)
+    models = [(1, [5.0, 2.951e-6 * 5.0 ** 3.52, 0.22 * 2.951e-6 * 5.0 ** 3.52, 0.1, 34.3, 0, 0, 0], [1.34, 1.0e-8, 0.012, 0.0]),
+              (1, [12.0, 2.951e-6 * 12.0 ** 3.52, 0.22 * 2.951e-6 * 12.0 ** 3.52, 1.0, 34.3, 0, 0, 0], [1.31, 0.02, 0.0, 0.0]),
+              (2, [0.6, 0.3, 0.4, 0.1, 0, 0, 0, 0], [0.0] * 4),
+              (2, [0.9, -0.2, 0.1, 0.5, 0, 0, 0, 0], [0.0] * 4),
+              (3, [0.08, 0.03, 0.0005, 1.0, 2.0, 0, 0, 0], [0.0] * 4),
+              (3, [0.3, 0.0, 0.0, 1.0, 1.0, 0, 0, 0], [0.0] * 4),
+              (3, [0.1, 0.05, 0.02, 1.0, 1.0, 0, 0, 0], [0.0] * 4)]            # flux albedo > 1 at grazing incidence
+    nmom = min(nstr + 2, 40)
+    recs = []
+    for im, (ibdrf, bpar, bitem) in enumerate(models):
+        for variant in range(3 if nstr <= 20 else 2):
+            rad = variant == 1 and nstr <= 32
+            L = int(rng.integers(2, 7))
+            plank = variant == 2 or (im % 3 == 0 and variant == 0)
+            g = rng.uniform(0.0, 0.85, L)
+            dt = rng.uniform(0.02, 1.5, L)
+            w = rng.uniform(0.2, 0.999, L)
+            if im == 2 and variant == 0:
+                dt, w = dt * 12.0, w * 0.3                                   # absorption depth >= 10: LYRCUT
+            fbeam = 0.0 if (im == 4 and variant == 2) else float(rng.uniform(0.5, 3.0))
+            flags = (0 if rad else F_ONLYFL) | (F_USRANG if rad else 0) | (F_PLANK if plank else 0)   # LAMBER off
+            recs.append(SolveRecord(
+                nlyr=L, nstr=nstr, nmom=nmom, flags=flags, wvnmlo=2500.0, wvnmhi=2600.0, fbeam=fbeam,
+                umu0=float(rng.uniform(0.2, 0.95)), phi0=30.0, albedo=0.0, btemp=300.0, ttemp=0.0, temis=0.0,
+                dtauc=dt, ssalb=w, temper=np.linspace(230.0, 295.0, L + 1), pmom=g[:, None] ** np.arange(nmom + 1)[None, :],
+                umu=np.array([-0.9, -0.3, 0.1, 0.6, 1.0]) if rad else np.zeros(0),
+                phi=np.array([0.0, 75.0, 180.0]) if rad else np.zeros(0),
+                ibdrf=ibdrf, bpar=np.array(bpar, dtype=float), bitem=np.array(bitem, dtype=float)))
+    outs = [pyoracle.disort(r) for r in recs]
+    keep = [i for i, o in enumerate(outs) if not (o["status"] & pyoracle.RETRY_NSTR)]
+    recs, outs = [recs[i] for i in keep], [outs[i] for i in keep]
+    assert any(o["status"] & pyoracle.ERR_INPUT for o in outs) and sum(o["status"] == 0 for o in outs) >= 10
+    flux, uu, st = solve_records(recs)
+    good = [i for i, o in enumerate(outs) if not (o["status"] & pyoracle.ERR_INPUT)]
+    for i, o in enumerate(outs):
+        if i not in good:
+            assert st[i] & 0x20, (i, st[i])
+    _check([flux[i] for i in good], [uu[i] for i in good], [st[i] for i in good],
+           [recs[i] for i in good], [outs[i] for i in good])
+
+
 def _linpack_rows(ipvt, N):
     """Original row taken as pivot of column k by SGBFA, from its IPVT (1-based positions; the interchange puts the
     row that sat at position k where the pivot row was, disutil.f:866-876)."""

@@ -175,6 +175,16 @@ def main():
     static("sun.eqt", "_QFzensunEeqt", "spectra.f:4467-4477")
     static("sun.dec", "_QFzensunEdec", "spectra.f:4478-4488")
 
+    # ---- ocean surface (ISALB 7, seabdrf): refractive index of water (indwat, spectra.f:594-1222) and Morel's case-I
+    #      water coefficients on 400..700 nm by 5 nm (morcasiwat, spectra.f:467-592) ----
+    static("ocean.wl", "_QFindwatEwltab", "spectra.f:623-800")
+    static("ocean.mr", "_QFindwatEmrtab", "spectra.f:801-985")
+    static("ocean.mi", "_QFindwatEmitab", "spectra.f:986-1190")
+    static("ocean.kw", "_QFmorcasiwatEtkw", "spectra.f:499-513")
+    static("ocean.xc", "_QFmorcasiwatEtxc", "spectra.f:514-528")
+    static("ocean.e", "_QFmorcasiwatEte", "spectra.f:529-543")
+    static("ocean.bw", "_QFmorcasiwatEtbw", "spectra.f:544-558")
+
     # ---- sensor response functions ISAT 1..29 on their even wavelength grids (spectra.f:3414-4380):
     #      [wlmin, wlmax, response(1:n)] ----
     sensors = ("meteo", "goese", "goesw", "avhr81", "avhr82", "avhr91", "avhr92", "avhr101", "avhr102", "avhr111",
