@@ -1451,6 +1451,29 @@ static void fluxes(work_t *w, int ntau, const int *layru, const double *utau, co
     }
 }
 
+/* CMPINT (disort.f:1658-1778): azimuthal intensity components at the quadrature angles; uum is UUM(nstr, ntau) */
+static void cmpint(work_t *w, int ntau, const int *layru, const double *utaupr, int mazim, double fbeam, int plank,
+                   double umu0, double *uum)
+{
+    const int n = w->n, nn = w->nn, ncut = w->ncut;
+    const double *taucpr = w->taucpr;
+    for (int lu = 1; lu <= ntau; ++lu) {
+        const int lyu = layru[lu - 1];
+        if (w->lyrcut && lyu > ncut) continue;
+        for (int iq = 1; iq <= n; ++iq) {
+            double zint = 0.0;
+            for (int jq = 1; jq <= nn; ++jq)
+                zint = zint + GC(iq, jq, lyu) * LL(jq, lyu) * exp(-KK(jq, lyu) * (utaupr[lu - 1] - taucpr[lyu]));
+            for (int jq = nn + 1; jq <= n; ++jq)
+                zint = zint + GC(iq, jq, lyu) * LL(jq, lyu) * exp(-KK(jq, lyu) * (utaupr[lu - 1] - taucpr[lyu - 1]));
+            F2(uum, n, iq, lu) = zint;
+            if (fbeam > 0.0) F2(uum, n, iq, lu) = zint + ZZ(iq, lyu) * exp(-utaupr[lu - 1] / umu0);
+            if (plank && mazim == 0)
+                F2(uum, n, iq, lu) = F2(uum, n, iq, lu) + ZPLK0(iq, lyu) + ZPLK1(iq, lyu) * utaupr[lu - 1];
+        }
+    }
+}
+
 /* USRINT (disort.f:4355-4793).  uum is UUM(numu, ntau), pre-zeroed. */
 static void usrint(work_t *w, int ntau, const int *layru, const double *utaupr, const double *umu,
                    int mazim, double delm0, double fbeam, double fisot, int lamber, int plank,
@@ -1675,7 +1698,8 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
     /* ---- CHEKIN subset (disort.f:4864-5176): fatal input errors ---- */
     if (n0 < 4 || (n0 % 2) != 0 || L < 1) { out->status = SBDO_ERR_INPUT; return out->status; }
     const int n = n0, nn = n / 2;
-    int numu = (in->usrang && !in->onlyfl) ? in->numu : 0;
+    /* USRANG = false in radiance mode: the output angles are the NSTR quadrature angles (SETDIS, disort.f:2655-2669) */
+    int numu = in->onlyfl ? 0 : (in->usrang ? in->numu : n);
     const int nphi = in->onlyfl ? 0 : in->nphi;
     const int ntau = in->usrtau ? in->ntau : L + 1;
     out->ntau = ntau;
@@ -1684,7 +1708,7 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
         out->rfldir[lu] = out->rfldn[lu] = out->flup[lu] = out->dfdt[lu] = out->uavg[lu] = 0.0;
     }
     if (out->uu && !in->onlyfl)
-        for (size_t i = 0; i < (size_t)nphi * ntau * (size_t)in->numu; ++i) out->uu[i] = 0.0;
+        for (size_t i = 0; i < (size_t)nphi * ntau * (size_t)numu; ++i) out->uu[i] = 0.0;
     if (out->u0c)
         for (size_t i = 0; i < (size_t)ntau * n; ++i) out->u0c[i] = 0.0;
 
@@ -1729,8 +1753,6 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
             if (in->umu[iu] < -1.0 || in->umu[iu] > 1.0 || in->umu[iu] == 0.0) inperr = 1;
             if (iu > 0 && in->umu[iu] < in->umu[iu - 1]) inperr = 1;
         }
-    } else if (!in->onlyfl) {
-        inperr = 1; /* CMPINT path (intensities at quadrature angles) is never used by SBDART */
     }
     if (!in->onlyfl) {
         if (in->nphi <= 0) inperr = 1;
@@ -1870,6 +1892,11 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
         }
     }
     const double *umu = in->umu;
+    double qumu[64];
+    if (!in->onlyfl && !in->usrang) {              /* UMU := the quadrature angles, downward first (disort.f:2655-2669) */
+        for (int iu = 1; iu <= nn; ++iu) { qumu[iu - 1] = -CMU(nn + 1 - iu); qumu[nn + iu - 1] = CMU(iu); }
+        umu = qumu;
+    }
 
     /* ---- Planck functions (disort.f:548-571) ---- */
     double bplank = 0.0, tplank = 0.0;
@@ -2000,8 +2027,11 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
         if (in->onlyfl) break;
 
         for (size_t i = 0; i < (size_t)numu * ntau; ++i) uum[i] = 0.0;
-        usrint(w, ntau, layru, utaupr, umu, mazim, delm0, in->fbeam, in->fisot, in->lamber, in->plank,
-               pi, bplank, tplank, in->umu0, wk, uum);
+        if (in->usrang)
+            usrint(w, ntau, layru, utaupr, umu, mazim, delm0, in->fbeam, in->fisot, in->lamber, in->plank,
+                   pi, bplank, tplank, in->umu0, wk, uum);
+        else
+            cmpint(w, ntau, layru, utaupr, mazim, in->fbeam, in->plank, in->umu0, uum);
 #define UU(iu, lu, j) out->uu[((size_t)((j) - 1) * ntau + (size_t)((lu) - 1)) * numu + (size_t)((iu) - 1)]
         if (mazim == 0) {
             for (int lu = 1; lu <= ntau; ++lu)

@@ -102,6 +102,7 @@ def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False, debug_mod
     ut = f(utau) if usrtau else np.zeros(1)
     ntau = len(ut) if usrtau else rec.nlyr + 1
     numu, nphi = len(rec.umu), len(rec.phi)
+    nout = numu if (rec.usrang or rec.onlyfl) else rec.nstr     # USRANG off: intensities at the NSTR quadrature angles
     i = _In(nlyr=rec.nlyr, nstr=rec.nstr, nmom=rec.nmom, numu=numu, nphi=nphi,
             plank=int(rec.plank), onlyfl=int(rec.onlyfl), lamber=int(rec.lamber),
             usrang=int(rec.usrang), usrtau=int(usrtau), ntau=ntau,
@@ -115,7 +116,7 @@ def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False, debug_mod
     for k_ in range(4):
         i.bitem[k_] = float(getattr(rec, "bitem", np.zeros(4))[k_])
     flx = np.zeros((5, ntau))
-    uu = np.zeros((max(nphi, 1), ntau, max(numu, 1)))
+    uu = np.zeros((max(nphi, 1), ntau, max(nout, 1)))
     u0c = np.zeros((ntau, rec.nstr))
     o = _Out(rfldir=_p(flx[0]), rfldn=_p(flx[1]), flup=_p(flx[2]), dfdt=_p(flx[3]),
              uavg=_p(flx[4]), uu=_p(uu), u0c=_p(u0c) if want_u0c else None)
@@ -134,7 +135,7 @@ def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False, debug_mod
     res = dict(status=st, nstr_out=o.nstr_out, rfldir=flx[0], rfldn=flx[1], flup=flx[2],
                dfdt=flx[3], uavg=flx[4])
     if not rec.onlyfl:
-        res["uu"] = uu[:nphi, :, :numu]
+        res["uu"] = uu[:nphi, :, :nout]
     if want_u0c:
         res["u0c"] = u0c
     if dbg is not None:

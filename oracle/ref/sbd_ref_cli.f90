@@ -145,14 +145,14 @@ program sbd_ref_cli
         recs(i)%ohdr = 0
         recs(i)%ohdr(1) = nstr_io
         recs(i)%ohdr(2) = nlyr + 1
-        recs(i)%ohdr(3) = numu
+        recs(i)%ohdr(3) = numu_io                  ! (USRANG off: DISORT set it to NSTR, disort.f:2655-2669)
         allocate(recs(i)%flx(nlyr+1, 5))
         recs(i)%flx(:,1) = rfldir; recs(i)%flx(:,2) = rfldn
         recs(i)%flx(:,3) = flup;   recs(i)%flx(:,4) = dfdt
         recs(i)%flx(:,5) = uavg
         if (.not. onlyfl) then
-          allocate(recs(i)%uu(numu, nlyr+1, nphi))
-          recs(i)%uu = uu(1:numu, 1:nlyr+1, 1:nphi)
+          allocate(recs(i)%uu(numu_io, nlyr+1, nphi))
+          recs(i)%uu = uu(1:numu_io, 1:nlyr+1, 1:nphi)
         end if
       end if
       deallocate(dtauc, ssalb, temper, pmom, umu, phi, utau, rfldir, rfldn, &

@@ -202,6 +202,7 @@ struct sbd_engine {
     bool brdf_bad = false;          // ... the model's flux albedo leaves [0,1]: every item gets SBD_ST_ERR_INPUT
     bool fused = false;             // band4, flux-only, levels = {top of layer 1, surface}: the band kernel carries FLUXES'
                                     // functionals through the elimination -- no U factor, no back-substitution kernel
+    bool quad = false;              // radiances at the quadrature angles (USRANG = false): CMPINT instead of TERPEV/TERPSO/USRINT
     bool corint = false;            // intensity corrections after the azimuth series (sbd_intcor.hpp)
     int32_t *d_pivdbg = nullptr;    // sbd_engine_debug_pivots: [2][chunk * nmode][L * n]
     int64_t fallback_layers = 0;    // timing mode: (item, mode, layer) problems of the last solve left to the QR kernel
@@ -266,11 +267,11 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     if (cfg->lamber && cfg->ibdrf != 0) return fail(SBD_E_INVALID, "ibdrf set with lamber = 1");
     if (!cfg->temper) return fail(SBD_E_INVALID, "temper is NULL");
     const bool rad = !cfg->onlyfl;
+    const bool quad = rad && !cfg->usrang;     // intensities at the quadrature angles (CMPINT, disort.f:1658-1778)
     if (rad) {
-        if (!cfg->usrang) return fail(SBD_E_UNSUPPORTED, "intensities at quadrature angles (CMPINT) are not used by SBDART");
-        if (cfg->numu < 1 || cfg->numu > SBD_MAX_NSTR || !cfg->umu) return fail(SBD_E_INVALID, "NUMU/UMU");
+        if (!quad && (cfg->numu < 1 || cfg->numu > SBD_MAX_NSTR || !cfg->umu)) return fail(SBD_E_INVALID, "NUMU/UMU");
         if (cfg->nphi < 1 || cfg->nphi > SBD_MAX_NSTR || !cfg->phi) return fail(SBD_E_INVALID, "NPHI/PHI");
-        for (int i = 0; i < cfg->numu; ++i) {
+        for (int i = 0; !quad && i < cfg->numu; ++i) {
             if (cfg->umu[i] < -1.0 || cfg->umu[i] > 1.0 || cfg->umu[i] == 0.0) return fail(SBD_E_INVALID, "UMU range");
             if (i && cfg->umu[i] < cfg->umu[i - 1]) return fail(SBD_E_INVALID, "UMU must ascend");
         }
@@ -300,7 +301,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->L = L;
     const int nn = e->nn;
     e->nlev = cfg->nlevel_out > 0 ? cfg->nlevel_out : L + 1;
-    const int numu = rad ? cfg->numu : 0, nphi = rad ? cfg->nphi : 0;
+    const int numu = rad ? (quad ? n : cfg->numu) : 0, nphi = rad ? cfg->nphi : 0;
+    const bool rad_user = rad && !quad;        // TERPEV / TERPSO / USRINT: the user-angle machinery
 
     // quadrature (SETDIS, disort.f:2629-2638)
     e->h_cmu.resize(n);
@@ -308,13 +310,17 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     gauss01(nn, e->h_cmu.data(), e->h_cwt.data());
     for (int i = 0; i < nn; ++i) { e->h_cmu[i + nn] = -e->h_cmu[i]; e->h_cwt[i + nn] = e->h_cwt[i]; }
 
+    // USRANG = false: the output angles are the quadrature angles, downward first (SETDIS, disort.f:2655-2669)
+    std::vector<double> qumu(n);
+    for (int iu = 0; iu < nn; ++iu) { qumu[iu] = -e->h_cmu[nn - 1 - iu]; qumu[nn + iu] = e->h_cmu[iu]; }
+    const double *umu_ptr = quad ? qumu.data() : cfg->umu;
     // azimuth modes (disort.f:577-586): per-run part of the NAZ rule
     int naz = n - 1;
     {
         const double e5 = (double)1.0e-5f;
         if (fabs(1.0 - cfg->umu0) < e5 || cfg->onlyfl
-            || (numu == 1 && fabs(1.0 - cfg->umu[0]) < e5) || (numu == 1 && fabs(1.0 + cfg->umu[0]) < e5)
-            || (numu == 2 && fabs(1.0 + cfg->umu[0]) < e5 && fabs(1.0 - cfg->umu[1]) < e5))
+            || (numu == 1 && fabs(1.0 - umu_ptr[0]) < e5) || (numu == 1 && fabs(1.0 + umu_ptr[0]) < e5)
+            || (numu == 2 && fabs(1.0 + umu_ptr[0]) < e5 && fabs(1.0 - umu_ptr[1]) < e5))
             naz = 0;
     }
     e->naz_run = naz;
@@ -330,7 +336,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         const double ang0 = -cfg->umu0;
         for (int m = 0; m < nmode; ++m) {
             legendre_norm(1, m, n, n - 1, &ang0, y0.data());
-            if (numu > 0) legendre_norm(numu, m, n, n - 1, cfg->umu, yu.data());
+            if (numu > 0) legendre_norm(numu, m, n, n - 1, umu_ptr, yu.data());
             legendre_norm(nn, m, n, n - 1, e->h_cmu.data(), yc.data());
             double sgn = -1.0;   // mirror to -mu (disort.f:611-627)
             for (int l = m; l <= n - 1; ++l) {
@@ -368,7 +374,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const size_t o_g50 = push(g50.data(), g50.size());
     const size_t o_temper = push(cfg->temper, L + 1);
     double zero = 0.0;
-    const size_t o_umu = numu > 0 ? push(cfg->umu, numu) : push(&zero, 1);
+    const size_t o_umu = numu > 0 ? push(umu_ptr, numu) : push(&zero, 1);
     const std::vector<double> zblock((size_t)n * n, 0.0);
     const size_t o_zero = push(zblock.data(), zblock.size());
     std::vector<double> tagblock((size_t)nn * nn, 0.0);
@@ -424,7 +430,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     if (const char *s = getenv("SBD_NO_FUSE")) fused = fused && atoi(s) == 0;
     const size_t nblk = band4 ? 1 : 3;
     const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)2 * n * n : 0) + (size_t)L * n * 6 + (size_t)L * nn + (fused ? 0 : (size_t)L * n * (2 * n))
-                                            + (rad ? (size_t)L * n * numu + 3 * (size_t)L * numu + (size_t)e->nlev * numu : 0));
+                                            + (rad_user ? (size_t)L * n * numu + 3 * (size_t)L * numu : 0) + (rad ? (size_t)e->nlev * numu : 0));
     const bool brdf = !cfg->lamber, brdf_item = brdf && cfg->ibdrf == 1;      // (the ocean's tables follow the wavelength)
     const size_t surf_per_ms = sizeof(double) * ((size_t)nn * (nn + 1) + nn + (size_t)numu * (nn + 1) + numu + 4);
     const size_t per_slot = (per_ms + (brdf_item ? surf_per_ms : 0)) * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
@@ -481,13 +487,13 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         P.ll = (double *)take(sizeof(double) * nms * L * n);
         P.yv = (double *)take(sizeof(double) * nms * L * n);
         P.ufac = fused ? nullptr : (double *)take(sizeof(double) * nms * L * n * (2 * n));   // sbd::u_width(n)
-        if (rad) {
+        if (rad_user) {
             P.gu = (double *)take(sizeof(double) * nms * L * n * numu);
             P.zb = (double *)take(sizeof(double) * nms * L * numu);
             P.z0u = (double *)take(sizeof(double) * nms * L * numu);
             P.z1u = (double *)take(sizeof(double) * nms * L * numu);
-            P.uum = (double *)take(sizeof(double) * nms * e->nlev * numu);
         }
+        if (rad) P.uum = (double *)take(sizeof(double) * nms * e->nlev * numu);
         P.ibdrf = brdf ? cfg->ibdrf : 0;
         P.brdf_shared = (brdf && !brdf_item) ? 1 : 0;
         for (int k = 0; k < 8; ++k) P.bpar[k] = brdf ? cfg->bpar[k] : 0.0;
@@ -530,6 +536,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->band1 = band1;
     e->fused = fused;
     e->corint = rad && cfg->corint != 0;
+    e->quad = quad;
     e->P.ublock = e->P.gconly = band4 ? 1 : 0;
     const sbd::BandLds bl(n, nn, e->band_reg);
     e->band_lds = (int)sizeof(double) * bl.total;
@@ -544,14 +551,14 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     CREATE_TRY(sbd::prepare_band_lds(nn, e->band_lds));
     CREATE_TRY(sbd::prepare_backsolve(nn, e->solve_lds));
     {
-        const sbd::Layer2Lds l2(n, nn, rad);
+        const sbd::Layer2Lds l2(n, nn, rad_user);
         e->G2 = sbd::l2_group(nn);
         e->layer2_lds = (int)sizeof(double) * (l2.shared_total + l2.group_total * (64 / e->G2));
         if (const char *s = getenv("SBD_LAYER_V1")) e->use_layer2 = atoi(s) == 0;
         if (e->layer2_lds > 160 * 1024) e->use_layer2 = false;
         // the list is emptied by setup_kernel, filled by layer_kernel2 and walked by the QR kernel
         CREATE_TRY(hipMemset(e->d_eigflag, 0, flag_bytes));
-        if (e->use_layer2) CREATE_TRY(sbd::prepare_layer2(nn, rad, e->layer2_lds));
+        if (e->use_layer2) CREATE_TRY(sbd::prepare_layer2(nn, rad_user, e->layer2_lds));
     }
     for (auto &x : e->ev) CREATE_TRY(hipEventCreate(&x));
     {   // second workspace (every field of P is final here): each workspace pointer moved by half the allocation
@@ -793,7 +800,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             if (e->use_layer2) {
                 const int gpb2 = 64 / e->G2;
                 const unsigned g2 = (unsigned)(((size_t)ns * L + gpb2 - 1) / gpb2) * (unsigned)nmode;
-                sbd::launch_layer2(e->nn, rad, g2, e->layer2_lds, st, P, eigflag);
+                sbd::launch_layer2(e->nn, rad && !e->quad, g2, e->layer2_lds, st, P, eigflag);
                 flt = eigflag;          // the QR kernel below only redoes the listed layers: a small
                 if (grid > 256u) grid = 256u;     // fixed grid (a block per CU) walks the list, normally empty:
                                                   // its blocks ask for 30 KB of LDS each, so few of them start fast
@@ -821,7 +828,8 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         SBD_DBG("backsolve");
         if (timing) HIP_TRY(hipEventRecord(e->ev[4], st));
         if (rad) {
-            sbd::launch_usrint((unsigned)((size_t)ns * nmode), e->usr_lds, st, P);
+            if (e->quad) sbd::launch_cmpint((unsigned)((size_t)ns * nmode), st, P);
+            else sbd::launch_usrint((unsigned)((size_t)ns * nmode), e->usr_lds, st, P);
             const long long items = (long long)ns * nlev * e->P.numu;
             sbd::launch_azimuth((unsigned)((items + 255) / 256), st, P, e->naz_run);
             if (e->corint) sbd::launch_intcor((unsigned)ns, st, P, e->naz_run);

@@ -6,6 +6,7 @@
 namespace sbd {
 void launch_setup(unsigned grid, hipStream_t st, const Params &P) { hipLaunchKernelGGL(setup_kernel, dim3(grid), dim3(64), 0, st, P); }
 void launch_usrint(unsigned grid, int lds, hipStream_t st, const Params &P) { hipLaunchKernelGGL(usrint_kernel, dim3(grid), dim3(64), lds, st, P); }
+void launch_cmpint(unsigned grid, hipStream_t st, const Params &P) { hipLaunchKernelGGL(cmpint_kernel, dim3(grid), dim3(64), 0, st, P); }
 void launch_intcor(unsigned grid, hipStream_t st, const Params &P, int naz_run)
 {
     hipLaunchKernelGGL(intcor_kernel, dim3(grid), dim3(256), sizeof(double) * 2 * kIntcorPairs * P.L, st, P, naz_run);

@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(64) layer_kernel(Params P, int32_t *only_flagg
     const double fbeam = P.fbeam[slot];
     if (mazim > 0 && fbeam == 0.0) continue;     // NAZ = 0 (disort.f:582)
     const bool plank = P.plank[slot] != 0;
-    const bool rad = !P.onlyfl;
+    const bool rad = !P.onlyfl && P.usrang;   // (USRANG = false: intensities at the quadrature angles need no interpolants)
 
     const SV o(L);
     const double *sv = P.sv + (size_t)slot * P.sv_stride;

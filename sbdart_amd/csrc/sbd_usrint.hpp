@@ -215,6 +215,60 @@ __global__ void __launch_bounds__(64) usrint_kernel(Params P)
 #undef Z1U
 }
 
+// CMPINT (disort.f:1658-1778), USRANG = false: the azimuthal intensity components at the QUADRATURE angles, in the
+// stored -1 .. +1 order of the streams (SETDIS sets UMU to them, disort.f:2655-2669).  One wave per (item, mode), a
+// lane per (output level, stream); needs GC of the output levels' layers and LL.
+__global__ void __launch_bounds__(64) cmpint_kernel(Params P)
+{
+    const int lane = threadIdx.x;
+    const long long ms = blockIdx.x;
+    const int nmode = P.nmode;
+    const int mazim = (int)(ms % nmode);
+    const int slot = (int)(ms / nmode);
+    if (slot >= P.nslot) return;
+    const int L = P.L, n = P.n, nn = P.nn, nlev = P.nlev;
+    const int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
+    const int st0 = svi[SBD_SVI_STATUS];
+    const double fbeam = P.fbeam[slot];
+    double *uum = P.uum + (size_t)ms * nlev * n;
+    if ((st0 & (0x20 | 0x10 | 0x08)) != 0 || (mazim > 0 && fbeam == 0.0)) {
+        for (int i = lane; i < nlev * n; i += 64) uum[i] = 0.0;
+        return;
+    }
+    const int ncut = svi[SBD_SVI_NCUT];
+    const bool lyrcut = svi[SBD_SVI_LYRCUT] != 0;
+    const bool therm = P.plank[slot] != 0 && mazim == 0;
+    const int32_t *layru = svi + SBD_SVI_LAYRU;
+    const SV o(L);
+    const double *sv = P.sv + (size_t)slot * P.sv_stride;
+    const double *taucpr = sv + o.taucpr(), *utaupr = sv + o.utaupr();
+    const double *gc = P.gc + (size_t)ms * L * n * n;
+    const double *kk = P.kk + (size_t)ms * L * n;
+    const double *zz = P.zz + (size_t)ms * L * n;
+    const double *zp0 = P.zp0 + (size_t)(ms - mazim) * L * n;
+    const double *zp1 = P.zp1 + (size_t)(ms - mazim) * L * n;
+    const double *ll = P.ll + (size_t)ms * L * n;
+    for (int item = lane; item < nlev * n; item += 64) {
+        const int li = item / n, iq = item % n + 1;
+        const int lev = P.all_levels ? li : P.t.level_out[li];
+        const int lyu = layru[lev];
+        double r = 0.0;
+        if (!(lyrcut && lyu > ncut)) {
+            const double up = utaupr[lev];
+            const size_t lo = (size_t)(lyu - 1) * n;
+            double zint = 0.0;
+            for (int jq = 1; jq <= nn; ++jq)
+                zint = zint + gc[(lo + (iq - 1)) * n + (jq - 1)] * ll[lo + jq - 1] * exp(-kk[lo + jq - 1] * (up - taucpr[lyu]));
+            for (int jq = nn + 1; jq <= n; ++jq)
+                zint = zint + gc[(lo + (iq - 1)) * n + (jq - 1)] * ll[lo + jq - 1] * exp(-kk[lo + jq - 1] * (up - taucpr[lyu - 1]));
+            r = zint;
+            if (fbeam > 0.0) r = zint + zz[lo + iq - 1] * exp(-up / P.umu0);
+            if (therm) r = r + zp0[lo + iq - 1] + zp1[lo + iq - 1] * up;
+        }
+        uum[(size_t)li * n + (iq - 1)] = r;
+    }
+}
+
 // grid: ceil(nslot*nlev*numu / 256) blocks of 256 threads.
 __global__ void __launch_bounds__(256) azimuth_kernel(Params P, int naz_run)
 {

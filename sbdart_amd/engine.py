@@ -49,18 +49,21 @@ class DisortEngine:
         assert self._temper.shape == (self.nlyr + 1,), "TEMPER has nlyr+1 levels"
         self._umu = _f64(umu if umu is not None else [])
         self._phi = _f64(phi if phi is not None else [])
-        self.numu, self.nphi = (0, 0) if self.onlyfl else (len(self._umu), len(self._phi))
         if usrang is None:
             usrang = not self.onlyfl
+        # (radiances without user angles: at the NSTR quadrature angles, CMPINT -- the engine reports NUMU = NSTR)
+        quad = not self.onlyfl and not usrang
+        self.numu, self.nphi = (0, 0) if self.onlyfl else ((self.nstr if quad else len(self._umu)), len(self._phi))
+        cfg_numu = 0 if quad else self.numu
         self._lev = None if level_out is None else np.ascontiguousarray(level_out, dtype=np.int32)
         self._cfg = cfg = RunCfg(
             abi_version=_lib.ABI_VERSION, nlyr=self.nlyr, nstr=self.nstr, nmom=self.nmom,
-            onlyfl=int(self.onlyfl), lamber=int(lamber), usrang=int(usrang), numu=self.numu,
+            onlyfl=int(self.onlyfl), lamber=int(lamber), usrang=int(usrang), numu=cfg_numu,
             nphi=self.nphi, nlevel_out=0 if self._lev is None else len(self._lev), device=device,
             max_batch=max_batch, corint=int(bool(corint)), ibdrf=0 if lamber else int(ibdrf), umu0=umu0, phi0=phi0, fisot=fisot, btemp=btemp, ttemp=ttemp,
             temis=temis,
             temper=self._temper.ctypes.data_as(C.POINTER(C.c_double)),
-            umu=self._umu.ctypes.data_as(C.POINTER(C.c_double)) if self.numu else None,
+            umu=self._umu.ctypes.data_as(C.POINTER(C.c_double)) if cfg_numu else None,
             phi=self._phi.ctypes.data_as(C.POINTER(C.c_double)) if self.nphi else None,
             level_out=None if self._lev is None else self._lev.ctypes.data_as(C.POINTER(C.c_int32)))
         self.ibdrf = 0 if lamber else int(ibdrf)

@@ -170,7 +170,8 @@ def read_records(path: str) -> List[SolveRecord]:
                 r.nstr_out = int(ohdr[0])
                 r.rfldir, r.rfldn, r.flup, r.dfdt, r.uavg = (flx[i] for i in range(5))
                 if not r.onlyfl:
-                    r.uu = _rd(f, "<f8", nphi * ntau * numu).reshape(nphi, ntau, numu)
+                    nout = int(ohdr[2])                    # (USRANG off: the NSTR quadrature angles, disort.f:2655-2669)
+                    r.uu = _rd(f, "<f8", nphi * ntau * nout).reshape(nphi, ntau, nout)
             out.append(r)
     return out
 
@@ -202,10 +203,11 @@ def write_records(path: str, recs: Iterable[SolveRecord], with_out: Optional[boo
                 f.write(np.ascontiguousarray(r.bitem, dtype="<f8").tobytes())
             if with_out:
                 ntau = len(r.rfldir)
-                f.write(np.array([r.nstr_out, ntau, r.numu, 0], "<i4").tobytes())
+                nout = r.numu if (r.onlyfl or r.uu is None) else np.asarray(r.uu).shape[2]
+                f.write(np.array([r.nstr_out, ntau, nout, 0], "<i4").tobytes())
                 for a in (r.rfldir, r.rfldn, r.flup, r.dfdt, r.uavg):
                     f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
                 if not r.onlyfl:
                     a = np.ascontiguousarray(r.uu, dtype="<f8")
-                    assert a.shape == (r.nphi, ntau, r.numu)
+                    assert a.shape == (r.nphi, ntau, nout)
                     f.write(a.tobytes())

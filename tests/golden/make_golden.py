@@ -134,6 +134,30 @@ def main():
           "idatm=4 isat=0 wlinf=.6 wlsup=.6 isalb=9 sc=0.08,0.03,0.0005,1.0,2.0 nstr=4 iout=10 sza=70"],
          lambda r: r[::2], keep_stdout=False)
 
+    # --- intensities at the quadrature angles (USRANG = false: CMPINT, disort.f:1658-1778).  SBDART never asks for
+    #     them, so the reference's DISORT is called directly (oracle/_ref/disort_ref_cli) on inputs of the records
+    #     above with ONLYFL and USRANG switched off and three azimuths
+    if not only or "quadangles_nstr16_4" in only:
+        import dataclasses
+        import numpy as np
+        from sbdart_amd.records import F_ONLYFL, F_USRANG
+        src = (read_records(os.path.join(HERE, "cfgB_sw_nstr16.sbdrec"))[::8]
+               + read_records(os.path.join(HERE, "cfg3_lw_nstr16_cloud.sbdrec"))[::12]
+               + read_records(os.path.join(HERE, "sbchk1.sbdrec"))[::60])
+        recs = [dataclasses.replace(r.inputs_only(), flags=(r.flags & ~F_ONLYFL & ~F_USRANG), phi=np.array([0.0, 70.0, 180.0]),
+                                    umu=np.zeros(0), phi0=20.0) for r in src]
+        with tempfile.TemporaryDirectory() as d:
+            write_records(os.path.join(d, "in.sbdrec"), recs, with_out=False)
+            subprocess.run([os.path.join(ROOT, "oracle", "_ref", "disort_ref_cli"), "in.sbdrec", "out.sbdrec", "1"],
+                           cwd=d, check=True, capture_output=True)
+            out = read_records(os.path.join(d, "out.sbdrec"))
+        path = os.path.join(HERE, "quadangles_nstr16_4.sbdrec")
+        write_records(path, out, with_out=True)
+        manifest["quadangles_nstr16_4"] = {"namelists": ["(disort_ref_cli on the inputs of cfgB / cfg3 / sbchk1 records, ONLYFL and USRANG off)"],
+                                           "records": len(out), "bytes": os.path.getsize(path),
+                                           "sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "reference_warnings": []}
+        print("quadangles_nstr16_4", len(out), "records")
+
     # --- ill-conditioned on purpose (kept apart from the 5e-6 parity files): the thermal window on a 65-level
     #     regridded atmosphere -- dozens of layers of optical depth ~1e-6 make the boundary-value system so
     #     nearly singular that the reference's own answer moves by 3e-5 when its arithmetic is merely contracted

@@ -33,9 +33,8 @@ def test_create_fails_loudly_without_gpu_or_with_bad_config():
         DisortEngine(nlyr=2, nstr=8, nmom=10, temper=[250, 260, 270], umu0=0.5, lamber=False)   # no surface model named
     assert ei.value.code == _lib.E_INVALID
     with pytest.raises(SbdError) as ei:
-        DisortEngine(nlyr=2, nstr=8, nmom=10, temper=[250, 260, 270], umu0=0.5, onlyfl=False, usrang=False,
-                     umu=[0.5], phi=[0.0])                                                   # intensities at the quadrature angles
-    assert ei.value.code == _lib.E_UNSUPPORTED
+        DisortEngine(nlyr=2, nstr=8, nmom=10, temper=[250, 260, 270], umu0=0.5, onlyfl=False, umu=[0.5, 0.2], phi=[0.0])
+    assert ei.value.code == _lib.E_INVALID                                                   # UMU must ascend
     if not torch.cuda.is_available():
         with pytest.raises(SbdError) as ei:
             DisortEngine(nlyr=2, nstr=8, nmom=10, temper=[250, 260, 270], umu0=0.5)
