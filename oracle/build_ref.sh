@@ -42,7 +42,7 @@ done
 
 # --- capture build: rename the three reference definitions, link wrappers ---
 "$OBJCOPY" --redefine-sym disort_=disort_ref_     disort.o  disort_cap.o
-"$OBJCOPY" --redefine-sym depthscl_=depthscl_ref_ --redefine-sym absint_=absint_ref_ taugas.o  taugas_cap.o
+"$OBJCOPY" --redefine-sym depthscl_=depthscl_ref_ --redefine-sym absint_=absint_ref_ --redefine-sym readk_=readk_ref_ taugas.o  taugas_cap.o
 "$OBJCOPY" --redefine-sym filter_=filter_ref_     spectra.o spectra_cap.o
 "$FC" $FFLAGS -c "$HERE/ref/sbd_ref_capture.f90" -o sbd_ref_capture.o
 "$FC" $FFLAGS -o "$OUT/sbdart_capture" params.o tauaero.o taugas_cap.o spectra_cap.o \

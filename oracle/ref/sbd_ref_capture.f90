@@ -23,8 +23,8 @@ module sbd_capture_state
   implicit none
   integer, parameter :: dp = selected_real_kind(10)
   integer :: rec_unit = -1
-  integer :: cur_kd = 0, cur_nk = 0, cur_iwl = 0
-  real(dp) :: cur_wl = 0, cur_wt = 0, cur_ff = 1, last_wl = -1
+  integer :: cur_kd = 0, cur_nk = 0, cur_iwl = 0, cur_ib = 1, cur_nb = 1, last_ib = 1
+  real(dp) :: cur_wl = 0, cur_wt = 0, cur_ff = 1, last_wl = -1, cur_ew = 1
 contains
   subroutine capture_open()
     character(len=1024) :: path
@@ -78,6 +78,7 @@ subroutine depthscl(kdist, kd, nk, ib, nz, wl, dtaur, dtaua, &
   cur_kd = kd
   cur_nk = nk
   cur_wt = wt
+  if (kdist == -1) cur_ib = ib            ! (nb: from the readk wrapper below)
   if (wl /= last_wl) then
     cur_iwl = cur_iwl + 1
     last_wl = wl
@@ -85,13 +86,29 @@ subroutine depthscl(kdist, kd, nk, ib, nz, wl, dtaur, dtaua, &
   cur_wl = wl
 end subroutine depthscl
 
+! KDIST = -1: the k-distribution file's record of this spectral point (drt.f:427-430): its equivalent-width
+! factor goes into ff, its sub-band counters into the record header
+subroutine readk(nz, wllo, wlhi, wl, wvnmlo, wvnmhi, ib, nb, nk, etirr, ewcoef, gwk, dtauk, idb)
+  use sbd_capture_state
+  implicit none
+  integer :: nz, ib, nb, nk, idb
+  real(dp) :: wllo, wlhi, wl, wvnmlo, wvnmhi, etirr, ewcoef, gwk(*), dtauk(65, *)
+  external readk_ref
+  call readk_ref(nz, wllo, wlhi, wl, wvnmlo, wvnmhi, ib, nb, nk, etirr, ewcoef, gwk, dtauk, idb)
+  if (nk > 0) then
+    cur_ew = ewcoef
+    cur_ib = ib
+    cur_nb = nb
+  end if
+end subroutine readk
+
 function filter(w)
   use sbd_capture_state
   implicit none
   real(dp) :: w, filter
   real(dp), external :: filter_ref
   filter = filter_ref(w)
-  cur_ff = filter
+  cur_ff = filter*cur_ew                  ! drt.f:461: ff = filter(wl)*ewcoef
 end function filter
 
 subroutine disort(nlyr, dtauc, ssalb, corint, nmom, pmom, temper, &
@@ -138,6 +155,7 @@ subroutine disort(nlyr, dtauc, ssalb, corint, nmom, pmom, temper, &
   hdr(5) = nphi_in; hdr(6) = flags; hdr(7) = cur_kd; hdr(8) = cur_nk
   hdr(9) = cur_iwl; hdr(10) = ibcnd
   if (.not. lamber) hdr(11) = ibdrf
+  if (cur_nb > 1) hdr(12) = cur_ib + 65536*cur_nb
   sc = 0
   sc(1) = cur_wl;  sc(2) = cur_wt;  sc(3) = cur_ff
   sc(4) = wvnmlo;  sc(5) = wvnmhi;  sc(6) = fbeam;  sc(7) = umu0

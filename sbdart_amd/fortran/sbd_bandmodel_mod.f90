@@ -14,6 +14,7 @@ module sbd_bandmodel_mod
   use sbd_aerosol_mod
   use sbd_filter_mod, only: read_spectrum_file
   use sbd_surface_mod
+  use sbd_ckfile_mod
   use omp_lib, only: omp_get_max_threads
   implicit none
   private
@@ -43,8 +44,8 @@ contains
     character(len=*), intent(out) :: why
     why = ''
     if (m%isalb <= -7) why = 'Lambertian surface with the flux albedo of a BRDF model (isalb -7, -8, -9)'
-    if (m%kdist < 0) why = 'k-distribution files (kdist=-1)'
-    if (m%nf == -2) why = 'solar spectrum from the k-distribution file (nf=-2)'
+    if (m%kdist < -1) why = 'k-distribution mode (kdist < -1)'
+    if (m%nf == -2 .and. m%kdist /= -1) why = 'solar spectrum from a k-distribution file (nf=-2) without kdist=-1'
     ok = len_trim(why) == 0
   end function
 
@@ -235,9 +236,10 @@ contains
   ! are independent of each other (the reference's saved state is replaced by values prepared once per run), so
   ! the loop over them is an OpenMP parallel loop: every wavelength fills its own MK slots, a second parallel
   ! loop closes the slots up.  No allocation inside the loops.
-  subroutine build_work_items(m, grid, umu, phi, recs, nrec, atm, bdtauc, bssalb, bpmom, btemper)
+  subroutine build_work_items(m, grid, umu, phi, recs, nrec, atm, bdtauc, bssalb, bpmom, btemper, ck)
     type(model_input), intent(in) :: m
     type(spectral_grid), intent(in) :: grid
+    type(ck_file), intent(in), optional :: ck           ! KDIST = -1: the k-distribution file pair; `grid` is its band list
     real(kr), intent(in) :: umu(:), phi(:)
     type(optics_t), allocatable, intent(out) :: recs(:)
     integer, intent(out) :: nrec
@@ -256,22 +258,37 @@ contains
     real(kr), allocatable :: run_wl(:)
     real(kr), parameter :: dtor = 3.1415926536_kr/180.
     integer :: nz, nmom, iwl, kd, i
-    integer :: nthreads
+    integer :: nthreads, mkt
+    logical :: from_ck
 
     ! ---- once per run: profiles, rescaling, absorber amounts, clouds, aerosols, surface (drt.f:297-423) ----
-    if (m%idatm == 0) then
-      atm = user_atmosphere()
+    from_ck = m%kdist == -1
+    if (from_ck .and. .not. present(ck)) call fatal('kdist=-1: no k-distribution file was read')
+    mkt = mk                                             ! k-term slots per spectral point
+    if (from_ck) then
+      ! levels, pressures and temperatures from CKATM; no gas amounts are needed (gasinit, taugas.f:7297-7390)
+      mkt = ck%maxk
+      atm%nz = ck%nz
+      atm%z = ck%z; atm%p = ck%p; atm%t = ck%t
+      allocate(atm%wh(ck%nz), atm%wo(ck%nz))
+      atm%wh = 0; atm%wo = 0
+      nz = atm%nz
+      rh_surface = relative_humidity(atm%t(1), ck%h2oden)
     else
-      atm = model_atmosphere(m%idatm)
+      if (m%idatm == 0) then
+        atm = user_atmosphere()
+      else
+        atm = model_atmosphere(m%idatm)
+      end if
+      if (m%amix > -1.) call mix_in(atm, m%amix)
+      if (m%ngrid /= 0) call regrid(atm, m%zgrid1, m%zgrid2, m%ngrid)
+      nz = atm%nz
+      pbar = m%pbar
+      if (m%zpres /= unset) pbar = pressure_at(atm, m%zpres)
+      call rescale_profiles(atm, m%sclh2o, m%uw, m%uo3, m%o3trp, m%ztrp, pbar)
+      call set_trace_gases(mix, m%xgas, m%xo4)
+      rh_surface = relative_humidity(atm%t(1), atm%wh(1))
     end if
-    if (m%amix > -1.) call mix_in(atm, m%amix)
-    if (m%ngrid /= 0) call regrid(atm, m%zgrid1, m%zgrid2, m%ngrid)
-    nz = atm%nz
-    pbar = m%pbar
-    if (m%zpres /= unset) pbar = pressure_at(atm, m%zpres)
-    call rescale_profiles(atm, m%sclh2o, m%uw, m%uo3, m%o3trp, m%ztrp, pbar)
-    call set_trace_gases(mix, m%xgas, m%xo4)
-    rh_surface = relative_humidity(atm%t(1), atm%wh(1))
     ! level temperatures top-down and the default boundary temperatures (drt.f:330-335) -- taken BEFORE the
     ! sub-surface layer is added, as the reference does (the extra bottom level keeps temperature zero)
     allocate(temper(0:nz + merge(1, 0, m%spowder)))
@@ -298,16 +315,16 @@ contains
       atm%nz = nz
     end if
     deck = new_cloud_deck(atm%z, m%zcloud, m%tcloud, m%lwp, m%nre, m%imomc)
-    if (m%rhcld >= 0) call saturate_clouds(atm, deck%layer, m%rhcld, m%krhclr == 1)
+    if (m%rhcld >= 0 .and. .not. from_ck) call saturate_clouds(atm, deck%layer, m%rhcld, m%krhclr == 1)   ! drt.f:357-365
     allocate(uu(mxq, nz))
-    call absorber_columns(atm, mix, uu)
+    if (.not. from_ck) call absorber_columns(atm, mix, uu)
     nmom = min(m%nstr + 2, nstrms)                          ! (two more than NSTR: room for the NSTR retry)
     if (m%radiance .and. m%corint) nmom = maxmom_all
     amu0 = cos(m%sza*dtor)
     surf = new_surface_model(m%isalb, m%sc)                 ! (ISALB 7, 8, 9: a bidirectional surface, no albedo spectrum)
     if (surf%ibdrf == 0) call surface_spectrum(m%isalb, m%albcon, m%sc, wlalb, alb)
     call solar_spectrum(m%nf, wsun, ssun)
-    call gas_tables_init()
+    if (.not. from_ck) call gas_tables_init()
     call cloud_tables_init()
     if (deck%nslot == 0 .and. m%nre(1) == 0.) lcloud = read_layer_clouds(nz)      ! drt.f:501-502
     load = new_aerosol_load(m%aer, atm%z, rh_surface)
@@ -319,8 +336,8 @@ contains
       call plan_aerosol_file(load, run_wl)
     end if
 
-    allocate(nk_of(grid%n), first(grid%n), sd(nz, mk*grid%n), ss(nz, mk*grid%n), sp(0:nmom, nz, mk*grid%n), &
-             swt(mk, grid%n), swl(grid%n), slo(grid%n), shi(grid%n), sfb(grid%n), salb(grid%n), splank(grid%n), &
+    allocate(nk_of(grid%n), first(grid%n), sd(nz, mkt*grid%n), ss(nz, mkt*grid%n), sp(0:nmom, nz, mkt*grid%n), &
+             swt(mkt, grid%n), swl(grid%n), slo(grid%n), shi(grid%n), sfb(grid%n), salb(grid%n), splank(grid%n), &
              sbit(4, grid%n))
     sbit = 0
     ! threads: one per 64 wavelengths, at most 16 (measured on the 256-core GPU box, 75 001 wavelengths: 1.2 s
@@ -343,9 +360,9 @@ contains
     do iwl = 1, grid%n
       do kd = 1, nk_of(iwl)
         i = first(iwl) + kd - 1
-        bdtauc(:, i) = sd(:, mk*(iwl - 1) + kd)
-        bssalb(:, i) = ss(:, mk*(iwl - 1) + kd)
-        bpmom(:, :, i) = sp(:, :, mk*(iwl - 1) + kd)
+        bdtauc(:, i) = sd(:, mkt*(iwl - 1) + kd)
+        bssalb(:, i) = ss(:, mkt*(iwl - 1) + kd)
+        bpmom(:, :, i) = sp(:, :, mkt*(iwl - 1) + kd)
         recs(i)%nlyr = nz; recs(i)%nstr = m%nstr; recs(i)%nmom = nmom; recs(i)%numu = size(umu); recs(i)%nphi = size(phi)
         recs(i)%flags = merge(1, 0, splank(iwl)) + merge(0, 2, m%radiance) + merge(16, 0, m%radiance .and. m%corint)
         recs(i)%kd = kd; recs(i)%nk = nk_of(iwl); recs(i)%iwl = iwl
@@ -354,6 +371,9 @@ contains
         recs(i)%umu0 = merge(1._kr, amu0, m%sza >= 90.); recs(i)%phi0 = m%phi0; recs(i)%albedo = salb(iwl)
         recs(i)%btemp = btemp; recs(i)%ttemp = ttemp; recs(i)%temis = m%temis; recs(i)%fisot = m%fisot
         recs(i)%ibdrf = surf%ibdrf; recs(i)%bpar = surf%par; recs(i)%bitem = sbit(:, iwl)
+        if (from_ck) then
+          recs(i)%ib = ck%ib(iwl); recs(i)%nb = ck%nb(iwl); recs(i)%ewcoef = ck%ewcoef(iwl)
+        end if
       end do
     end do
     !$omp end parallel do
@@ -363,9 +383,9 @@ contains
     subroutine one_wavelength(iw)
       integer, intent(in) :: iw
       type(gas_spectrum) :: spec
-      real(kr) :: dtaur(nz), dtauk(nz, 2*mk), dtaugc(nz), dtaug(nz), scat(nz), dtauc(nz), wcld(nz), &
+      real(kr) :: dtaur(nz), dtauk(nz, 2*max(mk, mkt)), dtaugc(nz), dtaug(nz), scat(nz), dtauc(nz), wcld(nz), &
                   pmom(0:nmom, nz), dtaua(nz), waer(nz)
-      real(kr) :: wl, wvlo, wvhi, dwl, flxin, rsfc, gwk(mk), wt, tsc, tglv, tgls, afac, ramp, amu_gas, amu_sun
+      real(kr) :: wl, wvlo, wvhi, dwl, flxin, rsfc, gwk(max(mk, mkt)), wt, tsc, tglv, tgls, afac, ramp, amu_gas, amu_sun
       integer :: nk, k, l
       logical :: plank
       call grid%band(iw - 1, wl, wvlo, wvhi)
@@ -376,10 +396,21 @@ contains
         amu_sun = 1.
         if (iw > 1) amu_gas = 1.
       end if
-      spec = spectrum_at(wl, mix%xo4)
-      call gas_terms(m%kdist, spec, uu, amu_gas, atm%z, nz, nk, gwk, dtauk, dtaugc)
+      if (from_ck) then                                          ! readk: weights and depths of this sub-band's k-terms
+        nk = ck%nk(iw)
+        gwk(1:nk) = ck%gwk(1:nk, iw)
+        dtauk(:, 1:nk) = ck%dtauk(:, 1:nk, iw)
+        dtaugc = 0.
+      else
+        spec = spectrum_at(wl, mix%xo4)
+        call gas_terms(m%kdist, spec, uu, amu_gas, atm%z, nz, nk, gwk, dtauk, dtaugc)
+      end if
       dwl = 10000./wvlo - 10000./wvhi
-      flxin = solar_irradiance(wl, m%nf, wsun, ssun)*dwl*m%solfac
+      if (m%nf == -2) then                                       ! the file's own extra-terrestrial flux (drt.f:446-448)
+        flxin = ck%etirr(iw)*m%solfac
+      else
+        flxin = solar_irradiance(wl, m%nf, wsun, ssun)*dwl*m%solfac
+      end if
       if (m%nf == 0) flxin = dwl
       if (m%sza >= 90.) flxin = 0.
       if (m%nothrm < 0) then
@@ -423,7 +454,9 @@ contains
       do k = 1, nk
         ! ---- gas depth of this k-term with the slant-path correction policy KDIST (depthscl) ----
         wt = gwk(k)
-        if (m%kdist == 0 .or. nk == 1) then
+        if (from_ck) then                                          ! depths straight from the file (taugas.f:7564-7566)
+          dtaug = dtauk(:, k)
+        else if (m%kdist == 0 .or. nk == 1) then
           wt = 1.
           tsc = 0.; tglv = 0.; tgls = 0.
           do l = 1, nz
@@ -451,13 +484,13 @@ contains
         if (m%spowder) dtaug(nz) = 0.
         ! ---- the work item's layer arrays ----
         swt(k, iw) = wt
-        sp(:, :, mk*(iw - 1) + k) = pmom
+        sp(:, :, mkt*(iw - 1) + k) = pmom
         do l = 1, nz
-          sd(l, mk*(iw - 1) + k) = dtaug(l) + dtauc(l) + dtaua(l) + dtaur(l)
-          if (sd(l, mk*(iw - 1) + k) > tiny(1._kr)) then
-            ss(l, mk*(iw - 1) + k) = (dtauc(l)*wcld(l) + dtaua(l)*waer(l) + dtaur(l))/sd(l, mk*(iw - 1) + k)
+          sd(l, mkt*(iw - 1) + k) = dtaug(l) + dtauc(l) + dtaua(l) + dtaur(l)
+          if (sd(l, mkt*(iw - 1) + k) > tiny(1._kr)) then
+            ss(l, mkt*(iw - 1) + k) = (dtauc(l)*wcld(l) + dtaua(l)*waer(l) + dtaur(l))/sd(l, mkt*(iw - 1) + k)
           else
-            ss(l, mk*(iw - 1) + k) = 0.
+            ss(l, mkt*(iw - 1) + k) = 0.
           end if
         end do
       end do

@@ -15,18 +15,20 @@
 module sbd_grid_mod
   implicit none
   private
-  public :: kr, mxly, nstrms, unset, spectral_grid, new_grid, view_geometry, new_view
+  public :: kr, mxly, nstrms, unset, spectral_grid, new_grid, new_grid_from_bands, view_geometry, new_view
 
   integer, parameter :: kr = selected_real_kind(10)
   integer, parameter :: mxly = 65, nstrms = 40          ! params.f:9-11
   real(kr), parameter :: unset = -1._kr                 ! "zip": the namelist's not-set value (params.f:24)
-  integer, parameter :: by_wavelength = 0, by_log = 1, by_wavenumber = 2
+  integer, parameter :: by_wavelength = 0, by_log = 1, by_wavenumber = 2, from_bands = 3
 
   type :: spectral_grid
     integer :: n = 1                 ! number of spectral points
     integer :: spacing = by_wavelength
     real(kr) :: lo = 0, hi = 0       ! first / last central wavelength (um)
     real(kr) :: step = 0             ! WLINC after the default rule
+    ! from_bands (KDIST = -1): the spectral points are the bands of a k-distribution file, in file order
+    real(kr), allocatable :: band_wl(:), band_lo(:), band_hi(:)
   contains
     procedure :: centre => grid_centre
     procedure :: band => grid_band
@@ -67,6 +69,18 @@ contains
     if (wlinf /= wlsup .and. g%n == 1) g%n = 2
   end function
 
+  ! a grid that IS a list of bands (CKTAU records, readk: taugas.f:7695-7835): wavelength, WVNMLO, WVNMHI per point
+  function new_grid_from_bands(wl, wvlo, wvhi) result(g)
+    real(kr), intent(in) :: wl(:), wvlo(:), wvhi(:)
+    type(spectral_grid) :: g
+    g%spacing = from_bands
+    g%n = size(wl)
+    g%band_wl = wl; g%band_lo = wvlo; g%band_hi = wvhi
+    if (g%n > 0) then
+      g%lo = minval(wl); g%hi = maxval(wl)
+    end if
+  end function
+
   ! wavelength at (possibly fractional) grid coordinate x, 0 <= x <= n-1
   pure function grid_centre(g, x) result(w)
     class(spectral_grid), intent(in) :: g
@@ -91,6 +105,10 @@ contains
     real(kr), intent(out) :: wl, wvnmlo, wvnmhi
     real(kr) :: x, edge_lo, edge_hi
     real(kr), parameter :: half = 0.5_kr
+    if (g%spacing == from_bands) then
+      wl = g%band_wl(il + 1); wvnmlo = g%band_lo(il + 1); wvnmhi = g%band_hi(il + 1)
+      return
+    end if
     x = real(il, kr)
     wl = g%centre(x)
     if (g%spacing == by_wavelength) then

@@ -15,6 +15,10 @@ module sbd_io_mod
     ! ocean's per-wavelength constants nr, ni, rsw (records.py: the block behind PHI when hdr(11) /= 0)
     integer :: ibdrf = 0
     real(kr) :: bpar(8) = 0, bitem(4) = 0
+    ! KDIST = -1: sub-band ib (counting down from nb to 1) of a spectral point of the k-distribution file; the
+    ! file's equivalent-width factor multiplies the filter value (drt.f:461, taugas.f:7695-7835)
+    integer :: ib = 1, nb = 1
+    real(kr) :: ewcoef = 1
   end type
 
 contains
@@ -58,6 +62,10 @@ contains
                r%umu(r%numu), r%phi(r%nphi))
       read(u) r%dtauc, r%ssalb, r%temper, r%pmom, r%umu, r%phi
       r%ibdrf = hdr(11); r%bpar = 0; r%bitem = 0
+      r%ib = 1; r%nb = 1
+      if (hdr(12) /= 0) then
+        r%ib = iand(hdr(12), 65535); r%nb = ishft(hdr(12), -16)
+      end if
       if (r%ibdrf /= 0) read(u) r%bpar, r%bitem
       if (has_out /= 0) then       ! reference outputs, if present, are ignored by the host
         read(u) ohdr
@@ -97,6 +105,7 @@ contains
       hdr(1:9) = (/recs(i)%nlyr, recs(i)%nstr, recs(i)%nmom, recs(i)%numu, recs(i)%nphi, recs(i)%flags, &
                    recs(i)%kd, recs(i)%nk, recs(i)%iwl/)
       hdr(11) = recs(i)%ibdrf
+      if (recs(i)%nb > 1) hdr(12) = recs(i)%ib + ishft(recs(i)%nb, 16)
       sc(1:13) = (/recs(i)%wl, recs(i)%wt, recs(i)%ff, recs(i)%wvnmlo, recs(i)%wvnmhi, recs(i)%fbeam, recs(i)%umu0, &
                    recs(i)%phi0, recs(i)%albedo, recs(i)%btemp, recs(i)%ttemp, recs(i)%temis, recs(i)%fisot/)
       write(u) hdr, sc

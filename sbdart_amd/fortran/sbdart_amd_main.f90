@@ -24,6 +24,7 @@ program sbdart_amd
   use sbd_output_mod
   use sbd_atmos_mod, only: atmosphere
   use sbd_bandmodel_mod
+  use sbd_ckfile_mod, only: ck_file, read_ck_files
   use sbd_tables_mod, only: tables_load
   use sbd_filter_mod
   implicit none
@@ -72,12 +73,13 @@ program sbdart_amd
   type(model_input) :: model
   type(sensor_filter) :: sensor
   type(atmosphere) :: atm
-  logical :: have_file, ok, from_model = .false., in_place
+  logical :: have_file, ok, from_model = .false., in_place, sum_widths
   real(kr), allocatable, target :: bdtauc(:, :), bssalb(:, :), bpmom(:, :, :)
   real(kr), allocatable :: btemper(:)
   integer(kind=8) :: tick0, tick1, tick2, tick_rate
   character(len=256) :: why
   ! the run's GPUs and the fleets created so far (stream count x intensity corrections)
+  type(ck_file) :: ck                                  ! KDIST = -1: the k-distribution file pair
   integer(c_int32_t), allocatable, target :: devices(:)
   type(c_ptr) :: fleets(6)
   integer :: fleet_ns(6), nfleet = 0
@@ -134,6 +136,11 @@ program sbdart_amd
   end if
   sensor = new_filter(isat, wlinf, wlsup)            ! setfilt: the sensor's response and its wavelength limits
   grid = new_grid(sensor%wlmin, sensor%wlmax, wlinc)
+  if (iout == 2) kdist = 0                              ! drt.f:303
+  if (kdist == -1) then                                 ! the spectral points are the bands of the k-distribution file
+    call read_ck_files(sensor%wlmin, sensor%wlmax, ck)
+    grid = new_grid_from_bands(ck%wl, ck%wvlo, ck%wvhi)
+  end if
 
   if (iout == 2) then                                   ! gas optical depths only: no radiative transfer
     call fill_model()
@@ -164,8 +171,13 @@ program sbdart_amd
     if (.not. ok) call fatal('band-model tables not found; tried'//trim(why))
     call viewing_cosines()
     call system_clock(tick0, tick_rate)
-    call build_work_items(model, grid, umu(1:numu), phiv(1:merge(view%nphi, 0, radcalc)), recs, nrec, atm, &
-                          bdtauc, bssalb, bpmom, btemper)
+    if (kdist == -1) then
+      call build_work_items(model, grid, umu(1:numu), phiv(1:merge(view%nphi, 0, radcalc)), recs, nrec, atm, &
+                            bdtauc, bssalb, bpmom, btemper, ck)
+    else
+      call build_work_items(model, grid, umu(1:numu), phiv(1:merge(view%nphi, 0, radcalc)), recs, nrec, atm, &
+                            bdtauc, bssalb, bpmom, btemper)
+    end if
     from_model = .true.
     call system_clock(tick1)
     call get_environment_variable('SBD_TIMING', path, plen, pstat)
@@ -175,7 +187,7 @@ program sbdart_amd
     allocate(zlev(nz), plev(nz))
     zlev = atm%z; plev = atm%p
     do i = 1, nrec
-      recs(i)%ff = filter_value(sensor, recs(i)%wl)       ! drt.f:461 (ewcoef = 1)
+      recs(i)%ff = filter_value(sensor, recs(i)%wl)*recs(i)%ewcoef      ! drt.f:461 (ewcoef = 1 without a k-distribution file)
     end do
     call corint_history(recs, nrec, bssalb)
     have_atm = .true.
@@ -340,26 +352,41 @@ program sbdart_amd
 
   ! ---- output ----
   call sums_init(sums, fmt, nz, view%nzen, view%nphi)
-  call write_banner(fmt, grid%n, nz)
+  if (kdist == -1) then                                  ! (gasinit counts the file's points, taugas.f:7362-7364)
+    call write_banner(fmt, count(recs(1:nrec)%ib == 1 .and. recs(1:nrec)%kd == recs(1:nrec)%nk), nz)
+  else
+    call write_banner(fmt, grid%n, nz)
+  end if
+  call get_environment_variable('SBD_SUBBAND_WIDTHS', path, plen, pstat)
+  sum_widths = pstat == 0 .and. plen >= 3 .and. path(1:3) == 'sum'
   if (fmt%per_point) then
-    ! one record per spectral point: the k-terms of a point are consecutive records (kd = 1..nk)
+    ! one record per spectral point: its k-terms are consecutive records (kd = 1..nk) -- and, with a
+    ! k-distribution file, so are its sub-bands (ib = nb..1): the point is complete at kd = nk, ib = 1 and the
+    ! wavelength printed is the last sub-band's (drt.f:967-994).  The widths: stdout1 means to add dwl*ff and dwl up
+    ! over the sub-bands (drt.f:984-987), but keeps the two sums in locals it never SAVEs (drt.f:957-959) -- the
+    ! reference as compiled here (amdflang -O2) starts them from zero at every call, so what it prints is the LAST
+    ! sub-band's width alone under the fluxes of all of them.  That observable behaviour is reproduced (the live
+    ! comparison of tests/test_fortran_host.py pins it); SBD_SUBBAND_WIDTHS=sum selects the intended sums.
     i0 = 1
     do while (i0 <= nrec)
       i1 = i0
       do while (i1 < nrec)
-        if (recs(i1 + 1)%iwl /= recs(i0)%iwl) exit
+        if (recs(i1)%kd == recs(i1)%nk .and. recs(i1)%ib == 1) exit
         i1 = i1 + 1
       end do
       call sums_clear(sums)
+      sums%width_eq = 0; sums%width_full = 0
       do i = i0, i1
         ip = where_solved(i)
         if (ip > 0) call sums_add_item(sums, fmt, weight(ip), flux(:, 1:3, ip), lev_top, lev_bot, &
                                        uu(:, :, :, merge(ip, 1, radcalc)), view%uzen)
+        if (recs(i)%kd == recs(i)%nk .and. (sum_widths .or. i == i1)) then
+          dwl = 10000._kr/recs(i)%wvnmlo - 10000._kr/recs(i)%wvnmhi    ! drt.f:438
+          sums%width_eq = sums%width_eq + dwl*recs(i)%ff
+          sums%width_full = sums%width_full + dwl
+        end if
       end do
-      dwl = 10000._kr/recs(i0)%wvnmlo - 10000._kr/recs(i0)%wvnmhi      ! drt.f:438
-      sums%width_eq = dwl*recs(i1)%ff
-      sums%width_full = dwl
-      call write_point_record(sums, fmt, recs(i0)%wl, zlev, view%phi, view%uzen)
+      call write_point_record(sums, fmt, recs(i1)%wl, zlev, view%phi, view%uzen)
       i0 = i1 + 1
     end do
   else

@@ -76,6 +76,8 @@ class SolveRecord:
     nk: int = 1
     iwl: int = 0
     ibcnd: int = 0
+    ib: int = 1                          # KDIST = -1: sub-band ib (counting down from nb) of a k-distribution file's point
+    nb: int = 1
     ibdrf: int = 0                       # 0 Lambertian, 1 ocean, 2 Hapke, 3 Ross-Li (LAMBER flag off)
     bpar: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(8))
     bitem: np.ndarray = dataclasses.field(default_factory=lambda: np.zeros(4))
@@ -162,6 +164,7 @@ def read_records(path: str) -> List[SolveRecord]:
                 fisot=sc[12], accur=sc[13], wl=sc[0], wt=sc[1], ff=sc[2],
                 kd=int(hdr[6]), nk=int(hdr[7]), iwl=int(hdr[8]), ibcnd=int(hdr[9]),
                 ibdrf=ibdrf, bpar=bpar, bitem=bitem,
+                ib=(int(hdr[11]) & 65535) or 1, nb=(int(hdr[11]) >> 16) or 1,
                 dtauc=dtauc, ssalb=ssalb, temper=temper, pmom=pmom, umu=umu, phi=phi)
             if has_out:
                 ohdr = _rd(f, "<i4", 4)
@@ -187,6 +190,7 @@ def write_records(path: str, recs: Iterable[SolveRecord], with_out: Optional[boo
             hdr = np.zeros(12, "<i4")
             hdr[:11] = [r.nlyr, r.nstr, r.nmom, r.numu, r.nphi, r.flags, r.kd, r.nk,
                         r.iwl, r.ibcnd, r.ibdrf]
+            hdr[11] = (r.ib + 65536 * r.nb) if r.nb > 1 else 0
             sc = np.zeros(16, "<f8")
             sc[:14] = [r.wl, r.wt, r.ff, r.wvnmlo, r.wvnmhi, r.fbeam, r.umu0, r.phi0,
                        r.albedo, r.btemp, r.ttemp, r.temis, r.fisot, r.accur]

@@ -300,7 +300,7 @@ def test_corint_history(tmp_path):
 @needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
     for namelist, word in (("isalb=-8 sc=.6,.3,.4,.1", "surface"),
-                           ("kdist=-1", "k-distribution")):
+                           ("kdist=-1", "CKATM")):                     # (no k-distribution file pair in the directory)
         d = str(tmp_path / word)
         os.makedirs(d)
         with open(os.path.join(d, "INPUT"), "w") as f:
@@ -354,3 +354,58 @@ def test_gas_optical_depth_report(tmp_path, namelist):
         return out
     r, g = tokens(ref), tokens(got)
     assert len(r) > 100 and r == g
+
+
+def write_ck_files(d, nz=12, seed=3, top_down=False):
+    """A synthetic correlated-k file pair for KDIST = -1 (gasinit / readk, taugas.f:7297-7390, 7695-7835): CKATM
+    (levels, pressures, temperatures; either order) and CKTAU (Fortran sequential unformatted: one record per
+    sub-band in order of decreasing wavenumber -- 1 to 3 sub-bands per spectral point, 1 to 5 k-terms each)."""
+    import struct
+    rng = np.random.default_rng(seed)
+    z = np.linspace(0, 60, nz)
+    p = 1013 * np.exp(-z / 7.5)
+    t = 288 - 6.5 * np.minimum(z, 11) + 0.5 * np.maximum(z - 20, 0)
+    if top_down:
+        z, p, t = z[::-1], p[::-1], t[::-1]
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "CKATM"), "w") as f:
+        f.write(f"{nz} 7.5\n" + " ".join(f"{x:.4f}" for x in z) + "\n" + " ".join(f"{x:.5f}" for x in p) + "\n"
+                + " ".join(f"{x:.3f}" for x in t) + "\n")
+    out, iv = [], 0
+    for vnu in (24000.0, 20000.0, 15000.0, 9000.0, 4000.0, 2400.0, 1100.0):
+        iv += 1
+        nb = int(rng.integers(1, 4))
+        for ib in range(nb, 0, -1):
+            nk = int(rng.integers(1, 6))
+            gw = rng.dirichlet(np.ones(nk)).astype("<f4")
+            width = vnu * 0.02 / nb
+            v0 = np.float32(vnu + (ib - 1) * width * 0.5)
+            v1, v2 = np.float32(v0 - width / 2), np.float32(v0 + width / 2)
+            etf, ewc = np.float32(rng.uniform(0.1, 20.0)), np.float32(rng.uniform(0.7, 1.0))
+            dtk = np.exp(rng.uniform(-9, 0.5, (nk, nz))).astype("<f4")          # dtk(1:nz, 1:nk), column-major
+            payload = struct.pack("<4i", iv, ib, nb, nk) + struct.pack("<5f", v0, v1, v2, etf, ewc) + gw.tobytes() + dtk.tobytes()
+            out.append(struct.pack("<i", len(payload)) + payload + struct.pack("<i", len(payload)))
+    with open(os.path.join(d, "CKTAU"), "wb") as f:
+        f.write(b"".join(out))
+
+
+@needs_host
+@pytest.mark.skipif(not os.path.exists(CAPTURE), reason="oracle/_ref/sbdart_capture not built")
+@pytest.mark.parametrize("namelist,top_down", [
+    ("kdist=-1 wlinf=.3 wlsup=12 iout=1 sza=40 nstr=8", False),
+    ("kdist=-1 wlinf=.55 wlsup=.55 iout=10 sza=20 nf=-2 tcloud=4 zcloud=2 iaer=1 vis=20", True),
+    ("kdist=-1 wlinf=.4 wlsup=5 iout=1 sza=95 nf=1 tcloud=1 zcloud=5 nre=-20", False),
+])
+def test_k_distribution_files(tmp_path, namelist, top_down):
+    """KDIST = -1: the gas depths, k-weights, band edges, the extra-terrestrial flux (NF = -2) and the equivalent-width
+    factor come from CKATM / CKTAU; sub-bands and k-terms become work items in file order."""
+    for d in ("ref", "mine"):
+        write_ck_files(str(tmp_path / d), top_down=top_down)
+    ref = reference_items(str(tmp_path / "ref"), namelist)
+    mine = host_items(str(tmp_path / "mine"), namelist)
+    assert ref and len(mine) >= len(ref)
+    worst = compare(mine, ref, "isat" not in namelist)
+    by = {(m.iwl, m.kd): m for m in mine}
+    assert all((by[(r.iwl, r.kd)].ib, by[(r.iwl, r.kd)].nb) == (r.ib, r.nb) for r in ref)
+    assert max(r.nb for r in ref) > 1 and max(r.nk for r in ref) > 3
+    print("%d work items, worst relative difference %.2e :: %s" % (len(ref), worst, namelist))

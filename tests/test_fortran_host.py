@@ -400,3 +400,25 @@ def test_bidirectional_surfaces_from_input_alone(tmp_path, namelist):
     _build()
     ref, got, _ = run_reference_and_host(namelist, str(tmp_path), from_input=True)
     _compare_stdout(got, ref)
+
+
+@pytest.mark.gpu
+@needs_flang
+@needs_ref
+@pytest.mark.parametrize("namelist,from_input", [
+    ("kdist=-1 wlinf=.3 wlsup=12 iout=1 sza=40 nstr=8", True),
+    ("kdist=-1 wlinf=.3 wlsup=12 iout=1 sza=40 nstr=8", False),
+    ("kdist=-1 wlinf=.3 wlsup=12 iout=10 sza=40 nstr=8 nf=-2 tcloud=3 zcloud=2", True),
+    ("kdist=-1 wlinf=.3 wlsup=12 iout=7 sza=60 nstr=4 albcon=.3", True),
+    ("kdist=-1 wlinf=.3 wlsup=4 iout=5 sza=30 nstr=8 nzen=3 uzen=10,70 nphi=2 phi=0,90", True),
+    ("kdist=-1 wlinf=.3 wlsup=12 iout=11 sza=40 nstr=8", True),
+], ids=["points", "points_reference_optics", "run_file_sun", "profiles", "radiance_points", "heating"])
+def test_k_distribution_files_end_to_end(tmp_path, namelist, from_input):
+    """KDIST = -1 (CKATM / CKTAU): spectral points made of sub-bands -- the per-point formats add the sub-bands of a
+    point and print once per point with the summed widths (drt.f:967-1044), the banner counts points, the per-run
+    formats add everything -- against the reference's stdout."""
+    from test_band_model import write_ck_files
+    _build()
+    write_ck_files(str(tmp_path))
+    ref, got, _ = run_reference_and_host(namelist, str(tmp_path), from_input=from_input)
+    _compare_stdout(got, ref)
