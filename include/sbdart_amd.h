@@ -58,7 +58,7 @@ extern "C" {
                                    without a beam (FBEAM = 0) can still be solved with it */
 #define SBD_E_NO_DEVICE     -3
 #define SBD_E_HIP           -4  /* a HIP runtime call failed; see sbd_last_error() */
-#define SBD_E_UNSUPPORTED   -5  /* IBCND=1, intensities at the quadrature angles */
+#define SBD_E_UNSUPPORTED   -5  /* a combination the reference itself cannot run (IBCND = 1 with USRANG and ONLYFL) */
 #define SBD_E_NOMEM         -6
 
 /* ---- per-work-item status bits ---- */
@@ -116,6 +116,12 @@ typedef struct {
                                         (seabdrf, spectra.f:441-451), pigment concentration, salinity
                               Hapke   : single-scattering albedo, asymmetry, hot-spot amplitude, hot-spot width
                               Ross-Li : isotropic, volumetric, geometric coefficients, hot-spot magnitude, width */
+    int32_t ibcnd;         /* IBCND: 0 the general case; 1 = albedo and transmissivity of the whole medium for beam
+                              incidence at the output angles instead of fluxes and intensities (ALBTRN,
+                              disort.f:6718-7432): umu[] then holds POSITIVE cosines (usrang = 1, onlyfl = 0 -- with
+                              both set the reference overruns its UMU array), or usrang = 0 for the nstr/2 quadrature
+                              cosines; results in sbd_batch_out::albtrn, ALBEDO from the work items, no sources */
+    int32_t reserved1;     /* 0 */
 } sbd_run_cfg;
 
 /* One batch of (wavelength, k-term) work items: the per-call DISORT arguments. */
@@ -138,6 +144,8 @@ typedef struct {
     double *flux;      /* [nwork][SBD_NFLUX][nlev]  nlev = nlevel_out or nlyr+1 */
     double *uu;        /* [nwork][nphi][nlev][numu] or NULL when onlyfl */
     int32_t *status;   /* [nwork] SBD_ST_* bits */
+    double *albtrn;    /* ibcnd = 1 only (else NULL / ignored): [nwork][2][nout] ALBMED then TRNMED at the nout = numu
+                          (usrang) or nstr/2 output cosines; flux comes back zero like DISORT's (ZEROAL) */
 } sbd_batch_out;
 
 /* ---- lifecycle ---- */

@@ -1700,6 +1700,9 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
     const int n = n0, nn = n / 2;
     /* USRANG = false in radiance mode: the output angles are the NSTR quadrature angles (SETDIS, disort.f:2655-2669) */
     int numu = in->onlyfl ? 0 : (in->usrang ? in->numu : n);
+    /* IBCND = 1: the user cosines (positive) are doubled into -umu reversed | +umu (SETDIS, disort.f:2672-2687);
+     * without user angles the NSTR quadrature angles already have that shape */
+    if (in->ibcnd == 1) numu = in->usrang ? 2 * in->numu : n;
     const int nphi = in->onlyfl ? 0 : in->nphi;
     const int ntau = in->usrtau ? in->ntau : L + 1;
     out->ntau = ntau;
@@ -1707,7 +1710,7 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
     for (int lu = 0; lu < ntau; ++lu) {
         out->rfldir[lu] = out->rfldn[lu] = out->flup[lu] = out->dfdt[lu] = out->uavg[lu] = 0.0;
     }
-    if (out->uu && !in->onlyfl)
+    if (out->uu && !in->onlyfl && in->ibcnd != 1)
         for (size_t i = 0; i < (size_t)nphi * ntau * (size_t)numu; ++i) out->uu[i] = 0.0;
     if (out->u0c)
         for (size_t i = 0; i < (size_t)ntau * n; ++i) out->u0c[i] = 0.0;
@@ -1750,11 +1753,12 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
     if (in->usrang) {
         if (in->numu < 0 || (!in->onlyfl && in->numu == 0)) inperr = 1;
         for (int iu = 0; iu < in->numu; ++iu) {
+            if (in->ibcnd == 1 && in->umu[iu] < 0.0) inperr = 1;          /* disort.f:5027-5028 */
             if (in->umu[iu] < -1.0 || in->umu[iu] > 1.0 || in->umu[iu] == 0.0) inperr = 1;
             if (iu > 0 && in->umu[iu] < in->umu[iu - 1]) inperr = 1;
         }
     }
-    if (!in->onlyfl) {
+    if (!in->onlyfl && in->ibcnd != 1) {
         if (in->nphi <= 0) inperr = 1;
         for (int j = 0; j < in->nphi; ++j)
             if (in->phi[j] < 0.0 || in->phi[j] > 360.0) inperr = 1;
@@ -1867,7 +1871,7 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
         if (in->fbeam > 0.0) w->expbea[lc] = exp(-w->taucpr[lc] / in->umu0);
     }
     int lyrcut = 0;
-    if (abstau >= abscut && !in->plank && L > 1) lyrcut = 1;
+    if (abstau >= abscut && !in->plank && in->ibcnd != 1 && L > 1) lyrcut = 1;   /* disort.f:2602-2603 */
     if (!lyrcut) ncut = L;
     w->ncut = ncut;
     w->lyrcut = lyrcut;
@@ -1893,9 +1897,126 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
     }
     const double *umu = in->umu;
     double qumu[64];
-    if (!in->onlyfl && !in->usrang) {              /* UMU := the quadrature angles, downward first (disort.f:2655-2669) */
+    if ((!in->onlyfl || in->ibcnd == 1) && !in->usrang) {   /* UMU := the quadrature angles, downward first (disort.f:2655-2669) */
         for (int iu = 1; iu <= nn; ++iu) { qumu[iu - 1] = -CMU(nn + 1 - iu); qumu[nn + iu - 1] = CMU(iu); }
         umu = qumu;
+    } else if (in->ibcnd == 1) {                   /* -umu reversed | +umu (disort.f:2672-2687) */
+        const int nu = in->numu;
+        for (int iu = 1; iu <= nu; ++iu) { qumu[nu + iu - 1] = in->umu[iu - 1]; qumu[iu - 1] = -in->umu[nu - iu]; }
+        umu = qumu;
+    }
+
+    /* ---- IBCND = 1: albedo and transmissivity of the medium (ALBTRN, disort.f:6718-7000) ---- */
+    if (in->ibcnd == 1) {
+        const int nu2 = numu / 2;
+        w->lyrcut = 0; w->ncut = L;
+        sbdo_lepoly(numu, 0, n, n - 1, umu, w->ylmu);
+        sbdo_lepoly(nn, 0, n, n - 1, w->cmu, w->ylmc);
+        double sg = -1.0;
+        for (int l = 0; l <= n - 1; ++l) {
+            sg = -sg;
+            for (int iq = nn + 1; iq <= n; ++iq) YLMC(l, iq) = sg * YLMC(l, iq - nn);
+        }
+        for (int i = 0; i < nn * (nn + 1); ++i) w->bdr[i] = 0.0;
+        for (int lc = 1; lc <= L; ++lc) {
+            int ier = soleig(w, lc, 0, amb, apb, array, cc, evecc, eval, wkd);
+            if (ier != 0) { status |= SBDO_ERR_ASYMTX; goto done; }
+            terpev(w, lc, 0, evecc, wk);
+        }
+        int ncol = 0;
+        setmtx(w, cband, lda, 1.0, 1, wk, &ncol);
+        const int ncd = 3 * nn - 1;
+        double rcond = sbdo_sgbco(cband, lda, ncol, ncd, ncd, ipvt, zwork);
+        if (1.0 + rcond == 1.0) status |= SBDO_WARN_SOLVE0_RCOND;          /* errmsg 11 */
+        double *u0u = uum;                                                  /* U0U(numu, 2) */
+        double alb[64], trn[64];
+        for (int ihom = 1; ihom <= ((L == 1) ? 1 : 2); ++ihom) {
+            /* SOLVE1 (disort.f:7232-7317): unit isotropic illumination from the top (1) or from the bottom (2) */
+            for (int i = 0; i < ncol; ++i) b[i] = 0.0;
+            for (int i = 1; i <= nn; ++i) {
+                b[i - 1] = (ihom == 1) ? 1.0 : 0.0;
+                b[ncol - nn + i - 1] = (ihom == 1) ? 0.0 : 1.0;
+            }
+            sbdo_sgbsl(cband, lda, ncol, ncd, ncd, ipvt, b);
+            for (int lc = 1; lc <= L; ++lc) {
+                const int ipnt = lc * n - nn;
+                for (int iq = 1; iq <= nn; ++iq) {
+                    LL(nn + 1 - iq, lc) = b[ipnt + 1 - iq - 1];
+                    LL(iq + nn, lc) = b[iq + ipnt - 1];
+                }
+            }
+            /* ALTRIN (disort.f:7000-7170): azimuthally averaged intensity at the top (upward angles) and at the
+             * bottom (downward angles) from the homogeneous solution alone */
+            const double utp[2] = {0.0, w->taucpr[L]};
+            for (int lu = 1; lu <= 2; ++lu) {
+                const int iumin = (lu == 1) ? nu2 + 1 : 1, iumax = (lu == 1) ? numu : nu2;
+                const double sgn = (lu == 1) ? 1.0 : -1.0;
+                for (int iu = iumin; iu <= iumax; ++iu) {
+                    const double mu = umu[iu - 1];
+                    double palint = 0.0;
+                    for (int lc = 1; lc <= L; ++lc) {
+                        const double dtau = w->taucpr[lc] - w->taucpr[lc - 1];
+                        const double exp1 = exp((utp[lu - 1] - w->taucpr[lc - 1]) / mu);
+                        const double exp2 = exp((utp[lu - 1] - w->taucpr[lc]) / mu);
+                        for (int iq = 1; iq <= nn; ++iq) {
+                            wk[iq - 1] = exp(KK(iq, lc) * dtau);
+                            const double denom = 1.0 + mu * KK(iq, lc);
+                            double expn;
+                            if (fabs(denom) < f32(0.0001f)) expn = dtau / mu * exp2;
+                            else expn = (exp1 * wk[iq - 1] - exp2) * sgn / denom;
+                            palint = palint + GU(iu, iq, lc) * LL(iq, lc) * expn;
+                        }
+                        for (int iq = nn + 1; iq <= n; ++iq) {
+                            const double denom = 1.0 + mu * KK(iq, lc);
+                            double expn;
+                            if (fabs(denom) < f32(0.0001f)) expn = -dtau / mu * exp1;
+                            else expn = (exp1 - exp2 * wk[n + 1 - iq - 1]) * sgn / denom;
+                            palint = palint + GU(iu, iq, lc) * LL(iq, lc) * expn;
+                        }
+                    }
+                    F2(u0u, numu, iu, lu) = palint;
+                }
+            }
+            if (ihom == 1) {
+                for (int iu = 1; iu <= nu2; ++iu) alb[iu - 1] = F2(u0u, numu, iu + nu2, 1);
+                if (L == 1)
+                    for (int iu = 1; iu <= nu2; ++iu)
+                        trn[iu - 1] = F2(u0u, numu, nu2 + 1 - iu, 2) + exp(-w->taucpr[L] / umu[iu + nu2 - 1]);
+            } else {
+                for (int iu = 1; iu <= nu2; ++iu)
+                    trn[iu - 1] = F2(u0u, numu, iu + nu2, 1) + exp(-w->taucpr[L] / umu[iu + nu2 - 1]);
+            }
+        }
+        if (in->albedo > 0.0) {
+            /* SPALTR (disort.f:7319-7432): flux up at the top, flux down at the bottom, of the LAST solution */
+            double sflup = 0.0, sfldn = 0.0;
+            for (int iq = nn + 1; iq <= n; ++iq) {
+                double zint = 0.0;
+                for (int jq = 1; jq <= nn; ++jq) zint = zint + GC(iq, jq, 1) * LL(jq, 1) * exp(KK(jq, 1) * w->taucpr[1]);
+                for (int jq = nn + 1; jq <= n; ++jq) zint = zint + GC(iq, jq, 1) * LL(jq, 1);
+                sflup = sflup + CWT(iq - nn) * CMU(iq - nn) * zint;
+            }
+            for (int iq = 1; iq <= nn; ++iq) {
+                double zint = 0.0;
+                for (int jq = 1; jq <= nn; ++jq) zint = zint + GC(iq, jq, L) * LL(jq, L);
+                for (int jq = nn + 1; jq <= n; ++jq)
+                    zint = zint + GC(iq, jq, L) * LL(jq, L) * exp(-KK(jq, L) * (w->taucpr[L] - w->taucpr[L - 1]));
+                sfldn = sfldn + CWT(nn + 1 - iq) * CMU(nn + 1 - iq) * zint;
+            }
+            sflup = 2.0 * sflup;
+            sfldn = 2.0 * sfldn;
+            const double sphalb = (L == 1) ? sflup : sfldn, sphtrn = (L == 1) ? sfldn : sflup;
+            /* (the reference runs this loop to the DOUBLED count, over entries it never set: the upper half is dropped) */
+            for (int iu = 1; iu <= nu2; ++iu) {
+                alb[iu - 1] = alb[iu - 1] + (in->albedo / (1.0 - in->albedo * sphalb)) * sphtrn * trn[iu - 1];
+                trn[iu - 1] = trn[iu - 1] + (in->albedo / (1.0 - in->albedo * sphalb)) * sphalb * trn[iu - 1];
+            }
+        }
+        for (int iu = 0; iu < nu2; ++iu) {
+            if (out->albmed) out->albmed[iu] = alb[iu];
+            if (out->trnmed) out->trnmed[iu] = trn[iu];
+        }
+        goto done;
     }
 
     /* ---- Planck functions (disort.f:548-571) ---- */

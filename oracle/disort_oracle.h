@@ -48,6 +48,8 @@ typedef struct {
        (layout: sbdart_amd/records.py) */
     int ibdrf;
     double bpar[8], bitem[4];
+    int ibcnd;                  /* 1: albedo and transmissivity of the whole medium for beam incidence at the user
+                                   angles (ALBTRN, disort.f:6718-7432) instead of fluxes and intensities */
 } sbdo_in;
 
 typedef struct {
@@ -63,6 +65,7 @@ typedef struct {
        zplk1 [nlyr][nstr] */
     int dbg_mode;
     double *dbg_gc, *dbg_kk, *dbg_ll, *dbg_zz, *dbg_zplk0, *dbg_zplk1;
+    double *albmed, *trnmed;    /* IBCND = 1: [numu] (or [nstr/2] when USRANG is off), else untouched; may be NULL */
     int *dbg_ipvt;              /* [nlyr*nstr] SGBFA's pivot rows of that mode's band system, 1-based (disutil.f:852-912) */
 } sbdo_out;
 

@@ -31,7 +31,7 @@ class _In(C.Structure):
                  "ttemp", "temis", "accur")] + \
                [("corint", C.c_int)] + \
                [(k, _dp) for k in ("dtauc", "ssalb", "temper", "pmom", "umu", "phi", "utau")] + \
-               [("ibdrf", C.c_int), ("bpar", C.c_double * 8), ("bitem", C.c_double * 4)]
+               [("ibdrf", C.c_int), ("bpar", C.c_double * 8), ("bitem", C.c_double * 4), ("ibcnd", C.c_int)]
 
 
 class _Out(C.Structure):
@@ -39,7 +39,7 @@ class _Out(C.Structure):
                [(k, _dp) for k in ("rfldir", "rfldn", "flup", "dfdt", "uavg", "uu", "u0c")] + \
                [("dbg_mode", C.c_int)] + \
                [(k, _dp) for k in ("dbg_gc", "dbg_kk", "dbg_ll", "dbg_zz", "dbg_zplk0", "dbg_zplk1")] + \
-               [("dbg_ipvt", C.POINTER(C.c_int))]
+               [("albmed", _dp), ("trnmed", _dp), ("dbg_ipvt", C.POINTER(C.c_int))]
 
 
 def build(force: bool = False) -> str:
@@ -110,7 +110,8 @@ def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False, debug_mod
             phi0=rec.phi0, fisot=rec.fisot, albedo=rec.albedo, btemp=rec.btemp,
             ttemp=rec.ttemp, temis=rec.temis, accur=accur, corint=int(getattr(rec, 'corint', False)),
             dtauc=_p(dtauc), ssalb=_p(ssalb), temper=_p(temper), pmom=_p(pmom),
-            umu=_p(umu), phi=_p(phi), utau=_p(ut), ibdrf=int(getattr(rec, "ibdrf", 0)))
+            umu=_p(umu), phi=_p(phi), utau=_p(ut), ibdrf=int(getattr(rec, "ibdrf", 0)),
+            ibcnd=int(getattr(rec, "ibcnd", 0)))
     for k_ in range(8):
         i.bpar[k_] = float(getattr(rec, "bpar", np.zeros(8))[k_])
     for k_ in range(4):
@@ -120,6 +121,10 @@ def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False, debug_mod
     u0c = np.zeros((ntau, rec.nstr))
     o = _Out(rfldir=_p(flx[0]), rfldn=_p(flx[1]), flup=_p(flx[2]), dfdt=_p(flx[3]),
              uavg=_p(flx[4]), uu=_p(uu), u0c=_p(u0c) if want_u0c else None)
+    albtrn = None
+    if getattr(rec, "ibcnd", 0) == 1:
+        albtrn = np.zeros((2, max(numu if rec.usrang else rec.nstr // 2, 1)))
+        o.albmed, o.trnmed = _p(albtrn[0]), _p(albtrn[1])
     dbg = None
     if debug_mode is not None:
         n_, L_ = rec.nstr, rec.nlyr
@@ -134,6 +139,8 @@ def disort(rec, utau=None, accur: float = 0.0, want_u0c: bool = False, debug_mod
     st = L.sbdo_disort(C.byref(i), C.byref(o))
     res = dict(status=st, nstr_out=o.nstr_out, rfldir=flx[0], rfldn=flx[1], flup=flx[2],
                dfdt=flx[3], uavg=flx[4])
+    if albtrn is not None:
+        res["albmed"], res["trnmed"] = albtrn[0], albtrn[1]
     if not rec.onlyfl:
         res["uu"] = uu[:nphi, :, :nout]
     if want_u0c:

@@ -24,7 +24,7 @@ module sbd_cli_types
     real(dp), allocatable :: dtauc(:), ssalb(:), temper(:), pmom(:,:), &
          umu(:), phi(:)
     integer :: ohdr(4)
-    real(dp), allocatable :: flx(:,:), uu(:,:,:)
+    real(dp), allocatable :: flx(:,:), uu(:,:,:), albtrn(:,:)
   end type
 end module
 
@@ -44,7 +44,7 @@ program sbd_ref_cli
   character(len=127) :: header
   integer :: nrec, has_out, nrep, irep, i, n, ios, narg
   integer :: nlyr, nstr, nmom, numu, nphi, flags, mxumu, mxphi
-  integer :: lc, k, lu, iu, j, ntau, numu_io, nstr_io
+  integer :: lc, k, lu, iu, j, ntau, numu_io, nstr_io, ibcnd
   integer(8) :: c0, c1, crate
   type(rec_t), allocatable :: recs(:)
   type(rec_t) :: tmp
@@ -117,7 +117,8 @@ program sbd_ref_cli
       lamber = iand(flags, 4) /= 0
       usrang = iand(flags, 8) /= 0
       corint = iand(flags, 16) /= 0
-      mxumu = max(numu, abs(nstr), 1)
+      ibcnd = recs(i)%hdr(10)
+      mxumu = max(2*numu, abs(nstr), 1)          ! (IBCND = 1 doubles the user angles in place, disort.f:2672-2687)
       mxphi = max(nphi, 1)
       allocate(dtauc(nlyr), ssalb(nlyr), temper(0:nlyr), pmom(0:nmom, nlyr), &
            umu(mxumu), phi(mxphi), utau(nlyr+1), rfldir(nlyr+1), &
@@ -134,7 +135,7 @@ program sbd_ref_cli
       call system_clock(c0)
       call disort(nlyr, dtauc, ssalb, corint, nmom, pmom, temper, &
            recs(i)%sc(4), recs(i)%sc(5), .false., ntau, utau, nstr_io, &
-           usrang, numu_io, umu, nphi, phi, 0, recs(i)%sc(6), recs(i)%sc(7), &
+           usrang, numu_io, umu, nphi, phi, ibcnd, recs(i)%sc(6), recs(i)%sc(7), &
            recs(i)%sc(8), recs(i)%sc(13), lamber, recs(i)%sc(9), &
            recs(i)%sc(10), recs(i)%sc(11), recs(i)%sc(12), plank, onlyfl, &
            recs(i)%sc(14), prnt, header, nlyr, nlyr+1, mxumu, mxphi, nmom, &
@@ -154,6 +155,10 @@ program sbd_ref_cli
           allocate(recs(i)%uu(numu_io, nlyr+1, nphi))
           recs(i)%uu = uu(1:numu_io, 1:nlyr+1, 1:nphi)
         end if
+        if (ibcnd == 1) then                       ! ALBMED, TRNMED at the (positive) output angles
+          allocate(recs(i)%albtrn(numu_io, 2))
+          recs(i)%albtrn(:, 1) = albmed(1:numu_io); recs(i)%albtrn(:, 2) = trnmed(1:numu_io)
+        end if
       end if
       deallocate(dtauc, ssalb, temper, pmom, umu, phi, utau, rfldir, rfldn, &
            flup, dfdt, uavg, uu, albmed, trnmed)
@@ -170,6 +175,7 @@ program sbd_ref_cli
     write(22) recs(i)%ohdr
     write(22) recs(i)%flx
     if (iand(recs(i)%hdr(6), 2) == 0) write(22) recs(i)%uu
+    if (recs(i)%hdr(10) == 1) write(22) recs(i)%albtrn
   end do
   close(22)
   write(*, '(a,i10,es16.8)') 'TIMING ', nrec*nrep, secs

@@ -27,7 +27,8 @@ class RunCfg(C.Structure):
                 ("abi_version", "nlyr", "nstr", "nmom", "onlyfl", "lamber", "usrang", "numu",
                  "nphi", "nlevel_out", "device", "max_batch", "corint", "ibdrf")] + \
                [(k, C.c_double) for k in ("umu0", "phi0", "fisot", "btemp", "ttemp", "temis")] + \
-               [("temper", _dp), ("umu", _dp), ("phi", _dp), ("level_out", _ip), ("bpar", C.c_double * 8)]
+               [("temper", _dp), ("umu", _dp), ("phi", _dp), ("level_out", _ip), ("bpar", C.c_double * 8),
+                ("ibcnd", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class BatchIn(C.Structure):
@@ -37,7 +38,7 @@ class BatchIn(C.Structure):
 
 
 class BatchOut(C.Structure):
-    _fields_ = [("flux", C.c_void_p), ("uu", C.c_void_p), ("status", C.c_void_p)]
+    _fields_ = [("flux", C.c_void_p), ("uu", C.c_void_p), ("status", C.c_void_p), ("albtrn", C.c_void_p)]
 
 
 EXPORTS = (

@@ -82,6 +82,9 @@ struct Params {
     double bpar[8];
     const double *bitem;
     double *bdr, *bem, *rmu, *emu;
+    // IBCND = 1 (ALBTRN): every work item is solved twice, lit isotropically from the top (even slots) and from the
+    // bottom (odd slots), without beam, thermal source, surface or LYRCUT; slot_base = global index of the pass's first slot
+    int32_t ibcnd, slot_base;
     int32_t *pivdbg;        // [ms][L*n] register index of each pivot row (band4_kernel<.., PIVDBG>), tests only
     // outputs (offset to the chunk)
     double *flux, *uu; int32_t *status;

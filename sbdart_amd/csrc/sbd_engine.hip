@@ -137,6 +137,51 @@ __global__ void accum_partial_kernel(int nwork, int nel, const double *w, const 
         partial[(size_t)seg * nel + e] = acc;
     }
 }
+// IBCND = 1: every work item becomes two consecutive internal items with the same optical properties, no beam,
+// no thermal source and a black surface (the surface's albedo enters ALBTRN's closing formulas only)
+__global__ void ibcnd_expand_kernel(int nwork, int L, int npm, const double *dt, const double *ss, const double *pm,
+                                    const double *lo, const double *hi, double *dt2, double *ss2, double *pm2,
+                                    double *lo2, double *hi2, double *fb2, double *al2, uint8_t *pl2)
+{
+    const size_t tot = (size_t)nwork * 2 * npm;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t s = t / npm, k = t % npm, i = s / 2;
+        pm2[t] = pm[i * npm + k];
+        if (k < (size_t)L) { dt2[s * L + k] = dt[i * L + k]; ss2[s * L + k] = ss[i * L + k]; }
+        if (k == 0) { lo2[s] = lo[i]; hi2[s] = hi[i]; fb2[s] = 0.0; al2[s] = 0.0; pl2[s] = 0; }
+    }
+}
+// ... and ALBTRN's results from the two solves (disort.f:6890-6990): the azimuthally averaged upward intensity at the
+// top for illumination from the top is the albedo for beam incidence at that angle, for illumination from the bottom
+// (USRINT's boundary term carries the directly transmitted part) the transmissivity; a reflecting surface is put
+// back analytically with the spherical albedo / transmissivity of the medium = the second solve's hemispheric
+// fluxes (SPALTR, disort.f:7319-7432, = FLUXES' sums over pi).
+__global__ void ibcnd_combine_kernel(int nwork, int nout, int numu2, double pi, const double *albedo, const double *flux2,
+                                     const double *uu2, const int32_t *st2, double *albtrn, double *flux, int32_t *status)
+{
+    const int i = blockIdx.x;
+    if (i >= nwork) return;
+    const double a = albedo[i];
+    const double *f2 = flux2 + (size_t)(2 * i + 1) * SBD_NFLUX * 2;        // bottom-lit slot: [5][2 levels]
+    const double sphtrn = f2[SBD_FLUP * 2 + 0] / pi, sphalb = f2[SBD_RFLDN * 2 + 1] / pi;
+    for (int iu = threadIdx.x; iu < nout; iu += blockDim.x) {
+        double alb = uu2[((size_t)(2 * i) * 2 + 0) * numu2 + (numu2 / 2 + iu)];       // [slot][1 azimuth][2 levels][numu2]
+        double trn = uu2[((size_t)(2 * i + 1) * 2 + 0) * numu2 + (numu2 / 2 + iu)];
+        if (a > 0.0) {
+            alb = alb + (a / (1.0 - a * sphalb)) * sphtrn * trn;
+            trn = trn + (a / (1.0 - a * sphalb)) * sphalb * trn;
+        }
+        albtrn[((size_t)i * 2 + 0) * nout + iu] = alb;
+        albtrn[((size_t)i * 2 + 1) * nout + iu] = trn;
+    }
+    if (threadIdx.x == 0) {
+        int st = st2[2 * i] | st2[2 * i + 1];
+        if (a < 0.0 || a > 1.0) st |= 0x20;                               // CHEKIN (disort.f:5099-5103)
+        status[i] = st;
+        if (flux) for (int k = 0; k < SBD_NFLUX * 2; ++k) flux[(size_t)i * SBD_NFLUX * 2 + k] = 0.0;
+    }
+}
+
 __global__ void accum_final_kernel(int nseg, int nel, const double *partial, double *acc)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,6 +247,10 @@ struct sbd_engine {
     bool brdf_bad = false;          // ... the model's flux albedo leaves [0,1]: every item gets SBD_ST_ERR_INPUT
     bool fused = false;             // band4, flux-only, levels = {top of layer 1, surface}: the band kernel carries FLUXES'
                                     // functionals through the elimination -- no U factor, no back-substitution kernel
+    int ibcnd = 0, ib_nout = 0;     // IBCND = 1 (ALBTRN): results at ib_nout cosines; the engine proper runs the doubled batch
+    std::vector<double> ib_umu;     // ... at -umu reversed | +umu
+    char *d_ib = nullptr;           // ... its doubled inputs and internal outputs
+    size_t ib_bytes = 0;
     bool quad = false;              // radiances at the quadrature angles (USRANG = false): CMPINT instead of TERPEV/TERPSO/USRINT
     bool corint = false;            // intensity corrections after the azimuth series (sbd_intcor.hpp)
     int32_t *d_pivdbg = nullptr;    // sbd_engine_debug_pivots: [2][chunk * nmode][L * n]
@@ -241,6 +290,7 @@ void sbd_engine_destroy(sbd_engine *e)
     if (e->d_red) (void)hipFree(e->d_red);
     if (e->d_pivdbg) (void)hipFree(e->d_pivdbg);
     if (e->d_surf) (void)hipFree(e->d_surf);
+    if (e->d_ib) (void)hipFree(e->d_ib);
     if (e->d_surf_flag) (void)hipFree(e->d_surf_flag);
     for (auto &x : e->ev)
         if (x) (void)hipEventDestroy(x);
@@ -258,6 +308,53 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     if (!cfg || !out) return fail(SBD_E_INVALID, "null argument");
     *out = nullptr;
     if (cfg->abi_version != SBD_ABI_VERSION) return fail(SBD_E_INVALID, "abi_version mismatch");
+    if (cfg->ibcnd == 1) {
+        // IBCND = 1 (ALBTRN, disort.f:6718-7432): albedo and transmissivity of the whole medium.  The engine proper is
+        // created for the equivalent run of the general case -- two internal items per work item (lit isotropically
+        // from the top / from the bottom), no beam, no thermal source, black surface, no LYRCUT, one azimuth mode,
+        // intensities at -umu reversed | +umu (SETDIS, disort.f:2672-2687) at the top level, fluxes at top and bottom
+        // (ibcnd = 2 marks it) -- and ibcnd_combine_kernel closes with ALBTRN's formulas.
+        const int n1 = cfg->nstr, nn1 = n1 / 2;
+        if (n1 < 4 || n1 > SBD_MAX_NSTR || (n1 & 1)) return fail(SBD_E_INVALID, "NSTR must be even, 4..40");
+        if (cfg->usrang && cfg->onlyfl)
+            return fail(SBD_E_UNSUPPORTED, "IBCND = 1 with USRANG and ONLYFL: the reference doubles NSTR angles into UMU(MAXUMU) (disort.f:2655-2687)");
+        std::vector<double> um;
+        int nout = 0;
+        if (cfg->usrang) {
+            if (cfg->numu < 1 || 2 * cfg->numu > SBD_MAX_NSTR || !cfg->umu) return fail(SBD_E_INVALID, "IBCND = 1: NUMU/UMU");
+            for (int i = 0; i < cfg->numu; ++i) {
+                if (!(cfg->umu[i] > 0.0) || cfg->umu[i] > 1.0) return fail(SBD_E_INVALID, "IBCND = 1: UMU must be positive cosines");
+                if (i && cfg->umu[i] < cfg->umu[i - 1]) return fail(SBD_E_INVALID, "UMU must ascend");
+            }
+            nout = cfg->numu;
+            um.resize(2 * nout);
+            for (int i = 0; i < nout; ++i) { um[nout + i] = cfg->umu[i]; um[i] = -cfg->umu[nout - 1 - i]; }
+        } else {
+            std::vector<double> c(nn1), wgt(nn1);
+            gauss01(nn1, c.data(), wgt.data());
+            nout = nn1;
+            um.resize(n1);
+            for (int i = 0; i < nn1; ++i) { um[i] = -c[nn1 - 1 - i]; um[nn1 + i] = c[i]; }
+        }
+        const double phi0 = 0.0;
+        const int32_t lev[2] = {0, cfg->nlyr};
+        sbd_run_cfg c2 = *cfg;
+        c2.ibcnd = 2;
+        c2.onlyfl = 0; c2.usrang = 1; c2.lamber = 1; c2.ibdrf = 0; c2.corint = 0;
+        c2.numu = (int32_t)um.size(); c2.umu = um.data();
+        c2.nphi = 1; c2.phi = &phi0; c2.phi0 = 0.0;
+        c2.nlevel_out = 2; c2.level_out = lev;
+        c2.fisot = 0.0; c2.temis = 0.0; c2.umu0 = 1.0;
+        if (c2.max_batch > 0) c2.max_batch = (c2.max_batch < (1 << 29)) ? 2 * c2.max_batch : c2.max_batch;
+        const int rc = sbd_engine_create(&c2, out);
+        if (*out) {
+            (*out)->ibcnd = 1;
+            (*out)->ib_nout = nout;
+            (*out)->ib_umu = um;
+            (*out)->cfg.umu = nullptr; (*out)->cfg.phi = nullptr; (*out)->cfg.level_out = nullptr;   // (locals of this call)
+        }
+        return rc == SBD_E_RETRY_NSTR ? SBD_OK : rc;     // (no beam: its angle never meets a quadrature angle)
+    }
     const int n = cfg->nstr, L = cfg->nlyr;
     // CHEKIN's per-run checks (disort.f:4926-5140)
     if (n < 4 || n > SBD_MAX_NSTR || (n & 1)) return fail(SBD_E_INVALID, "NSTR must be even, 4..40");
@@ -318,7 +415,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     int naz = n - 1;
     {
         const double e5 = (double)1.0e-5f;
-        if (fabs(1.0 - cfg->umu0) < e5 || cfg->onlyfl
+        if (fabs(1.0 - cfg->umu0) < e5 || cfg->onlyfl || cfg->ibcnd == 2
             || (numu == 1 && fabs(1.0 - umu_ptr[0]) < e5) || (numu == 1 && fabs(1.0 + umu_ptr[0]) < e5)
             || (numu == 2 && fabs(1.0 + umu_ptr[0]) < e5 && fabs(1.0 - umu_ptr[1]) < e5))
             naz = 0;
@@ -494,6 +591,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
             P.z1u = (double *)take(sizeof(double) * nms * L * numu);
         }
         if (rad) P.uum = (double *)take(sizeof(double) * nms * e->nlev * numu);
+        P.ibcnd = cfg->ibcnd == 2 ? 1 : 0;
+        P.slot_base = 0;
         P.ibdrf = brdf ? cfg->ibdrf : 0;
         P.brdf_shared = (brdf && !brdf_item) ? 1 : 0;
         for (int k = 0; k < 8; ++k) P.bpar[k] = brdf ? cfg->bpar[k] : 0.0;
@@ -693,8 +792,53 @@ struct HostSide {
 };
 static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, void *hip_stream, const HostSide *hs);
 
+// IBCND = 1: expand the batch into its top-lit / bottom-lit internal items, run the general pipeline on them, close with
+// ALBTRN's formulas (device pointers in and out, everything on the caller's stream)
+static int ibcnd_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, void *hip_stream)
+{
+    if (!in || !out) return fail(SBD_E_INVALID, "null argument");
+    if (in->nwork < 0) return fail(SBD_E_INVALID, "nwork < 0");
+    if (in->nwork == 0) return SBD_OK;
+    if (!in->dtauc || !in->ssalb || !in->pmom || !in->wvnmlo || !in->wvnmhi || !in->albedo) return fail(SBD_E_INVALID, "null input array");
+    if (!out->albtrn || !out->status) return fail(SBD_E_INVALID, "IBCND = 1: albtrn / status is NULL");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    const size_t W = in->nwork, W2 = 2 * W;
+    const int L = e->L, npm = L * (e->cfg.nmom + 1), numu2 = e->P.numu;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_lay = up(8 * W2 * L), b_pm = up(8 * W2 * npm), b_w = up(8 * W2), b_fl = up(8 * W2 * SBD_NFLUX * 2),
+                 b_uu = up(8 * W2 * 2 * numu2), b_st = up(4 * W2), b_pl = up(W2);
+    const size_t total = 2 * b_lay + b_pm + 4 * b_w + b_pl + b_fl + b_uu + b_st;
+    if (total > e->ib_bytes) {
+        if (e->d_ib) (void)hipFree(e->d_ib);
+        e->d_ib = nullptr; e->ib_bytes = 0;
+        if (hipMalloc(&e->d_ib, total) != hipSuccess) { (void)hipGetLastError(); return fail(SBD_E_NOMEM, "hipMalloc(IBCND staging)"); }
+        e->ib_bytes = total;
+    }
+    char *p = e->d_ib;
+    auto take = [&](size_t bytes) { char *r = p; p += bytes; return r; };
+    double *dt2 = (double *)take(b_lay), *ss2 = (double *)take(b_lay), *pm2 = (double *)take(b_pm);
+    double *lo2 = (double *)take(b_w), *hi2 = (double *)take(b_w), *fb2 = (double *)take(b_w), *al2 = (double *)take(b_w);
+    uint8_t *pl2 = (uint8_t *)take(b_pl);
+    double *flux2 = (double *)take(b_fl), *uu2 = (double *)take(b_uu);
+    int32_t *st2 = (int32_t *)take(b_st);
+    const size_t tot = W2 * npm;
+    const unsigned grid = (unsigned)((tot + 255) / 256 < 65535 ? (tot + 255) / 256 : 65535);
+    hipLaunchKernelGGL(ibcnd_expand_kernel, dim3(grid), dim3(256), 0, st, (int)W, L, npm, in->dtauc, in->ssalb, in->pmom,
+                       in->wvnmlo, in->wvnmhi, dt2, ss2, pm2, lo2, hi2, fb2, al2, pl2);
+    const sbd_batch_in in2 = {(int32_t)W2, dt2, ss2, pm2, lo2, hi2, fb2, al2, pl2, nullptr};
+    const sbd_batch_out out2 = {flux2, uu2, st2, nullptr};
+    const int rc = solve_device_impl(e, &in2, &out2, st, nullptr);
+    if (rc != SBD_OK) return rc;
+    hipLaunchKernelGGL(ibcnd_combine_kernel, dim3((unsigned)W), dim3(64), 0, st, (int)W, e->ib_nout, numu2, e->P.pi, in->albedo,
+                       (const double *)flux2, (const double *)uu2, (const int32_t *)st2, out->albtrn, out->flux, out->status);
+    HIP_TRY(hipGetLastError());
+    return SBD_OK;
+}
+
 int sbd_engine_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, void *hip_stream)
 {
+    if (e && e->ibcnd) return ibcnd_solve_device(e, in, out, hip_stream);
     return solve_device_impl(e, in, out, hip_stream, nullptr);
 }
 
@@ -780,6 +924,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         P.wvnmlo = in->wvnmlo + w0; P.wvnmhi = in->wvnmhi + w0;
         P.fbeam = in->fbeam + w0; P.albedo = in->albedo + w0; P.plank = in->plank + w0;
         P.bitem = in->bitem ? in->bitem + (size_t)w0 * 4 : nullptr;
+        P.slot_base = w0;
         P.brdf_bad = e->brdf_bad ? 1 : 0;
         P.flux = out->flux + (size_t)w0 * SBD_NFLUX * nlev;
         P.uu = rad ? out->uu + (size_t)w0 * e->P.nphi * nlev * e->P.numu : nullptr;
@@ -889,8 +1034,47 @@ static int ensure_stage(sbd_engine *e, size_t bytes)
 // Host-pointer solve, enqueue part: H2D of the inputs, the kernel pipeline, optionally the weighted
 // sums of the batch into e->d_acc (weight != NULL), D2H of the per-item outputs the caller asked
 // for -- all on the engine's stream, no synchronisation.
+// IBCND = 1 from host arrays: a plain staged call (H2D, ibcnd_solve_device, D2H) -- the mode is a diagnostic of the
+// medium, not a throughput path
+static int ibcnd_solve_host(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out)
+{
+    if (!out->albtrn || !out->status) return fail(SBD_E_INVALID, "IBCND = 1: albtrn / status is NULL");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const size_t W = in->nwork;
+    const int L = e->L, npm = L * (e->cfg.nmom + 1), nout = e->ib_nout;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_lay = up(8 * W * L), b_pm = up(8 * W * npm), b_w = up(8 * W), b_at = up(8 * W * 2 * nout), b_fl = up(8 * W * SBD_NFLUX * 2),
+                 b_st = up(4 * W);
+    int rc = ensure_stage(e, 2 * b_lay + b_pm + 3 * b_w + b_at + b_fl + b_st);
+    if (rc != SBD_OK) return rc;
+    char *p = e->d_stage;
+    auto take = [&](size_t bytes) { char *r = p; p += bytes; return r; };
+    double *dt = (double *)take(b_lay), *ss = (double *)take(b_lay), *pm = (double *)take(b_pm);
+    double *lo = (double *)take(b_w), *hi = (double *)take(b_w), *al = (double *)take(b_w);
+    double *at = (double *)take(b_at), *fl = (double *)take(b_fl);
+    int32_t *stt = (int32_t *)take(b_st);
+    hipStream_t st = e->stream;
+    HIP_TRY(hipMemcpyAsync(dt, in->dtauc, 8 * W * L, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ss, in->ssalb, 8 * W * L, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(pm, in->pmom, 8 * W * npm, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(lo, in->wvnmlo, 8 * W, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(hi, in->wvnmhi, 8 * W, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(al, in->albedo, 8 * W, hipMemcpyHostToDevice, st));
+    const sbd_batch_in din = {in->nwork, dt, ss, pm, lo, hi, nullptr, al, nullptr, nullptr};
+    const sbd_batch_out dout = {fl, nullptr, stt, at};
+    rc = ibcnd_solve_device(e, &din, &dout, st);
+    if (rc != SBD_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out->albtrn, at, 8 * W * 2 * nout, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->status, stt, 4 * W, hipMemcpyDeviceToHost, st));
+    if (out->flux) HIP_TRY(hipMemcpyAsync(out->flux, fl, 8 * W * SBD_NFLUX * 2, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    e->pending_out.clear();
+    return SBD_OK;
+}
+
 static int solve_host_enqueue(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, const double *weight)
 {
+    if (e->ibcnd) return ibcnd_solve_host(e, in, out);
     HIP_TRY(hipSetDevice(e->cfg.device));
     const size_t W = in->nwork;
     const int L = e->L, nlev = e->nlev;
@@ -961,7 +1145,7 @@ int sbd_engine_solve_host(sbd_engine *e, const sbd_batch_in *in, const sbd_batch
 {
     if (!e || !in || !out) return fail(SBD_E_INVALID, "null argument");
     if (in->nwork <= 0) return in->nwork == 0 ? SBD_OK : fail(SBD_E_INVALID, "nwork < 0");
-    if (!out->flux || !out->status) return fail(SBD_E_INVALID, "null output array");
+    if ((!out->flux && !e->ibcnd) || !out->status) return fail(SBD_E_INVALID, "null output array");
     int rc = solve_host_enqueue(e, in, out, nullptr);
     if (rc != SBD_OK) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1147,6 +1331,7 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
     if (weight && !acc_flux) return fail(SBD_E_INVALID, "acc_flux is NULL");
     const int nd = (int)f->eng.size();
     sbd_engine *e0 = f->eng[0];
+    if (e0->ibcnd) weight = nullptr;                 // (albedo / transmissivity of the medium: nothing to integrate)
     const int L = e0->L, nlev = e0->nlev, nmom1 = e0->cfg.nmom + 1;
     const bool rad = !e0->cfg.onlyfl;
     const size_t nel_f = (size_t)SBD_NFLUX * nlev, nel_u = rad ? (size_t)e0->P.nphi * nlev * e0->P.numu : 0, nel = nel_f + nel_u;
@@ -1195,7 +1380,8 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
                                in->wvnmlo + lo, in->wvnmhi + lo, in->fbeam + lo, in->albedo + lo, in->plank + lo,
                                in->bitem ? in->bitem + (size_t)lo * 4 : nullptr};
             sbd_batch_out so = {out->flux ? out->flux + (size_t)lo * nel_f : nullptr,
-                                (rad && out->uu) ? out->uu + (size_t)lo * uu_item : nullptr, out->status + lo};
+                                (rad && out->uu) ? out->uu + (size_t)lo * uu_item : nullptr, out->status + lo,
+                                (e0->ibcnd && out->albtrn) ? out->albtrn + (size_t)lo * 2 * e0->ib_nout : nullptr};
             f->t_enq[2 * r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
             rcs[r] = solve_host_enqueue(f->eng[r], &si, &so, weight ? weight + lo : nullptr);
             if (rcs[r] != SBD_OK) errs[r] = g_last_error;          // (thread-local: carried to the caller below)

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
             s_taucpr[lc + 1] = taucpr;
             s_dt[lc] = dt;
         }
-        const int lyrcut = (abstau >= 10.0 && !plank && L > 1) ? 1 : 0;   // disort.f:2602-2603
+        const int lyrcut = (abstau >= 10.0 && !plank && !P.ibcnd && L > 1) ? 1 : 0;   // disort.f:2602-2603
         if (!lyrcut) ncut = L;
         s_ncut = ncut;
         s_lyrcut = lyrcut;
@@ -190,9 +190,12 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
             s_pk[lev] = pk;
             sv[o.pkag() + lev] = pk;
         } else if (lev == L + 1) {
-            sv[o.tplank()] = P.temis * pk;
+            // (IBCND = 1: unit isotropic illumination from the top for the even slots -- it enters the boundary rows
+            //  exactly where FISOT + TPLANK does, disort.f:3434-3599 vs SOLVE1, disort.f:7232-7317 -- and from the
+            //  bottom for the odd ones, where BEM * BPLANK stands over a black surface)
+            sv[o.tplank()] = P.ibcnd ? (((P.slot_base + slot) & 1) ? 0.0 : 1.0) : P.temis * pk;
         } else {
-            sv[o.bplank()] = pk;
+            sv[o.bplank()] = P.ibcnd ? (((P.slot_base + slot) & 1) ? 1.0 : 0.0) : pk;
         }
     }
     if (pw) atomicOr(&s_pw, 1);

@@ -40,7 +40,7 @@ class DisortEngine:
                  btemp: float = 0.0, ttemp: float = 0.0, temis: float = 0.0, fisot: float = 0.0,
                  lamber: bool = True, level_out: Optional[Sequence[int]] = None, device: int = 0,
                  max_batch: int = 0, allow_retry_nstr: bool = False, corint: bool = False,
-                 ibdrf: int = 0, bpar: Optional[Sequence[float]] = None):
+                 ibdrf: int = 0, bpar: Optional[Sequence[float]] = None, ibcnd: int = 0):
         self._L = _lib.load()
         self._h = C.c_void_p()
         self.nlyr, self.nstr, self.nmom = int(nlyr), int(nstr), int(nmom)
@@ -67,6 +67,12 @@ class DisortEngine:
             phi=self._phi.ctypes.data_as(C.POINTER(C.c_double)) if self.nphi else None,
             level_out=None if self._lev is None else self._lev.ctypes.data_as(C.POINTER(C.c_int32)))
         self.ibdrf = 0 if lamber else int(ibdrf)
+        self.ibcnd = int(ibcnd)
+        cfg.ibcnd = self.ibcnd
+        if self.ibcnd == 1:                                 # ALBTRN: results at the positive user / quadrature cosines
+            cfg.numu = len(self._umu) if usrang else 0
+            cfg.umu = self._umu.ctypes.data_as(C.POINTER(C.c_double)) if (usrang and len(self._umu)) else None
+            self.nout = len(self._umu) if usrang else self.nstr // 2
         for k_, v_ in enumerate(list(bpar if bpar is not None else [])[:8]):
             cfg.bpar[k_] = float(v_)
         rc = self._create(cfg)
@@ -150,6 +156,24 @@ class DisortEngine:
         if got < 0:
             raise SbdError(int(got), "sbd_engine_debug_copy")
         return buf[: got // buf.itemsize]
+
+    def solve_albtrn(self, dtauc, ssalb, pmom, albedo, wvnmlo=1.0, wvnmhi=2.0):
+        """IBCND = 1 (engine created with ibcnd=1): albedo and transmissivity of the medium for beam incidence at the
+        output cosines.  Returns (albtrn[W, 2, nout], status[W])."""
+        assert self.ibcnd == 1
+        dtauc, ssalb, pmom = _f64(dtauc), _f64(ssalb), _f64(pmom)
+        W = dtauc.shape[0]
+        assert pmom.shape == (W, self.nlyr, self.nmom + 1)
+        lo, hi, al = (_f64(np.broadcast_to(x, (W,))) for x in (wvnmlo, wvnmhi, albedo))
+        albtrn = np.zeros((W, 2, self.nout))
+        status = np.zeros(W, dtype=np.int32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        bi = BatchIn(W, vp(dtauc), vp(ssalb), vp(pmom), vp(lo), vp(hi), None, vp(al), None, None)
+        bo = BatchOut(None, None, vp(status), vp(albtrn))
+        rc = self._L.sbd_engine_solve_host(self._h, C.byref(bi), C.byref(bo))
+        if rc != _lib.OK:
+            raise SbdError(rc, "sbd_engine_solve_host")
+        return albtrn, status
 
     def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, bitem=None):
         """Solve a batch.  Shapes: dtauc/ssalb [W, nlyr]; pmom [W, nlyr, nmom+1];

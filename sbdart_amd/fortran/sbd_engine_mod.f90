@@ -26,6 +26,7 @@ module sbd_engine_mod
     real(c_double) :: umu0, phi0, fisot, btemp, ttemp, temis
     type(c_ptr) :: temper, umu, phi, level_out
     real(c_double) :: bpar(8) = 0        ! bidirectional surface parameters (lamber = 0)
+    integer(c_int32_t) :: ibcnd = 0, reserved1 = 0   ! 1: albedo / transmissivity of the medium (ALBTRN); SBDART never sets it
   end type
 
   type, bind(C) :: sbd_batch_in
@@ -36,6 +37,7 @@ module sbd_engine_mod
 
   type, bind(C) :: sbd_batch_out
     type(c_ptr) :: flux, uu, status
+    type(c_ptr) :: albtrn = c_null_ptr   ! ibcnd = 1 only
   end type
 
   interface

@@ -27,6 +27,7 @@ All little-endian, no padding::
                   float64 rfldir[ntau], rfldn[ntau], flup[ntau], dfdt[ntau],
                           uavg[ntau]
                   if not ONLYFL: float64 uu[nphi][ntau][numu]
+                  if ibcnd == 1: float64 albmed[numu_out], trnmed[numu_out]  (ALBTRN, disort.f:6718-7000; ohdr[2] = numu_out)
 
 The argument names are DISORT's own (disort.f:1-6, Documents/disort.doc:561-986);
 ``wl, wt, ff, kd, nk, iwl`` are the driver-side quantities stdout1 needs
@@ -89,6 +90,8 @@ class SolveRecord:
     dfdt: Optional[np.ndarray] = None
     uavg: Optional[np.ndarray] = None
     uu: Optional[np.ndarray] = None   # [nphi, ntau, numu]
+    albmed: Optional[np.ndarray] = None   # IBCND = 1: albedo / transmissivity of the medium at the output angles
+    trnmed: Optional[np.ndarray] = None
 
     @property
     def plank(self) -> bool:
@@ -123,7 +126,7 @@ class SolveRecord:
 
     def inputs_only(self) -> "SolveRecord":
         return dataclasses.replace(self, nstr_out=None, rfldir=None, rfldn=None,
-                                   flup=None, dfdt=None, uavg=None, uu=None)
+                                   flup=None, dfdt=None, uavg=None, uu=None, albmed=None, trnmed=None)
 
 
 def _rd(f: BinaryIO, dtype, n: int) -> np.ndarray:
@@ -175,6 +178,8 @@ def read_records(path: str) -> List[SolveRecord]:
                 if not r.onlyfl:
                     nout = int(ohdr[2])                    # (USRANG off: the NSTR quadrature angles, disort.f:2655-2669)
                     r.uu = _rd(f, "<f8", nphi * ntau * nout).reshape(nphi, ntau, nout)
+                if r.ibcnd == 1:
+                    r.albmed, r.trnmed = _rd(f, "<f8", int(ohdr[2])), _rd(f, "<f8", int(ohdr[2]))
             out.append(r)
     return out
 
@@ -208,6 +213,8 @@ def write_records(path: str, recs: Iterable[SolveRecord], with_out: Optional[boo
             if with_out:
                 ntau = len(r.rfldir)
                 nout = r.numu if (r.onlyfl or r.uu is None) else np.asarray(r.uu).shape[2]
+                if r.ibcnd == 1 and r.albmed is not None:
+                    nout = len(r.albmed)
                 f.write(np.array([r.nstr_out, ntau, nout, 0], "<i4").tobytes())
                 for a in (r.rfldir, r.rfldn, r.flup, r.dfdt, r.uavg):
                     f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
@@ -215,3 +222,6 @@ def write_records(path: str, recs: Iterable[SolveRecord], with_out: Optional[boo
                     a = np.ascontiguousarray(r.uu, dtype="<f8")
                     assert a.shape == (r.nphi, ntau, nout)
                     f.write(a.tobytes())
+                if r.ibcnd == 1:
+                    f.write(np.ascontiguousarray(r.albmed, dtype="<f8").tobytes())
+                    f.write(np.ascontiguousarray(r.trnmed, dtype="<f8").tobytes())

@@ -158,6 +158,38 @@ def main():
                                            "sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "reference_warnings": []}
         print("quadangles_nstr16_4", len(out), "records")
 
+    # --- IBCND = 1 (ALBTRN, disort.f:6718-7432): albedo and transmissivity of the whole medium for beam incidence at
+    #     user angles (USRANG on, ONLYFL off: with both on the reference overruns its UMU array) or at the quadrature
+    #     angles, over surfaces of albedo 0 / 0.3 / 0.8, plus a single thick layer.  SBDART never sets IBCND, so the
+    #     reference's DISORT is called directly (oracle/_ref/disort_ref_cli)
+    if not only or "albtrn_ibcnd1" in only:
+        import dataclasses
+        import numpy as np
+        from sbdart_amd.records import F_LAMBER, F_ONLYFL, F_USRANG
+        src = (read_records(os.path.join(HERE, "cfgB_sw_nstr16.sbdrec"))[::9]
+               + read_records(os.path.join(HERE, "sbchk1.sbdrec"))[::70]
+               + read_records(os.path.join(HERE, "cfg3_lw_nstr16_cloud.sbdrec"))[::15])
+        recs = []
+        for k, r in enumerate(src):
+            fl = (F_LAMBER | F_USRANG) if k % 3 else (F_LAMBER | F_ONLYFL)
+            recs.append(dataclasses.replace(r.inputs_only(), flags=fl, ibcnd=1, albedo=[0.0, 0.3, 0.8][k % 3],
+                                            umu=np.array([0.1, 0.5, 0.9, 1.0]) if fl & F_USRANG else np.zeros(0),
+                                            phi=np.zeros(0)))
+        r = recs[1]
+        recs.append(dataclasses.replace(r, nlyr=1, dtauc=r.dtauc[-1:] * 50, ssalb=r.ssalb[-1:], pmom=r.pmom[-1:],
+                                        temper=r.temper[-2:], albedo=0.4))
+        with tempfile.TemporaryDirectory() as d:
+            write_records(os.path.join(d, "in.sbdrec"), recs, with_out=False)
+            subprocess.run([os.path.join(ROOT, "oracle", "_ref", "disort_ref_cli"), "in.sbdrec", "out.sbdrec", "1"],
+                           cwd=d, check=True, capture_output=True)
+            out = read_records(os.path.join(d, "out.sbdrec"))
+        path = os.path.join(HERE, "albtrn_ibcnd1.sbdrec")
+        write_records(path, out, with_out=True)
+        manifest["albtrn_ibcnd1"] = {"namelists": ["(disort_ref_cli with IBCND = 1 on the inputs of cfgB / sbchk1 / cfg3 records)"],
+                                     "records": len(out), "bytes": os.path.getsize(path),
+                                     "sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "reference_warnings": []}
+        print("albtrn_ibcnd1", len(out), "records")
+
     # --- ill-conditioned on purpose (kept apart from the 5e-6 parity files): the thermal window on a 65-level
     #     regridded atmosphere -- dozens of layers of optical depth ~1e-6 make the boundary-value system so
     #     nearly singular that the reference's own answer moves by 3e-5 when its arithmetic is merely contracted

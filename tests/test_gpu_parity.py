@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 
 FLUX = ("rfldir", "rfldn", "flup", "dfdt", "uavg")
 TOL = 5e-6
-FILES = sorted(glob.glob(os.path.join(GOLDEN, "*.sbdrec")))
+FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "*.sbdrec")) if "albtrn" not in f)   # (IBCND = 1: its own test)
 
 
 def _check(flux, uu, st, recs, outs, tol=TOL):
@@ -530,6 +530,43 @@ def test_bidirectional_surfaces_against_oracle(nstr):
             assert st[i] & 0x20, (i, st[i])
     _check([flux[i] for i in good], [uu[i] for i in good], [st[i] for i in good],
            [recs[i] for i in good], [outs[i] for i in good])
+
+
+def test_albedo_and_transmissivity_of_the_medium():
+    """IBCND = 1 (ALBTRN, disort.f:6718-7432): the captured reference results (user angles and quadrature angles,
+    surfaces of albedo 0 / 0.3 / 0.8, a single thick layer) and a seeded sweep against the oracle, NSTR 4 .. 32."""
+    import dataclasses
+    import pyoracle
+    from sbdart_amd.engine import DisortEngine
+    from sbdart_amd.records import F_LAMBER, F_ONLYFL, F_USRANG, read_records
+    recs = read_records(os.path.join(GOLDEN, "albtrn_ibcnd1.sbdrec"))
+    rng = np.random.default_rng(404)
+    for nstr in (4, 8, 12, 16, 24, 32):
+        L = int(rng.integers(2, 8))
+        nmom = nstr + 2
+        g = rng.uniform(0.0, 0.85, L)
+        usr = nstr % 8 == 0
+        recs.append(dataclasses.replace(
+            recs[0].inputs_only(), nlyr=L, nstr=nstr, nmom=nmom, flags=(F_LAMBER | F_USRANG) if usr else (F_LAMBER | F_ONLYFL),
+            dtauc=rng.uniform(0.01, 3.0, L), ssalb=rng.uniform(0.3, 1.0, L), temper=np.linspace(220, 290, L + 1),
+            pmom=g[:, None] ** np.arange(nmom + 1)[None, :], albedo=float(rng.uniform(0, 0.9)),
+            umu=np.array([0.05, 0.3, 0.77, 1.0]) if usr else np.zeros(0)))
+    worst = 0.0
+    for r in recs:
+        want = (r.albmed, r.trnmed) if r.albmed is not None else None
+        if want is None:
+            o = pyoracle.disort(r)
+            assert o["status"] == 0
+            want = (o["albmed"], o["trnmed"])
+        with DisortEngine(nlyr=r.nlyr, nstr=r.nstr, nmom=r.nmom, temper=r.temper, umu0=1.0, onlyfl=r.onlyfl,
+                          usrang=r.usrang, umu=r.umu, ibcnd=1) as eng:
+            at, st = eng.solve_albtrn(r.dtauc[None], r.ssalb[None], r.pmom[None], r.albedo)
+        assert st[0] == 0 and at.shape == (1, 2, len(want[0]))
+        for k in range(2):
+            err = np.abs(at[0, k] - want[k]).max()
+            worst = max(worst, err)
+            assert err <= TOL * max(np.abs(want[k]).max(), 1e-3), (r.nstr, r.nlyr, k, err, at[0, k], want[k])
+    print(f"IBCND = 1: {len(recs)} media, worst |engine - reference| = {worst:.2e}")
 
 
 def _linpack_rows(ipvt, N):

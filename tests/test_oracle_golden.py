@@ -41,6 +41,10 @@ def test_oracle_matches_reference_records(path):
             scale = max(np.abs(ref).max(), 1e-300)
             assert np.abs(o[f] - ref).max() <= TOL * scale, (path, f)
             nbit += int(np.array_equal(o[f], ref))
+        if r.ibcnd == 1:                      # ALBTRN (disort.f:6718-7000): albedo / transmissivity of the medium only
+            assert np.abs(o["albmed"] - r.albmed).max() <= TOL and np.abs(o["trnmed"] - r.trnmed).max() <= TOL, path
+            nbit += int(np.array_equal(o["albmed"], r.albmed)) + int(np.array_equal(o["trnmed"], r.trnmed))
+            continue
         if not r.onlyfl:
             assert np.abs(o["uu"] - r.uu).max() <= TOL * np.abs(r.uu).max()
             nbit += int(np.array_equal(o["uu"], r.uu))
