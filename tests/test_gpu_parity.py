@@ -229,7 +229,7 @@ def test_level_selection_for_every_band_kernel(nstr):
             assert np.abs(ft[c] - fa[c][[0, -1]]).max() <= 1e-8 * recmax, (nstr, name, "two levels vs all")
 
 
-@pytest.mark.parametrize("path", [f for f in FILES if "rad" not in f and "corint" not in f and "sbchk5" not in f],
+@pytest.mark.parametrize("path", [f for f in FILES if "rad" not in f and "corint" not in f and "sbchk5" not in f and "quadangles" not in f],
                          ids=lambda f: os.path.basename(f))
 def test_two_level_fused_path_matches_reference_records(path):
     """IOUT 1 / 10's level pair (top, surface) sends NSTR <= 16 flux runs through the fused band kernel (no stored
