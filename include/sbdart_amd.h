@@ -138,6 +138,12 @@ typedef struct {
     const double *bitem;    /* [nwork][4] ocean surface only (ibdrf = 1), else NULL: refractive index nr, ni of
                                the water and its sub-surface reflectance rsw at the item's wavelength (indwat,
                                morcasiwat: spectra.f:446-449), one spare */
+    const int32_t *pmom_row;/* NULL: pmom holds nwork blocks, one per item.  Else [nwork] row indices into pmom, which then
+                               holds npmom blocks [npmom][nlyr][nmom+1]: the k-terms of a spectral point share their
+                               phase-function moments (drt.f:476-533 computes them once per wavelength), so the host
+                               hands every block over once -- 2.3 x fewer input bytes at nk = 2.67.  Host entry points
+                               want the rows non-decreasing (items in wavelength order). */
+    int32_t npmom;          /* number of blocks in pmom when pmom_row != NULL */
 } sbd_batch_in;
 
 typedef struct {

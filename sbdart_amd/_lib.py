@@ -34,7 +34,8 @@ class RunCfg(C.Structure):
 class BatchIn(C.Structure):
     _fields_ = [("nwork", C.c_int32), ("dtauc", C.c_void_p), ("ssalb", C.c_void_p),
                 ("pmom", C.c_void_p), ("wvnmlo", C.c_void_p), ("wvnmhi", C.c_void_p),
-                ("fbeam", C.c_void_p), ("albedo", C.c_void_p), ("plank", C.c_void_p), ("bitem", C.c_void_p)]
+                ("fbeam", C.c_void_p), ("albedo", C.c_void_p), ("plank", C.c_void_p), ("bitem", C.c_void_p),
+                ("pmom_row", C.c_void_p), ("npmom", C.c_int32)]
 
 
 class BatchOut(C.Structure):

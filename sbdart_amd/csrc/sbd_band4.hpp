@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     if (dead) {   // DISORT returned before computing anything: outputs stay zero (ZEROAL)
         double *flux = P.flux + (size_t)slot * SBD_NFLUX_ * nlev;
         for (int i = q; i < SBD_NFLUX_ * nlev; i += 16) flux[i] = 0.0;
+        if constexpr (FUSED) { if (q == 0) P.status[slot] = st0; }
         return;
     }
     const int ncut = svi[SBD_SVI_NCUT];
@@ -530,6 +531,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     }
     if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
     if constexpr (FUSED) {
+        if (q == 0) P.status[slot] = st0 | status;          // (the last kernel of a fused pass: no finish_kernel)
         // ---- FLUXES (disort.f:1780-2042) at the two levels from the functionals ----
         // top level: the right-hand sides of the rows F; surface level: the nn rows left over by the last step are the
         // padding rows, three of them tagged 1..3 in what was their x_lc+1 slot (moved to slot 0 by the hand-over)

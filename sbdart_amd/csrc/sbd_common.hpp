@@ -66,6 +66,8 @@ struct Params {
     // chunk inputs (device pointers, already offset to the chunk)
     const double *dtauc, *ssalb, *pmom, *wvnmlo, *wvnmhi, *fbeam, *albedo;
     const uint8_t *plank;
+    const int32_t *pmom_row;   // NULL: pmom holds one block of moments per work item; else the block of item `slot` is
+                               // row pmom_row[slot] of pmom (moments per SPECTRAL POINT, shared by its k-terms)
     // workspace
     double *sv; int32_t *svi;
     double *gc, *kk, *ek, *zz, *zp0, *zp1, *ll, *ufac;
@@ -89,6 +91,9 @@ struct Params {
     // outputs (offset to the chunk)
     double *flux, *uu; int32_t *status;
 };
+
+// index of the [L][nmom+1] block of moments that belongs to work item `slot` of the pass
+SBD_DEVICE size_t pmom_item(const Params &P, int slot) { return P.pmom_row ? (size_t)P.pmom_row[slot] : (size_t)slot; }
 
 // ---- per-solve vector block (doubles) ----
 // offsets inside sv[slot]

@@ -125,18 +125,52 @@ __global__ void finish_kernel(sbd::Params P)
     P.status[slot] = P.svi[(size_t)slot * P.svi_stride + SBD_SVI_STATUS];
 }
 
-// stdout1's weighted sums (drt.f:964-1054), two fixed-order levels: 256-item segments
-// summed in work-item order, then segments summed in order.
-__global__ void accum_partial_kernel(int nwork, int nel, const double *w, const double *x, double *partial)
+// stdout1's weighted sums (drt.f:964-1054), two fixed-order levels: 256-item segments summed in work-item order,
+// then segments summed in order.  Both kernels stage their operands through LDS with coalesced loads and let one
+// thread per output element add them up IN ORDER from there (the sums are the same bits as a serial loop over the
+// items; read straight from HBM by ten threads that loop took 80 + 90 us of the 9.7 ms step).
+constexpr int kAccTile = 256;
+__global__ void __launch_bounds__(256) accum_partial_kernel(int nwork, int nel, const double *w, const double *x, double *partial)
 {
+    extern __shared__ __attribute__((aligned(16))) double sh[];      // [kAccTile][ne] products of one tile of elements
     const int seg = blockIdx.x;
-    const int i0 = seg * 256, i1 = (i0 + 256 < nwork) ? i0 + 256 : nwork;
-    for (int e = threadIdx.x; e < nel; e += blockDim.x) {
-        double acc = 0.0;
-        for (int i = i0; i < i1; ++i) acc = acc + w[i] * x[(size_t)i * nel + e];
-        partial[(size_t)seg * nel + e] = acc;
+    const int i0 = seg * 256, cnt = ((i0 + 256 < nwork) ? 256 : nwork - i0);
+    const int ET = 16;                                               // elements per LDS tile
+    for (int e0 = 0; e0 < nel; e0 += ET) {
+        const int ne = (nel - e0 < ET) ? nel - e0 : ET;
+        for (int t = threadIdx.x; t < cnt * ne; t += blockDim.x) {
+            const int i = t / ne, e = t % ne;
+            sh[i * ET + e] = w[i0 + i] * x[(size_t)(i0 + i) * nel + e0 + e];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < ne) {
+            double acc = 0.0;
+            for (int i = 0; i < cnt; ++i) acc = acc + sh[i * ET + threadIdx.x];
+            partial[(size_t)seg * nel + e0 + threadIdx.x] = acc;
+        }
+        __syncthreads();
     }
 }
+__global__ void __launch_bounds__(256) accum_final_kernel(int nseg, int nel, const double *partial, double *acc)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];      // [kAccTile segments][ET]
+    const int ET = 16, e0 = blockIdx.x * ET;
+    const int ne = (nel - e0 < ET) ? nel - e0 : ET;
+    double a = ((int)threadIdx.x < ne) ? acc[e0 + threadIdx.x] : 0.0;
+    for (int s0 = 0; s0 < nseg; s0 += kAccTile) {
+        const int ns = (nseg - s0 < kAccTile) ? nseg - s0 : kAccTile;
+        for (int t = threadIdx.x; t < ns * ne; t += blockDim.x) {
+            const int sg = t / ne, e = t % ne;
+            sh[sg * ET + e] = partial[(size_t)(s0 + sg) * nel + e0 + e];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < ne)
+            for (int sg = 0; sg < ns; ++sg) a = a + sh[sg * ET + threadIdx.x];
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < ne) acc[e0 + threadIdx.x] = a;
+}
+
 // IBCND = 1: every work item becomes two consecutive internal items with the same optical properties, no beam,
 // no thermal source and a black surface (the surface's albedo enters ALBTRN's closing formulas only)
 __global__ void ibcnd_expand_kernel(int nwork, int L, int npm, const double *dt, const double *ss, const double *pm,
@@ -180,15 +214,6 @@ __global__ void ibcnd_combine_kernel(int nwork, int nout, int numu2, double pi, 
         status[i] = st;
         if (flux) for (int k = 0; k < SBD_NFLUX * 2; ++k) flux[(size_t)i * SBD_NFLUX * 2 + k] = 0.0;
     }
-}
-
-__global__ void accum_final_kernel(int nseg, int nel, const double *partial, double *acc)
-{
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nel) return;
-    double a = acc[e];
-    for (int s = 0; s < nseg; ++s) a = a + partial[(size_t)s * nel + e];
-    acc[e] = a;
 }
 
 }  // namespace
@@ -789,6 +814,7 @@ long long sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t
 struct HostSide {
     const sbd_batch_in *in;     // host inputs (NULL members never occur: checked by the callers)
     const sbd_batch_out *out;   // host outputs; flux / uu / status may each be NULL (not wanted)
+    bool rows_sorted;           // in->pmom_row is non-decreasing: every pass needs one contiguous range of moment blocks
 };
 static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, void *hip_stream, const HostSide *hs);
 
@@ -801,6 +827,7 @@ static int ibcnd_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_b
     if (in->nwork == 0) return SBD_OK;
     if (!in->dtauc || !in->ssalb || !in->pmom || !in->wvnmlo || !in->wvnmhi || !in->albedo) return fail(SBD_E_INVALID, "null input array");
     if (!out->albtrn || !out->status) return fail(SBD_E_INVALID, "IBCND = 1: albtrn / status is NULL");
+    if (in->pmom_row) return fail(SBD_E_INVALID, "IBCND = 1: one block of moments per item (pmom_row must be NULL)");
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
     const size_t W = in->nwork, W2 = 2 * W;
@@ -888,7 +915,17 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         hipStream_t cs = e->copy;
         HIP_TRY(hipMemcpyAsync((void *)(in->dtauc + (size_t)w0 * L), hs->in->dtauc + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipMemcpyAsync((void *)(in->ssalb + (size_t)w0 * L), hs->in->ssalb + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, cs));
-        HIP_TRY(hipMemcpyAsync((void *)(in->pmom + (size_t)w0 * npm), hs->in->pmom + (size_t)w0 * npm, sizeof(double) * ns * npm, hipMemcpyHostToDevice, cs));
+        if (hs->in->pmom_row) {
+            // moments per spectral point: the blocks this pass's items point at (rows non-decreasing: a contiguous range;
+            // the first block of a pass may have gone over with the pass before -- copied again, harmlessly)
+            const int32_t r0 = hs->rows_sorted ? hs->in->pmom_row[w0] : 0;
+            const int32_t r1 = hs->rows_sorted ? hs->in->pmom_row[w0 + ns - 1] : hs->in->npmom - 1;
+            if (hs->rows_sorted || ip == 0)
+                HIP_TRY(hipMemcpyAsync((void *)(in->pmom + (size_t)r0 * npm), hs->in->pmom + (size_t)r0 * npm, sizeof(double) * (size_t)(r1 - r0 + 1) * npm, hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipMemcpyAsync((void *)(in->pmom_row + w0), hs->in->pmom_row + w0, sizeof(int32_t) * ns, hipMemcpyHostToDevice, cs));
+        } else {
+            HIP_TRY(hipMemcpyAsync((void *)(in->pmom + (size_t)w0 * npm), hs->in->pmom + (size_t)w0 * npm, sizeof(double) * ns * npm, hipMemcpyHostToDevice, cs));
+        }
         HIP_TRY(hipMemcpyAsync((void *)(in->wvnmlo + w0), hs->in->wvnmlo + w0, sizeof(double) * ns, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipMemcpyAsync((void *)(in->wvnmhi + w0), hs->in->wvnmhi + w0, sizeof(double) * ns, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipMemcpyAsync((void *)(in->fbeam + w0), hs->in->fbeam + w0, sizeof(double) * ns, hipMemcpyHostToDevice, cs));
@@ -920,7 +957,8 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         P.nslot = ns;
         P.dtauc = in->dtauc + (size_t)w0 * L;
         P.ssalb = in->ssalb + (size_t)w0 * L;
-        P.pmom = in->pmom + (size_t)w0 * L * (e->cfg.nmom + 1);
+        P.pmom = in->pmom_row ? in->pmom : in->pmom + (size_t)w0 * L * (e->cfg.nmom + 1);   // (rows are global indices)
+        P.pmom_row = in->pmom_row ? in->pmom_row + w0 : nullptr;
         P.wvnmlo = in->wvnmlo + w0; P.wvnmhi = in->wvnmhi + w0;
         P.fbeam = in->fbeam + w0; P.albedo = in->albedo + w0; P.plank = in->plank + w0;
         P.bitem = in->bitem ? in->bitem + (size_t)w0 * 4 : nullptr;
@@ -979,7 +1017,8 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             sbd::launch_azimuth((unsigned)((items + 255) / 256), st, P, e->naz_run);
             if (e->corint) sbd::launch_intcor((unsigned)ns, st, P, e->naz_run);
         }
-        hipLaunchKernelGGL(finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, P);
+        if (!e->fused)      // (the fused band kernel writes the status words itself: nothing runs after it)
+            hipLaunchKernelGGL(finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, P);
         if (hs) {   // this pass's outputs, staging -> host
             const size_t nf = (size_t)SBD_NFLUX * nlev, nu = rad ? (size_t)e->P.nphi * nlev * e->P.numu : 0;
             if (hs->out->flux) HIP_TRY(hipMemcpyAsync(hs->out->flux + (size_t)w0 * nf, P.flux, sizeof(double) * ns * nf, hipMemcpyDeviceToHost, st));
@@ -1079,14 +1118,16 @@ static int solve_host_enqueue(sbd_engine *e, const sbd_batch_in *in, const sbd_b
     const size_t W = in->nwork;
     const int L = e->L, nlev = e->nlev;
     const bool rad = !e->cfg.onlyfl;
-    const size_t b_lay = sizeof(double) * W * L, b_pm = sizeof(double) * W * L * (e->cfg.nmom + 1), b_w = sizeof(double) * W;
+    const bool shared = in->pmom_row != nullptr;
+    if (shared && in->npmom < 1) return fail(SBD_E_INVALID, "pmom_row given but npmom < 1");
+    const size_t b_lay = sizeof(double) * W * L, b_pm = sizeof(double) * (shared ? (size_t)in->npmom : W) * L * (e->cfg.nmom + 1), b_w = sizeof(double) * W;
     const size_t b_flux = sizeof(double) * W * SBD_NFLUX * nlev;
     const size_t b_uu = rad ? sizeof(double) * W * e->P.nphi * nlev * e->P.numu : 0;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const bool ocean = e->P.ibdrf == 1;
     if (ocean && !in->bitem) return fail(SBD_E_INVALID, "ocean surface (ibdrf = 1): bitem is NULL");
     const size_t total = 2 * up(b_lay) + up(b_pm) + 5 * up(b_w) + up(W) + up(b_flux) + up(b_uu) + up(sizeof(int32_t) * W)
-                         + (ocean ? up(4 * b_w) : 0);
+                         + (ocean ? up(4 * b_w) : 0) + (shared ? up(sizeof(int32_t) * W) : 0);
     int rc = ensure_stage(e, total);
     if (rc != SBD_OK) return rc;
     char *p = e->d_stage;
@@ -1099,9 +1140,17 @@ static int solve_host_enqueue(sbd_engine *e, const sbd_batch_in *in, const sbd_b
     double *d_uu = rad ? (double *)take(b_uu) : nullptr;
     int32_t *d_st = (int32_t *)take(sizeof(int32_t) * W);
     double *d_bi = ocean ? (double *)take(4 * b_w) : nullptr;
+    int32_t *d_row = shared ? (int32_t *)take(sizeof(int32_t) * W) : nullptr;
+    bool rows_sorted = true;
+    if (shared)
+        for (size_t i = 0; i < W; ++i) {
+            const int32_t r = in->pmom_row[i];
+            if (r < 0 || r >= in->npmom) return fail(SBD_E_INVALID, "pmom_row out of range");
+            if (i && r < in->pmom_row[i - 1]) rows_sorted = false;
+        }
     hipStream_t st = e->stream;
     if (weight) HIP_TRY(hipMemcpyAsync(d_wt, weight, b_w, hipMemcpyHostToDevice, st));
-    sbd_batch_in din = {in->nwork, d_dt, d_ss, d_pm, d_lo, d_hi, d_fb, d_al, d_pl, d_bi};
+    sbd_batch_in din = {in->nwork, d_dt, d_ss, d_pm, d_lo, d_hi, d_fb, d_al, d_pl, d_bi, d_row, shared ? in->npmom : 0};
     sbd_batch_out dout = {d_flux, d_uu, d_st};
     // pinned landing area for the outputs the caller wants (see sbd_engine::h_pin)
     const size_t w_flux = out->flux ? up(b_flux) : 0, w_uu = (rad && out->uu) ? up(b_uu) : 0, w_st = out->status ? up(sizeof(int32_t) * W) : 0;
@@ -1118,7 +1167,7 @@ static int solve_host_enqueue(sbd_engine *e, const sbd_batch_in *in, const sbd_b
     if (w_flux) { pout.flux = (double *)hp; e->pending_out.push_back({out->flux, hp, b_flux}); hp += w_flux; }
     if (w_uu) { pout.uu = (double *)hp; e->pending_out.push_back({out->uu, hp, b_uu}); hp += w_uu; }
     if (w_st) { pout.status = (int32_t *)hp; e->pending_out.push_back({out->status, hp, sizeof(int32_t) * W}); hp += w_st; }
-    const HostSide hs = {in, &pout};
+    const HostSide hs = {in, &pout, rows_sorted};
     rc = solve_device_impl(e, &din, &dout, st, &hs);   // (each pass stages its slice in and out on its own stream)
     if (rc != SBD_OK) return rc;
     if (weight) {
@@ -1171,11 +1220,12 @@ int sbd_engine_accumulate_device(sbd_engine *e, int32_t nwork, const double *wei
         HIP_TRY(hipMalloc(&e->d_partial, need * sizeof(double)));
         e->partial_elems = need;
     }
-    hipLaunchKernelGGL(accum_partial_kernel, dim3(nseg), dim3(256), 0, st, (int)nwork, nel_f, weight, flux, e->d_partial);
-    hipLaunchKernelGGL(accum_final_kernel, dim3((nel_f + 255) / 256), dim3(256), 0, st, nseg, nel_f, (const double *)e->d_partial, acc_flux);
+    const size_t acc_lds = sizeof(double) * kAccTile * 16;
+    hipLaunchKernelGGL(accum_partial_kernel, dim3(nseg), dim3(256), acc_lds, st, (int)nwork, nel_f, weight, flux, e->d_partial);
+    hipLaunchKernelGGL(accum_final_kernel, dim3((nel_f + 15) / 16), dim3(256), acc_lds, st, nseg, nel_f, (const double *)e->d_partial, acc_flux);
     if (nel_u > 0) {
-        hipLaunchKernelGGL(accum_partial_kernel, dim3(nseg), dim3(256), 0, st, (int)nwork, nel_u, weight, uu, e->d_partial);
-        hipLaunchKernelGGL(accum_final_kernel, dim3((nel_u + 255) / 256), dim3(256), 0, st, nseg, nel_u, (const double *)e->d_partial, acc_uu);
+        hipLaunchKernelGGL(accum_partial_kernel, dim3(nseg), dim3(256), acc_lds, st, (int)nwork, nel_u, weight, uu, e->d_partial);
+        hipLaunchKernelGGL(accum_final_kernel, dim3((nel_u + 15) / 16), dim3(256), acc_lds, st, nseg, nel_u, (const double *)e->d_partial, acc_uu);
     }
     HIP_TRY(hipGetLastError());
     return SBD_OK;
@@ -1356,7 +1406,7 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
     std::vector<void *> &pinned = pins.p;
     {
         const char *pe = getenv("SBD_PIN_INPUTS");
-        const size_t big = sizeof(double) * (size_t)in->nwork * L * nmom1;
+        const size_t big = sizeof(double) * (size_t)(in->pmom_row ? in->npmom : in->nwork) * L * nmom1;
         const bool pin = pe ? atoi(pe) != 0 : (busy.size() > 1 && big >= ((size_t)32 << 20));
         if (pin) {
             const std::pair<const void *, size_t> arr[3] = {{in->dtauc, sizeof(double) * (size_t)in->nwork * L},
@@ -1378,7 +1428,9 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
             sbd_shard_range(in->nwork, nd, r, &lo, &hi);
             sbd_batch_in si = {hi - lo, in->dtauc + (size_t)lo * L, in->ssalb + (size_t)lo * L, in->pmom + (size_t)lo * L * nmom1,
                                in->wvnmlo + lo, in->wvnmhi + lo, in->fbeam + lo, in->albedo + lo, in->plank + lo,
-                               in->bitem ? in->bitem + (size_t)lo * 4 : nullptr};
+                               in->bitem ? in->bitem + (size_t)lo * 4 : nullptr,
+                               in->pmom_row ? in->pmom_row + lo : nullptr, in->npmom};
+            if (in->pmom_row) si.pmom = in->pmom;          // (row indices are global: every shard sees the whole block list)
             sbd_batch_out so = {out->flux ? out->flux + (size_t)lo * nel_f : nullptr,
                                 (rad && out->uu) ? out->uu + (size_t)lo * uu_item : nullptr, out->status + lo,
                                 (e0->ibcnd && out->albtrn) ? out->albtrn + (size_t)lo * 2 * e0->ib_nout : nullptr};

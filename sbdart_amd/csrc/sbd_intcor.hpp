@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) intcor_kernel(Params P, int naz_run)
     const int32_t *layru = svi + SBD_SVI_LAYRU;
     const int ncut = svi[SBD_SVI_NCUT];
     const bool lyrcut = svi[SBD_SVI_LYRCUT] != 0;
-    const double *pmom = P.pmom + (size_t)slot * L * (nmom + 1);
+    const double *pmom = P.pmom + pmom_item(P, slot) * L * (nmom + 1);
     const double *dtauc = P.dtauc + (size_t)slot * L;
     const double umu0 = P.umu0, pi = P.pi, dither = P.dither, rpd = pi / 180.0;
     double *uu = P.uu + (size_t)slot * nphi * nlev * numu;

@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(64) layer_kernel(Params P, int32_t *only_flagg
     const double oprim = sv[o.oprim() + lc - 1];
     const double f = sv[o.flyr() + lc - 1];
     {
-        const double *pm = P.pmom + ((size_t)slot * L + (lc - 1)) * (P.nmom + 1);
+        const double *pm = P.pmom + (pmom_item(P, slot) * L + (lc - 1)) * (P.nmom + 1);
         if (g < n) {
             const int k = g;
             const double pk = (k == 0) ? 1.0 : ((k <= P.nmom) ? pm[k] : 0.0);   // PMOM(0,LC)=1 (2544)

@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
     constexpr int NPK = (n + G - 1) / G;
     double pkv[NPK];
     {
-        const double *pm = P.pmom + ((size_t)slot * L + (lcl - 1)) * (P.nmom + 1);
+        const double *pm = P.pmom + (pmom_item(P, slot) * L + (lcl - 1)) * (P.nmom + 1);
 #pragma unroll
         for (int t = 0; t < NPK; ++t) {
             const int k = g + t * G;

@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
     int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
     const double *dtauc = P.dtauc + (size_t)slot * L;
     const double *ssalb_in = P.ssalb + (size_t)slot * L;
-    const double *pmom = P.pmom + (size_t)slot * L * (nmom + 1);
+    const double *pmom = P.pmom + pmom_item(P, slot) * L * (nmom + 1);
     const double fbeam = P.fbeam[slot], umu0 = P.umu0;
     const bool plank = P.plank[slot] != 0;
     const double wlo = P.wvnmlo[slot], whi = P.wvnmhi[slot];
@@ -113,9 +113,18 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
         if (plank && (P.t.temper[lc + 1] < 0.0 || (lc == 0 && P.t.temper[0] < 0.0))) err = 1;
     }
     // PMOM range check (disort.f:4972-4981), all lanes stride the whole [L][nmom+1] block
-    for (int i = lane; i < L * (nmom + 1); i += 64) {
-        const double pm = pmom[i];
-        if (pm < -1.0 || pm > 1.0) err = 1;
+    // (sixteen loads in flight per lane and round: issued one at a time, each with its own wait, this loop WAS the
+    //  kernel -- ten dependent HBM round trips per block for a range check)
+    for (int i0 = lane; i0 < L * (nmom + 1); i0 += 64 * 16) {
+        double pv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = i0 + 64 * u;
+            pv[u] = (i < L * (nmom + 1)) ? pmom[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (pv[u] < -1.0 || pv[u] > 1.0) err = 1;
     }
     if (fbeam < 0.0 || (fbeam > 0.0 && (umu0 <= 0.0 || umu0 > 1.0))) err = 1;
     if (P.ibdrf == 0) {                  // LAMBER: ALBEDO in [0,1] (disort.f:5075-5078); a bidirectional surface is

@@ -175,8 +175,9 @@ class DisortEngine:
             raise SbdError(rc, "sbd_engine_solve_host")
         return albtrn, status
 
-    def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, bitem=None):
-        """Solve a batch.  Shapes: dtauc/ssalb [W, nlyr]; pmom [W, nlyr, nmom+1];
+    def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, bitem=None, pmom_row=None):
+        """Solve a batch.  Shapes: dtauc/ssalb [W, nlyr]; pmom [W, nlyr, nmom+1] -- or, with pmom_row [W] (int32 block
+        index per item), [npmom, nlyr, nmom+1]: the k-terms of a spectral point share their moments;
         wvnmlo/wvnmhi/fbeam/albedo [W]; plank [W] bool; bitem [W, 4] with the ocean surface (ibdrf = 1) only.
         Returns (flux[W,5,nlev], uu[W,nphi,nlev,numu] or None, status[W])."""
         try:
@@ -185,11 +186,12 @@ class DisortEngine:
         except Exception:  # torch is plumbing only
             is_t = False
         if is_t:
-            return self._solve_device(dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, bitem=bitem)
+            return self._solve_device(dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, bitem=bitem, pmom_row=pmom_row)
         dtauc, ssalb, pmom = _f64(dtauc), _f64(ssalb), _f64(pmom)
         W = dtauc.shape[0]
         assert dtauc.shape == (W, self.nlyr) and ssalb.shape == (W, self.nlyr)
-        assert pmom.shape == (W, self.nlyr, self.nmom + 1)
+        rows = None if pmom_row is None else np.ascontiguousarray(pmom_row, dtype=np.int32)
+        assert pmom.shape == ((W if rows is None else pmom.shape[0]), self.nlyr, self.nmom + 1)
         lo, hi, fb, al = (_f64(np.broadcast_to(x, (W,))) for x in (wvnmlo, wvnmhi, fbeam, albedo))
         pl = np.ascontiguousarray(np.broadcast_to(plank, (W,)), dtype=np.uint8)
         flux = np.zeros((W, _lib.NFLUX, self.nlev))
@@ -197,7 +199,8 @@ class DisortEngine:
         status = np.zeros(W, dtype=np.int32)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         bt = None if bitem is None else _f64(bitem).reshape(W, 4)
-        bi = BatchIn(W, vp(dtauc), vp(ssalb), vp(pmom), vp(lo), vp(hi), vp(fb), vp(al), vp(pl), None if bt is None else vp(bt))
+        bi = BatchIn(W, vp(dtauc), vp(ssalb), vp(pmom), vp(lo), vp(hi), vp(fb), vp(al), vp(pl), None if bt is None else vp(bt),
+                     None if rows is None else vp(rows), 0 if rows is None else pmom.shape[0])
         bo = BatchOut(vp(flux), None if uu is None else vp(uu), vp(status))
         rc = self._L.sbd_engine_solve_host(self._h, C.byref(bi), C.byref(bo))
         if rc != _lib.OK:
@@ -205,7 +208,7 @@ class DisortEngine:
         return flux, uu, status
 
     def _solve_device(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank,
-                      out=None, stream: Optional[int] = None, bitem=None):
+                      out=None, stream: Optional[int] = None, bitem=None, pmom_row=None):
         import torch
         W = dtauc.shape[0]
         for t in (dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo):
@@ -215,7 +218,7 @@ class DisortEngine:
         assert dev.index == self.device, "tensors live on cuda:%s, the engine on device %d" % (dev.index, self.device)
         assert all(t.device == dev for t in (ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank))
         assert dtauc.shape == (W, self.nlyr) and ssalb.shape == (W, self.nlyr)
-        assert pmom.shape == (W, self.nlyr, self.nmom + 1)
+        assert pmom.shape == ((W if pmom_row is None else pmom.shape[0]), self.nlyr, self.nmom + 1)
         assert all(t.shape == (W,) for t in (wvnmlo, wvnmhi, fbeam, albedo, plank))
         if out is None:
             flux = torch.empty((W, _lib.NFLUX, self.nlev), dtype=torch.float64, device=dev)
@@ -228,7 +231,8 @@ class DisortEngine:
             stream = torch.cuda.current_stream(dev).cuda_stream
         bi = BatchIn(W, dtauc.data_ptr(), ssalb.data_ptr(), pmom.data_ptr(), wvnmlo.data_ptr(),
                      wvnmhi.data_ptr(), fbeam.data_ptr(), albedo.data_ptr(), plank.data_ptr(),
-                     None if bitem is None else bitem.data_ptr())
+                     None if bitem is None else bitem.data_ptr(),
+                     None if pmom_row is None else pmom_row.data_ptr(), 0 if pmom_row is None else pmom.shape[0])
         bo = BatchOut(flux.data_ptr(), 0 if uu is None else uu.data_ptr(), status.data_ptr())
         rc = self._L.sbd_engine_solve_device(self._h, C.byref(bi), C.byref(bo), C.c_void_p(stream))
         if rc != _lib.OK:
@@ -303,13 +307,15 @@ class DisortFleet(DisortEngine):
         self._L.sbd_shard_range(nwork, self.size, rank, C.byref(lo), C.byref(hi))
         return lo.value, hi.value
 
-    def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, weight=None, items=True, bitem=None):
+    def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, weight=None, items=True, bitem=None,
+              pmom_row=None):
         """Host (numpy) batch through every device.  Returns (flux, uu, status) and, when `weight`
         is given, also (acc_flux[5,nlev], acc_uu or None) = sum_i weight[i] * outputs[i]."""
         dtauc, ssalb, pmom = _f64(dtauc), _f64(ssalb), _f64(pmom)
         W = dtauc.shape[0]
         assert dtauc.shape == (W, self.nlyr) and ssalb.shape == (W, self.nlyr)
-        assert pmom.shape == (W, self.nlyr, self.nmom + 1)
+        rows = None if pmom_row is None else np.ascontiguousarray(pmom_row, dtype=np.int32)
+        assert pmom.shape == ((W if rows is None else pmom.shape[0]), self.nlyr, self.nmom + 1)
         lo, hi, fb, al = (_f64(np.broadcast_to(x, (W,))) for x in (wvnmlo, wvnmhi, fbeam, albedo))
         pl = np.ascontiguousarray(np.broadcast_to(plank, (W,)), dtype=np.uint8)
         flux = np.zeros((W, _lib.NFLUX, self.nlev)) if items else None
@@ -317,7 +323,8 @@ class DisortFleet(DisortEngine):
         status = np.zeros(W, dtype=np.int32)
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         bt = None if bitem is None else _f64(bitem).reshape(W, 4)
-        bi = BatchIn(W, vp(dtauc), vp(ssalb), vp(pmom), vp(lo), vp(hi), vp(fb), vp(al), vp(pl), vp(bt))
+        bi = BatchIn(W, vp(dtauc), vp(ssalb), vp(pmom), vp(lo), vp(hi), vp(fb), vp(al), vp(pl), vp(bt), vp(rows),
+                     0 if rows is None else pmom.shape[0])
         bo = BatchOut(vp(flux), vp(uu), vp(status))
         acc_f = acc_u = None
         if weight is not None:

@@ -250,7 +250,7 @@ contains
     type(aerosol_load) :: load
     type(layer_clouds) :: lcloud
     real(kr), allocatable :: uu(:, :), temper(:), wlalb(:), alb(:), wsun(:), ssun(:)
-    real(kr), allocatable :: sd(:, :), ss(:, :), sp(:, :, :), swt(:, :), swl(:), slo(:), shi(:), sfb(:), salb(:), sbit(:, :)
+    real(kr), allocatable :: sd(:, :), ss(:, :), swt(:, :), swl(:), slo(:), shi(:), sfb(:), salb(:), sbit(:, :)
     type(surface_model) :: surf
     logical, allocatable :: splank(:)
     integer, allocatable :: nk_of(:), first(:)
@@ -336,7 +336,10 @@ contains
       call plan_aerosol_file(load, run_wl)
     end if
 
-    allocate(nk_of(grid%n), first(grid%n), sd(nz, mkt*grid%n), ss(nz, mkt*grid%n), sp(0:nmom, nz, mkt*grid%n), &
+    ! (the phase-function moments belong to the WAVELENGTH: one block per spectral point, shared by its k-terms --
+    !  drt.f:476-533 computes them before the k loop -- and handed to the engine that way, sbd_batch_in%pmom_row)
+    allocate(bpmom(0:nmom, nz, grid%n))
+    allocate(nk_of(grid%n), first(grid%n), sd(nz, mkt*grid%n), ss(nz, mkt*grid%n), &
              swt(mkt, grid%n), swl(grid%n), slo(grid%n), shi(grid%n), sfb(grid%n), salb(grid%n), splank(grid%n), &
              sbit(4, grid%n))
     sbit = 0
@@ -354,7 +357,7 @@ contains
       first(iwl) = nrec + 1
       nrec = nrec + nk_of(iwl)
     end do
-    allocate(recs(nrec), bdtauc(nz, nrec), bssalb(nz, nrec), bpmom(0:nmom, nz, nrec), btemper(0:nz))
+    allocate(recs(nrec), bdtauc(nz, nrec), bssalb(nz, nrec), btemper(0:nz))
     btemper = temper
     !$omp parallel do schedule(static) num_threads(nthreads) private(kd, i)
     do iwl = 1, grid%n
@@ -362,7 +365,6 @@ contains
         i = first(iwl) + kd - 1
         bdtauc(:, i) = sd(:, mkt*(iwl - 1) + kd)
         bssalb(:, i) = ss(:, mkt*(iwl - 1) + kd)
-        bpmom(:, :, i) = sp(:, :, mkt*(iwl - 1) + kd)
         recs(i)%nlyr = nz; recs(i)%nstr = m%nstr; recs(i)%nmom = nmom; recs(i)%numu = size(umu); recs(i)%nphi = size(phi)
         recs(i)%flags = merge(1, 0, splank(iwl)) + merge(0, 2, m%radiance) + merge(16, 0, m%radiance .and. m%corint)
         recs(i)%kd = kd; recs(i)%nk = nk_of(iwl); recs(i)%iwl = iwl
@@ -484,7 +486,7 @@ contains
         if (m%spowder) dtaug(nz) = 0.
         ! ---- the work item's layer arrays ----
         swt(k, iw) = wt
-        sp(:, :, mkt*(iw - 1) + k) = pmom
+        if (k == 1) bpmom(:, :, iw) = pmom
         do l = 1, nz
           sd(l, mkt*(iw - 1) + k) = dtaug(l) + dtauc(l) + dtaua(l) + dtaur(l)
           if (sd(l, mkt*(iw - 1) + k) > tiny(1._kr)) then

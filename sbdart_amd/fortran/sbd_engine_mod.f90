@@ -33,6 +33,8 @@ module sbd_engine_mod
     integer(c_int32_t) :: nwork
     type(c_ptr) :: dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank
     type(c_ptr) :: bitem = c_null_ptr    ! [4, nwork] ocean surface constants, else null
+    type(c_ptr) :: pmom_row = c_null_ptr ! [nwork] 0-based block of pmom per item when the k-terms share their moments
+    integer(c_int32_t) :: npmom = 0      ! blocks in pmom (pmom_row given)
   end type
 
   type, bind(C) :: sbd_batch_out

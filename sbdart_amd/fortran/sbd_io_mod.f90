@@ -90,7 +90,8 @@ contains
   end subroutine
 
   ! the work items as an input-only SBDREC1 file (what read_optics reads)
-  ! (the layer arrays either inside the records or, when the band model made them, in its batch arrays)
+  ! (the layer arrays either inside the records or, when the band model made them, in its batch arrays -- the moments
+  !  there one block per wavelength, bpmom(:, :, iwl))
   subroutine write_optics(path, recs, nrec, bdtauc, bssalb, bpmom, btemper, umu, phi)
     character(len=*), intent(in) :: path
     type(optics_t), intent(in) :: recs(:)
@@ -110,7 +111,7 @@ contains
                    recs(i)%phi0, recs(i)%albedo, recs(i)%btemp, recs(i)%ttemp, recs(i)%temis, recs(i)%fisot/)
       write(u) hdr, sc
       if (present(bdtauc)) then
-        write(u) bdtauc(:, i), bssalb(:, i), btemper, bpmom(:recs(i)%nmom + lbound(bpmom, 1), :, i), umu, phi
+        write(u) bdtauc(:, i), bssalb(:, i), btemper, bpmom(:recs(i)%nmom + lbound(bpmom, 1), :, recs(i)%iwl), umu, phi
       else
         write(u) recs(i)%dtauc, recs(i)%ssalb, recs(i)%temper, recs(i)%pmom, recs(i)%umu, recs(i)%phi
       end if

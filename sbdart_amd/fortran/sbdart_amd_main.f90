@@ -66,6 +66,7 @@ program sbdart_amd
        albedo(:), flux(:,:,:), uu(:,:,:,:), temper(:), umu(:), phiv(:), weight(:), acc_flux(:,:), acc_uu(:,:,:)
   integer(c_int8_t), allocatable, target :: plank(:)
   real(kr), allocatable, target :: bitem(:, :)        ! ocean surface: nr, ni, rsw per work item
+  integer(c_int32_t), allocatable, target :: pmom_row(:)   ! block of moments per work item (band model: per wavelength)
   integer(c_int32_t), allocatable, target :: status(:), level_out(:)
   integer, allocatable :: order(:), where_solved(:)
   real(kr), allocatable :: zlev(:), plev(:)
@@ -269,17 +270,23 @@ program sbdart_amd
   in_place = from_model .and. npart == nrec .and. (ncorr == nrec .or. nbeam - ncorr == nrec .or. nbeam == 0)
   allocate(wvnmlo(nrec), wvnmhi(nrec), fbeam(nrec), albedo(nrec), plank(nrec), status(nrec), weight(nrec), temper(0:nz))
   allocate(bitem(4, nrec))
-  if (in_place) then
-    call move_alloc(bdtauc, dtauc); call move_alloc(bssalb, ssalb); call move_alloc(bpmom, pmom)
+  allocate(pmom_row(nrec))
+  if (from_model) then
+    call move_alloc(bpmom, pmom)                       ! one block of moments per wavelength: pmom_row picks it per item
   else
-    allocate(dtauc(nz, nrec), ssalb(nz, nrec), pmom(0:nmom, nz, nrec))
+    allocate(pmom(0:nmom, nz, nrec))
+  end if
+  if (in_place) then
+    call move_alloc(bdtauc, dtauc); call move_alloc(bssalb, ssalb)
+  else
+    allocate(dtauc(nz, nrec), ssalb(nz, nrec))
   end if
   status = 0
   do ip = 1, npart
     i = order(ip)
     if (.not. in_place) then
       if (from_model) then
-        dtauc(:, ip) = bdtauc(:, i); ssalb(:, ip) = bssalb(:, i); pmom(:, :, ip) = bpmom(:, :, i)
+        dtauc(:, ip) = bdtauc(:, i); ssalb(:, ip) = bssalb(:, i)
       else
         dtauc(:, ip) = recs(i)%dtauc; ssalb(:, ip) = recs(i)%ssalb
         pmom(:, :, ip) = 0                             ! (a run whose CORINT went off holds shorter moment arrays later)
@@ -290,6 +297,7 @@ program sbdart_amd
     fbeam(ip) = recs(i)%fbeam; albedo(ip) = recs(i)%albedo
     plank(ip) = int(iand(recs(i)%flags, 1), c_int8_t)
     bitem(:, ip) = recs(i)%bitem
+    pmom_row(ip) = recs(i)%iwl - 1                     ! (0-based block of the item's wavelength; used when from_model)
     weight(ip) = recs(i)%wt*recs(i)%ff                 ! dwt of stdout1 (drt.f:964)
   end do
   if (from_model) then
@@ -342,7 +350,7 @@ program sbdart_amd
     end do
   end if
   if (corint .and. nmom > 10 .and. npart > 0) then       ! CHEKIN warning 5 (disort.f:4939-4941)
-    if (any(pmom(nmom, :, 1:npart) > real(1.e-3, kr))) &
+    if (any(pmom(nmom, :, 1:merge(size(pmom, 3), npart, from_model)) > real(1.e-3, kr))) &
       call warn_file(5, 'CHEKIN-- phase function not sufficiently resolved for use with corint=.true.')
   end if
   ! CHEKIN warning 7 (disort.f:5154-5158, 5169): every beam call whose CORINT argument is false -- the namelist's
@@ -655,6 +663,9 @@ contains
     bin%albedo = c_loc(albedo(p0)); bin%plank = c_loc(plank(p0))
     bin%bitem = c_null_ptr
     if (recs(1)%ibdrf == 1) bin%bitem = c_loc(bitem(1, p0))
+    if (from_model) then                               ! moments per wavelength, shared by the k-terms
+      bin%pmom = c_loc(pmom(0, 1, 1)); bin%pmom_row = c_loc(pmom_row(p0)); bin%npmom = int(size(pmom, 3), c_int32_t)
+    end if
     bout%flux = c_loc(flux(1, 1, p0)); bout%status = c_loc(status(p0))
     bout%uu = c_null_ptr
     if (radcalc) bout%uu = c_loc(uu(1, 1, 1, p0))

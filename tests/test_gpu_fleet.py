@@ -124,3 +124,37 @@ def test_rccl_reduce_path_on_one_device():
     assert res["0"]["rccl"] is False and res["1"]["rccl"] is True
     assert res["1"]["bad"] == 0
     assert res["1"]["acc"] == res["0"]["acc"] and res["1"]["acc2"] == res["1"]["acc"] and res["1"]["fsum"] == res["0"]["fsum"]
+
+
+def test_moments_shared_by_the_k_terms_of_a_point():
+    """sbd_batch_in::pmom_row: one block of phase-function moments per SPECTRAL POINT instead of per work item (the
+    reference computes them once per wavelength, drt.f:476-533).  Same answers, bit for bit, as the expanded batch --
+    through the host entry point (several passes: every pass copies the range of blocks its items point at), the
+    device entry point, a three-engine fleet, and with unsorted rows (all blocks copied up front)."""
+    import torch
+    from sbdart_amd.engine import DisortEngine, DisortFleet
+    from sbdart_amd.workload import sw_sweep
+    sw = sw_sweep(nwl=700, nstr=8, nlyr=20, seed=17)
+    rows = sw.wl_of.astype(np.int32)                            # item -> spectral point
+    pm_pt = np.stack([sw.pmom[np.nonzero(rows == k)[0][0]] for k in range(sw.nwl)])      # the point's first item's moments
+    pm_full = pm_pt[rows]
+    ins = lambda pm: (sw.dtauc, sw.ssalb, pm, sw.wvnmlo, sw.wvnmhi, sw.fbeam, sw.albedo, sw.plank)
+    kw = dict(nlyr=sw.nlyr, nstr=sw.nstr, nmom=sw.nmom, temper=sw.temper, umu0=sw.umu0, btemp=sw.btemp, ttemp=sw.ttemp,
+              temis=sw.temis, onlyfl=True, level_out=[0, sw.nlyr])
+    with DisortEngine(device=0, max_batch=256, **kw) as eng:
+        f0, _, s0 = eng.solve(*ins(pm_full))
+        f1, _, s1 = eng.solve(*ins(pm_pt), pmom_row=rows)
+        perm = np.random.default_rng(1).permutation(sw.nwork)
+        f2, _, s2 = eng.solve(sw.dtauc[perm], sw.ssalb[perm], pm_pt, sw.wvnmlo[perm], sw.wvnmhi[perm], sw.fbeam[perm],
+                              sw.albedo[perm], sw.plank[perm], pmom_row=rows[perm])
+        dev = torch.device("cuda:0")
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        f3, _, s3 = eng.solve(t(sw.dtauc), t(sw.ssalb), t(pm_pt), t(sw.wvnmlo), t(sw.wvnmhi), t(sw.fbeam), t(sw.albedo),
+                              t(sw.plank), pmom_row=t(rows))
+        torch.cuda.synchronize()
+    assert (s0 == 0).all() and sw.nwork > 4 * 256
+    assert np.array_equal(f0, f1) and np.array_equal(s0, s1)
+    assert np.array_equal(f0[perm], f2) and np.array_equal(f0, f3.cpu().numpy())
+    with DisortFleet(devices=[0, 0, 0], **kw) as fl:
+        f4, _, s4, acc, _ = fl.solve(*ins(pm_pt), weight=sw.weight, pmom_row=rows)
+    assert np.array_equal(f0, f4)
