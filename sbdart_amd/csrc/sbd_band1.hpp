@@ -74,12 +74,28 @@ SBD_DEVICE int wave_first_max_of(double a, int lane, int lm)
     return hit ? __ffsll((long long)hit) - 1 : 0;
 }
 
-template <int NN>
+// sum over the wave, result in every lane
+SBD_DEVICE double wave_sum64(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 64);
+    return v;
+}
+
+// FUSED (flux-only run, output levels = top of layer 1 and the surface): FLUXES' three angular sums at a level are linear
+// functionals c^T x of the solution; each rides through the elimination as an extra row of [A b; c^T 0] and never takes
+// part in the pivot search, so that after the last step its right-hand side is -c^T x (sbd_band4.hpp has the long
+// version).  Here: the top level's rows as one register per lane (F[k]: lanes < 32 the x_lc coefficients, lanes >= 32
+// the x_lc+1 ones) with a wave-uniform right-hand side; the surface level's rows in the zero padding rows nn..nn+2 of
+// the bottom block, scaled by 2^-300 (the exact first-maximum search never takes them while a real row is left), tagged
+// 1, 2, 3 in the x_lc+1 half, which the last step does not use.  No U, no B, no back-substitution kernel.
+template <int NN, bool FUSED = false>
 __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int n = 2 * NN, nn = NN, RW = nn + n, UW = u_width(n);
     static_assert(n <= 32 && RW <= 64, "band1_kernel: a layer's columns must fit half a wave");
+    constexpr double kTiny = 4.909093465297727e-91, kHuge = 2.037035976334486e+90;   // 2^-300, 2^300
     const int lane = threadIdx.x, q = lane & 31;
     const bool second = lane >= 32;                // this lane carries a column of x_lc+1
     const int nmode = P.nmode, L = P.L;
@@ -96,6 +112,7 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
     if (dead) {   // DISORT returned before computing anything: outputs stay zero (ZEROAL)
         double *flux = P.flux + (size_t)slot * SBD_NFLUX_ * nlev;
         for (int i = lane; i < SBD_NFLUX_ * nlev; i += 64) flux[i] = 0.0;
+        if constexpr (FUSED) { if (lane == 0) P.status[slot] = st0; }
         return;
     }
     const int ncut = svi[SBD_SVI_NCUT];
@@ -117,7 +134,7 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
     const double *ga_ms = P.ga + (size_t)ms * L * n * n;           // interface lc: [row][column of x_lc]
     const double *gb_ms = P.gb + (size_t)ms * L * n * n + (size_t)n * n;    // ... [row][column of x_lc+1]
     double *yv = P.yv + (size_t)ms * L * n;
-    double *ufac = P.ufac + (size_t)ms * (size_t)(L * n) * UW;
+    double *ufac = FUSED ? nullptr : P.ufac + (size_t)ms * (size_t)(L * n) * UW;
     double *bcb = P.bcb + (size_t)ms * 2 * n * n;                  // bottom-boundary rows + a block of zeros (below)
     double *mcol = smem;                                           // [RW] pivot column, for the right-hand side
     const int N = ncut * n;
@@ -175,8 +192,27 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
         if (refl && !brdf)
             for (int k = 1; k <= nn; ++k) sb = sb + cwt[k - 1] * cmu[k - 1] * albedo * GC(nn + 1 - k, iq1, ncut);
         const double f = (iq1 > nn) ? EK(n + 1 - iq1, ncut) : 1.0;
+        double cb[3] = {0.0, 0.0, 0.0};
+        if constexpr (FUSED) {   // the surface level's functionals (only a level inside layer ncut has any)
+            const int levb = P.t.level_out[1];
+            if (svi[SBD_SVI_LAYRU + levb] == ncut) {
+                const double upb = sv[o.utaupr() + levb];
+                const double refb = (qc < nn) ? taucpr[ncut] : taucpr[ncut - 1];
+                const double eb = exp(-KK(iq1, ncut) * (upb - refb)) * kTiny;
+                double sa = 0.0, sd = 0.0, su = 0.0;
+                for (int i = 0; i < n; ++i) {
+                    const int iw = (i < nn) ? nn - 1 - i : i - nn;
+                    const double g = GC(i + 1, iq1, ncut), w = cwt[iw];
+                    sa = sa + w * g;
+                    if (i < nn) sd = sd + (w * cmu[iw]) * g;
+                    else su = su + (w * cmu[iw]) * g;
+                }
+                cb[0] = sa * eb; cb[1] = sd * eb; cb[2] = su * eb;
+            }
+        }
         for (int r = 0; r < n; ++r) {
             double g = 0.0;
+            if constexpr (FUSED) { if (r >= nn && r < nn + 3) g = cb[r - nn]; }
             if (r < nn) {
                 g = GC(nn + 1 + r, iq1, ncut);
                 if (refl && brdf) {                        // row r+1 of BDR meets the downward streams (disort.f:2946-2952)
@@ -235,6 +271,29 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
         const Z3 z1 = load_z(1), z2 = load_z(2);
         const double y1 = step_rhs(1, z1, z2, expbea[1], taucpr[1]);
         y = (lane < nn) ? ytop : ((lane < RW) ? y1 : 0.0);
+        if constexpr (FUSED) {
+            if (ncut == 1 && second) { a[n] = 1.0; a[n + 1] = 2.0; a[n + 2] = 3.0; }   // (one layer: the first step is the last)
+        }
+    }
+    // FUSED: the top level's three functional rows (mean intensity, downward and upward flux sums); the level lies in
+    // layer 1, they enter with the first step
+    double F[3] = {0.0, 0.0, 0.0}, Fy[3] = {0.0, 0.0, 0.0};
+    if constexpr (FUSED) {
+        if (col && !second) {
+            const int levt = P.t.level_out[0];
+            const double upt = sv[o.utaupr() + levt];
+            const double reft = (qc < nn) ? taucpr[1] : taucpr[0];
+            const double et = exp(-KK(iq1, 1) * (upt - reft));
+            double sa = 0.0, sd = 0.0, su = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const int iw = (i < nn) ? nn - 1 - i : i - nn;
+                const double g = GC(i + 1, iq1, 1), w = cwt[iw];
+                sa = sa + w * g;
+                if (i < nn) sd = sd + (w * cmu[iw]) * g;
+                else su = su + (w * cmu[iw]) * g;
+            }
+            F[0] = sa * et; F[1] = sd * et; F[2] = su * et;
+        }
     }
     int status = 0;
     double pmin = 1.0e300, pmax = 0.0;         // see near_singular() in sbd_layer.hpp; lane J sees the pivot of sub-step J
@@ -247,7 +306,7 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
         Z3 zu, zn;
         double ebn = 0.0, tcn = 0.0;
         const int k0 = (lc - 1) * n;                            // rows k0+1 .. k0+n retire in this step
-        double *urow0 = ufac + (size_t)k0 * UW;
+        double *urow0 = FUSED ? nullptr : ufac + (size_t)k0 * UW;
         double *yrow0 = yv + k0;
         const bool tail = lc == ncut;                           // the last layer has no x_lc+1
         static_for<n>([&](auto jj) {
@@ -300,8 +359,8 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
             rn = (t != 0.0) ? -rn : 0.0;
             const double rns = uniform_from_lane(rn, J);
             if (ln == J) { pmin = fmin(pmin, fabs(t)); pmax = fmax(pmax, fabs(t)); }
-            // (4) the retired row: U(k, k..k+2n-1-J) relative to the diagonal, B(k)
-            {
+            // (4) the retired row: U(k, k..k+2n-1-J) relative to the diagonal, B(k) -- FUSED: nothing is stored
+            if constexpr (!FUSED) {
                 double *urow = urow0 + J * UW;
                 if (!second) {
                     if (lq >= J && col) urow[lq - J] = t;
@@ -321,6 +380,14 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
             {
                 const double yt = ypiv * rns;
                 y = (ln < LAST) ? y + v * yt : y;
+                if constexpr (FUSED) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const double mk = uniform_from_lane(F[k], J);     // the row's entry in column J of x_lc
+                        F[k] = F[k] + mk * tp;
+                        Fy[k] = Fy[k] + mk * yt;
+                    }
+                }
             }
         });
         // ---- the nn rows left over only touch x_lc+1: next step's carry (their entries move to the
@@ -333,6 +400,14 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
 #pragma unroll
         for (int r = 0; r < E; ++r) a[nn + r] = buf[r];
         y = (lane < nn) ? y : ((lane < RW) ? ynext : 0.0);
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double up = __shfl(F[k], lane + 32);
+                F[k] = second ? 0.0 : up;
+            }
+            if (lc + 1 == ncut && second) { a[n] = 1.0; a[n + 1] = 2.0; a[n + 2] = 3.0; }   // tags of the surface rows
+        }
     }
     {   // errmsg 2: min|pivot| <= 8 N eps max|pivot| over the N pivots of the system (a zero pivot included)
         double am = pmax, pm = pmin;
@@ -344,6 +419,69 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
         if (lane == 0 && !(pm > 8.0 * N * 2.220446049250313e-16 * am)) status |= 0x01;
     }
     if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
+    if constexpr (FUSED) {
+        if (lane == 0) P.status[slot] = st0 | status;       // (the last kernel of a fused pass: no finish_kernel)
+        // ---- FLUXES (disort.f:1780-2042) at the two levels from the functionals: the top level's are the right-hand
+        //      sides Fy; the surface level's are the right-hand sides of the nn rows the last step left over, three of
+        //      them tagged 1..3 in what was their x_lc+1 half (moved to lanes < 32 by the hand-over) ----
+        double fs[2][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            fs[0][k] = -Fy[k];
+            double v = 0.0;
+#pragma unroll
+            for (int p = 0; p < nn; ++p) {
+                const double tag = uniform_from_lane(a[p], 0);
+                const double yp = uniform_from_lane(y, p);
+                v = (tag == (double)(k + 1)) ? yp : v;
+            }
+            fs[1][k] = -v * kHuge;
+        }
+        const bool mycol = col && !second;
+        const int iqw = (qc < nn) ? nn - 1 - qc : qc - nn;
+        const double wq = mycol ? cwt[iqw] : 0.0, wmq = mycol ? cwt[iqw] * cmu[iqw] : 0.0;
+        const double pi = P.pi;
+        const int32_t *layru = svi + SBD_SVI_LAYRU;
+        const double *utau = sv + o.utau(), *utaupr = sv + o.utaupr(), *ssalbv = sv + o.ssalb();
+        const double *xr0 = sv + o.xr0(), *xr1 = sv + o.xr1();
+        double *flux = P.flux + (size_t)slot * SBD_NFLUX_ * nlev;
+#pragma unroll
+        for (int ol = 0; ol < 2; ++ol) {
+            const int lev = P.t.level_out[ol];
+            const int lc = layru[lev];
+            double rfldir = 0.0, rfldn = 0.0, flup = 0.0, dfdt = 0.0, uavg = 0.0;
+            if (lc <= ncut) {       // (levels below a cut-off layer stay zero, disort.f:1907-1916)
+                const double up = utaupr[lev];
+                // particular solutions' share of U0C(iq): ZZ e^{-tau'/mu0} + ZPLK0 + ZPLK1 tau' (disort.f:1945-1960)
+                double part = zp0[(lc - 1) * n + qc] + zp1[(lc - 1) * n + qc] * up;
+                if (beam) part = zz[(lc - 1) * n + qc] * exp(-up / umu0) + part;
+                const double uavg_s = fs[ol][0] + wave_sum64(wq * part);
+                const double fldn_s = fs[ol][1] + wave_sum64((qc < nn) ? wmq * part : 0.0);
+                const double flup_s = fs[ol][2] + wave_sum64((qc >= nn) ? wmq * part : 0.0);
+                double dirint = 0.0, fldir = 0.0;
+                if (beam) {
+                    const double fact = exp(-up / umu0);
+                    dirint = fbeam * fact;
+                    fldir = umu0 * (fbeam * fact);
+                    rfldir = umu0 * fbeam * exp(-utau[lev] / umu0);
+                }
+                flup = 2.0 * pi * flup_s;
+                const double fldn = 2.0 * pi * fldn_s;
+                const double fdntot = fldn + fldir;
+                rfldn = fdntot - rfldir;
+                uavg = (2.0 * pi * uavg_s + dirint) / (4.0 * pi);
+                const double plsorc = xr0[lc - 1] + xr1[lc - 1] * up;
+                dfdt = (1.0 - ssalbv[lc - 1]) * 4.0 * pi * (uavg - plsorc);
+            }
+            if (lane == 0) {
+                flux[0 * nlev + ol] = rfldir;
+                flux[1 * nlev + ol] = rfldn;
+                flux[2 * nlev + ol] = flup;
+                flux[3 * nlev + ol] = dfdt;
+                flux[4 * nlev + ol] = uavg;
+            }
+        }
+    }
 #undef GC
 #undef KK
 #undef EK

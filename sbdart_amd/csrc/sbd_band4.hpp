@@ -358,6 +358,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     // every load so far has landed before the loop: the waits inside then only count the loop's own
     // memory operations (vmcnt(0), expcnt/lgkmcnt unconstrained)
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    const unsigned long long lane0 = __ballot(q == 0);         // lane 0 of every system
     for (int lc = 1; lc <= ncut; ++lc) {
         RowSrc pna, pnb;                                        // next step's rows
         step_rows(lc + 1, pna, pnb);
@@ -394,8 +395,17 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             }
             // (2) pivot row out of its registers, the last live row into them: one pass per
             //     distinct row index among the systems of the wave
-            double t0, t1, t2;
-            TakeRows<RW, LAST>::run(a0, a1, a2, idxb, t0, t1, t2);
+            //     The right-hand side is the same in the 16 lanes of a system, a third register set that only sub-step 0
+            //     works on: from sub-step 1 on it RIDES IN LANE 0 OF SLOT 0 -- column 0 is finished by then and the
+            //     elimination treats the lane like any other column (tp0 of lane 0 = -B(pivot row) / pivot: the very
+            //     product the third set's update formed, bit for bit) -- and returns to its set at the hand-over.
+            //     That takes the third FMA per row and two of the six moves per take-out pass off 15 of 16 sub-steps.
+            constexpr bool RL = J >= 1;
+            double t0, t1, t2 = 0.0;
+            if constexpr (RL) {
+                TakeRows2<RW, LAST>::run(a0, a1, idxb, t0, t1);
+                if constexpr (!FUSED) t2 = dbl_lane_bcast<0>(t0);
+            } else TakeRows<RW, LAST>::run(a0, a1, a2, idxb, t0, t1, t2);
             // register LAST is free from here on: next interface's row LAST - nn moves in
             // (slot 1 only: slot 0 of an inner step waits in LDS, the bottom-boundary block of the last step is
             //  read at the hand-over -- once per system, not worth registers in every step)
@@ -457,22 +467,29 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             // (5) elimination: a_s[p] += a_0[p](lane J) * (t_s * -1/pivot); columns <= J of
             //     slot 0 are finished (their registers keep the unscaled multipliers)
             const double rnb = dbl_lane_bcast<J>(rn);
-            const double tp1 = rnb * t1, tp2 = rnb * t2;
+            const double tp1 = rnb * t1, tp2 = RL ? 0.0 : rnb * t2;
             // (no mask on slot 0: the finished columns q <= J then collect garbage instead of keeping the multipliers --
             //  nobody reads them again; the lanes left of the diagonal are skipped where U is used)
             const double tp0 = rnb * t0;
 #pragma unroll
             for (int p = 0; p < LAST; ++p) {
                 a1[p] = fmac_lane_bcast<J>(a1[p], a0[p], tp1);
-                a2[p] = fmac_lane_bcast<J>(a2[p], a0[p], tp2);
+                if constexpr (!RL) a2[p] = fmac_lane_bcast<J>(a2[p], a0[p], tp2);
                 a0[p] = fmac_lane_bcast<J>(a0[p], a0[p], tp0);
             }
             if constexpr (FUSED) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     F1[k] = fmac_lane_bcast<J>(F1[k], F0[k], tp1);
-                    F2[k] = fmac_lane_bcast<J>(F2[k], F0[k], tp2);
+                    if constexpr (!RL) F2[k] = fmac_lane_bcast<J>(F2[k], F0[k], tp2);
                     F0[k] = fmac_lane_bcast<J>(F0[k], F0[k], tp0);
+                }
+            }
+            if constexpr (J == 0) {                             // the right-hand side moves into the finished column's lane
+                InjectRhs<RW>::run(a0, a2, lane0);
+                if constexpr (FUSED) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) F0[k] = (q == 0) ? F2[k] : F0[k];
                 }
             }
         });
@@ -483,10 +500,10 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         }
         // ---- the nn rows left over only touch x_lc+1: next step's carry ----
 #pragma unroll
-        for (int p = 0; p < nn; ++p) { a0[p] = a1[p]; a1[p] = 0.0; }
+        for (int p = 0; p < nn; ++p) { a2[p] = dbl_lane_bcast<0>(a0[p]); a0[p] = a1[p]; a1[p] = 0.0; }   // (B back to its set)
         if constexpr (FUSED) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { F0[k] = F1[k]; F1[k] = 0.0; }
+            for (int k = 0; k < 3; ++k) { F2[k] = dbl_lane_bcast<0>(F0[k]); F0[k] = F1[k]; F1[k] = 0.0; }
         }
         // ... and the prefetched rows of the next step complete the window, scaled as they arrive
         // slot 0 of the next step: GC(lc+1) from LDS (inner step), the bottom-boundary block (last step, below)

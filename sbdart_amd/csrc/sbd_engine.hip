@@ -270,7 +270,7 @@ struct sbd_engine {
     int32_t *d_surf_flag = nullptr; // shared surface tables: CHEKIN's verdict on the model (sbd_surface.hpp)
     double *d_surf = nullptr;       // shared surface tables (Hapke / Ross-Li: one set per run)
     bool brdf_bad = false;          // ... the model's flux albedo leaves [0,1]: every item gets SBD_ST_ERR_INPUT
-    bool fused = false;             // band4, flux-only, levels = {top of layer 1, surface}: the band kernel carries FLUXES'
+    bool fused = false;             // band4 / band1, flux-only, levels = {top of layer 1, surface}: the band kernel carries FLUXES'
                                     // functionals through the elimination -- no U factor, no back-substitution kernel
     int ibcnd = 0, ib_nout = 0;     // IBCND = 1 (ALBTRN): results at ib_nout cosines; the engine proper runs the doubled batch
     std::vector<double> ib_umu;     // ... at -umu reversed | +umu
@@ -548,7 +548,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     bool band1 = nn >= 9 && nn <= 16;
     if (const char *s = getenv("SBD_BAND_V1")) { band4 = band4 && atoi(s) == 0; band1 = band1 && atoi(s) == 0; }
     // fluxes at the top of the first layer and at the surface only (IOUT 1 / 10 with the default ZOUT): fused band kernel
-    bool fused = band4 && nn >= 3 && cfg->onlyfl && cfg->nlevel_out == 2 && cfg->level_out[0] == 0 && cfg->level_out[1] == L;
+    bool fused = (band4 || band1) && nn >= 3 && cfg->onlyfl && cfg->nlevel_out == 2 && cfg->level_out[0] == 0 && cfg->level_out[1] == L;
     if (const char *s = getenv("SBD_NO_FUSE")) fused = fused && atoi(s) == 0;
     const size_t nblk = band4 ? 1 : 3;
     const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)2 * n * n : 0) + (size_t)L * n * 6 + (size_t)L * nn + (fused ? 0 : (size_t)L * n * (2 * n))
@@ -984,9 +984,11 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
                 const int gpb2 = 64 / e->G2;
                 const unsigned g2 = (unsigned)(((size_t)ns * L + gpb2 - 1) / gpb2) * (unsigned)nmode;
                 sbd::launch_layer2(e->nn, rad && !e->quad, g2, e->layer2_lds, st, P, eigflag);
-                flt = eigflag;          // the QR kernel below only redoes the listed layers: a small
-                if (grid > 256u) grid = 256u;     // fixed grid (a block per CU) walks the list, normally empty:
-                                                  // its blocks ask for 30 KB of LDS each, so few of them start fast
+                flt = eigflag;          // the QR kernel below only redoes the listed layers: a fixed grid walks the
+                if (grid > 2048u) grid = 2048u;   // list (normally empty: every block reads the count and leaves).  With
+                                                  // 256 blocks a batch with 1 % of its layers listed (thermal runs with
+                                                  // conservative cloud layers) spent more time here than in the fast
+                                                  // kernel: 5 632 layers in 5.5 rounds of 0.13 ms (tools/fallback_probe.py)
                 SBD_DBG("layer2");
             }
             sbd::launch_layer_v1(e->G, grid, e->layer_lds, st, P, flt);
@@ -999,7 +1001,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
                 P.pivdbg = e->d_pivdbg + (second ? (size_t)e->chunk * nmode * L * n : 0);
                 sbd::launch_band4_pivdbg(e->nn, (bgrid + 3) / 4, st, P);
             } else if (e->band4) sbd::launch_band4(e->nn, (bgrid + 3) / 4, st, P, e->fused);
-            else if (e->band1) sbd::launch_band1(e->nn, bgrid, st, P);
+            else if (e->band1) sbd::launch_band1(e->nn, bgrid, st, P, e->fused);
             else if (e->band_reg) sbd::launch_band_reg(e->nn, bgrid, e->band_lds, st, P);
             else sbd::launch_band_lds(e->nn, bgrid, e->band_lds, st, P);
         }

@@ -37,7 +37,7 @@ void launch_band_lds(int nn, unsigned grid, int lds, hipStream_t st, const Param
 void launch_band_reg(int nn, unsigned grid, int lds, hipStream_t st, const Params &P);
 void launch_band4(int nn, unsigned grid, hipStream_t st, const Params &P, bool fused);
 void launch_band4_pivdbg(int nn, unsigned grid, hipStream_t st, const Params &P);
-void launch_band1(int nn, unsigned grid, hipStream_t st, const Params &P);
+void launch_band1(int nn, unsigned grid, hipStream_t st, const Params &P, bool fused);
 hipError_t prepare_backsolve(int nn, int lds);
 void launch_backsolve(int nn, unsigned grid, int lds, hipStream_t st, const Params &P);
 void launch_backsolve4(int nn, unsigned grid, hipStream_t st, const Params &P);
