@@ -898,6 +898,28 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
     if (npass > 1 && (npass & 1)) ++npass;
     const bool fork = !timing && !dbg && npass > 1;
     const int per_pass = (in->nwork + npass - 1) / npass;
+    // pass ip = items [pw0[ip], pw0[ip + 1]).  Inputs resident on the device: the equal passes above.  Inputs coming
+    // from the host (hs): nothing can start before the first pass's inputs have crossed PCIe -- 1.15 ms for a sixth of
+    // the bench's batch (rocprofv3 time line) -- and copying a pass takes 0.77 of computing it, so the passes start
+    // at a quarter of the size and grow by 1.3 x: each copy still lands before the pass ahead of it has finished.
+    std::vector<int> pw0;
+    pw0.push_back(0);
+    // (Not below 8192 items: a smaller pass leaves the band kernel less than one wave per SIMD slot.  Only with the
+    //  moments shared per spectral point: with per-item moments the copies are the longer leg and more of them cost.)
+    if (hs && fork && in->nwork >= 32768 && hs->in->pmom_row) {
+        double sz = (0.25 * per_pass > 8192.0) ? 0.25 * per_pass : 8192.0;
+        while (sz < 0.95 * per_pass && pw0.back() + (int)sz < in->nwork) {
+            pw0.push_back(pw0.back() + (int)sz);
+            sz *= 1.3;
+        }
+        const int rest = in->nwork - pw0.back();
+        const int m = (rest + per_pass - 1) / per_pass;
+        for (int k = 1; k <= m; ++k) pw0.push_back(in->nwork - rest + (int)((long long)rest * k / m));
+    } else {
+        for (int w = per_pass; w < in->nwork; w += per_pass) pw0.push_back(w);
+        pw0.push_back(in->nwork);
+    }
+    const int npass_run = (int)pw0.size() - 1;
     if (fork) {
         HIP_TRY(hipEventRecord(e->ev_fork, st));                 // what the caller queued before this call ...
         HIP_TRY(hipStreamWaitEvent(e->aux, e->ev_fork, 0));      // ... is also ahead of the auxiliary stream
@@ -908,10 +930,10 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
     // pageable ones (the runtime stages those and returns when the copy is done) the calling thread copies
     // while the GPU computes the pass before
     auto copy_pass = [&](const int ip) -> int {
-        const int w0 = ip * per_pass;
-        if (!hs || w0 >= in->nwork) return SBD_OK;
+        if (!hs || ip >= npass_run) return SBD_OK;
+        const int w0 = pw0[ip];
         const size_t npm = (size_t)L * (e->cfg.nmom + 1);
-        const int ns = (in->nwork - w0 < per_pass) ? in->nwork - w0 : per_pass;
+        const int ns = pw0[ip + 1] - w0;
         hipStream_t cs = e->copy;
         HIP_TRY(hipMemcpyAsync((void *)(in->dtauc + (size_t)w0 * L), hs->in->dtauc + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipMemcpyAsync((void *)(in->ssalb + (size_t)w0 * L), hs->in->ssalb + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, cs));
@@ -946,9 +968,8 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         const int rc0 = copy_pass(0);
         if (rc0 != SBD_OK) return rc0;
     }
-    int ipass = 0;
-    for (int w0 = 0; w0 < in->nwork; w0 += per_pass, ++ipass) {
-        const int ns = (in->nwork - w0 < per_pass) ? in->nwork - w0 : per_pass;
+    for (int ipass = 0; ipass < npass_run; ++ipass) {
+        const int w0 = pw0[ipass], ns = pw0[ipass + 1] - w0;
         const bool second = (ipass & 1) != 0;
         sbd::Params P = second ? e->P2 : e->P;
         st = (fork && second) ? e->aux : st_main;
