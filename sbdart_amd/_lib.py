@@ -51,6 +51,7 @@ EXPORTS = (
     "sbd_last_error", "sbd_engine_debug_copy", "sbd_engine_debug_pivots",
     "sbd_fleet_create", "sbd_fleet_destroy", "sbd_fleet_size", "sbd_fleet_engine", "sbd_fleet_uses_rccl",
     "sbd_shard_range", "sbd_fleet_solve_host", "sbd_fleet_last_enqueue", "sbd_host_alloc", "sbd_host_free",
+    "sbd_surface_flux_albedo",
 )
 
 _LIB = None

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <chrono>
 #include <string>
@@ -741,6 +742,37 @@ int sbd_engine_quadrature(const sbd_engine *e, double *cmu, double *cwt)
 {
     if (!e || !cmu || !cwt) return SBD_E_INVALID;
     for (int i = 0; i < e->nn; ++i) { cmu[i] = e->h_cmu[i]; cwt[i] = e->h_cwt[i]; }
+    return SBD_OK;
+}
+
+// DREF(WVNMLO, WVNMHI, MU) (disort.f:5178-5284) on the host: the flux albedo of a bidirectional surface for incidence
+// cosine mu, with the very model functions the device integrates (sbd_surface.hpp) and the same 50-point rule.  The
+// reference's driver asks for it once per wavelength when ISALB is -7, -8 or -9 -- a LAMBERTIAN surface whose albedo
+// is the model's flux albedo at the solar zenith angle (drt.f:478-484) -- so it is a host program's call, no GPU.
+int sbd_surface_flux_albedo(int32_t ibdrf, const double *bpar, const double *bitem, double mu, double *albedo)
+{
+    if (!bpar || !albedo || ibdrf < 1 || ibdrf > 3) return fail(SBD_E_INVALID, "sbd_surface_flux_albedo: model 1..3, bpar, albedo");
+    if (ibdrf == 1 && !bitem) return fail(SBD_E_INVALID, "sbd_surface_flux_albedo: the ocean needs bitem");
+    if (!(mu >= 0.0 && mu <= 1.0)) return fail(SBD_E_INVALID, "DREF--input argument error(s)");   // disort.f:5262
+    constexpr int NG = sbd::kSurfGauss;
+    static double gmu[NG], gwt[NG];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        gauss01(NG / 2, gmu, gwt);
+        for (int k = 0; k < NG / 2; ++k) { gmu[k + NG / 2] = -gmu[k]; gwt[k + NG / 2] = gwt[k]; }
+    });
+    sbd::BrdfModel M;
+    M.ibdrf = ibdrf;
+    for (int k = 0; k < 8; ++k) M.bp[k] = bpar[k];
+    M.nr = bitem ? bitem[0] : 0.0; M.ni = bitem ? bitem[1] : 0.0; M.rsw = bitem ? bitem[2] : 0.0;
+    const double pi = ref_pi();
+    double d = 0.0;
+    for (int jg = 0; jg < NG; ++jg) {
+        double sum = 0.0;
+        for (int k = 0; k < NG / 2; ++k) sum = sum + gwt[k] * gmu[k] * sbd::surf_bdref(M, gmu[k], mu, pi * gmu[jg]);
+        d = d + gwt[jg] * sum;
+    }
+    *albedo = d;
     return SBD_OK;
 }
 

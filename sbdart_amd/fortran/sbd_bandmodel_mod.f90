@@ -43,7 +43,6 @@ contains
     type(model_input), intent(in) :: m
     character(len=*), intent(out) :: why
     why = ''
-    if (m%isalb <= -7) why = 'Lambertian surface with the flux albedo of a BRDF model (isalb -7, -8, -9)'
     if (m%kdist < -1) why = 'k-distribution mode (kdist < -1)'
     if (m%nf == -2 .and. m%kdist /= -1) why = 'solar spectrum from a k-distribution file (nf=-2) without kdist=-1'
     ok = len_trim(why) == 0
@@ -372,7 +371,9 @@ contains
         recs(i)%wvnmlo = slo(iwl); recs(i)%wvnmhi = shi(iwl); recs(i)%fbeam = sfb(iwl)
         recs(i)%umu0 = merge(1._kr, amu0, m%sza >= 90.); recs(i)%phi0 = m%phi0; recs(i)%albedo = salb(iwl)
         recs(i)%btemp = btemp; recs(i)%ttemp = ttemp; recs(i)%temis = m%temis; recs(i)%fisot = m%fisot
-        recs(i)%ibdrf = surf%ibdrf; recs(i)%bpar = surf%par; recs(i)%bitem = sbit(:, iwl)
+        if (.not. surf%as_albedo) then
+          recs(i)%ibdrf = surf%ibdrf; recs(i)%bpar = surf%par; recs(i)%bitem = sbit(:, iwl)
+        end if
         if (from_ck) then
           recs(i)%ib = ck%ib(iwl); recs(i)%nb = ck%nb(iwl); recs(i)%ewcoef = ck%ewcoef(iwl)
         end if
@@ -424,6 +425,10 @@ contains
         rsfc = 0.                                                 ! (LAMBER off: DISORT never reads ALBEDO)
         ! the ocean's water constants at BDREF's wavelength, the middle of the band in wavenumber (spectra.f:284)
         if (surf%ibdrf == 1) call ocean_constants(surf, 20000./(wvhi + wvlo), sbit(1, iw), sbit(2, iw), sbit(3, iw))
+        if (surf%as_albedo) then                                  ! ISALB -7, -8, -9 (drt.f:478-484)
+          rsfc = max(0._kr, min(flux_albedo(surf, sbit(:, iw), amu0), 1._kr))
+          sbit(:, iw) = 0.
+        end if
       else if (wl < wlalb(1) .or. wl > wlalb(size(wlalb))) then   ! (writes the reference's warning file: one at a time)
         !$omp critical (sbd_surface_warning)
         rsfc = max(0._kr, min(surface_albedo(wlalb, alb, wl), 1._kr))

@@ -10,18 +10,32 @@
 ! Literals are written as the reference types them (default-real where it has default-real) so that the numbers
 ! handed to the engine are the reference's to the bit: tests/test_band_model.py compares them with the captured ones.
 module sbd_surface_mod
+  use iso_c_binding
   use sbd_grid_mod, only: kr
   use sbd_tables_mod, only: tbl
   use sbd_atmos_mod, only: bracket
   implicit none
   private
-  public :: surface_model, new_surface_model, ocean_constants
+  public :: surface_model, new_surface_model, ocean_constants, flux_albedo
 
   type surface_model
     integer :: ibdrf = 0                 ! 0 Lambertian, 1 ocean, 2 Hapke, 3 Ross-thick / Li-sparse
     real(kr) :: par(8) = 0               ! sbd_run_cfg%bpar
     real(kr) :: pigment = 0              ! ocean: pigment concentration (mg/m3), SC(1)
+    logical :: as_albedo = .false.       ! ISALB -7, -8, -9: a LAMBERTIAN surface with the model's flux albedo at the
+                                         ! solar zenith angle (drt.f:478-484); the engine then sees ibdrf = 0
   end type
+
+  interface
+    function sbd_surface_flux_albedo(ibdrf, bpar, bitem, mu, albedo) bind(C, name='sbd_surface_flux_albedo') result(rc)
+      import
+      integer(c_int32_t), value :: ibdrf
+      real(c_double), intent(in) :: bpar(8), bitem(4)
+      real(c_double), value :: mu
+      real(c_double), intent(out) :: albedo
+      integer(c_int) :: rc
+    end function
+  end interface
 
 contains
 
@@ -30,7 +44,8 @@ contains
     real(kr), intent(in) :: sc(5)
     type(surface_model) :: s
     real(kr) :: cover
-    select case (isalb)
+    s%as_albedo = isalb < 0
+    select case (abs(isalb))
     case (7)                              ! SC = pigment, wind speed, salinity (suralb reads SC(3) as the salinity)
       s%ibdrf = 1
       s%pigment = sc(1)
@@ -43,6 +58,22 @@ contains
       s%ibdrf = 3
       s%par(1:5) = sc(1:5)
     end select
+  end function
+
+  ! DREF(mu): the model's flux albedo for incidence cosine mu -- the engine library's host-side integral over the
+  ! model functions the device uses (sbd_surface_flux_albedo; disort.f:5178-5284)
+  real(kr) function flux_albedo(s, bitem, mu) result(a)
+    type(surface_model), intent(in) :: s
+    real(kr), intent(in) :: bitem(4), mu
+    real(c_double) :: par(8), bit(4), val
+    integer(c_int) :: rc
+    par = s%par; bit = bitem
+    rc = sbd_surface_flux_albedo(int(s%ibdrf, c_int32_t), par, bit, real(mu, c_double), val)
+    if (rc /= 0) then
+      write(0, '(a)') 'sbdart_amd: DREF--input argument error(s)'     ! (disort.f:5262: the sun below the horizon)
+      stop 1
+    end if
+    a = val
   end function
 
   ! nr, ni of the water and the sub-surface reflectance rsw at wavelength wl (um); seabdrf hands the pigment

@@ -167,6 +167,11 @@ VARIANTS = [
     "idatm=2 isat=0 wlinf=.3 wlsup=4.2 wlinc=.3 isalb=7 sc=0,12,30,0 nstr=8 iout=10 sza=60",
     "idatm=4 isat=0 wlinf=.5 wlsup=.9 wlinc=.2 isalb=8 sc=0.6,0.3,0.4,0.1 nstr=8 iout=21 nzen=5 uzen=100,180 nphi=3 phi=0,180 sza=40",
     "idatm=4 isat=0 wlinf=.6 wlsup=.6 isalb=9 sc=0.08,0.03,0.0005,1.0,2.0 nstr=4 iout=10 sza=70",
+    # ... and the Lambertian surfaces with those models' flux albedo at the solar zenith angle (ISALB -7, -8, -9:
+    # DREF per wavelength, drt.f:478-484; the engine library integrates it on the host)
+    "idatm=4 isat=0 wlinf=.35 wlsup=.9 wlinc=.05 isalb=-7 sc=0.5,7,34.3,0 nstr=8 iout=10 sza=40",
+    "idatm=4 isat=0 wlinf=.5 wlsup=.9 wlinc=.2 isalb=-8 sc=0.6,0.3,0.4,0.1 nstr=8 iout=1 sza=25",
+    "idatm=4 isat=0 wlinf=.6 wlsup=.8 wlinc=.1 isalb=-9 sc=0.08,0.03,0.0005,1.0,2.0 nstr=4 iout=10 sza=70",
 ]
 
 
@@ -299,8 +304,7 @@ def test_corint_history(tmp_path):
 
 @needs_host
 def test_runs_outside_the_slice_are_refused_by_name(tmp_path):
-    for namelist, word in (("isalb=-8 sc=.6,.3,.4,.1", "surface"),
-                           ("kdist=-1", "CKATM")):                     # (no k-distribution file pair in the directory)
+    for namelist, word in (("kdist=-1", "CKATM"),):                     # (no k-distribution file pair in the directory)
         d = str(tmp_path / word)
         os.makedirs(d)
         with open(os.path.join(d, "INPUT"), "w") as f:
