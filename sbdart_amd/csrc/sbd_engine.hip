@@ -667,7 +667,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->band_lds = (int)sizeof(double) * bl.total;
     const sbd::SolveLds sl(n, nn, L);
     e->solve_lds = (int)sizeof(double) * sl.total;
-    e->usr_lds = (int)sizeof(double) * (nn + 2);
+    e->usr_lds = (int)(sizeof(double) * (nn + 2) + sizeof(int) * ((size_t)e->nlev * (numu > 0 ? numu : 1) + 2));   // dfu + the active-item list
     if (e->layer_lds > 160 * 1024 || e->band_lds > 160 * 1024 || e->solve_lds > 160 * 1024) {
         sbd_engine_destroy(e);
         return fail(SBD_E_UNSUPPORTED, "LDS footprint exceeds 160 KiB for this NSTR/NLYR");

@@ -105,25 +105,103 @@ __global__ void __launch_bounds__(64) usrint_kernel(Params P)
     }
 
     const double lh = SBD_F32(0.0001), eps6 = SBD_F32(1.0e-6);
-    for (int item = lane; item < nlev * numu; item += 64) {
-        const int li = item / numu, iu = item % numu + 1;
-        const int lev = P.all_levels ? li : P.t.level_out[li];
-        const int lyu = layru[lev];
+    // 1 / x to working precision: hardware seed + two Newton steps (the IEEE division sequence is a third of this
+    // kernel's instructions; the quotients only enter sums that are gated at 5e-6 of the column maximum)
+    auto rcp = [](double x) -> double {
+        double r = __builtin_amdgcn_rcp(x);
+        r = r * (2.0 - x * r);
+        return r * (2.0 - x * r);
+    };
+    // The layer-and-stream sums of one (level, angle) item.  An item is ACTIVE when its path crosses at least one
+    // whole layer or a part of its own (looking down from the top level, up from the bottom level ... are not: only
+    // the boundary term is left).  With IOUT's usual level pair half of the items are inactive and a lane per item
+    // leaves two thirds of the wave idle through the long loop: the active items are listed, and S = 1, 2, 4 or 8 lanes
+    // share one item, each taking nn / S streams of either half (S divides nn, S x active items <= 64); slice 0 also
+    // carries the beam and thermal terms; the partial sums meet on the DPP network.  (The sums over layers and
+    // streams therefore do not run in the reference's order any more: intensities are gated by tolerance.)
+    int *alist = (int *)(smem + nn + 2);                 // [nlev * numu] active items, compacted in item order
+    const int nitem = nlev * numu;
+    auto geometry = [&](const int item, int &lev, int &lyu, int &iu, bool &dark) {
+        const int li = item / numu;
+        iu = item % numu + 1;
+        lev = P.all_levels ? li : P.t.level_out[li];
+        lyu = layru[lev];
+        dark = lyrcut && lyu > ncut;
+    };
+    int nactive = 0;
+    for (int base = 0; base < nitem; base += 64) {
+        const int item = base + lane;
+        bool act = false;
+        if (item < nitem) {
+            int lev, lyu, iu;
+            bool dark;
+            geometry(item, lev, lyu, iu, dark);
+            if (!dark) {
+                const double um = umu[iu - 1], up = utaupr[lev];
+                const bool negumu = um < 0.0;
+                const bool whole = negumu ? (lyu - 1 >= 1) : (lyu + 1 <= ncut);
+                const bool skip = (fabs(up - taucpr[lyu - 1]) < eps6 && negumu) || (fabs(up - taucpr[lyu]) < eps6 && !negumu);
+                act = whole || !skip;
+            }
+        }
+        const unsigned long long m = __ballot(act);
+        if (act) alist[nactive + __popcll(m & ((1ull << lane) - 1ull))] = item;
+        nactive += __popcll(m);
+    }
+    wave_lds_sync();
+    int S = 1;
+    while (S < 8 && 2 * S * nactive <= 64 && nn % (2 * S) == 0) S *= 2;
+    const int per_round = 64 / S, sl = lane % S, nq = nn / S;
+    // ---- inactive items: the boundary term alone ----
+    auto boundary = [&](const int iu, const double um, const double up, const bool negumu) -> double {
+        if (negumu && mazim == 0) return (P.fisot + tplank) * exp(up / um);
+        if (!negumu && has_surface && brdf) {
+            double bnddfu = 0.0;
+            for (int iq = nn; iq >= 1; --iq)
+                bnddfu = bnddfu + (1.0 + delm0) * SBD_RMU(rmut, iu, nn + 1 - iq) * cmu[nn - iq] * cwt[nn - iq] * dfu[iq - 1];
+            double bnddir = 0.0;
+            if (beam) bnddir = umu0 * fbeam / pi * SBD_RMU(rmut, iu, 0) * expbea[L];
+            return (bnddfu + bnddir + delm0 * emut[iu - 1] * bplank) * exp((up - taucpr[L]) / um);
+        }
+        if (!negumu && has_surface) return bndsrf * exp((up - taucpr[L]) / um);
+        return 0.0;
+    };
+    for (int item = lane; item < nitem; item += 64) {
+        int lev, lyu, iu;
+        bool dark;
+        geometry(item, lev, lyu, iu, dark);
         double result = 0.0;
-        if (!(lyrcut && lyu > ncut)) {
+        if (!dark) {
             const double um = umu[iu - 1];
-            const double up = utaupr[lev];
-            const bool negumu = um < 0.0;
-            const double exp0 = beam ? exp(-up / umu0) : 0.0;
-            int lyrstr, lyrend;
-            double sgn;
-            if (negumu) { lyrstr = 1; lyrend = lyu - 1; sgn = -1.0; }
-            else { lyrstr = lyu + 1; lyrend = ncut; sgn = 1.0; }
-            double palint = 0.0, plkint = 0.0, exp1 = 0.0, exp2 = 0.0, denom, expn;
-            for (int lc = lyrstr; lc <= lyrend; ++lc) {
-                const double dtau = dtaucp[lc - 1];
-                exp1 = exp((up - taucpr[lc - 1]) / um);
-                exp2 = exp((up - taucpr[lc]) / um);
+            result = boundary(iu, um, utaupr[lev], um < 0.0);     // (active items: overwritten below, same wave, in order)
+        }
+        uum[(size_t)(item / numu) * numu + (iu - 1)] = result;
+    }
+    // ---- active items, S lanes each ----
+    for (int base = 0; base < nactive; base += per_round) {
+        const int ai = base + lane / S;
+        const bool live = ai < nactive;
+        const int item = alist[live ? ai : 0];
+        int lev, lyu, iu;
+        bool dark;
+        geometry(item, lev, lyu, iu, dark);
+        const double um = umu[iu - 1];
+        const double up = utaupr[lev];
+        const bool negumu = um < 0.0;
+        const double exp0 = beam ? exp(-up / umu0) : 0.0;
+        const double rum = rcp(um);
+        int lyrstr, lyrend;
+        double sgn;
+        if (negumu) { lyrstr = 1; lyrend = lyu - 1; sgn = -1.0; }
+        else { lyrstr = lyu + 1; lyrend = ncut; sgn = 1.0; }
+        if (!live) lyrend = lyrstr - 1;
+        const int q0 = sl * nq;                           // this lane's streams: q0+1 .. q0+nq of either half
+        double palint = 0.0, plkint = 0.0, exp1 = 0.0, exp2 = 0.0, denom, expn;
+        for (int lc = lyrstr; lc <= lyrend; ++lc) {
+            const double dtau = dtaucp[lc - 1];
+            exp1 = exp((up - taucpr[lc - 1]) * rum);
+            exp2 = exp((up - taucpr[lc]) * rum);
+            if (sl == 0) {
                 if (therm) {
                     const double f0n = sgn * (exp1 - exp2);
                     const double f1n = sgn * ((taucpr[lc - 1] + um) * exp1 - (taucpr[lc] + um) * exp2);
@@ -135,72 +213,63 @@ __global__ void __launch_bounds__(64) usrint_kernel(Params P)
                     else expn = (exp1 * expbea[lc - 1] - exp2 * expbea[lc]) * sgn / denom;
                     palint = palint + ZB(iu, lc) * expn;
                 }
-                for (int iq = 1; iq <= nn; ++iq) {   // KK negative
-                    denom = 1.0 + um * KK(iq, lc);
-                    if (fabs(denom) < lh) expn = dtau / um * exp2;
-                    else expn = sgn * (exp1 * EK(iq, lc) - exp2) / denom;
-                    palint = palint + (GU(iu, iq, lc) * LL(iq, lc)) * expn;
-                }
-                for (int iq = nn + 1; iq <= n; ++iq) {   // KK positive
-                    denom = 1.0 + um * KK(iq, lc);
-                    if (fabs(denom) < lh) expn = -dtau / um * exp1;
-                    else expn = sgn * (exp1 - exp2 * EK(n + 1 - iq, lc)) / denom;
-                    palint = palint + (GU(iu, iq, lc) * LL(iq, lc)) * expn;
-                }
             }
-            // from the output level to the adjacent computational level
-            const double dtau1 = up - taucpr[lyu - 1];
-            const double dtau2 = up - taucpr[lyu];
-            const bool skip = (fabs(dtau1) < eps6 && negumu) || (fabs(dtau2) < eps6 && !negumu);
-            if (!skip) {
-                if (negumu) exp1 = exp(dtau1 / um);
-                else exp2 = exp(dtau2 / um);
-                if (beam) {
-                    denom = 1.0 + um / umu0;
-                    if (fabs(denom) < lh) expn = (dtau1 / umu0) * exp0;
-                    else if (negumu) expn = (exp0 - expbea[lyu - 1] * exp1) / denom;
-                    else expn = (exp0 - expbea[lyu] * exp2) / denom;
-                    palint = palint + ZB(iu, lyu) * expn;
-                }
-                const double dtau = dtaucp[lyu - 1];
-                for (int iq = 1; iq <= nn; ++iq) {
-                    const double kq = KK(iq, lyu);
-                    denom = 1.0 + um * kq;
-                    if (fabs(denom) < lh) expn = -dtau2 / um * exp2;
-                    else if (negumu) expn = (exp(-kq * dtau2) - exp(kq * dtau) * exp1) / denom;
-                    else expn = (exp(-kq * dtau2) - exp2) / denom;
-                    palint = palint + (GU(iu, iq, lyu) * LL(iq, lyu)) * expn;
-                }
-                for (int iq = nn + 1; iq <= n; ++iq) {
-                    const double kq = KK(iq, lyu);
-                    denom = 1.0 + um * kq;
-                    if (fabs(denom) < lh) expn = -dtau1 / um * exp1;
-                    else if (negumu) expn = (exp(-kq * dtau1) - exp1) / denom;
-                    else expn = (exp(-kq * dtau1) - exp(-kq * dtau) * exp2) / denom;
-                    palint = palint + (GU(iu, iq, lyu) * LL(iq, lyu)) * expn;
-                }
-                if (therm) {
-                    double fact;
-                    if (negumu) { expn = exp1; fact = taucpr[lyu - 1] + um; }
-                    else { expn = exp2; fact = taucpr[lyu] + um; }
-                    const double f0n = 1.0 - expn;
-                    const double f1n = up + um - fact * expn;
-                    plkint = plkint + Z0U(iu, lyu) * f0n + Z1U(iu, lyu) * f1n;
-                }
+            for (int iq = q0 + 1; iq <= q0 + nq; ++iq) {   // KK negative
+                denom = 1.0 + um * KK(iq, lc);
+                if (fabs(denom) < lh) expn = dtau * rum * exp2;
+                else expn = sgn * (exp1 * EK(iq, lc) - exp2) * rcp(denom);
+                palint = palint + (GU(iu, iq, lc) * LL(iq, lc)) * expn;
             }
-            double bndint = 0.0;
-            if (negumu && mazim == 0) bndint = (P.fisot + tplank) * exp(up / um);
-            else if (!negumu && has_surface && brdf) {
-                double bnddfu = 0.0;
-                for (int iq = nn; iq >= 1; --iq)
-                    bnddfu = bnddfu + (1.0 + delm0) * SBD_RMU(rmut, iu, nn + 1 - iq) * cmu[nn - iq] * cwt[nn - iq] * dfu[iq - 1];
-                double bnddir = 0.0;
-                if (beam) bnddir = umu0 * fbeam / pi * SBD_RMU(rmut, iu, 0) * expbea[L];
-                bndint = (bnddfu + bnddir + delm0 * emut[iu - 1] * bplank) * exp((up - taucpr[L]) / um);
-            } else if (!negumu && has_surface) bndint = bndsrf * exp((up - taucpr[L]) / um);
-            result = palint + plkint + bndint;
+            for (int iq = nn + q0 + 1; iq <= nn + q0 + nq; ++iq) {   // KK positive
+                denom = 1.0 + um * KK(iq, lc);
+                if (fabs(denom) < lh) expn = -dtau * rum * exp1;
+                else expn = sgn * (exp1 - exp2 * EK(n + 1 - iq, lc)) * rcp(denom);
+                palint = palint + (GU(iu, iq, lc) * LL(iq, lc)) * expn;
+            }
         }
-        uum[(size_t)li * numu + (iu - 1)] = result;
+        // from the output level to the adjacent computational level
+        const double dtau1 = up - taucpr[lyu - 1];
+        const double dtau2 = up - taucpr[lyu];
+        const bool skip = !live || (fabs(dtau1) < eps6 && negumu) || (fabs(dtau2) < eps6 && !negumu);
+        if (!skip) {
+            if (negumu) exp1 = exp(dtau1 * rum);
+            else exp2 = exp(dtau2 * rum);
+            if (beam && sl == 0) {
+                denom = 1.0 + um / umu0;
+                if (fabs(denom) < lh) expn = (dtau1 / umu0) * exp0;
+                else if (negumu) expn = (exp0 - expbea[lyu - 1] * exp1) / denom;
+                else expn = (exp0 - expbea[lyu] * exp2) / denom;
+                palint = palint + ZB(iu, lyu) * expn;
+            }
+            const double dtau = dtaucp[lyu - 1];
+            for (int iq = q0 + 1; iq <= q0 + nq; ++iq) {
+                const double kq = KK(iq, lyu);
+                denom = 1.0 + um * kq;
+                if (fabs(denom) < lh) expn = -dtau2 * rum * exp2;
+                else if (negumu) expn = (exp(-kq * dtau2) - exp(kq * dtau) * exp1) * rcp(denom);
+                else expn = (exp(-kq * dtau2) - exp2) * rcp(denom);
+                palint = palint + (GU(iu, iq, lyu) * LL(iq, lyu)) * expn;
+            }
+            for (int iq = nn + q0 + 1; iq <= nn + q0 + nq; ++iq) {
+                const double kq = KK(iq, lyu);
+                denom = 1.0 + um * kq;
+                if (fabs(denom) < lh) expn = -dtau1 * rum * exp1;
+                else if (negumu) expn = (exp(-kq * dtau1) - exp1) * rcp(denom);
+                else expn = (exp(-kq * dtau1) - exp(-kq * dtau) * exp2) * rcp(denom);
+                palint = palint + (GU(iu, iq, lyu) * LL(iq, lyu)) * expn;
+            }
+            if (therm && sl == 0) {
+                double fact;
+                if (negumu) { expn = exp1; fact = taucpr[lyu - 1] + um; }
+                else { expn = exp2; fact = taucpr[lyu] + um; }
+                const double f0n = 1.0 - expn;
+                const double f1n = up + um - fact * expn;
+                plkint = plkint + Z0U(iu, lyu) * f0n + Z1U(iu, lyu) * f1n;
+            }
+        }
+        double part = palint + plkint;
+        for (int d = 1; d < S; d <<= 1) part = part + __shfl_xor(part, d, 64);
+        if (live && sl == 0) uum[(size_t)(item / numu) * numu + (iu - 1)] = part + boundary(iu, um, up, negumu);
     }
 #undef GC
 #undef KK
