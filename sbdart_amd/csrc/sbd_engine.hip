@@ -1037,12 +1037,11 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
                 const int gpb2 = 64 / e->G2;
                 const unsigned g2 = (unsigned)(((size_t)ns * L + gpb2 - 1) / gpb2) * (unsigned)nmode;
                 sbd::launch_layer2(e->nn, rad && !e->quad, g2, e->layer2_lds, st, P, eigflag);
-                flt = eigflag;          // the QR kernel below only redoes the listed layers: a fixed grid of one-group
-                grid = (unsigned)(groups < 8192 ? groups : 8192);   // blocks walks the list (normally empty: every block
-                                                  // reads the count and leaves).  With 256 four-group blocks a batch
-                                                  // with 1 % of its layers listed (thermal runs with conservative cloud
-                                                  // layers) spent more time here than in the fast kernel: 5 632 layers
-                                                  // in 5.5 rounds of 0.13 ms (tools/fallback_probe.py)
+                flt = eigflag;          // the QR kernel below only redoes the listed layers: a fixed grid walks the
+                if (grid > 2048u) grid = 2048u;   // list (normally empty: every block reads the count and leaves).  With
+                                                  // 256 blocks a batch with 1 % of its layers listed (thermal runs with
+                                                  // conservative cloud layers) spent more time here than in the fast
+                                                  // kernel: 5 632 layers in 5.5 rounds of 0.13 ms (tools/fallback_probe.py)
                 SBD_DBG("layer2");
             }
             sbd::launch_layer_v1(e->G, grid, e->layer_lds, st, P, flt);

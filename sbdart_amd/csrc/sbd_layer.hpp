@@ -127,16 +127,17 @@ SBD_DEVICE double lu_solve_group(const double *a, int ld, int n, const int *ipvt
 }
 
 // LIST = true: the form that walks layer_kernel2's list.  Normally the list is empty and the kernel only stands between
-// layer_kernel2 and the band kernel of its stream -- but a block of four groups asked for 30 KB of LDS and 256 VGPRs,
-// and on a chip filled by the OTHER stream's kernels (three 160-VGPR waves or two 256-VGPR waves per SIMD) such a
-// block waits until half a SIMD drains: the empty kernel held its stream for 0.25 - 0.7 ms per pass (rocprofv3 time
-// line of the host entry point).  Hence: ONE group per block (G threads, a quarter of the LDS) under a 168-VGPR cap (three waves per SIMD), so
-// that a block fits wherever any wave of the neighbours retires.
+// layer_kernel2 and the band kernel of its stream -- but its blocks asked for 256 VGPRs, and on a chip filled by the
+// OTHER stream's kernels (three 160-VGPR waves or two 256-VGPR waves per SIMD) such a wave waits until half a SIMD
+// drains: the empty kernel held its stream for 0.25 - 0.7 ms per pass (rocprofv3 time line of the host entry point).
+// Hence a 168-VGPR cap (three waves per SIMD): a block fits wherever ONE wave of the neighbours retires.  (LDS was
+// not the obstacle: 30 KB per block of four groups is free beside either neighbour.  One group per block placed as
+// easily but walked a long list with a quarter of the lanes: +11 % on a batch with 1 % of its layers listed.)
 template <int G, bool LIST = false>
 __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32_t *only_flagged)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int GPB = LIST ? 1 : 64 / G;
+    constexpr int GPB = 64 / G;
     const int lane = threadIdx.x;
     const int g = lane % G;
     const int gi = lane / G;

@@ -8,11 +8,20 @@ from collections import defaultdict
 
 root, out, solves_per_launch = sys.argv[1], sys.argv[2], int(sys.argv[3])
 nstr, nlyr = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (16, 33)
-acc = defaultdict(lambda: defaultdict(list))
+# only the launches at the bench's own launch size (the kernel's largest grid in the run: the host entry point's
+# passes, measured in the same command, are smaller)
+rows = []
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
-            acc[row["Kernel_Name"].split("(")[0].strip()][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            rows.append((row["Kernel_Name"].split("(")[0].strip(), row["Counter_Name"], int(row["Grid_Size"]), float(row["Counter_Value"])))
+gmax = defaultdict(int)
+for k, c, g, v in rows:
+    gmax[k] = max(gmax[k], g)
+acc = defaultdict(lambda: defaultdict(list))
+for k, c, g, v in rows:
+    if g == gmax[k]:
+        acc[k][c].append(v)
 res = {"solves_per_launch": solves_per_launch, "nstr": nstr, "nlyr": nlyr, "note": "FETCH_SIZE doubled (gfx950 64B-per-128B tally); KB*1024", "kernels": {}}
 for k, d in acc.items():
     if "sbd::" not in k:

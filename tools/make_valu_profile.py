@@ -7,13 +7,22 @@ from collections import defaultdict
 
 root, out, solves_per_launch = sys.argv[1], sys.argv[2], int(sys.argv[3])
 nstr, nlyr = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (16, 33)
-acc = defaultdict(list)
+# only the launches at the bench's own launch size (the kernel's largest grid in the run: the host entry point's
+# passes, measured in the same command, are smaller)
+rows = []
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if row["Counter_Name"] == "SQ_INSTS_VALU":
-            acc[row["Kernel_Name"].split("(")[0].strip()].append(float(row["Counter_Value"]))
+            rows.append((row["Kernel_Name"].split("(")[0].strip(), int(row["Grid_Size"]), float(row["Counter_Value"])))
+gmax = defaultdict(int)
+for k, g, v in rows:
+    gmax[k] = max(gmax[k], g)
+acc = defaultdict(list)
+for k, g, v in rows:
+    if g == gmax[k]:
+        acc[k].append(v)
 res = {"solves_per_launch": solves_per_launch, "nstr": nstr, "nlyr": nlyr,
-       "note": "SQ_INSTS_VALU summed over the dispatch (all SEs), averaged over the launches of the run", "kernels": {}}
+       "note": "SQ_INSTS_VALU summed over the dispatch (all SEs), averaged over the launches at the bench's launch size", "kernels": {}}
 for k, v in acc.items():
     if "sbd::" not in k:
         continue
