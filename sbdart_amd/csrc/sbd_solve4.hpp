@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(64, 2) backsolve4_kernel(Params P)
     static_for<n>([&](auto jj) { load_row(ncut, jj, u0[decltype(jj)::value], u1[decltype(jj)::value]); });
     double yq = yv[(ncut - 1) * n + cq];
     double xn = 0.0;                                 // x of the layer below (none below the last)
+    int ol_scan = nlev - 1;                          // all levels: the lowest level not yet evaluated
     for (int lc = ncut; lc >= 1; --lc) {
         const int lcp = (lc > 1) ? lc - 1 : 1;       // the layer whose rows are fetched meanwhile
         double xq = 0.0;
@@ -116,7 +117,17 @@ __global__ void __launch_bounds__(64, 2) backsolve4_kernel(Params P)
         if (col) ll[(lc - 1) * n + q] = xq;           // LL(j, lc) = B((lc-1)*n + j) (disort.f:3624-3633)
         // ---- FLUXES (mode 0) at the output levels that lie in this layer ----
         if (mazim == 0) {
-            for (int ol = 0; ol < nlev; ++ol) {
+            // (all levels: LAYRU does not decrease with the level, so the levels of layer lc are the next ones down from
+            //  where layer lc+1 stopped -- scanning every level for every layer cost as much as the solve itself:
+            //  NLYR x (NLYR+1) tests per system)
+            int ol_lo = 0, ol_hi = nlev - 1;
+            if (P.all_levels) {
+                while (ol_scan >= 0 && layru[ol_scan] > lc) --ol_scan;
+                ol_hi = ol_scan;
+                while (ol_scan >= 0 && layru[ol_scan] == lc) --ol_scan;
+                ol_lo = ol_scan + 1;
+            }
+            for (int ol = ol_lo; ol <= ol_hi; ++ol) {
                 const int lev = P.all_levels ? ol : P.t.level_out[ol];
                 if (layru[lev] != lc) continue;
                 // U0C(iq) = sum_j GC(iq,j) LL(j) E(j) + ZZ(iq) e^{-tau'/mu0} + ZPLK0 + ZPLK1 tau' (disort.f:1945-1960),
