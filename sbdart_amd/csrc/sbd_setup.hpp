@@ -135,8 +135,38 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
     if (err) atomicOr(&s_err, 1);
     __syncthreads();
 
-    // ---- serial prefix pass (lane 0): TAUC, delta-M optical depth, NCUT ----
-    if (lane == 0) {
+    // ---- serial prefix pass: TAUC, delta-M optical depth, NCUT.  The sums run in the reference's order (a scan would
+    //      round differently), but not on one lane fetching its operands from LDS -- three dependent LDS round trips
+    //      per layer were most of this kernel's life: every lane walks the chain on wave-uniform operands (v_readlane
+    //      from the lanes that loaded them) and keeps the partial sums of its own level ----
+    if (L <= 64) {
+        const int lc_mine = (lane < L) ? lane : 0;
+        const double w_mine = s_w[lc_mine], f_mine = s_f[lc_mine], dtraw_mine = s_dt[lc_mine];
+        double tauc = 0.0, taucpr = 0.0, abstau = 0.0, yessct = 0.0;
+        double tauc_me = 0.0, taucpr_me = 0.0;            // TAUC(lane), TAUCPR(lane): lane <-> level
+        int ncut = L;
+        for (int lc = 0; lc < L; ++lc) {
+            const double w = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(w_mine), lc), __builtin_amdgcn_readlane(__double2loint(w_mine), lc));
+            const double f = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(f_mine), lc), __builtin_amdgcn_readlane(__double2loint(f_mine), lc));
+            const double dr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dtraw_mine), lc), __builtin_amdgcn_readlane(__double2loint(dtraw_mine), lc));
+            tauc = tauc + dr;
+            const double dt = (dr < 0.0) ? 0.0 : dr;               // CHEKIN clamp (disort.f:4944)
+            yessct += w;
+            if (abstau < 10.0) ncut = lc + 1;                      // ABSCUT (disort.f:2561)
+            abstau = abstau + (1.0 - w) * dt;
+            taucpr = taucpr + (1.0 - f * w) * dt;                  // disort.f:2579
+            if (lane == lc + 1) { tauc_me = tauc; taucpr_me = taucpr; }
+        }
+        if (lane <= L) { s_tauc[lane] = tauc_me; s_taucpr[lane] = taucpr_me; }
+        if (lane < L) s_dt[lane] = (dtraw_mine < 0.0) ? 0.0 : dtraw_mine;
+        if (L == 64 && lane == 0) { s_tauc[64] = tauc; s_taucpr[64] = taucpr; }   // (level 64 has no lane)
+        if (lane == 0) {
+            const int lyrcut = (abstau >= 10.0 && !plank && !P.ibcnd && L > 1) ? 1 : 0;   // disort.f:2602-2603
+            s_ncut = lyrcut ? ncut : L;
+            s_lyrcut = lyrcut;
+            if (yessct > 0.0 && nmom < n) s_err = 1;                     // disort.f:4966
+        }
+    } else if (lane == 0) {
         double tauc = 0.0, taucpr = 0.0, abstau = 0.0, yessct = 0.0;
         int ncut = L;
         s_tauc[0] = 0.0;
@@ -181,10 +211,15 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
         sv[o.expbea() + lev] = eb;
         // USRTAU = .FALSE.: UTAU(lev+1) = TAUC(lev) (disort.f:2524-2529); LAYRU/UTAUPR (2610-2627)
         const double ut = s_tauc[lev];
-        int lc;
-        for (lc = 1; lc <= L; ++lc)
-            if (ut >= s_tauc[lc - 1] && ut <= s_tauc[lc]) break;
-        if (lc > L) lc = L;
+        // (the first layer, counted from the top, that holds the level -- LAYRU's search -- found from the level's own
+        //  index downwards: TAUC does not decrease, so only layers of zero depth above the level can come first)
+        int lc = (lev < 1) ? 1 : lev;
+        while (lc > 1 && s_tauc[lc - 1] >= ut) --lc;
+        if (!(ut >= s_tauc[lc - 1] && ut <= s_tauc[lc])) {       // (negative optical depths: the literal search)
+            for (lc = 1; lc <= L; ++lc)
+                if (ut >= s_tauc[lc - 1] && ut <= s_tauc[lc]) break;
+            if (lc > L) lc = L;
+        }
         sv[o.utau() + lev] = ut;
         sv[o.utaupr() + lev] = s_taucpr[lc - 1] + (1.0 - s_w[lc - 1] * s_f[lc - 1]) * (ut - s_tauc[lc - 1]);
         svi[SBD_SVI_LAYRU + lev] = lc;
