@@ -1040,6 +1040,20 @@ static double dref(const sbdo_in *in, const double *gmu, const double *gwt, doub
 }
 
 
+/* DREF(WVNMLO, WVNMHI, MU) by itself (disort.f:5178-5284): what drt.f:478-484 asks for with ISALB -7, -8, -9 */
+double sbdo_dref(int ibdrf, const double *bpar, const double *bitem, double mu)
+{
+    sbdo_in in;
+    memset(&in, 0, sizeof in);
+    in.ibdrf = ibdrf;
+    for (int k = 0; k < 8; ++k) in.bpar[k] = bpar[k];
+    for (int k = 0; k < 4; ++k) in.bitem[k] = bitem ? bitem[k] : 0.0;
+    double gmu50[50], gwt50[50];
+    sbdo_qgausn(25, gmu50, gwt50);
+    for (int k = 0; k < 25; ++k) { gmu50[k + 25] = -gmu50[k]; gwt50[k + 25] = gwt50[k]; }
+    return dref(&in, gmu50, gwt50, sbdo_pi(), mu);
+}
+
 /* SOLEIG (disort.f:3099-3320).  cc, evecc are (n x n); amb, apb, array are
  * (nn x nn); eval [nn]; wkd [n]. Returns IER from ASYMTX. */
 static int soleig(work_t *w, int lc, int mazim, double *amb, double *apb, double *array,

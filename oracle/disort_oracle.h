@@ -87,6 +87,7 @@ void   sbdo_sgesl(const double *a, int lda, int n, const int *ipvt, double *b);
 double sbdo_sgeco(double *a, int lda, int n, int *ipvt, double *z);
 
 /* reference constants (fp32 literals widened to fp64) */
+double sbdo_dref(int ibdrf, const double *bpar, const double *bitem, double mu);   /* disort.f:5178-5284 */
 double sbdo_pi(void);      /* 2.*ASIN(1.0) in fp32 = 3.14159274101257324 (disort.f:441) */
 double sbdo_dither(void);  /* 100*2^-52 (disort.f:442-448) */
 

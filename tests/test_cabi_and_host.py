@@ -81,3 +81,37 @@ def test_shard_range_partitions():
             for r in range(world):
                 L.sbd_shard_range(nwl, world, r, C.byref(lo), C.byref(hi))
                 assert (lo.value, hi.value) == parts[r]
+
+
+def test_flux_albedo_of_the_surface_models_on_the_host():
+    """sbd_surface_flux_albedo (DREF, disort.f:5178-5284: what drt.f:478-484 needs for ISALB -7, -8, -9) runs on the
+    host with the device's model functions: against the oracle's DREF for the three models over the incidence cosines,
+    and the reference's argument check."""
+    import ctypes as C
+    import pyoracle
+    from sbdart_amd import _lib
+    L = _lib.load()
+    L.sbd_surface_flux_albedo.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]
+    L.sbd_surface_flux_albedo.restype = C.c_int
+    O = pyoracle.lib()
+    O.sbdo_dref.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]
+    O.sbdo_dref.restype = C.c_double
+    cover = 2.951e-6 * 7.0 ** 3.52
+    models = [(1, [7.0, cover, cover * 0.22, 0.5, 34.3, 0, 0, 0], [1.34, 1.2e-8, 0.03, 0.0]),
+              (2, [0.6, 0.3, 0.4, 0.1, 0, 0, 0, 0], None),
+              (3, [0.08, 0.03, 0.0005, 1.0, 2.0, 0, 0, 0], None)]
+    worst = 0.0
+    for ibdrf, bpar, bitem in models:
+        bp = (C.c_double * 8)(*bpar)
+        bi = (C.c_double * 4)(*bitem) if bitem else None
+        for mu in (0.0, 0.01, 0.3, 0.7660444431, 1.0):
+            out = C.c_double(0.0)
+            assert L.sbd_surface_flux_albedo(ibdrf, bp, bi, mu, C.byref(out)) == _lib.OK
+            want = O.sbdo_dref(ibdrf, bp, bi, mu)
+            assert 0.0 <= want <= 1.0
+            worst = max(worst, abs(out.value - want) / max(abs(want), 1e-300))
+            assert abs(out.value - want) <= 1e-13 * max(abs(want), 1e-3), (ibdrf, mu, out.value, want)
+        out = C.c_double(0.0)
+        assert L.sbd_surface_flux_albedo(ibdrf, bp, bi, 1.5, C.byref(out)) != _lib.OK        # DREF--input argument error(s)
+    assert L.sbd_surface_flux_albedo(1, (C.c_double * 8)(*models[0][1]), None, 0.5, C.byref(C.c_double())) != _lib.OK
+    print("worst relative difference from the oracle's DREF: %.2e" % worst)
