@@ -8,14 +8,12 @@
 // and factors it in place.  Here the matrix is never materialised: partial-pivot LU only
 // ever touches rows k..k+NCD and columns k..k+2*NCD, so the wave keeps exactly that sliding
 // window on chip.  NSTR is a template parameter, so the window geometry is compile time.
-// Two homes for the window:
-//   * band_kernel<NN, true>  (NSTR <= 20): in REGISTERS, a column per lane -- see the block
-//     comment at "register-resident window" below;
-//   * band_kernel<NN, false> (NSTR > 20): in LDS -- rows without wrap-around in RW+MARGIN
-//     physical rows (re-based every MARGIN steps) so that the rank-1 update addresses them
-//     with immediate offsets, columns on a ring of CW positions, the pivot row kept in
-//     registers, the right-hand side of the window rows beside it.
-// Common to both: rows enter from the matrix-ready interface blocks ga/gb the layer kernel
+// The window lives in LDS -- rows without wrap-around in RW+MARGIN physical rows (re-based every MARGIN steps) so that
+// the rank-1 update addresses them with immediate offsets, columns on a ring of CW positions, the pivot row kept in
+// registers, the right-hand side of the window rows beside it.  (Round 1's second home, a register window for
+// NSTR <= 20, went when band4_kernel / band1_kernel took NSTR <= 32: it was only reachable through a developer switch.)
+// This kernel serves NSTR 34..40, and every NSTR under SBD_BAND_V1=1 as the cross-check of the block-form kernels.
+// Rows enter from the matrix-ready interface blocks ga/gb the layer kernel
 // wrote (unit stride, prefetched U steps ahead); the pivot search is a DPP max-scan plus a
 // ballot; multipliers come from the registers of the pivot search and are applied to the
 // right-hand side at once (L is never stored); only the rows with a non-zero multiplier
@@ -228,7 +226,7 @@ SBD_DEVICE void update_shift(double (&a)[RW], double t, double mlo, double mhi)
     });
 }
 
-template <int NN, bool REG>
+template <int NN, bool REG = false>   // (REG: always false since round 3)
 __global__ void __launch_bounds__(64) band_kernel(Params P)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -399,215 +397,6 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         return g * f;
     };
 
-    if constexpr (REG) {
-        // ================= register-resident window (NSTR <= 20) =================
-        // The window never touches LDS: lane l < 63 owns the column j == l (mod 63) and keeps
-        // its RW window rows in registers (a[i] = A(k+i, j)); lane 63 carries the right-hand
-        // side as one more column, so interchange and elimination treat it like the rest
-        // (SGBSL's forward sweep, disutil.f:1019-1036).  One step: the pivot column crosses
-        // to "lane t <-> row k+t" through RW doubles of LDS for the DPP pivot search; the pivot
-        // row is taken out of its register (row k's old content takes its place: LINPACK's
-        // interchange), retired to U in HBM, and rows 1.. slide down one register inside the
-        // elimination FMAs whose multipliers arrive through SGPRs.  A column's lane is reused
-        // 63 - CW steps after it left the window and is cleared in between.
-        static_assert(!REG || (2 * (3 * NN - 1) + 1) <= 59, "register variant: window must fit 63 lanes");
-        constexpr int RING = 63;
-        constexpr int ZPER = ((RING - CW) / 4) * 4;      // clearing period of idle lanes (steps)
-        double *tcol = smem + lds.win;                   // [RW] pivot column, transposed
-        double a[RW];
-#pragma unroll
-        for (int i = 0; i < RW; ++i) a[i] = 0.0;
-        int status = 0;
-        int km = 1 % RING;                               // k mod RING
-        const bool rhs = lane == 63;
-        // interface row r (nn < r <= N-nn) for the lane's column when k = kfirst: ONE load per
-        // lane whatever it carries (the right-hand side, the layer-lc block or the layer-lc+1
-        // block) and no other memory operation, so that nothing waits on it before its use
-        auto elem_fast = [&](int r, int kmr, int kfirst, unsigned long long &vmask) -> double {
-            int c = lane - kmr;
-            if (c < 0) c += RING;
-            const int col = kfirst + c;
-            const int qq = r - nn - 1;
-            const int d = col - (qq / n) * n;                    // 1..2n inside the row's support
-            const bool valid = rhs || (c < CW && col <= N && d >= 1 && d <= 2 * n);
-            const double *p = rhs ? yv + (r - 1)
-                                  : (d <= n ? ga_ms + ((size_t)qq * n + d - 1) : gb_ms + ((size_t)qq * n + d - n - 1));
-            vmask = __ballot(valid);
-            return *(valid ? p : yv);                            // every lane loads (a safe address when it has no element)
-        };
-        auto elem_for = [&](int r, int kmr, int kfirst) -> double {   // any row (boundary rows included)
-            if (r > N) return 0.0;
-            if (r > nn && r <= N - nn) {
-                unsigned long long vm;
-                const double g = elem_fast(r, kmr, kfirst, vm);
-                return ((vm >> lane) & 1ull) ? g : 0.0;
-            }
-            if (rhs) return yv[r - 1];
-            int c = lane - kmr;
-            if (c < 0) c += RING;
-            return (c < CW) ? row_elem(r, kfirst + c) : 0.0;
-        };
-        // rows 1..RW enter through the same shift register, PB rows per batch of loads
-        {
-            constexpr int PB = 6;
-            for (int r0 = 1; r0 <= RW; r0 += PB) {
-                double tmp[PB];
-#pragma unroll
-                for (int j = 0; j < PB; ++j) tmp[j] = (r0 + j <= RW) ? elem_for(r0 + j, km, 1) : 0.0;
-#pragma unroll
-                for (int j = 0; j < PB; ++j) {
-                    if (r0 + j <= RW) {
-                        static_for<RW - 1>([&](auto ii) { constexpr int i = decltype(ii)::value; a[i] = a[i + 1]; });
-                        a[RW - 1] = tmp[j];
-                    }
-                }
-            }
-        }
-        constexpr int U = 4;
-        double pre[U];
-        unsigned long long pmask[U];                     // lanes whose prefetched value is an element (else 0)
-        // steady-state form of elem_fast: the lane's column under the mapping of step k1 is carried
-        // along (it only changes when the lane is handed the next column, 63 further on)
-        int kmp = 0, colp = 0;                           // k1 mod 63 and the lane's column for the next fast load
-        auto elem_next = [&](int r, int k1, unsigned long long &vmask) -> double {
-            const int qq = r - nn - 1;
-            const int lcn = (qq / n) * n;                        // first column of the row's support - 1
-            const int d = colp - lcn;                            // 1..2n inside the row's support
-            const int lim = (k1 + CW < N + 1) ? k1 + CW : N + 1;
-            const bool valid = rhs || ((unsigned)(d - 1) < (unsigned)(2 * n) && colp < lim);
-            const int ix = qq * n - lcn - 1 + colp;              // index into the layer-lc block
-            const double *p = rhs ? yv + (r - 1) : (d <= n ? ga_ms + ix : gb_ms + (ix - n));
-            vmask = __ballot(valid);
-            const double g = *(valid ? p : yv);
-            if (lane == kmp) colp += RING;                       // this lane's column leaves at step k1
-            kmp = (kmp + 1 == RING) ? 0 : kmp + 1;
-            return g;
-        };
-        auto load_row = [&](int r, double &g, unsigned long long &vm, auto fast) {   // row r enters at the end of step r - RW
-            const int k1 = r - RW + 1;
-            if constexpr (decltype(fast)::value) g = elem_next(r, k1, vm);
-            else { g = elem_for(r, k1 % RING, k1); vm = ~0ull; }
-        };
-#pragma unroll
-        for (int u = 0; u < U; ++u) load_row(RW + 1 + u, pre[u], pmask[u], std::false_type{});
-        auto step = [&](const int k, double &pq, unsigned long long &pm, auto fast) {
-            const int lm = (ncd < N - k) ? ncd : N - k;
-            // (A) pivot column -> lanes (lane t <-> row k+t)
-            if (lane == km) {                            // (ds_write2_b64: any two registers per instruction)
-                const unsigned ta = lds_addr(tcol);
-                write_pairs<0>(ta, a);
-                if constexpr (RW & 1) tcol[RW - 1] = a[RW - 1];
-            }
-            wave_lds_sync();
-            // every row of 16 lanes reads the whole column (q = lane % 16: entries q and 16+q)
-            const int q16 = lane & 15;
-            double ak_lo = 0.0, ak_hi = 0.0;
-            if (q16 <= lm) ak_lo = tcol[q16];
-            if (16 + q16 <= lm) ak_hi = tcol[16 + q16];
-            const double ak = (lane < 16) ? ak_lo : ((lane < 32) ? ak_hi : 0.0);   // lane t <-> row k+t
-            double rk = __builtin_amdgcn_rcp(ak);        // -1/a for every candidate (v_rcp + 2 Newton steps)
-            rk = rk * (2.0 - ak * rk);
-            rk = rk * (2.0 - ak * rk);
-            rk = -rk;
-            // (B) ISAMAX's first-maximum rule on the DPP network
-            const int idx = wave_first_max<false>(ak, lm);
-            auto pick = [&](double x, int src) {
-                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src),
-                                        __builtin_amdgcn_readlane(__double2loint(x), src));
-            };
-            const double piv = pick(ak, idx), tsel = pick(rk, idx);
-            const double akk = bcast_lane<0>(ak);
-            if (piv == 0.0) status |= 0x01;
-            const double tinv = (piv != 0.0) ? tsel : 0.0;
-            // (C) multipliers -a/pivot (after the interchange), lane t holds the one of row k+t
-            double mlo = 0.0, mhi = 0.0;                 // m(q), m(16+q) in every row of lanes
-            if (q16 >= 1 && q16 <= lm) mlo = ((q16 == idx) ? akk : ak_lo) * tinv;
-            if (16 + q16 <= lm) mhi = ((16 + q16 == idx) ? akk : ak_hi) * tinv;
-            const double mreg = (lane < 16) ? mlo : ((lane < 32) ? mhi : 0.0);
-            // (D) pivot row out of its register, old row k into that register
-            double tj;
-            take_row<0, RW - 1>(a, idx, tj);
-            // (E) U(k, k..k+2ncd) row-major to HBM; forward-eliminated B(k)
-            {
-                int c = lane - km;
-                if (c < 0) c += RING;
-                const int wmax = (UW - 1 < N - k) ? UW - 1 : N - k;
-                if (!rhs && c <= wmax) ufac[(size_t)(k - 1) * UW + c] = tj;
-                if (rhs) yv[k - 1] = tj;
-            }
-            // (F) elimination + slide: a[i-1] = a[i] + tj * m(i) for the rows with a non-zero
-            //     multiplier (structural zeros below the next interface), plain moves beyond
-            const unsigned long long nzm = __ballot(mreg != 0.0);
-            const int lme = nzm ? 63 - __clzll((long long)nzm) : 0;
-            {
-                constexpr int D = (2 * NN + 3) / 4;
-                if (lme > ncd - D) update_shift<ncd>(a, tj, mlo, mhi);
-                else if (lme > ncd - 2 * D) update_shift<ncd - D>(a, tj, mlo, mhi);
-                else if (lme > ncd - 3 * D) update_shift<ncd - 2 * D>(a, tj, mlo, mhi);
-                else if (lme > 0) update_shift<ncd - 3 * D>(a, tj, mlo, mhi);
-                else update_shift<0>(a, tj, mlo, mhi);
-            }
-            // (G) the entering row takes the last register.  An explicit move: the prefetched
-            //     value keeps a register of its own for the whole loop, so the only wait for its
-            //     load sits here, U steps after the issue
-            asm volatile("v_mov_b64 %0, %1" : "=v"(a[RW - 1]) : "v"(pq));
-            if (!((pm >> lane) & 1ull)) a[RW - 1] = 0.0;
-            km = (km + 1 == RING) ? 0 : km + 1;
-            load_row(k + RW + U, pq, pm, fast);
-        };
-        // every load so far has landed before the loop: its waits then only count the loop's own
-        // loads (vmcnt(0), expcnt/lgkmcnt unconstrained)
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        int k = 1;
-        // steady state: whole groups of U steps whose entering rows are all interface rows (no
-        // exits and a single kind of load inside, so the loads stay in flight across steps)
-        const int kfast = N - nn - RW - U;               // last step whose load is an interface row
-        {                                                // mapping of the first fast load (step 1 loads row RW+1+U)
-            const int k1 = U + 2;
-            kmp = k1 % RING;
-            int c = lane - kmp;
-            if (c < 0) c += RING;
-            colp = k1 + c;
-        }
-        for (; k + U - 1 <= kfast; k += U) {
-            if (((k - 1) % ZPER) == 0) {                 // clear the lanes whose column has left the window
-                int c = lane - km;
-                if (c < 0) c += RING;
-                if (!rhs && c >= CW) {
-#pragma unroll
-                    for (int i = 0; i < RW; ++i) a[i] = 0.0;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) step(k + u, pre[u], pmask[u], std::true_type{});
-        }
-        for (; k <= N - 1; ++k) {                        // the tail: boundary rows enter, then nothing
-            {
-                int c = lane - km;
-                if (c < 0) c += RING;
-                if (!rhs && c >= CW) {
-#pragma unroll
-                    for (int i = 0; i < RW; ++i) a[i] = 0.0;
-                }
-            }
-            step(k, pre[0], pmask[0], std::false_type{});   // consumes pre[0], reloads it for step k+U
-            const double newest = pre[0];
-            const unsigned long long newm = pmask[0];
-#pragma unroll
-            for (int u = 0; u + 1 < U; ++u) { pre[u] = pre[u + 1]; pmask[u] = pmask[u + 1]; }
-            pre[U - 1] = newest;
-            pmask[U - 1] = newm;
-        }
-        {   // last row
-            const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[0]), km),
-                                              __builtin_amdgcn_readlane(__double2loint(a[0]), km));
-            if (d == 0.0) status |= 0x01;
-            if (lane == km) ufac[(size_t)(N - 1) * UW] = a[0];
-            if (rhs) yv[N - 1] = a[0];
-        }
-        if (status && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], status);
-        return;
-    }
     // logical row k+i lives in physical row kq+i (kq = k - kbase < MARGIN, re-based every
     // MARGIN steps); column j sits at ring position j % CW, tracked by a wrap-around counter
     {

@@ -655,8 +655,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->G = G;
     const sbd::LayerLds ll(n, nn);
     e->layer_lds = (int)sizeof(double) * ll.total * (64 / G);
-    e->band_reg = nn <= 10;                       // register-resident LU window (sbd_band.hpp)
-    if (const char *s = getenv("SBD_BAND_LDS")) e->band_reg = e->band_reg && atoi(s) == 0;
+    e->band_reg = false;                          // (round 1's register-window LU is gone: LDS window, sbd_band.hpp)
     e->band4 = band4;
     e->band1 = band1;
     e->fused = fused;
@@ -1055,7 +1054,6 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
                 sbd::launch_band4_pivdbg(e->nn, (bgrid + 3) / 4, st, P);
             } else if (e->band4) sbd::launch_band4(e->nn, (bgrid + 3) / 4, st, P, e->fused);
             else if (e->band1) sbd::launch_band1(e->nn, bgrid, st, P, e->fused);
-            else if (e->band_reg) sbd::launch_band_reg(e->nn, bgrid, e->band_lds, st, P);
             else sbd::launch_band_lds(e->nn, bgrid, e->band_lds, st, P);
         }
         SBD_DBG("band");

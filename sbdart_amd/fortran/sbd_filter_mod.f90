@@ -17,40 +17,45 @@ module sbd_filter_mod
 
 contains
 
-  ! Solar zenith and azimuth angle (degrees) and the Earth-Sun distance factor 1/r^2 for day of year iday, UTC
-  ! hours `time`, latitude and longitude in degrees: equation of time and declination interpolated in a table of
-  ! five-day values, spherical triangle pole-observer-subsolar point (zensun, spectra.f:4440-4556)
+  ! Where the sun stands for an observer (zensun, spectra.f:4440-4556): zenith and azimuth angle in degrees and the
+  ! Earth-Sun distance factor 1/r^2 for day of year iday, UTC hours `time`, latitude and longitude in degrees.
+  ! Two points on the unit sphere -- the observer and the sub-solar point, each as (colatitude, longitude) -- and the
+  ! spherical triangle they form with the pole; the sub-solar point's declination and the equation of time come from
+  ! a table of five-day values.  (The sums keep the reference's operand order: the angles print to four digits, but
+  ! they also enter the band model's air masses, which are compared bit for bit.)
   subroutine solar_position(iday, time, alat, alon, zenith, azimuth, solfac)
     integer, intent(in) :: iday
     real(kr), intent(in) :: time, alat, alon
     real(kr), intent(out) :: zenith, azimuth, solfac
-    real(kr), parameter :: pi = 3.1415926536_kr, degpday = 360./365.242, eccen = 0.01671, dayph = 2.
-    real(kr), pointer :: eqt(:), dec(:)
-    real(kr) :: dtor, dd, frac, eqtime, decang, sunlon, t0, t1, p0, p1, zz, xx, yy, rsun
-    integer :: i, d0, d1
-    eqt => tbl('sun.eqt'); dec => tbl('sun.dec')
-    dtor = pi/180.
-    dd = mod(iday - 1, 365) + 1
-    i = 2                                            ! table days 1, 6, 11, ... 366: the first one beyond dd
-    do while (1 + 5*(i - 1) <= dd .and. i < 74)
-      i = i + 1
-    end do
-    d0 = 1 + 5*(i - 2); d1 = 1 + 5*(i - 1)
-    frac = (dd - d0)/(d1 - d0)
-    eqtime = eqt(i - 1)*(1. - frac) + frac*eqt(i)
-    decang = dec(i - 1)*(1. - frac) + frac*dec(i)
-    sunlon = -15.*(time - 12. + eqtime/60.)
-    t0 = (90. - alat)*dtor
-    t1 = (90. - decang)*dtor
-    p0 = alon*dtor
-    p1 = sunlon*dtor
-    zz = cos(t0)*cos(t1) + sin(t0)*sin(t1)*cos(p1 - p0)
-    xx = sin(t1)*sin(p1 - p0)
-    yy = sin(t0)*cos(t1) - cos(t0)*sin(t1)*cos(p1 - p0)
-    azimuth = atan2(xx, yy)/dtor
-    zenith = acos(zz)/dtor
-    rsun = 1. - eccen*cos(degpday*(dd - dayph)*dtor)
-    solfac = 1./rsun**2
+    real(kr), parameter :: pi = 3.1415926536_kr, rad = pi/180.
+    real(kr), parameter :: orbit_deg_per_day = 360./365.242, eccentricity = 0.01671, perihelion_day = 2.
+    real(kr) :: day, minutes_fast, declination, colat_obs, colat_sun, dlon, cosz, east, north, distance
+    day = mod(iday - 1, 365) + 1
+    minutes_fast = five_day_table(tbl('sun.eqt'), day)
+    declination = five_day_table(tbl('sun.dec'), day)
+    colat_obs = (90. - alat)*rad
+    colat_sun = (90. - declination)*rad
+    dlon = (-15.*(time - 12. + minutes_fast/60.))*rad - alon*rad          ! sub-solar longitude minus the observer's
+    cosz = cos(colat_obs)*cos(colat_sun) + sin(colat_obs)*sin(colat_sun)*cos(dlon)
+    east = sin(colat_sun)*sin(dlon)
+    north = sin(colat_obs)*cos(colat_sun) - cos(colat_obs)*sin(colat_sun)*cos(dlon)
+    azimuth = atan2(east, north)/rad
+    zenith = acos(cosz)/rad
+    distance = 1. - eccentricity*cos(orbit_deg_per_day*(day - perihelion_day)*rad)
+    solfac = 1./distance**2
+  contains
+    ! linear interpolation in a table whose entries stand for days 1, 6, 11, ... 366
+    real(kr) function five_day_table(tab, d) result(v)
+      real(kr), intent(in) :: tab(:), d
+      integer :: hi
+      real(kr) :: w
+      hi = 2
+      do while (1 + 5*(hi - 1) <= d .and. hi < 74)
+        hi = hi + 1
+      end do
+      w = (d - (1 + 5*(hi - 2)))/real(5, kr)
+      v = tab(hi - 1)*(1. - w) + w*tab(hi)
+    end function
   end subroutine
 
   ! two-column text file "wavelength value", at most nmax lines, returned in ascending wavelength

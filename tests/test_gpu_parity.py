@@ -414,9 +414,9 @@ def _alt_path_errors(**env):
 
 
 def test_lds_window_variant_matches():
-    """SBD_BAND_LDS=1 sends NSTR <= 20 through the LDS-window LU kernel (the one NSTR > 20 always
-    uses) instead of the register-window one: same answers."""
-    errs = _alt_path_errors(SBD_BAND_LDS="1")
+    """SBD_BAND_V1=1 sends every NSTR through the LDS-window LU kernel and the LDS-staged back-substitution (the
+    pair NSTR > 32 always uses) instead of the block-form kernels: same answers."""
+    errs = _alt_path_errors(SBD_BAND_V1="1")
     assert max(errs) < TOL, max(errs)
 
 
