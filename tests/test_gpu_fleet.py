@@ -158,3 +158,33 @@ def test_moments_shared_by_the_k_terms_of_a_point():
     with DisortFleet(devices=[0, 0, 0], **kw) as fl:
         f4, _, s4, acc, _ = fl.solve(*ins(pm_pt), weight=sw.weight, pmom_row=rows)
     assert np.array_equal(f0, f4)
+
+
+def test_growing_passes_of_the_host_entry_point():
+    """With the moments shared per spectral point and 32 768 items or more, the host entry point starts with a pass of
+    8 192 items and grows the passes by 1.3 x (the first inputs cross PCIe sooner; sbd_engine.hip, solve_device_impl).
+    An item's result does not depend on the pass it rides in: bit for bit the answers of the device entry point (equal
+    passes) and of the host entry point with per-item moments (equal passes)."""
+    import torch
+    from sbdart_amd.engine import DisortEngine
+    from sbdart_amd.workload import sw_sweep
+    sw = sw_sweep(nwl=13000, nstr=8, nlyr=12, seed=23)
+    assert sw.nwork >= 32768
+    rows = sw.wl_of.astype(np.int32)
+    first = np.concatenate([[0], np.nonzero(np.diff(rows))[0] + 1])
+    pm_pt = np.ascontiguousarray(sw.pmom[first])
+    pm_full = pm_pt[rows]
+    kw = dict(nlyr=sw.nlyr, nstr=sw.nstr, nmom=sw.nmom, temper=sw.temper, umu0=sw.umu0, btemp=sw.btemp, ttemp=sw.ttemp,
+              temis=sw.temis, onlyfl=True, level_out=[0, sw.nlyr])
+    with DisortEngine(device=0, **kw) as eng:
+        assert eng.chunk < sw.nwork or sw.nwork >= 32768
+        f_ramp, _, s_ramp = eng.solve(sw.dtauc, sw.ssalb, pm_pt, sw.wvnmlo, sw.wvnmhi, sw.fbeam, sw.albedo, sw.plank, pmom_row=rows)
+        f_host, _, s_host = eng.solve(sw.dtauc, sw.ssalb, pm_full, sw.wvnmlo, sw.wvnmhi, sw.fbeam, sw.albedo, sw.plank)
+        dev = torch.device("cuda:0")
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        f_dev, _, s_dev = eng.solve(t(sw.dtauc), t(sw.ssalb), t(pm_pt), t(sw.wvnmlo), t(sw.wvnmhi), t(sw.fbeam), t(sw.albedo),
+                                    t(sw.plank), pmom_row=t(rows))
+        torch.cuda.synchronize()
+    assert (s_ramp == 0).all()
+    assert np.array_equal(f_ramp, f_host) and np.array_equal(s_ramp, s_host)
+    assert np.array_equal(f_ramp, f_dev.cpu().numpy()) and np.array_equal(s_ramp, s_dev.cpu().numpy())
