@@ -210,9 +210,11 @@ int      sbd_host_alloc(size_t bytes, void **out);
 void     sbd_host_free(void *p);
 
 /* DREF (disort.f:5178-5284) on the host: flux albedo of the bidirectional surface model `ibdrf` (1 ocean, 2 Hapke,
- * 3 Ross-Li; bpar / bitem as in sbd_run_cfg / sbd_batch_in, bitem = NULL for 2 and 3) for incidence cosine mu in
- * [0,1].  What drt.f:478-484 calls per wavelength for ISALB -7, -8, -9 (a Lambertian surface with that albedo).
- * No GPU involved. */
+ * 3 Ross-Li; bpar / bitem as in sbd_run_cfg / sbd_batch_in, bitem = NULL for 2 and 3) for incidence cosine mu,
+ * |mu| <= 1 as in the reference (its driver passes cos(SZA) also when the sun is below the horizon).  What
+ * drt.f:478-484 calls per wavelength for ISALB -7, -8, -9 (a Lambertian surface with that albedo, clamped to [0,1]
+ * by the caller; the reference warns when the value lies outside) and what CHEKIN's test of a bidirectional surface
+ * prints (disort.f:5080-5096).  No GPU involved. */
 int      sbd_surface_flux_albedo(int32_t ibdrf, const double *bpar, const double *bitem, double mu, double *albedo);
 
 /* ---- introspection ---- */

@@ -752,7 +752,8 @@ int sbd_surface_flux_albedo(int32_t ibdrf, const double *bpar, const double *bit
 {
     if (!bpar || !albedo || ibdrf < 1 || ibdrf > 3) return fail(SBD_E_INVALID, "sbd_surface_flux_albedo: model 1..3, bpar, albedo");
     if (ibdrf == 1 && !bitem) return fail(SBD_E_INVALID, "sbd_surface_flux_albedo: the ocean needs bitem");
-    if (!(mu >= 0.0 && mu <= 1.0)) return fail(SBD_E_INVALID, "DREF--input argument error(s)");   // disort.f:5262
+    if (!(fabs(mu) <= 1.0)) return fail(SBD_E_INVALID, "DREF--input argument error(s)");   // disort.f:5262: ABS(MU) > 1 only --
+    // a cosine below zero (the sun under the horizon: drt.f hands cos(SZA) over as it is) goes through the model functions
     constexpr int NG = sbd::kSurfGauss;
     static double gmu[NG], gwt[NG];
     static std::once_flag once;

@@ -425,8 +425,14 @@ contains
         rsfc = 0.                                                 ! (LAMBER off: DISORT never reads ALBEDO)
         ! the ocean's water constants at BDREF's wavelength, the middle of the band in wavenumber (spectra.f:284)
         if (surf%ibdrf == 1) call ocean_constants(surf, 20000./(wvhi + wvlo), sbit(1, iw), sbit(2, iw), sbit(3, iw))
-        if (surf%as_albedo) then                                  ! ISALB -7, -8, -9 (drt.f:478-484)
-          rsfc = max(0._kr, min(flux_albedo(surf, sbit(:, iw), amu0), 1._kr))
+        if (surf%as_albedo) then                                  ! ISALB -7, -8, -9 (drt.f:478-484): DREF at cos(SZA) as it
+          rsfc = flux_albedo(surf, sbit(:, iw), amu0)             ! is, also below the horizon; DREF warns outside [0,1]
+          if (rsfc < 0._kr .or. rsfc > 1._kr) then                ! (disort.f:5279-5280), the driver clamps
+            !$omp critical (sbd_surface_warning)
+            call warn_file(8, 'DREF--albedo value not in (0,1)')
+            !$omp end critical (sbd_surface_warning)
+          end if
+          rsfc = max(0._kr, min(rsfc, 1._kr))
           sbit(:, iw) = 0.
         end if
       else if (wl < wlalb(1) .or. wl > wlalb(size(wlalb))) then   ! (writes the reference's warning file: one at a time)

@@ -69,8 +69,8 @@ contains
     integer(c_int) :: rc
     par = s%par; bit = bitem
     rc = sbd_surface_flux_albedo(int(s%ibdrf, c_int32_t), par, bit, real(mu, c_double), val)
-    if (rc /= 0) then
-      write(0, '(a)') 'sbdart_amd: DREF--input argument error(s)'     ! (disort.f:5262: the sun below the horizon)
+    if (rc /= 0) then                                ! (disort.f:5262: |mu| > 1 -- cannot happen with a cosine)
+      write(0, '(a)') 'sbdart_amd: DREF--input argument error(s)'
       stop 1
     end if
     a = val

@@ -70,7 +70,7 @@ program sbdart_amd
   integer(c_int32_t), allocatable, target :: status(:), level_out(:)
   integer, allocatable :: order(:), where_solved(:)
   real(kr), allocatable :: zlev(:), plev(:)
-  integer :: stall
+  integer :: stall, fatal_at
   type(model_input) :: model
   type(sensor_filter) :: sensor
   type(atmosphere) :: atm
@@ -335,7 +335,23 @@ program sbdart_amd
   do i = 1, npart
     stall = ior(stall, status(i))
   end do
-  if (iand(stall, SBD_ST_ERR_INPUT) /= 0) call warn_file(0, 'DISORT--input and/or dimension errors')
+  ! (input errors: the reference stops INSIDE the DISORT call that finds them -- what it printed for the wavelengths
+  !  before stays on stdout.  With a bidirectional surface CHEKIN also reports the offending cosines there; that case
+  !  is replayed in order below, at the record where it happens)
+  fatal_at = 0
+  if (iand(stall, SBD_ST_ERR_INPUT) /= 0) then
+    do i = 1, nrec
+      ip = where_solved(i)
+      if (ip > 0) then
+        if (iand(status(ip), SBD_ST_ERR_INPUT) /= 0) then
+          fatal_at = i
+          exit
+        end if
+      end if
+    end do
+    if (fatal_at == 0) call warn_file(0, 'DISORT--input and/or dimension errors')
+    if (recs(fatal_at)%ibdrf == 0) call warn_file(0, 'DISORT--input and/or dimension errors')
+  end if
   if (iand(stall, SBD_ST_ERR_EIGEN) /= 0) call warn_file(0, 'ASYMTX--convergence problems')
   if (iand(stall, SBD_ST_WARN_SOLVE0) /= 0) call warn_file(2, 'SOLVE0--SGBCO says matrix near singular')
   if (iand(stall, SBD_ST_WARN_UPBEAM) /= 0) call warn_file(3, 'UPBEAM--SGECO says matrix near singular')
@@ -382,6 +398,7 @@ program sbdart_amd
         if (recs(i1)%kd == recs(i1)%nk .and. recs(i1)%ib == 1) exit
         i1 = i1 + 1
       end do
+      if (fatal_at >= i0 .and. fatal_at <= i1) call brdf_input_stop(fatal_at)
       call sums_clear(sums)
       sums%width_eq = 0; sums%width_full = 0
       do i = i0, i1
@@ -403,6 +420,7 @@ program sbdart_amd
     !  the association of the sums, hence their last bits, follows the part split and the number of GPUs.
     !  SBD_ORDERED_SUMS=1 adds the per-item outputs here instead, in the reference's wavelength order
     !  (drt.f:964-1054): bit-reproducible on any number of devices)
+    if (fatal_at > 0) call brdf_input_stop(fatal_at)
     call get_environment_variable('SBD_ORDERED_SUMS', path, plen, pstat)
     if (pstat == 0 .and. plen > 0 .and. path(1:1) /= '0') then
       do i = 1, nrec
@@ -622,6 +640,28 @@ contains
     nfleet = nfleet + 1
     fleets(nfleet) = fl; fleet_ns(nfleet) = ns; fleet_corr(nfleet) = corr; fleet_rc(nfleet) = rc
   end function
+
+  ! CHEKIN's report on a bidirectional surface whose flux albedo leaves [0,1] (disort.f:5080-5096: 101 incidence
+  ! cosines, one line pair per offender, on stdout before the fatal message) for record k, then the fatal stop: the
+  ! engine flags the item, the lines come from the same integral on the host (sbd_surface_flux_albedo)
+  subroutine brdf_input_stop(k)
+    use sbd_surface_mod, only: surface_model, flux_albedo
+    integer, intent(in) :: k
+    type(surface_model) :: sm
+    integer :: irmu
+    real(kr) :: rmu, flxalb
+    sm%ibdrf = recs(k)%ibdrf; sm%par = recs(k)%bpar
+    do irmu = 0, 100
+      rmu = real(irmu*0.01, kr)                         ! (IRMU*0.01 in default real, as the reference types it)
+      flxalb = flux_albedo(sm, recs(k)%bitem, rmu)
+      if (flxalb < 0._kr .or. flxalb > 1._kr) then
+        call warn_file(8, 'DREF--albedo value not in (0,1)')
+        print '(a,2es11.3)', 'mu, flxalb: ', rmu, flxalb
+        write(*, '(3a)') ' ****  Input variable  ', 'FUNCTION BDREF', '  in error  ****'
+      end if
+    end do
+    call warn_file(0, 'DISORT--input and/or dimension errors')
+  end subroutine
 
   subroutine release_fleets()
     integer :: k

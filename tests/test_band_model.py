@@ -172,6 +172,11 @@ VARIANTS = [
     "idatm=4 isat=0 wlinf=.35 wlsup=.9 wlinc=.05 isalb=-7 sc=0.5,7,34.3,0 nstr=8 iout=10 sza=40",
     "idatm=4 isat=0 wlinf=.5 wlsup=.9 wlinc=.2 isalb=-8 sc=0.6,0.3,0.4,0.1 nstr=8 iout=1 sza=25",
     "idatm=4 isat=0 wlinf=.6 wlsup=.8 wlinc=.1 isalb=-9 sc=0.08,0.03,0.0005,1.0,2.0 nstr=4 iout=10 sza=70",
+    # ... with the sun below and on the horizon: drt.f hands cos(SZA) to DREF as it is (found by the end-to-end fuzz)
+    "idatm=4 wlinf=1 wlsup=1 sza=95 nf=0 isalb=-8 sc=0.8,0.3,0.4,0.1 iout=10 nstr=4",
+    "idatm=2 wlinf=8 wlsup=8 sza=89.995 kdist=3 isalb=-8 sc=0.4,0.1,0,0.1 iout=7 nstr=8",
+    "idatm=2 wlinf=5 wlsup=10 wlinc=20 iday=355 time=22.5 alat=0 alon=0 isalb=-9 sc=0.05,0.03,0.002,1.0,2.0 iout=1 nstr=16",
+    "idatm=3 wlinf=.5 wlsup=.7 wlinc=.1 sza=100 isalb=-7 sc=1,12,34.3,0 iout=10 nstr=4",
 ]
 
 

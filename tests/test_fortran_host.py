@@ -395,7 +395,10 @@ def test_device_list_and_ordered_sums(tmp_path):
     "idatm=2 isat=0 wlinf=3.7 wlsup=3.9 wlinc=.1 isalb=7 sc=1.0,10,34.3,0 nstr=12 iout=11 sza=55 tcloud=1 zcloud=3",
     "idatm=4 isat=0 wlinf=.4 wlsup=.9 wlinc=.1 isalb=-7 sc=0.1,5,34.3,0 nstr=8 iout=10 sza=40",
     "idatm=4 isat=0 wlinf=.5 wlsup=.9 wlinc=.2 isalb=-9 sc=0.08,0.03,0.0005,1.0,2.0 nstr=8 iout=1 sza=30",
-], ids=["ocean_radiance", "hapke_radiance_down", "rossli_flux", "ocean_thermal_profile", "ocean_flux_albedo", "rossli_flux_albedo"])
+    "idatm=4 wlinf=1 wlsup=1 sza=95 nf=0 isalb=-8 sc=0.8,0.3,0.4,0.1 iout=10 nstr=4",
+    "idatm=3 wlinf=12.6 wlsup=13.2 wlinc=.2 sza=30 isalb=7 sc=1,12,34.3,0 iout=1 nstr=4",
+], ids=["ocean_radiance", "hapke_radiance_down", "rossli_flux", "ocean_thermal_profile", "ocean_flux_albedo", "rossli_flux_albedo",
+        "hapke_flux_albedo_at_night", "ocean_fails_chekin"])
 def test_bidirectional_surfaces_from_input_alone(tmp_path, namelist):
     """ISALB 7, 8, 9 end to end: INPUT -> the host's band model (surface parameters, the ocean's water constants) ->
     SURFAC on the device, the BRDF branches of the band kernels and of USRINT -> the reference's stdout."""
