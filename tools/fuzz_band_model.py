@@ -42,7 +42,10 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
         p.append(pick("iaer=%d vis=%g"%(pick(1,2,3,4),pick(5,23,60)), "iaer=%d tbaer=%g rhaer=%g"%(pick(1,2,3,4),pick(.05,.5),pick(.3,.75,.9,.99))))
         if random.random()<.3: p.append("nosct=%d"%pick(1,3))
     if random.random()<.2: p.append("jaer=%d zaer=%g taerst=%g"%(pick(1,2,3,4),pick(15,22),pick(.01,.1)))
-    if random.random()<.5: p.append(pick("albcon=%g"%pick(0,.3,.9),"isalb=%d"%pick(1,2,3,4,5,6),"isalb=10 sc=.25,.25,.25,.25"))
+    if random.random()<.5: p.append(pick("albcon=%g"%pick(0,.3,.9),"isalb=%d"%pick(1,2,3,4,5,6),"isalb=10 sc=.25,.25,.25,.25",
+                                         "isalb=%d sc=%g,%g,34.3,0"%(pick(7,-7),pick(0,.1,1.),pick(2,7,12)),
+                                         "isalb=%d sc=%g,%g,%g,%g"%(pick(8,-8),pick(.4,.6,.8),pick(.1,.3),pick(0,.4),pick(.05,.1)),
+                                         "isalb=%d sc=%g,%g,%g,1.0,2.0"%(pick(9,-9),pick(.05,.08,.2),pick(.01,.03),pick(.0005,.002))))
     if aerfile is None and random.random()<.25: p.append("ngrid=%d zgrid1=%g zgrid2=%g"%(pick(20,40,65),pick(.5,1,2),pick(10,30)))
     if random.random()<.2: p.append("nothrm=%d"%pick(0,1))
     if random.random()<.2: p.append("xrsc=%g"%pick(0,.5,2))
