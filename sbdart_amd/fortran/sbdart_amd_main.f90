@@ -320,10 +320,16 @@ program sbdart_amd
   !      coincides with a quadrature angle makes DISORT ask for another stream count, drt.f:536-555),
   !      the beamless items with the stream count as given ----
   call system_clock(tick1)
-  call solve_part(1, ncorr, .true., corint)
-  call solve_part(ncorr + 1, nbeam, .true., .false.)
-  call solve_part(nbeam + 1, npart, .false., .false.)
-  call release_fleets()
+  ! (IBCND = 1 in &DINPUT: the reference hands it to DISORT, which then returns the medium's albedo and
+  !  transmissivity in two arguments SBDART never looks at and leaves every flux and intensity at zero
+  !  (disort.f:545-556) -- the run prints zeros; so does this one, without a solve.  The engine offers the
+  !  mode itself through sbd_run_cfg::ibcnd.)
+  if (ibcnd /= 1) then
+    call solve_part(1, ncorr, .true., corint)
+    call solve_part(ncorr + 1, nbeam, .true., .false.)
+    call solve_part(nbeam + 1, npart, .false., .false.)
+    call release_fleets()
+  end if
   call system_clock(tick2)
   call get_environment_variable('SBD_TIMING', path, plen, pstat)
   if (pstat == 0 .and. plen > 0) write(0, '(a,f9.4,a,i0,a,f9.4,a)') 'sbdart_amd: batch assembly ', &

@@ -427,3 +427,21 @@ def test_k_distribution_files_end_to_end(tmp_path, namelist, from_input):
     write_ck_files(str(tmp_path))
     ref, got, _ = run_reference_and_host(namelist, str(tmp_path), from_input=from_input)
     _compare_stdout(got, ref)
+
+
+@needs_flang
+@needs_ref
+@pytest.mark.parametrize("namelist", [
+    "idatm=4 wlinf=.5 wlsup=.7 wlinc=.1 sza=30 iout=10 nstr=4",
+    "idatm=4 wlinf=.5 wlsup=.6 wlinc=.1 sza=30 iout=20 nstr=4 nzen=3 uzen=10,70 nphi=2 phi=0,90",
+    "idatm=4 wlinf=8 wlsup=9 wlinc=.5 sza=30 iout=11 nstr=4",
+    "idatm=2 wlinf=.4 wlsup=.5 wlinc=.05 sza=50 iout=1 nstr=8 tcloud=3 zcloud=2",
+])
+def test_ibcnd_in_dinput_prints_the_reference_zeros(tmp_path, namelist):
+    """IBCND = 1 in &DINPUT: the reference passes it on to DISORT, whose special case (ALBTRN, disort.f:545-556)
+    fills two arguments SBDART never reads and leaves every flux and intensity zero -- the run prints zeros.  The host
+    prints the same text without a solve (no GPU needed); the mode itself is the engine's sbd_run_cfg::ibcnd."""
+    _build()
+    ref, got, _ = run_reference_and_host(namelist + "\n /\n &DINPUT\n ibcnd=1", str(tmp_path), from_input=True)
+    assert got.split() == ref.split()
+    assert any(float(t) == 0.0 for t in ref.split() if t[0].isdigit() or t[0] == "-")
