@@ -81,20 +81,28 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
     if random.random()<.15: p.append("isat=%d"%pick(1,4,9,13,17,22,26))
     nl=" ".join(p)
     if random.random()<.3 and "iout=7" not in nl: nl += " zout=%g,%g"%(pick(0,1,3),pick(10,30,100))
+    if random.random()<.25:                       # DISORT's own namelist: boundary illumination and temperatures, beam azimuth
+        dp=[]
+        if random.random()<.4: dp.append("fisot=%g"%pick(.5,20.))
+        if random.random()<.4: dp.append("temis=%g ttemp=%g"%(pick(.3,1.),pick(200.,270.)))
+        if random.random()<.4: dp.append("btemp=%g"%pick(250.,300.,320.))
+        if random.random()<.4: dp.append("phi0=%g"%pick(30.,180.))
+        if dp: nl += "\n /\n &DINPUT\n " + " ".join(dp)
+    nlp = nl.replace("\n", " ")
     with tempfile.TemporaryDirectory() as d:
         try:
             ref, got, cap = run_reference_and_host(nl, d, from_input=True)
         except subprocess.CalledProcessError:
             continue                                   # the reference rejects this INPUT
         except AssertionError as e:
-            bad+=1; print("FAIL(host) ::",nl,"::",str(e)[:300]); continue
+            bad+=1; print("FAIL(host) ::",nlp,"::",str(e)[:300]); continue
         if not ref.split(): continue
         if "NaN" in ref.split():
-            print("skip (the reference prints NaN) ::", nl); continue
+            print("skip (the reference prints NaN) ::", nlp); continue
         try:
             off=_compare_stdout(got,ref)
             ntok+=len(ref.split())
-            print("ok %6d tokens, %d off by one unit :: %s"%(len(ref.split()),off,nl))
+            print("ok %6d tokens, %d off by one unit :: %s"%(len(ref.split()),off,nlp))
         except AssertionError as e:
             try:
                 sens = sensitivity(cap)
@@ -102,13 +110,13 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
                 sens = 0.0
                 print("(no sensitivity: %s)" % type(e2).__name__)
             if sens > 2e-6:
-                print("ill-conditioned (reference moves by %.1e under FMA contraction) ::" % sens, nl, "::", str(e)[:120])
+                print("ill-conditioned (reference moves by %.1e under FMA contraction) ::" % sens, nlp, "::", str(e)[:120])
             elif "iout=11" in nl and engine_error(cap) <= 5e-6:
                 # IOUT 11 prints the flux divergence and the heating rate (divergence / pressure): at the top of a finely
                 # regridded atmosphere a difference of 1e-9 of the fluxes is a printed digit of K/day.  The engine's own
                 # outputs are inside the parity gate on every record of the run.
-                print("cancellation in the printed flux divergence / heating rate (engine within 5e-6 on every record) ::", nl, "::", str(e)[:120])
+                print("cancellation in the printed flux divergence / heating rate (engine within 5e-6 on every record) ::", nlp, "::", str(e)[:120])
             else:
                 bad+=1
-                print("FAIL (sensitivity %.1e) ::" % sens, nl, "::", str(e)[:300])
+                print("FAIL (sensitivity %.1e) ::" % sens, nlp, "::", str(e)[:300])
 print("failures",bad,"tokens compared",ntok)
