@@ -88,8 +88,16 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
         if random.random()<.4: dp.append("btemp=%g"%pick(250.,300.,320.))
         if random.random()<.4: dp.append("phi0=%g"%pick(30.,180.))
         if dp: nl += "\n /\n &DINPUT\n " + " ".join(dp)
+    ck = random.random()<.08                       # KDIST = -1: gas depths from a synthetic CKATM / CKTAU pair in the run directory
+    if ck:
+        import re
+        nl = re.sub(r"(wlinf|wlsup|wlinc|kdist|nf|ngrid|zgrid1|zgrid2|isat)=\S+ ?", "", nl)
+        nl = "kdist=-1 wlinf=%g wlsup=%g %s"%(pick(.3,.4,.6),pick(.7,5,12),pick("","nf=-2","nf=1")) + " " + nl
     nlp = nl.replace("\n", " ")
     with tempfile.TemporaryDirectory() as d:
+        if ck:
+            from test_band_model import write_ck_files
+            write_ck_files(d, seed=random.randrange(1,1000), top_down=random.random()<.5)
         try:
             ref, got, cap = run_reference_and_host(nl, d, from_input=True)
         except subprocess.CalledProcessError:
