@@ -555,7 +555,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)2 * n * n : 0) + (size_t)L * n * 6 + (size_t)L * nn + (fused ? 0 : (size_t)L * n * (2 * n))
                                             + (rad_user ? (size_t)L * n * numu + 3 * (size_t)L * numu : 0) + (rad ? (size_t)e->nlev * numu : 0));
     const bool brdf = !cfg->lamber, brdf_item = brdf && cfg->ibdrf == 1;      // (the ocean's tables follow the wavelength)
-    const size_t surf_per_ms = sizeof(double) * ((size_t)nn * (nn + 1) + nn + (size_t)numu * (nn + 1) + numu + 4);
+    const size_t numu1 = numu > 0 ? (size_t)numu : 1;     // (a flux-only run still carves one row of RMU / EMU per item)
+    const size_t surf_per_ms = sizeof(double) * ((size_t)nn * (nn + 1) + nn + numu1 * (nn + 1) + numu1 + 4);
     const size_t per_slot = (per_ms + (brdf_item ? surf_per_ms : 0)) * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
     size_t budget = (size_t)64 << 30;   // of 288 GB: fewer, larger passes (launch tails cost ~7 % at 16k items)
     if (const char *s = getenv("SBD_WORKSPACE_MB")) budget = (size_t)atoll(s) << 20;

@@ -773,3 +773,42 @@ def test_ill_conditioned_records():
             seen = max(seen, sens)
             assert err <= max(TOL, 8.0 * sens), (i, f, err, sens)
     assert seen > 1e-5, seen                                            # (the fixture is still ill-conditioned)
+
+
+@pytest.mark.gpu
+def test_ocean_surface_flux_batch_of_hundreds():
+    """A flux-only run over an ocean surface with a few hundred work items (found by the end-to-end fuzz: the workspace
+    was sized without the one row of RMU / EMU the per-item surface tables carve when there are no user angles --
+    fine for the handful of items the other tests send, 'workspace carve overflow' from ~170 on).  Every item against
+    the oracle."""
+    import dataclasses
+    import pyoracle
+    from sbdart_amd.engine import solve_records
+    from sbdart_amd.records import F_ONLYFL, SolveRecord
+    rng = np.random.default_rng(9)
+    nstr, L, nmom = 16, 6, 16
+    wind = 7.0
+    cover = 2.951e-6 * wind ** 3.52
+    bpar = np.array([wind, cover, 0.22 * cover, 0.1, 34.3, 0, 0, 0])
+    g = rng.uniform(0.2, 0.8, L)
+    base = SolveRecord(nlyr=L, nstr=nstr, nmom=nmom, flags=F_ONLYFL, wvnmlo=15000.0, wvnmhi=15100.0, fbeam=1.0, umu0=0.6,
+                       phi0=0.0, albedo=0.0, btemp=290.0, ttemp=0.0, temis=0.0, dtauc=rng.uniform(0.02, 0.6, L),
+                       ssalb=rng.uniform(0.3, 0.99, L), temper=np.linspace(220.0, 290.0, L + 1),
+                       pmom=g[:, None] ** np.arange(nmom + 1)[None, :], umu=np.zeros(0), phi=np.zeros(0), ibdrf=1, bpar=bpar,
+                       bitem=np.array([1.34, 1.0e-8, 0.01, 0.0]))
+    recs = [dataclasses.replace(base, dtauc=base.dtauc * rng.uniform(0.5, 2.0), fbeam=float(rng.uniform(0.5, 2.0)),
+                                bitem=np.array([1.33 + 0.02 * rng.uniform(), 1e-8 * (1 + 9 * rng.uniform()), 0.02 * rng.uniform(), 0.0]))
+            for _ in range(400)]
+    flux, _, st = solve_records(recs)
+    assert all(s == 0 for s in st)
+    worst = 0.0
+    for i in range(0, len(recs), 7):
+        o = pyoracle.disort(recs[i])
+        assert o["status"] == 0
+        recmax = max(np.abs(o[f]).max() for f in FLUX)
+        for c, f in enumerate(FLUX):
+            scale = np.abs(o[f]).max()
+            err = np.abs(flux[i][c] - o[f][[0, -1]] if flux[i].shape[1] == 2 else flux[i][c] - o[f]).max()
+            worst = max(worst, err / max(scale, 1e-9 * recmax))
+            assert err <= TOL * scale + 1e-12 * recmax, (i, f, err, scale)
+    print(f"400 ocean items, worst error {worst:.2e} of the column maximum")

@@ -93,13 +93,26 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
         import re
         nl = re.sub(r"(wlinf|wlsup|wlinc|kdist|nf|ngrid|zgrid1|zgrid2|isat)=\S+ ?", "", nl)
         nl = "kdist=-1 wlinf=%g wlsup=%g %s"%(pick(.3,.4,.6),pick(.7,5,12),pick("","nf=-2","nf=1")) + " " + nl
+    files = None
+    if not ck and random.random()<.15:             # the user's data files in the run directory (same texts as tests/test_band_model.py)
+        import re
+        from test_band_model import USER_FILES
+        files = USER_FILES
+        kind = pick("isalb=-1", "idatm=0", "nf=-1", "isat=-1", "nre=0")
+        key = kind.split("=")[0]
+        head, sep, tail = nl.partition("\n")
+        head = re.sub(r"\b%s=\S+ ?" % key, "", head)
+        if key == "isalb": head = re.sub(r"\b(albcon|sc)=\S+ ?", "", head)
+        if key == "nre": head = re.sub(r"\b(tcloud|zcloud|lwp|rhcld|krhclr)=\S+ ?", "", head)
+        if key == "isat": head = re.sub(r"\b(wlinf|wlsup|wlinc)=\S+ ?", "", head) + " wlinc=.01"
+        nl = head.strip() + " " + kind + sep + tail
     nlp = nl.replace("\n", " ")
     with tempfile.TemporaryDirectory() as d:
         if ck:
             from test_band_model import write_ck_files
             write_ck_files(d, seed=random.randrange(1,1000), top_down=random.random()<.5)
         try:
-            ref, got, cap = run_reference_and_host(nl, d, from_input=True)
+            ref, got, cap = run_reference_and_host(nl, d, from_input=True, files=files)
         except subprocess.CalledProcessError:
             continue                                   # the reference rejects this INPUT
         except AssertionError as e:
