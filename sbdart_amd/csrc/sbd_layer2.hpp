@@ -436,10 +436,22 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
         // (only B's columns rotate: the eigenvectors follow from the converged columns and C afterwards)
         // |b_j|^2 of this lane's column, exact at the start of every sweep, carried through the rotations
         // (alpha' = alpha - t gamma, beta' = beta + t gamma): a meeting costs one inner product, not three
-        double nrm = 0.0;
-        auto meet = [&](const int partner, const bool valid, const double (&ob)[nn], const double bb) {
+        double nrm = 0.0, wsc = 1.0;
+        // Scaled rotations (the fast-Givens idea carried to one-sided Jacobi): lane j keeps its column as
+        // bcol = w_j^1/2 x (the true column) and the squared scale w_j beside it.  With a = |p|^2, b = |q|^2,
+        // g = p.q of the STORED columns, the pair is rotated as  p' = p - tau q,  q' = q + tau' p  with
+        //   e = w_p b - w_q a,  H = (e^2 + 4 g^2 w_p w_q)^1/2,  u = 2 g / (|e| + H),
+        //   tau = sign(e) u w_p,  tau' = sign(e) u w_q,   both scales x (1 + tau tau')  [tau tau' = tan^2],
+        // which is the exact rotation of the true pair (tan = tau (w_q / w_p)^1/2: the quadratic for tau has no
+        // square root of the scales in it) -- no c = (1 + t^2)^-1/2 (a v_rsq_f64 and two Newton steps per
+        // meeting), one FMA per element instead of a product and an FMA.  Whatever the rounding of u, the
+        // transformation stays orthogonal x diagonal to working precision: u only has to be close (one Newton
+        // step on the hardware seeds: the pair comes out orthogonal to ~1e-8 of what it was, the next sweep sees
+        // to the rest).  cos^2 = g^2 / (a b) does not see the scales; they leave once, after the last sweep.
+        // In both lanes of a pair the own coefficient is  -sign(w_own b_other - w_other a_own) u w_own.
+        auto meet = [&](const int partner, const bool valid, const double (&ob)[nn], const double bb, const double wb) {
             if (valid && !done) {
-                const double aa = nrm;
+                const double aa = nrm, wa = wsc;
                 double gg = 0.0;
 #pragma unroll
                 for (int i = 0; i < nn; ++i) gg = gg + bcol[i] * ob[i];
@@ -447,30 +459,28 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
                 if (g2 > tol * tol * ab) {           // |cos(angle)| > tol
                     rotated = true;
                     coarse = coarse || (g2 > 1.0e-13 * ab);   // ... > 3e-7
-                    const bool lo = j < partner;
-                    // rotation defined for the ordered pair (p<q): alpha=|b_p|^2, beta=|b_q|^2
-                    const double alpha = lo ? aa : bb, beta = lo ? bb : aa;
-                    // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (beta - alpha) / (2 gg), written
-                    // without zeta: t = sign(d) 2gg / (|d| + sqrt(d^2 + 4 gg^2)); c = (1 + t^2)^-1/2.
-                    // t only has to be close (one Newton step on the hardware seeds: the pair comes out
-                    // orthogonal to ~1e-8 of what it was, the next sweep sees to the rest); c and s = c t
-                    // must make a rotation to working precision (two steps)
-                    const double d = beta - alpha, tg = 2.0 * gg;
-                    const double h2 = d * d + tg * tg;
+                    const double e = wa * bb - wb * aa, ww = wa * wb, tg = 2.0 * gg;
+                    const double h2 = e * e + (tg * tg) * ww;
                     const double h = h2 * rsqrt_n1(h2);
-                    const double t = ((d >= 0.0) ? tg : -tg) * rcp_n1(fabs(d) + h);
-                    const double c = rsqrt_nr(1.0 + t * t), sn = c * t;
-                    // p' = c p - s q ; q' = s p + c q
-                    const double mine = c, other = lo ? -sn : sn;
+                    const double u = tg * rcp_n1(fabs(e) + h);
+                    const double q1 = 1.0 + (u * u) * ww;
+                    const double coef = ((e >= 0.0) ? -u : u) * wa;
 #pragma unroll
-                    for (int i = 0; i < nn; ++i) bcol[i] = mine * bcol[i] + other * ob[i];
-                    nrm = lo ? aa - t * gg : aa + t * gg;
+                    for (int i = 0; i < nn; ++i) bcol[i] = bcol[i] + coef * ob[i];
+                    nrm = q1 * (aa + coef * gg);
+                    wsc = wa * q1;
                 }
             }
         };
         for (int sweep = 0; sweep < 30; ++sweep) {
             rotated = false;
             coarse = false;          // some pair met in this sweep with |cos(angle)| > 3e-7
+            if (wsc > 0x1p+64) {             // (a scale doubles at most per meeting: rare; the lane's own business)
+                const double rs = rsqrt_nr(wsc);
+#pragma unroll
+                for (int i = 0; i < nn; ++i) bcol[i] = bcol[i] * rs;
+                wsc = 1.0;
+            }
             nrm = 0.0;
 #pragma unroll
             for (int i = 0; i < nn; ++i) nrm = nrm + bcol[i] * bcol[i];
@@ -483,7 +493,7 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
                     double ob[nn];
 #pragma unroll
                     for (int i = 0; i < nn; ++i) ob[i] = lane_xor<sx>(bcol[i]);
-                    meet(partner, (j < nn) && (partner < nn), ob, lane_xor<sx>(nrm));
+                    meet(partner, (j < nn) && (partner < nn), ob, lane_xor<sx>(nrm), lane_xor<sx>(wsc));
                 });
             } else {
                 for (int s = 0; s < NP - 1; ++s) {
@@ -495,7 +505,7 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
                     double ob[nn];
 #pragma unroll
                     for (int i = 0; i < nn; ++i) ob[i] = __shfl(bcol[i], src, G);
-                    meet(partner, (j < nn) && (partner < nn) && (j < NP), ob, __shfl(nrm, src, G));
+                    meet(partner, (j < nn) && (partner < nn) && (j < NP), ob, __shfl(nrm, src, G), __shfl(wsc, src, G));
                 }
             }
             // quadratic convergence: a sweep that started below 3e-7 ends below 1e-13 (eigenvalues to
@@ -509,6 +519,11 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
         if (!done) {   // 30 sweeps without convergence: the reference-algorithm kernel redoes this layer
             if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;
             return;
+        }
+        {   // the columns' scales leave: b' = B v with |v| = 1 from here on
+            const double rs = rsqrt_nr(wsc);
+#pragma unroll
+            for (int i = 0; i < nn; ++i) bcol[i] = bcol[i] * rs;
         }
     }
 

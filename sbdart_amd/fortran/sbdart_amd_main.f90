@@ -356,7 +356,6 @@ program sbdart_amd
       end if
     end do
     if (fatal_at == 0) call warn_file(0, 'DISORT--input and/or dimension errors')
-    if (recs(fatal_at)%ibdrf == 0) call warn_file(0, 'DISORT--input and/or dimension errors')
   end if
   if (iand(stall, SBD_ST_ERR_EIGEN) /= 0) call warn_file(0, 'ASYMTX--convergence problems')
   if (iand(stall, SBD_ST_WARN_SOLVE0) /= 0) call warn_file(2, 'SOLVE0--SGBCO says matrix near singular')
@@ -404,7 +403,7 @@ program sbdart_amd
         if (recs(i1)%kd == recs(i1)%nk .and. recs(i1)%ib == 1) exit
         i1 = i1 + 1
       end do
-      if (fatal_at >= i0 .and. fatal_at <= i1) call brdf_input_stop(fatal_at)
+      if (fatal_at >= i0 .and. fatal_at <= i1) call input_stop(fatal_at)
       call sums_clear(sums)
       sums%width_eq = 0; sums%width_full = 0
       do i = i0, i1
@@ -426,7 +425,7 @@ program sbdart_amd
     !  the association of the sums, hence their last bits, follows the part split and the number of GPUs.
     !  SBD_ORDERED_SUMS=1 adds the per-item outputs here instead, in the reference's wavelength order
     !  (drt.f:964-1054): bit-reproducible on any number of devices)
-    if (fatal_at > 0) call brdf_input_stop(fatal_at)
+    if (fatal_at > 0) call input_stop(fatal_at)
     call get_environment_variable('SBD_ORDERED_SUMS', path, plen, pstat)
     if (pstat == 0 .and. plen > 0 .and. path(1:1) /= '0') then
       do i = 1, nrec
@@ -650,12 +649,34 @@ contains
   ! CHEKIN's report on a bidirectional surface whose flux albedo leaves [0,1] (disort.f:5080-5096: 101 incidence
   ! cosines, one line pair per offender, on stdout before the fatal message) for record k, then the fatal stop: the
   ! engine flags the item, the lines come from the same integral on the host (sbd_surface_flux_albedo)
-  subroutine brdf_input_stop(k)
+  subroutine input_stop(k)
     use sbd_surface_mod, only: surface_model, flux_albedo
     integer, intent(in) :: k
     type(surface_model) :: sm
-    integer :: irmu
+    integer :: irmu, lc, km, ipk, row, nbad
     real(kr) :: rmu, flxalb
+    ! CHEKIN's reports on the layer arrays come first, in its order (disort.f:4947-4953: the albedo and its layer,
+    ! then the variable's name, per offending layer; disort.f:4975-4982: one line per offending moment; the 50th
+    ! line raises warning 12, disutil.f:345-346).  The band model itself can make such a record: a cloud table
+    ! interpolated beyond its wavelengths returns a single-scattering albedo above one, and the reference stops there
+    ! with the wavelengths before it on stdout.
+    ipk = where_solved(k)
+    nbad = 0
+    if (ipk > 0) then
+      do lc = 1, nz
+        if (ssalb(lc, ipk) < 0._kr .or. ssalb(lc, ipk) > 1._kr) then
+          print *, ssalb(lc, ipk), ', ', lc
+          call write_bad('SSALB')
+        end if
+      end do
+      row = merge(int(pmom_row(ipk)) + 1, ipk, from_model)
+      do lc = 1, nz
+        do km = 0, nmom
+          if (pmom(km, lc, row) < -1._kr .or. pmom(km, lc, row) > 1._kr) call write_bad('PMOM')
+        end do
+      end do
+    end if
+    if (recs(k)%ibdrf == 0) call warn_file(0, 'DISORT--input and/or dimension errors')
     sm%ibdrf = recs(k)%ibdrf; sm%par = recs(k)%bpar
     do irmu = 0, 100
       rmu = real(irmu*0.01, kr)                         ! (IRMU*0.01 in default real, as the reference types it)
@@ -663,10 +684,17 @@ contains
       if (flxalb < 0._kr .or. flxalb > 1._kr) then
         call warn_file(8, 'DREF--albedo value not in (0,1)')
         print '(a,2es11.3)', 'mu, flxalb: ', rmu, flxalb
-        write(*, '(3a)') ' ****  Input variable  ', 'FUNCTION BDREF', '  in error  ****'
+        call write_bad('FUNCTION BDREF')
       end if
     end do
     call warn_file(0, 'DISORT--input and/or dimension errors')
+  contains
+    subroutine write_bad(name)
+      character(len=*), intent(in) :: name
+      write(*, '(3a)') ' ****  Input variable  ', name, '  in error  ****'
+      nbad = nbad + 1
+      if (nbad == 50) call warn_file(12, 'Too many input errors.  Aborting...')
+    end subroutine
   end subroutine
 
   subroutine release_fleets()

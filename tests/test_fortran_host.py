@@ -410,6 +410,25 @@ def test_bidirectional_surfaces_from_input_alone(tmp_path, namelist):
 @pytest.mark.gpu
 @needs_flang
 @needs_ref
+def test_input_error_inside_the_run_stops_where_the_reference_stops(tmp_path):
+    """Found by the end-to-end fuzz (seed 4002): a two-slot cloud on a regridded atmosphere takes the reference's own
+    cloud table to a single-scattering albedo of 1.276 at the eighth wavelength; CHEKIN prints the value, its layer
+    and the variable's name (disort.f:4947-4953) and the run stops INSIDE that DISORT call -- the banner and the seven
+    wavelengths before it stay on stdout (the host stopped before printing anything)."""
+    _build()
+    nl = ("idatm=5 wlinf=3.5 wlsup=4.2 wlinc=-0.003 iday=355 time=6 alat=0 alon=0 nf=1 uo3=0.35 xo4=0 xn2o=0.4 "
+          "tcloud=3,0.5 zcloud=2,-4 nre=10,16 ngrid=65 zgrid1=1 zgrid2=10 nothrm=1 iout=1 nstr=4")
+    # (from INPUT alone: the capture of a run that stops inside DISORT ends in the middle of a record)
+    ref, got, _ = run_reference_and_host(nl, str(tmp_path), from_input=True)
+    assert "Input variable  SSALB  in error" in ref and len(ref.split()) > 60, ref
+    _compare_stdout(got, ref)
+    warn = (tmp_path / "SBDART_WARNING.00").read_text()
+    assert "DISORT--input and/or dimension errors" in warn
+
+
+@pytest.mark.gpu
+@needs_flang
+@needs_ref
 @pytest.mark.parametrize("namelist,from_input", [
     ("kdist=-1 wlinf=.3 wlsup=12 iout=1 sza=40 nstr=8", True),
     ("kdist=-1 wlinf=.3 wlsup=12 iout=1 sza=40 nstr=8", False),
