@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
     //      side, lower factors, lane i <-> row i ----
     bool spd = true;
     double rp[nn], rm[nn];
+    double rdiag = 1.0;                                  // 1 / C(me, me) as the factorisation formed it (G = 8, 16)
     if constexpr (G == 8 || G == 16) {
         // Lane j forms column j = row j of S+- (symmetric); the row stays in registers for the factorisation,
         // whose column k travels by DPP inside the group.  L and C go to LDS once, at the end.
@@ -315,7 +316,7 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
             const double dp = group_bcast<k - 1, G>(rp[k - 1]), dm = group_bcast<k - 1, G>(rm[k - 1]);
             if (!(dp > 0.0) || !(dm > 0.0)) spd = false;
             const double rdp = rsqrt_nr(dp), rdm = rsqrt_nr(dm);      // 1/sqrt(pivot): the factors are an ulp or two off
-            if (me == k) { rp[k - 1] = dp * rdp; rm[k - 1] = dm * rdm; }
+            if (me == k) { rp[k - 1] = dp * rdp; rm[k - 1] = dm * rdm; rdiag = rdm; }
             else if (me > k) { rp[k - 1] = rp[k - 1] * rdp; rm[k - 1] = rm[k - 1] * rdm; }
             // row me, column j > k: minus L(me,k) L(j,k), L(j,k) = lane j's entry k (the lanes above row j
             // compute on their unused upper part)
@@ -565,8 +566,8 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
         }
     }
     if (me <= nn) {
-        kq = sqrt(fabs(lam));
-        const double rkq = 1.0 / kq;
+        const double rkq = rsqrt_nr(fabs(lam));           // (lam > 0 here; k to an ulp or two, like the factors)
+        kq = fabs(lam) * rkq;
         // one walk over C, column by column from the last: entry C(k,i) serves the back-substitution
         // C^T y = b' (row i) and the product C b' (row k) -- read once, and never more than a column in flight
         static_for<nn>([&](auto ii) {
@@ -581,7 +582,10 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
                 cb[k - 1] = cb[k - 1] + c * bi;
             }
             cb[i - 1] = cb[i - 1] + cii * bi;
-            yv[i - 1] = s * rcp_nr(cii);
+            // (1 / C(i,i): lane i kept it from the factorisation -- two DPP moves instead of a v_rcp_f64 and two
+            //  Newton steps per row)
+            if constexpr (G == 8 || G == 16) yv[i - 1] = s * group_bcast<i - 1, G>(rdiag);
+            else yv[i - 1] = s * rcp_nr(cii);
             __builtin_amdgcn_sched_barrier(0);
         });
         if constexpr (rad) {
