@@ -60,7 +60,7 @@ struct Params {
     int32_t cw, ncd;        // band: CW = 2*ncd+1 columns kept per U row, ncd = 3nn-1
     int32_t ublock;         // U rows stored by layer block (sbd_band4.hpp) instead of diagonal-relative
     int32_t gconly;         // the band kernel scales GC itself (sbd_band4.hpp): the layer kernels write no ga/gb
-    double umu0, fisot, btemp, ttemp, temis;
+    double umu0, rumu0, fisot, btemp, ttemp, temis;      // (rumu0 = 1 / umu0, formed once on the host)
     double pi, dither;
     Tables t;
     // chunk inputs (device pointers, already offset to the chunk)

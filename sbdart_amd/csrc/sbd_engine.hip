@@ -641,7 +641,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         P.all_levels = cfg->nlevel_out > 0 ? 0 : 1;
         P.sv_stride = sv_stride; P.svi_stride = svi_stride;
         P.cw = cw; P.ncd = ncd;
-        P.umu0 = cfg->umu0; P.fisot = cfg->fisot; P.btemp = cfg->btemp; P.ttemp = cfg->ttemp; P.temis = cfg->temis;
+        P.umu0 = cfg->umu0; P.rumu0 = (cfg->umu0 != 0.0) ? 1.0 / cfg->umu0 : 0.0; P.fisot = cfg->fisot; P.btemp = cfg->btemp; P.ttemp = cfg->ttemp; P.temis = cfg->temis;
         P.pi = ref_pi();
         P.dither = 100.0 * 2.220446049250313e-16;   // disort.f:442-448
         P.t = e->tab;

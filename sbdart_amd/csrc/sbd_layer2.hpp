@@ -731,8 +731,9 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
         wave_lds_sync();                                 // (the pivots were read from the area that now turns scratch)
     }
     const double rme = (me <= nn) ? srr[me - 1] : 1.0, rw = (me <= nn) ? srr[me - 1] * swi[me - 1] : 0.0;
-    const double cmu_me = (me <= nn) ? scmu[me - 1] : 1.0;
-    const double rk2 = 1.0 / lam;
+    const double rk2 = rkq_me * rkq_me;                  // 1 / k^2 (idle lanes: 0, their sums are empty)
+    // reciprocals from the block's tables instead of IEEE divisions (each ~17 instructions): 1 / R = mu X, 1 / mu
+    const double rrme = (me <= nn) ? scmu[me - 1] * sxi[me - 1] : 1.0, rcmu_me = (me <= nn) ? smi[me - 1] : 1.0;
     if (thermal) {
         // UPISOT (disort.f:4309-4349).  (I - CC) Z1 = (1-w') XR1 (the same in both halves): Z1+- = (1-w') XR1 u,
         // (I - S+ W) u = 1;  (I - CC) Z0 = (1-w') XR0 + CMU Z1: Z0+- = (1-w') XR0 u +- e, (I - S- W) e = mu Z1.
@@ -769,7 +770,7 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
         double *spa = scra, *spp = scra + nn;            // the two spread vectors, read before the products land
         if (me <= nn) {
             spa[me - 1] = rme * rs;
-            spp[me - 1] = (scwt[me - 1] / rme) * (rdv / cmu_me);
+            spp[me - 1] = (scwt[me - 1] * rrme) * (rdv * rcmu_me);
         }
         wave_lds_sync();
         double pa = 0.0, pp = 0.0;
@@ -779,11 +780,11 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
             pp = pp + yv[i] * spp[i];
         }
         wave_lds_sync();
-        const double cj = (pa - umu0 * lam * pp) / (lam * (1.0 / umu0 - umu0 * lam));
+        const double cj = (pa - umu0 * lam * pp) * rcp_nr(lam * (P.rumu0 - umu0 * lam));
         double vy, vc;
         combine2(cj, vy, vc);
         const double dv = rw * vy;
-        const double sv_ = umu0 * (rdv - vc / rme) / cmu_me;
+        const double sv_ = umu0 * (rdv - vc * rrme) * rcmu_me;
         const double zpl = 0.5 * (sv_ + dv), zmi = 0.5 * (sv_ - dv);     // Z(+mu_me), Z(-mu_me)
         if (me <= nn) {
             double *zzout = P.zz + lidx * n;
