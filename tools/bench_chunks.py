@@ -19,7 +19,7 @@ for _ in range(10): eng.solve_device(*d_in, out=(flux, None, status), stream=s.c
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
 print(os.environ.get("SBD_CHUNK"), eng.chunk, "%.2f ms" % (dt * 1e3), "%.3f M pts/s" % (49152 / dt / 1e6))
 '''
-for ch in ("8192", "16384", "21876", "32814", "43752", "65627"):
+for ch in (sys.argv[1:] or ("8192", "16384", "21876", "32814", "43752", "65627")):
     env = dict(os.environ, SBD_CHUNK=ch)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:])
