@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_VEC_PEAK_TF = 78.6        # fp64 vector peak
+PCIE_PEAK_GBS = 64.0           # PCIe 5.0 x16, one direction (the host entry point's bound)
 
 
 def algorithmic_bytes_per_solve(nlyr, nstr, nlev):
@@ -259,6 +260,8 @@ def main():
     ap.add_argument("--nlyr", type=int, default=33)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-lines", action="store_true", help="skip the latency case and the other BASELINE shapes")
+    ap.add_argument("--rendezvous-only", choices=["nccl", "gloo"], default=None,
+                    help="launcher check: bring up --gpus ranks on this backend, count them, print that, exit (no bench line)")
     args = ap.parse_args()
     on = [k for k in DEV_SWITCHES if os.environ.get(k)]
     if on:   # the headline number is the default path only
@@ -266,14 +269,24 @@ def main():
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    from sbdart_amd.launch import launched_world, relaunch_one_rank_per_gpu, rendezvous
+    if args.gpus > 1 and launched_world() is None:
+        # `python bench.py --gpus N` on its own: this process becomes the launcher of N ranks (one per GPU) and
+        # passes their exit code on -- it never prints a bench line itself (a 1-GPU line labelled N would be a lie)
+        backend = "gloo" if args.rendezvous_only == "gloo" else "nccl"
+        if backend == "nccl" and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s): "
+                     f"refusing to print a line for fewer devices than asked for")
+        sys.exit(relaunch_one_rank_per_gpu(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    rank, local_rank, world = rendezvous(args.gpus, backend="gloo" if args.rendezvous_only == "gloo" else "nccl")
+    if args.rendezvous_only:
+        # launcher path only (CPU test of `--gpus N`): the ranks met, counted each other, rank 0 says so -- no metric
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "backend": args.rendezvous_only,
+                              "ranks_counted": world}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -381,6 +394,8 @@ def main():
     barrier()
     elapsed_hs = time.perf_counter() - t0
     fleet.close()
+    h2d_bytes = int(sum(a.nbytes for a in h_in) + h_w.nbytes)
+    h2d_bytes_shared = int(h2d_bytes - h_in[2].nbytes + h_pm_pt.nbytes + h_rows.nbytes)
     if world > 1:
         tt = torch.tensor([elapsed_h], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -429,6 +444,15 @@ def main():
             "solves_per_s": W * world * args.steps / elapsed,
             "value_incl_h2d": nwl_total * nh / elapsed_h, "ms_per_step_incl_h2d": 1e3 * elapsed_h / nh,
             "value_incl_h2d_shared_moments": nwl_total * nh / elapsed_hs, "ms_per_step_incl_h2d_shared_moments": 1e3 * elapsed_hs / nh,
+            # SURVEY 8(d)'s own wording of the metric ("H2D of inputs + kernels + D2H/reduce"): the host entry point's
+            # rate; its bound is the PCIe link, not HBM (roofline_pcie).  `value` stays the HBM-resident rate.
+            "value_8d": nwl_total * nh / elapsed_h,
+            "roofline_pcie": {"bound": "pcie", "achieved": h2d_bytes * world * nh / elapsed_h / 1e9, "peak": PCIE_PEAK_GBS,
+                              "unit": "GB/s", "frac": h2d_bytes * nh / elapsed_h / 1e9 / PCIE_PEAK_GBS,
+                              "bytes_per_step": h2d_bytes, "bytes_per_step_shared_moments": h2d_bytes_shared,
+                              "achieved_shared_moments": h2d_bytes_shared * nh / elapsed_hs / 1e9,
+                              "note": "H2D bytes of one step's inputs (per-item moments / moments once per spectral "
+                                      "point) over the host-entry-point step time; peak = PCIe 5.0 x16 per direction"},
             "incl_h2d_note": "same step through the host entry point (sbd_fleet_solve_host): inputs in pinned host memory, the passes' H2D back to back on a copy stream beside the kernels, sums on the device, D2H of sums + status",
             "nonzero_status": bad, "fallback_layers": fallback_layers,
             "kernel_ms": {names[i]: float(phase_ms[i]) for i in range(5)},
