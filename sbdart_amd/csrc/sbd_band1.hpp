@@ -12,14 +12,25 @@
 // window rows in registers: ONE array a[RW] per lane (96 VGPRs at NSTR = 32), against 33 KB of LDS per
 // wave in the LDS-window kernel it replaces (one wave per SIMD).  The right-hand side is a vector across
 // the lanes: lane p <-> window row p.  One sub-step J:
-//   * column J of the live rows (lane J's registers) crosses to the lanes through 384 bytes of LDS: lane J
-//     writes (ds_write2_b64), every lane reads its row's entry and the entries of rows 16k + lane%16;
-//   * pivot search over the lanes on the DPP network, LINPACK's first-maximum rule exactly;
+//   * column J of the live rows (lane J's registers) crosses to the lanes through 384 bytes of LDS -- but NOT at the
+//     head of sub-step J: lane J wrote it, two rows per ds_write2_b64, BETWEEN the elimination FMAs of sub-step
+//     J-1, as soon as a pair of rows was final (round 4; a burst of 16-24 one-lane LDS writes at the head of
+//     every sub-step held the wave for ~300 cycles of LDS queue on its critical path -- PMC: SQ_WAIT_INST_LDS
+//     22 % of the wave cycles); every lane reads its row's entry (v: pivot search, right-hand side) and the
+//     entries of rows 16k + lane%16 (the multipliers);
+//   * pivot search, LINPACK's first-maximum rule exactly, without a reduction over the lanes: the maximum of the
+//     leading words |hi(a[p])| is kept IN the lanes along the same FMA stream (v_max3_f32 with abs modifiers,
+//     half an instruction per row: positive doubles order like their leading words read as floats), lane J's
+//     maximum goes to an SGPR and the lanes whose entry carries that leading word vote (ballot); only a tie on
+//     the leading word pays a second pass on the low words;
+//   * -1/pivot is formed lane-wise from the column entries while the vote runs and picked from the pivot's lane;
 //   * the pivot row leaves its registers by a computed jump on the wave-uniform row index (generated
 //     inline asm, sbd_band1_take.inc) and the last live row takes its place;
 //   * elimination a[p] += a[p](lane J) * (t * -1/pivot): the multipliers, replicated in every row of 16
 //     lanes, are read by the DP-ALU DPP form of the FMA (row_newbcast): ONE instruction per live row;
 //   * the right-hand side takes its multipliers lane-wise from the same column: one FMA;
+//   * FUSED: the top level's three functional rows are three more window rows (registers F[k], LDS slots and
+//     right-hand-side lanes RW..RW+2) that the search never sees: three more DPP FMAs, nothing through SGPRs;
 //   * rows of the next interface are fetched into the registers of retired rows (+ E buffer rows) while
 //     this layer is eliminated.
 #pragma once
@@ -31,17 +42,57 @@ namespace sbd {
 
 #include "sbd_band1_take.inc"   // TakeRow1<RW, LAST>: generated inline asm (tools/gen_band1_take.py)
 
-// a[I..CNT-1] of this lane to LDS doubles addr[I..CNT-1], two registers per ds_write2_b64
-template <int I, int CNT, int RW>
-SBD_DEVICE void write_live(unsigned addr, const double (&a)[RW])
+// ONE lane writes rows P, P+1 of its column to LDS doubles addr[P], addr[P+1].  Two ways to single the lane out:
+// SBD_B1_MASKED: exec = that lane around the write (two scalar moves per write in the wave's instruction stream);
+// default: every lane executes the write, the other 63 into a dump area behind the column (the address register
+// carries the choice: one v_cndmask per sub-step, no scalar instruction per write)
+struct LaneSel { unsigned addr; unsigned long long bit; };
+template <int P>
+SBD_DEVICE void lane_write2(const LaneSel &w, double x0, double x1)
 {
-    if constexpr (I + 1 < CNT) {
-        asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4"
-                     :: "v"(addr), "v"(a[I]), "v"(a[I + 1]), "n"(I), "n"(I + 1) : "memory");
-        write_live<I + 2, CNT>(addr, a);
-    } else if constexpr (I < CNT) {
-        asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(addr), "v"(a[I]), "n"(I * 8) : "memory");
-    }
+#ifdef SBD_B1_MASKED
+    asm volatile("s_mov_b64 exec, %3\n\tds_write2_b64 %0, %1, %2 offset0:%4 offset1:%5\n\ts_mov_b64 exec, -1"
+                 :: "v"(w.addr), "v"(x0), "v"(x1), "s"(w.bit), "n"(P), "n"(P + 1) : "memory");
+#else
+    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(w.addr), "v"(x0), "v"(x1), "n"(P), "n"(P + 1) : "memory");
+#endif
+}
+template <int P>
+SBD_DEVICE void lane_write1(const LaneSel &w, double x0)
+{
+#ifdef SBD_B1_MASKED
+    asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
+                 :: "v"(w.addr), "v"(x0), "s"(w.bit), "n"(P * 8) : "memory");
+#else
+    asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(w.addr), "v"(x0), "n"(P * 8) : "memory");
+#endif
+}
+// LDS doubles per wave: the column (64) + the dump area (lane stride 16 bytes + the row offsets)
+constexpr int kBand1LdsDoubles = 64 + 64 * 2 + 64;
+SBD_DEVICE LaneSel lane_sel(unsigned mc, unsigned dump, int ln, int writer)   // dump = mc + 512 + 16 * lane
+{
+#ifdef SBD_B1_MASKED
+    return LaneSel{mc, 1ull << (writer & 63)};
+#else
+    return LaneSel{(ln == writer) ? mc : dump, 0ull};
+#endif
+}
+
+// running maximum of the leading words of |x|: positive doubles (below 2^1017) order like their leading words read as
+// floats, so one v_max3_f32 with abs modifiers folds two rows (in asm: the compiler's fmaxf canonicalises every operand
+// first, three instructions per row).  The words travel as integers; a denormal-as-float pattern (|x| < 2^-1015) may be
+// flushed to zero -- such a column is singular anyway
+SBD_DEVICE int lead_max2(int m, double x0, double x1)
+{
+    int r;
+    asm volatile("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(__double2hiint(x0)), "v"(__double2hiint(x1)), "v"(m));
+    return r;
+}
+SBD_DEVICE int lead_max1(int m, double x0)
+{
+    int r;
+    asm volatile("v_max_f32 %0, |%1|, %2" : "=v"(r) : "v"(__double2hiint(x0)), "v"(m));
+    return r;
 }
 
 template <int I>
@@ -58,18 +109,16 @@ SBD_DEVICE double uniform_from_lane(double x, int src)          // x of lane src
                             __builtin_amdgcn_readlane(__double2loint(x), src));
 }
 
-// ISAMAX's first-maximum rule over lanes 0..lm (wave_first_max with the lane number passed in)
-SBD_DEVICE int wave_first_max_of(double a, int lane, int lm)
+// ISAMAX's first-maximum rule over lanes 0..lm, the maximum of the leading words (mhi, wave-uniform) known already:
+// the lanes holding it vote; a tie on the leading word is settled on the low words (reduction over the lanes)
+SBD_DEVICE int first_max_lane(double a, int lane, int lm, unsigned mhi)
 {
-    const bool cand = lane <= lm;
-    const unsigned hi = cand ? ((unsigned)__double2hiint(a) & 0x7fffffffu) : 0u;
-    const unsigned mhi = wave_umax<true>(hi);
-    unsigned long long hit = __ballot(cand && hi == mhi);
+    const bool c2 = lane <= lm && ((unsigned)__double2hiint(a) & 0x7fffffffu) == mhi;
+    unsigned long long hit = __builtin_amdgcn_ballot_w64(c2);
     if (hit & (hit - 1ull)) {                       // several lanes share the leading word
-        const bool c2 = cand && hi == mhi;
         const unsigned lo = c2 ? (unsigned)__double2loint(a) : 0u;
         const unsigned mlo = wave_umax<true>(lo);
-        hit = __ballot(c2 && lo == mlo);
+        hit = __builtin_amdgcn_ballot_w64(c2 && lo == mlo);
     }
     return hit ? __ffsll((long long)hit) - 1 : 0;
 }
@@ -86,13 +135,13 @@ SBD_DEVICE double wave_sum64(double v)
 // functionals c^T x of the solution; each rides through the elimination as an extra row of [A b; c^T 0] and never takes
 // part in the pivot search, so that after the last step its right-hand side is -c^T x (sbd_band4.hpp has the long
 // version).  Here: the top level's rows as one register per lane (F[k]: lanes < 32 the x_lc coefficients, lanes >= 32
-// the x_lc+1 ones) with a wave-uniform right-hand side; the surface level's rows in the zero padding rows nn..nn+2 of
+// the x_lc+1 ones) = window rows RW..RW+2 with their right-hand sides in lanes RW..RW+2 of y; the surface level's rows in the zero padding rows nn..nn+2 of
 // the bottom block, scaled by 2^-300 (the exact first-maximum search never takes them while a real row is left), tagged
 // 1, 2, 3 in the x_lc+1 half, which the last step does not use.  No U, no B, no back-substitution kernel.
 template <int NN, bool FUSED = false>
 __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // kBand1LdsDoubles
     constexpr int n = 2 * NN, nn = NN, RW = nn + n, UW = u_width(n);
     static_assert(n <= 32 && RW <= 64, "band1_kernel: a layer's columns must fit half a wave");
     constexpr double kTiny = 4.909093465297727e-91, kHuge = 2.037035976334486e+90;   // 2^-300, 2^300
@@ -276,8 +325,11 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
         }
     }
     // FUSED: the top level's three functional rows (mean intensity, downward and upward flux sums); the level lies in
-    // layer 1, they enter with the first step
-    double F[3] = {0.0, 0.0, 0.0}, Fy[3] = {0.0, 0.0, 0.0};
+    // layer 1, they enter with the first step as window rows RW..RW+2 (right-hand sides: lanes RW..RW+2 of y)
+    constexpr int NF = FUSED ? 3 : 0, NG = (RW + NF + 15) / 16;     // multiplier registers: rows 16k + lane%16
+    static_assert(RW + NF <= 64, "band1_kernel: the pivot column and the functional rows share 64 LDS slots");
+    double F[3] = {0.0, 0.0, 0.0};
+    const bool frow = FUSED && lane >= RW && lane < RW + 3;
     if constexpr (FUSED) {
         if (col && !second) {
             const int levt = P.t.level_out[0];
@@ -296,9 +348,11 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
         }
     }
     int status = 0;
-    double pmin = 1.0e300, pmax = 0.0;         // see near_singular() in sbd_layer.hpp; lane J sees the pivot of sub-step J
+    unsigned pmin_hi = 0x7fefffffu, pmax_hi = 0u;   // leading words of the smallest / largest |pivot| (wave-uniform, SGPRs)
     constexpr int E = 4;
     double buf[E], ynext = 0.0;
+    const unsigned mc = lds_addr(mcol), dump = mc + 512u + 16u * (unsigned)lane;
+    const double *mrow = mcol + lane, *mrep = mcol + (lane & 15);   // this lane's row entry, its multiplier slots
     __builtin_amdgcn_s_waitcnt(0x0F70);         // every load so far has landed: the waits inside count the loop's own
     for (int lc = 1; lc <= ncut; ++lc) {
         const RowSrc nx = step_rows(lc + 1);                   // next step's rows
@@ -309,6 +363,23 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
         double *urow0 = FUSED ? nullptr : ufac + (size_t)k0 * UW;
         double *yrow0 = yv + k0;
         const bool tail = lc == ncut;                           // the last layer has no x_lc+1
+        // column 0 of the step's window: lane 0 writes its rows, every lane keeps the maximum of its column's
+        // leading words (the later columns: inside the elimination of the sub-step before them)
+        int mxf = 0;
+        {
+            const LaneSel w0 = lane_sel(mc, dump, lane, 0);
+            static_for<(RW + 1) / 2>([&](auto hh) {
+                constexpr int p = 2 * decltype(hh)::value;
+                if constexpr (p + 1 < RW) {
+                    lane_write2<p>(w0, a[p], a[p + 1]);
+                    mxf = lead_max2(mxf, a[p], a[p + 1]);
+                } else {
+                    lane_write1<p>(w0, a[p]);
+                    mxf = lead_max1(mxf, a[p]);
+                }
+            });
+            if constexpr (FUSED) { lane_write2<RW>(w0, F[0], F[1]); lane_write1<RW + 2>(w0, F[2]); }
+        }
         static_for<n>([&](auto jj) {
             constexpr int J = decltype(jj)::value;
             constexpr int LAST = RW - 1 - J;                    // live rows: registers 0..LAST
@@ -318,18 +389,28 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
             asm volatile("" : "+v"(ln));
             const int lq = ln & 31, l16 = ln & 15;
             const bool second = ln >= 32, col = lq < n;
-            // (1) column J of the live rows crosses to the lanes through LDS: lane J writes its registers,
-            //     every lane reads row `lane`'s entry (v: pivot search, right-hand side) and the entries of
-            //     rows 16k + lane%16 (m0..m2: the multipliers, replicated in each row of 16 lanes for the
-            //     DPP form of the elimination FMA)
-            if (ln == J) write_live<0, LAST + 1>(lds_addr(mcol), a);   // (only live registers: the others may be loads in flight)
+            // (1) column J of the live rows, written by lane J while the sub-step before was eliminated (LDS serves
+            //     a wave's requests in order): row `lane`'s entry (v: pivot search, right-hand side) and the
+            //     entries of rows 16k + lane%16 (m[k]: the multipliers, replicated in each row of 16 lanes)
             wave_lds_sync();
-            double v = mcol[ln];                                 // (lanes beyond the live rows: never used)
-            double m0 = mcol[l16], m1 = mcol[16 + l16], m2 = mcol[32 + l16];
-            wave_lds_sync();
-            // (2) ISAMAX's first-maximum rule on the DPP network; the pivot row leaves its registers, the
-            //     last live row takes its place -- in the window, in y and in the column just read
-            const int idx = wave_first_max_of(v, ln, LAST);
+            double v = *mrow;                                    // (lanes beyond the live rows: never used)
+            double m[NG];
+#pragma unroll
+            for (int k = 0; k < NG; ++k) m[k] = mrep[16 * k];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v), "+v"(m[0]), "+v"(m[NG - 1]) :: "memory");   // (before the next column's writes queue up behind them)
+            // (2) ISAMAX's first-maximum rule: lane J's in-lane maximum of the leading words, the vote of the lanes
+            //     that hold it; -1/pivot lane-wise meanwhile (v_rcp + two Newton steps), a zero pivot is flagged
+            //     and skipped; the pivot row leaves its registers, the last live row takes its place -- in the
+            //     window, in y and in the column just read
+            const unsigned mhi = (unsigned)__builtin_amdgcn_readlane(mxf, J);
+            double rn = __builtin_amdgcn_rcp(v);
+            rn = rn * (2.0 - v * rn);
+            rn = rn * (2.0 - v * rn);
+            rn = (v != 0.0) ? -rn : 0.0;
+            const int idx = first_max_lane(v, ln, LAST, mhi);
+            const double rns = uniform_from_lane(rn, idx);
+            pmin_hi = (mhi < pmin_hi) ? mhi : pmin_hi;            // (scalar: the pivot's leading word is the column's maximum)
+            pmax_hi = (mhi > pmax_hi) ? mhi : pmax_hi;
             double t;
             TakeRow1<RW, LAST>::run(a, idx, t);
             const double ypiv = uniform_from_lane(y, idx);
@@ -338,9 +419,8 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
                 y = (ln == idx) ? ylast : y;
                 v = (ln == idx) ? vlast : v;
                 const bool mine = l16 == (idx & 15);
-                m0 = (mine && (idx >> 4) == 0) ? vlast : m0;
-                m1 = (mine && (idx >> 4) == 1) ? vlast : m1;
-                m2 = (mine && (idx >> 4) == 2) ? vlast : m2;
+#pragma unroll
+                for (int k = 0; k < (RW + 15) / 16; ++k) m[k] = (mine && (idx >> 4) == k) ? vlast : m[k];
             }
             // register LAST is free from here on: next interface's row LAST - nn moves in
             if constexpr (LAST - nn >= E) a[LAST] = nx.p[(LAST - nn) * n];
@@ -352,14 +432,7 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
                 tcn = taucpr[lcb];
             }
             if constexpr (J == 3) ynext = step_rhs(lc + 1, zu, zn, ebn, tcn);
-            // (3) -1/pivot (v_rcp + two Newton steps) from lane J, a zero pivot is flagged and skipped
-            double rn = __builtin_amdgcn_rcp(t);
-            rn = rn * (2.0 - t * rn);
-            rn = rn * (2.0 - t * rn);
-            rn = (t != 0.0) ? -rn : 0.0;
-            const double rns = uniform_from_lane(rn, J);
-            if (ln == J) { pmin = fmin(pmin, fabs(t)); pmax = fmax(pmax, fabs(t)); }
-            // (4) the retired row: U(k, k..k+2n-1-J) relative to the diagonal, B(k) -- FUSED: nothing is stored
+            // (3) the retired row: U(k, k..k+2n-1-J) relative to the diagonal, B(k) -- FUSED: nothing is stored
             if constexpr (!FUSED) {
                 double *urow = urow0 + J * UW;
                 if (!second) {
@@ -369,25 +442,58 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
                 }
                 if (ln == 0) yrow0[J] = ypiv;
             }
-            // (5) elimination: a[p] += a[p](lane J) * (t * -1/pivot), the multiplier from lane p%16 of the
-            //     lane's own row of 16 (v_fmac_f64_dpp row_newbcast); columns <= J of x_lc are finished
-            const double tp = (second || lq > J) ? rns * t : 0.0;
-            static_for<LAST>([&](auto pp) {
+            // (4) elimination: a[p] += a[p](lane J) * (t * -1/pivot), the multiplier from lane p%16 of the
+            //     lane's own row of 16 (v_fmac_f64_dpp row_newbcast); columns <= J of x_lc are finished.
+            //     Lane J+1 sends its finished rows to LDS pair by pair (next sub-step's column) and every lane
+            //     folds the new leading words into its maximum
+            const double tp = (ln > J) ? rns * t : 0.0;          // (lanes >= 32: columns of x_lc+1, all of them live)
+            constexpr bool NEXT = J + 1 < n;
+            const LaneSel wn = lane_sel(mc, dump, ln, J + 1);
+            int mx2 = 0, mx3 = 0;     // two running maxima, pairs alternate (a statement that reads what the one before wrote costs a wait state)
+            // (the maximum and the write of a pair of rows follow two pairs behind their FMAs; a pair's four instructions
+            //  are ONE asm statement: between separate statements the compiler puts a wait state per pair)
+            auto send = [&](auto pp) {
                 constexpr int p = decltype(pp)::value;
-                a[p] = fmac_row16<p & 15>(a[p], (p < 16) ? m0 : ((p < 32) ? m1 : m2), tp);
+                if constexpr (NEXT && p >= 0) {
+                    if constexpr (p + 1 < LAST) { lane_write2<p>(wn, a[p], a[p + 1]); mx2 = lead_max2(mx2, a[p], a[p + 1]); }
+                    else { lane_write1<p>(wn, a[p]); mx2 = lead_max1(mx2, a[p]); }
+                }
+            };
+            asm volatile("s_nop 1" ::: "memory");    // (a multiplier register fixed just above -> its DPP read: two wait states)
+            static_for<(LAST + 1) / 2>([&](auto hh) {
+                constexpr int p = 2 * decltype(hh)::value, lp = p - 4;
+#ifndef SBD_B1_MASKED
+                if constexpr (NEXT && lp >= 0 && p + 1 < LAST) {
+                    asm volatile("v_fmac_f64_dpp %0, %3, %4 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+                                 "ds_write2_b64 %5, %6, %7 offset0:%11 offset1:%12\n\t"
+                                 "v_max3_f32 %2, |%8|, |%13|, %2"
+                                 : "+v"(a[p]), "+v"(a[p + 1]), "+v"((p & 2) ? mx3 : mx2)
+                                 : "v"(m[p >> 4]), "v"(tp), "v"(wn.addr), "v"(a[lp]), "v"(a[lp + 1]), "v"(__double2hiint(a[lp])),
+                                   "n"(p & 15), "n"((p + 1) & 15), "n"(lp), "n"(lp + 1), "v"(__double2hiint(a[lp + 1]))
+                                 : "memory");
+                } else
+#endif
+                {
+                    a[p] = fmac_row16<p & 15>(a[p], m[p >> 4], tp);
+                    if constexpr (p + 1 < LAST) a[p + 1] = fmac_row16<(p + 1) & 15>(a[p + 1], m[(p + 1) >> 4], tp);
+                    send(std::integral_constant<int, lp>{});
+                }
             });
-            // right-hand side: y(p) += a[p](lane J) * (y_pivot * -1/pivot) for the live rows
+            if constexpr (FUSED) {
+                static_for<3>([&](auto kk_) {
+                    constexpr int k = decltype(kk_)::value, r = RW + k;
+                    F[k] = fmac_row16<r & 15>(F[k], m[r >> 4], tp);
+                });
+            }
+            send(std::integral_constant<int, 2 * ((LAST + 1) / 2) - 4>{});
+            send(std::integral_constant<int, 2 * ((LAST + 1) / 2) - 2>{});
+            if constexpr (FUSED && NEXT) { lane_write2<RW>(wn, F[0], F[1]); lane_write1<RW + 2>(wn, F[2]); }
+            asm volatile("v_max_f32 %0, %1, %2" : "=v"(mxf) : "v"(mx2), "v"(mx3));
+            // right-hand side: y(p) += a[p](lane J) * (y_pivot * -1/pivot) for the live rows (and the functional rows)
             {
                 const double yt = ypiv * rns;
-                y = (ln < LAST) ? y + v * yt : y;
-                if constexpr (FUSED) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const double mk = uniform_from_lane(F[k], J);     // the row's entry in column J of x_lc
-                        F[k] = F[k] + mk * tp;
-                        Fy[k] = Fy[k] + mk * yt;
-                    }
-                }
+                y = y + v * yt;      // (retired rows' lanes and the lanes beyond the window gather garbage nobody reads)
             }
         });
         // ---- the nn rows left over only touch x_lc+1: next step's carry (their entries move to the
@@ -399,7 +505,7 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
         }
 #pragma unroll
         for (int r = 0; r < E; ++r) a[nn + r] = buf[r];
-        y = (lane < nn) ? y : ((lane < RW) ? ynext : 0.0);
+        y = (lane < nn || frow) ? y : ((lane < RW) ? ynext : 0.0);
         if constexpr (FUSED) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -409,15 +515,9 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
             if (lc + 1 == ncut && second) { a[n] = 1.0; a[n + 1] = 2.0; a[n + 2] = 3.0; }   // tags of the surface rows
         }
     }
-    {   // errmsg 2: min|pivot| <= 8 N eps max|pivot| over the N pivots of the system (a zero pivot included)
-        double am = pmax, pm = pmin;
-#pragma unroll
-        for (int d = 16; d >= 1; d >>= 1) {
-            am = fmax(am, __shfl_xor(am, d, 32));
-            pm = fmin(pm, __shfl_xor(pm, d, 32));
-        }
-        if (lane == 0 && !(pm > 8.0 * N * 2.220446049250313e-16 * am)) status |= 0x01;
-    }
+    // errmsg 2: min|pivot| <= 8 N eps max|pivot| over the N pivots of the system (a zero pivot included)
+    // (near_singular() of sbd_layer.hpp on the leading words: 20 bits of mantissa are plenty for a threshold of 8 N eps)
+    if (lane == 0 && !(__hiloint2double((int)pmin_hi, 0) > 8.0 * N * 2.220446049250313e-16 * __hiloint2double((int)pmax_hi, 0))) status |= 0x01;
     if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
     if constexpr (FUSED) {
         if (lane == 0) P.status[slot] = st0 | status;       // (the last kernel of a fused pass: no finish_kernel)
@@ -427,7 +527,7 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
         double fs[2][3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            fs[0][k] = -Fy[k];
+            fs[0][k] = -uniform_from_lane(y, RW + k);
             double v = 0.0;
 #pragma unroll
             for (int p = 0; p < nn; ++p) {

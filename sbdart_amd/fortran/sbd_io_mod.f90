@@ -5,7 +5,8 @@ module sbd_io_mod
   use sbd_grid_mod, only: kr
   implicit none
   private
-  public :: optics_t, read_optics, write_optics, read_atmosphere, warn_file, fatal
+  public :: optics_t, read_optics, write_optics, read_atmosphere, write_atmosphere, warn_file, warn_reset, fatal
+  logical, save :: issued(0:20) = .false.              ! warning numbers written by this run (errmsg writes each once)
 
   type optics_t      ! one (wavelength, k-term) work item as handed to DISORT (drt.f:541-546)
     integer :: nlyr, nstr, nmom, numu, nphi, flags, kd, nk, iwl
@@ -144,10 +145,28 @@ contains
 
   ! errmsg (disutil.f:278-325): message + copy of INPUT into SBDART_WARNING.NN, once per number;
   ! number 0 is fatal
-  subroutine warn_file(msgnum, messag)
+  subroutine warn_reset()                                ! a new run of a batch starts with no warning issued
+    issued = .false.
+  end subroutine
+
+  subroutine write_atmosphere(path, nz, z, p)
+    character(len=*), intent(in) :: path
+    integer, intent(in) :: nz
+    real(kr), intent(in) :: z(nz), p(nz)
+    integer :: u, i
+    open(newunit=u, file=path, status='replace', form='formatted')
+    write(u, '(i0)') nz
+    do i = 1, nz
+      write(u, '(2es26.17e3)') z(i), p(i)
+    end do
+    close(u)
+  end subroutine
+
+  ! (stops: number 0 ends the run -- the process too unless the caller runs a batch and says so)
+  subroutine warn_file(msgnum, messag, stops)
     integer, intent(in) :: msgnum
     character(len=*), intent(in) :: messag
-    logical, save :: issued(0:20) = .false.
+    logical, intent(in), optional :: stops
     character(len=2) :: num
     character(len=132) :: line
     integer :: u, v, ios
@@ -171,7 +190,12 @@ contains
       close(v)
     end if
     close(u)
-    if (msgnum == 0) stop
+    if (msgnum == 0) then
+      if (present(stops)) then
+        if (.not. stops) return
+      end if
+      stop
+    end if
     issued(msgnum) = .true.
   end subroutine
 

@@ -16,7 +16,37 @@
 ! file the reference produced (environment SBD_OPTICS, default ./OPTICS.sbdrec; an optics file, when
 ! present, always wins).  Everything downstream of that
 ! -- engine, retry of NSTR, accumulation, output formats -- is this program.
-program sbdart_amd
+!
+! Round 4: the run is a procedure (run_once) so that ONE process can serve many runs -- `sbdart_amd --batch LIST`
+! (LIST: one run directory per line, each holding its INPUT) for the harnesses that launch hundreds of tiny runs
+! (RunRT's sweeps, RunRT/RunRT.py:2158-2193; TestRuns/test_runs): the HIP runtime comes up once, the fleets are kept
+! and found again by configuration, every run's text goes to SBDART.stdout in its directory.  A run of a batch is made
+! in two phases: phase 1 (INPUT -> screening -> band model -> work items) in a forked child per run, where the
+! reference's STOP semantics cost nothing and a pool of workers runs them side by side; phase 2 (work items -> engine
+! -> output records) in the one process that owns the GPU.
+module sbd_fleet_cache_mod
+  use iso_c_binding
+  use sbd_grid_mod, only: kr
+  implicit none
+  integer, parameter :: max_fleets = 48
+  type fleet_slot
+    type(c_ptr) :: fleet = c_null_ptr
+    integer(c_int) :: rc = 0
+    integer :: max_batch = 0, age = 0
+    real(kr), allocatable :: key(:)
+  end type
+  type(fleet_slot), save :: slots(max_fleets)
+  integer, save :: nslot = 0, clock = 0
+  integer(c_int32_t), allocatable, target, save :: devices(:)
+end module
+
+module sbd_run_mod
+  implicit none
+  character(len=*), parameter :: items_file = '.sbd_items', stdout_file = 'SBDART.stdout', stderr_file = 'SBDART.stderr', phase1_mark = '.sbd_phase1'
+contains
+
+! phase 0: the whole run, as the reference's executable; 1: up to the work items (written to items_file); 2: from there
+subroutine run_once(phase)
   use iso_c_binding
   use sbd_engine_mod
   use sbd_grid_mod
@@ -27,23 +57,18 @@ program sbdart_amd
   use sbd_ckfile_mod, only: ck_file, read_ck_files
   use sbd_tables_mod, only: tables_load
   use sbd_filter_mod
-  implicit none
+  use sbd_fleet_cache_mod
+  integer, intent(in) :: phase
   integer, parameter :: ncldz = 5, naerz = 5, naerb = 150, maxmom = 299, ndb = 20
   ! ---- &INPUT / &DINPUT (drt.f:200-215), same names, same defaults where they matter ----
-  integer :: idatm = 4, isat = 0, nf = 2, iday = 0, isalb = 0, krhclr = 0, jaer(naerz) = 0, iaer = 0, &
-             nothrm = -1, nosct = 0, kdist = 3, ngrid = 0, idb(ndb) = 0, iout = 10, nstr = 0, nzen = 0, &
-             nphi = 0, imomc = 3, imoma = 3, ibcnd = 0, ipth = 0
-  real(kr) :: amix = unset, wlinf = real(.55, kr), wlsup = real(.55, kr), wlinc = 0, sza = 0, csza = unset, solfac = 1, &
-       time = 16, alat = real(-64.767, kr), alon = real(-64.067, kr), zpres = unset, pbar = unset, sclh2o = unset, &
-       uw = unset, uo3 = unset, o3trp = unset, ztrp = 0, xrsc = 1, xn2 = unset, xo2 = unset, xco2 = unset, xch4 = unset, &
-       xn2o = unset, xco = unset, xno2 = unset, xso2 = unset, xnh3 = unset, xno = unset, xhno3 = unset, xo4 = 1, &
-       albcon = 0, sc(5) = huge(0.), zcloud(ncldz) = 0, tcloud(ncldz) = 0, lwp(ncldz) = 0, nre(ncldz) = 8, &
-       rhcld = unset, zaer(naerz) = 0, taerst(naerz) = 0, vis = unset, rhaer = unset, tbaer = unset, &
-       wlbaer(naerb) = unset, qbaer(naerb) = unset, abaer = 0, wbaer(naerb) = unset, gbaer(naerb) = unset, &
-       pmaer(naerb*maxmom) = unset, zbaer(mxly) = unset, dbaer(mxly) = unset, zgrid1 = 1, zgrid2 = 30, &
-       zout(2) = (/0._kr, 100._kr/), temis = 0, uzen(nstrms) = unset, vzen(nstrms) = 90, phi(nstrms) = unset, &
-       saza = 180, ttemp = unset, btemp = unset, phi0 = 0, fisot = 0
-  logical :: prnt(7) = .false., corint = .false., spowder = .false.
+  integer :: idatm, isat, nf, iday, isalb, krhclr, jaer(naerz), iaer, nothrm, nosct, kdist, ngrid, idb(ndb), iout, nstr, &
+             nzen, nphi, imomc, imoma, ibcnd, ipth
+  real(kr) :: amix, wlinf, wlsup, wlinc, sza, csza, solfac, time, alat, alon, zpres, pbar, sclh2o, uw, uo3, o3trp, ztrp, &
+       xrsc, xn2, xo2, xco2, xch4, xn2o, xco, xno2, xso2, xnh3, xno, xhno3, xo4, albcon, sc(5), zcloud(ncldz), &
+       tcloud(ncldz), lwp(ncldz), nre(ncldz), rhcld, zaer(naerz), taerst(naerz), vis, rhaer, tbaer, wlbaer(naerb), &
+       qbaer(naerb), abaer, wbaer(naerb), gbaer(naerb), pmaer(naerb*maxmom), zbaer(mxly), dbaer(mxly), zgrid1, zgrid2, &
+       zout(2), temis, uzen(nstrms), vzen(nstrms), phi(nstrms), saza, ttemp, btemp, phi0, fisot
+  logical :: prnt(7), corint, spowder
   namelist /input/ idatm, amix, isat, wlinf, wlsup, wlinc, sza, csza, solfac, nf, iday, time, alat, alon, &
        zpres, pbar, sclh2o, uw, uo3, o3trp, ztrp, xrsc, xn2, xo2, xco2, xch4, xn2o, xco, xno2, xso2, xnh3, &
        xno, xhno3, xo4, isalb, albcon, sc, zcloud, tcloud, lwp, nre, rhcld, krhclr, jaer, zaer, taerst, iaer, &
@@ -70,36 +95,38 @@ program sbdart_amd
   integer(c_int32_t), allocatable, target :: status(:), level_out(:)
   integer, allocatable :: order(:), where_solved(:)
   real(kr), allocatable :: zlev(:), plev(:)
-  integer :: stall, fatal_at
+  integer :: stall, fatal_at, nbad
   type(model_input) :: model
   type(sensor_filter) :: sensor
   type(atmosphere) :: atm
-  logical :: have_file, ok, from_model = .false., in_place, sum_widths
+  logical :: have_file, ok, from_model, in_place, sum_widths, aborted
   real(kr), allocatable, target :: bdtauc(:, :), bssalb(:, :), bpmom(:, :, :)
   real(kr), allocatable :: btemper(:)
   integer(kind=8) :: tick0, tick1, tick2, tick_rate
   character(len=256) :: why
-  ! the run's GPUs and the fleets created so far (stream count x intensity corrections)
   type(ck_file) :: ck                                  ! KDIST = -1: the k-distribution file pair
-  integer(c_int32_t), allocatable, target :: devices(:)
-  type(c_ptr) :: fleets(6)
-  integer :: fleet_ns(6), nfleet = 0
-  logical :: fleet_corr(6)
-  integer(c_int) :: fleet_rc(6)
+
+  call set_defaults()
+  call warn_reset()
+  aborted = .false.
 
   ! ---- read ./INPUT exactly like drt.f:220-231 ----
   open(newunit=u11, file='INPUT', status='old', iostat=ios)
   if (ios == 0) then
     read(u11, input, iostat=ios)
-    if (ios /= 0) stop 'error: namelist block $INPUT not found'
+    if (ios /= 0) then
+      write(0, '(a)') 'error: namelist block $INPUT not found'
+      call leave(); return
+    end if
     read(u11, dinput, iostat=ios)
     close(u11)
   else
     write(*, input)
-    stop
+    call leave(); return
   end if
 
   call check_input()
+  if (aborted) return
   if (iout /= 2) fmt = find_format(iout, known)
   if (iout == 2) known = .true.
   if (.not. known) call fatal('this IOUT is not an output format of the hot path (1,2,5,6,7,10,11,20,21,22,23)')
@@ -133,7 +160,7 @@ program sbdart_amd
         end if
       end do
     end if
-    stop
+    call leave(); return
   end if
   sensor = new_filter(isat, wlinf, wlsup)            ! setfilt: the sensor's response and its wavelength limits
   grid = new_grid(sensor%wlmin, sensor%wlmax, wlinc)
@@ -149,12 +176,13 @@ program sbdart_amd
     call tables_load(ok, why)
     if (.not. ok) call fatal('band-model tables not found; tried'//trim(why))
     call gas_depth_report(model, grid)
-    stop
+    call leave(); return
   end if
 
   ! ---- per-work-item optical properties: optics file if there is one, else the band model ----
   call get_environment_variable('SBD_OPTICS', path, plen, pstat)
   if (pstat /= 0 .or. plen <= 0) path = 'OPTICS.sbdrec'
+  if (phase == 2) path = items_file                     ! batch mode: the work items phase 1 left in the run's directory
   inquire(file=trim(path), exist=have_file)
   if (have_file) then
     call read_optics(trim(path), recs, nrec)
@@ -163,6 +191,7 @@ program sbdart_amd
     allocate(zlev(nz), plev(nz))
     call get_environment_variable('SBD_ATMOS', path, plen, pstat)
     if (pstat /= 0 .or. plen <= 0) path = 'ATMOS.sbdatm'
+    if (phase == 2) path = items_file//'.atm'
     call read_atmosphere(trim(path), nz, zlev, plev, have_atm)
   else
     call fill_model()
@@ -195,6 +224,10 @@ program sbdart_amd
   end if
   nmom = maxval(recs(1:nrec)%nmom)
   call get_environment_variable('SBD_DUMP_OPTICS', path, plen, pstat)      ! the work items, for inspection / tests
+  if (phase == 1) then                                  ! batch mode: hand the work items to the process that solves
+    path = items_file; plen = len(items_file); pstat = 0
+    if (have_atm) call write_atmosphere(items_file//'.atm', nz, zlev, plev)
+  end if
   if (pstat == 0 .and. plen > 0) then
     if (from_model) then
       call write_optics(trim(path), recs, nrec, bdtauc, bssalb, bpmom, btemper, umu(1:numu), &
@@ -202,7 +235,7 @@ program sbdart_amd
     else
       call write_optics(trim(path), recs, nrec)
     end if
-    stop
+    call leave(); return
   end if
 
   ! the spectral grid of INPUT must be the one the optics were made for (wllimits, drt.f:1657-1740)
@@ -326,9 +359,10 @@ program sbdart_amd
   !  mode itself through sbd_run_cfg::ibcnd.)
   if (ibcnd /= 1) then
     call solve_part(1, ncorr, .true., corint)
-    call solve_part(ncorr + 1, nbeam, .true., .false.)
-    call solve_part(nbeam + 1, npart, .false., .false.)
-    call release_fleets()
+    if (.not. aborted) call solve_part(ncorr + 1, nbeam, .true., .false.)
+    if (.not. aborted) call solve_part(nbeam + 1, npart, .false., .false.)
+    if (phase == 0) call release_fleets()               ! (a batch keeps its fleets for the runs that follow)
+    if (aborted) return
   end if
   call system_clock(tick2)
   call get_environment_variable('SBD_TIMING', path, plen, pstat)
@@ -355,9 +389,15 @@ program sbdart_amd
         end if
       end if
     end do
-    if (fatal_at == 0) call warn_file(0, 'DISORT--input and/or dimension errors')
+    if (fatal_at == 0) then
+      call warn_file(0, 'DISORT--input and/or dimension errors', phase == 0)
+      call leave(); return
+    end if
   end if
-  if (iand(stall, SBD_ST_ERR_EIGEN) /= 0) call warn_file(0, 'ASYMTX--convergence problems')
+  if (iand(stall, SBD_ST_ERR_EIGEN) /= 0) then
+    call warn_file(0, 'ASYMTX--convergence problems', phase == 0)
+    call leave(); return
+  end if
   if (iand(stall, SBD_ST_WARN_SOLVE0) /= 0) call warn_file(2, 'SOLVE0--SGBCO says matrix near singular')
   if (iand(stall, SBD_ST_WARN_UPBEAM) /= 0) call warn_file(3, 'UPBEAM--SGECO says matrix near singular')
   if (iand(stall, SBD_ST_WARN_UPISOT) /= 0) call warn_file(4, 'UPISOT--SGECO says matrix near singular')
@@ -403,7 +443,10 @@ program sbdart_amd
         if (recs(i1)%kd == recs(i1)%nk .and. recs(i1)%ib == 1) exit
         i1 = i1 + 1
       end do
-      if (fatal_at >= i0 .and. fatal_at <= i1) call input_stop(fatal_at)
+      if (fatal_at >= i0 .and. fatal_at <= i1) then
+        call input_stop(fatal_at)
+        call leave(); return
+      end if
       call sums_clear(sums)
       sums%width_eq = 0; sums%width_full = 0
       do i = i0, i1
@@ -425,7 +468,10 @@ program sbdart_amd
     !  the association of the sums, hence their last bits, follows the part split and the number of GPUs.
     !  SBD_ORDERED_SUMS=1 adds the per-item outputs here instead, in the reference's wavelength order
     !  (drt.f:964-1054): bit-reproducible on any number of devices)
-    if (fatal_at > 0) call input_stop(fatal_at)
+    if (fatal_at > 0) then
+      call input_stop(fatal_at)
+      call leave(); return
+    end if
     call get_environment_variable('SBD_ORDERED_SUMS', path, plen, pstat)
     if (pstat == 0 .and. plen > 0 .and. path(1:1) /= '0') then
       do i = 1, nrec
@@ -452,6 +498,31 @@ program sbdart_amd
   end if
 
 contains
+
+  ! the end of a run before its last line: a single run stops the process as the reference does; a run of a batch
+  ! only marks itself finished and the caller RETURNs (every call is followed by one)
+  subroutine leave()
+    aborted = .true.
+    if (phase == 0) stop
+  end subroutine
+
+  subroutine set_defaults()                            ! drt.f:144-198: the namelist's defaults
+    idatm = 4; isat = 0; nf = 2; iday = 0; isalb = 0; krhclr = 0; jaer = 0; iaer = 0
+    nothrm = -1; nosct = 0; kdist = 3; ngrid = 0; idb = 0; iout = 10; nstr = 0; nzen = 0
+    nphi = 0; imomc = 3; imoma = 3; ibcnd = 0; ipth = 0
+    amix = unset; wlinf = real(.55, kr); wlsup = real(.55, kr); wlinc = 0; sza = 0; csza = unset; solfac = 1
+    time = 16; alat = real(-64.767, kr); alon = real(-64.067, kr); zpres = unset; pbar = unset; sclh2o = unset
+    uw = unset; uo3 = unset; o3trp = unset; ztrp = 0; xrsc = 1; xn2 = unset; xo2 = unset; xco2 = unset; xch4 = unset
+    xn2o = unset; xco = unset; xno2 = unset; xso2 = unset; xnh3 = unset; xno = unset; xhno3 = unset; xo4 = 1
+    albcon = 0; sc = huge(0.); zcloud = 0; tcloud = 0; lwp = 0; nre = 8
+    rhcld = unset; zaer = 0; taerst = 0; vis = unset; rhaer = unset; tbaer = unset
+    wlbaer = unset; qbaer = unset; abaer = 0; wbaer = unset; gbaer = unset
+    pmaer = unset; zbaer = unset; dbaer = unset; zgrid1 = 1; zgrid2 = 30
+    zout = (/0._kr, 100._kr/); temis = 0; uzen = unset; vzen = 90; phi = unset
+    saza = 180; ttemp = unset; btemp = unset; phi0 = 0; fisot = 0
+    prnt = .false.; corint = .false.; spowder = .false.
+    from_model = .false.
+  end subroutine
 
   subroutine fill_model()                              ! the &INPUT variables the band model reads
     model%idatm = idatm; model%nf = nf; model%isalb = isalb; model%kdist = kdist; model%nothrm = nothrm
@@ -494,7 +565,6 @@ contains
   ! with its messages and stop the run; two combinations only warn (errmsg 16/17).  One rule per line:
   ! the condition that makes the value unacceptable, the name and the range text that are printed.
   subroutine check_input()
-    integer :: nbad
     nbad = 0
     if (iaer == 0 .and. (vis /= unset .or. tbaer /= unset)) call warn_file(16, 'CHKIN--IAER=0, though VIS or TBAER set')
     if (corint .and. .not. any(iout == (/5, 6, 20, 21, 22, 23/))) &
@@ -539,34 +609,35 @@ contains
       write(*, *) 'set TCLOUD or LWP, but not both'
       nbad = nbad + 1
     end if
-    if (nbad > 0) stop
-  contains
-    subroutine rule(violated, name, range, echo)
-      logical, intent(in) :: violated
-      character(len=*), intent(in) :: name, range, echo
-      if (.not. violated) return
-      if (nbad == 0) print '(a)', 'CHKIN --- Errors detected in INPUT'
-      print '(/5x,4a)', 'Input parameter ', name, ' not within ', range
-      print '(a)', echo
-      nbad = nbad + 1
-    end subroutine
-    function iv(label, v) result(t)                 ! "label value(s)" as list-directed output prints it
-      character(len=*), intent(in) :: label
-      integer, intent(in) :: v(:)
-      character(len=:), allocatable :: t
-      character(len=512) :: buf
-      write(buf, *) label, v
-      t = trim(buf)
-    end function
-    function rv(label, v) result(t)
-      character(len=*), intent(in) :: label
-      real(kr), intent(in) :: v(:)
-      character(len=:), allocatable :: t
-      character(len=2048) :: buf
-      write(buf, *) label, v
-      t = trim(buf)
-    end function
+    if (nbad > 0) call leave()
   end subroutine
+
+  ! (helpers of check_input; flang takes no internal procedure inside an internal procedure of a module procedure)
+  subroutine rule(violated, name, range, echo)
+    logical, intent(in) :: violated
+    character(len=*), intent(in) :: name, range, echo
+    if (.not. violated) return
+    if (nbad == 0) print '(a)', 'CHKIN --- Errors detected in INPUT'
+    print '(/5x,4a)', 'Input parameter ', name, ' not within ', range
+    print '(a)', echo
+    nbad = nbad + 1
+  end subroutine
+  function iv(label, v) result(t)                   ! "label value(s)" as list-directed output prints it
+    character(len=*), intent(in) :: label
+    integer, intent(in) :: v(:)
+    character(len=:), allocatable :: t
+    character(len=512) :: buf
+    write(buf, *) label, v
+    t = trim(buf)
+  end function
+  function rv(label, v) result(t)
+    character(len=*), intent(in) :: label
+    real(kr), intent(in) :: v(:)
+    character(len=:), allocatable :: t
+    character(len=2048) :: buf
+    write(buf, *) label, v
+    t = trim(buf)
+  end function
 
   ! index of the level nearest to altitude zq in the bottom-up altitudes (ties: the lower level)
   integer function nearest_level(z, zq) result(k)
@@ -606,19 +677,26 @@ contains
     end do
   end subroutine
 
-  ! the fleet for stream count ns with / without the intensity corrections: created once per run and reused by
-  ! the parts that ask for the same pair (engines, workspaces and the communicator are the expensive part of a
-  ! small run); rc as sbd_fleet_create returned it the first time
+  ! the fleet for stream count ns with / without the intensity corrections: created once and found again by
+  ! EVERYTHING sbd_fleet_create reads (engines, workspaces and the communicator are the expensive part of a small
+  ! run) -- by the parts of a run, and in a batch by the runs that follow; rc as sbd_fleet_create returned it
   function fleet_for(ns, corr, rc) result(fl)
     integer, intent(in) :: ns
     logical, intent(in) :: corr
     integer(c_int), intent(out) :: rc
     type(c_ptr) :: fl
     type(sbd_run_cfg) :: cfg
-    integer :: k
-    do k = 1, nfleet
-      if (fleet_ns(k) == ns .and. (fleet_corr(k) .eqv. corr)) then
-        fl = fleets(k); rc = fleet_rc(k)
+    real(kr), allocatable :: key(:)
+    integer :: k, oldest
+    key = (/real(ns, kr), merge(1._kr, 0._kr, corr), real(nz, kr), real(nmom, kr), merge(1._kr, 0._kr, radcalc), &
+            real(recs(1)%ibdrf, kr), real(numu, kr), real(merge(view%nphi, 0, radcalc), kr), real(nlev, kr), &
+            recs(1)%umu0, phi0, fisot, btemp, ttemp, temis, recs(1)%bpar, temper, umu(1:max(numu, 0)), &
+            phiv(1:merge(view%nphi, 0, radcalc)), real(level_out, kr)/)
+    clock = clock + 1
+    do k = 1, nslot
+      if (size(slots(k)%key) /= size(key) .or. slots(k)%max_batch < npart) cycle
+      if (all(slots(k)%key == key)) then
+        fl = slots(k)%fleet; rc = slots(k)%rc; slots(k)%age = clock
         return
       end if
     end do
@@ -629,7 +707,9 @@ contains
     cfg%lamber = merge(1, 0, recs(1)%ibdrf == 0)       ! a bidirectional surface: ISALB 7, 8, 9 (drt.f:468-470)
     cfg%ibdrf = recs(1)%ibdrf; cfg%bpar = recs(1)%bpar
     cfg%numu = numu; cfg%nphi = merge(view%nphi, 0, radcalc)
-    cfg%nlevel_out = nlev; cfg%device = 0; cfg%max_batch = max(1, npart)
+    cfg%nlevel_out = nlev; cfg%device = 0
+    cfg%max_batch = max(1, npart)
+    if (phase == 2) cfg%max_batch = max(256, npart)    ! (a batch's later runs of this configuration may be longer)
     cfg%corint = merge(1, 0, corr)
     cfg%umu0 = recs(1)%umu0; cfg%phi0 = phi0; cfg%fisot = fisot
     cfg%btemp = btemp; cfg%ttemp = ttemp; cfg%temis = temis
@@ -642,8 +722,19 @@ contains
     end if
     if (rc /= SBD_OK .and. rc /= SBD_E_RETRY_NSTR) &
       call fatal('sbd_fleet_create: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
-    nfleet = nfleet + 1
-    fleets(nfleet) = fl; fleet_ns(nfleet) = ns; fleet_corr(nfleet) = corr; fleet_rc(nfleet) = rc
+    if (nslot < max_fleets) then
+      nslot = nslot + 1
+      k = nslot
+    else                                               ! full: the fleet used longest ago makes room
+      oldest = 1
+      do k = 2, nslot
+        if (slots(k)%age < slots(oldest)%age) oldest = k
+      end do
+      k = oldest
+      if (c_associated(slots(k)%fleet)) call sbd_fleet_destroy(slots(k)%fleet)
+    end if
+    slots(k)%fleet = fl; slots(k)%rc = rc; slots(k)%max_batch = int(cfg%max_batch); slots(k)%age = clock
+    slots(k)%key = key
   end function
 
   ! CHEKIN's report on a bidirectional surface whose flux albedo leaves [0,1] (disort.f:5080-5096: 101 incidence
@@ -653,7 +744,7 @@ contains
     use sbd_surface_mod, only: surface_model, flux_albedo
     integer, intent(in) :: k
     type(surface_model) :: sm
-    integer :: irmu, lc, km, ipk, row, nbad
+    integer :: irmu, lc, km, ipk, row
     real(kr) :: rmu, flxalb
     ! CHEKIN's reports on the layer arrays come first, in its order (disort.f:4947-4953: the albedo and its layer,
     ! then the variable's name, per offending layer; disort.f:4975-4982: one line per offending moment; the 50th
@@ -676,7 +767,10 @@ contains
         end do
       end do
     end if
-    if (recs(k)%ibdrf == 0) call warn_file(0, 'DISORT--input and/or dimension errors')
+    if (recs(k)%ibdrf == 0) then
+      call warn_file(0, 'DISORT--input and/or dimension errors', phase == 0)
+      return
+    end if
     sm%ibdrf = recs(k)%ibdrf; sm%par = recs(k)%bpar
     do irmu = 0, 100
       rmu = real(irmu*0.01, kr)                         ! (IRMU*0.01 in default real, as the reference types it)
@@ -687,22 +781,17 @@ contains
         call write_bad('FUNCTION BDREF')
       end if
     end do
-    call warn_file(0, 'DISORT--input and/or dimension errors')
-  contains
-    subroutine write_bad(name)
-      character(len=*), intent(in) :: name
-      write(*, '(3a)') ' ****  Input variable  ', name, '  in error  ****'
-      nbad = nbad + 1
-      if (nbad == 50) call warn_file(12, 'Too many input errors.  Aborting...')
-    end subroutine
+    call warn_file(0, 'DISORT--input and/or dimension errors', phase == 0)
+  end subroutine
+  subroutine write_bad(name)
+    character(len=*), intent(in) :: name
+    write(*, '(3a)') ' ****  Input variable  ', name, '  in error  ****'
+    nbad = nbad + 1
+    if (nbad == 50) call warn_file(12, 'Too many input errors.  Aborting...')
   end subroutine
 
   subroutine release_fleets()
-    integer :: k
-    do k = 1, nfleet
-      call sbd_fleet_destroy(fleets(k))
-    end do
-    nfleet = 0
+    call release_all_fleets()
   end subroutine
 
   ! solve batch positions p0..p1 on the run's GPUs; per-run formats also get their weighted sums
@@ -729,7 +818,7 @@ contains
     end do
     if (.not. c_associated(fleet)) then
       write(*, *) 'Error --- NSTR dithering procedure failed'
-      stop
+      call leave(); return
     end if
     bin%nwork = p1 - p0 + 1
     bin%dtauc = c_loc(dtauc(1, p0)); bin%ssalb = c_loc(ssalb(1, p0)); bin%pmom = c_loc(pmom(0, 1, p0))
@@ -751,4 +840,188 @@ contains
     rc = sbd_fleet_solve_host(fleet, bin, bout, wptr, aptr, uptr)
     if (rc /= SBD_OK) call fatal('sbd_fleet_solve_host: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
   end subroutine
+end subroutine run_once
+
+subroutine release_all_fleets()
+  use iso_c_binding
+  use sbd_engine_mod
+  use sbd_fleet_cache_mod
+  integer :: k
+  do k = 1, nslot
+    if (c_associated(slots(k)%fleet)) call sbd_fleet_destroy(slots(k)%fleet)
+    slots(k)%fleet = c_null_ptr
+    if (allocated(slots(k)%key)) deallocate(slots(k)%key)
+  end do
+  nslot = 0
+end subroutine
+
+! sbdart_amd --batch LIST: every directory of LIST (one per line, each with its INPUT) is one run; its text goes to
+! SBDART.stdout in that directory, warning files beside it as always.  A pool of worker processes (forked before this
+! process touches the GPU) runs phase 1 of the runs, a child per run -- the reference's own process-per-run isolation,
+! STOPs included, at the price of a fork; this process owns the GPU and runs phase 2 of the runs in LIST order as their
+! work items arrive.
+subroutine run_batch(listfile)
+  use iso_c_binding
+  use sbd_tables_mod, only: tables_load
+  use omp_lib
+  character(len=*), intent(in) :: listfile
+  interface
+    integer(c_int) function sbd_px_chdir(path) bind(C, name='sbd_px_chdir')
+      import; character(kind=c_char), intent(in) :: path(*)
+    end function
+    integer(c_int) function sbd_px_stdout_to(path, append) bind(C, name='sbd_px_stdout_to')
+      import; character(kind=c_char), intent(in) :: path(*); integer(c_int), value :: append
+    end function
+    integer(c_int) function sbd_px_stderr_to(path) bind(C, name='sbd_px_stderr_to')
+      import; character(kind=c_char), intent(in) :: path(*)
+    end function
+    integer(c_int) function sbd_px_fork() bind(C, name='sbd_px_fork')
+      import
+    end function
+    integer(c_int) function sbd_px_wait(pid) bind(C, name='sbd_px_wait')
+      import; integer(c_int), value :: pid
+    end function
+    subroutine sbd_px_exit_now(code) bind(C, name='sbd_px_exit_now')
+      import; integer(c_int), value :: code
+    end subroutine
+    integer(c_int) function sbd_px_exists(path) bind(C, name='sbd_px_exists')
+      import; character(kind=c_char), intent(in) :: path(*)
+    end function
+    integer(c_int) function sbd_px_remove(path) bind(C, name='sbd_px_remove')
+      import; character(kind=c_char), intent(in) :: path(*)
+    end function
+    integer(c_int) function sbd_px_touch(path, value) bind(C, name='sbd_px_touch')
+      import; character(kind=c_char), intent(in) :: path(*); integer(c_int), value :: value
+    end function
+    subroutine sbd_px_usleep(us) bind(C, name='sbd_px_usleep')
+      import; integer(c_int), value :: us
+    end subroutine
+    integer(c_int) function sbd_px_ncpu() bind(C, name='sbd_px_ncpu')
+      import
+    end function
+    integer(c_int) function sbd_px_getcwd(buf, n) bind(C, name='sbd_px_getcwd')
+      import; character(kind=c_char) :: buf(*); integer(c_int), value :: n
+    end function
+  end interface
+  character(len=1024), allocatable :: dirs(:)
+  character(len=1024) :: line, home
+  character(len=16) :: txt
+  integer :: u, ios, nrun, i, k, nw, tlen, tstat, waited
+  integer(c_int) :: pid, cpid, rc
+  integer(c_int), allocatable :: wpid(:)
+  logical :: ok, phase1_only
+  character(len=256) :: why
+
+  call get_environment_variable('SBD_BATCH_PHASE1_ONLY', txt, tlen, tstat)
+  phase1_only = tstat == 0 .and. tlen > 0
+  k = sbd_px_getcwd(home, int(len(home), c_int))
+  if (k < 0) stop 'sbdart_amd --batch: getcwd failed'
+  home = home(1:k)
+  open(newunit=u, file=listfile, status='old', iostat=ios)
+  if (ios /= 0) stop 'sbdart_amd --batch: cannot open the list of run directories'
+  nrun = 0
+  do
+    read(u, '(a)', iostat=ios) line
+    if (ios /= 0) exit
+    if (len_trim(line) > 0) nrun = nrun + 1
+  end do
+  rewind(u)
+  allocate(dirs(nrun))
+  i = 0
+  do
+    read(u, '(a)', iostat=ios) line
+    if (ios /= 0) exit
+    if (len_trim(line) == 0) cycle
+    i = i + 1
+    line = adjustl(line)
+    if (line(1:1) == '/') then
+      dirs(i) = line
+    else
+      dirs(i) = trim(home)//'/'//trim(line)
+    end if
+  end do
+  close(u)
+  do i = 1, nrun                                        ! (markers of an earlier batch in the same directories)
+    k = sbd_px_remove(trim(dirs(i))//'/'//phase1_mark//c_null_char)
+    k = sbd_px_remove(trim(dirs(i))//'/'//items_file//c_null_char)
+  end do
+  call tables_load(ok, why)                             ! once, before the fork: the children inherit the tables
+  nw = min(max(1, int(sbd_px_ncpu()) - 1), 16, max(1, nrun))
+  call get_environment_variable('SBD_BATCH_WORKERS', txt, tlen, tstat)
+  if (tstat == 0 .and. tlen > 0) read(txt(1:tlen), *, iostat=ios) nw
+  nw = max(1, min(nw, max(1, nrun)))
+  allocate(wpid(nw))
+  flush(6)
+  do k = 1, nw
+    pid = sbd_px_fork()
+    if (pid < 0) stop 'sbdart_amd --batch: fork failed'
+    if (pid == 0) then                                  ! worker k: runs k, k+nw, ... -- a child per run
+      call omp_set_num_threads(1)                       ! (the pool is the parallelism; a child's band model runs on one core)
+      do i = k, nrun, nw
+        cpid = sbd_px_fork()
+        if (cpid == 0) then
+          if (sbd_px_chdir(trim(dirs(i))//c_null_char) /= 0) call sbd_px_exit_now(3_c_int)
+          if (sbd_px_stdout_to(stdout_file//c_null_char, 0_c_int) /= 0) call sbd_px_exit_now(3_c_int)
+          if (sbd_px_stderr_to(stderr_file//c_null_char) /= 0) call sbd_px_exit_now(3_c_int)
+          call run_once(1)
+          flush(6)
+          call sbd_px_exit_now(0_c_int)
+        end if
+        rc = -1
+        if (cpid > 0) rc = sbd_px_wait(cpid)
+        if (sbd_px_touch(trim(dirs(i))//'/'//phase1_mark//c_null_char, rc) /= 0) continue
+      end do
+      call sbd_px_exit_now(0_c_int)
+    end if
+    wpid(k) = pid
+  end do
+  ! this process: the GPU side, runs in order
+  do i = 1, nrun
+    waited = 0
+    do while (sbd_px_exists(trim(dirs(i))//'/'//phase1_mark//c_null_char) == 0)
+      call sbd_px_usleep(100_c_int)
+      waited = waited + 1
+      if (waited > 6000000) stop 'sbdart_amd --batch: a run never finished its first phase'
+    end do
+    if (phase1_only) cycle                              ! (tests without a GPU: the work items stay where phase 1 left them)
+    if (sbd_px_exists(trim(dirs(i))//'/'//items_file//c_null_char) /= 0) then
+      if (sbd_px_chdir(trim(dirs(i))//c_null_char) /= 0) stop 'sbdart_amd --batch: cannot enter a run directory'
+      flush(6)
+      if (sbd_px_stdout_to(stdout_file//c_null_char, 1_c_int) /= 0) stop 'sbdart_amd --batch: cannot append to SBDART.stdout'
+      call run_once(2)
+      flush(6)
+      k = sbd_px_remove(items_file//c_null_char)
+      k = sbd_px_remove(items_file//'.atm'//c_null_char)
+    end if
+    k = sbd_px_remove(trim(dirs(i))//'/'//phase1_mark//c_null_char)
+  end do
+  do k = 1, nw
+    rc = sbd_px_wait(wpid(k))
+  end do
+  call release_all_fleets()
+  k = sbd_px_chdir(trim(home)//c_null_char)
+end subroutine
+
+end module sbd_run_mod
+
+program sbdart_amd
+  use sbd_run_mod
+  implicit none
+  character(len=1024) :: arg, list
+  integer :: n
+  n = command_argument_count()
+  if (n >= 2) then
+    call get_command_argument(1, arg)
+    if (trim(arg) == '--batch') then
+      call get_command_argument(2, list)
+      call run_batch(trim(list))
+      stop
+    end if
+  end if
+  if (n >= 1) then
+    write(0, '(a)') 'usage: sbdart_amd            (one run: ./INPUT -> stdout, as the reference)'
+    write(0, '(a)') '       sbdart_amd --batch LIST   (LIST: run directories, one per line; text -> <dir>/SBDART.stdout)'
+    stop 2
+  end if
+  call run_once(0)
 end program sbdart_amd

@@ -104,6 +104,43 @@ class Sweep:
         return outs
 
 
+    def run_batch(self, exe: str, workdir: str, env: Optional[Dict[str, str]] = None, prepare=None) -> List[str]:
+        """The same runs through ONE process: `exe --batch LIST` (sbdart_amd's batch mode: the GPU runtime comes up
+        once, engines are kept and found again by configuration, phase 1 of the runs -- INPUT to work items -- in a
+        pool of forked children).  Every run keeps its own directory and finds its text in SBDART.stdout there;
+        returns those texts in iteration order, byte for byte what `run` returns."""
+        dirs = []
+        for it in range(len(self)):
+            d = os.path.join(workdir, f"run{it:04d}")
+            os.makedirs(d, exist_ok=True)
+            body, _ = self.inputs(it)
+            with open(os.path.join(d, "INPUT"), "w") as f:
+                f.write("\n &INPUT\n" + body + " /\n")
+            if prepare is not None:
+                prepare(d, body)
+            dirs.append(os.path.abspath(d))
+        return run_directories(exe, dirs, workdir, env)
+
+
+def run_directories(exe: str, dirs: Sequence[str], workdir: str, env: Optional[Dict[str, str]] = None) -> List[str]:
+    """`exe --batch LIST` over run directories that already hold their INPUT; the texts of SBDART.stdout."""
+    lst = os.path.join(workdir, "batch.list")
+    with open(lst, "w") as f:
+        f.write("\n".join(dirs) + "\n")
+    for d in dirs:
+        for name in ("SBDART.stdout", "SBDART.stderr"):
+            if os.path.exists(os.path.join(d, name)):
+                os.remove(os.path.join(d, name))
+    p = subprocess.run([exe, "--batch", lst], cwd=workdir, env=env, capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError(f"{exe} --batch failed: {p.stderr.strip()[-2000:]}")
+    outs = []
+    for d in dirs:
+        with open(os.path.join(d, "SBDART.stdout")) as f:
+            outs.append(f.read())
+    return outs
+
+
 FLUX_KEYS = ("TOPDN", "TOPUP", "TOPDIR", "BOTDN", "BOTUP", "BOTDIR")
 
 

@@ -212,8 +212,10 @@ def run_reference_and_host(namelist, d, sums=False, from_input=False, files=None
 def test_host_reproduces_sbchk3_and_sbchk4_in_full(tmp_path):
     """TestRuns examples 3 (thermal, three cloud cases, 161 wavelengths each) and 4 (126 single-
     wavelength runs up to optical depth 128) replayed completely: the reference runs on the box,
-    the host gets the optics it used and must print what the reference printed -- and what
-    TestRuns/sbchk.3 holds (tests/golden/sbchk3.stdout is that file)."""
+    the host gets the optics it used and must print what the reference printed on the box -- which is
+    tests/golden/sbchk3.stdout, the amdflang rebuild's print of these runs (NOT the authors' file: that one is
+    tests/golden/shipped/sbchk.3.gz, differing in cancellation-noise fields; tests/test_shipped_goldens.py compares
+    both the rebuild and the engine with it)."""
     _build()
     man = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
     ref_all, got_all = "", ""
