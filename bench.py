@@ -141,21 +141,62 @@ MI355X_SIMDS = 256 * 4         # CUs x SIMDs
 MI355X_CLOCK_HZ = 2.4e9        # peak engine clock (MI355X_MICROARCH.md)
 
 
-def valu_issue(W, step_s, nstr, nlyr):
+PROFILE_TAG = "r04"
+
+
+def load_profile(kind, nstr, nlyr, shape=""):
+    """profiles/<tag>[_<shape>]_<kind>.json (kind: "valu" | "traffic") -- counters recorded in their own rocprofv3 --pmc
+    passes (tools/profile_round.sh), NOT observations of this run.  Used only when recorded for THESE kernel sources
+    (kernel_source_hash) and this shape; otherwise (None, why) -- a stale profile must not dress up a new kernel."""
+    from sbdart_amd._srchash import kernel_source_hash
+    name = f"{PROFILE_TAG}{'_' + shape if shape else ''}_{kind}.json"
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None, f"profiles/{name} missing"
+    if d.get("nstr") != nstr or d.get("nlyr") != nlyr:
+        return None, f"profiles/{name} is for another shape"
+    if d.get("kernel_source_hash") != kernel_source_hash():
+        return None, (f"profiles/{name} was recorded for kernel sources {d.get('kernel_source_hash')}, "
+                      f"these are {kernel_source_hash()}: stale, not used")
+    return d, f"profiles/{name} (kernel sources {d['kernel_source_hash']})"
+
+
+def valu_issue(W, step_s, nstr, nlyr, shape=""):
     """Executed-instruction occupancy of the vector ALUs over the timed step: VALU wave-instructions per solve
     (rocprofv3 --pmc SQ_INSTS_VALU of this command, committed under profiles/ like the traffic figures) x the
     step's solves x 4 issue cycles per wave64 instruction / (1 024 SIMDs x 2.4 GHz x the step's time)."""
-    try:
-        vp = json.load(open(os.path.join(ROOT, "profiles", "r03_valu.json")))
-        if vp.get("nstr") != nstr or vp.get("nlyr") != nlyr:
-            return None
-        per_solve = sum(k["valu_wave_insts_per_solve"] for k in vp["kernels"].values())
-        frac = per_solve * W * 4.0 / (MI355X_SIMDS * MI355X_CLOCK_HZ * step_s)
-        return {"valu_wave_insts_per_solve": per_solve, "issue_cycles_per_inst": 4,
-                "frac_of_step": frac, "source": "profiles/r03_valu.json (SQ_INSTS_VALU, separate PMC pass)",
-                "per_kernel": {k: v["valu_wave_insts_per_solve"] for k, v in vp["kernels"].items()}}
-    except Exception:
-        return None
+    vp, src = load_profile("valu", nstr, nlyr, shape)
+    if vp is None:
+        return {"valu_wave_insts_per_solve": None, "source": src}
+    per_solve = sum(k["valu_wave_insts_per_solve"] for k in vp["kernels"].values())
+    frac = per_solve * W * 4.0 / (MI355X_SIMDS * MI355X_CLOCK_HZ * step_s)
+    return {"valu_wave_insts_per_solve": per_solve, "issue_cycles_per_inst": 4,
+            "frac_of_step": frac, "source": src + " (SQ_INSTS_VALU, separate PMC pass)",
+            "per_kernel": {k: v["valu_wave_insts_per_solve"] for k, v in vp["kernels"].items()}}
+
+
+def shape_roofline(names, phase_ms, nlaunch, pass_size, W, nstr, nlyr, nlev, shape="", extra_out_bytes=0):
+    """The `roofline` object for the kernel that takes the most time: algorithmic bytes over its time."""
+    dom = int(np.argmax(phase_ms))
+    abytes = algorithmic_bytes_per_solve(nlyr, nstr, nlev) + extra_out_bytes
+    ach = abytes * W / (phase_ms[dom] * 1e-3) / 1e9
+    traffic = None
+    tp, src = load_profile("traffic", nstr, nlyr, shape)
+    if tp is not None and tp.get("solves_per_launch") == pass_size:
+        key = {"layer_kernel": "layer_kernel2", "band_kernel": ("band4_kernel", "band1_kernel", "band_kernel")}.get(names[dom], names[dom])
+        keys = key if isinstance(key, tuple) else (key,)
+        for kname, kd in tp["kernels"].items():
+            if any(k in kname for k in keys):
+                traffic = (traffic or 0.0) + kd["bytes_per_launch"]
+    elif tp is not None:
+        src = f"{src}: recorded at {tp.get('solves_per_launch')} solves per launch, this run has {pass_size}"
+    return {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_unit": f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE; {src})",
+            "algorithmic_bytes_per_solve": abytes, "solves_per_launch": pass_size, "launches": nlaunch,
+            "avg_launch_ms": float(phase_ms[dom] / max(1, nlaunch))}
 
 
 def latency_case(device):
@@ -236,10 +277,19 @@ def other_shapes(dev):
             kms = [eng.last_ms(p) for p in range(5)]
             fb = eng.last_fallback_layers()
             finite = bool(torch.isfinite(flux).all().item()) and (uu is None or bool(torch.isfinite(uu).all().item()))
+            names = ["setup_kernel", "layer_kernel", "band_kernel", "backsolve_kernel", "usrint+azimuth"]
+            nl = max(1, (sw.nwork + eng.chunk - 1) // eng.chunk)
+            if nl == 1 and sw.nwork >= 16384:
+                nl = 2
+            nl += nl > 1 and nl % 2
+            shape = "cfgC" if rad else "cfgD"
             out[name] = {"value": sw.nwl / dt if finite else None, "unit": "spectral-points/s", "ms_per_step": 1e3 * dt,
                          "nwl": sw.nwl, "solves": sw.nwork, "nstr": sw.nstr, "nlyr": sw.nlyr,
                          "kernel_ms": dict(zip(["setup", "layer", "band", "backsolve", "usrint+azimuth"], map(float, kms))),
-                         "nonzero_status": int((st != 0).sum().item()), "fallback_layers": int(fb), "finite": finite}
+                         "nonzero_status": int((st != 0).sum().item()), "fallback_layers": int(fb), "finite": finite,
+                         "roofline": shape_roofline(names, np.array(kms), nl, (sw.nwork + nl - 1) // nl, sw.nwork, sw.nstr,
+                                                    sw.nlyr, 2, shape, extra_out_bytes=8 * 20 * 16 if rad else 0),
+                         "valu_issue": valu_issue(sw.nwork, dt, sw.nstr, sw.nlyr, shape)}
             eng.close()
         except Exception as ex:   # a side line must not take the headline down
             out[name] = {"value": None, "error": repr(ex)}
@@ -407,28 +457,15 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = nwl_total * args.steps / elapsed
         names = ["setup_kernel", "layer_kernel", "band_kernel", "backsolve_kernel", "usrint+azimuth"]
-        dom = int(np.argmax(phase_ms))
         abytes = algorithmic_bytes_per_solve(sw.nlyr, sw.nstr, eng.nlev)
         nlaunch = (W + eng.chunk - 1) // eng.chunk          # the engine's rule (sbd_engine_solve_device): an even
         if nlaunch == 1 and W >= 16384:                     # number of equal passes, alternating between its two
             nlaunch = 2                                     # workspaces / streams
         nlaunch += nlaunch > 1 and nlaunch % 2
         pass_size = (W + nlaunch - 1) // nlaunch
-        ach = abytes * W / (phase_ms[dom] * 1e-3) / 1e9
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes
-        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/make_traffic_profile.py)
-        # HBM bytes per launch of the dominant kernel: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-        # separate runs, tools/make_traffic_profile.py) of this command at this launch size
-        traffic, traffic_src = None, None
-        try:
-            tp = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
-            key = {"layer_kernel": "layer_kernel2", "band_kernel": "band4_kernel"}.get(names[dom], names[dom])
-            if tp.get("nstr") == sw.nstr and tp.get("nlyr") == sw.nlyr and tp.get("solves_per_launch") == pass_size:
-                for kname, kd in tp["kernels"].items():
-                    if key in kname:
-                        traffic, traffic_src = kd["bytes_per_launch"], "profiles/r03_traffic.json"
-        except Exception:
-            traffic = None
+        roof = shape_roofline(names, phase_ms, nlaunch, pass_size, W, sw.nstr, sw.nlyr, eng.nlev)
+        roof["note"] = ("latency/issue bound by construction (SURVEY 8d): ~5 KB of inputs per 2.5 MFLOP of pivoted fp64; the "
+                        "binding figure is valu_issue (executed VALU occupancy), beside it")
         flops = algorithmic_flops_per_solve(sw.nlyr, sw.nstr)
         out = {
             "metric": "spectral-points/sec (whole node) + flux RMSE vs CPU, 16-stream SW sweep",
@@ -456,13 +493,7 @@ def main():
             "incl_h2d_note": "same step through the host entry point (sbd_fleet_solve_host): inputs in pinned host memory, the passes' H2D back to back on a copy stream beside the kernels, sums on the device, D2H of sums + status",
             "nonzero_status": bad, "fallback_layers": fallback_layers,
             "kernel_ms": {names[i]: float(phase_ms[i]) for i in range(5)},
-            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {traffic_src})",
-                         "algorithmic_bytes_per_solve": abytes, "solves_per_launch": pass_size,
-                         "launches": nlaunch, "avg_launch_ms": float(phase_ms[dom] / nlaunch),
-                         "note": "latency/issue bound by construction (SURVEY 8d): ~5 KB of inputs per 2.5 MFLOP of "
-                                 "pivoted fp64; the binding figure is valu_issue (executed VALU occupancy), beside it"},
+            "roofline": roof,
         }
         out["valu_issue"] = valu_issue(W, elapsed / args.steps, sw.nstr, sw.nlyr)
         flux_h = flux.cpu().numpy()

@@ -154,6 +154,31 @@ typedef struct {
                           (usrang) or nstr/2 output cosines; flux comes back zero like DISORT's (ZEROAL) */
 } sbd_batch_out;
 
+/* The same batch in COMPACT form (ABI v5): per SPECTRAL POINT what scatters there, per WORK ITEM only the gas of its
+ * k-term -- the operands of the three statements with which the reference turns its band model's output into DISORT's
+ * arguments, which the engine then executes on the device (assemble_kernel) instead of receiving their results over
+ * PCIe:
+ *   DTAUC(l) = dtaug(item, l) + dtaux(point, l)                          depthscl, taugas.f:7625-7646 (dtaus)
+ *   SSALB(l) = (tsc_hg + tsc_ray)(point, l) / DTAUC(l), 0 where DTAUC is 0   taugas.f:7640-7646 (wreal)
+ *   PMOM(k, l) = (tsc_hg g**k + [k = 2] 0.1 tsc_ray) / (tsc_hg + tsc_ray), PMOM(0, l) = 1
+ *                                                                        GETMOM iphas 3 and 2 (disutil.f:2176-2188: g**k
+ *                                                                        with an integer power, the Rayleigh 0.1 as the
+ *                                                                        reference's REAL*4 literal), normom drt.f:1366-1397
+ * The moments are formed once per spectral point and shared by its k-terms (as sbd_batch_in::pmom_row).  Bytes over
+ * PCIe: 8 [W L + P (4 L + 4)] against 8 W L (nmom + 3) -- a ninth at NSTR 16 with nk = 2.67.
+ * Host entry points only (on the device side the assembled arrays ARE sbd_batch_in).  point_of non-decreasing. */
+typedef struct {
+    int32_t nwork, npoint;
+    const int32_t *point_of;  /* [nwork]        spectral point of each work item, 0-based, non-decreasing           */
+    const double *dtaug;      /* [nwork][nlyr]  absorption optical depth of the item's k-term (gases, dtaug)       */
+    const double *dtaux;      /* [npoint][nlyr] extinction optical depth of everything else: cloud + aerosol + Rayleigh */
+    const double *tsc_hg;     /* [npoint][nlyr] scattering optical depth of the particles (Henyey-Greenstein family)   */
+    const double *g_hg;       /* [npoint][nlyr] their asymmetry factor                                               */
+    const double *tsc_ray;    /* [npoint][nlyr] Rayleigh scattering optical depth (dtaur)                           */
+    const double *wvnmlo, *wvnmhi, *fbeam, *albedo;   /* [npoint] as in sbd_batch_in, per spectral point            */
+    const uint8_t *plank;     /* [npoint]                                                                           */
+} sbd_mix_in;
+
 /* ---- lifecycle ---- */
 int  sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out);
 void sbd_engine_destroy(sbd_engine *e);
@@ -198,6 +223,12 @@ int32_t  sbd_fleet_uses_rccl(const sbd_fleet *f);           /* 1: sums are reduc
 void     sbd_shard_range(int32_t nwork, int32_t nshard, int32_t rank, int32_t *lo, int32_t *hi);
 int      sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_out *out,
                               const double *weight, double *acc_flux, double *acc_uu);
+/* ... from the compact form (sbd_mix_in, HOST pointers): every pass stages its slice of the compact arrays and
+ * assembles DTAUC / SSALB / PMOM on the device ahead of its kernels.  A fleet of one device (the sharded form cuts
+ * between spectral points: not built yet -- SBD_E_UNSUPPORTED for more).  Lambertian surface or a bidirectional one
+ * without per-item constants (ibdrf 0, 2, 3). */
+int      sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_batch_out *out,
+                                  const double *weight, double *acc_flux, double *acc_uu);
 /* How the devices are fed (replaces nothing in the reference: its loop is serial, drt.f:425-561): every device's
  * shard is enqueued from a host thread of its own, and when the fleet spans several devices (or SBD_PIN_INPUTS=1)
  * dtauc / ssalb / pmom are page-locked for the duration of the call, so pageable arrays of the caller do not

@@ -12,12 +12,16 @@
 // window rows in registers: ONE array a[RW] per lane (96 VGPRs at NSTR = 32), against 33 KB of LDS per
 // wave in the LDS-window kernel it replaces (one wave per SIMD).  The right-hand side is a vector across
 // the lanes: lane p <-> window row p.  One sub-step J:
-//   * column J of the live rows (lane J's registers) crosses to the lanes through 384 bytes of LDS -- but NOT at the
-//     head of sub-step J: lane J wrote it, two rows per ds_write2_b64, BETWEEN the elimination FMAs of sub-step
-//     J-1, as soon as a pair of rows was final (round 4; a burst of 16-24 one-lane LDS writes at the head of
-//     every sub-step held the wave for ~300 cycles of LDS queue on its critical path -- PMC: SQ_WAIT_INST_LDS
-//     22 % of the wave cycles); every lane reads its row's entry (v: pivot search, right-hand side) and the
-//     entries of rows 16k + lane%16 (the multipliers);
+//   * column J of the live rows (lane J's registers) crosses to the lanes through LDS, TWO columns per write: while an
+//     odd sub-step J-1 is eliminated, lanes J and J+1 send their finished rows, pair by pair between the FMAs, to the
+//     column buffers A and B (one ds_write2_b64 serves both lanes).  Column J+1 is then one pivot behind: sub-step J
+//     brings buffer B up to date itself -- every lane takes its row's entry (lane of the pivot row: the LAST row's,
+//     which takes that place), adds its own multiplier times the pivot row's entry of that column, writes it back:
+//     the same FMA on the same operands as lane J+1's registers see, bit for bit.  (Round 4: the LDS pipe, ~14 cycles
+//     per one-lane ds_write2_b64 with 8 waves per CU doing 16-24 of them per sub-step, was this kernel's bound --
+//     PMC SQ_WAIT_INST_LDS 22 % of the wave cycles, tools/microbench/lds_lane_write.hip; 20 LDS instructions per
+//     sub-step before, 12 now.)  Every lane reads the entries of rows 16k + lane%16 (the multipliers); its own row's
+//     entry (pivot vote, right-hand side) is one of those;
 //   * pivot search, LINPACK's first-maximum rule exactly, without a reduction over the lanes: the maximum of the
 //     leading words |hi(a[p])| is kept IN the lanes along the same FMA stream (v_max3_f32 with abs modifiers,
 //     half an instruction per row: positive doubles order like their leading words read as floats), lane J's
@@ -42,40 +46,30 @@ namespace sbd {
 
 #include "sbd_band1_take.inc"   // TakeRow1<RW, LAST>: generated inline asm (tools/gen_band1_take.py)
 
-// ONE lane writes rows P, P+1 of its column to LDS doubles addr[P], addr[P+1].  Two ways to single the lane out:
-// SBD_B1_MASKED: exec = that lane around the write (two scalar moves per write in the wave's instruction stream);
-// default: every lane executes the write, the other 63 into a dump area behind the column (the address register
-// carries the choice: one v_cndmask per sub-step, no scalar instruction per write)
+// TWO lanes (wave-uniform exec mask `bit`) write rows P, P+1 of their columns to LDS doubles addr[P], addr[P+1] -- each
+// to its own column buffer (addr differs between the two).  Round 4, measured (tools/microbench/lds_lane_write.hip): a
+// ds_write2_b64 holds the CU's LDS pipe for ~14 cycles whether one lane or all 64 are active, and with 8 waves per CU
+// transposing 16-24 pairs per sub-step that pipe was the kernel's bound.  Hence two columns per write (the odd one is
+// brought up to date in LDS, below), and the exec mask rather than a dump area for the idle lanes (16 cycles).
 struct LaneSel { unsigned addr; unsigned long long bit; };
 template <int P>
 SBD_DEVICE void lane_write2(const LaneSel &w, double x0, double x1)
 {
-#ifdef SBD_B1_MASKED
     asm volatile("s_mov_b64 exec, %3\n\tds_write2_b64 %0, %1, %2 offset0:%4 offset1:%5\n\ts_mov_b64 exec, -1"
                  :: "v"(w.addr), "v"(x0), "v"(x1), "s"(w.bit), "n"(P), "n"(P + 1) : "memory");
-#else
-    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%3 offset1:%4" :: "v"(w.addr), "v"(x0), "v"(x1), "n"(P), "n"(P + 1) : "memory");
-#endif
 }
 template <int P>
 SBD_DEVICE void lane_write1(const LaneSel &w, double x0)
 {
-#ifdef SBD_B1_MASKED
     asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
                  :: "v"(w.addr), "v"(x0), "s"(w.bit), "n"(P * 8) : "memory");
-#else
-    asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(w.addr), "v"(x0), "n"(P * 8) : "memory");
-#endif
 }
-// LDS doubles per wave: the column (64) + the dump area (lane stride 16 bytes + the row offsets)
-constexpr int kBand1LdsDoubles = 64 + 64 * 2 + 64;
-SBD_DEVICE LaneSel lane_sel(unsigned mc, unsigned dump, int ln, int writer)   // dump = mc + 512 + 16 * lane
+// LDS doubles per wave: column buffer A (even sub-steps' columns) and B (odd ones), 64 rows each
+constexpr int kBand1LdsDoubles = 128;
+// lanes `writer` (-> buffer A at mc) and writer + 1 (-> buffer B at mc + 512)
+SBD_DEVICE LaneSel lane_sel(unsigned mc, int ln, int writer)
 {
-#ifdef SBD_B1_MASKED
-    return LaneSel{mc, 1ull << (writer & 63)};
-#else
-    return LaneSel{(ln == writer) ? mc : dump, 0ull};
-#endif
+    return LaneSel{(ln == writer + 1) ? mc + 512u : mc, 3ull << (writer & 63)};
 }
 
 // running maximum of the leading words of |x|: positive doubles (below 2^1017) order like their leading words read as
@@ -351,8 +345,8 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
     unsigned pmin_hi = 0x7fefffffu, pmax_hi = 0u;   // leading words of the smallest / largest |pivot| (wave-uniform, SGPRs)
     constexpr int E = 4;
     double buf[E], ynext = 0.0;
-    const unsigned mc = lds_addr(mcol), dump = mc + 512u + 16u * (unsigned)lane;
-    const double *mrow = mcol + lane, *mrep = mcol + (lane & 15);   // this lane's row entry, its multiplier slots
+    const unsigned mc = lds_addr(mcol);
+    const double *mrep = mcol + (lane & 15);             // this lane's multiplier slots: rows 16k + lane%16
     __builtin_amdgcn_s_waitcnt(0x0F70);         // every load so far has landed: the waits inside count the loop's own
     for (int lc = 1; lc <= ncut; ++lc) {
         const RowSrc nx = step_rows(lc + 1);                   // next step's rows
@@ -363,11 +357,11 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
         double *urow0 = FUSED ? nullptr : ufac + (size_t)k0 * UW;
         double *yrow0 = yv + k0;
         const bool tail = lc == ncut;                           // the last layer has no x_lc+1
-        // column 0 of the step's window: lane 0 writes its rows, every lane keeps the maximum of its column's
-        // leading words (the later columns: inside the elimination of the sub-step before them)
+        // columns 0 and 1 of the step's window: lanes 0 and 1 write their rows (buffers A, B), every lane keeps the
+        // maximum of its column's leading words (the later columns: inside the elimination of the sub-steps before)
         int mxf = 0;
         {
-            const LaneSel w0 = lane_sel(mc, dump, lane, 0);
+            const LaneSel w0 = lane_sel(mc, lane, 0);
             static_for<(RW + 1) / 2>([&](auto hh) {
                 constexpr int p = 2 * decltype(hh)::value;
                 if constexpr (p + 1 < RW) {
@@ -380,6 +374,7 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
             });
             if constexpr (FUSED) { lane_write2<RW>(w0, F[0], F[1]); lane_write1<RW + 2>(w0, F[2]); }
         }
+        double mnext[NG];                                       // the odd sub-step's multipliers, made by the even one before it
         static_for<n>([&](auto jj) {
             constexpr int J = decltype(jj)::value;
             constexpr int LAST = RW - 1 - J;                    // live rows: registers 0..LAST
@@ -389,15 +384,23 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
             asm volatile("" : "+v"(ln));
             const int lq = ln & 31, l16 = ln & 15;
             const bool second = ln >= 32, col = lq < n;
-            // (1) column J of the live rows, written by lane J while the sub-step before was eliminated (LDS serves
-            //     a wave's requests in order): row `lane`'s entry (v: pivot search, right-hand side) and the
-            //     entries of rows 16k + lane%16 (m[k]: the multipliers, replicated in each row of 16 lanes)
-            wave_lds_sync();
-            double v = *mrow;                                    // (lanes beyond the live rows: never used)
+            // (1) column J of the live rows: the entries of rows 16k + lane%16 (m[k]: the multipliers, replicated in each
+            //     row of 16 lanes) -- even J: from buffer A (LDS serves a wave's requests in order: the writes of the
+            //     sub-step before are there); odd J: made from buffer B and this wave's registers by the sub-step before
+            //     (2b).  Row `lane`'s entry (v: pivot vote, right-hand side) is the one of them in the lane's own row of 16
             double m[NG];
+            if constexpr ((J & 1) == 0) {
+                wave_lds_sync();
 #pragma unroll
-            for (int k = 0; k < NG; ++k) m[k] = mrep[16 * k];
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v), "+v"(m[0]), "+v"(m[NG - 1]) :: "memory");   // (before the next column's writes queue up behind them)
+                for (int k = 0; k < NG; ++k) m[k] = mrep[16 * k];
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m[0]), "+v"(m[NG - 1]) :: "memory");
+            } else {
+#pragma unroll
+                for (int k = 0; k < NG; ++k) m[k] = mnext[k];
+            }
+            double v = m[NG - 1];                                // (lanes beyond the rows: never used)
+#pragma unroll
+            for (int k = NG - 2; k >= 0; --k) v = (ln < 16 * (k + 1)) ? m[k] : v;
             // (2) ISAMAX's first-maximum rule: lane J's in-lane maximum of the leading words, the vote of the lanes
             //     that hold it; -1/pivot lane-wise meanwhile (v_rcp + two Newton steps), a zero pivot is flagged
             //     and skipped; the pivot row leaves its registers, the last live row takes its place -- in the
@@ -421,6 +424,16 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
                 const bool mine = l16 == (idx & 15);
 #pragma unroll
                 for (int k = 0; k < (RW + 15) / 16; ++k) m[k] = (mine && (idx >> 4) == k) ? vlast : m[k];
+            }
+            // (2b) even J: column J+1 waits in buffer B as it was before this pivot.  Its entries are fetched now (rows
+            //      16k + lane%16, the pivot row's entry, the last row's) and brought up to date in registers behind the
+            //      elimination below, where the LDS latency costs nothing
+            double cb = 0.0, blast = 0.0;
+            if constexpr ((J & 1) == 0 && J + 1 < n) {
+#pragma unroll
+                for (int k = 0; k < NG; ++k) mnext[k] = mrep[16 * k + 64];
+                cb = mcol[64 + idx];
+                blast = mcol[64 + LAST];
             }
             // register LAST is free from here on: next interface's row LAST - nn moves in
             if constexpr (LAST - nn >= E) a[LAST] = nx.p[(LAST - nn) * n];
@@ -447,34 +460,47 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
             //     Lane J+1 sends its finished rows to LDS pair by pair (next sub-step's column) and every lane
             //     folds the new leading words into its maximum
             const double tp = (ln > J) ? rns * t : 0.0;          // (lanes >= 32: columns of x_lc+1, all of them live)
-            constexpr bool NEXT = J + 1 < n;
-            const LaneSel wn = lane_sel(mc, dump, ln, J + 1);
+            constexpr bool NEXT = J + 1 < n;                     // (there is a next sub-step in this layer step)
+            constexpr bool SEND = NEXT && (J & 1) == 1;          // odd sub-steps send the next two columns
+            const LaneSel wn = lane_sel(mc, ln, J + 1);
             int mx2 = 0, mx3 = 0;     // two running maxima, pairs alternate (a statement that reads what the one before wrote costs a wait state)
-            // (the maximum and the write of a pair of rows follow two pairs behind their FMAs; a pair's four instructions
+            // (the maximum and the write of a pair of rows follow two pairs behind their FMAs; a pair's instructions
             //  are ONE asm statement: between separate statements the compiler puts a wait state per pair)
             auto send = [&](auto pp) {
                 constexpr int p = decltype(pp)::value;
                 if constexpr (NEXT && p >= 0) {
-                    if constexpr (p + 1 < LAST) { lane_write2<p>(wn, a[p], a[p + 1]); mx2 = lead_max2(mx2, a[p], a[p + 1]); }
-                    else { lane_write1<p>(wn, a[p]); mx2 = lead_max1(mx2, a[p]); }
+                    if constexpr (p + 1 < LAST) {
+                        if constexpr (SEND) lane_write2<p>(wn, a[p], a[p + 1]);
+                        mx2 = lead_max2(mx2, a[p], a[p + 1]);
+                    } else {
+                        if constexpr (SEND) lane_write1<p>(wn, a[p]);
+                        mx2 = lead_max1(mx2, a[p]);
+                    }
                 }
             };
             asm volatile("s_nop 1" ::: "memory");    // (a multiplier register fixed just above -> its DPP read: two wait states)
             static_for<(LAST + 1) / 2>([&](auto hh) {
                 constexpr int p = 2 * decltype(hh)::value, lp = p - 4;
-#ifndef SBD_B1_MASKED
                 if constexpr (NEXT && lp >= 0 && p + 1 < LAST) {
-                    asm volatile("v_fmac_f64_dpp %0, %3, %4 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-                                 "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
-                                 "ds_write2_b64 %5, %6, %7 offset0:%11 offset1:%12\n\t"
-                                 "v_max3_f32 %2, |%8|, |%13|, %2"
-                                 : "+v"(a[p]), "+v"(a[p + 1]), "+v"((p & 2) ? mx3 : mx2)
-                                 : "v"(m[p >> 4]), "v"(tp), "v"(wn.addr), "v"(a[lp]), "v"(a[lp + 1]), "v"(__double2hiint(a[lp])),
-                                   "n"(p & 15), "n"((p + 1) & 15), "n"(lp), "n"(lp + 1), "v"(__double2hiint(a[lp + 1]))
-                                 : "memory");
-                } else
-#endif
-                {
+                    if constexpr (SEND)
+                        asm volatile("v_fmac_f64_dpp %0, %3, %4 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+                                     "s_mov_b64 exec, %14\n\t"
+                                     "ds_write2_b64 %5, %6, %7 offset0:%11 offset1:%12\n\t"
+                                     "s_mov_b64 exec, -1\n\t"
+                                     "v_max3_f32 %2, |%8|, |%13|, %2"
+                                     : "+v"(a[p]), "+v"(a[p + 1]), "+v"((p & 2) ? mx3 : mx2)
+                                     : "v"(m[p >> 4]), "v"(tp), "v"(wn.addr), "v"(a[lp]), "v"(a[lp + 1]), "v"(__double2hiint(a[lp])),
+                                       "n"(p & 15), "n"((p + 1) & 15), "n"(lp), "n"(lp + 1), "v"(__double2hiint(a[lp + 1])), "s"(wn.bit)
+                                     : "memory");
+                    else
+                        asm volatile("v_fmac_f64_dpp %0, %3, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_max3_f32 %2, |%5|, |%6|, %2"
+                                     : "+v"(a[p]), "+v"(a[p + 1]), "+v"((p & 2) ? mx3 : mx2)
+                                     : "v"(m[p >> 4]), "v"(tp), "v"(__double2hiint(a[lp])), "v"(__double2hiint(a[lp + 1])),
+                                       "n"(p & 15), "n"((p + 1) & 15));
+                } else {
                     a[p] = fmac_row16<p & 15>(a[p], m[p >> 4], tp);
                     if constexpr (p + 1 < LAST) a[p + 1] = fmac_row16<(p + 1) & 15>(a[p + 1], m[(p + 1) >> 4], tp);
                     send(std::integral_constant<int, lp>{});
@@ -488,8 +514,19 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
             }
             send(std::integral_constant<int, 2 * ((LAST + 1) / 2) - 4>{});
             send(std::integral_constant<int, 2 * ((LAST + 1) / 2) - 2>{});
-            if constexpr (FUSED && NEXT) { lane_write2<RW>(wn, F[0], F[1]); lane_write1<RW + 2>(wn, F[2]); }
+            if constexpr (FUSED && SEND) { lane_write2<RW>(wn, F[0], F[1]); lane_write1<RW + 2>(wn, F[2]); }
             asm volatile("v_max_f32 %0, %1, %2" : "=v"(mxf) : "v"(mx2), "v"(mx3));
+            if constexpr ((J & 1) == 0 && J + 1 < n) {
+                // column J+1 after this pivot: the row exchange, then row p's entry += multiplier(p) * (pivot row's
+                // entry * -1/pivot) -- the FMA lane J+1's registers just received, on the same operands: bit for bit
+                const bool mine = l16 == (idx & 15);
+                const double c = rns * cb;
+#pragma unroll
+                for (int k = 0; k < NG; ++k) {
+                    const double fixed = (k < (RW + 15) / 16 && mine && (idx >> 4) == k) ? blast : mnext[k];
+                    mnext[k] = __builtin_fma(m[k], c, fixed);
+                }
+            }
             // right-hand side: y(p) += a[p](lane J) * (y_pivot * -1/pivot) for the live rows (and the functional rows)
             {
                 const double yt = ypiv * rns;

@@ -172,6 +172,59 @@ __global__ void __launch_bounds__(256) accum_final_kernel(int nseg, int nel, con
     if ((int)threadIdx.x < ne) acc[e0 + threadIdx.x] = a;
 }
 
+// The compact form of a batch (sbd_mix_in) -> DISORT's arguments, on the device: what depthscl (taugas.f:7625-7646),
+// GETMOM (disutil.f:2176-2188) and normom (drt.f:1366-1397) do on the host for every (wavelength, k-term).  A block per
+// work item, a thread per layer: DTAUC and SSALB of the item; the FIRST item of a spectral point (in this launch) also
+// forms the point's block of moments, which its k-terms share (pmom_row).  Integer powers of g the way the reference's
+// compiler forms GG**K (square-and-multiply from the low bit, compiler-rt's __powidf2), the Rayleigh 0.1 as the REAL*4
+// literal it is there: the oracle's restatement (oracle/mix_restatement.py) is bit-equal.
+__device__ __forceinline__ double powi_like_fortran(double a, int b)
+{
+    double r = 1.0;
+    while (true) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return r;
+}
+__global__ void __launch_bounds__(64) assemble_kernel(int w0, int nitem, int L, int nmom, int first_point_done,
+                                                      const int32_t *point_of, const double *dtaug, const double *dtaux,
+                                                      const double *tsc_hg, const double *g_hg, const double *tsc_ray,
+                                                      const double *plo, const double *phi_, const double *pfb, const double *pal,
+                                                      const uint8_t *ppl, double *dtauc, double *ssalb, double *pmom,
+                                                      int32_t *pmom_row, double *wvnmlo, double *wvnmhi, double *fbeam,
+                                                      double *albedo, uint8_t *plank)
+{
+    const int w = w0 + blockIdx.x;
+    if (blockIdx.x >= nitem) return;
+    const int p = point_of[w];
+    // the point's moments: by its first item in this launch -- unless the launch before already made them
+    const bool first = (blockIdx.x == 0) ? (first_point_done == 0) : (point_of[w - 1] != p);
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        const double sh = tsc_hg[(size_t)p * L + l], sr = tsc_ray[(size_t)p * L + l];
+        const double scat = sh + sr;
+        const double dt = dtaug[(size_t)w * L + l] + dtaux[(size_t)p * L + l];
+        dtauc[(size_t)w * L + l] = dt;
+        ssalb[(size_t)w * L + l] = (dt > 2.2250738585072014e-308) ? scat / dt : 0.0;      // (tiny(1.d0): the host's guard)
+        if (first) {
+            const double g = g_hg[(size_t)p * L + l];
+            double *pm = pmom + ((size_t)p * L + l) * (nmom + 1);
+            pm[0] = 1.0;
+            for (int k = 1; k <= nmom; ++k) {
+                double q = sh * powi_like_fortran(g, k);
+                if (k == 2) q = q + (double)0.1f * sr;
+                pm[k] = (scat != 0.0) ? q / scat : q;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        pmom_row[w] = p;
+        wvnmlo[w] = plo[p]; wvnmhi[w] = phi_[p]; fbeam[w] = pfb[p]; albedo[w] = pal[p]; plank[w] = ppl[p];
+    }
+}
+
 // IBCND = 1: every work item becomes two consecutive internal items with the same optical properties, no beam,
 // no thermal source and a black surface (the surface's albedo enters ALBTRN's closing formulas only)
 __global__ void ibcnd_expand_kernel(int nwork, int L, int npm, const double *dt, const double *ss, const double *pm,
@@ -844,10 +897,17 @@ long long sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t
 // Host arrays behind a device-pointer solve (sbd_engine_solve_host, fleets): every pass copies its own
 // slice in before its kernels and its outputs back after them, on the pass's stream -- the H2D of one
 // pass then runs beside the kernels of the other instead of ahead of everything.
+struct MixStage {               // device staging of a compact batch (sbd_mix_in), all of it
+    int32_t *point_of;
+    double *dtaug, *dtaux, *tsc_hg, *g_hg, *tsc_ray, *lo, *hi, *fb, *al;
+    uint8_t *pl;
+};
 struct HostSide {
     const sbd_batch_in *in;     // host inputs (NULL members never occur: checked by the callers)
     const sbd_batch_out *out;   // host outputs; flux / uu / status may each be NULL (not wanted)
     bool rows_sorted;           // in->pmom_row is non-decreasing: every pass needs one contiguous range of moment blocks
+    const sbd_mix_in *mix = nullptr;   // the batch comes in compact form: `in` is unused, every pass assembles its slice
+    MixStage ms = {};
 };
 static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, void *hip_stream, const HostSide *hs);
 
@@ -939,7 +999,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
     pw0.push_back(0);
     // (Not below 8192 items: a smaller pass leaves the band kernel less than one wave per SIMD slot.  Only with the
     //  moments shared per spectral point: with per-item moments the copies are the longer leg and more of them cost.)
-    if (hs && fork && in->nwork >= 32768 && hs->in->pmom_row) {
+    if (hs && fork && in->nwork >= 32768 && (hs->mix || hs->in->pmom_row)) {
         double sz = (0.25 * per_pass > 8192.0) ? 0.25 * per_pass : 8192.0;
         while (sz < 0.95 * per_pass && pw0.back() + (int)sz < in->nwork) {
             pw0.push_back(pw0.back() + (int)sz);
@@ -968,14 +1028,51 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         const size_t npm = (size_t)L * (e->cfg.nmom + 1);
         const int ns = pw0[ip + 1] - w0;
         hipStream_t cs = e->copy;
+        if (hs->mix) {
+            // compact form: this pass's items' gas depths and the scatterers of the spectral points they belong to cross
+            // PCIe, then DISORT's arguments are formed where they are needed (assemble_kernel, on the copy stream:
+            // ordered behind the copies, ahead of the event the pass's kernels wait for)
+            const sbd_mix_in *m = hs->mix;
+            const MixStage &d = hs->ms;
+            const int p0 = m->point_of[w0], p1 = m->point_of[w0 + ns - 1];
+            const bool done = ip > 0 && m->point_of[w0 - 1] == p0;        // (its moments exist: the pass before made them)
+            const int q0 = done ? p0 + 1 : p0, nq = p1 - q0 + 1;
+            HIP_TRY(hipMemcpyAsync(d.point_of + w0, m->point_of + w0, sizeof(int32_t) * ns, hipMemcpyHostToDevice, cs));
+            HIP_TRY(hipMemcpyAsync(d.dtaug + (size_t)w0 * L, m->dtaug + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, cs));
+            if (nq > 0) {
+                const std::pair<double *, const double *> lay[4] = {{d.dtaux, m->dtaux}, {d.tsc_hg, m->tsc_hg}, {d.g_hg, m->g_hg}, {d.tsc_ray, m->tsc_ray}};
+                for (const auto &a : lay)
+                    HIP_TRY(hipMemcpyAsync(a.first + (size_t)q0 * L, a.second + (size_t)q0 * L, sizeof(double) * nq * L, hipMemcpyHostToDevice, cs));
+                const std::pair<double *, const double *> sc[4] = {{d.lo, m->wvnmlo}, {d.hi, m->wvnmhi}, {d.fb, m->fbeam}, {d.al, m->albedo}};
+                for (const auto &a : sc)
+                    HIP_TRY(hipMemcpyAsync(a.first + q0, a.second + q0, sizeof(double) * nq, hipMemcpyHostToDevice, cs));
+                HIP_TRY(hipMemcpyAsync(d.pl + q0, m->plank + q0, (size_t)nq, hipMemcpyHostToDevice, cs));
+            }
+            hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)ns), dim3(64), 0, cs, w0, ns, L, e->cfg.nmom, done ? 1 : 0,
+                               (const int32_t *)d.point_of, (const double *)d.dtaug, (const double *)d.dtaux, (const double *)d.tsc_hg,
+                               (const double *)d.g_hg, (const double *)d.tsc_ray, (const double *)d.lo, (const double *)d.hi,
+                               (const double *)d.fb, (const double *)d.al, (const uint8_t *)d.pl,
+                               (double *)in->dtauc, (double *)in->ssalb, (double *)in->pmom, (int32_t *)in->pmom_row,
+                               (double *)in->wvnmlo, (double *)in->wvnmhi, (double *)in->fbeam, (double *)in->albedo, (uint8_t *)in->plank);
+            HIP_TRY(hipGetLastError());
+            if ((int)e->ev_h2d.size() <= ip) {
+                hipEvent_t ev = nullptr;
+                HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                e->ev_h2d.push_back(ev);
+            }
+            HIP_TRY(hipEventRecord(e->ev_h2d[ip], cs));
+            return SBD_OK;
+        }
         HIP_TRY(hipMemcpyAsync((void *)(in->dtauc + (size_t)w0 * L), hs->in->dtauc + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, cs));
         HIP_TRY(hipMemcpyAsync((void *)(in->ssalb + (size_t)w0 * L), hs->in->ssalb + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, cs));
         if (hs->in->pmom_row) {
-            // moments per spectral point: the blocks this pass's items point at (rows non-decreasing: a contiguous range;
-            // the first block of a pass may have gone over with the pass before -- copied again, harmlessly)
-            const int32_t r0 = hs->rows_sorted ? hs->in->pmom_row[w0] : 0;
+            // moments per spectral point: the blocks this pass's items point at (rows non-decreasing: a contiguous range).
+            // The first block of a pass may have gone over with the pass before, whose kernels may be READING it now:
+            // it is not copied again (same bytes, but a DMA write racing a kernel's reads of the same lines)
+            int32_t r0 = hs->rows_sorted ? hs->in->pmom_row[w0] : 0;
             const int32_t r1 = hs->rows_sorted ? hs->in->pmom_row[w0 + ns - 1] : hs->in->npmom - 1;
-            if (hs->rows_sorted || ip == 0)
+            if (hs->rows_sorted && ip > 0 && r0 == hs->in->pmom_row[w0 - 1]) ++r0;
+            if ((hs->rows_sorted || ip == 0) && r1 >= r0)
                 HIP_TRY(hipMemcpyAsync((void *)(in->pmom + (size_t)r0 * npm), hs->in->pmom + (size_t)r0 * npm, sizeof(double) * (size_t)(r1 - r0 + 1) * npm, hipMemcpyHostToDevice, cs));
             HIP_TRY(hipMemcpyAsync((void *)(in->pmom_row + w0), hs->in->pmom_row + w0, sizeof(int32_t) * ns, hipMemcpyHostToDevice, cs));
         } else {
@@ -1133,6 +1230,8 @@ static int ensure_stage(sbd_engine *e, size_t bytes)
 static int ibcnd_solve_host(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out)
 {
     if (!out->albtrn || !out->status) return fail(SBD_E_INVALID, "IBCND = 1: albtrn / status is NULL");
+    if (!in->dtauc || !in->ssalb || !in->pmom || !in->wvnmlo || !in->wvnmhi || !in->albedo)
+        return fail(SBD_E_INVALID, "IBCND = 1: dtauc / ssalb / pmom / wvnmlo / wvnmhi / albedo is NULL");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const size_t W = in->nwork;
     const int L = e->L, npm = L * (e->cfg.nmom + 1), nout = e->ib_nout;

@@ -144,7 +144,11 @@ SBD_DEVICE double group_bcast(double x)
 }
 
 template <int NN, int G, bool RAD>
-__global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(Params P, int32_t *eigflag)
+#ifndef SBD_RAD_WAVES
+#define SBD_RAD_WAVES 2      // waves per SIMD of the intensity variant at NN > 12: a 256-register cap, ~170 spills -- and the NSTR 32
+                             // radiance layer kernel 33.6 -> 26.5 ms per 768 points (same-box A/B, round 4; 1: 340 registers, no spill)
+#endif
+__global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1) layer_kernel2(Params P, int32_t *eigflag)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int n = 2 * NN, nn = NN, GPB = 64 / G;
@@ -460,12 +464,22 @@ __global__ void __launch_bounds__(64, (NN > 12 && !RAD) ? 2 : 1) layer_kernel2(P
                 if (g2 > tol * tol * ab) {           // |cos(angle)| > tol
                     rotated = true;
                     coarse = coarse || (g2 > 1.0e-13 * ab);   // ... > 3e-7
-                    const double e = wa * bb - wb * aa, ww = wa * wb, tg = 2.0 * gg;
+                    // e of the ordered pair: both lanes must see the SAME magnitude with opposite signs, or both would take
+                    // the same branch below and the two columns come out parallel.  Two rounded products and a difference
+                    // (no contraction: the partner forms the same two products and subtracts them the other way round,
+                    // bit for bit -e); an exact tie, e = +0 in both lanes, goes to the lane order
+                    double e;
+                    {
+#pragma clang fp contract(off)
+                        const double p1 = wa * bb, p2 = wb * aa;
+                        e = p1 - p2;
+                    }
+                    const double ww = wa * wb, tg = 2.0 * gg;
                     const double h2 = e * e + (tg * tg) * ww;
                     const double h = h2 * rsqrt_n1(h2);
                     const double u = tg * rcp_n1(fabs(e) + h);
                     const double q1 = 1.0 + (u * u) * ww;
-                    const double coef = ((e >= 0.0) ? -u : u) * wa;
+                    const double coef = ((e > 0.0 || (e == 0.0 && j < partner)) ? -u : u) * wa;
 #pragma unroll
                     for (int i = 0; i < nn; ++i) bcol[i] = bcol[i] + coef * ob[i];
                     nrm = q1 * (aa + coef * gg);

@@ -135,8 +135,12 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
     if (err) atomicOr(&s_err, 1);
     __syncthreads();
 
-    // ---- serial prefix pass: TAUC, delta-M optical depth, NCUT.  The sums run in the reference's order (a scan would
-    //      round differently), but not on one lane fetching its operands from LDS -- three dependent LDS round trips
+    // ---- serial prefix pass: TAUC, delta-M optical depth, NCUT.  The sums run in the reference's order.  (Round 4 tried
+    //      a wave scan on the DPP network instead -- six adds per quantity, 0.60 -> 0.50 ms per step -- and the parity
+    //      fuzz refused it: with a layer of optical depth ~1e-9 the reference's own thermal source term XR0 + XR1 * tau
+    //      cancels ten digits, and TAUCPR rounded as a tree instead of a chain moved DFDT by 9e-5 of its maximum.  Only
+    //      the reference's summation order reproduces the reference there.)  Not on one lane fetching its operands
+    //      from LDS, though: but not on one lane fetching its operands from LDS -- three dependent LDS round trips
     //      per layer were most of this kernel's life: every lane walks the chain on wave-uniform operands (v_readlane
     //      from the lanes that loaded them) and keeps the partial sums of its own level ----
     if (L <= 64) {

@@ -128,6 +128,14 @@ __global__ void __launch_bounds__(64) usrint_kernel(Params P)
         lyu = layru[lev];
         dark = lyrcut && lyu > ncut;
     };
+    auto is_active = [&](const int lev, const int lyu, const int iu, const bool dark) -> bool {
+        if (dark) return false;
+        const double um = umu[iu - 1], up = utaupr[lev];
+        const bool negumu = um < 0.0;
+        const bool whole = negumu ? (lyu - 1 >= 1) : (lyu + 1 <= ncut);
+        const bool skip = (fabs(up - taucpr[lyu - 1]) < eps6 && negumu) || (fabs(up - taucpr[lyu]) < eps6 && !negumu);
+        return whole || !skip;
+    };
     int nactive = 0;
     for (int base = 0; base < nitem; base += 64) {
         const int item = base + lane;
@@ -136,13 +144,7 @@ __global__ void __launch_bounds__(64) usrint_kernel(Params P)
             int lev, lyu, iu;
             bool dark;
             geometry(item, lev, lyu, iu, dark);
-            if (!dark) {
-                const double um = umu[iu - 1], up = utaupr[lev];
-                const bool negumu = um < 0.0;
-                const bool whole = negumu ? (lyu - 1 >= 1) : (lyu + 1 <= ncut);
-                const bool skip = (fabs(up - taucpr[lyu - 1]) < eps6 && negumu) || (fabs(up - taucpr[lyu]) < eps6 && !negumu);
-                act = whole || !skip;
-            }
+            act = is_active(lev, lyu, iu, dark);
         }
         const unsigned long long m = __ballot(act);
         if (act) alist[nactive + __popcll(m & ((1ull << lane) - 1ull))] = item;
@@ -170,10 +172,11 @@ __global__ void __launch_bounds__(64) usrint_kernel(Params P)
         int lev, lyu, iu;
         bool dark;
         geometry(item, lev, lyu, iu, dark);
+        if (is_active(lev, lyu, iu, dark)) continue;              // (written once, by the lanes that sum its layers below)
         double result = 0.0;
         if (!dark) {
             const double um = umu[iu - 1];
-            result = boundary(iu, um, utaupr[lev], um < 0.0);     // (active items: overwritten below, same wave, in order)
+            result = boundary(iu, um, utaupr[lev], um < 0.0);
         }
         uum[(size_t)(item / numu) * numu + (iu - 1)] = result;
     }

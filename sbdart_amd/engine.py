@@ -357,7 +357,8 @@ def engine_for_record(rec, level_out=None, device=0, max_batch=0, allow_retry_ns
 def run_key(rec):
     return (rec.nlyr, rec.nstr, rec.nmom, rec.flags & ~1, rec.umu0, rec.phi0, rec.btemp, rec.ttemp,
             rec.temis, rec.fisot, rec.temper.tobytes(), rec.umu.tobytes(), rec.phi.tobytes(),
-            getattr(rec, "ibdrf", 0), np.asarray(getattr(rec, "bpar", np.zeros(8))).tobytes())
+            getattr(rec, "ibdrf", 0), np.asarray(getattr(rec, "bpar", np.zeros(8))).tobytes(),
+            int(getattr(rec, "ibcnd", 0)))
 
 
 def solve_records(recs, level_out=None, device=0):
@@ -369,6 +370,10 @@ def solve_records(recs, level_out=None, device=0):
     flux_out, uu_out, st_out = [None] * len(recs), [None] * len(recs), [0] * len(recs)
     for idx in groups.values():
         r0 = recs[idx[0]]
+        if getattr(r0, "ibcnd", 0) == 1:
+            # the reference returns zeros in every flux / intensity argument and ALBMED / TRNMED beside them (disort.f:545-556):
+            # another result shape -- DisortEngine(ibcnd=1).solve_albtrn is the entry point, not this one
+            raise ValueError("solve_records: IBCND = 1 records are solved with DisortEngine(ibcnd=1).solve_albtrn")
         with engine_for_record(r0, level_out=level_out, device=device, max_batch=len(idx)) as eng:
             flux, uu, st = eng.solve(
                 np.stack([recs[i].dtauc for i in idx]), np.stack([recs[i].ssalb for i in idx]),

@@ -42,6 +42,7 @@ end module
 
 module sbd_run_mod
   implicit none
+  real(kind=8), save :: t_engine = 0, t_wait = 0, t_phase2 = 0        ! batch mode's time account (SBD_TIMING)
   character(len=*), parameter :: items_file = '.sbd_items', stdout_file = 'SBDART.stdout', stderr_file = 'SBDART.stderr', phase1_mark = '.sbd_phase1'
 contains
 
@@ -365,7 +366,9 @@ subroutine run_once(phase)
     if (aborted) return
   end if
   call system_clock(tick2)
+  t_engine = t_engine + real(tick2 - tick1, 8)/real(tick_rate, 8)
   call get_environment_variable('SBD_TIMING', path, plen, pstat)
+  if (phase == 2) pstat = 1                             ! (a batch reports its totals once, at the end)
   if (pstat == 0 .and. plen > 0) write(0, '(a,f9.4,a,i0,a,f9.4,a)') 'sbdart_amd: batch assembly ', &
     real(tick1 - tick0, kr)/real(tick_rate, kr), ' s; engine (create + H2D + solve + D2H), ', npart, ' solves: ', &
     real(tick2 - tick1, kr)/real(tick_rate, kr), ' s'
@@ -821,13 +824,15 @@ contains
       call leave(); return
     end if
     bin%nwork = p1 - p0 + 1
-    bin%dtauc = c_loc(dtauc(1, p0)); bin%ssalb = c_loc(ssalb(1, p0)); bin%pmom = c_loc(pmom(0, 1, p0))
+    bin%dtauc = c_loc(dtauc(1, p0)); bin%ssalb = c_loc(ssalb(1, p0))
     bin%wvnmlo = c_loc(wvnmlo(p0)); bin%wvnmhi = c_loc(wvnmhi(p0)); bin%fbeam = c_loc(fbeam(p0))
     bin%albedo = c_loc(albedo(p0)); bin%plank = c_loc(plank(p0))
     bin%bitem = c_null_ptr
     if (recs(1)%ibdrf == 1) bin%bitem = c_loc(bitem(1, p0))
     if (from_model) then                               ! moments per wavelength, shared by the k-terms
       bin%pmom = c_loc(pmom(0, 1, 1)); bin%pmom_row = c_loc(pmom_row(p0)); bin%npmom = int(size(pmom, 3), c_int32_t)
+    else                                               ! (per item: only here is p0 a valid third index of pmom)
+      bin%pmom = c_loc(pmom(0, 1, p0))
     end if
     bout%flux = c_loc(flux(1, 1, p0)); bout%status = c_loc(status(p0))
     bout%uu = c_null_ptr
@@ -841,6 +846,11 @@ contains
     if (rc /= SBD_OK) call fatal('sbd_fleet_solve_host: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
   end subroutine
 end subroutine run_once
+
+integer function nslot_now()
+  use sbd_fleet_cache_mod, only: nslot
+  nslot_now = nslot
+end function
 
 subroutine release_all_fleets()
   use iso_c_binding
@@ -906,8 +916,9 @@ subroutine run_batch(listfile)
   character(len=1024), allocatable :: dirs(:)
   character(len=1024) :: line, home
   character(len=16) :: txt
-  integer :: u, ios, nrun, i, k, nw, tlen, tstat, waited
-  integer(c_int) :: pid, cpid, rc
+  integer :: u, ios, nrun, i, k, nw, tlen, tstat
+  integer(kind=8) :: c0, c1, crate
+  integer(c_int) :: pid, rc
   integer(c_int), allocatable :: wpid(:)
   logical :: ok, phase1_only
   character(len=256) :: why
@@ -942,8 +953,7 @@ subroutine run_batch(listfile)
   end do
   close(u)
   do i = 1, nrun                                        ! (markers of an earlier batch in the same directories)
-    k = sbd_px_remove(trim(dirs(i))//'/'//phase1_mark//c_null_char)
-    k = sbd_px_remove(trim(dirs(i))//'/'//items_file//c_null_char)
+    call forget(i)
   end do
   call tables_load(ok, why)                             ! once, before the fork: the children inherit the tables
   nw = min(max(1, int(sbd_px_ncpu()) - 1), 16, max(1, nrun))
@@ -958,18 +968,7 @@ subroutine run_batch(listfile)
     if (pid == 0) then                                  ! worker k: runs k, k+nw, ... -- a child per run
       call omp_set_num_threads(1)                       ! (the pool is the parallelism; a child's band model runs on one core)
       do i = k, nrun, nw
-        cpid = sbd_px_fork()
-        if (cpid == 0) then
-          if (sbd_px_chdir(trim(dirs(i))//c_null_char) /= 0) call sbd_px_exit_now(3_c_int)
-          if (sbd_px_stdout_to(stdout_file//c_null_char, 0_c_int) /= 0) call sbd_px_exit_now(3_c_int)
-          if (sbd_px_stderr_to(stderr_file//c_null_char) /= 0) call sbd_px_exit_now(3_c_int)
-          call run_once(1)
-          flush(6)
-          call sbd_px_exit_now(0_c_int)
-        end if
-        rc = -1
-        if (cpid > 0) rc = sbd_px_wait(cpid)
-        if (sbd_px_touch(trim(dirs(i))//'/'//phase1_mark//c_null_char, rc) /= 0) continue
+        call first_phase(i)
       end do
       call sbd_px_exit_now(0_c_int)
     end if
@@ -977,29 +976,77 @@ subroutine run_batch(listfile)
   end do
   ! this process: the GPU side, runs in order
   do i = 1, nrun
-    waited = 0
-    do while (sbd_px_exists(trim(dirs(i))//'/'//phase1_mark//c_null_char) == 0)
-      call sbd_px_usleep(100_c_int)
-      waited = waited + 1
-      if (waited > 6000000) stop 'sbdart_amd --batch: a run never finished its first phase'
-    end do
-    if (phase1_only) cycle                              ! (tests without a GPU: the work items stay where phase 1 left them)
-    if (sbd_px_exists(trim(dirs(i))//'/'//items_file//c_null_char) /= 0) then
-      if (sbd_px_chdir(trim(dirs(i))//c_null_char) /= 0) stop 'sbdart_amd --batch: cannot enter a run directory'
-      flush(6)
-      if (sbd_px_stdout_to(stdout_file//c_null_char, 1_c_int) /= 0) stop 'sbdart_amd --batch: cannot append to SBDART.stdout'
-      call run_once(2)
-      flush(6)
-      k = sbd_px_remove(items_file//c_null_char)
-      k = sbd_px_remove(items_file//'.atm'//c_null_char)
-    end if
-    k = sbd_px_remove(trim(dirs(i))//'/'//phase1_mark//c_null_char)
+    call second_phase(i)
   end do
   do k = 1, nw
     rc = sbd_px_wait(wpid(k))
   end do
+  call get_environment_variable('SBD_TIMING', txt, tlen, tstat)
+  if (tstat == 0 .and. tlen > 0) write(0, '(a,i0,a,f8.3,a,f8.3,a,f8.3,a,i0,a)') 'sbdart_amd --batch: ', nrun, &
+    ' runs; waiting for phase 1 ', t_wait, ' s; phase 2 ', t_phase2, ' s of which engine calls ', t_engine, ' s; ', &
+    nslot_now(), ' fleets kept'
   call release_all_fleets()
   k = sbd_px_chdir(trim(home)//c_null_char)
+
+contains
+
+  ! (one procedure call per run: the path strings built here are stack temporaries (-fstack-arrays) that live until the
+  !  procedure returns -- in a loop of the caller they piled up to a stack overflow after ~2 000 runs)
+  subroutine forget(irun)
+    integer, intent(in) :: irun
+    integer :: r
+    r = sbd_px_remove(trim(dirs(irun))//'/'//phase1_mark//c_null_char)
+    r = sbd_px_remove(trim(dirs(irun))//'/'//items_file//c_null_char)
+  end subroutine
+
+  subroutine first_phase(irun)
+    integer, intent(in) :: irun
+    integer(c_int) :: child, code
+    child = sbd_px_fork()
+    if (child == 0) then
+      if (sbd_px_chdir(trim(dirs(irun))//c_null_char) /= 0) call sbd_px_exit_now(3_c_int)
+      if (sbd_px_stdout_to(stdout_file//c_null_char, 0_c_int) /= 0) call sbd_px_exit_now(3_c_int)
+      if (sbd_px_stderr_to(stderr_file//c_null_char) /= 0) call sbd_px_exit_now(3_c_int)
+      call run_once(1)
+      flush(6)
+      call sbd_px_exit_now(0_c_int)
+    end if
+    code = -1
+    if (child > 0) code = sbd_px_wait(child)
+    if (sbd_px_touch(trim(dirs(irun))//'/'//phase1_mark//c_null_char, code) /= 0) continue
+  end subroutine
+
+  subroutine second_phase(irun)
+    integer, intent(in) :: irun
+    character(len=:), allocatable :: mark, items
+    integer :: polls, r
+    mark = trim(dirs(irun))//'/'//phase1_mark//c_null_char
+    items = trim(dirs(irun))//'/'//items_file//c_null_char
+    polls = 0
+    call system_clock(c0, crate)
+    do while (sbd_px_exists(mark) == 0)
+      call sbd_px_usleep(100_c_int)
+      polls = polls + 1
+      if (polls > 6000000) stop 'sbdart_amd --batch: a run never finished its first phase'
+    end do
+    call system_clock(c1)
+    t_wait = t_wait + real(c1 - c0, 8)/real(crate, 8)
+    if (.not. phase1_only) then                         ! (tests without a GPU: the work items stay where phase 1 left them)
+      if (sbd_px_exists(items) /= 0) then
+        if (sbd_px_chdir(trim(dirs(irun))//c_null_char) /= 0) stop 'sbdart_amd --batch: cannot enter a run directory'
+        flush(6)
+        if (sbd_px_stdout_to(stdout_file//c_null_char, 1_c_int) /= 0) stop 'sbdart_amd --batch: cannot append to SBDART.stdout'
+        call system_clock(c0)
+        call run_once(2)
+        flush(6)
+        call system_clock(c1)
+        t_phase2 = t_phase2 + real(c1 - c0, 8)/real(crate, 8)
+        r = sbd_px_remove(items_file//c_null_char)
+        r = sbd_px_remove(items_file//'.atm'//c_null_char)
+      end if
+    end if
+    r = sbd_px_remove(mark)
+  end subroutine
 end subroutine
 
 end module sbd_run_mod

@@ -133,7 +133,7 @@ def run_directories(exe: str, dirs: Sequence[str], workdir: str, env: Optional[D
                 os.remove(os.path.join(d, name))
     p = subprocess.run([exe, "--batch", lst], cwd=workdir, env=env, capture_output=True, text=True)
     if p.returncode != 0:
-        raise RuntimeError(f"{exe} --batch failed: {p.stderr.strip()[-2000:]}")
+        raise RuntimeError(f"{exe} --batch failed with code {p.returncode}: {p.stderr.strip()[-2000:]} {p.stdout.strip()[-500:]}")
     outs = []
     for d in dirs:
         with open(os.path.join(d, "SBDART.stdout")) as f:

@@ -179,11 +179,23 @@ CAPTURE = os.path.join(ROOT, "oracle", "_ref", "sbdart_capture")
 needs_ref = pytest.mark.skipif(not os.access(CAPTURE, os.X_OK), reason="oracle/_ref not built")
 
 
-def run_reference_and_host(namelist, d, sums=False, from_input=False, files=None, host_env=None):
+def _warning_numbers(d, clear=True):
+    """The SBDART_WARNING.NN files in d (errmsg, disutil.f:278-325) as a sorted list of numbers; removed when `clear`."""
+    out = []
+    for name in sorted(os.listdir(d)):
+        if name.startswith("SBDART_WARNING."):
+            out.append(int(name.split(".")[1]))
+            if clear:
+                os.remove(os.path.join(d, name))
+    return out
+
+
+def run_reference_and_host(namelist, d, sums=False, from_input=False, files=None, host_env=None, warnings=None):
     """In directory d: the reference (capture build: unmodified objects, DISORT call site recorded)
     on this INPUT, then the host -- on the optics the reference just used, or (from_input) on INPUT
     alone through its own band model.  Returns (reference stdout, host stdout, path of the captured
-    records[, host's full-precision sums])."""
+    records[, host's full-precision sums]).  `warnings` (a dict) receives the warning-file numbers each of the
+    two wrote: {"ref": [...], "host": [...]}."""
     os.makedirs(d, exist_ok=True)
     with open(os.path.join(d, "INPUT"), "w") as f:
         f.write("\n &INPUT\n" + namelist + "\n /\n")
@@ -193,6 +205,8 @@ def run_reference_and_host(namelist, d, sums=False, from_input=False, files=None
     cap = os.path.join(d, "cap.sbdrec")
     ref = subprocess.run([CAPTURE], cwd=d, env=dict(os.environ, SBD_CAPTURE_FILE=cap), capture_output=True,
                          text=True, check=True).stdout
+    if warnings is not None:
+        warnings["ref"] = _warning_numbers(d)
     env = dict(os.environ, SBD_OPTICS=cap, SBD_ATMOS=cap + ".atm")
     if from_input:
         env = dict(os.environ, SBD_OPTICS=os.path.join(d, "no-optics-file"), SBD_ATMOS=os.path.join(d, "no-atm-file"))
@@ -200,6 +214,8 @@ def run_reference_and_host(namelist, d, sums=False, from_input=False, files=None
         env["SBD_SUMS_FILE"] = os.path.join(d, "sums.txt")
     env.update(host_env or {})
     p = subprocess.run([HOST], cwd=d, env=env, capture_output=True, text=True)
+    if warnings is not None:
+        warnings["host"] = _warning_numbers(d)
     assert p.returncode == 0, p.stderr
     if sums:
         return ref, p.stdout, cap, np.loadtxt(env["SBD_SUMS_FILE"])

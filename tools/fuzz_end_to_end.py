@@ -32,6 +32,10 @@ def engine_error(cap):
     return worst
 _build()
 ntok=0
+# warning files (SBDART_WARNING.NN) of every compared run: the reference's set against the host's (a16: LINPACK's RCOND
+# test drives warnings 2/3/4 in the reference, a pivot-ratio test in the engine -- does a real INPUT ever tell them apart?)
+from collections import Counter
+wstat = {"runs": 0, "same_set": 0, "ref": Counter(), "host": Counter(), "differ": []}
 random.seed(int(sys.argv[1]) if len(sys.argv)>1 else 1)
 def pick(*a): return random.choice(a)
 bad=0
@@ -112,12 +116,19 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
             from test_band_model import write_ck_files
             write_ck_files(d, seed=random.randrange(1,1000), top_down=random.random()<.5)
         try:
-            ref, got, cap = run_reference_and_host(nl, d, from_input=True, files=files)
+            wn = {}
+            ref, got, cap = run_reference_and_host(nl, d, from_input=True, files=files, warnings=wn)
         except subprocess.CalledProcessError:
             continue                                   # the reference rejects this INPUT
         except AssertionError as e:
             bad+=1; print("FAIL(host) ::",nlp,"::",str(e)[:300]); continue
         if not ref.split(): continue
+        wstat["runs"] += 1
+        wstat["ref"].update(wn.get("ref", [])); wstat["host"].update(wn.get("host", []))
+        if wn.get("ref") == wn.get("host"): wstat["same_set"] += 1
+        else:
+            wstat["differ"].append({"ref": wn.get("ref"), "host": wn.get("host"), "input": nlp})
+            print("WARNING FILES DIFFER :: ref %s host %s :: %s" % (wn.get("ref"), wn.get("host"), nlp))
         if "NaN" in ref.split():
             print("skip (the reference prints NaN) ::", nlp); continue
         try:
@@ -141,3 +152,8 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
                 bad+=1
                 print("FAIL (sensitivity %.1e) ::" % sens, nlp, "::", str(e)[:300])
 print("failures",bad,"tokens compared",ntok)
+import json
+print("WARNING_FILES " + json.dumps({"runs": wstat["runs"], "same_set": wstat["same_set"],
+                                     "reference_counts": {str(k): v for k, v in sorted(wstat["ref"].items())},
+                                     "host_counts": {str(k): v for k, v in sorted(wstat["host"].items())},
+                                     "differ": wstat["differ"][:40]}))

@@ -2,7 +2,9 @@
 """Turn a rocprofv3 --pmc SQ_INSTS_VALU pass of the bench command into profiles/<tag>_valu.json:
 executed vector-ALU wave-instructions per launch and per solve for each engine kernel (bench.py's
 `valu_issue` prices them at 4 issue cycles per wave64 instruction)."""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from sbdart_amd._srchash import kernel_source_hash
 from collections import defaultdict
 
 root, out, solves_per_launch = sys.argv[1], sys.argv[2], int(sys.argv[3])
@@ -21,7 +23,7 @@ acc = defaultdict(list)
 for k, g, v in rows:
     if g == gmax[k]:
         acc[k].append(v)
-res = {"solves_per_launch": solves_per_launch, "nstr": nstr, "nlyr": nlyr,
+res = {"kernel_source_hash": kernel_source_hash(), "solves_per_launch": solves_per_launch, "nstr": nstr, "nlyr": nlyr,
        "note": "SQ_INSTS_VALU summed over the dispatch (all SEs), averaged over the launches at the bench's launch size", "kernels": {}}
 for k, v in acc.items():
     if "sbd::" not in k:

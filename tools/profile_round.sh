@@ -2,7 +2,7 @@
 # Round-end evidence on the GPU box: kernel-trace stats of the bench command, PMC passes (instruction
 # mix at a reduced size, HBM traffic at the bench's own launch size), bench line.
 # usage: tools/profile_round.sh TAG    (writes gpurun_out/TAG/...; copy what is to be judged into profiles/)
-tag=${1:-r03}
+tag=${1:-r04}
 o=gpurun_out/$tag
 mkdir -p $o
 cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
