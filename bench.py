@@ -443,7 +443,58 @@ def main():
         step_host_shared()
     barrier()
     elapsed_hs = time.perf_counter() - t0
+    # ... and from the COMPACT form of a batch (sbd_mix_in: per spectral point the scatterers, per item the gas of its
+    # k-term; DTAUC / SSALB / PMOM assembled on the device): SURVEY 8(d)'s engine phase -- H2D + kernels + D2H/reduce --
+    # with the H2D a ninth of the bytes.  The same sizes and k-term structure as the headline sweep, its optical
+    # properties drawn per spectral point (sbdart_amd/workload.py: sw_sweep_mix); `value_8d`.  The same sweep's rate
+    # with its assembled arrays resident in HBM is measured beside it (value_8d_resident): the ratio is the cost of
+    # feeding the engine from the host.
+    from sbdart_amd.workload import sw_sweep_mix
+    mx = sw_sweep_mix(nwl=args.nwl, nstr=args.nstr, nlyr=args.nlyr, seed=12345, shard=rank)
+    pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().numpy()
+    m_in = [pin(x) for x in (mx.point_of, mx.dtaug, mx.dtaux, mx.tsc_hg, mx.g_hg, mx.tsc_ray, mx.wvnmlo, mx.wvnmhi,
+                             mx.fbeam, mx.albedo, mx.plank)]
+    m_w = pin(mx.weight)
+
+    def step_mix():
+        return fleet.solve_mix(*m_in, weight=m_w, items=False)[3]
+
+    acc_m = step_mix()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(nh):
+        acc_m = step_mix()
+    barrier()
+    elapsed_m = time.perf_counter() - t0
     fleet.close()
+    # the same sweep, arrays resident
+    md, msa, mp = mx.arrays()
+    r_in = [t(md), t(msa), t(mp), t(mx.wvnmlo[mx.point_of]), t(mx.wvnmhi[mx.point_of]), t(mx.fbeam[mx.point_of]),
+            t(mx.albedo[mx.point_of]), t(mx.plank[mx.point_of])]
+    r_row = t(mx.point_of.astype(np.int32))
+    r_w = t(mx.weight)
+    acc_r = torch.zeros((5, eng.nlev), dtype=torch.float64, device=dev)
+
+    def step_res():
+        eng.solve_device(*r_in, out=(flux, None, status), stream=stream, pmom_row=r_row)
+        acc_r.zero_()
+        rc = L.sbd_engine_accumulate_device(eng._h, W, r_w.data_ptr(), flux.data_ptr(), None, acc_r.data_ptr(), None, C.c_void_p(stream))
+        assert rc == 0, rc
+
+    step_res()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(nh):
+        step_res()
+    barrier()
+    elapsed_r = time.perf_counter() - t0
+    mix_agree = bool(np.allclose(acc_m, acc_r.cpu().numpy(), rtol=1e-12, atol=0))
+    bad_mix = int((status != 0).sum().item())
+    del r_in, r_row, r_w
+    if world > 1:
+        tt = torch.tensor([elapsed_m, elapsed_r], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed_m, elapsed_r = float(tt[0].item()), float(tt[1].item())
     h2d_bytes = int(sum(a.nbytes for a in h_in) + h_w.nbytes)
     h2d_bytes_shared = int(h2d_bytes - h_in[2].nbytes + h_pm_pt.nbytes + h_rows.nbytes)
     if world > 1:
@@ -483,13 +534,23 @@ def main():
             "value_incl_h2d_shared_moments": nwl_total * nh / elapsed_hs, "ms_per_step_incl_h2d_shared_moments": 1e3 * elapsed_hs / nh,
             # SURVEY 8(d)'s own wording of the metric ("H2D of inputs + kernels + D2H/reduce"): the host entry point's
             # rate; its bound is the PCIe link, not HBM (roofline_pcie).  `value` stays the HBM-resident rate.
-            "value_8d": nwl_total * nh / elapsed_h,
+            "value_8d": nwl_total * nh / elapsed_m, "ms_per_step_8d": 1e3 * elapsed_m / nh,
+            "value_8d_resident": nwl_total * nh / elapsed_r, "ms_per_step_8d_resident": 1e3 * elapsed_r / nh,
+            "value_8d_over_resident": elapsed_r / elapsed_m,
+            "value_8d_note": "SURVEY 8(d)'s engine phase (H2D + kernels + D2H/reduce) through sbd_fleet_solve_mix_host: the batch "
+                             "in compact form (per spectral point the scatterers, per item the gas of its k-term), DTAUC / SSALB / "
+                             "PMOM assembled on the device; value_8d_resident = the same sweep with the assembled arrays already in "
+                             f"HBM; sums of the two agree to 1e-12: {mix_agree}; nonzero status {bad_mix}",
             "roofline_pcie": {"bound": "pcie", "achieved": h2d_bytes * world * nh / elapsed_h / 1e9, "peak": PCIE_PEAK_GBS,
                               "unit": "GB/s", "frac": h2d_bytes * nh / elapsed_h / 1e9 / PCIE_PEAK_GBS,
                               "bytes_per_step": h2d_bytes, "bytes_per_step_shared_moments": h2d_bytes_shared,
+                              "bytes_per_step_compact": mx.h2d_bytes(),
                               "achieved_shared_moments": h2d_bytes_shared * nh / elapsed_hs / 1e9,
+                              "achieved_compact": mx.h2d_bytes() * nh / elapsed_m / 1e9,
                               "note": "H2D bytes of one step's inputs (per-item moments / moments once per spectral "
-                                      "point) over the host-entry-point step time; peak = PCIe 5.0 x16 per direction"},
+                                      "point / compact form) over the host-entry-point step time; peak = PCIe 5.0 x16 per "
+                                      "direction.  `achieved`/`frac` belong to value_incl_h2d (DISORT's arguments as arrays: "
+                                      "PCIe-bound); the compact form needs a ninth of the bytes and is compute-bound again"},
             "incl_h2d_note": "same step through the host entry point (sbd_fleet_solve_host): inputs in pinned host memory, the passes' H2D back to back on a copy stream beside the kernels, sums on the device, D2H of sums + status",
             "nonzero_status": bad, "fallback_layers": fallback_layers,
             "kernel_ms": {names[i]: float(phase_ms[i]) for i in range(5)},

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SBD_ABI_VERSION 4
+#define SBD_ABI_VERSION 5
 
 /* limits of the reference (params.f:9-15) */
 #define SBD_MAX_NLYR 65   /* mxly   */

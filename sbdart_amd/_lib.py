@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SBDART_AMD_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get("SBDART_AMD_LIB") or os.path.join(_HERE, "lib", "libsbdart_amd.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NFLUX = 5
 RFLDIR, RFLDN, FLUP, DFDT, UAVG = range(5)
 
@@ -42,6 +42,14 @@ class BatchOut(C.Structure):
     _fields_ = [("flux", C.c_void_p), ("uu", C.c_void_p), ("status", C.c_void_p), ("albtrn", C.c_void_p)]
 
 
+class MixIn(C.Structure):
+    """sbd_mix_in: a batch in compact form (per spectral point the scatterers, per work item the gas of its k-term)."""
+    _fields_ = [("nwork", C.c_int32), ("npoint", C.c_int32), ("point_of", C.c_void_p), ("dtaug", C.c_void_p),
+                ("dtaux", C.c_void_p), ("tsc_hg", C.c_void_p), ("g_hg", C.c_void_p), ("tsc_ray", C.c_void_p),
+                ("wvnmlo", C.c_void_p), ("wvnmhi", C.c_void_p), ("fbeam", C.c_void_p), ("albedo", C.c_void_p),
+                ("plank", C.c_void_p)]
+
+
 EXPORTS = (
     "sbd_engine_create", "sbd_engine_destroy", "sbd_engine_solve_device", "sbd_engine_solve_host",
     "sbd_engine_accumulate_device", "sbd_engine_accumulate_host", "sbd_abi_version",
@@ -51,7 +59,7 @@ EXPORTS = (
     "sbd_last_error", "sbd_engine_debug_copy", "sbd_engine_debug_pivots",
     "sbd_fleet_create", "sbd_fleet_destroy", "sbd_fleet_size", "sbd_fleet_engine", "sbd_fleet_uses_rccl",
     "sbd_shard_range", "sbd_fleet_solve_host", "sbd_fleet_last_enqueue", "sbd_host_alloc", "sbd_host_free",
-    "sbd_surface_flux_albedo",
+    "sbd_surface_flux_albedo", "sbd_fleet_solve_mix_host",
 )
 
 _LIB = None
@@ -117,6 +125,8 @@ def load() -> C.CDLL:
     L.sbd_shard_range.restype = None
     L.sbd_fleet_solve_host.argtypes = [vp, C.POINTER(BatchIn), C.POINTER(BatchOut), vp, vp, vp]
     L.sbd_fleet_solve_host.restype = C.c_int
+    L.sbd_fleet_solve_mix_host.argtypes = [vp, C.POINTER(MixIn), C.POINTER(BatchOut), vp, vp, vp]
+    L.sbd_fleet_solve_mix_host.restype = C.c_int
     L.sbd_fleet_last_enqueue.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.sbd_fleet_last_enqueue.restype = C.c_int
     L.sbd_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]

@@ -180,6 +180,7 @@ __global__ void __launch_bounds__(256) accum_final_kernel(int nseg, int nel, con
 // literal it is there: the oracle's restatement (oracle/mix_restatement.py) is bit-equal.
 __device__ __forceinline__ double powi_like_fortran(double a, int b)
 {
+#pragma clang fp contract(off)
     double r = 1.0;
     while (true) {
         if (b & 1) r *= a;
@@ -197,6 +198,7 @@ __global__ void __launch_bounds__(64) assemble_kernel(int w0, int nitem, int L, 
                                                       int32_t *pmom_row, double *wvnmlo, double *wvnmhi, double *fbeam,
                                                       double *albedo, uint8_t *plank)
 {
+#pragma clang fp contract(off)      // (the host forms these products and sums one rounding at a time: so must this kernel)
     const int w = w0 + blockIdx.x;
     if (blockIdx.x >= nitem) return;
     const int p = point_of[w];
@@ -1000,10 +1002,13 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
     // (Not below 8192 items: a smaller pass leaves the band kernel less than one wave per SIMD slot.  Only with the
     //  moments shared per spectral point: with per-item moments the copies are the longer leg and more of them cost.)
     if (hs && fork && in->nwork >= 32768 && (hs->mix || hs->in->pmom_row)) {
-        double sz = (0.25 * per_pass > 8192.0) ? 0.25 * per_pass : 8192.0;
+        double sz = (0.25 * per_pass > 8192.0) ? 0.25 * per_pass : 8192.0, grow = 1.3;
+        if (hs->mix) { sz = 0.5 * per_pass; grow = 2.0; }     // (compact form: a ninth of the bytes -- one half-size pass ahead)
+        if (const char *s1 = getenv("SBD_HOST_FIRST_PASS")) sz = atof(s1);      // (developer knobs: tools/host_passes_probe.py)
+        if (const char *s2 = getenv("SBD_HOST_PASS_GROWTH")) grow = atof(s2);
         while (sz < 0.95 * per_pass && pw0.back() + (int)sz < in->nwork) {
             pw0.push_back(pw0.back() + (int)sz);
-            sz *= 1.3;
+            sz *= grow;
         }
         const int rest = in->nwork - pw0.back();
         const int m = (rest + per_pass - 1) / per_pass;
@@ -1337,6 +1342,84 @@ static int solve_host_enqueue(sbd_engine *e, const sbd_batch_in *in, const sbd_b
     return SBD_OK;
 }
 
+// The compact form (sbd_mix_in) through the same pipeline: staging for the compact arrays AND for the arguments the
+// assemble kernel makes of them (the latter never exist on the host), then solve_device_impl with hs.mix set.
+static int solve_mix_host_enqueue(sbd_engine *e, const sbd_mix_in *m, const sbd_batch_out *out, const double *weight)
+{
+    if (e->ibcnd) return fail(SBD_E_UNSUPPORTED, "compact batches: not with IBCND = 1");
+    if (e->P.ibdrf == 1) return fail(SBD_E_UNSUPPORTED, "compact batches: not with the ocean surface (per-item constants)");
+    if (!m->point_of || !m->dtaug || !m->dtaux || !m->tsc_hg || !m->g_hg || !m->tsc_ray || !m->wvnmlo || !m->wvnmhi
+        || !m->fbeam || !m->albedo || !m->plank) return fail(SBD_E_INVALID, "compact batch: null input array");
+    if (m->npoint < 1) return fail(SBD_E_INVALID, "compact batch: npoint < 1");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const size_t W = m->nwork, NP = m->npoint;
+    for (size_t i = 0; i < W; ++i) {
+        const int32_t p = m->point_of[i];
+        if (p < 0 || p >= m->npoint || (i && p < m->point_of[i - 1]))
+            return fail(SBD_E_INVALID, "compact batch: point_of must be non-decreasing and inside 0..npoint-1");
+    }
+    const int L = e->L, nlev = e->nlev;
+    const bool rad = !e->cfg.onlyfl;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_lay = sizeof(double) * W * L, b_pm = sizeof(double) * NP * L * (e->cfg.nmom + 1), b_w = sizeof(double) * W;
+    const size_t b_play = sizeof(double) * NP * L, b_p = sizeof(double) * NP;
+    const size_t b_flux = sizeof(double) * W * SBD_NFLUX * nlev;
+    const size_t b_uu = rad ? sizeof(double) * W * e->P.nphi * nlev * e->P.numu : 0;
+    const size_t total = 3 * up(b_lay) + up(b_pm) + 5 * up(b_w) + up(W) + up(b_flux) + up(b_uu) + 3 * up(sizeof(int32_t) * W)
+                         + 4 * up(b_play) + 4 * up(b_p) + up(NP);
+    int rc = ensure_stage(e, total);
+    if (rc != SBD_OK) return rc;
+    char *p = e->d_stage;
+    auto take = [&](size_t bytes) { char *r = p; p += up(bytes); return r; };
+    double *d_dt = (double *)take(b_lay), *d_ss = (double *)take(b_lay), *d_pm = (double *)take(b_pm);
+    double *d_lo = (double *)take(b_w), *d_hi = (double *)take(b_w), *d_fb = (double *)take(b_w), *d_al = (double *)take(b_w);
+    double *d_wt = (double *)take(b_w);
+    uint8_t *d_pl = (uint8_t *)take(W);
+    double *d_flux = (double *)take(b_flux);
+    double *d_uu = rad ? (double *)take(b_uu) : nullptr;
+    int32_t *d_st = (int32_t *)take(sizeof(int32_t) * W);
+    int32_t *d_row = (int32_t *)take(sizeof(int32_t) * W);
+    HostSide hs = {nullptr, nullptr, true};
+    hs.mix = m;
+    hs.ms.point_of = (int32_t *)take(sizeof(int32_t) * W);
+    hs.ms.dtaug = (double *)take(b_lay);
+    hs.ms.dtaux = (double *)take(b_play); hs.ms.tsc_hg = (double *)take(b_play); hs.ms.g_hg = (double *)take(b_play); hs.ms.tsc_ray = (double *)take(b_play);
+    hs.ms.lo = (double *)take(b_p); hs.ms.hi = (double *)take(b_p); hs.ms.fb = (double *)take(b_p); hs.ms.al = (double *)take(b_p);
+    hs.ms.pl = (uint8_t *)take(NP);
+    hipStream_t st = e->stream;
+    if (weight) HIP_TRY(hipMemcpyAsync(d_wt, weight, b_w, hipMemcpyHostToDevice, st));
+    sbd_batch_in din = {m->nwork, d_dt, d_ss, d_pm, d_lo, d_hi, d_fb, d_al, d_pl, nullptr, d_row, m->npoint};
+    sbd_batch_out dout = {d_flux, d_uu, d_st};
+    const size_t w_flux = out->flux ? up(b_flux) : 0, w_uu = (rad && out->uu) ? up(b_uu) : 0, w_st = out->status ? up(sizeof(int32_t) * W) : 0;
+    if (w_flux + w_uu + w_st > e->h_pin_bytes) {
+        if (e->h_pin) (void)hipHostFree(e->h_pin);
+        e->h_pin = nullptr;
+        e->h_pin_bytes = 0;
+        if (hipHostMalloc(&e->h_pin, w_flux + w_uu + w_st, hipHostMallocDefault) != hipSuccess) return fail(SBD_E_NOMEM, "hipHostMalloc(outputs)");
+        e->h_pin_bytes = w_flux + w_uu + w_st;
+    }
+    char *hp = e->h_pin;
+    sbd_batch_out pout = {nullptr, nullptr, nullptr};
+    e->pending_out.clear();
+    if (w_flux) { pout.flux = (double *)hp; e->pending_out.push_back({out->flux, hp, b_flux}); hp += w_flux; }
+    if (w_uu) { pout.uu = (double *)hp; e->pending_out.push_back({out->uu, hp, b_uu}); hp += w_uu; }
+    if (w_st) { pout.status = (int32_t *)hp; e->pending_out.push_back({out->status, hp, sizeof(int32_t) * W}); hp += w_st; }
+    hs.out = &pout;
+    rc = solve_device_impl(e, &din, &dout, st, &hs);
+    if (rc != SBD_OK) return rc;
+    if (weight) {
+        const size_t nel_f = (size_t)SBD_NFLUX * nlev, nel_u = rad ? (size_t)e->P.nphi * nlev * e->P.numu : 0;
+        if (!e->d_acc) {
+            HIP_TRY(hipMalloc(&e->d_acc, sizeof(double) * (nel_f + nel_u)));
+            HIP_TRY(hipMalloc(&e->d_red, sizeof(double) * (nel_f + nel_u)));
+        }
+        HIP_TRY(hipMemsetAsync(e->d_acc, 0, sizeof(double) * (nel_f + nel_u), st));
+        rc = sbd_engine_accumulate_device(e, m->nwork, d_wt, d_flux, d_uu, e->d_acc, rad ? e->d_acc + nel_f : nullptr, st);
+        if (rc != SBD_OK) return rc;
+    }
+    return SBD_OK;
+}
+
 // after the engine's stream has drained: the outputs of the last host-pointer solve, pinned buffer -> caller
 static void deliver_host_outputs(sbd_engine *e)
 {
@@ -1637,6 +1720,33 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
         }
     } else {
         for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); deliver_host_outputs(f->eng[r]); }
+    }
+    return SBD_OK;
+}
+
+int sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_batch_out *out,
+                             const double *weight, double *acc_flux, double *acc_uu)
+{
+    if (!f || !in || !out) return fail(SBD_E_INVALID, "null argument");
+    if (in->nwork <= 0) return in->nwork == 0 ? SBD_OK : fail(SBD_E_INVALID, "nwork < 0");
+    if (!out->status) return fail(SBD_E_INVALID, "status is NULL");
+    if (weight && !acc_flux) return fail(SBD_E_INVALID, "acc_flux is NULL");
+    if (f->eng.size() != 1) return fail(SBD_E_UNSUPPORTED, "compact batches: a fleet of one device (shards must cut between spectral points)");
+    sbd_engine *e = f->eng[0];
+    const int nlev = e->nlev;
+    const bool rad = !e->cfg.onlyfl;
+    const size_t nel_f = (size_t)SBD_NFLUX * nlev, nel_u = rad ? (size_t)e->P.nphi * nlev * e->P.numu : 0, nel = nel_f + nel_u;
+    int rc = solve_mix_host_enqueue(e, in, out, weight);
+    if (rc != SBD_OK) { (void)hipStreamSynchronize(e->stream); return rc; }
+    if (weight) {
+        f->hacc.assign(nel, 0.0);
+        HIP_TRY(hipMemcpyAsync(f->hacc.data(), e->d_acc, sizeof(double) * nel, hipMemcpyDeviceToHost, e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    deliver_host_outputs(e);
+    if (weight) {
+        for (size_t i = 0; i < nel_f; ++i) acc_flux[i] += f->hacc[i];
+        if (acc_uu) for (size_t i = 0; i < nel_u; ++i) acc_uu[i] += f->hacc[nel_f + i];
     }
     return SBD_OK;
 }

@@ -6,17 +6,17 @@ module sbd_engine_mod
   use iso_c_binding
   implicit none
   private
-  public :: sbd_run_cfg, sbd_batch_in, sbd_batch_out
+  public :: sbd_run_cfg, sbd_batch_in, sbd_batch_out, sbd_mix_in
   public :: sbd_engine_create, sbd_engine_destroy, sbd_engine_solve_host, &
             sbd_engine_solve_device, sbd_engine_accumulate_host, sbd_engine_nlevel, &
             sbd_engine_chunk, sbd_strerror_f, sbd_last_error_f, sbd_abi_version
   public :: sbd_fleet_create, sbd_fleet_destroy, sbd_fleet_size, sbd_fleet_uses_rccl, sbd_shard_range, &
-            sbd_fleet_solve_host
+            sbd_fleet_solve_host, sbd_fleet_solve_mix_host
   public :: SBD_OK, SBD_E_RETRY_NSTR, SBD_NFLUX, SBD_ABI_VER
   public :: SBD_ST_WARN_SOLVE0, SBD_ST_WARN_UPBEAM, SBD_ST_WARN_UPISOT, SBD_ST_ERR_EIGEN, &
             SBD_ST_RETRY_NSTR, SBD_ST_ERR_INPUT, SBD_ST_WARN_PLKAVG
 
-  integer(c_int), parameter :: SBD_ABI_VER = 4, SBD_OK = 0, SBD_E_RETRY_NSTR = -2, SBD_NFLUX = 5
+  integer(c_int), parameter :: SBD_ABI_VER = 5, SBD_OK = 0, SBD_E_RETRY_NSTR = -2, SBD_NFLUX = 5
   integer(c_int), parameter :: SBD_ST_WARN_SOLVE0 = 1, SBD_ST_WARN_UPBEAM = 2, SBD_ST_WARN_UPISOT = 4, &
        SBD_ST_ERR_EIGEN = 8, SBD_ST_RETRY_NSTR = 16, SBD_ST_ERR_INPUT = 32, SBD_ST_WARN_PLKAVG = 64
 
@@ -40,6 +40,13 @@ module sbd_engine_mod
   type, bind(C) :: sbd_batch_out
     type(c_ptr) :: flux, uu, status
     type(c_ptr) :: albtrn = c_null_ptr   ! ibcnd = 1 only
+  end type
+
+  ! a batch in compact form (include/sbdart_amd.h): per spectral point the scatterers, per work item the gas of its
+  ! k-term; the engine assembles DTAUC / SSALB / PMOM on the device
+  type, bind(C) :: sbd_mix_in
+    integer(c_int32_t) :: nwork, npoint
+    type(c_ptr) :: point_of, dtaug, dtaux, tsc_hg, g_hg, tsc_ray, wvnmlo, wvnmhi, fbeam, albedo, plank
   end type
 
   interface
@@ -107,6 +114,14 @@ module sbd_engine_mod
       import
       type(c_ptr), value :: fleet, weight, acc_flux, acc_uu
       type(sbd_batch_in), intent(in) :: bin
+      type(sbd_batch_out), intent(in) :: bout
+      integer(c_int) :: rc
+    end function
+    function sbd_fleet_solve_mix_host(fleet, min, bout, weight, acc_flux, acc_uu) &
+         bind(C, name='sbd_fleet_solve_mix_host') result(rc)
+      import
+      type(c_ptr), value :: fleet, weight, acc_flux, acc_uu
+      type(sbd_mix_in), intent(in) :: min
       type(sbd_batch_out), intent(in) :: bout
       integer(c_int) :: rc
     end function

@@ -126,3 +126,96 @@ def sweep_to_records(sw: Sweep, idx):
             temis=sw.temis, dtauc=sw.dtauc[i], ssalb=sw.ssalb[i], temper=sw.temper, pmom=sw.pmom[i],
             wl=float(sw.wl[sw.wl_of[i]]), wt=float(sw.weight[i]), iwl=int(sw.wl_of[i]) + 1))
     return out
+
+
+@dataclasses.dataclass
+class MixSweep:
+    """The sweep of SURVEY 8(d) in the COMPACT form of include/sbdart_amd.h (sbd_mix_in): per spectral point a
+    Henyey-Greenstein scatterer (g = U(0, 0.9)) and Rayleigh scattering, per work item the gas of its k-term."""
+    nlyr: int
+    nstr: int
+    nmom: int
+    nwl: int
+    point_of: np.ndarray   # [W]
+    weight: np.ndarray     # [W]
+    dtaug: np.ndarray      # [W, nlyr]
+    dtaux: np.ndarray      # [nwl, nlyr]
+    tsc_hg: np.ndarray
+    g_hg: np.ndarray
+    tsc_ray: np.ndarray
+    wvnmlo: np.ndarray     # [nwl]
+    wvnmhi: np.ndarray
+    fbeam: np.ndarray
+    albedo: np.ndarray
+    plank: np.ndarray      # [nwl] uint8
+    temper: np.ndarray
+    umu0: float
+    btemp: float
+    ttemp: float
+    temis: float
+
+    @property
+    def nwork(self) -> int:
+        return int(self.dtaug.shape[0])
+
+    def arrays(self):
+        """(dtauc [W][L], ssalb [W][L], pmom [nwl][L][nmom+1]): DISORT's arguments of this sweep, the way the engine forms
+        them on the device (include/sbdart_amd.h, sbd_mix_in) -- for runs that want them resident in HBM beforehand."""
+        dtauc = self.dtaug + self.dtaux[self.point_of]
+        scat = self.tsc_hg + self.tsc_ray
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ssalb = np.where(dtauc > np.finfo(np.float64).tiny, scat[self.point_of] / dtauc, 0.0)
+        pmom = np.zeros((self.nwl, self.nlyr, self.nmom + 1))
+        pmom[:, :, 0] = 1.0
+        gk = np.ones_like(self.g_hg)
+        pw = {}
+        for k in range(1, self.nmom + 1):        # g**k by square-and-multiply from the low bit (a Fortran integer power)
+            a, r, b = self.g_hg.copy(), np.ones_like(self.g_hg), k
+            while True:
+                if b & 1:
+                    r = r * a
+                b //= 2
+                if b == 0:
+                    break
+                a = a * a
+            q = self.tsc_hg * r
+            if k == 2:
+                q = q + float(np.float32(0.1)) * self.tsc_ray
+            with np.errstate(divide="ignore", invalid="ignore"):
+                pmom[:, :, k] = np.where(scat != 0.0, q / scat, q)
+        return dtauc, ssalb, pmom
+
+    def h2d_bytes(self) -> int:
+        return int(sum(a.nbytes for a in (self.point_of, self.dtaug, self.dtaux, self.tsc_hg, self.g_hg, self.tsc_ray,
+                                          self.wvnmlo, self.wvnmhi, self.fbeam, self.albedo, self.plank, self.weight)))
+
+
+def sw_sweep_mix(nwl: int, nstr: int = 16, nlyr: int = 33, seed: int = 12345, wlinf: float = 0.25, wlsup: float = 4.0,
+                 albedo: float = 0.2, sza_deg: float = 30.0, thermal_above_um: float = 2.0, shard: int = 0) -> MixSweep:
+    """Same sizes, k-term structure, wavelength grid and column optical depths as sw_sweep; the layer optical properties
+    are drawn per SPECTRAL POINT (what a band model delivers): extinction of the scatterers exp(U(-9,1)) split into a
+    Henyey-Greenstein part (single-scattering albedo U(0, 0.999999) of it scatters, g = U(0, 0.9)) and a Rayleigh part
+    that grows with height, and per work item the gas absorption of its k-term (stronger for the higher terms)."""
+    base = sw_sweep(nwl=nwl, nstr=nstr, nlyr=nlyr, seed=seed, wlinf=wlinf, wlsup=wlsup, albedo=albedo, sza_deg=sza_deg,
+                    thermal_above_um=thermal_above_um, shard=shard)
+    W = base.nwork
+    seed = int(seed) + 1000003 * int(shard)
+    r = splitmix64(seed ^ 0x2545F4914F6CDD1D, nwl * 4 * nlyr).reshape(nwl, 4, nlyr)
+    ext = np.exp(-9.0 + 10.0 * r[:, 0])
+    ext *= np.minimum(1.0, 25.0 / ext.sum(axis=1, keepdims=True))
+    lw = np.linspace(1.0, 0.2, nlyr)[None, :] * r[:, 3]                 # Rayleigh's share of the extinction, larger aloft
+    tsc_ray = ext * lw
+    part = ext - tsc_ray
+    tsc_hg = part * (0.999999 * r[:, 1])
+    g_hg = 0.9 * r[:, 2]
+    first = np.concatenate([[0], np.nonzero(np.diff(base.wl_of))[0] + 1])
+    kidx = np.arange(W) - first[base.wl_of]
+    rg = splitmix64(seed ^ 0x9E3779B9, W * nlyr).reshape(W, nlyr)
+    dtaug = np.exp(-9.0 + 10.0 * rg) * (1.0 + 4.0 * kidx)[:, None]
+    dtaug *= np.minimum(1.0, 25.0 / dtaug.sum(axis=1, keepdims=True))
+    return MixSweep(nlyr=nlyr, nstr=nstr, nmom=base.nmom, nwl=nwl, point_of=base.wl_of.astype(np.int32), weight=base.weight,
+                    dtaug=np.ascontiguousarray(dtaug), dtaux=np.ascontiguousarray(ext), tsc_hg=np.ascontiguousarray(tsc_hg),
+                    g_hg=np.ascontiguousarray(g_hg), tsc_ray=np.ascontiguousarray(tsc_ray),
+                    wvnmlo=base.wvnmlo[first], wvnmhi=base.wvnmhi[first], fbeam=np.ones(nwl), albedo=np.full(nwl, albedo),
+                    plank=base.plank[first], temper=base.temper, umu0=base.umu0, btemp=base.btemp, ttemp=base.ttemp,
+                    temis=base.temis)

@@ -9,7 +9,7 @@ differs between compilers), at most 0.2 % of the tokens one unit off in the last
   * CPU leg (`-m "not gpu"`): the reference compiled here (oracle/_ref/sbdart_ref) -- closes the chain
     GPU engine -> oracle -> amdflang build -> what the authors' own build printed;
   * GPU leg (`-m gpu`): sbdart_amd in batch mode (one process for the sweep's hundreds of runs).
-The counts go to gpurun_out/shipped_tokens.json (copied to profiles/ per round)."""
+The counts go to gpurun_out/shipped_tokens_<leg>.json (copied to profiles/ per round)."""
 import gzip
 import json
 import os
@@ -53,10 +53,10 @@ def test_fixtures_are_what_the_manifest_says():
 
 def _record(leg, name, ntok, off):
     try:
-        out = os.path.join(ROOT, "gpurun_out", "shipped_tokens.json")
+        out = os.path.join(ROOT, "gpurun_out", f"shipped_tokens_{leg}.json")      # (a file per leg: they run on different boxes)
         os.makedirs(os.path.dirname(out), exist_ok=True)
         d = json.load(open(out)) if os.path.exists(out) else {}
-        d.setdefault(leg, {})[name] = {"tokens": ntok, "one_unit_off": off}
+        d[name] = {"tokens": ntok, "one_unit_off": off}
         json.dump(d, open(out, "w"), indent=1, sort_keys=True)
     except OSError:
         pass
