@@ -544,7 +544,8 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             kp = (op < kp) ? op : kp;
         }
         const double am = __hiloint2double((int)ka, 0), pm = __hiloint2double((int)kp, 0);   // (leading words: 2^-20 relative)
-        if (q == 0 && !(pm > 8.0 * N * 2.220446049250313e-16 * am)) status |= 0x01;
+        // (1 + ratio == 1, the reference's test on RCOND with the pivot ratio in its place: see sbd_band1.hpp)
+        if (q == 0 && !(pm > 1.1102230246251565e-16 * am)) status |= 0x01;
     }
     if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
     if constexpr (FUSED) {

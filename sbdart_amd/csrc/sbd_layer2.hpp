@@ -39,7 +39,10 @@ struct Layer2Lds {   // doubles; per-group part + per-block shared part
         lu = gl + ((n + 2) & ~1);
         // groups of 8 or 16 lanes (nn > 4) keep L in the lower triangle of ONE block, C transposed in its upper
         // triangle and C's diagonal behind it; the groups of 4 keep Q+ | Q- side by side
-        vec = lu + ((nn > 4) ? nn * ldq + nn : 2 * nn * ldq);
+        // (nn > 16 -- groups of 32 lanes, NSTR 34-40 -- keep the two blocks like the groups of 4.  Round 3 sized them for the
+        //  packed form: Q- ran into the next group's memory, every layer came out "not positive definite" and went to the
+        //  reference-algorithm kernel -- right answers, 47 x slower; found by the round-4 profile of NSTR 40)
+        vec = lu + ((nn > 4 && nn <= 16) ? nn * ldq + nn : 2 * nn * ldq);
         // radiance mode adds zjs, z0s, z1s, psi[2n]
         group_total = (vec + (rad ? 5 * n : 0) + 1) & ~1;
         // Lane g of a group reads word g of a row: G consecutive doubles.  ds_read_b64 serves 32 lanes per LDS cycle over
@@ -396,6 +399,9 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
     //  is singular to working precision and the reference-algorithm kernel raises errmsg 4 from its pivots)
     const bool hard_thermal = plank && mazim == 0 && ssalb_lc >= 1.0 - 64.0 * 1.1102230246251565e-16;
     if (!spd || P.force_fallback || hard_thermal) {
+#ifdef SBD_L2_DEBUG
+        if (g == 0 && blockIdx.x < 8) printf("layer2 list: block %u group %d reason %s\n", blockIdx.x, gi, !spd ? "not SPD" : "thermal/forced");
+#endif
         if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;   // count, then the entries
         return;
     }
@@ -532,6 +538,9 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
             if (!__any(!done)) break;
         }
         if (!done) {   // 30 sweeps without convergence: the reference-algorithm kernel redoes this layer
+#ifdef SBD_L2_DEBUG
+            if (g == 0 && blockIdx.x < 8) printf("layer2 list: block %u group %d reason no convergence\n", blockIdx.x, gi);
+#endif
             if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;
             return;
         }
@@ -575,6 +584,9 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
         const bool bad = (me <= nn) && (!(lam > 0.0) || (fbeam > 0.0 && !(gap > 1.0e-10)));
         const unsigned long long gmask = ((G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull)) << ((gi * G) & 63);
         if ((__ballot(bad) & gmask) != 0ull) {
+#ifdef SBD_L2_DEBUG
+            if (bad && blockIdx.x < 8) printf("layer2 list: block %u group %d lane %d reason lam %g gap %g\n", blockIdx.x, gi, g, lam, gap);
+#endif
             if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;
             return;
         }

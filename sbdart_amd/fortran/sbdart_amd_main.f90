@@ -413,14 +413,31 @@ subroutine run_once(phase)
       end if
     end do
   end if
-  if (corint .and. nmom > 10 .and. npart > 0) then       ! CHEKIN warning 5 (disort.f:4939-4941)
-    if (any(pmom(nmom, :, 1:merge(size(pmom, 3), npart, from_model)) > real(1.e-3, kr))) &
-      call warn_file(5, 'CHEKIN-- phase function not sufficiently resolved for use with corint=.true.')
+  ! CHEKIN warning 5 (disort.f:4939-4941): looked at in every call whose CORINT argument is still true on entry (flag 16,
+  ! corint_history) -- the moments of THAT call, its highest one.  (Until round 4: any moment block of the run, also
+  ! of wavelengths never solved or solved after CORINT had gone off; the end-to-end fuzz found the two runs that differ.)
+  if (corint .and. npart > 0) then
+    do i = 1, nrec
+      ip = where_solved(i)
+      if (ip == 0 .or. iand(recs(i)%flags, 16) == 0 .or. recs(i)%nmom <= 10) cycle
+      j = merge(int(pmom_row(ip)) + 1, ip, from_model)
+      if (any(pmom(recs(i)%nmom, :, j) > real(1.e-3, kr))) then
+        call warn_file(5, 'CHEKIN-- phase function not sufficiently resolved for use with corint=.true.')
+        exit
+      end if
+    end do
   end if
   ! CHEKIN warning 7 (disort.f:5154-5158, 5169): every beam call whose CORINT argument is false -- the namelist's
   ! value, or the one DISORT switched off in place at an earlier beamless call (corint_history: items ncorr+1..nbeam)
-  if (radcalc .and. nbeam > 0 .and. (.not. corint .or. nbeam > ncorr)) &
-    call warn_file(7, 'CHEKIN--intensity correction is off; intensities may be less accurate')
+  ! -- and in which something scatters (YESSCT > 0, disort.f:5163-5166: the fuzz's Rayleigh-free clear-sky runs)
+  if (radcalc .and. nbeam > 0 .and. (.not. corint .or. nbeam > ncorr)) then
+    do ip = merge(ncorr + 1, 1, corint), nbeam
+      if (sum(ssalb(:, ip)) > 0._kr) then
+        call warn_file(7, 'CHEKIN--intensity correction is off; intensities may be less accurate')
+        exit
+      end if
+    end do
+  end if
 
   ! ---- output ----
   call sums_init(sums, fmt, nz, view%nzen, view%nphi)
