@@ -474,11 +474,13 @@ def main():
     r_row = t(mx.point_of.astype(np.int32))
     r_w = t(mx.weight)
     acc_r = torch.zeros((5, eng.nlev), dtype=torch.float64, device=dev)
+    flux_r = torch.empty_like(flux)                     # (its own outputs: `flux` / `status` belong to the headline sweep)
+    status_r = torch.empty_like(status)
 
     def step_res():
-        eng.solve_device(*r_in, out=(flux, None, status), stream=stream, pmom_row=r_row)
+        eng.solve_device(*r_in, out=(flux_r, None, status_r), stream=stream, pmom_row=r_row)
         acc_r.zero_()
-        rc = L.sbd_engine_accumulate_device(eng._h, W, r_w.data_ptr(), flux.data_ptr(), None, acc_r.data_ptr(), None, C.c_void_p(stream))
+        rc = L.sbd_engine_accumulate_device(eng._h, W, r_w.data_ptr(), flux_r.data_ptr(), None, acc_r.data_ptr(), None, C.c_void_p(stream))
         assert rc == 0, rc
 
     step_res()
@@ -489,8 +491,8 @@ def main():
     barrier()
     elapsed_r = time.perf_counter() - t0
     mix_agree = bool(np.allclose(acc_m, acc_r.cpu().numpy(), rtol=1e-12, atol=0))
-    bad_mix = int((status != 0).sum().item())
-    del r_in, r_row, r_w
+    bad_mix = int((status_r != 0).sum().item())
+    del r_in, r_row, r_w, flux_r, status_r
     if world > 1:
         tt = torch.tensor([elapsed_m, elapsed_r], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

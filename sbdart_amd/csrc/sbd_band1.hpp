@@ -52,24 +52,30 @@ namespace sbd {
 // transposing 16-24 pairs per sub-step that pipe was the kernel's bound.  Hence two columns per write (the odd one is
 // brought up to date in LDS, below), and the exec mask rather than a dump area for the idle lanes (16 cycles).
 struct LaneSel { unsigned addr; unsigned long long bit; };
+// (every lane executing the write, the idle ones into a dump area, was measured against the exec mask: no scalar
+//  instruction per write, but 16 instead of 14 LDS cycles -- band kernel 10.2 against 9.0 ms.  The mask stays.)
+#define SBD_B1_EXEC_ON(m) "s_mov_b64 exec, " m "\n\t"
+#define SBD_B1_EXEC_OFF "\n\ts_mov_b64 exec, -1"
 template <int P>
 SBD_DEVICE void lane_write2(const LaneSel &w, double x0, double x1)
 {
-    asm volatile("s_mov_b64 exec, %3\n\tds_write2_b64 %0, %1, %2 offset0:%4 offset1:%5\n\ts_mov_b64 exec, -1"
+    asm volatile(SBD_B1_EXEC_ON("%3") "ds_write2_b64 %0, %1, %2 offset0:%4 offset1:%5" SBD_B1_EXEC_OFF
                  :: "v"(w.addr), "v"(x0), "v"(x1), "s"(w.bit), "n"(P), "n"(P + 1) : "memory");
 }
 template <int P>
 SBD_DEVICE void lane_write1(const LaneSel &w, double x0)
 {
-    asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
+    asm volatile(SBD_B1_EXEC_ON("%2") "ds_write_b64 %0, %1 offset:%3" SBD_B1_EXEC_OFF
                  :: "v"(w.addr), "v"(x0), "s"(w.bit), "n"(P * 8) : "memory");
 }
-// LDS doubles per wave: column buffer A (even sub-steps' columns) and B (odd ones), 64 rows each
-constexpr int kBand1LdsDoubles = 128;
-// lanes `writer` (-> buffer A at mc) and writer + 1 (-> buffer B at mc + 512)
+// LDS doubles per wave: column buffer A (even sub-steps' columns) and B (odd ones), 64 rows each.  B starts 80 doubles
+// behind A, not 64: the two writer lanes store the same rows of their buffers in ONE instruction, and 512 bytes apart
+// they hit the same banks (64 banks x 4 bytes) -- SQ_LDS_BANK_CONFLICT 14 cycles per sub-step in the first profile.
+constexpr int kBand1B = 80, kBand1LdsDoubles = kBand1B + 64;
+// lanes `writer` (-> buffer A at mc) and writer + 1 (-> buffer B)
 SBD_DEVICE LaneSel lane_sel(unsigned mc, int ln, int writer)
 {
-    return LaneSel{(ln == writer + 1) ? mc + 512u : mc, 3ull << (writer & 63)};
+    return LaneSel{(ln == writer + 1) ? mc + 8u * kBand1B : mc, 3ull << (writer & 63)};
 }
 
 // running maximum of the leading words of |x|: positive doubles (below 2^1017) order like their leading words read as
@@ -431,9 +437,9 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
             double cb = 0.0, blast = 0.0;
             if constexpr ((J & 1) == 0 && J + 1 < n) {
 #pragma unroll
-                for (int k = 0; k < NG; ++k) mnext[k] = mrep[16 * k + 64];
-                cb = mcol[64 + idx];
-                blast = mcol[64 + LAST];
+                for (int k = 0; k < NG; ++k) mnext[k] = mrep[16 * k + kBand1B];
+                cb = mcol[kBand1B + idx];
+                blast = mcol[kBand1B + LAST];
             }
             // register LAST is free from here on: next interface's row LAST - nn moves in
             if constexpr (LAST - nn >= E) a[LAST] = nx.p[(LAST - nn) * n];
@@ -485,9 +491,9 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
                     if constexpr (SEND)
                         asm volatile("v_fmac_f64_dpp %0, %3, %4 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
                                      "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
-                                     "s_mov_b64 exec, %14\n\t"
-                                     "ds_write2_b64 %5, %6, %7 offset0:%11 offset1:%12\n\t"
-                                     "s_mov_b64 exec, -1\n\t"
+                                     SBD_B1_EXEC_ON("%14")
+                                     "ds_write2_b64 %5, %6, %7 offset0:%11 offset1:%12"
+                                     SBD_B1_EXEC_OFF "\n\t"
                                      "v_max3_f32 %2, |%8|, |%13|, %2"
                                      : "+v"(a[p]), "+v"(a[p + 1]), "+v"((p & 2) ? mx3 : mx2)
                                      : "v"(m[p >> 4]), "v"(tp), "v"(wn.addr), "v"(a[lp]), "v"(a[lp + 1]), "v"(__double2hiint(a[lp])),

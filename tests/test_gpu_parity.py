@@ -828,3 +828,25 @@ def test_ocean_surface_flux_batch_of_hundreds():
             worst = max(worst, err / max(scale, 1e-9 * recmax))
             assert err <= TOL * scale + 1e-12 * recmax, (i, f, err, scale)
     print(f"400 ocean items, worst error {worst:.2e} of the column maximum")
+
+
+@pytest.mark.parametrize("nstr", [4, 8, 16, 20, 32, 34, 40])
+def test_fast_layer_kernel_keeps_a_benign_batch(nstr):
+    """The fast layer kernel hands a layer to the reference-algorithm kernel only for cause (not positive definite after
+    symmetrisation, Jacobi non-convergence, an eigenvalue next to the beam, a thermal source in a conservative layer).
+    A benign short-wave batch has none of that: zero listed layers, at EVERY stream count.  (Round 3 sized the LDS
+    block of the 32-lane groups -- NSTR 34-40 -- too small: 85 % of the layers were listed, the answers stayed right
+    and the run was 47 x slower; only a profile noticed.)"""
+    import torch
+    from sbdart_amd.engine import DisortEngine
+    from sbdart_amd.workload import sw_sweep
+    sw = sw_sweep(nwl=40, nstr=nstr, seed=11, thermal_above_um=99.0)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    with DisortEngine(nlyr=sw.nlyr, nstr=sw.nstr, nmom=sw.nmom, temper=sw.temper, umu0=sw.umu0, btemp=sw.btemp,
+                      ttemp=sw.ttemp, temis=sw.temis, onlyfl=True, level_out=[0, sw.nlyr], device=0) as eng:
+        eng.enable_timing(True)
+        _, _, st = eng.solve(t(sw.dtauc), t(sw.ssalb), t(sw.pmom), t(sw.wvnmlo), t(sw.wvnmhi), t(sw.fbeam), t(sw.albedo), t(sw.plank))
+        torch.cuda.synchronize()
+        assert int((st != 0).sum().item()) == 0
+        assert eng.last_fallback_layers() == 0, (nstr, eng.last_fallback_layers(), sw.nwork * sw.nlyr)
