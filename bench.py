@@ -278,10 +278,7 @@ def other_shapes(dev):
             fb = eng.last_fallback_layers()
             finite = bool(torch.isfinite(flux).all().item()) and (uu is None or bool(torch.isfinite(uu).all().item()))
             names = ["setup_kernel", "layer_kernel", "band_kernel", "backsolve_kernel", "usrint+azimuth"]
-            nl = max(1, (sw.nwork + eng.chunk - 1) // eng.chunk)
-            if nl == 1 and sw.nwork >= 16384:
-                nl = 2
-            nl += nl > 1 and nl % 2
+            nl = eng.pass_count(sw.nwork)
             shape = "cfgC" if rad else "cfgD"
             out[name] = {"value": sw.nwl / dt if finite else None, "unit": "spectral-points/s", "ms_per_step": 1e3 * dt,
                          "nwl": sw.nwl, "solves": sw.nwork, "nstr": sw.nstr, "nlyr": sw.nlyr,
@@ -349,6 +346,7 @@ def main():
     eng = DisortEngine(nlyr=sw.nlyr, nstr=sw.nstr, nmom=sw.nmom, temper=sw.temper, umu0=sw.umu0,
                        btemp=sw.btemp, ttemp=sw.ttemp, temis=sw.temis, onlyfl=True,
                        level_out=level_out, device=local_rank)
+    npass_headline = eng.pass_count(W)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     d_in = [t(sw.dtauc), t(sw.ssalb), t(sw.pmom), t(sw.wvnmlo), t(sw.wvnmhi), t(sw.fbeam), t(sw.albedo), t(sw.plank)]
     d_w = t(sw.weight)
@@ -511,10 +509,8 @@ def main():
         value = nwl_total * args.steps / elapsed
         names = ["setup_kernel", "layer_kernel", "band_kernel", "backsolve_kernel", "usrint+azimuth"]
         abytes = algorithmic_bytes_per_solve(sw.nlyr, sw.nstr, eng.nlev)
-        nlaunch = (W + eng.chunk - 1) // eng.chunk          # the engine's rule (sbd_engine_solve_device): an even
-        if nlaunch == 1 and W >= 16384:                     # number of equal passes, alternating between its two
-            nlaunch = 2                                     # workspaces / streams
-        nlaunch += nlaunch > 1 and nlaunch % 2
+        nlaunch = npass_headline                            # (sbd_engine_pass_count: an even number of equal passes,
+                                                            #  alternating between the engine's two workspaces / streams)
         pass_size = (W + nlaunch - 1) // nlaunch
         roof = shape_roofline(names, phase_ms, nlaunch, pass_size, W, sw.nstr, sw.nlyr, eng.nlev)
         roof["note"] = ("latency/issue bound by construction (SURVEY 8d): ~5 KB of inputs per 2.5 MFLOP of pivoted fp64; the "

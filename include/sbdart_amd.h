@@ -253,6 +253,7 @@ int32_t     sbd_abi_version(void);
 int32_t     sbd_engine_nlevel(const sbd_engine *e);     /* nlev of the outputs */
 size_t      sbd_engine_workspace_bytes(const sbd_engine *e);
 int32_t     sbd_engine_chunk(const sbd_engine *e);      /* work items per internal pass */
+int32_t     sbd_engine_pass_count(const sbd_engine *e, int32_t nwork);   /* equal passes a resident batch of nwork items is cut into */
 void       *sbd_engine_stream(sbd_engine *e);           /* the engine's hipStream_t */
 /* Gauss quadrature the engine uses (QGAUSN, disort.f:5984): cmu/cwt get nstr/2 values */
 int         sbd_engine_quadrature(const sbd_engine *e, double *cmu, double *cwt);

@@ -59,7 +59,7 @@ EXPORTS = (
     "sbd_last_error", "sbd_engine_debug_copy", "sbd_engine_debug_pivots",
     "sbd_fleet_create", "sbd_fleet_destroy", "sbd_fleet_size", "sbd_fleet_engine", "sbd_fleet_uses_rccl",
     "sbd_shard_range", "sbd_fleet_solve_host", "sbd_fleet_last_enqueue", "sbd_host_alloc", "sbd_host_free",
-    "sbd_surface_flux_albedo", "sbd_fleet_solve_mix_host",
+    "sbd_surface_flux_albedo", "sbd_fleet_solve_mix_host", "sbd_engine_pass_count",
 )
 
 _LIB = None
@@ -94,6 +94,8 @@ def load() -> C.CDLL:
     L.sbd_engine_workspace_bytes.restype = C.c_size_t
     L.sbd_engine_chunk.argtypes = [vp]
     L.sbd_engine_chunk.restype = C.c_int32
+    L.sbd_engine_pass_count.argtypes = [vp, C.c_int32]
+    L.sbd_engine_pass_count.restype = C.c_int32
     L.sbd_engine_stream.argtypes = [vp]
     L.sbd_engine_stream.restype = vp
     L.sbd_engine_quadrature.argtypes = [vp, _dp, _dp]

@@ -1,9 +1,12 @@
 // Band LU kernel for 16 < NSTR <= 32: ONE boundary-value system per wave, block form, window in registers.
 //
 // Same job and the same inputs/outputs as band_kernel (sbd_band.hpp): SETMTX + SOLVE0's right-hand side
-// + SGBFA + the forward half of SGBSL (disort.f:2702-2994, 3322-3637, disutil.f:771-912, 1019-1036); the
-// interface rows come matrix-ready from the layer kernel's ga/gb blocks, U goes out row-major relative to
-// the diagonal (2 NSTR wide) for backsolve_kernel.  The elimination walks the matrix LAYER BY LAYER like
+// + SGBFA + the forward half of SGBSL (disort.f:2702-2994, 3322-3637, disutil.f:771-912, 1019-1036).  The
+// interface rows are built HERE from GC's two independent quarters (Params::gcc, what the layer kernels write
+// for band4_kernel too) and the STWJ factors exp(-k dtau'): until round 4 the layer kernels wrote them
+// matrix-ready (ga / gb, 2 NSTR^2 doubles per layer beside GC's NSTR^2) -- at NSTR 32 that made the layer kernel
+// write 1.5 MB per solve at 4.3 TB/s: bound by HBM writes.  U goes out row-major relative to the diagonal
+// (2 NSTR wide) for backsolve_kernel.  The elimination walks the matrix LAYER BY LAYER like
 // band4_kernel (sbd_band4.hpp, see there for why these are exactly the rows and columns LINPACK touches):
 // layer step lc holds NN carry rows and the NSTR rows of interface lc -- RW = 3 NN rows over the columns
 // of x_lc and x_lc+1 -- and retires NSTR rows to U in NSTR sub-steps with partial pivoting.
@@ -139,7 +142,10 @@ SBD_DEVICE double wave_sum64(double v)
 // the bottom block, scaled by 2^-300 (the exact first-maximum search never takes them while a real row is left), tagged
 // 1, 2, 3 in the x_lc+1 half, which the last step does not use.  No U, no B, no back-substitution kernel.
 template <int NN, bool FUSED = false>
-__global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
+#ifndef SBD_B1_WAVES
+#define SBD_B1_WAVES 3       // waves per SIMD the kernel is compiled for: 3 = a 168-register cap (the fused variant then spills
+#endif                       // ~36 registers, nearly all outside the sub-steps; 2: 238 registers, no spill) -- measured, DESIGN 6
+__global__ void __launch_bounds__(64, SBD_B1_WAVES) band1_kernel(Params P)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];   // kBand1LdsDoubles
     constexpr int n = 2 * NN, nn = NN, RW = nn + n, UW = u_width(n);
@@ -180,8 +186,7 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
     const double *zz = P.zz + (size_t)ms * L * n;
     const double *zp0 = P.zp0 + (size_t)(ms - mazim) * L * n;     // thermal solutions: mode 0 only
     const double *zp1 = P.zp1 + (size_t)(ms - mazim) * L * n;
-    const double *ga_ms = P.ga + (size_t)ms * L * n * n;           // interface lc: [row][column of x_lc]
-    const double *gb_ms = P.gb + (size_t)ms * L * n * n + (size_t)n * n;    // ... [row][column of x_lc+1]
+    const double *gcc = P.gcc + (size_t)ms * L * 2 * nn * nn;      // [layer][2][nn][nn]: the quarters (rows iq+nn | nn+1-iq) x columns me+nn
     double *yv = P.yv + (size_t)ms * L * n;
     double *ufac = FUSED ? nullptr : P.ufac + (size_t)ms * (size_t)(L * n) * UW;
     double *bcb = P.bcb + (size_t)ms * 2 * n * n;                  // bottom-boundary rows + a block of zeros (below)
@@ -271,21 +276,45 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
                 } else if (refl) g = g - (1.0 + delm0) * sb;
                 g = g * f;
             }
-            bcb[r * n + qc] = g;
-            bcb[(n + r) * n + qc] = 0.0;
+            // (stored like the layers' quarters, so that one addressing serves every step: column qc belongs to half
+            //  hq = qc / nn, rows nn.. to block BU[hq] in their order, rows ..nn-1 to block BD[hq] REVERSED;
+            //  blocks [BU0, BD0, BU1, BD1, zeros], nn x nn doubles each)
+            const int hq = (qc >= nn) ? 1 : 0, cq = qc - hq * nn;
+            if (r >= nn) bcb[(size_t)(2 * hq) * nn * nn + (r - nn) * nn + cq] = g;
+            else bcb[(size_t)(2 * hq + 1) * nn * nn + (nn - 1 - r) * nn + cq] = g;
         }
+        for (int i = qc; i < nn * nn; i += n) bcb[(size_t)4 * nn * nn + i] = 0.0;        // (the n column lanes run this branch)
     }
     __threadfence_block();   // the boundary block is re-read by this wave as its rows enter the window
 
-    // rows of step lci (r = 0..n-1) for this lane: p[r * n] -- an interface block, the boundary block, or
-    // the block of zeros behind it (compile-time stride: immediate offsets, no per-row address registers)
-    struct RowSrc { const double *p; };
+    // rows of step lci (r = 0..n-1) for this lane, from GC's quarters of layer lci (columns of x_lc) or lci + 1 (columns
+    // of x_lc+1): rows nn.. come from pu[(r - nn) * nn], rows ..nn-1 from pd[(nn - 1 - r) * nn] (compile-time offsets), times
+    // the lane's factor of the step (STWJ scaling, disort.f:2846-2876, and the sign of the x_lc+1 block):
+    //   column q >= nn (k > 0, eigenvalue me = q - nn + 1): quarters (cc0 | cc1);  x_lc: * EK(n - q, lci);       x_lc+1: * -1
+    //   column q <  nn (k < 0, eigenvalue me = nn - q):     quarters (cc1 | cc0);  x_lc: * -1;                  x_lc+1: * EK(q + 1, lci + 1)
+    // The bottom-boundary block (last step) and the zeros behind it are stored in the same form, factor 1.
+    struct RowSrc { const double *pu, *pd; double fac; };
+    const int me0 = (qc >= nn) ? qc - nn : nn - 1 - qc;            // eigenvalue index - 1 of this lane's column
     auto step_rows = [&](int lci) -> RowSrc {
-        const double *zeros = bcb + (size_t)n * n + qc;
-        if (!col || lci > ncut) return RowSrc{zeros};
-        if (lci == ncut) return second ? RowSrc{zeros} : RowSrc{bcb + qc};
-        const size_t blk = (size_t)(lci - 1) * n * n + qc;
-        return RowSrc{(second ? gb_ms : ga_ms) + blk};
+        const double *zeros = bcb + (size_t)4 * nn * nn;
+        if (!col || lci > ncut) return RowSrc{zeros, zeros, 1.0};
+        if (lci == ncut) {
+            if (second) return RowSrc{zeros, zeros, 1.0};
+            const int hq = (qc >= nn) ? 1 : 0;
+            return RowSrc{bcb + (size_t)(2 * hq) * nn * nn + (qc - hq * nn), bcb + (size_t)(2 * hq + 1) * nn * nn + (qc - hq * nn), 1.0};
+        }
+        const int lay = second ? lci + 1 : lci;                    // (lci < ncut <= L: layer lci + 1 exists)
+        const double *c0 = gcc + (size_t)(lay - 1) * 2 * nn * nn + me0, *c1 = c0 + nn * nn;
+        const bool pos = qc >= nn;
+        double f = -1.0;
+        if (!second && pos) f = EK(n - qc, lay);
+        if (second && !pos) f = EK(qc + 1, lay);
+        return RowSrc{pos ? c0 : c1, pos ? c1 : c0, f};
+    };
+    auto row_of = [&](const RowSrc &src, auto rr) -> double {      // (unscaled: the factor is applied when the rows enter the window)
+        constexpr int r = decltype(rr)::value;
+        if constexpr (r >= nn) return src.pu[(r - nn) * nn];
+        else return src.pd[(nn - 1 - r) * nn];
     };
     // right-hand side of row r = lane - nn of step lci: an interface, the bottom boundary, nothing
     const int rr = (lane >= nn && lane < RW) ? lane - nn : 0;
@@ -312,11 +341,11 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
 #pragma unroll
         for (int r = 1; r <= nn; ++r) a[r - 1] = (col && !second) ? GC(nn + 1 - r, iq1, 1) * f : 0.0;
         const RowSrc s1 = step_rows(1);
-#pragma unroll
-        for (int r = 0; r < n; ++r) {
-            const double v = s1.p[r * n];
+        static_for<n>([&](auto rr) {
+            constexpr int r = decltype(rr)::value;
+            const double v = row_of(s1, rr) * s1.fac;
             a[nn + r] = col ? v : 0.0;
-        }
+        });
         const Z3 z1 = load_z(1), z2 = load_z(2);
         const double y1 = step_rhs(1, z1, z2, expbea[1], taucpr[1]);
         y = (lane < nn) ? ytop : ((lane < RW) ? y1 : 0.0);
@@ -442,8 +471,8 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
                 blast = mcol[kBand1B + LAST];
             }
             // register LAST is free from here on: next interface's row LAST - nn moves in
-            if constexpr (LAST - nn >= E) a[LAST] = nx.p[(LAST - nn) * n];
-            if constexpr (J < E) buf[J] = nx.p[J * n];
+            if constexpr (LAST - nn >= E) a[LAST] = row_of(nx, std::integral_constant<int, LAST - nn>{});
+            if constexpr (J < E) buf[J] = row_of(nx, std::integral_constant<int, J>{});
             if constexpr (J == 0) {
                 zu = load_z(lc + 1);
                 zn = load_z(lc + 2);
@@ -548,6 +577,9 @@ __global__ void __launch_bounds__(64, 2) band1_kernel(Params P)
         }
 #pragma unroll
         for (int r = 0; r < E; ++r) a[nn + r] = buf[r];
+        // the new interface's rows take their STWJ factor / sign (they came in as GC's quarter entries)
+#pragma unroll
+        for (int r = 0; r < n; ++r) a[nn + r] = a[nn + r] * nx.fac;
         y = (lane < nn || frow) ? y : ((lane < RW) ? ynext : 0.0);
         if constexpr (FUSED) {
 #pragma unroll

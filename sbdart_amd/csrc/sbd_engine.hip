@@ -606,8 +606,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     // fluxes at the top of the first layer and at the surface only (IOUT 1 / 10 with the default ZOUT): fused band kernel
     bool fused = (band4 || band1) && nn >= 3 && cfg->onlyfl && cfg->nlevel_out == 2 && cfg->level_out[0] == 0 && cfg->level_out[1] == L;
     if (const char *s = getenv("SBD_NO_FUSE")) fused = fused && atoi(s) == 0;
-    const size_t nblk = band4 ? 1 : 3;
-    const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)2 * n * n : 0) + (size_t)L * n * 6 + (size_t)L * nn + (fused ? 0 : (size_t)L * n * (2 * n))
+    const size_t nblk = (band4 || band1) ? 1 : 3;          // GC alone, or GC + the matrix-ready interface blocks ga / gb
+    const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)2 * n * n + (size_t)L * 2 * nn * nn : 0) + (size_t)L * n * 6 + (size_t)L * nn + (fused ? 0 : (size_t)L * n * (2 * n))
                                             + (rad_user ? (size_t)L * n * numu + 3 * (size_t)L * numu : 0) + (rad ? (size_t)e->nlev * numu : 0));
     const bool brdf = !cfg->lamber, brdf_item = brdf && cfg->ibdrf == 1;      // (the ocean's tables follow the wavelength)
     const size_t numu1 = numu > 0 ? (size_t)numu : 1;     // (a flux-only run still carves one row of RMU / EMU per item)
@@ -651,6 +651,10 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         if (band4) {
             P.ga = P.gb = nullptr;
             P.bcb = (double *)take(sizeof(double) * nms * n * n);
+            P.gcc = (double *)take(sizeof(double) * nms * L * 2 * nn * nn);
+        } else if (band1) {      // (round 4: band1_kernel builds its interface rows from GC's quarters like band4_kernel)
+            P.ga = P.gb = nullptr;
+            P.bcb = (double *)take(sizeof(double) * nms * 2 * n * n);
             P.gcc = (double *)take(sizeof(double) * nms * L * 2 * nn * nn);
         } else {
             P.ga = (double *)take(sizeof(double) * nms * L * n * n);
@@ -717,7 +721,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->fused = fused;
     e->corint = rad && cfg->corint != 0;
     e->quad = quad;
-    e->P.ublock = e->P.gconly = band4 ? 1 : 0;
+    e->P.ublock = band4 ? 1 : 0;
+    e->P.gconly = (band4 || band1) ? 1 : 0;
     const sbd::BandLds bl(n, nn, e->band_reg);
     e->band_lds = (int)sizeof(double) * bl.total;
     const sbd::SolveLds sl(n, nn, L);
@@ -913,6 +918,22 @@ struct HostSide {
 };
 static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, void *hip_stream, const HostSide *hs);
 
+// A batch larger than the workspace goes through in EQUAL passes (no short tail pass whose kernels cost their full launch
+// latency for a handful of items); consecutive passes alternate between the two workspaces and run on two streams: an even
+// number, the kernels of pass i+1 beside those of pass i.
+int32_t sbd_engine_pass_count(const sbd_engine *e, int32_t nwork)
+{
+    if (!e || nwork <= 0) return 0;
+    int npass = (nwork + e->chunk - 1) / e->chunk;
+    if (npass == 1 && nwork >= 16384) npass = 2;
+    // NSTR 18-32, flux: the layer kernel (VALU) and band1_kernel (LDS pipe, dependent chains) of different passes fill each
+    // other's gaps -- six passes of >= 1 365 items instead of one: 446 k -> 461 k points/s on 16 258 solves of NSTR 32 x 50
+    // layers (tools/chunk_probe_cfgD.py, round 4)
+    if (e->band1 && e->cfg.onlyfl && nwork >= 8192 && npass < 6) npass = 6;
+    if (npass > 1 && (npass & 1)) ++npass;
+    return npass;
+}
+
 // IBCND = 1: expand the batch into its top-lit / bottom-lit internal items, run the general pipeline on them, close with
 // ALBTRN's formulas (device pointers in and out, everything on the caller's stream)
 static int ibcnd_solve_device(sbd_engine *e, const sbd_batch_in *in, const sbd_batch_out *out, void *hip_stream)
@@ -988,9 +1009,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
     // With more than one pass, consecutive passes alternate between the two workspaces and run on two
     // streams (the caller's and the engine's auxiliary one): an even number of equal passes, the
     // kernels of pass i+1 beside those of pass i.  Per-kernel timing (enable_timing) keeps one stream.
-    int npass = (in->nwork + e->chunk - 1) / e->chunk;
-    if (npass == 1 && in->nwork >= 16384) npass = 2;
-    if (npass > 1 && (npass & 1)) ++npass;
+    int npass = sbd_engine_pass_count(e, in->nwork);
     const bool fork = !timing && !dbg && npass > 1;
     const int per_pass = (in->nwork + npass - 1) / npass;
     // pass ip = items [pw0[ip], pw0[ip + 1]).  Inputs resident on the device: the equal passes above.  Inputs coming

@@ -175,6 +175,10 @@ class DisortEngine:
             raise SbdError(rc, "sbd_engine_solve_host")
         return albtrn, status
 
+    def pass_count(self, nwork: int) -> int:
+        """Equal passes a resident batch of nwork items goes through (alternating between two workspaces / streams)."""
+        return int(self._L.sbd_engine_pass_count(self._h, int(nwork)))
+
     def solve(self, dtauc, ssalb, pmom, wvnmlo, wvnmhi, fbeam, albedo, plank, bitem=None, pmom_row=None):
         """Solve a batch.  Shapes: dtauc/ssalb [W, nlyr]; pmom [W, nlyr, nmom+1] -- or, with pmom_row [W] (int32 block
         index per item), [npmom, nlyr, nmom+1]: the k-terms of a spectral point share their moments;

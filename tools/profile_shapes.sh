@@ -18,7 +18,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $o/traceC --
 grep 'radiance nstr' $o/traceC.log | tail -1 > $o/cfgC_bench_under_rocprof.txt
 find $o/traceC -name "*kernel_stats.csv" -exec cp {} $o/cfgC_kernel_stats.csv \;
 # counters, one pass each
-WD=$(python -c "import json;print(json.loads(open('$o/cfgD_bench_under_rocprof.json').read())['config']['solves_per_gpu'])")
+WD=$(python -c "import json;print(json.loads(open('$o/cfgD_bench_under_rocprof.json').read())['roofline']['solves_per_launch'])")   # (one PASS of the batch)
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   timeout 300 rocprofv3 --pmc $c --output-format csv -d $o/pmcD/$c -- $cmdD > $o/pmcD_$c.log 2>&1 || echo "D $c pass failed"
   timeout 300 rocprofv3 --pmc $c --output-format csv -d $o/pmcC/$c -- $cmdC > $o/pmcC_$c.log 2>&1 || echo "C $c pass failed"
