@@ -632,11 +632,17 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
         // GC (disort.f:3290-3312) and the matrix-ready interface blocks (disort.f:2851-2876)
         // straight from registers: this lane owns columns me+nn (k > 0) and nn+1-me (k < 0) of
         // every row, nn lanes write nn consecutive doubles per instruction.  GC itself is only
-        // read back for the layers FLUXES / the boundary rows / USRINT need.
+        // read back for the layers FLUXES / the boundary rows / USRINT need (USRINT: the last layer's, for the
+        // surface term; until round 4 the radiance variant wrote all of them -- 8 KB per layer and mode at NSTR 32,
+        // a third of this kernel's stores, read by nobody).
         // (gconly: sbd_band4.hpp scales GC by the STWJ factors itself and only needs GC's two independent
         //  quarters, Params::gcc -- a quarter of the bytes of ga + gb)
-        bool need_gc = rad || P.all_levels || lc == 1 || lc == ncut || lay0 == lc || lay1 == lc;
-        if (!need_gc) {
+        bool need_gc = P.all_levels || lc == 1 || lc == ncut || (rad && lc == L) || lay0 == lc || lay1 == lc;
+        if constexpr (rad) {
+            // (a third output level without all of them does not occur under the Fortran host: then every layer's GC is
+            //  written as before -- the loop over the levels below costs this variant 130 more spilled registers)
+            need_gc = need_gc || P.nlev > 2;
+        } else if (!need_gc) {
             for (int i = 2; i < P.nlev; ++i) need_gc = need_gc || layru[P.t.level_out[i]] == lc;
         }
         double *gcout = P.gc + lidx * n * n;

@@ -16,7 +16,7 @@
 
 namespace sbd {
 
-__global__ void __launch_bounds__(64) usrint_kernel(Params P)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) usrint_kernel(Params P)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
@@ -200,9 +200,13 @@ __global__ void __launch_bounds__(64) usrint_kernel(Params P)
         if (!live) lyrend = lyrstr - 1;
         const int q0 = sl * nq;                           // this lane's streams: q0+1 .. q0+nq of either half
         double palint = 0.0, plkint = 0.0, exp1 = 0.0, exp2 = 0.0, denom, expn;
+        // (the loads of a batch of streams -- KK, EK, LL, GU: 4 per stream -- are issued together, then the batch is
+        //  summed in the same order as before: the loop used to pay a memory round trip per stream, 1 056 of them in a
+        //  row at NSTR 32 x 33 layers.  exp2 of a layer is exp1 of the next: the same expression on the same operands)
+        if (lyrstr <= lyrend) exp2 = exp((up - taucpr[lyrstr - 1]) * rum);
         for (int lc = lyrstr; lc <= lyrend; ++lc) {
             const double dtau = dtaucp[lc - 1];
-            exp1 = exp((up - taucpr[lc - 1]) * rum);
+            exp1 = exp2;
             exp2 = exp((up - taucpr[lc]) * rum);
             if (sl == 0) {
                 if (therm) {
@@ -217,18 +221,49 @@ __global__ void __launch_bounds__(64) usrint_kernel(Params P)
                     palint = palint + ZB(iu, lc) * expn;
                 }
             }
-            for (int iq = q0 + 1; iq <= q0 + nq; ++iq) {   // KK negative
-                denom = 1.0 + um * KK(iq, lc);
-                if (fabs(denom) < lh) expn = dtau * rum * exp2;
-                else expn = sgn * (exp1 * EK(iq, lc) - exp2) * rcp(denom);
-                palint = palint + (GU(iu, iq, lc) * LL(iq, lc)) * expn;
-            }
-            for (int iq = nn + q0 + 1; iq <= nn + q0 + nq; ++iq) {   // KK positive
-                denom = 1.0 + um * KK(iq, lc);
-                if (fabs(denom) < lh) expn = -dtau * rum * exp1;
-                else expn = sgn * (exp1 - exp2 * EK(n + 1 - iq, lc)) * rcp(denom);
-                palint = palint + (GU(iu, iq, lc) * LL(iq, lc)) * expn;
-            }
+            const double *kp = kk + (lc - 1) * n + q0, *lp = ll + (lc - 1) * n + q0;
+            const double *gp = gu + ((size_t)(lc - 1) * n + q0) * numu + (iu - 1);
+            const double *ep = ek + (lc - 1) * nn + q0;                       // EK(iq, lc), iq = q0+1 ..
+            const double *er = ek + (lc - 1) * nn + (nn - 1 - q0);            // EK(n+1-iq, lc), iq = nn+q0+1 ..: descending
+            const double dlo = dtau * rum * exp2, dhi = -dtau * rum * exp1;
+            auto lower = [&](const double k, const double e, const double l, const double g) {   // KK negative
+                const double dn = 1.0 + um * k;
+                const double ex = (fabs(dn) < lh) ? dlo : sgn * (exp1 * e - exp2) * rcp(dn);
+                palint = palint + (g * l) * ex;
+            };
+            auto upper = [&](const double k, const double e, const double l, const double g) {   // KK positive
+                const double dn = 1.0 + um * k;
+                const double ex = (fabs(dn) < lh) ? dhi : sgn * (exp1 - exp2 * e) * rcp(dn);
+                palint = palint + (g * l) * ex;
+            };
+            // batches of 8, then 4, 2, 1 streams (nq = 8 at NSTR 32 with two lanes per item, 4 at NSTR 16)
+            auto run = [&](auto bb, int &c, const bool up_half) {
+                constexpr int B = decltype(bb)::value;
+                for (; c + B <= nq; c += B) {
+                    double k8[B], e8[B], l8[B], g8[B];
+#pragma unroll
+                    for (int t = 0; t < B; ++t) {
+                        k8[t] = kp[c + t]; l8[t] = lp[c + t]; g8[t] = gp[(size_t)(c + t) * numu];
+                        e8[t] = up_half ? er[-(c + t)] : ep[c + t];
+                    }
+#pragma unroll
+                    for (int t = 0; t < B; ++t) {
+                        if (up_half) upper(k8[t], e8[t], l8[t], g8[t]);
+                        else lower(k8[t], e8[t], l8[t], g8[t]);
+                    }
+                }
+            };
+            int c = 0;
+            run(std::integral_constant<int, 8>{}, c, false);
+            run(std::integral_constant<int, 4>{}, c, false);
+            run(std::integral_constant<int, 2>{}, c, false);
+            run(std::integral_constant<int, 1>{}, c, false);
+            kp += nn; lp += nn; gp += (size_t)nn * numu;
+            c = 0;
+            run(std::integral_constant<int, 8>{}, c, true);
+            run(std::integral_constant<int, 4>{}, c, true);
+            run(std::integral_constant<int, 2>{}, c, true);
+            run(std::integral_constant<int, 1>{}, c, true);
         }
         // from the output level to the adjacent computational level
         const double dtau1 = up - taucpr[lyu - 1];
