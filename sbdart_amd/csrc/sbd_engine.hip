@@ -736,7 +736,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     CREATE_TRY(sbd::prepare_band_lds(nn, e->band_lds));
     CREATE_TRY(sbd::prepare_backsolve(nn, e->solve_lds));
     {
-        const sbd::Layer2Lds l2(n, nn, rad_user);
+        const sbd::Layer2Lds l2(n, nn, rad_user, rad_user ? numu : 0);
         e->G2 = sbd::l2_group(nn);
         e->layer2_lds = (int)sizeof(double) * (l2.shared_total + l2.group_total * (64 / e->G2));
         if (const char *s = getenv("SBD_LAYER_V1")) e->use_layer2 = atoi(s) == 0;

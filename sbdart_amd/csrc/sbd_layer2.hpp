@@ -30,8 +30,8 @@
 namespace sbd {
 
 struct Layer2Lds {   // doubles; per-group part + per-block shared part
-    int ld, ldq, gl, lu, vec, group_total, shared_y, shared_total;
-    __host__ __device__ Layer2Lds(int n, int nn, bool rad)
+    int ld, ldq, gl, lu, vec, group_total, shared_y, shared_yu, shared_total;
+    __host__ __device__ Layer2Lds(int n, int nn, bool rad, int numu = 0)
     {
         ld = n | 1;
         ldq = nn | 1;                       // Q+-/L/C, later a scratch block: walked by rows and by columns
@@ -54,6 +54,8 @@ struct Layer2Lds {   // doubles; per-group part + per-block shared part
         if (G <= 16) group_total += ((G - group_total) % 32 + 32) % 32;
         shared_y = 0;                       // Y(l, iq) l-major: [n][nn]
         shared_total = (n * nn + 2 * n + 4 * nn + 1) & ~1;   // + R, 1/(M R), 1/W, 1/M tables
+        shared_yu = shared_total;           // radiance mode: Ylm of the block's mode at the user angles, [numu][n] (TERPEV)
+        if (rad) shared_total += (numu * n + 1) & ~1;
     }
 };
 
@@ -169,7 +171,7 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
     const int lc = live ? (int)(fid % L) + 1 : L + 1;
     const long long ms = (long long)slot * nmode + mazim;
 
-    const Layer2Lds lds(n, nn, RAD);
+    const Layer2Lds lds(n, nn, RAD, P.numu);
     double *shy = smem;                                  // shared: Y(l, iq), cmu, cwt
     double *scmu = smem + n * nn, *scwt = scmu + n;
     double *srr = scwt + n, *sxi = srr + nn, *swi = sxi + nn, *smi = swi + nn;   // R = (W/M)^1/2, 1/(M R), 1/W, 1/M
@@ -193,6 +195,16 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
         yent[t] = (e < n * nn) ? ylmc[iq * (n + 1) + l] : 0.0;
     }
     const double tcmu = (lane < n) ? P.t.cmu[lane] : 1.0, tcwt = (lane < n) ? P.t.cwt[lane] : 1.0;
+    constexpr int NYU = RAD ? 12 : 1;                      // radiance: the user-angle Ylm of this mode, 64 per load
+    const double *ylmu_g = P.t.ylmu + (size_t)mazim * numu * (n + 1);
+    double yub[NYU];
+    if constexpr (RAD) {
+#pragma unroll
+        for (int t = 0; t < NYU; ++t) {
+            const int e = lane + 64 * t;
+            yub[t] = (e < numu * n) ? ylmu_g[(e / n) * (n + 1) + e % n] : 0.0;
+        }
+    }
     const int st0 = svi[SBD_SVI_STATUS];
     const int ncut = svi[SBD_SVI_NCUT];
     const double fbeam = P.fbeam[slot];
@@ -227,6 +239,15 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
         const int e = lane + 64 * t;
         if (e < n * nn) shy[e] = yent[t];
     }
+    if constexpr (rad) {   // TERPEV's table: Ylm(mu_user) of this mode, rows of n (the tables' rows hold n + 1)
+        double *syu = smem + lds.shared_yu;
+#pragma unroll
+        for (int t = 0; t < NYU; ++t) {
+            const int e = lane + 64 * t;
+            if (e < numu * n) syu[e] = yub[t];
+        }
+        for (int e = lane + 64 * NYU; e < numu * n; e += 64) syu[e] = ylmu_g[(e / n) * (n + 1) + e % n];   // (more than 24 angles at NSTR 32)
+    }
     if (lane < n) { scmu[lane] = tcmu; scwt[lane] = tcwt; }
     if (lane < nn) {
         const double r = sqrt(tcwt / tcmu);
@@ -259,7 +280,7 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
 #define QM(i, j) qm_at((i), (j))
 
 #ifdef SBD_PHASE_TICKS
-    unsigned long long tick0 = 0, tick1 = 0, tick2 = 0, tick3 = 0, tick4 = 0, tick5 = 0, tick6 = 0;
+    unsigned long long tick0 = 0, tick1 = 0, tick2 = 0, tick3 = 0, tick4 = 0, tick5 = 0, tick6 = 0, tick5b = 0;
 #endif
     SBD_TICK(0)
     // ---- GL(k) (SETDIS, disort.f:2583-2585) ----
@@ -684,44 +705,73 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
 
     // ---- radiance mode: TERPEV from the register-resident eigenvector columns ----
     if constexpr (rad) {
-        const double *ylmu = P.t.ylmu + (size_t)mazim * numu * (n + 1);
+        // Until round 4 this block was three quarters of the radiance variant's time (tools/layer_phases_rad.py:
+        // 236 k of 319 k cycles per wave at NSTR 32): the user-angle Ylm came from global memory one value -- one
+        // memory round trip -- at a time, the quadrature-angle Ylm from LDS the same way.  Now: the user-angle table of
+        // the block's mode waits in LDS (staged with the first batch of loads), a row of quadrature-angle values is read
+        // as one batch, the parity of l - m is a uniform branch instead of a multiplication.  Every sum is formed from
+        // the same operands in the same order as before.
+        const double *syu = smem + lds.shared_yu;
         double *guout = P.gu + lidx * n * numu;
         if (me <= nn) {
             // EVECC column me (k>0) and me+nn (k<0): rows iq<=nn / iq>nn
-            double wkp[n], wkn[n];
+            double e11[nn], e21[nn];
 #pragma unroll
-            for (int l = 0; l < n; ++l) {
+            for (int i = 0; i < nn; ++i) { e11[i] = 0.5 * (gp[i] + xcol[i]); e21[i] = 0.5 * (gp[i] - xcol[i]); }
+            double wkp[n], wkn[n];
+            static_for<n>([&](auto ll) {
+                constexpr int l = decltype(ll)::value;
                 double sp_ = 0.0, sn_ = 0.0;
                 if (l >= mazim) {
-                    const double sgn = (((l - mazim) & 1) == 0) ? 1.0 : -1.0;   // Y(l,-mu) = sgn * Y(l,mu)
-                    for (int jq = 1; jq <= nn; ++jq) {
-                        const double y = YS(l, jq) * scwt[jq - 1];
-                        const double e11 = 0.5 * (gp[jq - 1] + xcol[jq - 1]), e21 = 0.5 * (gp[jq - 1] - xcol[jq - 1]);
-                        sp_ = sp_ + y * e11 + sgn * y * e21;          // column me
-                        sn_ = sn_ + y * (-e21) + sgn * y * (-e11);    // column me+nn
+                    double y[nn];
+#pragma unroll
+                    for (int jq = 0; jq < nn; ++jq) y[jq] = YS(l, jq + 1) * scwt[jq];
+                    if (((l - mazim) & 1) == 0) {                      // Y(l,-mu) = +Y(l,mu)
+#pragma unroll
+                        for (int jq = 0; jq < nn; ++jq) {
+                            sp_ = sp_ + y[jq] * e11[jq] + 1.0 * y[jq] * e21[jq];          // column me
+                            sn_ = sn_ + y[jq] * (-e21[jq]) + 1.0 * y[jq] * (-e11[jq]);    // column me+nn
+                        }
+                    } else {                                           // Y(l,-mu) = -Y(l,mu)
+#pragma unroll
+                        for (int jq = 0; jq < nn; ++jq) {
+                            sp_ = sp_ + y[jq] * e11[jq] + (-y[jq]) * e21[jq];
+                            sn_ = sn_ + y[jq] * (-e21[jq]) + (-y[jq]) * (-e11[jq]);
+                        }
                     }
                     sp_ = 0.5 * gl[l] * sp_;
                     sn_ = 0.5 * gl[l] * sn_;
                 }
                 wkp[l] = sp_;
                 wkn[l] = sn_;
-            }
+            });
+            // (the terms l < m are +0 x Ylm = +-0 added to a sum that starts at +0: they leave it as it is, so whole
+            //  blocks of eight l are taken or skipped)
             for (int iu = 1; iu <= numu; ++iu) {
+                const double *yrow = syu + (iu - 1) * n;
                 double s1 = 0.0, s2 = 0.0;
+                static_for<(n + 7) / 8>([&](auto bb) {
+                    constexpr int l0 = 8 * decltype(bb)::value;
+                    if (l0 + 7 >= mazim) {
+                        double yu[8];
 #pragma unroll
-                for (int l = 0; l < n; ++l) {
-                    if (l >= mazim) {
-                        const double yu = ylmu[(iu - 1) * (n + 1) + l];
-                        s1 = s1 + wkp[l] * yu;
-                        s2 = s2 + wkn[l] * yu;
+                        for (int t = 0; t < 8; ++t) yu[t] = (l0 + t < n) ? yrow[l0 + t] : 0.0;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            if (l0 + t < n) {
+                                s1 = s1 + wkp[l0 + t] * yu[t];
+                                s2 = s2 + wkn[l0 + t] * yu[t];
+                            }
+                        }
                     }
-                }
+                });
                 guout[(me + nn - 1) * numu + (iu - 1)] = s1;        // IQ = me      -> GU(iu, me+nn)
                 guout[(nn + 1 - me - 1) * numu + (iu - 1)] = s2;    // IQ = me+nn   -> GU(iu, n+1-(me+nn))
             }
         }
     }
 
+    SBD_TICK(5b)
     // ---- UPBEAM / UPISOT on the +-mu-reduced systems (see the header), from the singular vectors at hand.
     //      With Y = [y_j] (y_j = L v_j), CB' = [C b'_j] = Q- Y and K = diag(k_j):
     //        Y Y^T = Q+,   Y^T (CB') = K^2,   Q+^-1 = (CB') K^-4 (CB')^T,   Q- = (CB') K^-2 (CB')^T,
@@ -891,6 +941,7 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
             atomicAdd(&tk[4], tick5 - tick4); atomicAdd(&tk[5], tick6 - tick5);
             atomicAdd(&tk[6], tick7 - tick6); atomicAdd(&tk[7], 1ull);
             atomicAdd(&tk[8], (unsigned long long)nsweep);
+            atomicAdd(&tk[9], tick5b - tick5);            // (radiance variant: TERPEV, part of counter 5)
         }
     }
 #endif
