@@ -55,7 +55,7 @@ struct Layer2Lds {   // doubles; per-group part + per-block shared part
         shared_y = 0;                       // Y(l, iq) l-major: [n][nn]
         shared_total = (n * nn + 2 * n + 4 * nn + 1) & ~1;   // + R, 1/(M R), 1/W, 1/M tables
         shared_yu = shared_total;           // radiance mode: Ylm of the block's mode at the user angles, [numu][n] (TERPEV)
-        if (rad) shared_total += (numu * n + 1) & ~1;
+        if (rad) shared_total += numu * (n + 2);     // (rows n + 2 apart: TERPSO walks the table a row per lane)
     }
 };
 
@@ -244,9 +244,9 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
 #pragma unroll
         for (int t = 0; t < NYU; ++t) {
             const int e = lane + 64 * t;
-            if (e < numu * n) syu[e] = yub[t];
+            if (e < numu * n) syu[(e / n) * (n + 2) + e % n] = yub[t];
         }
-        for (int e = lane + 64 * NYU; e < numu * n; e += 64) syu[e] = ylmu_g[(e / n) * (n + 1) + e % n];   // (more than 24 angles at NSTR 32)
+        for (int e = lane + 64 * NYU; e < numu * n; e += 64) syu[(e / n) * (n + 2) + e % n] = ylmu_g[(e / n) * (n + 1) + e % n];   // (more than 24 angles at NSTR 32)
     }
     if (lane < n) { scmu[lane] = tcmu; scwt[lane] = tcwt; }
     if (lane < nn) {
@@ -748,7 +748,7 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
             // (the terms l < m are +0 x Ylm = +-0 added to a sum that starts at +0: they leave it as it is, so whole
             //  blocks of eight l are taken or skipped)
             for (int iu = 1; iu <= numu; ++iu) {
-                const double *yrow = syu + (iu - 1) * n;
+                const double *yrow = syu + (iu - 1) * (n + 2);
                 double s1 = 0.0, s2 = 0.0;
                 static_for<(n + 7) / 8>([&](auto bb) {
                     constexpr int l0 = 8 * decltype(bb)::value;
@@ -881,7 +881,9 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
     }
     // ---- TERPSO (disort.f:3980-4128) ----
     if constexpr (rad) {
-        const double *ylmu = P.t.ylmu + (size_t)mazim * numu * (n + 1);
+        // (the user-angle Ylm from TERPEV's LDS table, the beam's Ylm from the registers of the first load batch, eight
+        //  terms per batch of LDS reads; until round 4 a global load per term.  Same sums, same order.)
+        const double *syu = smem + lds.shared_yu;
         double *zbout = P.zb + lidx * numu, *z0uout = P.z0u + lidx * numu, *z1uout = P.z1u + lidx * numu;
         double *psi0 = psi, *psi1 = psi + n;
         if (fbeam > 0.0) {
@@ -895,9 +897,26 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
             wave_lds_sync();
             const double fact = (2.0 - delm0) * fbeam / (4.0 * P.pi);
             for (int iu = me; iu <= numu; iu += G) {
+                const double *yrow = syu + (iu - 1) * (n + 2);
                 double sum = 0.0;
-                for (int iq = mazim; iq <= n - 1; ++iq)
-                    sum = sum + ylmu[(iu - 1) * (n + 1) + iq] * (psi0[iq] + fact * gl[iq] * ylm0[iq]);
+                static_for<(n + 7) / 8>([&](auto bb) {
+                    constexpr int l0 = 8 * decltype(bb)::value;
+                    if (l0 + 7 >= mazim) {
+                        double yu[8], ps[8], gv[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const int iq = (l0 + t < n) ? l0 + t : n - 1;
+                            yu[t] = yrow[iq]; ps[t] = (iq >= mazim) ? psi0[iq] : 0.0; gv[t] = gl[iq];
+                        }
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            if (l0 + t < n) {
+                                const double nx = sum + yu[t] * (ps[t] + fact * gv[t] * y0[l0 + t]);
+                                sum = (l0 + t >= mazim) ? nx : sum;
+                            }
+                        }
+                    }
+                });
                 zbout[iu - 1] = sum;
             }
             wave_lds_sync();
@@ -917,9 +936,11 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
             }
             wave_lds_sync();
             for (int iu = me; iu <= numu; iu += G) {
+                const double *yrow = syu + (iu - 1) * (n + 2);
                 double sum0 = 0.0, sum1 = 0.0;
+#pragma unroll
                 for (int iq = 0; iq <= n - 1; ++iq) {
-                    const double yu = ylmu[(iu - 1) * (n + 1) + iq];
+                    const double yu = yrow[iq];
                     sum0 = sum0 + yu * psi0[iq];
                     sum1 = sum1 + yu * psi1[iq];
                 }
