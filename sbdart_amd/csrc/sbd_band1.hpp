@@ -596,7 +596,12 @@ __global__ void __launch_bounds__(64, SBD_B1_WAVES) band1_kernel(Params P)
     // reference writes none (ultraviolet and near-infrared columns with optical depths of tens per layer: pivots of
     // exp(-k dtau) ~ 1e-13, RCOND ~ 1e-14 -- ill-conditioned, not singular to working precision).  On the leading words:
     // 20 bits of mantissa are plenty for a threshold.
-    if (lane == 0 && !(__hiloint2double((int)pmin_hi, 0) > 1.1102230246251565e-16 * __hiloint2double((int)pmax_hi, 0))) status |= 0x01;
+    // (NaN: the reference's RCOND is NaN then and 1 + NaN == 1 false -- no warning; the leading-word maxima above skip
+    //  NaN, so the right-hand side is asked: sbd_band4.hpp has the story)
+    {
+        const bool ynan = __builtin_amdgcn_ballot_w64(y != y) != 0ull;
+        if (lane == 0 && !ynan && __hiloint2double((int)pmin_hi, 0) <= 1.1102230246251565e-16 * __hiloint2double((int)pmax_hi, 0)) status |= 0x01;
+    }
     if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
     if constexpr (FUSED) {
         if (lane == 0) P.status[slot] = st0 | status;       // (the last kernel of a fused pass: no finish_kernel)

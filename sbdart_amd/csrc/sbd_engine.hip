@@ -1563,6 +1563,7 @@ struct sbd_fleet {
     std::vector<double> t_enq;        // [ndev][2] host clock (s since the call began) around each device's enqueue
     int retry_nstr = 0;
     int pinned_last = 0;              // arrays of the last call that were page-locked for its duration
+    std::vector<std::vector<int32_t>> shard_rows;   // [ndev] a shard's moment-block rows counted from its first block (kept until the next call)
 };
 
 void sbd_shard_range(int32_t nwork, int32_t nshard, int32_t rank, int32_t *lo, int32_t *hi)
@@ -1675,6 +1676,7 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
         f->pinned_last = (int)pinned.size();
     }
     f->t_enq.assign((size_t)nd * 2, 0.0);
+    f->shard_rows.resize((size_t)nd);
     {
         const auto t_begin = std::chrono::steady_clock::now();
         std::vector<int> rcs(nd, SBD_OK);
@@ -1686,7 +1688,24 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
                                in->wvnmlo + lo, in->wvnmhi + lo, in->fbeam + lo, in->albedo + lo, in->plank + lo,
                                in->bitem ? in->bitem + (size_t)lo * 4 : nullptr,
                                in->pmom_row ? in->pmom_row + lo : nullptr, in->npmom};
-            if (in->pmom_row) si.pmom = in->pmom;          // (row indices are global: every shard sees the whole block list)
+            if (in->pmom_row) {
+                // moments per spectral point.  Items in wavelength order (rows non-decreasing inside the shard): the
+                // shard is handed ITS blocks only, rows counted from its first one -- its device stages r1 - r0 + 1
+                // blocks, not all npmom of them (round 3 sized every device's staging area for the whole list).
+                // Unsorted rows: the whole block list, global indices.
+                si.pmom = in->pmom;
+                bool sorted = hi > lo;
+                for (int32_t i = lo + 1; i < hi && sorted; ++i) sorted = in->pmom_row[i] >= in->pmom_row[i - 1];
+                const int32_t r0 = sorted ? in->pmom_row[lo] : 0, r1 = sorted ? in->pmom_row[hi - 1] : -1;
+                if (sorted && nd > 1 && r0 >= 0 && r1 < in->npmom) {
+                    std::vector<int32_t> &rows = f->shard_rows[r];
+                    rows.resize((size_t)(hi - lo));
+                    for (int32_t i = lo; i < hi; ++i) rows[(size_t)(i - lo)] = in->pmom_row[i] - r0;
+                    si.pmom = in->pmom + (size_t)r0 * L * nmom1;
+                    si.pmom_row = rows.data();
+                    si.npmom = r1 - r0 + 1;
+                }
+            }
             sbd_batch_out so = {out->flux ? out->flux + (size_t)lo * nel_f : nullptr,
                                 (rad && out->uu) ? out->uu + (size_t)lo * uu_item : nullptr, out->status + lo,
                                 (e0->ibcnd && out->albtrn) ? out->albtrn + (size_t)lo * 2 * e0->ib_nout : nullptr};
