@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     const int st0 = svi[SBD_SVI_STATUS];
     const double fbeam = P.fbeam[slot];
     const bool dead = (st0 & (0x20 | 0x10 | 0x08)) != 0;
-    if (mazim > 0 && (fbeam == 0.0 || dead)) return;
+    if (mazim > 0 && (mazim > svi[SBD_SVI_NAZ] || dead)) return;
     const int nlev = P.nlev;
     double *flux = P.flux + (size_t)slot * SBD_NFLUX_ * nlev;
     if (dead) {   // DISORT returned before computing anything: outputs stay zero (ZEROAL)

@@ -119,7 +119,8 @@ struct SV {
 #define SBD_SVI_NCUT 0
 #define SBD_SVI_LYRCUT 1
 #define SBD_SVI_STATUS 2
-#define SBD_SVI_LAYRU 3
+#define SBD_SVI_NAZ 3        /* highest azimuth mode of the item that can differ from zero (setup_kernel) */
+#define SBD_SVI_LAYRU 4
 
 // Lanes of one wave exchange data through LDS without a hardware barrier: LDS
 // instructions of a wave execute in order, so a compiler+counter fence suffices.

@@ -598,7 +598,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const int ncd = 3 * nn - 1, cw = 2 * ncd + 1;
     const sbd::SV sv(L);
     const int sv_stride = (sv.size() + 1) & ~1;
-    const int svi_stride = (3 + L + 1 + 3) & ~3;
+    const int svi_stride = (SBD_SVI_LAYRU + L + 1 + 3) & ~3;
     // (band4: the band kernel reads GC and scales it itself, no ga/gb blocks -- a third of the workspace)
     bool band4 = nn <= 8;
     bool band1 = nn >= 9 && nn <= 16;

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
     if (st0 & (0x20 | 0x10)) continue;          // input error / retry: DISORT returned early
     if (lc > svi[SBD_SVI_NCUT]) continue;        // layer loop runs 1..NCUT (disort.f:638)
     const double fbeam = P.fbeam[slot];
-    if (mazim > 0 && fbeam == 0.0) continue;     // NAZ = 0 (disort.f:582)
+    if (mazim > svi[SBD_SVI_NAZ]) continue;      // NAZ = 0 without a beam (disort.f:582); modes with no moment left
     const bool plank = P.plank[slot] != 0;
     const bool rad = !P.onlyfl && P.usrang;   // (USRANG = false: intensities at the quadrature angles need no interpolants)
 

@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
     }
     const int st0 = svi[SBD_SVI_STATUS];
     const int ncut = svi[SBD_SVI_NCUT];
+    const int naz_item = svi[SBD_SVI_NAZ];
     const double fbeam = P.fbeam[slot];
     const bool plank = P.plank[slot] != 0;
     const double oprim = sv[o.oprim() + lcl - 1];
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
     if (lc > L) return;
     if (st0 & (0x20 | 0x10)) return;
     if (lc > ncut) return;
-    if (mazim > 0 && fbeam == 0.0) return;
+    if (mazim > naz_item) return;
 
     double *base = smem + lds.shared_total + (size_t)gi * lds.group_total;
     double *gl = base + lds.gl;

@@ -96,8 +96,8 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
     __shared__ double s_dt[kMaxNlyr + 1], s_w[kMaxNlyr + 1], s_f[kMaxNlyr + 1];
     __shared__ double s_tauc[kMaxNlyr + 2], s_taucpr[kMaxNlyr + 2];
     __shared__ double s_pk[kMaxNlyr + 2];
-    __shared__ int s_err, s_ncut, s_lyrcut, s_pw;
-    if (lane == 0) { s_err = 0; s_pw = 0; }
+    __shared__ int s_err, s_ncut, s_lyrcut, s_pw, s_kmax;
+    if (lane == 0) { s_err = 0; s_pw = 0; s_kmax = 0; }
     __syncthreads();
 
     // ---- per-layer loads (coalesced along the layer axis) + CHEKIN per-item checks ----
@@ -134,6 +134,30 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
     if (plank && (wlo < 0.0 || whi <= wlo)) err = 1;
     if (err) atomicOr(&s_err, 1);
     __syncthreads();
+    // ---- the item's last azimuth mode that can differ from zero (radiance runs).  Mode m works with the delta-M scaled
+    //      moments GL(l), l = m .. NSTR-1 (disort.f:2583-2585: (2l+1) OPRIM (PMOM(l) - F) / (1 - F)); when every one of them
+    //      is zero in every layer -- molecular scattering alone has none beyond l = 2 -- the mode's source, its boundary
+    //      terms and therefore its intensities are exactly zero (Lambertian surface: it reflects in mode 0 only): the reference finds two such modes in a row and leaves
+    //      its loop (disort.f:821-825 with ACCUR = 0), this engine used to solve all NSTR of them.  No beam: NAZ = 0
+    //      (disort.f:577-586). ----
+    if (P.nmode > 1) {
+        int kmax = 0;
+        if (fbeam > 0.0 && P.ibdrf != 0) kmax = P.nmode - 1;   // (a bidirectional surface reflects the beam into every mode)
+        else if (fbeam > 0.0) {
+            const int nm1 = nmom + 1;
+            int lc = lane / nm1, k = lane - lc * nm1;
+            for (int i = lane; i < L * nm1; i += 64) {
+                if (k < n && k > kmax) {
+                    const double w = s_w[lc], f = s_f[lc];
+                    if (w != 0.0 && f != 1.0 && pmom[i] != f) kmax = k;
+                }
+                k += 64;
+                while (k >= nm1) { k -= nm1; ++lc; }
+            }
+        }
+        atomicMax(&s_kmax, kmax);
+        __syncthreads();
+    }
 
     // ---- serial prefix pass: TAUC, delta-M optical depth, NCUT.  The sums run in the reference's order.  (Round 4 tried
     //      a wave scan on the DPP network instead -- six adds per quantity, 0.60 -> 0.50 ms per step -- and the parity
@@ -270,6 +294,7 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
                 if (fabs(umu0 - P.t.cmu[iq]) / umu0 < SBD_F32(1.0e-4)) st |= 0x10;
         }
         svi[SBD_SVI_NCUT] = s_ncut;
+        svi[SBD_SVI_NAZ] = (fbeam > 0.0) ? ((s_kmax < P.nmode - 1) ? s_kmax : P.nmode - 1) : 0;
         svi[SBD_SVI_LYRCUT] = s_lyrcut;
         svi[SBD_SVI_STATUS] = st;
     }

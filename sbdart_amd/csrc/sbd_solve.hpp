@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(64) backsolve_kernel(Params P)
     const double fbeam = P.fbeam[slot];
     // same early exits as the LU kernel (which zeroed the fluxes of a dead item)
     if ((st0 & (0x20 | 0x10 | 0x08)) != 0) return;
-    if (mazim > 0 && fbeam == 0.0) return;
+    if (mazim > svi[SBD_SVI_NAZ]) return;
     const int nlev = P.nlev;
     double *flux = P.flux + (size_t)slot * SBD_NFLUX_ * nlev;
     const int ncut = svi[SBD_SVI_NCUT];

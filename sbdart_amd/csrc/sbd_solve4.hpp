@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(64, 2) backsolve4_kernel(Params P)
     const double fbeam = P.fbeam[slot];
     // same early exits as the LU kernel (which zeroed the fluxes of a dead item)
     if ((st0 & (0x20 | 0x10 | 0x08)) != 0) return;
-    if (mazim > 0 && fbeam == 0.0) return;
+    if (mazim > svi[SBD_SVI_NAZ]) return;
     const int nlev = P.nlev;
     const int ncut = svi[SBD_SVI_NCUT];
     const bool lyrcut = svi[SBD_SVI_LYRCUT] != 0;

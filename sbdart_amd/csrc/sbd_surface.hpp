@@ -208,7 +208,7 @@ static __global__ void __launch_bounds__(256) surfac_kernel(Params P, int32_t *b
         const int st0 = svi[SBD_SVI_STATUS];
         fbeam = P.fbeam[slot];
         if (st0 & (0x20 | 0x10)) return;
-        if (mazim > 0 && fbeam == 0.0) return;
+        if (mazim > svi[SBD_SVI_NAZ]) return;
         M.nr = P.bitem[(size_t)slot * 4 + 0];
         M.ni = P.bitem[(size_t)slot * 4 + 1];
         M.rsw = P.bitem[(size_t)slot * 4 + 2];

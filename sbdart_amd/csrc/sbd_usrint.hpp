@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const double fbeam = P.fbeam[slot];
     double *uum = P.uum + (size_t)ms * nlev * numu;
     const bool dead = (st0 & (0x20 | 0x10 | 0x08)) != 0;
-    if (dead || (mazim > 0 && fbeam == 0.0)) {
+    if (dead || mazim > svi[SBD_SVI_NAZ]) {
         for (int i = lane; i < nlev * numu; i += 64) uum[i] = 0.0;
         return;
     }
@@ -203,24 +203,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
         // (the loads of a batch of streams -- KK, EK, LL, GU: 4 per stream -- are issued together, then the batch is
         //  summed in the same order as before: the loop used to pay a memory round trip per stream, 1 056 of them in a
         //  row at NSTR 32 x 33 layers.  exp2 of a layer is exp1 of the next: the same expression on the same operands)
-        if (lyrstr <= lyrend) exp2 = exp((up - taucpr[lyrstr - 1]) * rum);
+        // (a layer's own scalars -- TAUCPR, DTAUCP, EXPBEA, ZB / Z0U / Z1U -- are asked for one layer ahead)
+        const bool any = lyrstr <= lyrend;
+        if (any) exp2 = exp((up - taucpr[lyrstr - 1]) * rum);
+        const int lf = any ? lyrstr : 1;
+        double tc_lo = taucpr[lf - 1], eb_lo = expbea[lf - 1];
+        double tc_n = taucpr[lf], eb_n = expbea[lf], dt_n = dtaucp[lf - 1];
+        double zb_n = (beam && sl == 0) ? ZB(iu, lf) : 0.0, z0_n = (therm && sl == 0) ? Z0U(iu, lf) : 0.0, z1_n = (therm && sl == 0) ? Z1U(iu, lf) : 0.0;
         for (int lc = lyrstr; lc <= lyrend; ++lc) {
-            const double dtau = dtaucp[lc - 1];
+            const double dtau = dt_n, tc_hi = tc_n, eb_hi = eb_n, zbc = zb_n, z0c = z0_n, z1c = z1_n;
+            {
+                const int ln = (lc < lyrend) ? lc + 1 : lc;      // (the last layer asks for itself again: a valid address)
+                tc_n = taucpr[ln]; eb_n = expbea[ln]; dt_n = dtaucp[ln - 1];
+                if (beam && sl == 0) zb_n = ZB(iu, ln);
+                if (therm && sl == 0) { z0_n = Z0U(iu, ln); z1_n = Z1U(iu, ln); }
+            }
             exp1 = exp2;
-            exp2 = exp((up - taucpr[lc]) * rum);
+            exp2 = exp((up - tc_hi) * rum);
             if (sl == 0) {
                 if (therm) {
                     const double f0n = sgn * (exp1 - exp2);
-                    const double f1n = sgn * ((taucpr[lc - 1] + um) * exp1 - (taucpr[lc] + um) * exp2);
-                    plkint = plkint + Z0U(iu, lc) * f0n + Z1U(iu, lc) * f1n;
+                    const double f1n = sgn * ((tc_lo + um) * exp1 - (tc_hi + um) * exp2);
+                    plkint = plkint + z0c * f0n + z1c * f1n;
                 }
                 if (beam) {
                     denom = 1.0 + um / umu0;
                     if (fabs(denom) < lh) expn = (dtau / umu0) * exp0;
-                    else expn = (exp1 * expbea[lc - 1] - exp2 * expbea[lc]) * sgn / denom;
-                    palint = palint + ZB(iu, lc) * expn;
+                    else expn = (exp1 * eb_lo - exp2 * eb_hi) * sgn / denom;
+                    palint = palint + zbc * expn;
                 }
             }
+            tc_lo = tc_hi; eb_lo = eb_hi;
             const double *kp = kk + (lc - 1) * n + q0, *lp = ll + (lc - 1) * n + q0;
             const double *gp = gu + ((size_t)(lc - 1) * n + q0) * numu + (iu - 1);
             const double *ep = ek + (lc - 1) * nn + q0;                       // EK(iq, lc), iq = q0+1 ..
@@ -236,34 +249,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
                 const double ex = (fabs(dn) < lh) ? dhi : sgn * (exp1 - exp2 * e) * rcp(dn);
                 palint = palint + (g * l) * ex;
             };
-            // batches of 8, then 4, 2, 1 streams (nq = 8 at NSTR 32 with two lanes per item, 4 at NSTR 16)
-            auto run = [&](auto bb, int &c, const bool up_half) {
+            // batches of 8, then 4, 2, 1 streams over the lane's 2 nq streams, the nq of the lower half first (nq = 8 at
+            // NSTR 32 with two lanes per item: a batch per half; 4 at NSTR 16: both halves in one batch)
+            auto run = [&](auto bb, int &s0) {
                 constexpr int B = decltype(bb)::value;
-                for (; c + B <= nq; c += B) {
+                for (; s0 + B <= 2 * nq; s0 += B) {
                     double k8[B], e8[B], l8[B], g8[B];
 #pragma unroll
                     for (int t = 0; t < B; ++t) {
-                        k8[t] = kp[c + t]; l8[t] = lp[c + t]; g8[t] = gp[(size_t)(c + t) * numu];
-                        e8[t] = up_half ? er[-(c + t)] : ep[c + t];
+                        const int sq = s0 + t;
+                        const bool up_half = sq >= nq;
+                        const int c = up_half ? sq - nq : sq, ix = up_half ? nn + c : c;
+                        k8[t] = kp[ix]; l8[t] = lp[ix]; g8[t] = gp[(size_t)ix * numu];
+                        e8[t] = up_half ? er[-c] : ep[c];
                     }
 #pragma unroll
                     for (int t = 0; t < B; ++t) {
-                        if (up_half) upper(k8[t], e8[t], l8[t], g8[t]);
+                        if (s0 + t >= nq) upper(k8[t], e8[t], l8[t], g8[t]);
                         else lower(k8[t], e8[t], l8[t], g8[t]);
                     }
                 }
             };
-            int c = 0;
-            run(std::integral_constant<int, 8>{}, c, false);
-            run(std::integral_constant<int, 4>{}, c, false);
-            run(std::integral_constant<int, 2>{}, c, false);
-            run(std::integral_constant<int, 1>{}, c, false);
-            kp += nn; lp += nn; gp += (size_t)nn * numu;
-            c = 0;
-            run(std::integral_constant<int, 8>{}, c, true);
-            run(std::integral_constant<int, 4>{}, c, true);
-            run(std::integral_constant<int, 2>{}, c, true);
-            run(std::integral_constant<int, 1>{}, c, true);
+            int s0 = 0;
+            run(std::integral_constant<int, 8>{}, s0);
+            run(std::integral_constant<int, 4>{}, s0);
+            run(std::integral_constant<int, 2>{}, s0);
+            run(std::integral_constant<int, 1>{}, s0);
         }
         // from the output level to the adjacent computational level
         const double dtau1 = up - taucpr[lyu - 1];
@@ -338,7 +349,7 @@ __global__ void __launch_bounds__(64) cmpint_kernel(Params P)
     const int st0 = svi[SBD_SVI_STATUS];
     const double fbeam = P.fbeam[slot];
     double *uum = P.uum + (size_t)ms * nlev * n;
-    if ((st0 & (0x20 | 0x10 | 0x08)) != 0 || (mazim > 0 && fbeam == 0.0)) {
+    if ((st0 & (0x20 | 0x10 | 0x08)) != 0 || mazim > svi[SBD_SVI_NAZ]) {
         for (int i = lane; i < nlev * n; i += 64) uum[i] = 0.0;
         return;
     }
@@ -386,7 +397,8 @@ __global__ void __launch_bounds__(256) azimuth_kernel(Params P, int naz_run)
     const int slot = (int)(tid / per);
     const int rem = (int)(tid % per);   // li*numu + iu
     const double fbeam = P.fbeam[slot];
-    const int naz = (fbeam == 0.0) ? 0 : naz_run;   // disort.f:577-586
+    const int nazi = P.svi[(size_t)slot * P.svi_stride + SBD_SVI_NAZ];
+    const int naz = (nazi < naz_run) ? nazi : naz_run;   // disort.f:577-586 (0 without a beam) and the item's last mode with a moment
     const double *uum = P.uum + (size_t)slot * nmode * per + rem;
     double *uu = P.uu + (size_t)slot * nphi * per + rem;
     // All NAZ modes are added.  DISORT stops the series after two consecutive modes whose largest term is

@@ -68,10 +68,13 @@ def _edge_records():
     rng = np.random.default_rng(2024)
     out = []
 
-    def rec(nlyr, nstr, dt, w, g, plank=False, fbeam=1.0, albedo=0.3, umu0=0.6, rad=False, wl=(10000.0, 10100.0)):
+    def rec(nlyr, nstr, dt, w, g, plank=False, fbeam=1.0, albedo=0.3, umu0=0.6, rad=False, wl=(10000.0, 10100.0), rayleigh=()):
         nmom = nstr + 2
         k = np.arange(nmom + 1)
         pm = np.asarray(g, dtype=float)[:, None] ** k[None, :]
+        for lc in rayleigh:                                 # molecular scattering: 1, 0, 0.1, 0, ... (GETMOM iphas 2)
+            pm[lc, :] = 0.0
+            pm[lc, 0], pm[lc, 2] = 1.0, 0.1
         flags = F_LAMBER | (F_PLANK if plank else 0) | ((F_USRANG) if rad else F_ONLYFL)
         temper = np.linspace(220.0, 295.0, nlyr + 1)
         return SolveRecord(nlyr=nlyr, nstr=nstr, nmom=nmom, flags=flags, wvnmlo=wl[0], wvnmhi=wl[1],
@@ -107,11 +110,37 @@ def _edge_records():
                    plank=True, wl=(2000.0, 2200.0)))
     out.append(rec(5, 8, [3.0, 4.0, 5.0, 6.0, 1.0], [0.2] * 5, [0.5] * 5, rad=True))      # LYRCUT + radiance
     out.append(rec(5, 8, [0.3] * 5, [0.8] * 5, [0.6] * 5, rad=True, fbeam=0.0, plank=True, wl=(900.0, 950.0)))
+    # radiance runs whose higher azimuth modes have no moment left (the engine stops at the item's last mode that can
+    # differ from zero, SBD_SVI_NAZ; the reference at two modes of zeros in a row, disort.f:821-825): isotropic
+    # scattering (mode 0 alone), molecular scattering (modes 0-2), molecular above one layer of particles (all modes)
+    out.append(rec(5, 8, [0.3] * 5, [0.8] * 5, [0.0] * 5, rad=True))
+    out.append(rec(5, 16, [0.1, 0.2, 0.3, 0.4, 0.5], [0.9, 1.0, 0.99, 0.7, 0.95], [0.0] * 5, rad=True, rayleigh=range(5)))
+    out.append(rec(5, 16, [0.1, 0.2, 0.3, 0.4, 0.5], [0.9, 1.0, 0.99, 0.7, 0.95], [0.0, 0.0, 0.0, 0.75, 0.0], rad=True,
+                   rayleigh=(0, 1, 2, 4)))
+    out.append(rec(6, 32, [0.05, 0.1, 0.2, 0.3, 0.4, 0.5], [1.0, 0.9, 1.0, 0.99, 0.7, 0.95], [0.0] * 6, rad=True, rayleigh=range(6)))
     # the reference's maximum dimensions: nstrms = 40 streams, mxly = 65 layers (params.f:9-11)
     out.append(rec(65, 40, rng.uniform(0.01, 0.3, 65), rng.uniform(0.2, 0.99, 65), rng.uniform(0, 0.8, 65),
                    plank=True, wl=(2100.0, 2300.0)))
     out.append(rec(65, 40, rng.uniform(0.01, 0.2, 65), rng.uniform(0.5, 1.0, 65), rng.uniform(0, 0.85, 65), rad=True))
     return out
+
+
+def test_last_azimuth_mode_per_item():
+    """SBD_SVI_NAZ (setup_kernel): the last azimuth mode of an item that can differ from zero -- 0 without a beam and for
+    isotropic scattering, 2 for molecular scattering alone, NSTR - 1 as soon as one layer holds particles -- read back from
+    the engine's per-item integers; the intensities of such items against the oracle: test_edge_cases_against_oracle."""
+    from sbdart_amd.engine import engine_for_record
+    recs = [r for r in _edge_records() if r.nstr == 16 and r.nlyr == 5 and len(r.umu) and not r.plank]
+    assert len(recs) == 2
+    r0 = recs[0]
+    args = (np.stack([r.dtauc for r in recs]), np.stack([r.ssalb for r in recs]), np.stack([r.pmom for r in recs]),
+            [r.wvnmlo for r in recs], [r.wvnmhi for r in recs], [r.fbeam for r in recs],
+            [r.albedo for r in recs], [r.plank for r in recs])
+    with engine_for_record(r0, max_batch=len(recs)) as eng:
+        eng.solve(*args)
+        svi = eng.debug_array(8, np.int32, 1 << 12)
+    stride = (4 + r0.nlyr + 1 + 3) & ~3
+    assert [int(svi[i * stride + 3]) for i in range(2)] == [2, 15]
 
 
 def test_edge_cases_against_oracle():
@@ -685,7 +714,7 @@ def test_pivot_sequence_against_linpack(name):
         ek = eng.debug_array(2, np.float64, len(recs) * nmode * L * nn).reshape(len(recs), nmode, L, nn)
         eng.debug_pivots(False)
     piv = piv.reshape(len(recs), nmode, L * n)
-    svi_stride = (3 + L + 1 + 3) & ~3
+    svi_stride = (4 + L + 1 + 3) & ~3          # NCUT, LYRCUT, STATUS, NAZ, LAYRU[L + 1]
     lib = pyoracle.lib()
     total = differ = items_differ = 0
     for i, r in enumerate(recs):
