@@ -154,10 +154,12 @@ __global__ void __launch_bounds__(64, SBD_B1_WAVES) band1_kernel(Params P)
     const int lane = threadIdx.x, q = lane & 31;
     const bool second = lane >= 32;                // this lane carries a column of x_lc+1
     const int nmode = P.nmode, L = P.L;
-    const long long ms = blockIdx.x;
-    const int mazim = (int)(ms % nmode);
-    const int slot = (int)(ms / nmode);
-    if (slot >= P.nslot) return;
+    // (blocks in mode-major order: the items of mode 0 first.  Item-major, the modes an item does not need -- no beam, no
+    //  moment left, SBD_SVI_NAZ -- left their live blocks on a few of the eight XCDs: block b goes to XCD b mod 8)
+    const int mazim = (int)(blockIdx.x / (unsigned)P.nslot);
+    const int slot = (int)(blockIdx.x % (unsigned)P.nslot);
+    if (mazim >= nmode) return;
+    const long long ms = (long long)slot * nmode + mazim;
     int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
     const int st0 = svi[SBD_SVI_STATUS];
     const double fbeam = P.fbeam[slot];

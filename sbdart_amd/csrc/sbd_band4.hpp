@@ -91,10 +91,13 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     constexpr double kTiny = 4.909093465297727e-91, kHuge = 2.037035976334486e+90;   // 2^-300, 2^300
     const int lane = threadIdx.x, q = lane & 15;
     const int nmode = P.nmode, L = P.L;
-    const long long ms = (long long)blockIdx.x * 4 + (lane >> 4);
-    if (ms >= (long long)P.nslot * nmode) return;
-    const int mazim = (int)(ms % nmode);
-    const int slot = (int)(ms / nmode);
+    // (blocks in mode-major order: the items of mode 0 first.  Item-major, the modes an item does not need -- no beam, no
+    //  moment left, SBD_SVI_NAZ -- left their live blocks on a few of the eight XCDs: block b goes to XCD b mod 8)
+    const long long bid = (long long)blockIdx.x * 4 + (lane >> 4);
+    if (bid >= (long long)P.nslot * nmode) return;
+    const int mazim = (int)((unsigned)bid / (unsigned)P.nslot);
+    const int slot = (int)((unsigned)bid % (unsigned)P.nslot);
+    const long long ms = (long long)slot * nmode + mazim;
     int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
     const int st0 = svi[SBD_SVI_STATUS];
     const double fbeam = P.fbeam[slot];

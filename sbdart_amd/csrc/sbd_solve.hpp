@@ -13,11 +13,13 @@ __global__ void __launch_bounds__(64) backsolve_kernel(Params P)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
-    const long long ms = blockIdx.x;
     const int nmode = P.nmode;
-    const int mazim = (int)(ms % nmode);
-    const int slot = (int)(ms / nmode);
-    if (slot >= P.nslot) return;
+    // (blocks in mode-major order: the items of mode 0 first.  Item-major, the modes an item does not need -- no beam, no
+    //  moment left, SBD_SVI_NAZ -- left their live blocks on a few of the eight XCDs: block b goes to XCD b mod 8)
+    const int mazim = (int)(blockIdx.x / (unsigned)P.nslot);
+    const int slot = (int)(blockIdx.x % (unsigned)P.nslot);
+    if (mazim >= nmode) return;
+    const long long ms = (long long)slot * nmode + mazim;
     constexpr int n = 2 * NN, nn = NN;
     const int L = P.L;
     const int32_t *svi = P.svi + (size_t)slot * P.svi_stride;

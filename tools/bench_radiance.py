@@ -11,6 +11,10 @@ from sbdart_amd.workload import sw_sweep
 nwl = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 nstr = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 sw = sw_sweep(nwl=nwl, nstr=nstr, thermal_above_um=99.0)
+if len(sys.argv) > 3 and sys.argv[3] == "rayleigh":      # clear sky: molecular scattering alone (moments 1, 0, 0.1, 0, ...)
+    sw.pmom[...] = 0.0
+    sw.pmom[..., 0] = 1.0
+    sw.pmom[..., 2] = 0.1
 uzen = np.linspace(0, 85, 20)
 umu = np.cos(np.deg2rad(uzen[::-1]))
 phi = np.linspace(0, 180, 16)
