@@ -62,10 +62,13 @@ extern "C" {
 #define SBD_E_NOMEM         -6
 
 /* ---- per-work-item status bits ---- */
-/* warnings 2/3/4: the reference raises them from LINPACK's RCOND estimate (1+RCOND == 1), which needs the L
- * factor this engine never stores; the engine raises them when min|pivot| <= 8 n eps max|pivot| over the pivots
- * of the system it factors (an exactly singular pivot included) -- the same regimes, not the same ulp
- * (tests/test_gpu_parity.py::test_near_singular_systems_raise_the_reference_warnings). */
+/* warnings 2/3/4: the reference raises them from LINPACK's RCOND estimate (1 + RCOND == 1), which needs the L
+ * factor this engine never stores.  The band system (warning 2) is tested the same way with the pivot ratio in RCOND's
+ * place -- 1 + min|pivot| / max|pivot| == 1, a zero pivot included, and like the reference's test silent when the
+ * system is full of NaN; the two dense systems (warnings 3, 4) with min|pivot| <= 8 n eps max|pivot|.  The same regimes,
+ * not the same ulp: on 800 random INPUTs the host writes the reference's set of warning files in 798
+ * (profiles/r04_warning_files_fuzz.json;
+ * tests/test_gpu_parity.py::test_near_singular_systems_raise_the_reference_warnings). */
 #define SBD_ST_WARN_SOLVE0   0x01  /* band matrix singular pivot        (errmsg 2, disort.f:3609) */
 #define SBD_ST_WARN_UPBEAM   0x02  /* beam-source system singular pivot (errmsg 3, disort.f:4227) */
 #define SBD_ST_WARN_UPISOT   0x04  /* thermal-source system singular    (errmsg 4, disort.f:4333) */
