@@ -318,6 +318,7 @@ struct sbd_engine {
     float ms_phase[kPhases] = {};
     bool have_times = false;
     int layer_lds = 0, band_lds = 0, solve_lds = 0, usr_lds = 0, layer2_lds = 0;
+    bool solve_v1 = false;
     int32_t *d_eigflag = nullptr;
     bool use_layer2 = true;
     bool band_reg = false;
@@ -606,6 +607,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     // fluxes at the top of the first layer and at the surface only (IOUT 1 / 10 with the default ZOUT): fused band kernel
     bool fused = (band4 || band1) && nn >= 3 && cfg->onlyfl && cfg->nlevel_out == 2 && cfg->level_out[0] == 0 && cfg->level_out[1] == L;
     if (const char *s = getenv("SBD_NO_FUSE")) fused = fused && atoi(s) == 0;
+    if (const char *s = getenv("SBD_SOLVE_V1")) e->solve_v1 = atoi(s) != 0;   // (developer switch: the column-oriented back-substitution also for NSTR 18-32)
     const size_t nblk = (band4 || band1) ? 1 : 3;          // GC alone, or GC + the matrix-ready interface blocks ga / gb
     const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)2 * n * n + (size_t)L * 2 * nn * nn : 0) + (size_t)L * n * 6 + (size_t)L * nn + (fused ? 0 : (size_t)L * n * (2 * n))
                                             + (rad_user ? (size_t)L * n * numu + 3 * (size_t)L * numu : 0) + (rad ? (size_t)e->nlev * numu : 0));
@@ -1183,6 +1185,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         if (timing) HIP_TRY(hipEventRecord(e->ev[3], st));
         if (e->fused) { /* the band kernel has written the fluxes */ }
         else if (e->band4) sbd::launch_backsolve4(e->nn, (unsigned)(((size_t)ns * nmode + 3) / 4), st, P);
+        else if (e->band1 && !e->solve_v1) sbd::launch_backsolve1(e->nn, (unsigned)((size_t)ns * nmode), st, P);
         else sbd::launch_backsolve(e->nn, (unsigned)((size_t)ns * nmode), e->solve_lds, st, P);
         SBD_DBG("backsolve");
         if (timing) HIP_TRY(hipEventRecord(e->ev[4], st));

@@ -40,6 +40,7 @@ void launch_band1(int nn, unsigned grid, hipStream_t st, const Params &P, bool f
 hipError_t prepare_backsolve(int nn, int lds);
 void launch_backsolve(int nn, unsigned grid, int lds, hipStream_t st, const Params &P);
 void launch_backsolve4(int nn, unsigned grid, hipStream_t st, const Params &P);
+void launch_backsolve1(int nn, unsigned grid, hipStream_t st, const Params &P);
 void launch_usrint(unsigned grid, int lds, hipStream_t st, const Params &P);
 void launch_cmpint(unsigned grid, hipStream_t st, const Params &P);
 void launch_azimuth(unsigned grid, hipStream_t st, const Params &P, int naz_run);
