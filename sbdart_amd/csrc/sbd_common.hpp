@@ -54,6 +54,7 @@ struct Params {
     int32_t L, n, nn, nmom, numu, nphi, nlev, nmode;
     int32_t onlyfl, usrang, all_levels;
     int32_t force_fallback;  // test hook: route every layer through the QR kernel
+    int32_t *eighint;        // host-visible word: the list's length as the list-walking layer kernel last found it (this workspace)
     int32_t *eiglist;        // [1 + nslot*nmode*L] count + (item, mode, layer) indices left to the QR kernel
     int32_t nslot;          // work items in this chunk
     int32_t sv_stride, svi_stride;

@@ -319,6 +319,7 @@ struct sbd_engine {
     bool have_times = false;
     int layer_lds = 0, band_lds = 0, solve_lds = 0, usr_lds = 0, layer2_lds = 0;
     bool solve_v1 = false;
+    int32_t *h_hint = nullptr;      // [2] pinned, device-visible: length of the fallback list of the workspace's last pass (-1: not known yet)
     int32_t *d_eigflag = nullptr;
     bool use_layer2 = true;
     bool band_reg = false;
@@ -367,6 +368,7 @@ void sbd_engine_destroy(sbd_engine *e)
     if (e->d_ws) (void)hipFree(e->d_ws);
     if (e->d_stage) (void)hipFree(e->d_stage);
     if (e->h_pin) (void)hipHostFree(e->h_pin);
+    if (e->h_hint) (void)hipHostFree(e->h_hint);
     if (e->d_partial) (void)hipFree(e->d_partial);
     if (e->d_acc) (void)hipFree(e->d_acc);
     if (e->d_red) (void)hipFree(e->d_red);
@@ -640,6 +642,10 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         chunk /= 2;
     }
     e->chunk = chunk;
+    // the list-walking layer kernel tells the host how long it found the list (a word of pinned host memory per workspace,
+    // written by the kernel itself: no copy command in the stream)
+    if (hipHostMalloc((void **)&e->h_hint, 2 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess) { e->h_hint[0] = -1; e->h_hint[1] = -1; }
+    else { (void)hipGetLastError(); e->h_hint = nullptr; }
     {
         char *p = e->d_ws;
         auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~(size_t)255; return r; };
@@ -647,6 +653,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         const size_t nms = (size_t)chunk * nmode;
         e->d_eigflag = (int32_t *)take(flag_bytes);
         P.eiglist = e->d_eigflag;
+        P.eighint = e->h_hint;
         P.sv = (double *)take(sizeof(double) * (size_t)chunk * sv_stride);
         P.svi = (int32_t *)take(sizeof(int32_t) * (size_t)chunk * svi_stride);
         P.gc = (double *)take(sizeof(double) * nms * L * n * n);
@@ -757,6 +764,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         mv(Q.zp1); mv(Q.ll); mv(Q.yv); mv(Q.ufac); mv(Q.gu); mv(Q.zb); mv(Q.z0u); mv(Q.z1u); mv(Q.uum);
         if (brdf_item) { mv(Q.bdr); mv(Q.bem); mv(Q.rmu); mv(Q.emu); }
         CREATE_TRY(hipMemset(Q.eiglist, 0, sizeof(int32_t) * ((size_t)e->chunk * e->nmode * e->L + 4)));
+        Q.eighint = e->h_hint ? e->h_hint + 1 : nullptr;
     }
     if (brdf && !brdf_item) {
         // Hapke / Ross-Li do not depend on the wavelength: SURFAC's tables and CHEKIN's test of the model are made
@@ -1167,6 +1175,12 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
                                                   // conservative cloud layers) spent more time here than in the fast
                                                   // kernel: 5 632 layers in 5.5 rounds of 0.13 ms (tools/fallback_probe.py)
                 SBD_DBG("layer2");
+            }
+            // (an empty list last time this workspace ran -- the kernel's own report, e->h_hint -- : 64 blocks instead of
+            //  2 048 wait for room behind the other stream's kernels; should the list be long after all, they walk it, slower)
+            if (flt && e->h_hint && !getenv("SBD_NO_HINT")) {
+                const int32_t hint = ((volatile int32_t *)e->h_hint)[second ? 1 : 0];
+                if (hint == 0 && grid > 64u) grid = 64u;
             }
             sbd::launch_layer_v1(e->G, grid, e->layer_lds, st, P, flt);
         }

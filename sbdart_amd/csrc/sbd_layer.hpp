@@ -147,6 +147,8 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
     // follow the count -- walked by a small fixed grid.
     const long long total = (long long)P.nslot * nmode * L;
     const long long nwork = only_flagged ? (long long)only_flagged[0] : total;
+    // (the host sizes the next pass's list-walking grid by what this one found: sbd_engine.hip)
+    if (only_flagged && P.eighint && blockIdx.x == 0 && lane == 0) *P.eighint = only_flagged[0];
     for (long long it = (long long)blockIdx.x * GPB + gi; it < nwork; it += (long long)gridDim.x * GPB) {
     const long long gid = only_flagged ? (long long)only_flagged[1 + it] : it;
     const int lc = (int)(gid % L) + 1;
