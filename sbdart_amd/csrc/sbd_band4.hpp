@@ -120,12 +120,18 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
     const double delm0 = (mazim == 0) ? 1.0 : 0.0;
     const double umu0 = P.umu0;
     const double *cmu = P.t.cmu, *cwt = P.t.cwt;
-    const double *gc = P.gc + (size_t)ms * L * n * n;
-    const double *kk = P.kk + (size_t)ms * L * n;
-    const double *ek = P.ek + (size_t)ms * L * nn;
-    const double *zz = P.zz + (size_t)ms * L * n;
-    const double *zp0 = P.zp0 + (size_t)(ms - mazim) * L * n;     // thermal solutions: mode 0 only
-    const double *zp1 = P.zp1 + (size_t)(ms - mazim) * L * n;
+#ifdef SBD_AB_SHARED_INPUTS   // developer A/B (wrong results): every system reads the layer outputs of one of the
+    const long long msr = ms % 16;   // first 16 systems (the four of a wave: four different ones) -- 0.85 MB that stay in L2, the
+                                     // band kernel's HBM reads all but vanish.  Does its time move?  (tools/ab_traffic.sh)
+#else
+    const long long msr = ms;
+#endif
+    const double *gc = P.gc + (size_t)msr * L * n * n;
+    const double *kk = P.kk + (size_t)msr * L * n;
+    const double *ek = P.ek + (size_t)msr * L * nn;
+    const double *zz = P.zz + (size_t)msr * L * n;
+    const double *zp0 = P.zp0 + (size_t)(msr - mazim) * L * n;     // thermal solutions: mode 0 only
+    const double *zp1 = P.zp1 + (size_t)(msr - mazim) * L * n;
     double *yv = P.yv + (size_t)ms * L * n;
     double *ufac = FUSED ? nullptr : P.ufac + (size_t)ms * (size_t)(L * n) * UW;
     double *bcb = P.bcb + (size_t)ms * n * n;                  // bottom-boundary rows (below)
@@ -305,8 +311,8 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         const int qq = col ? q : 0;
         const bool upper = qq >= nn;
         const int jo = upper ? qq - nn : nn - 1 - qq;                      // jq - 1
-        const double *ca = P.gcc + ((size_t)ms * L + ((lci < L ? lci : L) - 1)) * 2 * nn * nn + jo;
-        const double *cb = P.gcc + ((size_t)ms * L + ((lci + 1 < L ? lci + 1 : L) - 1)) * 2 * nn * nn + jo;
+        const double *ca = P.gcc + ((size_t)msr * L + ((lci < L ? lci : L) - 1)) * 2 * nn * nn + jo;
+        const double *cb = P.gcc + ((size_t)msr * L + ((lci + 1 < L ? lci + 1 : L) - 1)) * 2 * nn * nn + jo;
         const double *bc = bcb + (qq / nn) * (2 * nn * nn) + (qq % nn);
         const double *zr = P.t.zeros + (qq % nn);
         const double *tg = FUSED ? P.t.tags + (qq % nn) : zr;              // (rows nn..nn+2 of the last step: 1, 2, 3)

@@ -675,8 +675,12 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
             for (int iq = 1; iq <= nn; ++iq) {
                 const double gpp = -(cb[iq - 1] * sxi[iq - 1]) * rkq_me, gmm = yv[iq - 1] * sxi[iq - 1];
                 const double vua = 0.5 * (gpp + gmm), vda = 0.5 * (gpp - gmm);   // rows iq+nn, nn+1-iq of column ja
+#ifdef SBD_AB_NO_GC_STORES    // developer A/B (wrong results): GC's quarters -- 33 of the layer kernel's 57 KB per solve -- are not written
+                if (P.nslot < 0) { cc0[(iq - 1) * nn] = vua; cc1[(iq - 1) * nn] = vda; }
+#else
                 cc0[(iq - 1) * nn] = vua;
                 cc1[(iq - 1) * nn] = vda;
+#endif
                 if (need_gc) {
                     const int ru = (iq + nn - 1) * n, rd = (nn - iq) * n;
                     gcout[ru + ja] = vua;  gcout[rd + ja] = vda;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 PMC passes (one run per counter set, no tracing) over a short bench run.
 # usage: tools/pmc_run.sh OUTDIR [bench args...]; summary: python tools/pmc_summary.py OUTDIR
+# (PMC_CMD="python tools/bench_radiance.py 384": another command instead of bench.py)
 out=${1:-gpurun_out/pmc}; shift
 args=${@:---steps 1 --warmup 0 --nwl 6144 --no-cpu-baseline --no-side-lines}
 cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
@@ -13,7 +14,7 @@ sets=(
 )
 i=0
 for s in "${sets[@]}"; do
-  timeout 240 rocprofv3 --pmc $s --output-format csv -d $out/set$i -- python bench.py $args > $out/set$i.log 2>&1 || { echo "set $i ($s) failed or timed out"; tail -3 $out/set$i.log; }
+  timeout 240 rocprofv3 --pmc $s --output-format csv -d $out/set$i -- ${PMC_CMD:-python bench.py $args} > $out/set$i.log 2>&1 || { echo "set $i ($s) failed or timed out"; tail -3 $out/set$i.log; }
   i=$((i+1))
 done
 python tools/pmc_summary.py $out

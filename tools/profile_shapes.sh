@@ -29,5 +29,6 @@ python tools/make_traffic_profile.py $o/pmcC $o/cfgC_traffic.json 512 32 33 > /d
 python tools/make_valu_profile.py $o/pmcC/SQ_INSTS_VALU $o/cfgC_valu.json 512 32 33 > /dev/null
 # SQ counter sets (instruction mix, waits, LDS)
 bash tools/pmc_run.sh $o/sqD --nstr 32 --nlyr 50 --nwl 6144 --steps 1 --warmup 0 --no-cpu-baseline --no-side-lines > $o/cfgD_pmc.txt 2>&1
+PMC_CMD="$cmdC" bash tools/pmc_run.sh $o/sqC > $o/cfgC_pmc.txt 2>&1
 head -8 $o/cfgD_kernel_stats.csv; head -8 $o/cfgC_kernel_stats.csv; cat $o/cfgC_bench_under_rocprof.txt
 python -c "import json;d=json.load(open('$o/cfgD_bench_under_rocprof.json'));print(d['value'],d['ms_per_step'],d['kernel_ms'])"
