@@ -37,7 +37,9 @@ struct LayerLds {   // per-group carve-up (doubles)
 // Stand-in for LINPACK's condition estimate.  The reference calls SGECO/SGBCO (disutil.f:567-767,
 // 1094-1353) only to test 1 + RCOND == 1 (errmsg 2/3/4: disort.f:3607-3610, 4227, 4333), i.e. "singular
 // to working precision".  The engine stores no L factor, so it looks at the pivots instead: the matrix is
-// flagged when min|pivot| <= 8 n eps max|pivot| (eps = 2^-52).  For DISORT's systems that is where a
+// flagged when min|pivot| <= 16 eps max|pivot| (eps = 2^-52; until round 4: 8 n eps -- the end-to-end fuzz's last two
+// differing warning-file sets were warning 4 raised at NSTR 16 and 32 for layers with 1 - SSALB ~ 1e-14, where the
+// reference's RCOND stays above eps: tools/warn_probe.py).  For DISORT's systems that is where a
 // single-scattering albedo one ulp below 1 lands (the only way into these warnings with valid input: the
 // dither of disort.f:486 keeps SSALB = 1 itself 200 ulps away, 10-20 times above the threshold), and in
 // that range LINPACK's own estimate flips between warning and not from one ulp to the next.
@@ -50,7 +52,8 @@ SBD_DEVICE bool near_singular(double pivot, int n)
         pmin = fmin(pmin, __shfl_xor(pmin, d, G));
         pmax = fmax(pmax, __shfl_xor(pmax, d, G));
     }
-    return !(pmin > 8.0 * n * 2.220446049250313e-16 * pmax);
+    (void)n;
+    return !(pmin > 16.0 * 2.220446049250313e-16 * pmax);
 }
 
 // LU with partial pivoting of the n x n LDS matrix a (SGEFA's pivot rule: first maximal

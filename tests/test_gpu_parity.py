@@ -188,7 +188,7 @@ def _thermal_record(nstr, nlyr, tau, w_mid):
 
 def test_near_singular_systems_raise_the_reference_warnings():
     """errmsg 2/3/4 (disort.f:3607-3610, 4227, 4333).  The reference tests 1 + RCOND == 1 with LINPACK's
-    condition estimate; the engine, which keeps no L factor, flags min|pivot| <= 8 n eps max|pivot|
+    condition estimate; the engine, which keeps no L factor, flags min|pivot| <= 16 eps max|pivot|
     (near_singular(), sbdart_amd/csrc/sbd_layer.hpp).  With valid input the only way into these warnings is a
     single-scattering albedo a few ulps below 1 (it is not dithered, disort.f:486) in a layer with a
     thermal source: I - CC is then singular to working precision and the reference returns NaN fluxes.
