@@ -66,7 +66,7 @@ extern "C" {
  * factor this engine never stores.  The band system (warning 2) is tested the same way with the pivot ratio in RCOND's
  * place -- 1 + min|pivot| / max|pivot| == 1, a zero pivot included, and like the reference's test silent when the
  * system is full of NaN; the two dense systems (warnings 3, 4) with min|pivot| <= 16 eps max|pivot|.  The same regimes,
- * not the same ulp: on 800 random INPUTs the host writes the reference's set of warning files in 798
+ * not the same ulp: on 800 random INPUTs the host writes the reference's set of warning files in 799
  * (profiles/r04_warning_files_fuzz.json;
  * tests/test_gpu_parity.py::test_near_singular_systems_raise_the_reference_warnings). */
 #define SBD_ST_WARN_SOLVE0   0x01  /* band matrix singular pivot        (errmsg 2, disort.f:3609) */
