@@ -124,7 +124,10 @@ typedef struct {
                               disort.f:6718-7432): umu[] then holds POSITIVE cosines (usrang = 1, onlyfl = 0 -- with
                               both set the reference overruns its UMU array), or usrang = 0 for the nstr/2 quadrature
                               cosines; results in sbd_batch_out::albtrn, ALBEDO from the work items, no sources */
-    int32_t reserved1;     /* 0 */
+    int32_t pivot_exact;   /* (a formerly reserved word: 0 keeps every caller's behaviour) NSTR <= 16: 1 = the band LU searches its pivot
+                              with LINPACK's rule exactly -- ISAMAX's first maximum of |a| (disutil.f:2060-2072) -- instead of on the
+                              leading 27 bits (threshold 1 - 2^-15); ~10 % more band-kernel instructions.  NSTR > 16 always does.
+                              SBD_EXACT_PIVOT=1 in the environment sets it for every engine. */
 } sbd_run_cfg;
 
 /* One batch of (wavelength, k-term) work items: the per-call DISORT arguments. */

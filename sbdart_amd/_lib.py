@@ -28,7 +28,7 @@ class RunCfg(C.Structure):
                  "nphi", "nlevel_out", "device", "max_batch", "corint", "ibdrf")] + \
                [(k, C.c_double) for k in ("umu0", "phi0", "fisot", "btemp", "ttemp", "temis")] + \
                [("temper", _dp), ("umu", _dp), ("phi", _dp), ("level_out", _ip), ("bpar", C.c_double * 8),
-                ("ibcnd", C.c_int32), ("reserved1", C.c_int32)]
+                ("ibcnd", C.c_int32), ("pivot_exact", C.c_int32)]
 
 
 class BatchIn(C.Structure):

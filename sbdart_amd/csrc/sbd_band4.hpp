@@ -82,7 +82,9 @@ SBD_DEVICE double row_sum16(double v)
 // kernel (two thirds of the pipeline's HBM bytes) do not exist in this mode.
 // PIVDBG (tests only): the register index of every pivot row goes to Params::pivdbg -- the host replays the window's
 // bookkeeping from it and compares the ROWS chosen with LINPACK's (tests/test_gpu_parity.py::test_pivot_sequence...).
-template <int NN, bool FUSED = false, bool PIVDBG = false>
+// EXACT (sbd_run_cfg::pivot_exact): ISAMAX's first maximum of |a| instead of the keyed search -- a compare and three
+// selects per live row instead of 1.5 instructions.
+template <int NN, bool FUSED = false, bool PIVDBG = false, bool EXACT = false>
 __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
 {
     constexpr int n = 2 * NN, nn = NN, RW = nn + n, UW = u_width(n);
@@ -391,13 +393,26 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
             //     |a| and, among candidates that agree in the leading 27 bits, the first row.  Partial
             //     pivoting with threshold 1 - 2^-15 (LINPACK's ISAMAX takes the exact maximum; a
             //     pivot within 3e-5 of it bounds the multipliers by 1.00003 instead of 1)
-            unsigned kmax = 0u;
+            int idx;
+            if constexpr (EXACT) {                              // LINPACK's rule to the letter (disutil.f:2060-2072)
+                double best = fabs(a0[0]);
+                idx = 0;
 #pragma unroll
-            for (int p = 0; p <= LAST; ++p) {
-                const unsigned key = ((unsigned)__double2hiint(a0[p]) & 0x7fffffe0u) | (unsigned)(31 - p);
-                kmax = (key > kmax) ? key : kmax;
+                for (int p = 1; p <= LAST; ++p) {
+                    const double m = fabs(a0[p]);
+                    const bool g = m > best;
+                    best = g ? m : best;
+                    idx = g ? p : idx;
+                }
+            } else {
+                unsigned kmax = 0u;
+#pragma unroll
+                for (int p = 0; p <= LAST; ++p) {
+                    const unsigned key = ((unsigned)__double2hiint(a0[p]) & 0x7fffffe0u) | (unsigned)(31 - p);
+                    kmax = (key > kmax) ? key : kmax;
+                }
+                idx = 31 - (int)(kmax & 31u);
             }
-            const int idx = 31 - (int)(kmax & 31u);
             const int idxb = int_lane_bcast<J>(idx);            // ... to the 16 lanes of the system
             if constexpr (PIVDBG) {
                 if (q == 0) P.pivdbg[(size_t)ms * L * n + (size_t)(lc - 1) * n + J] = idxb;

@@ -319,6 +319,7 @@ struct sbd_engine {
     bool have_times = false;
     int layer_lds = 0, band_lds = 0, solve_lds = 0, usr_lds = 0, layer2_lds = 0;
     bool solve_v1 = false;
+    bool pivot_exact = false;       // sbd_run_cfg::pivot_exact / SBD_EXACT_PIVOT: ISAMAX's rule in band4_kernel
     int32_t *h_hint = nullptr;      // [2] pinned, device-visible: length of the fallback list of the workspace's last pass (-1: not known yet)
     int32_t *d_eigflag = nullptr;
     bool use_layer2 = true;
@@ -609,6 +610,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     // fluxes at the top of the first layer and at the surface only (IOUT 1 / 10 with the default ZOUT): fused band kernel
     bool fused = (band4 || band1) && nn >= 3 && cfg->onlyfl && cfg->nlevel_out == 2 && cfg->level_out[0] == 0 && cfg->level_out[1] == L;
     if (const char *s = getenv("SBD_NO_FUSE")) fused = fused && atoi(s) == 0;
+    e->pivot_exact = cfg->pivot_exact != 0;
+    if (const char *s = getenv("SBD_EXACT_PIVOT")) e->pivot_exact = e->pivot_exact || atoi(s) != 0;
     if (const char *s = getenv("SBD_SOLVE_V1")) e->solve_v1 = atoi(s) != 0;   // (developer switch: the column-oriented back-substitution also for NSTR 18-32)
     const size_t nblk = (band4 || band1) ? 1 : 3;          // GC alone, or GC + the matrix-ready interface blocks ga / gb
     const size_t per_ms = sizeof(double) * (nblk * L * n * n + (band4 ? (size_t)n * n + (size_t)L * 2 * nn * nn : 0) + (band1 ? (size_t)2 * n * n + (size_t)L * 2 * nn * nn : 0) + (size_t)L * n * 6 + (size_t)L * nn + (fused ? 0 : (size_t)L * n * (2 * n))
@@ -1190,8 +1193,10 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             const unsigned bgrid = (unsigned)((size_t)ns * nmode);
             if (e->band4 && e->d_pivdbg) {
                 P.pivdbg = e->d_pivdbg + (second ? (size_t)e->chunk * nmode * L * n : 0);
-                sbd::launch_band4_pivdbg(e->nn, (bgrid + 3) / 4, st, P);
-            } else if (e->band4) sbd::launch_band4(e->nn, (bgrid + 3) / 4, st, P, e->fused);
+                if (e->pivot_exact) sbd::launch_band4_exact(e->nn, (bgrid + 3) / 4, st, P, false, true);
+                else sbd::launch_band4_pivdbg(e->nn, (bgrid + 3) / 4, st, P);
+            } else if (e->band4 && e->pivot_exact) sbd::launch_band4_exact(e->nn, (bgrid + 3) / 4, st, P, e->fused, false);
+            else if (e->band4) sbd::launch_band4(e->nn, (bgrid + 3) / 4, st, P, e->fused);
             else if (e->band1) sbd::launch_band1(e->nn, bgrid, st, P, e->fused);
             else sbd::launch_band_lds(e->nn, bgrid, e->band_lds, st, P);
         }

@@ -36,6 +36,7 @@ hipError_t prepare_band_lds(int nn, int lds);
 void launch_band_lds(int nn, unsigned grid, int lds, hipStream_t st, const Params &P);
 void launch_band4(int nn, unsigned grid, hipStream_t st, const Params &P, bool fused);
 void launch_band4_pivdbg(int nn, unsigned grid, hipStream_t st, const Params &P);
+void launch_band4_exact(int nn, unsigned grid, hipStream_t st, const Params &P, bool fused, bool pivdbg);
 void launch_band1(int nn, unsigned grid, hipStream_t st, const Params &P, bool fused);
 hipError_t prepare_backsolve(int nn, int lds);
 void launch_backsolve(int nn, unsigned grid, int lds, hipStream_t st, const Params &P);

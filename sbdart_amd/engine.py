@@ -40,7 +40,7 @@ class DisortEngine:
                  btemp: float = 0.0, ttemp: float = 0.0, temis: float = 0.0, fisot: float = 0.0,
                  lamber: bool = True, level_out: Optional[Sequence[int]] = None, device: int = 0,
                  max_batch: int = 0, allow_retry_nstr: bool = False, corint: bool = False,
-                 ibdrf: int = 0, bpar: Optional[Sequence[float]] = None, ibcnd: int = 0):
+                 ibdrf: int = 0, bpar: Optional[Sequence[float]] = None, ibcnd: int = 0, pivot_exact: bool = False):
         self._L = _lib.load()
         self._h = C.c_void_p()
         self.nlyr, self.nstr, self.nmom = int(nlyr), int(nstr), int(nmom)
@@ -69,6 +69,7 @@ class DisortEngine:
         self.ibdrf = 0 if lamber else int(ibdrf)
         self.ibcnd = int(ibcnd)
         cfg.ibcnd = self.ibcnd
+        cfg.pivot_exact = int(bool(pivot_exact))          # NSTR <= 16: LINPACK's first-maximum pivot rule to the letter
         if self.ibcnd == 1:                                 # ALBTRN: results at the positive user / quadrature cosines
             cfg.numu = len(self._umu) if usrang else 0
             cfg.umu = self._umu.ctypes.data_as(C.POINTER(C.c_double)) if (usrang and len(self._umu)) else None
@@ -381,14 +382,15 @@ class DisortFleet(DisortEngine):
     quadrature = enable_timing = last_ms = None
 
 
-def engine_for_record(rec, level_out=None, device=0, max_batch=0, allow_retry_nstr=True):
+def engine_for_record(rec, level_out=None, device=0, max_batch=0, allow_retry_nstr=True, pivot_exact=False):
     """Engine whose per-run arguments are those of one SolveRecord."""
     return DisortEngine(
         nlyr=rec.nlyr, nstr=rec.nstr, nmom=rec.nmom, temper=rec.temper, umu0=rec.umu0,
         phi0=rec.phi0, onlyfl=rec.onlyfl, usrang=rec.usrang, umu=rec.umu, phi=rec.phi,
         btemp=rec.btemp, ttemp=rec.ttemp, temis=rec.temis, fisot=rec.fisot, lamber=rec.lamber,
         level_out=level_out, device=device, max_batch=max_batch, allow_retry_nstr=allow_retry_nstr,
-        corint=getattr(rec, "corint", False), ibdrf=getattr(rec, "ibdrf", 0), bpar=getattr(rec, "bpar", None))
+        corint=getattr(rec, "corint", False), ibdrf=getattr(rec, "ibdrf", 0), bpar=getattr(rec, "bpar", None),
+        pivot_exact=pivot_exact)
 
 
 def run_key(rec):

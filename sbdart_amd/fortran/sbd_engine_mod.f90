@@ -26,7 +26,7 @@ module sbd_engine_mod
     real(c_double) :: umu0, phi0, fisot, btemp, ttemp, temis
     type(c_ptr) :: temper, umu, phi, level_out
     real(c_double) :: bpar(8) = 0        ! bidirectional surface parameters (lamber = 0)
-    integer(c_int32_t) :: ibcnd = 0, reserved1 = 0   ! 1: albedo / transmissivity of the medium (ALBTRN); SBDART never sets it
+    integer(c_int32_t) :: ibcnd = 0, pivot_exact = 0   ! (pivot_exact = 1: LINPACK's exact pivot rule for NSTR <= 16) 1: albedo / transmissivity of the medium (ALBTRN); SBDART never sets it
   end type
 
   type, bind(C) :: sbd_batch_in

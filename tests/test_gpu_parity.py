@@ -680,15 +680,18 @@ def _band_matrix(gc, kk, ek, cmu, cwt, albedo, ncut, L):
     return abd, ncd
 
 
+@pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("name", ["cfgB_sw_nstr16", "cfg3_lw_nstr16_cloud", "sbchk1", "sbchk3", "corint_nstr8"])
-def test_pivot_sequence_against_linpack(name):
+def test_pivot_sequence_against_linpack(name, exact):
     """The band LU's pivot ROWS against the ones LINPACK's SGBFA takes (ISAMAX: first exact maximum,
     disutil.f:852-912, 2060-2072) -- on the engine's own band matrix, assembled on the host from the GC / KK / EK the
     layer kernel left (the reference's matrix has its layers' columns in ASYMTX's eigenvalue order, the engine's in
     its Jacobi order: different but equivalent systems whose pivot rows cannot be matched one to one).  The engine
     searches on the leading 27 bits of |a| (threshold 1 - 2^-15, equal keys in register order); an exact search
     costs 1 to 1.5 more instructions per live row and sub-step (+12 % of the kernel), so the threshold stays and
-    THIS is its measured price: the fraction of pivots whose row differs from SGBFA's."""
+    THIS is its measured price: the fraction of pivots whose row differs from SGBFA's.
+    exact: sbd_run_cfg::pivot_exact = 1 -- ISAMAX's first maximum in the kernel: no row may differ, and the fluxes of the
+    two rules agree within the parity gate."""
     import ctypes as C
     import pyoracle
     from sbdart_amd.engine import engine_for_record
@@ -702,7 +705,7 @@ def test_pivot_sequence_against_linpack(name):
     args = (np.stack([r.dtauc for r in recs]), np.stack([r.ssalb for r in recs]), np.stack([r.pmom for r in recs]),
             [r.wvnmlo for r in recs], [r.wvnmhi for r in recs], [r.fbeam for r in recs],
             [r.albedo for r in recs], [r.plank for r in recs])
-    with engine_for_record(r0, max_batch=len(recs)) as eng:
+    with engine_for_record(r0, max_batch=len(recs), pivot_exact=exact) as eng:
         eng.debug_pivots(True)
         flux, uu, st = eng.solve(*args)
         cmu, cwt = eng.quadrature()
@@ -737,11 +740,18 @@ def test_pivot_sequence_against_linpack(name):
     try:
         import json
         with open(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "pivot_rows.jsonl"), "a") as f:
-            f.write(json.dumps({"records": name, "pivots": total, "rows_differ": differ, "systems": len(recs),
-                                "systems_affected": items_differ}) + "\n")
+            f.write(json.dumps({"records": name, "pivot_exact": bool(exact), "pivots": total, "rows_differ": differ,
+                                "systems": len(recs), "systems_affected": items_differ}) + "\n")
     except OSError:
         pass
     assert frac <= 5e-3, frac
+    if exact:
+        assert differ == 0, (differ, total)
+        with engine_for_record(r0, max_batch=len(recs)) as eng0:          # the default rule on the same batch
+            flux0, _, st0 = eng0.solve(*args)
+        assert np.array_equal(np.asarray(st), np.asarray(st0))
+        f1, f0 = np.asarray(flux), np.asarray(flux0)
+        assert np.abs(f1 - f0).max() <= TOL * np.abs(f0).max()
 
 
 @pytest.mark.parametrize("delta", [1e-5, 1e-7, 1e-8, 1e-9, 3e-10, -1e-8, 1e-11])
