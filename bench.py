@@ -294,7 +294,7 @@ def other_shapes(dev):
 
 
 DEV_SWITCHES = ("SBD_CHUNK", "SBD_WORKSPACE_MB", "SBD_BAND_V1", "SBD_LAYER_V1",
-                "SBD_FORCE_EIG_FALLBACK", "SBD_DEBUG_SYNC", "SBD_DBG_FLAGS", "SBD_NO_FUSE", "SBD_SOLVE_V1", "SBD_NO_HINT")
+                "SBD_FORCE_EIG_FALLBACK", "SBD_DEBUG_SYNC", "SBD_DBG_FLAGS", "SBD_NO_FUSE", "SBD_SOLVE_V1", "SBD_NO_HINT", "SBD_EXACT_PIVOT")
 
 
 def main():
