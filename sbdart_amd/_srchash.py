@@ -9,7 +9,7 @@ def kernel_source_hash() -> str:
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
     h = hashlib.sha1()
     for f in sorted(glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.hpp"))
-                    + [os.path.join(root, "sbd_band4_take.inc")]):
+                    + glob.glob(os.path.join(root, "*.inc"))):      # (generated at build time: sbd_band{1,4}_take.inc)
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())

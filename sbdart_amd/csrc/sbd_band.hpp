@@ -414,6 +414,8 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
 
     // ---- banded LU with partial pivoting + forward elimination of B ----
     int status = 0;
+    double pv_min = 1.0e300, pv_max = 0.0;   // errmsg 2: the pivot ratio stands in for RCOND as in band1 / band4 (sbd_band1.hpp)
+    bool pv_nan = false;
     int ju = 0;
     int kq = 0, kc = 1 % CW;                 // physical row of row k, ring position of column k
     constexpr bool two = CW > 64;            // second pass of lanes over the window width
@@ -483,7 +485,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
             if (ju > N) ju = N;
         }
         const double bk = (idx != 0) ? bl_old : bk_old;      // B(k) after the interchange
-        if (piv == 0.0) status |= 0x01;
+        { const double ap = fabs(piv); pv_nan = pv_nan || (ap != ap); pv_min = fmin(pv_min, ap); pv_max = fmax(pv_max, ap); }
         const double tinv = (piv != 0.0) ? tsel : 0.0;
         // (C) row interchange: row k is retired by this step and never read from LDS again, so
         //     only row l has to receive the old row k (LDS round trip 2: one read, one write);
@@ -562,7 +564,9 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     }
     {   // last row
         const double d = win[kq * CWP + kc];
-        if (d == 0.0) status |= 0x01;
+        { const double ap = fabs(d); pv_nan = pv_nan || (ap != ap); pv_min = fmin(pv_min, ap); pv_max = fmax(pv_max, ap); }
+        // 1 + min|pivot| / max|pivot| == 1 (a zero pivot included), silent on NaN like the reference's 1 + RCOND == 1
+        if (!pv_nan && pv_min <= 1.1102230246251565e-16 * pv_max) status |= 0x01;
         if (lane == 0) { ufac[(size_t)(N - 1) * UW] = d; yv[N - 1] = bw[kq]; }
     }
     if (status && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], status);

@@ -55,6 +55,26 @@ int sbd_px_touch(const char *path, int value)     /* a marker file holding one i
     return fclose(f);
 }
 
+int sbd_px_rename(const char *from, const char *to) { return rename(from, to); }
+
+int sbd_px_append_line(const char *path, const char *text)
+{
+    FILE *f = fopen(path, "a");
+    if (!f) return -1;
+    fprintf(f, "%s\n", text);
+    return fclose(f);
+}
+
+/* the caller's file descriptor 1, kept aside while a batch re-points it per run, and put back afterwards */
+int sbd_px_stdout_save(void) { fflush(stdout); return dup(1); }
+int sbd_px_stdout_restore(int fd)
+{
+    fflush(stdout);
+    if (dup2(fd, 1) < 0) return -1;
+    close(fd);
+    return 0;
+}
+
 void sbd_px_usleep(int us) { usleep((useconds_t)us); }
 
 int sbd_px_ncpu(void)

@@ -43,7 +43,7 @@ end module
 module sbd_run_mod
   implicit none
   real(kind=8), save :: t_engine = 0, t_wait = 0, t_phase2 = 0        ! batch mode's time account (SBD_TIMING)
-  character(len=*), parameter :: items_file = '.sbd_items', stdout_file = 'SBDART.stdout', stderr_file = 'SBDART.stderr', phase1_mark = '.sbd_phase1'
+  character(len=*), parameter :: items_tmp = '.sbd_items.part', items_file = '.sbd_items', stdout_file = 'SBDART.stdout', stderr_file = 'SBDART.stderr', phase1_mark = '.sbd_phase1'
 contains
 
 ! phase 0: the whole run, as the reference's executable; 1: up to the work items (written to items_file); 2: from there
@@ -130,7 +130,8 @@ subroutine run_once(phase)
   if (aborted) return
   if (iout /= 2) fmt = find_format(iout, known)
   if (iout == 2) known = .true.
-  if (.not. known) call fatal('this IOUT is not an output format of the hot path (1,2,5,6,7,10,11,20,21,22,23)')
+  if (.not. known) call quit('this IOUT is not an output format of the hot path (1,2,5,6,7,10,11,20,21,22,23)')
+  if (aborted) return
   radcalc = .false.
   if (iout /= 2) radcalc = fmt%radiance /= rad_none     ! drt.f:237-247
   if (nstr == 0) nstr = merge(min(20, nstrms), 4, radcalc)
@@ -139,7 +140,8 @@ subroutine run_once(phase)
   ! ---- solar geometry (drt.f:275-283) ----
   if (iday /= 0 .or. isat > 0) then
     call tables_load(ok, why)
-    if (.not. ok) call fatal('tables not found; tried'//trim(why))
+    if (.not. ok) call quit('tables not found; tried'//trim(why))
+    if (aborted) return
   end if
   if (iday /= 0) then
     call solar_position(abs(iday), time, alat, alon, sza, saza, solfac)
@@ -173,9 +175,11 @@ subroutine run_once(phase)
 
   if (iout == 2) then                                   ! gas optical depths only: no radiative transfer
     call fill_model()
-    if (.not. covered_by_band_model(model, why)) call fatal('IOUT=2: the band model does not cover this run: '//trim(why))
+    if (.not. covered_by_band_model(model, why)) call quit('IOUT=2: the band model does not cover this run: '//trim(why))
+    if (aborted) return
     call tables_load(ok, why)
-    if (.not. ok) call fatal('band-model tables not found; tried'//trim(why))
+    if (.not. ok) call quit('band-model tables not found; tried'//trim(why))
+    if (aborted) return
     call gas_depth_report(model, grid)
     call leave(); return
   end if
@@ -187,7 +191,8 @@ subroutine run_once(phase)
   inquire(file=trim(path), exist=have_file)
   if (have_file) then
     call read_optics(trim(path), recs, nrec)
-    if (nrec < 1) call fatal('optics file holds no work items')
+    if (nrec < 1) call quit('optics file holds no work items')
+    if (aborted) return
     nz = recs(1)%nlyr
     allocate(zlev(nz), plev(nz))
     call get_environment_variable('SBD_ATMOS', path, plen, pstat)
@@ -197,9 +202,11 @@ subroutine run_once(phase)
   else
     call fill_model()
     if (.not. covered_by_band_model(model, why)) &
-      call fatal('no optics file ('//trim(path)//') and the band model does not cover this run yet: '//trim(why))
+      call quit('no optics file ('//trim(path)//') and the band model does not cover this run yet: '//trim(why))
+    if (aborted) return
     call tables_load(ok, why)
-    if (.not. ok) call fatal('band-model tables not found; tried'//trim(why))
+    if (.not. ok) call quit('band-model tables not found; tried'//trim(why))
+    if (aborted) return
     call viewing_cosines()
     call system_clock(tick0, tick_rate)
     if (kdist == -1) then
@@ -226,7 +233,7 @@ subroutine run_once(phase)
   nmom = maxval(recs(1:nrec)%nmom)
   call get_environment_variable('SBD_DUMP_OPTICS', path, plen, pstat)      ! the work items, for inspection / tests
   if (phase == 1) then                                  ! batch mode: hand the work items to the process that solves
-    path = items_file; plen = len(items_file); pstat = 0
+    path = items_tmp; plen = len(items_tmp); pstat = 0    ! (renamed to items_file by the worker once this child has exited with code 0)
     if (have_atm) call write_atmosphere(items_file//'.atm', nz, zlev, plev)
   end if
   if (pstat == 0 .and. plen > 0) then
@@ -241,12 +248,15 @@ subroutine run_once(phase)
 
   ! the spectral grid of INPUT must be the one the optics were made for (wllimits, drt.f:1657-1740)
   do i = 1, nrec
-    if (recs(i)%iwl < 1 .or. recs(i)%iwl > grid%n) call fatal('optics record outside the spectral grid of INPUT')
+    if (recs(i)%iwl < 1 .or. recs(i)%iwl > grid%n) call quit('optics record outside the spectral grid of INPUT')
+    if (aborted) return
     call grid%band(recs(i)%iwl - 1, wl, wvlo, wvhi)
     if (abs(wl - recs(i)%wl) > 1e-12_kr*wl .or. abs(wvlo - recs(i)%wvnmlo) > 1e-9_kr*wvlo .or. &
-        abs(wvhi - recs(i)%wvnmhi) > 1e-9_kr*wvhi) call fatal('optics record disagrees with the wavelength grid of INPUT')
+        abs(wvhi - recs(i)%wvnmhi) > 1e-9_kr*wvhi) call quit('optics record disagrees with the wavelength grid of INPUT')
+    if (aborted) return
     if (recs(i)%nlyr /= nz .or. recs(i)%nmom > nmom .or. recs(i)%nmom < min(recs(i)%nstr, nmom)) &
-      call fatal('optics records differ in NLYR/NMOM')        ! (fewer moments: after CORINT went off, corint_history)
+      call quit('optics records differ in NLYR/NMOM')        ! (fewer moments: after CORINT went off, corint_history)
+    if (aborted) return
   end do
 
   ! ---- output levels: the computational levels nearest to ZOUT (drt.f:368-381); level 1 = top ----
@@ -256,9 +266,11 @@ subroutine run_once(phase)
     ntop = nz - nearest_level(zlev, abs(zout(2))) + 2
     if (ntop == 2) ntop = 1
   else
-    if (.not. default_zout) call fatal('ZOUT needs the level altitudes: no atmosphere file (SBD_ATMOS / ATMOS.sbdatm)')
+    if (.not. default_zout) call quit('ZOUT needs the level altitudes: no atmosphere file (SBD_ATMOS / ATMOS.sbdatm)')
+    if (aborted) return
     if (fmt%code == 7 .or. fmt%code == 11 .or. fmt%code == 22) &
-      call fatal('this IOUT prints altitudes/pressures: no atmosphere file (SBD_ATMOS / ATMOS.sbdatm)')
+      call quit('this IOUT prints altitudes/pressures: no atmosphere file (SBD_ATMOS / ATMOS.sbdatm)')
+    if (aborted) return
     ntop = 1; nbot = nz + 1
   end if
   if (fmt%profile .or. fmt%radiance == rad_levels) then
@@ -526,6 +538,24 @@ contains
     if (phase == 0) stop
   end subroutine
 
+  ! a condition this host cannot continue from.  One run per process (phase 0, and a batch's phase 1 in its own
+  ! child): the message and a non-zero exit, like the reference's STOPs.  Phase 2 of a batch runs in the process that
+  ! owns the GPU and serves the runs that follow: the message goes to the run's SBDART.stderr and only this run ends
+  ! (every call site returns on `aborted`).
+  subroutine quit(msg)
+    character(len=*), intent(in) :: msg
+    integer :: ue, ios2
+    if (phase /= 2) call fatal(msg)
+    aborted = .true.
+    open(newunit=ue, file=stderr_file, position='append', action='write', iostat=ios2)
+    if (ios2 == 0) then
+      write(ue, '(a)') 'sbdart_amd: '//msg
+      close(ue)
+    else
+      write(0, '(a)') 'sbdart_amd: '//msg
+    end if
+  end subroutine
+
   subroutine set_defaults()                            ! drt.f:144-198: the namelist's defaults
     idatm = 4; isat = 0; nf = 2; iday = 0; isalb = 0; krhclr = 0; jaer = 0; iaer = 0
     nothrm = -1; nosct = 0; kdist = 3; ngrid = 0; idb = 0; iout = 10; nstr = 0; nzen = 0
@@ -629,6 +659,17 @@ contains
       write(*, *) 'set TCLOUD or LWP, but not both'
       nbad = nbad + 1
     end if
+    ! IDB(1:9): the reference's diagnostic prints (drt.f:235 helper, 360-366 saturation and absorber amounts, 412
+    ! chkprn, 429-434 k-distribution terms, 471-485 surface albedo, 507-514 cloud and aerosol tables, 533-534 depthscl)
+    ! replace the run's output: with any of them set there is no banner (drt.f:327) and the wavelength loop prints the
+    ! table and skips DISORT (drt.f:515, 534).  They are listings of the band model's intermediate arrays, not outputs of
+    ! the hot path: refused by name rather than ignored (an INPUT that sets one would print something else here).
+    do j = 1, ndb
+      if (idb(j) == 0) cycle
+      write(*, '(1x,a,i0,a,i0,a)') 'idb(', j, ')=', idb(j), ': the diagnostic listings of the reference (idb, drt.f:235-534) '// &
+        'are not produced by sbdart_amd; unset idb to run'
+      nbad = nbad + 1
+    end do
     if (nbad > 0) call leave()
   end subroutine
 
@@ -692,7 +733,8 @@ contains
       nxt = index(txt(pos:tlen), ',')
       if (nxt == 0) nxt = tlen - pos + 2
       read(txt(pos:pos + nxt - 2), *, iostat=ios) devices(k)
-      if (ios /= 0) call fatal('SBD_DEVICES: expected "all" or a comma-separated list of device ordinals')
+      if (ios /= 0) call quit('SBD_DEVICES: expected "all" or a comma-separated list of device ordinals')
+      if (aborted) return
       pos = pos + nxt
     end do
   end subroutine
@@ -721,6 +763,9 @@ contains
       end if
     end do
     call pick_devices()
+    if (aborted) then
+      fl = c_null_ptr; rc = -1_c_int; return
+    end if
     cfg%abi_version = SBD_ABI_VER
     cfg%nlyr = nz; cfg%nstr = ns; cfg%nmom = nmom
     cfg%onlyfl = merge(0, 1, radcalc); cfg%usrang = merge(1, 0, radcalc)
@@ -741,7 +786,10 @@ contains
       rc = sbd_fleet_create(cfg, int(size(devices), c_int32_t), c_loc(devices), fl)
     end if
     if (rc /= SBD_OK .and. rc /= SBD_E_RETRY_NSTR) &
-      call fatal('sbd_fleet_create: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
+      call quit('sbd_fleet_create: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
+    if (aborted) then
+      fl = c_null_ptr; rc = -1_c_int; return
+    end if
     if (nslot < max_fleets) then
       nslot = nslot + 1
       k = nslot
@@ -830,6 +878,7 @@ contains
       if (ns < 4) cycle
       if (ns > nstrms) exit
       fleet = fleet_for(ns, corrections .and. radcalc .and. beam, rc)   ! (corrections off without a beam, disort.f:2695)
+      if (aborted) return
       if (rc == SBD_OK) exit
       ! rc == SBD_E_RETRY_NSTR: SETDIS tests the beam angle only when there is a beam (disort.f:2641-2650)
       if (.not. beam) exit
@@ -860,7 +909,8 @@ contains
       if (radcalc) uptr = c_loc(acc_uu)
     end if
     rc = sbd_fleet_solve_host(fleet, bin, bout, wptr, aptr, uptr)
-    if (rc /= SBD_OK) call fatal('sbd_fleet_solve_host: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
+    if (rc /= SBD_OK) call quit('sbd_fleet_solve_host: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
+    if (aborted) return
   end subroutine
 end subroutine run_once
 
@@ -920,6 +970,18 @@ subroutine run_batch(listfile)
     integer(c_int) function sbd_px_touch(path, value) bind(C, name='sbd_px_touch')
       import; character(kind=c_char), intent(in) :: path(*); integer(c_int), value :: value
     end function
+    integer(c_int) function sbd_px_rename(from, to) bind(C, name='sbd_px_rename')
+      import; character(kind=c_char), intent(in) :: from(*), to(*)
+    end function
+    integer(c_int) function sbd_px_append_line(path, text) bind(C, name='sbd_px_append_line')
+      import; character(kind=c_char), intent(in) :: path(*), text(*)
+    end function
+    integer(c_int) function sbd_px_stdout_save() bind(C, name='sbd_px_stdout_save')
+      import
+    end function
+    integer(c_int) function sbd_px_stdout_restore(fd) bind(C, name='sbd_px_stdout_restore')
+      import; integer(c_int), value :: fd
+    end function
     subroutine sbd_px_usleep(us) bind(C, name='sbd_px_usleep')
       import; integer(c_int), value :: us
     end subroutine
@@ -935,7 +997,7 @@ subroutine run_batch(listfile)
   character(len=16) :: txt
   integer :: u, ios, nrun, i, k, nw, tlen, tstat
   integer(kind=8) :: c0, c1, crate
-  integer(c_int) :: pid, rc
+  integer(c_int) :: pid, rc, fd1
   integer(c_int), allocatable :: wpid(:)
   logical :: ok, phase1_only
   character(len=256) :: why
@@ -991,10 +1053,14 @@ subroutine run_batch(listfile)
     end if
     wpid(k) = pid
   end do
-  ! this process: the GPU side, runs in order
+  ! this process: the GPU side, runs in order (file descriptor 1 is re-pointed per run: the caller's is kept and put back)
+  flush(6)
+  fd1 = sbd_px_stdout_save()
   do i = 1, nrun
     call second_phase(i)
   end do
+  flush(6)
+  if (fd1 >= 0) rc = sbd_px_stdout_restore(fd1)
   do k = 1, nw
     rc = sbd_px_wait(wpid(k))
   end do
@@ -1014,6 +1080,7 @@ contains
     integer :: r
     r = sbd_px_remove(trim(dirs(irun))//'/'//phase1_mark//c_null_char)
     r = sbd_px_remove(trim(dirs(irun))//'/'//items_file//c_null_char)
+    r = sbd_px_remove(trim(dirs(irun))//'/'//items_tmp//c_null_char)
   end subroutine
 
   subroutine first_phase(irun)
@@ -1030,6 +1097,22 @@ contains
     end if
     code = -1
     if (child > 0) code = sbd_px_wait(child)
+    ! The work items become visible to phase 2 only COMPLETE: the child wrote them under a temporary name, and they get
+    ! their name here once the child has exited with code 0.  A child that was killed or stopped on the way (a STOP of
+    ! the model code after the file was opened, a signal) leaves no items: phase 2 skips the run, what the child printed
+    ! stays in SBDART.stdout / SBDART.stderr like the reference's own process would have left it.
+    if (sbd_px_exists(trim(dirs(irun))//'/'//items_tmp//c_null_char) /= 0) then
+      if (code == 0) then
+        if (sbd_px_rename(trim(dirs(irun))//'/'//items_tmp//c_null_char, trim(dirs(irun))//'/'//items_file//c_null_char) /= 0) code = -2
+      else
+        if (sbd_px_remove(trim(dirs(irun))//'/'//items_tmp//c_null_char) /= 0) continue
+      end if
+    end if
+    if (code >= 128 .or. code < 0) then
+      write(txt, '(i0)') code
+      if (sbd_px_append_line(trim(dirs(irun))//'/'//stderr_file//c_null_char, &
+          'sbdart_amd --batch: the first phase of this run ended with code '//trim(txt)//'; run skipped'//c_null_char) /= 0) continue
+    end if
     if (sbd_px_touch(trim(dirs(irun))//'/'//phase1_mark//c_null_char, code) /= 0) continue
   end subroutine
 

@@ -71,6 +71,17 @@ def test_input_screening_matches_the_reference(tmp_path):
         assert got == want
 
 
+@needs_flang
+def test_diagnostic_listings_are_refused_by_name(tmp_path):
+    """idb(1:9) (drt.f:235-534) replace the reference's output by listings of the band model's intermediate arrays:
+    not an output of the hot path -- the host says so and stops before any work instead of ignoring the switch."""
+    _build()
+    (tmp_path / "INPUT").write_text(" &INPUT\n idatm=4, wlinf=.25, wlsup=1.0, wlinc=.005, iout=1, idb=0,0,1,0,0,0,2\n /\n")
+    r = subprocess.run([HOST], cwd=tmp_path, capture_output=True, text=True)
+    assert "idb(3)=1" in r.stdout and "idb(7)=2" in r.stdout and "not produced by sbdart_amd" in r.stdout
+    assert '"tbf' not in r.stdout and "no usable HIP device" not in r.stderr
+
+
 def _tokens(text):
     out = []
     for tok in text.split():
