@@ -243,9 +243,61 @@ def latency_case(device):
             "nonzero_status": int(np.count_nonzero(st)), "repeats": len(ts)}
 
 
-def other_shapes(dev):
+def e2e_input_to_stdout(device):
+    """INPUT -> stdout of the drop-in executable (sbdart_amd/bin/sbdart_amd: namelist, band model, engine, writers) on
+    BASELINE's sweeps, as a caller of `sbdart` sees it: wall time of the process (median of 3 after one discarded run) and
+    the host's own account (SBD_TIMING: seconds inside the process from its first statement) -- `points_per_s_in_process`
+    excludes exec / dynamic loading / teardown, `points_per_s_wall` does not.  Never `value`."""
+    host = os.path.join(ROOT, "sbdart_amd", "bin", "sbdart_amd")
+    if not os.path.exists(host):
+        return None
+    cases = (("configs[1] wlinc=.005", "idatm=6 isat=0 wlinf=.25 wlsup=4.0 wlinc=.005 nstr=16 iout=10"),
+             ("configs[1] wlinc=.00005", "idatm=6 isat=0 wlinf=.25 wlsup=4.0 wlinc=.00005 nstr=16 iout=10"),
+             ("configs[4] 0.25-100um, 1 cm-1 steps, nstr=32, 50 layers", "idatm=6 isat=0 wlinf=.25 wlsup=100 wlinc=1.0001 nstr=32 ngrid=50 iout=10 sza=30"))
+    out = {}
+    env = dict(os.environ, SBD_TIMING="1", SBD_OPTICS="/nonexistent", SBD_DEVICES=str(device))
+    for name, nml in cases:
+        try:
+            with tempfile.TemporaryDirectory() as d:
+                with open(os.path.join(d, "INPUT"), "w") as f:
+                    f.write(f"\n &INPUT\n {nml}\n /\n")
+                walls, acct, text = [], {}, ""
+                for rep in range(4):
+                    t0 = time.perf_counter()
+                    r = subprocess.run([host], cwd=d, env=env, capture_output=True, text=True, timeout=600)
+                    w = time.perf_counter() - t0
+                    if r.returncode != 0:
+                        raise RuntimeError(f"exit code {r.returncode}: {r.stderr[-300:]}")
+                    if rep:
+                        walls.append(w)
+                    text = r.stdout
+                    for line in r.stderr.splitlines():
+                        if line.startswith("sbdart_amd: timing "):
+                            kv = dict(x.split("=") for x in line.split()[2:])
+                            if rep:
+                                for k, v in kv.items():
+                                    acct.setdefault(k, []).append(float(v))
+                walls.sort()
+                med = lambda v: float(sorted(v)[len(v) // 2])
+                a = {k: med(v) for k, v in acct.items()}
+                nwl = int(a.get("nwl", 0))
+                rec = {"namelist": nml, "wall_s_median": walls[len(walls) // 2], "wall_s_min": walls[0], "wall_s_max": walls[-1],
+                       "account_s": a, "stdout_tokens": len(text.split())}
+                if nwl:
+                    rec["nwl"] = nwl
+                    rec["points_per_s_wall"] = nwl / rec["wall_s_median"]
+                    if a.get("total"):
+                        rec["points_per_s_in_process"] = nwl / a["total"]
+                out[name] = rec
+        except Exception as ex:   # a side line must not take the headline down
+            out[name] = {"error": repr(ex)}
+    return out
+
+
+def other_shapes(dev, only=None):
     """One-step lines for the other BASELINE shapes (parity-test cases, not the headline): configs[4]'s
-    NSTR 32 x 50 layers in flux mode and configs[3]'s radiance shape (NSTR 32, 20 x 16 angles, 32 azimuth modes)."""
+    NSTR 32 x 50 layers in flux mode and configs[3]'s radiance shape (NSTR 32, 20 x 16 angles, 32 azimuth modes).
+    `only` = "cfgC" | "cfgD": that shape alone (bench.py --shape: the command the shape's counters are recorded with)."""
     import torch
     from sbdart_amd.engine import DisortEngine
     from sbdart_amd.workload import sw_sweep
@@ -253,6 +305,8 @@ def other_shapes(dev):
     out = {}
     for name, kw, nwl in (("cfgD_nstr32_50layers_flux", dict(nstr=32, nlyr=50), 6144),
                           ("cfgC_nstr32_radiance_20x16", dict(nstr=32, nlyr=33, thermal_above_um=99.0), 384)):
+        if only and not name.startswith(only):
+            continue
         try:
             sw = sw_sweep(nwl=nwl, seed=12345, **kw)
             rad = "radiance" in name
@@ -293,115 +347,15 @@ def other_shapes(dev):
     return out
 
 
-DEV_SWITCHES = ("SBD_CHUNK", "SBD_WORKSPACE_MB", "SBD_BAND_V1", "SBD_LAYER_V1",
-                "SBD_FORCE_EIG_FALLBACK", "SBD_DEBUG_SYNC", "SBD_DBG_FLAGS", "SBD_NO_FUSE", "SBD_SOLVE_V1", "SBD_NO_HINT", "SBD_EXACT_PIVOT")
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nwl", type=int, default=49152, help="spectral points per GPU (W = 2.67x)")
-    ap.add_argument("--nstr", type=int, default=16)
-    ap.add_argument("--nlyr", type=int, default=33)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-side-lines", action="store_true", help="skip the latency case and the other BASELINE shapes")
-    ap.add_argument("--rendezvous-only", choices=["nccl", "gloo"], default=None,
-                    help="launcher check: bring up --gpus ranks on this backend, count them, print that, exit (no bench line)")
-    args = ap.parse_args()
-    on = [k for k in DEV_SWITCHES if os.environ.get(k)]
-    if on:   # the headline number is the default path only
-        sys.exit(f"bench.py: developer switch(es) {on} set in the environment -- refusing to produce a bench line")
-
+def host_entry_legs(args, sw, eng, d_in, d_w, acc, flux, status, stream, dev, local_rank, rank, world, level_out, barrier, strong):
+    """The step through the HOST entry points (never `value`): DISORT's arguments as arrays, the moments once per spectral
+    point, and the compact form of SURVEY 8(d)'s engine phase (`value_8d`).  Returns the fields of the bench line."""
+    import ctypes as C
     import torch
     import torch.distributed as dist
-    from sbdart_amd.launch import launched_world, relaunch_one_rank_per_gpu, rendezvous
-    if args.gpus > 1 and launched_world() is None:
-        # `python bench.py --gpus N` on its own: this process becomes the launcher of N ranks (one per GPU) and
-        # passes their exit code on -- it never prints a bench line itself (a 1-GPU line labelled N would be a lie)
-        backend = "gloo" if args.rendezvous_only == "gloo" else "nccl"
-        if backend == "nccl" and torch.cuda.device_count() < args.gpus:
-            sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s): "
-                     f"refusing to print a line for fewer devices than asked for")
-        sys.exit(relaunch_one_rank_per_gpu(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
-    rank, local_rank, world = rendezvous(args.gpus, backend="gloo" if args.rendezvous_only == "gloo" else "nccl")
-    if args.rendezvous_only:
-        # launcher path only (CPU test of `--gpus N`): the ranks met, counted each other, rank 0 says so -- no metric
-        if rank == 0:
-            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "backend": args.rendezvous_only,
-                              "ranks_counted": world}))
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    from sbdart_amd.engine import DisortEngine
-    from sbdart_amd.workload import sw_sweep
-
-    sw = sw_sweep(nwl=args.nwl, nstr=args.nstr, nlyr=args.nlyr, seed=12345, shard=rank)
     W = sw.nwork
-    level_out = [0, sw.nlyr]                      # ntop, nbot of IOUT 1/10 (drt.f:376-381)
-    eng = DisortEngine(nlyr=sw.nlyr, nstr=sw.nstr, nmom=sw.nmom, temper=sw.temper, umu0=sw.umu0,
-                       btemp=sw.btemp, ttemp=sw.ttemp, temis=sw.temis, onlyfl=True,
-                       level_out=level_out, device=local_rank)
-    npass_headline = eng.pass_count(W)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    d_in = [t(sw.dtauc), t(sw.ssalb), t(sw.pmom), t(sw.wvnmlo), t(sw.wvnmhi), t(sw.fbeam), t(sw.albedo), t(sw.plank)]
-    d_w = t(sw.weight)
-    flux = torch.empty((W, 5, eng.nlev), dtype=torch.float64, device=dev)
-    status = torch.empty(W, dtype=torch.int32, device=dev)
-    acc = torch.zeros((5, eng.nlev), dtype=torch.float64, device=dev)
-    tstream = torch.cuda.Stream(dev)                   # an explicit stream: copies, kernels and sums of a step in order
-    torch.cuda.synchronize()
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
-    import ctypes as C
     L = eng._L
-
-    def step():
-        eng.solve_device(*d_in, out=(flux, None, status), stream=stream)
-        acc.zero_()
-        rc = L.sbd_engine_accumulate_device(eng._h, W, d_w.data_ptr(), flux.data_ptr(), None,
-                                            acc.data_ptr(), None, C.c_void_p(stream))
-        assert rc == 0, rc
-        if world > 1:
-            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)   # the one RCCL collective of the path
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    bad = int((status != 0).sum().item())
-    if not bool(torch.isfinite(flux).all().item()):
-        sys.exit("bench.py: non-finite fluxes -- refusing to report a rate for wrong answers")
-
-    # ---- per-kernel timing pass (HIP events on the launch stream), outside the timed region ----
-    eng.enable_timing(True)
-    phase_ms = np.zeros(5)
-    nrep = 3
-    for _ in range(nrep):
-        eng.solve_device(*d_in, out=(flux, None, status), stream=stream)
-        phase_ms += [eng.last_ms(p) for p in range(5)]
-    phase_ms /= nrep
-    fallback_layers = int(eng.last_fallback_layers())
-    eng.enable_timing(False)
-    torch.cuda.synchronize()
-
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     # ---- the same step through the HOST entry point (what the Fortran host calls): inputs in pinned host
     #      memory, every pass stages its slice H2D on its stream beside the other pass's kernels, weighted
     #      sums on the device, D2H of the sums and the status words (SURVEY 8d's "engine phase"); never `value` ----
@@ -448,10 +402,14 @@ def main():
     # with its assembled arrays resident in HBM is measured beside it (value_8d_resident): the ratio is the cost of
     # feeding the engine from the host.
     from sbdart_amd.workload import sw_sweep_mix
-    mx = sw_sweep_mix(nwl=args.nwl, nstr=args.nstr, nlyr=args.nlyr, seed=12345, shard=rank)
+    if strong:
+        from sbdart_amd.shard import shard_range
+        p_lo, p_hi = shard_range(args.nwl, rank, world)
+        mx = sw_sweep_mix(nwl=args.nwl, nstr=args.nstr, nlyr=args.nlyr, seed=12345, shard=0).points(p_lo, p_hi)
+    else:
+        mx = sw_sweep_mix(nwl=args.nwl, nstr=args.nstr, nlyr=args.nlyr, seed=12345, shard=rank)
     pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().numpy()
-    m_in = [pin(x) for x in (mx.point_of, mx.dtaug, mx.dtaux, mx.tsc_hg, mx.g_hg, mx.tsc_ray, mx.wvnmlo, mx.wvnmhi,
-                             mx.fbeam, mx.albedo, mx.plank)]
+    m_in = [x if isinstance(x, tuple) else pin(x) for x in mx.mix_args()]
     m_w = pin(mx.weight)
 
     def step_mix():
@@ -504,10 +462,194 @@ def main():
         tt = torch.tensor([elapsed_h], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed_h = float(tt.item())
+
     assert np.allclose(acc_h, acc.cpu().numpy(), rtol=1e-12, atol=0) or world > 1, "host entry point disagrees with the device one"
+    nwl_total = args.nwl if strong else sw.nwl * world
+    med_m = float(np.median(mix_steps))
+    if world > 1:
+        # (every rank's own median, the slowest rank's is the node's pace -- and the same statistic on both
+        #  sides of the resident ratio)
+        tt = torch.tensor([med_m], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        med_m = float(tt.item())
+    med_r = 1e3 * elapsed_r / nh
+    return {
+        "value_incl_h2d": nwl_total * nh / elapsed_h, "ms_per_step_incl_h2d": 1e3 * elapsed_h / nh,
+        "value_incl_h2d_shared_moments": nwl_total * nh / elapsed_hs, "ms_per_step_incl_h2d_shared_moments": 1e3 * elapsed_hs / nh,
+        # SURVEY 8(d)'s own wording of the metric ("H2D of inputs + kernels + D2H/reduce"): the host entry point's
+        # rate; its bound is the PCIe link, not HBM (roofline_pcie).  `value` stays the HBM-resident rate.
+        # (median of the steps, MAX over the ranks: one step in five runs takes 70 ms instead of 9 on some boxes of the pool --
+        #  a stall of the host side; rank 0's steps are listed in ms_steps_8d, the mean is ms_per_step_8d_mean)
+        "value_8d": nwl_total / (1e-3 * med_m), "ms_per_step_8d": med_m,
+        "ms_per_step_8d_mean": 1e3 * elapsed_m / nh,
+        "ms_steps_8d": [round(x, 2) for x in mix_steps],
+        "value_8d_resident": nwl_total * nh / elapsed_r, "ms_per_step_8d_resident": med_r,
+        "value_8d_over_resident": (1e3 * elapsed_r / nh) / (1e3 * elapsed_m / nh),
+        "value_8d_note": "SURVEY 8(d)'s engine phase (H2D + kernels + D2H/reduce) through sbd_fleet_solve_mix_host: the batch "
+                         "in compact form (per spectral point the scatterers, per item the gas of its k-term), DTAUC / SSALB / "
+                         "PMOM assembled on the device; value_8d_resident = the same sweep with the assembled arrays already in "
+                         f"HBM (value_8d_over_resident: mean step over mean step); sums of the two agree to 1e-12: {mix_agree}; "
+                         f"nonzero status {bad_mix}",
+        "roofline_pcie": {"bound": "pcie", "achieved": h2d_bytes * world * nh / elapsed_h / 1e9, "peak": PCIE_PEAK_GBS,
+                          "unit": "GB/s", "frac": h2d_bytes * nh / elapsed_h / 1e9 / PCIE_PEAK_GBS,
+                          "bytes_per_step": h2d_bytes, "bytes_per_step_shared_moments": h2d_bytes_shared,
+                          "bytes_per_step_compact": mx.h2d_bytes(),
+                          "achieved_shared_moments": h2d_bytes_shared * nh / elapsed_hs / 1e9,
+                          "achieved_compact": mx.h2d_bytes() * nh / elapsed_m / 1e9,
+                          "note": "H2D bytes of one step's inputs (per-item moments / moments once per spectral "
+                                  "point / compact form) over the host-entry-point step time; peak = PCIe 5.0 x16 per "
+                                  "direction.  `achieved`/`frac` belong to value_incl_h2d (DISORT's arguments as arrays: "
+                                  "PCIe-bound); the compact form needs a ninth of the bytes and is compute-bound again"},
+        "incl_h2d_note": "same step through the host entry point (sbd_fleet_solve_host): inputs in pinned host memory, the passes' H2D back to back on a copy stream beside the kernels, sums on the device, D2H of sums + status",
+    }
+
+
+DEV_SWITCHES = ("SBD_CHUNK", "SBD_WORKSPACE_MB", "SBD_BAND_V1", "SBD_LAYER_V1",
+                "SBD_FORCE_EIG_FALLBACK", "SBD_DEBUG_SYNC", "SBD_DBG_FLAGS", "SBD_NO_FUSE", "SBD_SOLVE_V1", "SBD_NO_HINT", "SBD_EXACT_PIVOT")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nwl", type=int, default=49152, help="spectral points per GPU (W = 2.67x)")
+    ap.add_argument("--nstr", type=int, default=16)
+    ap.add_argument("--nlyr", type=int, default=33)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-lines", action="store_true", help="skip the latency case and the other BASELINE shapes")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --nwl spectral points PER GPU (the default; each rank its own PRNG stream); strong: ONE sweep of "
+                         "--nwl points cut between spectral points by sbd_shard_range, rank r solves its shard (north_star's split)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="the timed steps and the per-kernel timing pass only: no host-entry-point legs (whose passes have other "
+                         "sizes) -- the command profiles/<tag>_kernel_stats.csv is recorded with, so that its averages are "
+                         "bench-size launches")
+    ap.add_argument("--shape", choices=["cfgC", "cfgD"], default=None,
+                    help="print the one-step line of another BASELINE shape (other_shapes) and nothing else: the command its "
+                         "counters in profiles/ are recorded with")
+    ap.add_argument("--rendezvous-only", choices=["nccl", "gloo"], default=None,
+                    help="launcher check: bring up --gpus ranks on this backend, count them, print that, exit (no bench line)")
+    args = ap.parse_args()
+    on = [k for k in DEV_SWITCHES if os.environ.get(k)]
+    if on:   # the headline number is the default path only
+        sys.exit(f"bench.py: developer switch(es) {on} set in the environment -- refusing to produce a bench line")
+
+    import torch
+    import torch.distributed as dist
+    from sbdart_amd.launch import launched_world, relaunch_one_rank_per_gpu, rendezvous
+    if args.gpus > 1 and launched_world() is None:
+        # `python bench.py --gpus N` on its own: this process becomes the launcher of N ranks (one per GPU) and
+        # passes their exit code on -- it never prints a bench line itself (a 1-GPU line labelled N would be a lie)
+        backend = "gloo" if args.rendezvous_only == "gloo" else "nccl"
+        if backend == "nccl" and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s): "
+                     f"refusing to print a line for fewer devices than asked for")
+        sys.exit(relaunch_one_rank_per_gpu(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    rank, local_rank, world = rendezvous(args.gpus, backend="gloo" if args.rendezvous_only == "gloo" else "nccl")
+    if args.rendezvous_only:
+        # launcher path only (CPU test of `--gpus N`): the ranks met, counted each other, rank 0 says so -- no metric
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "backend": args.rendezvous_only,
+                              "ranks_counted": world}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from sbdart_amd.engine import DisortEngine
+    from sbdart_amd.workload import sw_sweep
+
+    if args.shape:
+        # a side shape on its own (rank 0's device): the line its counters in profiles/ are recorded for
+        if rank == 0:
+            print(json.dumps({"shape": args.shape, **other_shapes(dev, only=args.shape)}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    strong = args.scaling == "strong"
+    if strong:
+        # ONE sweep of --nwl spectral points, the same on every rank (same PRNG stream); rank r takes the points
+        # sbd_shard_range gives it -- shards cut between spectral points, total work fixed as N grows
+        from sbdart_amd.shard import shard_range
+        p_lo, p_hi = shard_range(args.nwl, rank, world)
+        sw = sw_sweep(nwl=args.nwl, nstr=args.nstr, nlyr=args.nlyr, seed=12345, shard=0).points(p_lo, p_hi)
+    else:
+        sw = sw_sweep(nwl=args.nwl, nstr=args.nstr, nlyr=args.nlyr, seed=12345, shard=rank)
+    W = sw.nwork
+    level_out = [0, sw.nlyr]                      # ntop, nbot of IOUT 1/10 (drt.f:376-381)
+    eng = DisortEngine(nlyr=sw.nlyr, nstr=sw.nstr, nmom=sw.nmom, temper=sw.temper, umu0=sw.umu0,
+                       btemp=sw.btemp, ttemp=sw.ttemp, temis=sw.temis, onlyfl=True,
+                       level_out=level_out, device=local_rank)
+    npass_headline = eng.pass_count(W)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_in = [t(sw.dtauc), t(sw.ssalb), t(sw.pmom), t(sw.wvnmlo), t(sw.wvnmhi), t(sw.fbeam), t(sw.albedo), t(sw.plank)]
+    d_w = t(sw.weight)
+    flux = torch.empty((W, 5, eng.nlev), dtype=torch.float64, device=dev)
+    status = torch.empty(W, dtype=torch.int32, device=dev)
+    acc = torch.zeros((5, eng.nlev), dtype=torch.float64, device=dev)
+    tstream = torch.cuda.Stream(dev)                   # an explicit stream: copies, kernels and sums of a step in order
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    import ctypes as C
+    L = eng._L
+
+    def step():
+        eng.solve_device(*d_in, out=(flux, None, status), stream=stream)
+        acc.zero_()
+        rc = L.sbd_engine_accumulate_device(eng._h, W, d_w.data_ptr(), flux.data_ptr(), None,
+                                            acc.data_ptr(), None, C.c_void_p(stream))
+        assert rc == 0, rc
+        if world > 1:
+            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)   # the one RCCL collective of the path
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    W_all = W
+    if world > 1:
+        tt = torch.tensor([float(W)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        W_all = int(tt.item())
+    bad = int((status != 0).sum().item())
+    if not bool(torch.isfinite(flux).all().item()):
+        sys.exit("bench.py: non-finite fluxes -- refusing to report a rate for wrong answers")
+
+    # ---- per-kernel timing pass (HIP events on the launch stream), outside the timed region ----
+    eng.enable_timing(True)
+    phase_ms = np.zeros(5)
+    nrep = 3
+    for _ in range(nrep):
+        eng.solve_device(*d_in, out=(flux, None, status), stream=stream)
+        phase_ms += [eng.last_ms(p) for p in range(5)]
+    phase_ms /= nrep
+    fallback_layers = int(eng.last_fallback_layers())
+    eng.enable_timing(False)
+    torch.cuda.synchronize()
+
+    # ---- the same step through the HOST entry points (what the Fortran host calls), outside the timed region; never `value` ----
+    hl = None if args.headline_only else host_entry_legs(args, sw, eng, d_in, d_w, acc, flux, status, stream, dev, local_rank,
+                                                         rank, world, level_out, barrier, strong)
 
     if rank == 0:
-        nwl_total = sw.nwl * world
+        nwl_total = args.nwl if strong else sw.nwl * world
+        W_total = W_all                                     # solves of the whole node per step
         ms_per_step = 1e3 * elapsed / args.steps
         value = nwl_total * args.steps / elapsed
         names = ["setup_kernel", "layer_kernel", "band_kernel", "backsolve_kernel", "usrint+azimuth"]
@@ -517,46 +659,33 @@ def main():
         pass_size = (W + nlaunch - 1) // nlaunch
         roof = shape_roofline(names, phase_ms, nlaunch, pass_size, W, sw.nstr, sw.nlyr, eng.nlev)
         roof["note"] = ("latency/issue bound by construction (SURVEY 8d): ~5 KB of inputs per 2.5 MFLOP of pivoted fp64; the "
-                        "binding figure is valu_issue (executed VALU occupancy), beside it")
+                        "binding figures are roofline_fp64 (algorithmic flops against the fp64 vector peak) and valu_issue "
+                        "(executed VALU occupancy), beside it")
         flops = algorithmic_flops_per_solve(sw.nlyr, sw.nstr)
+        tf = flops * W_total * args.steps / elapsed / 1e12
         out = {
             "metric": "spectral-points/sec (whole node) + flux RMSE vs CPU, 16-stream SW sweep",
             "value": value, "unit": "spectral-points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"SW 0.25-4.0um synthetic sweep, nstr={sw.nstr}, {sw.nlyr} layers, "
-                                   f"{sw.nwl} spectral points/GPU, {W} DISORT solves/GPU (avg nk {W / sw.nwl:.2f}), "
-                                   f"flux at TOA+surface, seed 12345",
+                                   + (f"ONE sweep of {args.nwl} spectral points cut between points over {world} GPU(s) "
+                                      f"(sbd_shard_range; rank 0: {sw.nwl} points, {W} solves), {W_total} DISORT solves, "
+                                      if strong else
+                                      f"{sw.nwl} spectral points/GPU, {W} DISORT solves/GPU (avg nk {W / sw.nwl:.2f}), ")
+                                   + "flux at TOA+surface, seed 12345",
                        "nstr": sw.nstr, "nlyr": sw.nlyr, "nwl_per_gpu": sw.nwl, "solves_per_gpu": W,
+                       "nwl_total": nwl_total, "solves_total": W_total,
                        "parallelism": f"spectral shard x{world}, 1 RCCL reduce of {5 * eng.nlev} doubles/step; per GPU {nlaunch} passes alternating on 2 streams",
                        "chunk": eng.chunk, "workspace_bytes": eng.workspace_bytes},
-            "solves_per_s": W * world * args.steps / elapsed,
-            "value_incl_h2d": nwl_total * nh / elapsed_h, "ms_per_step_incl_h2d": 1e3 * elapsed_h / nh,
-            "value_incl_h2d_shared_moments": nwl_total * nh / elapsed_hs, "ms_per_step_incl_h2d_shared_moments": 1e3 * elapsed_hs / nh,
-            # SURVEY 8(d)'s own wording of the metric ("H2D of inputs + kernels + D2H/reduce"): the host entry point's
-            # rate; its bound is the PCIe link, not HBM (roofline_pcie).  `value` stays the HBM-resident rate.
-            # (median of the steps: one step in five runs takes 70 ms instead of 9 on some boxes of the pool -- a stall of the
-            #  host side, every step is listed in ms_steps_8d, the mean is ms_per_step_8d_mean)
-            "value_8d": nwl_total / (1e-3 * float(np.median(mix_steps))), "ms_per_step_8d": float(np.median(mix_steps)),
-            "ms_per_step_8d_mean": 1e3 * elapsed_m / nh,
-            "ms_steps_8d": [round(x, 2) for x in mix_steps],
-            "value_8d_resident": nwl_total * nh / elapsed_r, "ms_per_step_8d_resident": 1e3 * elapsed_r / nh,
-            "value_8d_over_resident": (1e3 * elapsed_r / nh) / float(np.median(mix_steps)),
-            "value_8d_note": "SURVEY 8(d)'s engine phase (H2D + kernels + D2H/reduce) through sbd_fleet_solve_mix_host: the batch "
-                             "in compact form (per spectral point the scatterers, per item the gas of its k-term), DTAUC / SSALB / "
-                             "PMOM assembled on the device; value_8d_resident = the same sweep with the assembled arrays already in "
-                             f"HBM; sums of the two agree to 1e-12: {mix_agree}; nonzero status {bad_mix}",
-            "roofline_pcie": {"bound": "pcie", "achieved": h2d_bytes * world * nh / elapsed_h / 1e9, "peak": PCIE_PEAK_GBS,
-                              "unit": "GB/s", "frac": h2d_bytes * nh / elapsed_h / 1e9 / PCIE_PEAK_GBS,
-                              "bytes_per_step": h2d_bytes, "bytes_per_step_shared_moments": h2d_bytes_shared,
-                              "bytes_per_step_compact": mx.h2d_bytes(),
-                              "achieved_shared_moments": h2d_bytes_shared * nh / elapsed_hs / 1e9,
-                              "achieved_compact": mx.h2d_bytes() * nh / elapsed_m / 1e9,
-                              "note": "H2D bytes of one step's inputs (per-item moments / moments once per spectral "
-                                      "point / compact form) over the host-entry-point step time; peak = PCIe 5.0 x16 per "
-                                      "direction.  `achieved`/`frac` belong to value_incl_h2d (DISORT's arguments as arrays: "
-                                      "PCIe-bound); the compact form needs a ninth of the bytes and is compute-bound again"},
-            "incl_h2d_note": "same step through the host entry point (sbd_fleet_solve_host): inputs in pinned host memory, the passes' H2D back to back on a copy stream beside the kernels, sums on the device, D2H of sums + status",
+            "solves_per_s": W_total * args.steps / elapsed,
+            # SURVEY 8(d)'s fp64 fraction: ALGORITHMIC flops per solve (its formula, algorithmic_flops_per_solve) x the
+            # solves of the timed steps / their time, against the fp64 VECTOR peak of the GPUs used (no MFMA on this path)
+            "roofline_fp64": {"bound": "fp64_vector", "achieved": tf, "peak": FP64_VEC_PEAK_TF * world, "unit": "TFLOP/s",
+                              "frac": tf / (FP64_VEC_PEAK_TF * world), "algorithmic_flops_per_solve": flops,
+                              "note": "whole timed step (all kernels, all ranks), SURVEY 8(d)'s flop count; executed "
+                                      "instructions are in valu_issue"},
+            **(hl or {}),
             "nonzero_status": bad, "fallback_layers": fallback_layers,
             "kernel_ms": {names[i]: float(phase_ms[i]) for i in range(5)},
             "roofline": roof,
@@ -569,6 +698,7 @@ def main():
             torch.cuda.empty_cache()
             out["latency_case"] = latency_case(local_rank)
             out["other_shapes"] = other_shapes(dev)
+            out["e2e_input_to_stdout"] = e2e_input_to_stdout(local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], allc, idx, ref = cpu_baseline(sw)
             if allc is not None:

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SBD_ABI_VERSION 5
+#define SBD_ABI_VERSION 6
 
 /* limits of the reference (params.f:9-15) */
 #define SBD_MAX_NLYR 65   /* mxly   */
@@ -160,27 +160,38 @@ typedef struct {
                           (usrang) or nstr/2 output cosines; flux comes back zero like DISORT's (ZEROAL) */
 } sbd_batch_out;
 
-/* The same batch in COMPACT form (ABI v5): per SPECTRAL POINT what scatters there, per WORK ITEM only the gas of its
- * k-term -- the operands of the three statements with which the reference turns its band model's output into DISORT's
+/* The same batch in COMPACT form (ABI v6): per SPECTRAL POINT what scatters there, per WORK ITEM only the gas of its
+ * k-term -- the operands of the statements with which the reference turns its band model's output into DISORT's
  * arguments, which the engine then executes on the device (assemble_kernel) instead of receiving their results over
- * PCIe:
- *   DTAUC(l) = dtaug(item, l) + dtaux(point, l)                          depthscl, taugas.f:7625-7646 (dtaus)
- *   SSALB(l) = (tsc_hg + tsc_ray)(point, l) / DTAUC(l), 0 where DTAUC is 0   taugas.f:7640-7646 (wreal)
- *   PMOM(k, l) = (tsc_hg g**k + [k = 2] 0.1 tsc_ray) / (tsc_hg + tsc_ray), PMOM(0, l) = 1
- *                                                                        GETMOM iphas 3 and 2 (disutil.f:2176-2188: g**k
- *                                                                        with an integer power, the Rayleigh 0.1 as the
- *                                                                        reference's REAL*4 literal), normom drt.f:1366-1397
+ * PCIe.  The statements, in the reference's own association (one rounding per operation, no contraction):
+ *
+ *   DTAUC(l) = ((dtaug(item,l) + dtauc(point,l)) + dtaua(point,l)) + dtaur(point,l)     depthscl, taugas.f:7598
+ *   SSALB(l) = tsc(point,l) / DTAUC(l) where DTAUC(l) > tiny(1.d0), else 0               depthscl, taugas.f:7599-7603
+ *       tsc = dtauc*wcld + dtaua*waer + dtaur, formed by the host (it is depthscl's numerator and normom's dtsct)
+ *   PMOM(k,l) = [ sum over the layer's scattering terms t, in slot order, of (P_t(k) * m1_t) * m2_t
+ *                 + (k == 2) 0.1 * dtaur ] / tsc   (not divided where tsc == 0);  PMOM(0,l) = 1     normom, drt.f:1390-1395
+ *       P_t(k): GETMOM's moment k of the slot's phase-function family (disutil.f:2104-2209) -- 1 isotropic (0 for k >= 1),
+ *       2 Rayleigh (0.1 at k = 2), 3 Henyey-Greenstein g**k (an INTEGER power: square-and-multiply from the low bit, as
+ *       the reference's compiler forms it), and the Rayleigh 0.1 the reference's REAL*4 literal.
+ *       A cloud layer is one term (g, taucld*wcld, 1): taucloud's TAUCLD*WCLD*PMOM/ICNT (taucloud.f:103, 132 with one
+ *       cloud per layer; usrcloud taucloud.f:262-266); the boundary-layer aerosol (g, dtaua, waer): tauaero's PM*DTAUA*WAER (tauaero.f:1300);
+ *       a stratospheric layer (g, dt, wa) (tauaero.f:1330).  A slot a layer does not use carries m1 = 0.
+ *
  * The moments are formed once per spectral point and shared by its k-terms (as sbd_batch_in::pmom_row).  Bytes over
- * PCIe: 8 [W L + P (4 L + 4)] against 8 W L (nmom + 3) -- a ninth at NSTR 16 with nk = 2.67.
- * Host entry points only (on the device side the assembled arrays ARE sbd_batch_in).  point_of non-decreasing. */
+ * PCIe: 8 [W L + P ((4 + 3 nterm) L + 4)] against 8 W L (nmom + 3) -- a ninth at NSTR 16 with nk = 2.67.
+ * Host entry points only (on the device side the assembled arrays ARE sbd_batch_in).  point_of non-decreasing; a call
+ * may reference any contiguous range of the npoint blocks (only the blocks its items point at are staged).
+ * Tabulated phase functions (GETMOM 4, 5; aerosol.dat / user moments), several clouds in one layer and the ocean
+ * surface's per-item constants keep the arrays form (sbd_batch_in). */
+#define SBD_MIX_MAX_TERMS 6
 typedef struct {
     int32_t nwork, npoint;
     const int32_t *point_of;  /* [nwork]        spectral point of each work item, 0-based, non-decreasing           */
     const double *dtaug;      /* [nwork][nlyr]  absorption optical depth of the item's k-term (gases, dtaug)       */
-    const double *dtaux;      /* [npoint][nlyr] extinction optical depth of everything else: cloud + aerosol + Rayleigh */
-    const double *tsc_hg;     /* [npoint][nlyr] scattering optical depth of the particles (Henyey-Greenstein family)   */
-    const double *g_hg;       /* [npoint][nlyr] their asymmetry factor                                               */
-    const double *tsc_ray;    /* [npoint][nlyr] Rayleigh scattering optical depth (dtaur)                           */
+    int32_t nterm;            /* scattering terms per layer besides Rayleigh, 0..SBD_MIX_MAX_TERMS                  */
+    int32_t family[SBD_MIX_MAX_TERMS];   /* GETMOM's iphas of slot t: 1, 2 or 3                                     */
+    const double *lay;        /* [npoint][4 + 3 nterm][nlyr]: channels dtauc, dtaua, dtaur, tsc, then per slot t its
+                                 g, m1, m2 -- one block per spectral point, a channel's layers contiguous          */
     const double *wvnmlo, *wvnmhi, *fbeam, *albedo;   /* [npoint] as in sbd_batch_in, per spectral point            */
     const uint8_t *plank;     /* [npoint]                                                                           */
 } sbd_mix_in;
@@ -230,9 +241,12 @@ void     sbd_shard_range(int32_t nwork, int32_t nshard, int32_t rank, int32_t *l
 int      sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_out *out,
                               const double *weight, double *acc_flux, double *acc_uu);
 /* ... from the compact form (sbd_mix_in, HOST pointers): every pass stages its slice of the compact arrays and
- * assembles DTAUC / SSALB / PMOM on the device ahead of its kernels.  A fleet of one device (the sharded form cuts
- * between spectral points: not built yet -- SBD_E_UNSUPPORTED for more).  Lambertian surface or a bidirectional one
- * without per-item constants (ibdrf 0, 2, 3). */
+ * assembles DTAUC / SSALB / PMOM on the device ahead of its kernels.  Several devices: the batch is cut BETWEEN
+ * spectral points -- sbd_shard_range_points: the item boundaries of sbd_shard_range, each moved up to the next item
+ * that starts a spectral point (the k-terms of a point stay on one device, which forms the point's moments once) --
+ * and summed like sbd_fleet_solve_host.  Lambertian surface or a bidirectional one without per-item constants
+ * (ibdrf 0, 2, 3). */
+void     sbd_shard_range_points(int32_t nwork, const int32_t *point_of, int32_t nshard, int32_t rank, int32_t *lo, int32_t *hi);
 int      sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_batch_out *out,
                                   const double *weight, double *acc_flux, double *acc_uu);
 /* How the devices are fed (replaces nothing in the reference: its loop is serial, drt.f:425-561): every device's

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SBDART_AMD_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get("SBDART_AMD_LIB") or os.path.join(_HERE, "lib", "libsbdart_amd.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NFLUX = 5
 RFLDIR, RFLDN, FLUP, DFDT, UAVG = range(5)
 
@@ -42,10 +42,14 @@ class BatchOut(C.Structure):
     _fields_ = [("flux", C.c_void_p), ("uu", C.c_void_p), ("status", C.c_void_p), ("albtrn", C.c_void_p)]
 
 
+MIX_MAX_TERMS = 6
+
+
 class MixIn(C.Structure):
-    """sbd_mix_in: a batch in compact form (per spectral point the scatterers, per work item the gas of its k-term)."""
+    """sbd_mix_in (ABI v6): a batch in compact form -- per spectral point a block [4 + 3 nterm][nlyr] (dtauc, dtaua, dtaur,
+    tsc, then g, m1, m2 of every scattering term), per work item the gas of its k-term."""
     _fields_ = [("nwork", C.c_int32), ("npoint", C.c_int32), ("point_of", C.c_void_p), ("dtaug", C.c_void_p),
-                ("dtaux", C.c_void_p), ("tsc_hg", C.c_void_p), ("g_hg", C.c_void_p), ("tsc_ray", C.c_void_p),
+                ("nterm", C.c_int32), ("family", C.c_int32 * MIX_MAX_TERMS), ("lay", C.c_void_p),
                 ("wvnmlo", C.c_void_p), ("wvnmhi", C.c_void_p), ("fbeam", C.c_void_p), ("albedo", C.c_void_p),
                 ("plank", C.c_void_p)]
 
@@ -59,7 +63,7 @@ EXPORTS = (
     "sbd_last_error", "sbd_engine_debug_copy", "sbd_engine_debug_pivots",
     "sbd_fleet_create", "sbd_fleet_destroy", "sbd_fleet_size", "sbd_fleet_engine", "sbd_fleet_uses_rccl",
     "sbd_shard_range", "sbd_fleet_solve_host", "sbd_fleet_last_enqueue", "sbd_host_alloc", "sbd_host_free",
-    "sbd_surface_flux_albedo", "sbd_fleet_solve_mix_host", "sbd_engine_pass_count",
+    "sbd_surface_flux_albedo", "sbd_fleet_solve_mix_host", "sbd_engine_pass_count", "sbd_shard_range_points",
 )
 
 _LIB = None
@@ -129,6 +133,8 @@ def load() -> C.CDLL:
     L.sbd_fleet_solve_host.restype = C.c_int
     L.sbd_fleet_solve_mix_host.argtypes = [vp, C.POINTER(MixIn), C.POINTER(BatchOut), vp, vp, vp]
     L.sbd_fleet_solve_mix_host.restype = C.c_int
+    L.sbd_shard_range_points.argtypes = [C.c_int32, vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.sbd_shard_range_points.restype = None
     L.sbd_fleet_last_enqueue.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.sbd_fleet_last_enqueue.restype = C.c_int
     L.sbd_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]

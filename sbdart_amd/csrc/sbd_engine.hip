@@ -172,8 +172,9 @@ __global__ void __launch_bounds__(256) accum_final_kernel(int nseg, int nel, con
     if ((int)threadIdx.x < ne) acc[e0 + threadIdx.x] = a;
 }
 
-// The compact form of a batch (sbd_mix_in) -> DISORT's arguments, on the device: what depthscl (taugas.f:7625-7646),
-// GETMOM (disutil.f:2176-2188) and normom (drt.f:1366-1397) do on the host for every (wavelength, k-term).  A block per
+// The compact form of a batch (sbd_mix_in, ABI v6) -> DISORT's arguments, on the device: what depthscl (taugas.f:7598-7603),
+// GETMOM (disutil.f:2104-2209), taucloud / tauaero's accumulation (taucloud.f:103, 132; tauaero.f:1300, 1330) and normom
+// (drt.f:1390-1395) do on the host for every (wavelength, k-term), in the reference's own association.  A block per
 // work item, a thread per layer: DTAUC and SSALB of the item; the FIRST item of a spectral point (in this launch) also
 // forms the point's block of moments, which its k-terms share (pmom_row).  Integer powers of g the way the reference's
 // compiler forms GG**K (square-and-multiply from the low bit, compiler-rt's __powidf2), the Rayleigh 0.1 as the REAL*4
@@ -190,9 +191,11 @@ __device__ __forceinline__ double powi_like_fortran(double a, int b)
     }
     return r;
 }
-__global__ void __launch_bounds__(64) assemble_kernel(int w0, int nitem, int L, int nmom, int first_point_done,
-                                                      const int32_t *point_of, const double *dtaug, const double *dtaux,
-                                                      const double *tsc_hg, const double *g_hg, const double *tsc_ray,
+struct MixFamilies { int32_t f[SBD_MIX_MAX_TERMS]; };
+// point blocks: lay[(p - pbase)][4 + 3 nterm][L]; outputs: dtauc / ssalb [item], pmom [(p - pbase)], pmom_row = p - pbase
+__global__ void __launch_bounds__(64) assemble_kernel(int w0, int nitem, int L, int nmom, int first_point_done, int pbase,
+                                                      int nterm, MixFamilies fam,
+                                                      const int32_t *point_of, const double *dtaug, const double *lay,
                                                       const double *plo, const double *phi_, const double *pfb, const double *pal,
                                                       const uint8_t *ppl, double *dtauc, double *ssalb, double *pmom,
                                                       int32_t *pmom_row, double *wvnmlo, double *wvnmhi, double *fbeam,
@@ -201,23 +204,29 @@ __global__ void __launch_bounds__(64) assemble_kernel(int w0, int nitem, int L, 
 #pragma clang fp contract(off)      // (the host forms these products and sums one rounding at a time: so must this kernel)
     const int w = w0 + blockIdx.x;
     if (blockIdx.x >= nitem) return;
-    const int p = point_of[w];
+    const int p = point_of[w] - pbase;
     // the point's moments: by its first item in this launch -- unless the launch before already made them
-    const bool first = (blockIdx.x == 0) ? (first_point_done == 0) : (point_of[w - 1] != p);
+    const bool first = (blockIdx.x == 0) ? (first_point_done == 0) : (point_of[w - 1] - pbase != p);
+    const int nch = 4 + 3 * nterm;
+    const double *blk = lay + (size_t)p * nch * L;
     for (int l = threadIdx.x; l < L; l += blockDim.x) {
-        const double sh = tsc_hg[(size_t)p * L + l], sr = tsc_ray[(size_t)p * L + l];
-        const double scat = sh + sr;
-        const double dt = dtaug[(size_t)w * L + l] + dtaux[(size_t)p * L + l];
+        const double dc = blk[l], da = blk[L + l], dr = blk[2 * L + l], scat = blk[3 * L + l];
+        const double dt = ((dtaug[(size_t)w * L + l] + dc) + da) + dr;                     // taugas.f:7598
         dtauc[(size_t)w * L + l] = dt;
-        ssalb[(size_t)w * L + l] = (dt > 2.2250738585072014e-308) ? scat / dt : 0.0;      // (tiny(1.d0): the host's guard)
+        ssalb[(size_t)w * L + l] = (dt > 2.2250738585072014e-308) ? scat / dt : 0.0;      // (tiny(1.d0): taugas.f:7599)
         if (first) {
-            const double g = g_hg[(size_t)p * L + l];
             double *pm = pmom + ((size_t)p * L + l) * (nmom + 1);
             pm[0] = 1.0;
             for (int k = 1; k <= nmom; ++k) {
-                double q = sh * powi_like_fortran(g, k);
-                if (k == 2) q = q + (double)0.1f * sr;
-                pm[k] = (scat != 0.0) ? q / scat : q;
+                double q = 0.0;
+                for (int t = 0; t < nterm; ++t) {
+                    const double *tc = blk + (size_t)(4 + 3 * t) * L;
+                    const int f = fam.f[t];
+                    const double pk = (f == 3) ? powi_like_fortran(tc[l], k) : ((f == 2 && k == 2) ? (double)0.1f : 0.0);
+                    q = q + (pk * tc[L + l]) * tc[2 * L + l];
+                }
+                if (k == 2) q = q + (double)0.1f * dr;                                      // drt.f:1391
+                pm[k] = (scat != 0.0) ? q / scat : q;                                       // drt.f:1392-1393
             }
         }
     }
@@ -917,10 +926,11 @@ long long sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t
 // Host arrays behind a device-pointer solve (sbd_engine_solve_host, fleets): every pass copies its own
 // slice in before its kernels and its outputs back after them, on the pass's stream -- the H2D of one
 // pass then runs beside the kernels of the other instead of ahead of everything.
-struct MixStage {               // device staging of a compact batch (sbd_mix_in), all of it
+struct MixStage {               // device staging of a compact batch (sbd_mix_in): its items, and the point blocks pbase .. they refer to
     int32_t *point_of;
-    double *dtaug, *dtaux, *tsc_hg, *g_hg, *tsc_ray, *lo, *hi, *fb, *al;
+    double *dtaug, *lay, *lo, *hi, *fb, *al;
     uint8_t *pl;
+    int32_t pbase;              // first spectral point the call's items refer to: staged block q holds point pbase + q
 };
 struct HostSide {
     const sbd_batch_in *in;     // host inputs (NULL members never occur: checked by the callers)
@@ -1073,21 +1083,23 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             const MixStage &d = hs->ms;
             const int p0 = m->point_of[w0], p1 = m->point_of[w0 + ns - 1];
             const bool done = ip > 0 && m->point_of[w0 - 1] == p0;        // (its moments exist: the pass before made them)
-            const int q0 = done ? p0 + 1 : p0, nq = p1 - q0 + 1;
+            const int q0 = done ? p0 + 1 : p0, nq = p1 - q0 + 1;           // (global point indices)
+            const size_t blk = (size_t)(4 + 3 * m->nterm) * L;
             HIP_TRY(hipMemcpyAsync(d.point_of + w0, m->point_of + w0, sizeof(int32_t) * ns, hipMemcpyHostToDevice, cs));
             HIP_TRY(hipMemcpyAsync(d.dtaug + (size_t)w0 * L, m->dtaug + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, cs));
             if (nq > 0) {
-                const std::pair<double *, const double *> lay[4] = {{d.dtaux, m->dtaux}, {d.tsc_hg, m->tsc_hg}, {d.g_hg, m->g_hg}, {d.tsc_ray, m->tsc_ray}};
-                for (const auto &a : lay)
-                    HIP_TRY(hipMemcpyAsync(a.first + (size_t)q0 * L, a.second + (size_t)q0 * L, sizeof(double) * nq * L, hipMemcpyHostToDevice, cs));
+                const int s0 = q0 - d.pbase;                               // (staged block index)
+                HIP_TRY(hipMemcpyAsync(d.lay + (size_t)s0 * blk, m->lay + (size_t)q0 * blk, sizeof(double) * nq * blk, hipMemcpyHostToDevice, cs));
                 const std::pair<double *, const double *> sc[4] = {{d.lo, m->wvnmlo}, {d.hi, m->wvnmhi}, {d.fb, m->fbeam}, {d.al, m->albedo}};
                 for (const auto &a : sc)
-                    HIP_TRY(hipMemcpyAsync(a.first + q0, a.second + q0, sizeof(double) * nq, hipMemcpyHostToDevice, cs));
-                HIP_TRY(hipMemcpyAsync(d.pl + q0, m->plank + q0, (size_t)nq, hipMemcpyHostToDevice, cs));
+                    HIP_TRY(hipMemcpyAsync(a.first + s0, a.second + q0, sizeof(double) * nq, hipMemcpyHostToDevice, cs));
+                HIP_TRY(hipMemcpyAsync(d.pl + s0, m->plank + q0, (size_t)nq, hipMemcpyHostToDevice, cs));
             }
+            MixFamilies fam;
+            for (int t = 0; t < SBD_MIX_MAX_TERMS; ++t) fam.f[t] = m->family[t];
             hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)ns), dim3(64), 0, cs, w0, ns, L, e->cfg.nmom, done ? 1 : 0,
-                               (const int32_t *)d.point_of, (const double *)d.dtaug, (const double *)d.dtaux, (const double *)d.tsc_hg,
-                               (const double *)d.g_hg, (const double *)d.tsc_ray, (const double *)d.lo, (const double *)d.hi,
+                               (int)d.pbase, (int)m->nterm, fam,
+                               (const int32_t *)d.point_of, (const double *)d.dtaug, (const double *)d.lay, (const double *)d.lo, (const double *)d.hi,
                                (const double *)d.fb, (const double *)d.al, (const uint8_t *)d.pl,
                                (double *)in->dtauc, (double *)in->ssalb, (double *)in->pmom, (int32_t *)in->pmom_row,
                                (double *)in->wvnmlo, (double *)in->wvnmhi, (double *)in->fbeam, (double *)in->albedo, (uint8_t *)in->plank);
@@ -1389,25 +1401,30 @@ static int solve_mix_host_enqueue(sbd_engine *e, const sbd_mix_in *m, const sbd_
 {
     if (e->ibcnd) return fail(SBD_E_UNSUPPORTED, "compact batches: not with IBCND = 1");
     if (e->P.ibdrf == 1) return fail(SBD_E_UNSUPPORTED, "compact batches: not with the ocean surface (per-item constants)");
-    if (!m->point_of || !m->dtaug || !m->dtaux || !m->tsc_hg || !m->g_hg || !m->tsc_ray || !m->wvnmlo || !m->wvnmhi
+    if (!m->point_of || !m->dtaug || !m->lay || !m->wvnmlo || !m->wvnmhi
         || !m->fbeam || !m->albedo || !m->plank) return fail(SBD_E_INVALID, "compact batch: null input array");
     if (m->npoint < 1) return fail(SBD_E_INVALID, "compact batch: npoint < 1");
+    if (m->nterm < 0 || m->nterm > SBD_MIX_MAX_TERMS) return fail(SBD_E_INVALID, "compact batch: nterm outside 0..SBD_MIX_MAX_TERMS");
+    for (int t = 0; t < m->nterm; ++t)
+        if (m->family[t] < 1 || m->family[t] > 3) return fail(SBD_E_UNSUPPORTED, "compact batch: phase-function family of a term is not 1, 2 or 3 (tabulated families: arrays form)");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    const size_t W = m->nwork, NP = m->npoint;
+    const size_t W = m->nwork;
     for (size_t i = 0; i < W; ++i) {
         const int32_t p = m->point_of[i];
         if (p < 0 || p >= m->npoint || (i && p < m->point_of[i - 1]))
             return fail(SBD_E_INVALID, "compact batch: point_of must be non-decreasing and inside 0..npoint-1");
     }
+    const int32_t pbase = m->point_of[0];
+    const size_t NP = (size_t)(m->point_of[W - 1] - pbase + 1);      // the point blocks this call's items refer to
     const int L = e->L, nlev = e->nlev;
     const bool rad = !e->cfg.onlyfl;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t b_lay = sizeof(double) * W * L, b_pm = sizeof(double) * NP * L * (e->cfg.nmom + 1), b_w = sizeof(double) * W;
-    const size_t b_play = sizeof(double) * NP * L, b_p = sizeof(double) * NP;
+    const size_t b_blk = sizeof(double) * NP * (size_t)(4 + 3 * m->nterm) * L, b_p = sizeof(double) * NP;
     const size_t b_flux = sizeof(double) * W * SBD_NFLUX * nlev;
     const size_t b_uu = rad ? sizeof(double) * W * e->P.nphi * nlev * e->P.numu : 0;
     const size_t total = 3 * up(b_lay) + up(b_pm) + 5 * up(b_w) + up(W) + up(b_flux) + up(b_uu) + 3 * up(sizeof(int32_t) * W)
-                         + 4 * up(b_play) + 4 * up(b_p) + up(NP);
+                         + up(b_blk) + 4 * up(b_p) + up(NP);
     int rc = ensure_stage(e, total);
     if (rc != SBD_OK) return rc;
     char *p = e->d_stage;
@@ -1422,14 +1439,15 @@ static int solve_mix_host_enqueue(sbd_engine *e, const sbd_mix_in *m, const sbd_
     int32_t *d_row = (int32_t *)take(sizeof(int32_t) * W);
     HostSide hs = {nullptr, nullptr, true};
     hs.mix = m;
+    hs.ms.pbase = pbase;
     hs.ms.point_of = (int32_t *)take(sizeof(int32_t) * W);
     hs.ms.dtaug = (double *)take(b_lay);
-    hs.ms.dtaux = (double *)take(b_play); hs.ms.tsc_hg = (double *)take(b_play); hs.ms.g_hg = (double *)take(b_play); hs.ms.tsc_ray = (double *)take(b_play);
+    hs.ms.lay = (double *)take(b_blk);
     hs.ms.lo = (double *)take(b_p); hs.ms.hi = (double *)take(b_p); hs.ms.fb = (double *)take(b_p); hs.ms.al = (double *)take(b_p);
     hs.ms.pl = (uint8_t *)take(NP);
     hipStream_t st = e->stream;
     if (weight) HIP_TRY(hipMemcpyAsync(d_wt, weight, b_w, hipMemcpyHostToDevice, st));
-    sbd_batch_in din = {m->nwork, d_dt, d_ss, d_pm, d_lo, d_hi, d_fb, d_al, d_pl, nullptr, d_row, m->npoint};
+    sbd_batch_in din = {m->nwork, d_dt, d_ss, d_pm, d_lo, d_hi, d_fb, d_al, d_pl, nullptr, d_row, (int32_t)NP};
     sbd_batch_out dout = {d_flux, d_uu, d_st};
     const size_t w_flux = out->flux ? up(b_flux) : 0, w_uu = (rad && out->uu) ? up(b_uu) : 0, w_st = out->status ? up(sizeof(int32_t) * W) : 0;
     if (w_flux + w_uu + w_st > e->h_pin_bytes) {
@@ -1598,6 +1616,22 @@ void sbd_shard_range(int32_t nwork, int32_t nshard, int32_t rank, int32_t *lo, i
     if (hi) *hi = l + base + (rank < extra ? 1 : 0);
 }
 
+// ... for a batch in compact form: the same balanced item boundaries, each moved UP to the next item that starts a
+// spectral point (point_of non-decreasing), so that the k-terms of a point stay on one device -- which then forms the
+// point's moments once -- and every shard refers to a contiguous range of point blocks disjoint from its neighbours'.
+void sbd_shard_range_points(int32_t nwork, const int32_t *point_of, int32_t nshard, int32_t rank, int32_t *lo, int32_t *hi)
+{
+    auto snap = [&](int32_t i) {
+        if (!point_of) return i;
+        while (i > 0 && i < nwork && point_of[i] == point_of[i - 1]) ++i;
+        return i;
+    };
+    int32_t l = 0, h = 0;
+    sbd_shard_range(nwork, nshard, rank, &l, &h);
+    if (lo) *lo = snap(l);
+    if (hi) *hi = snap(h);
+}
+
 void sbd_fleet_destroy(sbd_fleet *f)
 {
     if (!f) return;
@@ -1649,6 +1683,50 @@ int sbd_fleet_create(const sbd_run_cfg *cfg, int32_t ndev, const int32_t *device
     }
     *out = f;
     return rc_all;
+}
+
+// after every busy device's shard has been enqueued: the one collective of the path -- the sum of the accumulator blocks
+// onto device 0 over xGMI (RCCL), or on the host in device order --, then the per-item outputs pinned buffer -> caller
+static int fleet_finish(sbd_fleet *f, const std::vector<int> &busy, const bool weight, double *acc_flux, double *acc_uu)
+{
+    const int nd = (int)f->eng.size();
+    sbd_engine *e0 = f->eng[0];
+    const int nlev = e0->nlev;
+    const bool rad = !e0->cfg.onlyfl;
+    const size_t nel_f = (size_t)SBD_NFLUX * nlev, nel_u = rad ? (size_t)e0->P.nphi * nlev * e0->P.numu : 0, nel = nel_f + nel_u;
+    if (weight) {
+        if (!f->comm.empty() && (int)busy.size() == nd) {
+            // the one collective of the path: sum of the accumulator blocks onto device 0 over xGMI
+            if (rccl_api().GroupStart() != ncclSuccess) return fail(SBD_E_HIP, "ncclGroupStart");
+            for (int r = 0; r < nd; ++r) {
+                HIP_TRY(hipSetDevice(f->eng[r]->cfg.device));
+                if (rccl_api().Reduce(f->eng[r]->d_acc, f->eng[r]->d_red, nel, ncclDouble, ncclSum, 0, f->comm[r], f->eng[r]->stream) != ncclSuccess)
+                    return fail(SBD_E_HIP, "ncclReduce");
+            }
+            if (rccl_api().GroupEnd() != ncclSuccess) return fail(SBD_E_HIP, "ncclGroupEnd");
+            f->hacc.assign(nel, 0.0);
+            HIP_TRY(hipSetDevice(e0->cfg.device));
+            HIP_TRY(hipMemcpyAsync(f->hacc.data(), e0->d_red, sizeof(double) * nel, hipMemcpyDeviceToHost, e0->stream));
+            for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); deliver_host_outputs(f->eng[r]); }
+            for (size_t i = 0; i < nel_f; ++i) acc_flux[i] += f->hacc[i];
+            if (acc_uu) for (size_t i = 0; i < nel_u; ++i) acc_uu[i] += f->hacc[nel_f + i];
+        } else {
+            f->hacc.assign((size_t)nd * nel, 0.0);
+            for (int r : busy) {
+                HIP_TRY(hipSetDevice(f->eng[r]->cfg.device));
+                HIP_TRY(hipMemcpyAsync(f->hacc.data() + (size_t)r * nel, f->eng[r]->d_acc, sizeof(double) * nel, hipMemcpyDeviceToHost, f->eng[r]->stream));
+            }
+            for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); deliver_host_outputs(f->eng[r]); }
+            for (int r : busy) {   // fixed order: device 0's block first
+                const double *h = f->hacc.data() + (size_t)r * nel;
+                for (size_t i = 0; i < nel_f; ++i) acc_flux[i] += h[i];
+                if (acc_uu) for (size_t i = 0; i < nel_u; ++i) acc_uu[i] += h[nel_f + i];
+            }
+        }
+    } else {
+        for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); deliver_host_outputs(f->eng[r]); }
+    }
+    return SBD_OK;
 }
 
 int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_out *out,
@@ -1749,66 +1827,82 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
                 return fail(rcs[r], errs[r]);
             }
     }
-    if (weight) {
-        if (!f->comm.empty() && (int)busy.size() == nd) {
-            // the one collective of the path: sum of the accumulator blocks onto device 0 over xGMI
-            if (rccl_api().GroupStart() != ncclSuccess) return fail(SBD_E_HIP, "ncclGroupStart");
-            for (int r = 0; r < nd; ++r) {
-                HIP_TRY(hipSetDevice(f->eng[r]->cfg.device));
-                if (rccl_api().Reduce(f->eng[r]->d_acc, f->eng[r]->d_red, nel, ncclDouble, ncclSum, 0, f->comm[r], f->eng[r]->stream) != ncclSuccess)
-                    return fail(SBD_E_HIP, "ncclReduce");
-            }
-            if (rccl_api().GroupEnd() != ncclSuccess) return fail(SBD_E_HIP, "ncclGroupEnd");
-            f->hacc.assign(nel, 0.0);
-            HIP_TRY(hipSetDevice(e0->cfg.device));
-            HIP_TRY(hipMemcpyAsync(f->hacc.data(), e0->d_red, sizeof(double) * nel, hipMemcpyDeviceToHost, e0->stream));
-            for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); deliver_host_outputs(f->eng[r]); }
-            for (size_t i = 0; i < nel_f; ++i) acc_flux[i] += f->hacc[i];
-            if (acc_uu) for (size_t i = 0; i < nel_u; ++i) acc_uu[i] += f->hacc[nel_f + i];
-        } else {
-            f->hacc.assign((size_t)nd * nel, 0.0);
-            for (int r : busy) {
-                HIP_TRY(hipSetDevice(f->eng[r]->cfg.device));
-                HIP_TRY(hipMemcpyAsync(f->hacc.data() + (size_t)r * nel, f->eng[r]->d_acc, sizeof(double) * nel, hipMemcpyDeviceToHost, f->eng[r]->stream));
-            }
-            for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); deliver_host_outputs(f->eng[r]); }
-            for (int r : busy) {   // fixed order: device 0's block first
-                const double *h = f->hacc.data() + (size_t)r * nel;
-                for (size_t i = 0; i < nel_f; ++i) acc_flux[i] += h[i];
-                if (acc_uu) for (size_t i = 0; i < nel_u; ++i) acc_uu[i] += h[nel_f + i];
-            }
-        }
-    } else {
-        for (int r : busy) { HIP_TRY(hipSetDevice(f->eng[r]->cfg.device)); HIP_TRY(hipStreamSynchronize(f->eng[r]->stream)); deliver_host_outputs(f->eng[r]); }
-    }
-    return SBD_OK;
+    return fleet_finish(f, busy, weight != nullptr, acc_flux, acc_uu);
 }
 
 int sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_batch_out *out,
                              const double *weight, double *acc_flux, double *acc_uu)
 {
-    if (!f || !in || !out) return fail(SBD_E_INVALID, "null argument");
+    if (!f || !in || !out || f->eng.empty()) return fail(SBD_E_INVALID, "null argument");
     if (in->nwork <= 0) return in->nwork == 0 ? SBD_OK : fail(SBD_E_INVALID, "nwork < 0");
     if (!out->status) return fail(SBD_E_INVALID, "status is NULL");
     if (weight && !acc_flux) return fail(SBD_E_INVALID, "acc_flux is NULL");
-    if (f->eng.size() != 1) return fail(SBD_E_UNSUPPORTED, "compact batches: a fleet of one device (shards must cut between spectral points)");
-    sbd_engine *e = f->eng[0];
-    const int nlev = e->nlev;
-    const bool rad = !e->cfg.onlyfl;
-    const size_t nel_f = (size_t)SBD_NFLUX * nlev, nel_u = rad ? (size_t)e->P.nphi * nlev * e->P.numu : 0, nel = nel_f + nel_u;
-    int rc = solve_mix_host_enqueue(e, in, out, weight);
-    if (rc != SBD_OK) { (void)hipStreamSynchronize(e->stream); return rc; }
-    if (weight) {
-        f->hacc.assign(nel, 0.0);
-        HIP_TRY(hipMemcpyAsync(f->hacc.data(), e->d_acc, sizeof(double) * nel, hipMemcpyDeviceToHost, e->stream));
+    if (!in->point_of) return fail(SBD_E_INVALID, "compact batch: null input array");
+    const int nd = (int)f->eng.size();
+    sbd_engine *e0 = f->eng[0];
+    const int L = e0->L, nlev = e0->nlev;
+    const bool rad = !e0->cfg.onlyfl;
+    const size_t nel_f = (size_t)SBD_NFLUX * nlev;
+    const size_t uu_item = rad ? (size_t)e0->P.nphi * nlev * e0->P.numu : 0;
+    for (int32_t i = 1; i < in->nwork; ++i)          // (the cut rule below needs it; every shard checks its own range again)
+        if (in->point_of[i] < in->point_of[i - 1]) return fail(SBD_E_INVALID, "compact batch: point_of must be non-decreasing and inside 0..npoint-1");
+    // shards cut between spectral points (sbd_shard_range_points): neighbours share no point block
+    std::vector<int> busy;
+    std::vector<int32_t> slo(nd), shi(nd);
+    for (int r = 0; r < nd; ++r) {
+        sbd_shard_range_points(in->nwork, in->point_of, nd, r, &slo[r], &shi[r]);
+        if (shi[r] > slo[r]) busy.push_back(r);
     }
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    deliver_host_outputs(e);
-    if (weight) {
-        for (size_t i = 0; i < nel_f; ++i) acc_flux[i] += f->hacc[i];
-        if (acc_uu) for (size_t i = 0; i < nel_u; ++i) acc_uu[i] += f->hacc[nel_f + i];
+    struct PinGuard {
+        std::vector<void *> p;
+        ~PinGuard() { for (void *x : p) (void)hipHostUnregister(x); }
+    } pins;
+    {
+        const char *pe = getenv("SBD_PIN_INPUTS");
+        const size_t big = sizeof(double) * (size_t)in->nwork * L;
+        const bool pin = pe ? atoi(pe) != 0 : (busy.size() > 1 && big >= ((size_t)32 << 20));
+        if (pin && in->dtaug && in->lay) {
+            const std::pair<const void *, size_t> arr[2] = {{in->dtaug, big},
+                                                            {in->lay, sizeof(double) * (size_t)in->npoint * (4 + 3 * (in->nterm > 0 ? in->nterm : 0)) * L}};
+            for (const auto &a : arr) {
+                if (hipHostRegister((void *)a.first, a.second, hipHostRegisterPortable) == hipSuccess) pins.p.push_back((void *)a.first);
+                else (void)hipGetLastError();
+            }
+        }
+        f->pinned_last = (int)pins.p.size();
     }
-    return SBD_OK;
+    f->t_enq.assign((size_t)nd * 2, 0.0);
+    {
+        const auto t_begin = std::chrono::steady_clock::now();
+        std::vector<int> rcs(nd, SBD_OK);
+        std::vector<std::string> errs(nd);
+        auto enqueue = [&](const int r) {
+            const int32_t lo = slo[r], hi = shi[r];
+            sbd_mix_in si = *in;                                     // (point blocks by their GLOBAL index: the engine stages the range its items refer to)
+            si.nwork = hi - lo;
+            si.point_of = in->point_of + lo;
+            si.dtaug = in->dtaug ? in->dtaug + (size_t)lo * L : nullptr;
+            sbd_batch_out so = {out->flux ? out->flux + (size_t)lo * nel_f : nullptr,
+                                (rad && out->uu) ? out->uu + (size_t)lo * uu_item : nullptr, out->status + lo, nullptr};
+            f->t_enq[2 * r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+            rcs[r] = solve_mix_host_enqueue(f->eng[r], &si, &so, weight ? weight + lo : nullptr);
+            if (rcs[r] != SBD_OK) errs[r] = g_last_error;
+            f->t_enq[2 * r + 1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        };
+        if (busy.size() > 1) {
+            std::vector<std::thread> th;
+            for (int r : busy) th.emplace_back(enqueue, r);
+            for (auto &t : th) t.join();
+        } else if (!busy.empty()) {
+            enqueue(busy[0]);
+        }
+        for (int r : busy)
+            if (rcs[r] != SBD_OK) {
+                for (int q : busy) { (void)hipSetDevice(f->eng[q]->cfg.device); (void)hipStreamSynchronize(f->eng[q]->stream); }
+                return fail(rcs[r], errs[r]);
+            }
+    }
+    return fleet_finish(f, busy, weight != nullptr, acc_flux, acc_uu);
 }
 
 // host clock around device i's enqueue in the last sbd_fleet_solve_host (seconds since that call began), and how

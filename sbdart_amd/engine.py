@@ -343,26 +343,29 @@ class DisortFleet(DisortEngine):
             return flux, uu, status
         return flux, uu, status, acc_f, acc_u
 
-    def solve_mix(self, point_of, dtaug, dtaux, tsc_hg, g_hg, tsc_ray, wvnmlo, wvnmhi, fbeam, albedo, plank,
-                  weight=None, items=True):
-        """A batch in COMPACT form (sbd_mix_in, include/sbdart_amd.h): per spectral point the scatterers, per work item
-        the gas of its k-term; DTAUC / SSALB / PMOM are formed on the device (what depthscl, GETMOM and normom do on
-        the host: taugas.f:7625-7646, disutil.f:2176-2188, drt.f:1366-1397).  Same returns as `solve`."""
-        from ._lib import MixIn
+    def solve_mix(self, point_of, dtaug, lay, family, wvnmlo, wvnmhi, fbeam, albedo, plank, weight=None, items=True):
+        """A batch in COMPACT form (sbd_mix_in, include/sbdart_amd.h): per spectral point a block lay[point] of
+        [4 + 3 nterm][nlyr] doubles (dtauc, dtaua, dtaur, tsc, then g, m1, m2 of every scattering term; `family` =
+        GETMOM's iphas per term), per work item the gas of its k-term; DTAUC / SSALB / PMOM are formed on the device
+        (what depthscl, GETMOM, taucloud / tauaero and normom do on the host: taugas.f:7598-7603, disutil.f:2104-2209,
+        drt.f:1390-1395).  A fleet of several devices cuts the batch between spectral points.  Same returns as `solve`."""
+        from ._lib import MIX_MAX_TERMS, MixIn
         rows = np.ascontiguousarray(point_of, dtype=np.int32)
         W = rows.shape[0]
         dtaug = _f64(dtaug)
-        dtaux, tsc_hg, g_hg, tsc_ray = (_f64(x) for x in (dtaux, tsc_hg, g_hg, tsc_ray))
-        NP = dtaux.shape[0]
-        assert dtaug.shape == (W, self.nlyr) and all(x.shape == (NP, self.nlyr) for x in (dtaux, tsc_hg, g_hg, tsc_ray))
+        lay = _f64(lay)
+        family = [int(x) for x in family]
+        nterm = len(family)
+        NP = lay.shape[0]
+        assert dtaug.shape == (W, self.nlyr) and lay.shape == (NP, 4 + 3 * nterm, self.nlyr) and nterm <= MIX_MAX_TERMS
         lo, hi, fb, al = (_f64(np.broadcast_to(x, (NP,))) for x in (wvnmlo, wvnmhi, fbeam, albedo))
         pl = np.ascontiguousarray(np.broadcast_to(plank, (NP,)), dtype=np.uint8)
         flux = np.zeros((W, _lib.NFLUX, self.nlev)) if items else None
         uu = None if (self.onlyfl or not items) else np.zeros((W, self.nphi, self.nlev, self.numu))
         status = np.zeros(W, dtype=np.int32)
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
-        mi = MixIn(W, NP, vp(rows), vp(dtaug), vp(dtaux), vp(tsc_hg), vp(g_hg), vp(tsc_ray), vp(lo), vp(hi), vp(fb),
-                   vp(al), vp(pl))
+        fam = (C.c_int32 * MIX_MAX_TERMS)(*(family + [0] * (MIX_MAX_TERMS - nterm)))
+        mi = MixIn(W, NP, vp(rows), vp(dtaug), nterm, fam, vp(lay), vp(lo), vp(hi), vp(fb), vp(al), vp(pl))
         bo = BatchOut(vp(flux), vp(uu), vp(status))
         acc_f = acc_u = None
         if weight is not None:

@@ -17,7 +17,7 @@ module sbd_aerosol_mod
   use sbd_cloud_mod, only: phase_moments, layers_of_altitudes
   implicit none
   private
-  public :: aerosol_input, aerosol_load, new_aerosol_load, aerosol_depths, naerz, naerb, plan_aerosol_file
+  public :: aerosol_input, aerosol_load, new_aerosol_load, aerosol_depths, naerz, naerb, plan_aerosol_file, aerosol_terms
 
   integer, parameter :: naerz = 5, naerb = 150, naerw = 47
   real(kr), parameter :: wl55 = 0.55
@@ -476,16 +476,49 @@ contains
     end subroutine
   end subroutine
 
-  subroutine aerosol_depths(a, wl, nz, nmom, dtaua, waer, pmom, iw)
+  ! The run's aerosols as scattering terms of the compact batch form (include/sbdart_amd.h, sbd_mix_in): slot 1 the
+  ! boundary layer's (family = IMOMA) when there is one, then one slot per active stratospheric layer (Henyey-
+  ! Greenstein).  ok = .false.: moments that are not a function of one asymmetry factor (aerosol.dat, the user's own
+  ! moments) -- such runs keep the arrays form.
+  subroutine aerosol_terms(a, nterm, family, ok)
+    type(aerosol_load), intent(in) :: a
+    integer, intent(out) :: nterm, family(:)
+    logical, intent(out) :: ok
+    integer :: i
+    nterm = 0; family = 0
+    ok = a%iaer /= -1
+    if (a%iaer /= 0 .and. a%iaer /= -1) then
+      ok = a%imoma >= 1 .and. a%imoma <= 3
+      nterm = 1
+      family(1) = a%imoma
+    end if
+    do i = 1, a%nstrat
+      if (a%jaer(i) /= 0 .and. a%taerst(i) > 0.) then
+        nterm = nterm + 1
+        if (nterm > size(family)) then
+          ok = .false.
+          return
+        end if
+        family(nterm) = 3
+      end if
+    end do
+  end subroutine
+
+  ! trm (optional, slots as aerosol_terms counts them): per layer and slot the asymmetry factor and the two factors
+  ! the term's moments are multiplied with, in the reference's order: PM*DTAUA*WAER (tauaero.f:1300), PM*DT*WA (1330)
+  subroutine aerosol_depths(a, wl, nz, nmom, dtaua, waer, pmom, iw, trm)
     type(aerosol_load), intent(in) :: a
     real(kr), intent(in) :: wl
     integer, intent(in) :: nz, nmom
     real(kr), intent(out) :: dtaua(nz), waer(nz)
     real(kr), intent(inout) :: pmom(0:nmom, nz)
     integer, intent(in), optional :: iw                  ! index of wl among the run's wavelengths (aerosol.dat)
+    real(kr), intent(out), optional :: trm(:, :, :)      ! (nz, 3, slots)
     real(kr) :: pm(0:nmom), extinc, wa, ga, dt, wt, ta, tb, gg
-    integer :: i, j, nl, namom, l, ia, ib, k
+    integer :: i, j, nl, namom, l, ia, ib, k, slot
     dtaua = 0.; waer = 0.
+    slot = 0
+    if (present(trm)) trm = 0.
     if (a%iaer == -1) then
       ! layers nz-nn+1 .. nz from the file (the layers above them: nothing; the reference leaves them unset);
       ! depth log-log between the two sets where both are positive, everything else linear in the weight
@@ -539,6 +572,10 @@ contains
           pmom(j, i) = pmom(j, i) + pm(j)*dtaua(i)*waer(i)
         end do
       end do
+      slot = 1
+      if (present(trm)) then
+        trm(:, 1, 1) = ga; trm(:, 2, 1) = dtaua; trm(:, 3, 1) = waer
+      end if
     end if
     do i = 1, a%nstrat
       if (a%jaer(i) /= 0 .and. a%taerst(i) > 0.) then
@@ -549,6 +586,10 @@ contains
         do j = 1, nmom
           pmom(j, nl) = pmom(j, nl) + pm(j)*dt*wa
         end do
+        slot = slot + 1
+        if (present(trm)) then
+          trm(nl, 1, slot) = ga; trm(nl, 2, slot) = dt; trm(nl, 3, slot) = wa
+        end if
         waer(nl) = (waer(nl)*dtaua(nl) + wa*dt)/(dtaua(nl) + dt)
         dtaua(nl) = dtaua(nl) + dt
       end if

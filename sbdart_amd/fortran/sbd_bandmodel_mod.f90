@@ -18,7 +18,8 @@ module sbd_bandmodel_mod
   use omp_lib, only: omp_get_max_threads
   implicit none
   private
-  public :: model_input, covered_by_band_model, build_work_items, aerosol_input, gas_depth_report, corint_history
+  public :: model_input, covered_by_band_model, build_work_items, aerosol_input, gas_depth_report, corint_history, &
+            mix_batch, mix_max_terms, assemble_item
   integer, parameter :: maxmom_all = 299               ! params.f:10
 
   type model_input                     ! the &INPUT variables this step reads, same names
@@ -36,7 +37,51 @@ module sbd_bandmodel_mod
     integer :: numu = 0, nphi = 0
   end type
 
+  ! The run's work items in the COMPACT form of the engine's C ABI (include/sbdart_amd.h, sbd_mix_in): per spectral
+  ! point a block lay(:, :, point) -- cloud, aerosol and Rayleigh depths, their scattering depth, then asymmetry factor
+  ! and the two factors of every scattering term (slot 1 the cloud when the run has one, then the aerosol_terms) --
+  ! and per work item only the gas absorption of its k-term.  The engine forms DTAUC / SSALB / PMOM from these on the
+  ! device, statement for statement what depthscl and normom do (taugas.f:7598-7603, drt.f:1390-1395).
+  integer, parameter :: mix_max_terms = 6                 ! SBD_MIX_MAX_TERMS
+  type mix_batch
+    logical :: want = .false.                             ! in: the caller can use the compact form
+    logical :: ok = .false.                               ! out: the run fits it, and the arrays below are the run's
+    character(len=96) :: why = ''                         ! ... or why not
+    integer :: nterm = 0, family(mix_max_terms) = 0
+    real(kr), allocatable :: lay(:, :, :)                 ! (nz, 4 + 3 nterm, npoint)
+  end type
+
 contains
+
+  ! DTAUC, SSALB and the moments of one work item from its compact form -- the host-side twin of the engine's
+  ! assemble_kernel, for the rare paths that want the numbers on the host (CHEKIN's report on a bad item)
+  subroutine assemble_item(mix, ipoint, dtaug, nmom, dtau, wreal, pmom)
+    type(mix_batch), intent(in) :: mix
+    integer, intent(in) :: ipoint, nmom
+    real(kr), intent(in) :: dtaug(:)
+    real(kr), intent(out) :: dtau(:), wreal(:), pmom(0:, :)
+    real(kr) :: q, pk, dtsct
+    integer :: l, k, t
+    do l = 1, size(dtaug)
+      dtau(l) = dtaug(l) + mix%lay(l, 1, ipoint) + mix%lay(l, 2, ipoint) + mix%lay(l, 3, ipoint)
+      dtsct = mix%lay(l, 4, ipoint)
+      wreal(l) = 0.
+      if (dtau(l) > tiny(1._kr)) wreal(l) = dtsct/dtau(l)
+      pmom(0, l) = 1.
+      do k = 1, nmom
+        q = 0.
+        do t = 1, mix%nterm
+          pk = 0.
+          if (mix%family(t) == 3) pk = mix%lay(l, 2 + 3*t, ipoint)**k
+          if (mix%family(t) == 2 .and. k == 2) pk = .1
+          q = q + pk*mix%lay(l, 3 + 3*t, ipoint)*mix%lay(l, 4 + 3*t, ipoint)
+        end do
+        if (k == 2) q = q + .1*mix%lay(l, 3, ipoint)
+        if (dtsct /= 0.) q = q/dtsct
+        pmom(k, l) = q
+      end do
+    end do
+  end subroutine
 
   ! .true. when every switch of the run is inside the first slice; otherwise why not
   logical function covered_by_band_model(m, why) result(ok)
@@ -235,10 +280,13 @@ contains
   ! are independent of each other (the reference's saved state is replaced by values prepared once per run), so
   ! the loop over them is an OpenMP parallel loop: every wavelength fills its own MK slots, a second parallel
   ! loop closes the slots up.  No allocation inside the loops.
-  subroutine build_work_items(m, grid, umu, phi, recs, nrec, atm, bdtauc, bssalb, bpmom, btemper, ck)
+  subroutine build_work_items(m, grid, umu, phi, recs, nrec, atm, bdtauc, bssalb, bpmom, btemper, ck, mixb)
     type(model_input), intent(in) :: m
     type(spectral_grid), intent(in) :: grid
     type(ck_file), intent(in), optional :: ck           ! KDIST = -1: the k-distribution file pair; `grid` is its band list
+    ! mixb%want: hand the items over in compact form when the run fits it (mixb%ok): bdtauc then holds the GAS depth of
+    ! every item, bssalb and bpmom stay empty, mixb%lay holds the spectral points' blocks
+    type(mix_batch), intent(inout), optional :: mixb
     real(kr), intent(in) :: umu(:), phi(:)
     type(optics_t), allocatable, intent(out) :: recs(:)
     integer, intent(out) :: nrec
@@ -258,7 +306,8 @@ contains
     real(kr), parameter :: dtor = 3.1415926536_kr/180.
     integer :: nz, nmom, iwl, kd, i
     integer :: nthreads, mkt
-    logical :: from_ck
+    logical :: from_ck, compact, aer_ok
+    integer :: ncloud_term, naer_term, aer_family(mix_max_terms), nch
 
     ! ---- once per run: profiles, rescaling, absorber amounts, clouds, aerosols, surface (drt.f:297-423) ----
     from_ck = m%kdist == -1
@@ -335,10 +384,50 @@ contains
       call plan_aerosol_file(load, run_wl)
     end if
 
+    ! ---- does the run fit the compact form?  (every scatterer one term GETMOM(family, g) x two factors) ----
+    compact = .false.
+    ncloud_term = 0; naer_term = 0; nch = 4
+    call aerosol_terms(load, naer_term, aer_family, aer_ok)      ! (also sizes the term recorder of every wavelength)
+    if (deck%nslot > 0 .or. lcloud%given) ncloud_term = 1
+    if (present(mixb)) then
+      mixb%ok = .false.; mixb%why = ''
+      if (mixb%want) then
+        if (m%radiance .and. m%corint) then
+          mixb%why = 'intensity corrections (299 moments, CORINT history on the host)'
+        else if (m%spowder) then
+          mixb%why = 'SPOWDER (normom and depthscl see different Rayleigh depths in the sub-surface layer)'
+        else if (surf%ibdrf == 1 .and. .not. surf%as_albedo) then
+          mixb%why = 'ocean surface (per-item constants)'
+        else if (ncloud_term == 1 .and. (m%imomc < 1 .or. m%imomc > 3)) then
+          mixb%why = 'tabulated cloud phase function (imomc)'
+        else if (deck%nslot > 0 .and. .not. one_cloud_per_layer(deck, nz)) then
+          mixb%why = 'two clouds in one layer'
+        else if (.not. aer_ok) then
+          mixb%why = 'aerosol moments that are not a function of one asymmetry factor'
+        else if (ncloud_term + naer_term > mix_max_terms) then
+          mixb%why = 'more scattering terms per layer than the compact form holds'
+        else
+          compact = .true.
+          mixb%ok = .true.
+          mixb%nterm = ncloud_term + naer_term
+          mixb%family = 0
+          if (ncloud_term == 1) mixb%family(1) = m%imomc
+          mixb%family(ncloud_term + 1:ncloud_term + naer_term) = aer_family(1:naer_term)
+          nch = 4 + 3*mixb%nterm
+          if (allocated(mixb%lay)) deallocate(mixb%lay)
+          allocate(mixb%lay(nz, nch, grid%n))
+        end if
+      end if
+    end if
+
     ! (the phase-function moments belong to the WAVELENGTH: one block per spectral point, shared by its k-terms --
     !  drt.f:476-533 computes them before the k loop -- and handed to the engine that way, sbd_batch_in%pmom_row)
-    allocate(bpmom(0:nmom, nz, grid%n))
-    allocate(nk_of(grid%n), first(grid%n), sd(nz, mkt*grid%n), ss(nz, mkt*grid%n), &
+    if (compact) then
+      allocate(bpmom(0:0, 1, 1))
+    else
+      allocate(bpmom(0:nmom, nz, grid%n))
+    end if
+    allocate(nk_of(grid%n), first(grid%n), sd(nz, mkt*grid%n), ss(nz, merge(1, mkt*grid%n, compact)), &
              swt(mkt, grid%n), swl(grid%n), slo(grid%n), shi(grid%n), sfb(grid%n), salb(grid%n), splank(grid%n), &
              sbit(4, grid%n))
     sbit = 0
@@ -356,14 +445,14 @@ contains
       first(iwl) = nrec + 1
       nrec = nrec + nk_of(iwl)
     end do
-    allocate(recs(nrec), bdtauc(nz, nrec), bssalb(nz, nrec), btemper(0:nz))
+    allocate(recs(nrec), bdtauc(nz, nrec), bssalb(nz, merge(1, nrec, compact)), btemper(0:nz))
     btemper = temper
     !$omp parallel do schedule(static) num_threads(nthreads) private(kd, i)
     do iwl = 1, grid%n
       do kd = 1, nk_of(iwl)
         i = first(iwl) + kd - 1
         bdtauc(:, i) = sd(:, mkt*(iwl - 1) + kd)
-        bssalb(:, i) = ss(:, mkt*(iwl - 1) + kd)
+        if (.not. compact) bssalb(:, i) = ss(:, mkt*(iwl - 1) + kd)
         recs(i)%nlyr = nz; recs(i)%nstr = m%nstr; recs(i)%nmom = nmom; recs(i)%numu = size(umu); recs(i)%nphi = size(phi)
         recs(i)%flags = merge(1, 0, splank(iwl)) + merge(0, 2, m%radiance) + merge(16, 0, m%radiance .and. m%corint)
         recs(i)%kd = kd; recs(i)%nk = nk_of(iwl); recs(i)%iwl = iwl
@@ -387,7 +476,9 @@ contains
       integer, intent(in) :: iw
       type(gas_spectrum) :: spec
       real(kr) :: dtaur(nz), dtauk(nz, 2*max(mk, mkt)), dtaugc(nz), dtaug(nz), scat(nz), dtauc(nz), wcld(nz), &
-                  pmom(0:nmom, nz), dtaua(nz), waer(nz)
+                  pmom(0:merge(2, nmom, compact), nz), dtaua(nz), waer(nz)
+      real(kr) :: trm_c(nz, 3), trm_a(nz, 3, naerz + 1)      ! (boundary layer + every stratospheric layer)
+      integer :: nmw
       real(kr) :: wl, wvlo, wvhi, dwl, flxin, rsfc, gwk(max(mk, mkt)), wt, tsc, tglv, tgls, afac, ramp, amu_gas, amu_sun
       integer :: nk, k, l
       logical :: plank
@@ -448,18 +539,32 @@ contains
       ! moment x scattering depth, Rayleigh 0.1 in the second moment; normalised by the total (drt.f:1366-1380)
       pmom = 0.
       dtauc = 0.; wcld = 0.
+      ! (compact form: the scatterers leave as terms -- asymmetry factor and factors -- and no moment is formed here:
+      !  the routines run with two moments, GETMOM's Rayleigh family writes the second)
+      nmw = merge(2, nmom, compact)
+      trm_c = 0.
       if (deck%nslot > 0) then
-        call cloud_depths(deck, wl, nz, nmom, dtauc, wcld, pmom)
+        call cloud_depths(deck, wl, nz, nmw, dtauc, wcld, pmom, trm_c)
       else if (lcloud%given) then
-        call layer_cloud_depths(lcloud, m%imomc, wl, nz, nmom, dtauc, wcld, pmom)
+        call layer_cloud_depths(lcloud, m%imomc, wl, nz, nmw, dtauc, wcld, pmom, trm_c)
       end if
-      call aerosol_depths(load, wl, nz, nmom, dtaua, waer, pmom, iw)
+      call aerosol_depths(load, wl, nz, nmw, dtaua, waer, pmom, iw, trm_a)
       do l = 1, nz
-        pmom(2, l) = pmom(2, l) + .1*dtaur(l)
         scat(l) = dtauc(l)*wcld(l) + dtaua(l)*waer(l) + dtaur(l)
-        if (scat(l) /= 0.) pmom(:, l) = pmom(:, l)/scat(l)
       end do
-      pmom(0, :) = 1.
+      if (compact) then
+        mixb%lay(:, 1, iw) = dtauc; mixb%lay(:, 2, iw) = dtaua; mixb%lay(:, 3, iw) = dtaur; mixb%lay(:, 4, iw) = scat
+        if (ncloud_term == 1) mixb%lay(:, 5:7, iw) = trm_c
+        do k = 1, naer_term
+          mixb%lay(:, 5 + 3*(ncloud_term + k - 1):7 + 3*(ncloud_term + k - 1), iw) = trm_a(:, :, k)
+        end do
+      else
+        do l = 1, nz
+          pmom(2, l) = pmom(2, l) + .1*dtaur(l)
+          if (scat(l) /= 0.) pmom(:, l) = pmom(:, l)/scat(l)
+        end do
+        pmom(0, :) = 1.
+      end if
 
       nk_of(iw) = nk
       swl(iw) = wl; slo(iw) = wvlo; shi(iw) = wvhi; sfb(iw) = flxin; salb(iw) = rsfc; splank(iw) = plank
@@ -497,6 +602,10 @@ contains
         if (m%spowder) dtaug(nz) = 0.
         ! ---- the work item's layer arrays ----
         swt(k, iw) = wt
+        if (compact) then
+          sd(:, mkt*(iw - 1) + k) = dtaug                       ! (the gas alone: the device adds the point's scatterers)
+          cycle
+        end if
         if (k == 1) bpmom(:, :, iw) = pmom
         do l = 1, nz
           sd(l, mkt*(iw - 1) + k) = dtaug(l) + dtauc(l) + dtaua(l) + dtaur(l)

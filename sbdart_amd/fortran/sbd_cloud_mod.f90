@@ -10,7 +10,7 @@ module sbd_cloud_mod
   implicit none
   private
   public :: cloud_deck, new_cloud_deck, cloud_depths, phase_moments, layers_of_altitudes, ncldz, cloud_tables_init, &
-            layer_clouds, read_layer_clouds, layer_cloud_depths
+            layer_clouds, read_layer_clouds, layer_cloud_depths, one_cloud_per_layer
 
   integer, parameter :: ncldz = 5                    ! cloud slots (params.f:12)
   real(kr), parameter :: wl55 = 0.55                 ! wavelength TCLOUD is quoted at (params.f:27)
@@ -66,12 +66,15 @@ contains
     close(u)
   end function
 
-  subroutine layer_cloud_depths(c, imomc, wl, nz, nmom, taucld, wcld, pmom)
+  ! trm (optional): the layer's cloud as ONE scattering term of the compact batch form (include/sbdart_amd.h,
+  ! sbd_mix_in): asymmetry factor, TAUCLD*WCLD, 1 -- what the device multiplies GETMOM's moments with, in this order
+  subroutine layer_cloud_depths(c, imomc, wl, nz, nmom, taucld, wcld, pmom, trm)
     type(layer_clouds), intent(in) :: c
     integer, intent(in) :: imomc, nz, nmom
     real(kr), intent(in) :: wl
     real(kr), intent(out) :: taucld(nz), wcld(nz)
     real(kr), intent(inout) :: pmom(0:nmom, nz)
+    real(kr), intent(out), optional :: trm(nz, 3)
     real(kr) :: qw, ww, gw, tauw
     integer :: i, j
     if (imomc < 0) then
@@ -79,6 +82,7 @@ contains
       stop
     end if
     taucld = 0.; wcld = 0.
+    if (present(trm)) trm = 0.
     do i = 1, nz
       tauw = 0.
       if (c%lwp(i) > 0.) then
@@ -89,11 +93,17 @@ contains
       if (taucld(i) /= 0.) then
         wcld(i) = (tauw*ww)/taucld(i)
         call phase_moments(imomc, (tauw*gw)/taucld(i), nmom, pmom(:, i))
+        if (present(trm)) trm(i, 1) = (tauw*gw)/taucld(i)
       end if
       taucld(i) = taucld(i)*c%frac(i)**1.5
       do j = 1, nmom
         pmom(j, i) = taucld(i)*wcld(i)*pmom(j, i)
       end do
+      if (present(trm)) then
+        if (tauw /= 0.) then
+          trm(i, 2) = taucld(i)*wcld(i); trm(i, 3) = 1.
+        end if
+      end if
     end do
   end subroutine
 
@@ -200,18 +210,45 @@ contains
     end select
   end subroutine
 
+  ! .true. when no layer holds more than one of the deck's clouds (the same walk as cloud_depths): a layer's cloud
+  ! is then one scattering term TAUCLD*WCLD*PMOM (taucloud.f:132 with ICNT = 1) and the run's batches can go to the
+  ! engine in compact form; two clouds in a layer average their moments first -- those runs keep the arrays form
+  logical function one_cloud_per_layer(c, nz) result(single)
+    type(cloud_deck), intent(in) :: c
+    integer, intent(in) :: nz
+    integer :: cnt(nz), i, j, lbot, ltop
+    cnt = 0
+    do i = 1, c%nslot
+      if (c%layer(i) <= 0) cycle
+      lbot = c%layer(i)
+      ltop = lbot
+      if (i /= ncldz) then
+        if (c%layer(i + 1) < 0) ltop = -c%layer(i + 1)
+      end if
+      if (c%tcloud(i) == 0. .and. c%lwp(i) == 0.) cycle
+      do j = ltop, lbot
+        cnt(j) = cnt(j) + 1
+      end do
+    end do
+    single = all(cnt <= 1)
+  end function
+
   ! optical depth, single-scattering albedo of the cloud in every layer at wavelength wl, and the cloud's
   ! part of the un-normalised phase-function moments (moment x scattering optical depth) ADDED to pmom
-  subroutine cloud_depths(c, wl, nz, nmom, taucld, wcld, pmom)
+  ! trm (optional; a deck with one_cloud_per_layer): the layer's cloud as ONE scattering term of the compact batch form
+  ! (include/sbdart_amd.h, sbd_mix_in): asymmetry factor, TAUCLD*WCLD, 1
+  subroutine cloud_depths(c, wl, nz, nmom, taucld, wcld, pmom, trm)
     type(cloud_deck), intent(in) :: c
     real(kr), intent(in) :: wl
     integer, intent(in) :: nz, nmom
     real(kr), intent(out) :: taucld(nz), wcld(nz)
     real(kr), intent(inout) :: pmom(0:nmom, nz)
+    real(kr), intent(out), optional :: trm(nz, 3)
     real(kr), parameter :: rhoice = .917
     real(kr) :: pm(0:nmom), reff, tcld, lwpth, wt, qc, wc, gc, q550, w550, g550
     integer :: cnt(nz), i, j, k, lbot, ltop
     taucld = 0.; wcld = 0.; cnt = 0
+    if (present(trm)) trm = 0.
     do i = 1, c%nslot
       if (c%layer(i) <= 0) cycle                      ! not the base of a cloud
       lbot = c%layer(i)
@@ -232,6 +269,7 @@ contains
         call mie_lookup(wl, reff, qc, wc, gc)
         call phase_moments(c%imomc, gc, nmom, pm)
         pmom(1:nmom, j) = pm(1:nmom) + pmom(1:nmom, j)
+        if (present(trm)) trm(j, 1) = gc
         wcld(j) = wc + wcld(j)
         cnt(j) = 1 + cnt(j)
         if (c%tcloud(i) /= 0.) then                   ! optical depth given at 0.55 um: scale with the efficiency
@@ -252,6 +290,9 @@ contains
         do k = 1, nmom
           pmom(k, j) = taucld(j)*wcld(j)*pmom(k, j)/cnt(j)
         end do
+        if (present(trm)) then
+          trm(j, 2) = taucld(j)*wcld(j); trm(j, 3) = 1.
+        end if
       end if
     end do
   contains

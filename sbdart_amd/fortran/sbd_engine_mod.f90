@@ -12,11 +12,11 @@ module sbd_engine_mod
             sbd_engine_chunk, sbd_strerror_f, sbd_last_error_f, sbd_abi_version
   public :: sbd_fleet_create, sbd_fleet_destroy, sbd_fleet_size, sbd_fleet_uses_rccl, sbd_shard_range, &
             sbd_fleet_solve_host, sbd_fleet_solve_mix_host
-  public :: SBD_OK, SBD_E_RETRY_NSTR, SBD_NFLUX, SBD_ABI_VER
+  public :: SBD_OK, SBD_E_RETRY_NSTR, SBD_NFLUX, SBD_ABI_VER, SBD_MIX_MAX_TERMS
   public :: SBD_ST_WARN_SOLVE0, SBD_ST_WARN_UPBEAM, SBD_ST_WARN_UPISOT, SBD_ST_ERR_EIGEN, &
             SBD_ST_RETRY_NSTR, SBD_ST_ERR_INPUT, SBD_ST_WARN_PLKAVG
 
-  integer(c_int), parameter :: SBD_ABI_VER = 5, SBD_OK = 0, SBD_E_RETRY_NSTR = -2, SBD_NFLUX = 5
+  integer(c_int), parameter :: SBD_ABI_VER = 6, SBD_OK = 0, SBD_E_RETRY_NSTR = -2, SBD_NFLUX = 5
   integer(c_int), parameter :: SBD_ST_WARN_SOLVE0 = 1, SBD_ST_WARN_UPBEAM = 2, SBD_ST_WARN_UPISOT = 4, &
        SBD_ST_ERR_EIGEN = 8, SBD_ST_RETRY_NSTR = 16, SBD_ST_ERR_INPUT = 32, SBD_ST_WARN_PLKAVG = 64
 
@@ -42,11 +42,16 @@ module sbd_engine_mod
     type(c_ptr) :: albtrn = c_null_ptr   ! ibcnd = 1 only
   end type
 
-  ! a batch in compact form (include/sbdart_amd.h): per spectral point the scatterers, per work item the gas of its
-  ! k-term; the engine assembles DTAUC / SSALB / PMOM on the device
+  ! a batch in compact form (include/sbdart_amd.h, ABI v6): per spectral point a block lay(nlyr, 4 + 3 nterm) -- cloud,
+  ! aerosol and Rayleigh depths, their scattering depth, then g, m1, m2 of every scattering term -- and per work item
+  ! the gas of its k-term; the engine assembles DTAUC / SSALB / PMOM on the device in the reference's own association
+  integer, parameter :: SBD_MIX_MAX_TERMS = 6
   type, bind(C) :: sbd_mix_in
     integer(c_int32_t) :: nwork, npoint
-    type(c_ptr) :: point_of, dtaug, dtaux, tsc_hg, g_hg, tsc_ray, wvnmlo, wvnmhi, fbeam, albedo, plank
+    type(c_ptr) :: point_of, dtaug
+    integer(c_int32_t) :: nterm = 0
+    integer(c_int32_t) :: family(SBD_MIX_MAX_TERMS) = 0
+    type(c_ptr) :: lay, wvnmlo, wvnmhi, fbeam, albedo, plank
   end type
 
   interface

@@ -43,6 +43,8 @@ end module
 module sbd_run_mod
   implicit none
   real(kind=8), save :: t_engine = 0, t_wait = 0, t_phase2 = 0        ! batch mode's time account (SBD_TIMING)
+  integer(kind=8), save :: tick_program = -1                          ! system_clock at the program's first statement
+  real(kind=8), save :: t_create = 0                                  ! sbd_fleet_create calls of the run (SBD_TIMING)
   character(len=*), parameter :: items_tmp = '.sbd_items.part', items_file = '.sbd_items', stdout_file = 'SBDART.stdout', stderr_file = 'SBDART.stderr', phase1_mark = '.sbd_phase1'
 contains
 
@@ -93,6 +95,8 @@ subroutine run_once(phase)
   integer(c_int8_t), allocatable, target :: plank(:)
   real(kr), allocatable, target :: bitem(:, :)        ! ocean surface: nr, ni, rsw per work item
   integer(c_int32_t), allocatable, target :: pmom_row(:)   ! block of moments per work item (band model: per wavelength)
+  real(kr), allocatable, target :: pt_lo(:), pt_hi(:), pt_fb(:), pt_al(:)   ! compact form: per SPECTRAL POINT
+  integer(c_int8_t), allocatable, target :: pt_pl(:)
   integer(c_int32_t), allocatable, target :: status(:), level_out(:)
   integer, allocatable :: order(:), where_solved(:)
   real(kr), allocatable :: zlev(:), plev(:)
@@ -103,9 +107,12 @@ subroutine run_once(phase)
   logical :: have_file, ok, from_model, in_place, sum_widths, aborted
   real(kr), allocatable, target :: bdtauc(:, :), bssalb(:, :), bpmom(:, :, :)
   real(kr), allocatable :: btemper(:)
-  integer(kind=8) :: tick0, tick1, tick2, tick_rate
+  integer(kind=8) :: tick0, tick1, tick2, tick_rate, tick_bm0, tick_bm1, tick_out, tick_c0, tick_c1
   character(len=256) :: why
   type(ck_file) :: ck                                  ! KDIST = -1: the k-distribution file pair
+  type(mix_batch), target :: mix                       ! the run's batch in compact form (sbd_mix_in), when it fits
+  logical :: use_mix
+  real(kr), allocatable :: one_dtau(:), one_ssalb(:), one_pmom(:, :)
 
   call set_defaults()
   call warn_reset()
@@ -209,15 +216,42 @@ subroutine run_once(phase)
     if (aborted) return
     call viewing_cosines()
     call system_clock(tick0, tick_rate)
+    ! the batch in compact form (the scatterers per spectral point, the gas per work item; DISORT's arguments are formed
+    ! on the device) whenever the run's output is the engine's: not when the work items themselves are asked for
+    ! (SBD_DUMP_OPTICS, phase 1 of a batch) and not for IBCND = 1 (no solve at all).  SBD_NO_MIX=1 keeps the arrays form.
+    call get_environment_variable('SBD_DUMP_OPTICS', path, plen, pstat)
+    mix%want = phase == 0 .and. .not. (pstat == 0 .and. plen > 0) .and. ibcnd /= 1
+    call get_environment_variable('SBD_NO_MIX', path, plen, pstat)
+    if (pstat == 0 .and. plen > 0) mix%want = .false.
     if (kdist == -1) then
       call build_work_items(model, grid, umu(1:numu), phiv(1:merge(view%nphi, 0, radcalc)), recs, nrec, atm, &
-                            bdtauc, bssalb, bpmom, btemper, ck)
+                            bdtauc, bssalb, bpmom, btemper, ck, mix)
     else
       call build_work_items(model, grid, umu(1:numu), phiv(1:merge(view%nphi, 0, radcalc)), recs, nrec, atm, &
-                            bdtauc, bssalb, bpmom, btemper)
+                            bdtauc, bssalb, bpmom, btemper, mixb=mix)
+    end if
+    use_mix = mix%ok
+    ! SBD_DUMP_MIX=file: the run's batch in compact form, for inspection / tests (stream: int32 nz, channels, points,
+    ! terms, family(6), items; then lay, the items' gas depths and their points, 0-based) -- and stop before the engine
+    call get_environment_variable('SBD_DUMP_MIX', path, plen, pstat)
+    if (pstat == 0 .and. plen > 0) then
+      open(newunit=u11, file=trim(path), access='stream', form='unformatted', status='replace')
+      if (use_mix) then
+        write(u11) int(atm%nz, 4), int(size(mix%lay, 2), 4), int(size(mix%lay, 3), 4), int(mix%nterm, 4), &
+                   int(mix%family, 4), int(nrec, 4)
+        write(u11) mix%lay
+        write(u11) bdtauc
+        write(u11) (int(recs(i)%iwl - 1, 4), i = 1, nrec)
+      else
+        write(u11) 0_4, 0_4, 0_4, 0_4, (0_4, i = 1, 6), 0_4
+        write(0, '(a)') 'sbdart_amd: arrays form: '//trim(mix%why)
+      end if
+      close(u11)
+      call leave(); return
     end if
     from_model = .true.
     call system_clock(tick1)
+    tick_bm0 = tick0; tick_bm1 = tick1
     call get_environment_variable('SBD_TIMING', path, plen, pstat)
     if (pstat == 0 .and. plen > 0) write(0, '(a,i0,a,i0,a,f9.4,a)') 'sbdart_amd: band model: ', grid%n, &
       ' wavelengths, ', nrec, ' work items in ', real(tick1 - tick0, kr)/real(tick_rate, kr), ' s'
@@ -227,7 +261,7 @@ subroutine run_once(phase)
     do i = 1, nrec
       recs(i)%ff = filter_value(sensor, recs(i)%wl)*recs(i)%ewcoef      ! drt.f:461 (ewcoef = 1 without a k-distribution file)
     end do
-    call corint_history(recs, nrec, bssalb)
+    if (.not. use_mix) call corint_history(recs, nrec, bssalb)     ! (compact form: never with the intensity corrections)
     have_atm = .true.
   end if
   nmom = maxval(recs(1:nrec)%nmom)
@@ -322,17 +356,20 @@ subroutine run_once(phase)
   else
     allocate(pmom(0:nmom, nz, nrec))
   end if
+  ! (compact form: `dtauc` holds the GAS depth of every item -- sbd_mix_in%dtaug --, `ssalb` and `pmom` are not formed
+  !  on the host at all)
   if (in_place) then
     call move_alloc(bdtauc, dtauc); call move_alloc(bssalb, ssalb)
   else
-    allocate(dtauc(nz, nrec), ssalb(nz, nrec))
+    allocate(dtauc(nz, nrec), ssalb(nz, merge(1, nrec, use_mix)))
   end if
   status = 0
   do ip = 1, npart
     i = order(ip)
     if (.not. in_place) then
       if (from_model) then
-        dtauc(:, ip) = bdtauc(:, i); ssalb(:, ip) = bssalb(:, i)
+        dtauc(:, ip) = bdtauc(:, i)
+        if (.not. use_mix) ssalb(:, ip) = bssalb(:, i)
       else
         dtauc(:, ip) = recs(i)%dtauc; ssalb(:, ip) = recs(i)%ssalb
         pmom(:, :, ip) = 0                             ! (a run whose CORINT went off holds shorter moment arrays later)
@@ -346,6 +383,15 @@ subroutine run_once(phase)
     pmom_row(ip) = recs(i)%iwl - 1                     ! (0-based block of the item's wavelength; used when from_model)
     weight(ip) = recs(i)%wt*recs(i)%ff                 ! dwt of stdout1 (drt.f:964)
   end do
+  if (use_mix) then                                    ! (a point's scalars: any of its items carries them)
+    allocate(pt_lo(grid%n), pt_hi(grid%n), pt_fb(grid%n), pt_al(grid%n), pt_pl(grid%n))
+    pt_lo = 0; pt_hi = 0; pt_fb = 0; pt_al = 0; pt_pl = 0
+    do i = 1, nrec
+      j = recs(i)%iwl
+      pt_lo(j) = recs(i)%wvnmlo; pt_hi(j) = recs(i)%wvnmhi; pt_fb(j) = recs(i)%fbeam; pt_al(j) = recs(i)%albedo
+      pt_pl(j) = int(iand(recs(i)%flags, 1), c_int8_t)
+    end do
+  end if
   if (from_model) then
     temper = btemper
   else
@@ -444,7 +490,12 @@ subroutine run_once(phase)
   ! -- and in which something scatters (YESSCT > 0, disort.f:5163-5166: the fuzz's Rayleigh-free clear-sky runs)
   if (radcalc .and. nbeam > 0 .and. (.not. corint .or. nbeam > ncorr)) then
     do ip = merge(ncorr + 1, 1, corint), nbeam
-      if (sum(ssalb(:, ip)) > 0._kr) then
+      if (use_mix) then                                  ! (SSALB = tsc / DTAUC where DTAUC > tiny: positive iff tsc is)
+        known = any(mix%lay(:, 4, int(pmom_row(ip)) + 1) > tiny(1._kr))
+      else
+        known = sum(ssalb(:, ip)) > 0._kr
+      end if
+      if (known) then
         call warn_file(7, 'CHEKIN--intensity correction is off; intensities may be less accurate')
         exit
       end if
@@ -521,6 +572,19 @@ subroutine run_once(phase)
       end if
     end do
     call write_run_record(sums, fmt, sensor%wlmin, sensor%wlmax, zlev, plev, view%phi, view%uzen)   ! (wl1, wl2 of setfilt)
+  end if
+  ! SBD_TIMING: the run's account in one line (seconds inside the process, counted from the program's first statement):
+  ! setup = namelist, screening, tables, grid; band_model; assembly = batch arrays; engine = fleet create (of which
+  ! engine_create) + H2D + kernels + D2H / reduce; output = warnings and writers; total = first statement -> here
+  call get_environment_variable('SBD_TIMING', path, plen, pstat)
+  if (pstat == 0 .and. plen > 0 .and. phase == 0 .and. from_model .and. tick_program >= 0) then
+    flush(6)
+    call system_clock(tick_out)
+    write(0, '(a,i0,a,i0,a,i0,7(a,f0.4))') 'sbdart_amd: timing nwl=', grid%n, ' items=', npart, ' compact=', merge(1, 0, use_mix), &
+      ' setup=', real(tick_bm0 - tick_program, 8)/real(tick_rate, 8), ' band_model=', real(tick_bm1 - tick_bm0, 8)/real(tick_rate, 8), &
+      ' assembly=', real(tick1 - tick0, 8)/real(tick_rate, 8) + real(tick0 - tick_bm1, 8)/real(tick_rate, 8), &
+      ' engine=', real(tick2 - tick1, 8)/real(tick_rate, 8), ' engine_create=', t_create, &
+      ' output=', real(tick_out - tick2, 8)/real(tick_rate, 8), ' total=', real(tick_out - tick_program, 8)/real(tick_rate, 8)
   end if
   call get_environment_variable('SBD_SUMS_FILE', path, plen, pstat)   ! full-precision sums for parity tests
   if (pstat == 0 .and. plen > 0) then
@@ -780,11 +844,14 @@ contains
     cfg%btemp = btemp; cfg%ttemp = ttemp; cfg%temis = temis
     cfg%temper = c_loc(temper); cfg%umu = c_loc(umu); cfg%phi = c_loc(phiv)
     cfg%level_out = c_loc(level_out)
+    call system_clock(tick_c0)
     if (size(devices) == 0) then
       rc = sbd_fleet_create(cfg, 0, c_null_ptr, fl)
     else
       rc = sbd_fleet_create(cfg, int(size(devices), c_int32_t), c_loc(devices), fl)
     end if
+    call system_clock(tick_c1)
+    t_create = t_create + real(tick_c1 - tick_c0, 8)/real(tick_rate, 8)
     if (rc /= SBD_OK .and. rc /= SBD_E_RETRY_NSTR) &
       call quit('sbd_fleet_create: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
     if (aborted) then
@@ -821,7 +888,21 @@ contains
     ! with the wavelengths before it on stdout.
     ipk = where_solved(k)
     nbad = 0
-    if (ipk > 0) then
+    if (ipk > 0 .and. use_mix) then                      ! the item's arguments as the device formed them
+      allocate(one_dtau(nz), one_ssalb(nz), one_pmom(0:nmom, nz))
+      call assemble_item(mix, int(pmom_row(ipk)) + 1, dtauc(:, ipk), nmom, one_dtau, one_ssalb, one_pmom)
+      do lc = 1, nz
+        if (one_ssalb(lc) < 0._kr .or. one_ssalb(lc) > 1._kr) then
+          print *, one_ssalb(lc), ', ', lc
+          call write_bad('SSALB')
+        end if
+      end do
+      do lc = 1, nz
+        do km = 0, nmom
+          if (one_pmom(km, lc) < -1._kr .or. one_pmom(km, lc) > 1._kr) call write_bad('PMOM')
+        end do
+      end do
+    else if (ipk > 0) then
       do lc = 1, nz
         if (ssalb(lc, ipk) < 0._kr .or. ssalb(lc, ipk) > 1._kr) then
           print *, ssalb(lc, ipk), ', ', lc
@@ -867,6 +948,7 @@ contains
     integer, intent(in) :: p0, p1
     logical, intent(in) :: beam, corrections
     type(sbd_batch_in) :: bin
+    type(sbd_mix_in) :: mxin
     type(sbd_batch_out) :: bout
     type(c_ptr) :: fleet, wptr, aptr, uptr
     integer(c_int) :: rc
@@ -889,6 +971,29 @@ contains
       write(*, *) 'Error --- NSTR dithering procedure failed'
       call leave(); return
     end if
+    bout%flux = c_loc(flux(1, 1, p0)); bout%status = c_loc(status(p0))
+    bout%uu = c_null_ptr
+    if (radcalc) bout%uu = c_loc(uu(1, 1, 1, p0))
+    wptr = c_null_ptr; aptr = c_null_ptr; uptr = c_null_ptr
+    if (.not. fmt%per_point) then
+      wptr = c_loc(weight(p0)); aptr = c_loc(acc_flux)
+      if (radcalc) uptr = c_loc(acc_uu)
+    end if
+    if (use_mix) then
+      ! compact form: the part's items with the gas of their k-term, the spectral points' blocks by their index in the
+      ! run (the engine stages the blocks the part's items refer to); per point the band edges, the incident flux, the
+      ! albedo and the thermal switch (the same for the k-terms of a point)
+      mxin%nwork = p1 - p0 + 1; mxin%npoint = int(size(mix%lay, 3), c_int32_t)
+      mxin%point_of = c_loc(pmom_row(p0)); mxin%dtaug = c_loc(dtauc(1, p0))
+      mxin%nterm = mix%nterm; mxin%family = 0
+      mxin%family(1:mix%nterm) = mix%family(1:mix%nterm)
+      mxin%lay = c_loc(mix%lay)
+      mxin%wvnmlo = c_loc(pt_lo); mxin%wvnmhi = c_loc(pt_hi); mxin%fbeam = c_loc(pt_fb); mxin%albedo = c_loc(pt_al)
+      mxin%plank = c_loc(pt_pl)
+      rc = sbd_fleet_solve_mix_host(fleet, mxin, bout, wptr, aptr, uptr)
+      if (rc /= SBD_OK) call quit('sbd_fleet_solve_mix_host: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
+      return
+    end if
     bin%nwork = p1 - p0 + 1
     bin%dtauc = c_loc(dtauc(1, p0)); bin%ssalb = c_loc(ssalb(1, p0))
     bin%wvnmlo = c_loc(wvnmlo(p0)); bin%wvnmhi = c_loc(wvnmhi(p0)); bin%fbeam = c_loc(fbeam(p0))
@@ -899,14 +1004,6 @@ contains
       bin%pmom = c_loc(pmom(0, 1, 1)); bin%pmom_row = c_loc(pmom_row(p0)); bin%npmom = int(size(pmom, 3), c_int32_t)
     else                                               ! (per item: only here is p0 a valid third index of pmom)
       bin%pmom = c_loc(pmom(0, 1, p0))
-    end if
-    bout%flux = c_loc(flux(1, 1, p0)); bout%status = c_loc(status(p0))
-    bout%uu = c_null_ptr
-    if (radcalc) bout%uu = c_loc(uu(1, 1, 1, p0))
-    wptr = c_null_ptr; aptr = c_null_ptr; uptr = c_null_ptr
-    if (.not. fmt%per_point) then
-      wptr = c_loc(weight(p0)); aptr = c_loc(acc_flux)
-      if (radcalc) uptr = c_loc(acc_uu)
     end if
     rc = sbd_fleet_solve_host(fleet, bin, bout, wptr, aptr, uptr)
     if (rc /= SBD_OK) call quit('sbd_fleet_solve_host: '//sbd_strerror_f(rc)//' '//sbd_last_error_f())
@@ -1156,6 +1253,7 @@ program sbdart_amd
   implicit none
   character(len=1024) :: arg, list
   integer :: n
+  call system_clock(tick_program)
   n = command_argument_count()
   if (n >= 2) then
     call get_command_argument(1, arg)

@@ -19,6 +19,20 @@ def shard_range(nwl: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def shard_range_points(point_of, rank: int, world: int) -> Tuple[int, int]:
+    """Work items [lo, hi) of `rank` for a batch in compact form: shard_range's item boundaries, each moved UP to the
+    next item that starts a spectral point (point_of non-decreasing) -- the k-terms of a point stay on one device.
+    Same rule as the C ABI's sbd_shard_range_points (include/sbdart_amd.h); tests pin the two together."""
+    n = len(point_of)
+
+    def snap(i):
+        while 0 < i < n and point_of[i] == point_of[i - 1]:
+            i += 1
+        return i
+    lo, hi = shard_range(n, rank, world)
+    return snap(lo), snap(hi)
+
+
 def reduce_accumulators(acc, dst: int = 0, group=None):
     """Sum the per-rank accumulator tensor onto rank `dst` (in place).  One collective."""
     import torch.distributed as dist

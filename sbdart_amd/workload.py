@@ -62,6 +62,17 @@ class Sweep:
     def nwork(self) -> int:
         return int(self.dtauc.shape[0])
 
+    def points(self, lo: int, hi: int) -> "Sweep":
+        """The spectral points lo..hi-1 of this sweep with all their k-terms: one shard of a sweep that is cut BETWEEN
+        spectral points (sbd_shard_range over the points; strong scaling, north_star's split)."""
+        a = int(np.searchsorted(self.wl_of, lo, side="left"))
+        b = int(np.searchsorted(self.wl_of, hi, side="left"))
+        cut = lambda x: np.ascontiguousarray(x[a:b])
+        return dataclasses.replace(self, nwl=hi - lo, nk=self.nk[lo:hi], wl_of=cut(self.wl_of) - lo, weight=cut(self.weight),
+                                   wl=self.wl[lo:hi], dtauc=cut(self.dtauc), ssalb=cut(self.ssalb), pmom=cut(self.pmom),
+                                   wvnmlo=cut(self.wvnmlo), wvnmhi=cut(self.wvnmhi), fbeam=cut(self.fbeam),
+                                   albedo=cut(self.albedo), plank=cut(self.plank))
+
 
 def sw_sweep(nwl: int, nstr: int = 16, nlyr: int = 33, seed: int = 12345, wlinf: float = 0.25,
              wlsup: float = 4.0, albedo: float = 0.2, sza_deg: float = 30.0,
@@ -130,8 +141,10 @@ def sweep_to_records(sw: Sweep, idx):
 
 @dataclasses.dataclass
 class MixSweep:
-    """The sweep of SURVEY 8(d) in the COMPACT form of include/sbdart_amd.h (sbd_mix_in): per spectral point a
-    Henyey-Greenstein scatterer (g = U(0, 0.9)) and Rayleigh scattering, per work item the gas of its k-term."""
+    """The sweep of SURVEY 8(d) in the COMPACT form of include/sbdart_amd.h (sbd_mix_in, ABI v6): per spectral point the
+    layer block lay[point] = [dtauc, dtaua, dtaur, tsc, then (g, m1, m2) per scattering term][nlyr] -- here a cloud-like
+    Henyey-Greenstein scatterer (g = U(0, 0.9)), an aerosol-like one (g = U(0.5, 0.8)) and Rayleigh scattering --, per work
+    item the gas of its k-term."""
     nlyr: int
     nstr: int
     nmom: int
@@ -139,10 +152,8 @@ class MixSweep:
     point_of: np.ndarray   # [W]
     weight: np.ndarray     # [W]
     dtaug: np.ndarray      # [W, nlyr]
-    dtaux: np.ndarray      # [nwl, nlyr]
-    tsc_hg: np.ndarray
-    g_hg: np.ndarray
-    tsc_ray: np.ndarray
+    lay: np.ndarray        # [nwl, 4 + 3 nterm, nlyr]
+    family: tuple          # GETMOM's iphas per term
     wvnmlo: np.ndarray     # [nwl]
     wvnmhi: np.ndarray
     fbeam: np.ndarray
@@ -158,44 +169,70 @@ class MixSweep:
     def nwork(self) -> int:
         return int(self.dtaug.shape[0])
 
+    def points(self, lo: int, hi: int) -> "MixSweep":
+        """Spectral points lo..hi-1 with their k-terms (a shard cut between points, like Sweep.points)."""
+        a = int(np.searchsorted(self.point_of, lo, side="left"))
+        b = int(np.searchsorted(self.point_of, hi, side="left"))
+        pt = lambda x: np.ascontiguousarray(x[lo:hi])
+        return dataclasses.replace(self, nwl=hi - lo, point_of=np.ascontiguousarray(self.point_of[a:b] - lo).astype(np.int32),
+                                   weight=np.ascontiguousarray(self.weight[a:b]), dtaug=np.ascontiguousarray(self.dtaug[a:b]),
+                                   lay=pt(self.lay), wvnmlo=pt(self.wvnmlo), wvnmhi=pt(self.wvnmhi), fbeam=pt(self.fbeam),
+                                   albedo=pt(self.albedo), plank=pt(self.plank))
+
+    def mix_args(self):
+        """Positional arguments of DisortFleet.solve_mix."""
+        return (self.point_of, self.dtaug, self.lay, self.family, self.wvnmlo, self.wvnmhi, self.fbeam, self.albedo, self.plank)
+
     def arrays(self):
         """(dtauc [W][L], ssalb [W][L], pmom [nwl][L][nmom+1]): DISORT's arguments of this sweep, the way the engine forms
-        them on the device (include/sbdart_amd.h, sbd_mix_in) -- for runs that want them resident in HBM beforehand."""
-        dtauc = self.dtaug + self.dtaux[self.point_of]
-        scat = self.tsc_hg + self.tsc_ray
+        them on the device (include/sbdart_amd.h, sbd_mix_in) -- for runs that want them resident in HBM beforehand.
+        (A numpy statement of assemble_kernel like oracle/mix_restatement.py, which the tests compare it with: the
+        product does not import the oracle.)"""
+        lay = self.lay
+        dc, da, dr, scat = lay[:, 0], lay[:, 1], lay[:, 2], lay[:, 3]
+        po = self.point_of
+        dtauc = ((self.dtaug + dc[po]) + da[po]) + dr[po]
         with np.errstate(divide="ignore", invalid="ignore"):
-            ssalb = np.where(dtauc > np.finfo(np.float64).tiny, scat[self.point_of] / dtauc, 0.0)
+            ssalb = np.where(dtauc > np.finfo(np.float64).tiny, scat[po] / dtauc, 0.0)
         pmom = np.zeros((self.nwl, self.nlyr, self.nmom + 1))
         pmom[:, :, 0] = 1.0
-        gk = np.ones_like(self.g_hg)
-        pw = {}
-        for k in range(1, self.nmom + 1):        # g**k by square-and-multiply from the low bit (a Fortran integer power)
-            a, r, b = self.g_hg.copy(), np.ones_like(self.g_hg), k
-            while True:
-                if b & 1:
-                    r = r * a
-                b //= 2
-                if b == 0:
-                    break
-                a = a * a
-            q = self.tsc_hg * r
+        ray2 = float(np.float32(0.1))
+        for k in range(1, self.nmom + 1):
+            q = np.zeros_like(scat)
+            for t, fam in enumerate(self.family):
+                g, m1, m2 = lay[:, 4 + 3 * t], lay[:, 5 + 3 * t], lay[:, 6 + 3 * t]
+                if fam == 3:                     # g**k by square-and-multiply from the low bit (a Fortran integer power)
+                    a, r, b = g.copy(), np.ones_like(g), k
+                    while True:
+                        if b & 1:
+                            r = r * a
+                        b //= 2
+                        if b == 0:
+                            break
+                        a = a * a
+                    pk = r
+                else:
+                    pk = np.full_like(g, ray2 if (fam == 2 and k == 2) else 0.0)
+                q = q + (pk * m1) * m2
             if k == 2:
-                q = q + float(np.float32(0.1)) * self.tsc_ray
+                q = q + ray2 * dr
             with np.errstate(divide="ignore", invalid="ignore"):
                 pmom[:, :, k] = np.where(scat != 0.0, q / scat, q)
         return dtauc, ssalb, pmom
 
     def h2d_bytes(self) -> int:
-        return int(sum(a.nbytes for a in (self.point_of, self.dtaug, self.dtaux, self.tsc_hg, self.g_hg, self.tsc_ray,
-                                          self.wvnmlo, self.wvnmhi, self.fbeam, self.albedo, self.plank, self.weight)))
+        return int(sum(a.nbytes for a in (self.point_of, self.dtaug, self.lay, self.wvnmlo, self.wvnmhi, self.fbeam,
+                                          self.albedo, self.plank, self.weight)))
 
 
 def sw_sweep_mix(nwl: int, nstr: int = 16, nlyr: int = 33, seed: int = 12345, wlinf: float = 0.25, wlsup: float = 4.0,
                  albedo: float = 0.2, sza_deg: float = 30.0, thermal_above_um: float = 2.0, shard: int = 0) -> MixSweep:
     """Same sizes, k-term structure, wavelength grid and column optical depths as sw_sweep; the layer optical properties
     are drawn per SPECTRAL POINT (what a band model delivers): extinction of the scatterers exp(U(-9,1)) split into a
-    Henyey-Greenstein part (single-scattering albedo U(0, 0.999999) of it scatters, g = U(0, 0.9)) and a Rayleigh part
-    that grows with height, and per work item the gas absorption of its k-term (stronger for the higher terms)."""
+    cloud-like Henyey-Greenstein part (single-scattering albedo U(0, 0.999999), g = U(0, 0.9)), an aerosol-like one in the
+    lowest third of the layers (a fifth of the particles' extinction there, single-scattering albedo 0.9, g = U(0.5, 0.8))
+    and a Rayleigh part that grows with height; per work item the gas absorption of its k-term (stronger for the higher
+    terms)."""
     base = sw_sweep(nwl=nwl, nstr=nstr, nlyr=nlyr, seed=seed, wlinf=wlinf, wlsup=wlsup, albedo=albedo, sza_deg=sza_deg,
                     thermal_above_um=thermal_above_um, shard=shard)
     W = base.nwork
@@ -204,18 +241,26 @@ def sw_sweep_mix(nwl: int, nstr: int = 16, nlyr: int = 33, seed: int = 12345, wl
     ext = np.exp(-9.0 + 10.0 * r[:, 0])
     ext *= np.minimum(1.0, 25.0 / ext.sum(axis=1, keepdims=True))
     lw = np.linspace(1.0, 0.2, nlyr)[None, :] * r[:, 3]                 # Rayleigh's share of the extinction, larger aloft
-    tsc_ray = ext * lw
-    part = ext - tsc_ray
-    tsc_hg = part * (0.999999 * r[:, 1])
-    g_hg = 0.9 * r[:, 2]
+    dtaur = ext * lw
+    part = ext - dtaur
+    low = (np.arange(nlyr) >= (2 * nlyr) // 3)[None, :]                 # aerosol in the lowest third
+    dtaua = np.where(low, 0.2 * part, 0.0)
+    dtauc = part - dtaua
+    wcld = 0.999999 * r[:, 1]
+    waer = np.full_like(dtaua, 0.9)
+    g_c = 0.9 * r[:, 2]
+    g_a = 0.5 + 0.3 * r[:, 2][:, ::-1]
+    tw = dtauc * wcld
+    tsc = tw + dtaua * waer + dtaur                                      # depthscl's numerator, normom's dtsct
+    one = np.ones_like(tw)
+    lay = np.stack([dtauc, dtaua, dtaur, tsc, g_c, tw, one, g_a, dtaua, waer], axis=1)
     first = np.concatenate([[0], np.nonzero(np.diff(base.wl_of))[0] + 1])
     kidx = np.arange(W) - first[base.wl_of]
     rg = splitmix64(seed ^ 0x9E3779B9, W * nlyr).reshape(W, nlyr)
     dtaug = np.exp(-9.0 + 10.0 * rg) * (1.0 + 4.0 * kidx)[:, None]
     dtaug *= np.minimum(1.0, 25.0 / dtaug.sum(axis=1, keepdims=True))
     return MixSweep(nlyr=nlyr, nstr=nstr, nmom=base.nmom, nwl=nwl, point_of=base.wl_of.astype(np.int32), weight=base.weight,
-                    dtaug=np.ascontiguousarray(dtaug), dtaux=np.ascontiguousarray(ext), tsc_hg=np.ascontiguousarray(tsc_hg),
-                    g_hg=np.ascontiguousarray(g_hg), tsc_ray=np.ascontiguousarray(tsc_ray),
+                    dtaug=np.ascontiguousarray(dtaug), lay=np.ascontiguousarray(lay), family=(3, 3),
                     wvnmlo=base.wvnmlo[first], wvnmhi=base.wvnmhi[first], fbeam=np.ones(nwl), albedo=np.full(nwl, albedo),
                     plank=base.plank[first], temper=base.temper, umu0=base.umu0, btemp=base.btemp, ttemp=base.ttemp,
                     temis=base.temis)

@@ -83,6 +83,38 @@ def test_shard_range_partitions():
                 assert (lo.value, hi.value) == parts[r]
 
 
+def test_shard_range_points_cuts_between_spectral_points():
+    """sbd_shard_range_points (a batch in compact form over several devices): shard_range's item boundaries moved up to
+    the next item that starts a spectral point.  Contiguous cover, every cut at a point start, never more than one
+    point's k-terms (<= 3 - 1 items here) away from the balanced boundary, C == Python mirror, empty shards allowed."""
+    import ctypes as C
+    from sbdart_amd import _lib
+    from sbdart_amd.shard import shard_range, shard_range_points
+    from sbdart_amd.workload import splitmix64
+    L = _lib.load()
+    lo, hi = C.c_int32(), C.c_int32()
+    for npoint, seed in ((1, 1), (2, 2), (5, 3), (751, 4), (20000, 5)):
+        nk = np.where(splitmix64(seed, npoint) < 0.835, 3, 1)
+        po = np.ascontiguousarray(np.repeat(np.arange(npoint), nk), dtype=np.int32)
+        po += 11                                                  # (a part of a run: block indices need not start at 0)
+        n = len(po)
+        for world in (1, 2, 3, 8):
+            parts = [shard_range_points(po, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            for (a0, a1), (b0, b1) in zip(parts, parts[1:]):
+                assert a1 == b0 and a0 <= a1
+            for r, (a, b) in enumerate(parts):
+                assert a == 0 or a == n or po[a] != po[a - 1]      # every cut starts a spectral point
+                bl, bh = shard_range(n, r, world)
+                assert 0 <= a - bl <= 2 and 0 <= b - bh <= 2
+                L.sbd_shard_range_points(n, po.ctypes.data_as(C.c_void_p), world, r, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == (a, b)
+    # one point with three k-terms on eight devices: the first shard whose boundary passes its end takes all of it
+    po = np.zeros(3, dtype=np.int32)
+    parts = [shard_range_points(po, r, 8) for r in range(8)]
+    assert sum(b - a for a, b in parts) == 3 and max(b - a for a, b in parts) == 3
+
+
 def test_flux_albedo_of_the_surface_models_on_the_host():
     """sbd_surface_flux_albedo (DREF, disort.f:5178-5284: what drt.f:478-484 needs for ISALB -7, -8, -9) runs on the
     host with the device's model functions: against the oracle's DREF for the three models over the incidence cosines,

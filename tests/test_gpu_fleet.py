@@ -188,3 +188,29 @@ def test_growing_passes_of_the_host_entry_point():
     assert (s_ramp == 0).all()
     assert np.array_equal(f_ramp, f_host) and np.array_equal(s_ramp, s_host)
     assert np.array_equal(f_ramp, f_dev.cpu().numpy()) and np.array_equal(s_ramp, s_dev.cpu().numpy())
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_compact_form_over_several_devices_cuts_between_points(devices):
+    """sbd_fleet_solve_mix_host on a fleet of one, two and three engines (the box's one GPU listed again): the batch is cut
+    by sbd_shard_range_points, every shard stages only the point blocks its items refer to (block indices counted from
+    its first), and the per-item outputs and status words equal the one-engine call bit for bit; the sums agree to the
+    association of their shard-wise addition."""
+    from sbdart_amd.engine import DisortFleet
+    from sbdart_amd.shard import shard_range_points
+    from sbdart_amd.workload import sw_sweep_mix
+    m = sw_sweep_mix(nwl=900, nstr=16, seed=99)
+    kw = dict(nlyr=m.nlyr, nstr=m.nstr, nmom=m.nmom, temper=m.temper, umu0=m.umu0, btemp=m.btemp, ttemp=m.ttemp,
+              temis=m.temis, onlyfl=True, level_out=[0, m.nlyr])
+    with DisortFleet(devices=[0], **kw) as one:
+        f1, _, s1, a1, _ = one.solve_mix(*m.mix_args(), weight=m.weight)
+    with DisortFleet(devices=devices, **kw) as fl:
+        f2, _, s2, a2, _ = fl.solve_mix(*m.mix_args(), weight=m.weight)
+        # a part of a run: items of the points 300.. only, block indices global (the host's beam / no-beam parts)
+        lo = int(np.searchsorted(m.point_of, 300))
+        f3, _, s3 = fl.solve_mix(m.point_of[lo:], m.dtaug[lo:], m.lay, m.family, m.wvnmlo, m.wvnmhi, m.fbeam, m.albedo, m.plank)
+    assert np.array_equal(f1, f2) and np.array_equal(s1, s2) and (s1 == 0).all()
+    assert np.array_equal(f1[lo:], f3) and np.array_equal(s1[lo:], s3)
+    assert np.allclose(a1, a2, rtol=1e-13, atol=0)
+    cuts = [shard_range_points(m.point_of, r, len(devices)) for r in range(len(devices))]
+    assert all(a == 0 or m.point_of[a] != m.point_of[a - 1] for a, _ in cuts)

@@ -10,7 +10,7 @@ from sbdart_amd.workload import sw_sweep_mix
 
 mx = sw_sweep_mix(nwl=49152, nstr=16, nlyr=33, seed=12345)
 pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().numpy()
-m_in = [pin(x) for x in (mx.point_of, mx.dtaug, mx.dtaux, mx.tsc_hg, mx.g_hg, mx.tsc_ray, mx.wvnmlo, mx.wvnmhi, mx.fbeam, mx.albedo, mx.plank)]
+m_in = [x if isinstance(x, tuple) else pin(x) for x in mx.mix_args()]
 m_w = pin(mx.weight)
 for first, grow in [(None, None), (8192, 1.3), (8192, 2.0), (4096, 2.0), (16384, 2.0), (21876, 1.0), (11000, 1.0), (5469, 4.0)]:
     for k, v in (("SBD_HOST_FIRST_PASS", first), ("SBD_HOST_PASS_GROWTH", grow)):
