@@ -194,7 +194,32 @@ typedef struct {
                                  g, m1, m2 -- one block per spectral point, a channel's layers contiguous          */
     const double *wvnmlo, *wvnmhi, *fbeam, *albedo;   /* [npoint] as in sbd_batch_in, per spectral point            */
     const uint8_t *plank;     /* [npoint]                                                                           */
+    const int32_t *kterm;     /* NULL, or with dtaug == NULL: [nwork] k-term (0-based) of each item -- its gas depth is
+                                 the one sbd_fleet_gas_terms left ON THE DEVICE for (point_of, kterm): the gas never
+                                 crosses PCIe.  point_of then counts the points of that gas call, and a fleet of several
+                                 devices hands every item to the device that holds its point */
 } sbd_mix_in;
+
+/* The gas part of the band model for a run (ABI v6): LOWTRAN7's band model and continua along a vertical and a slant
+ * path, the three-term k-distribution fit, the Newton slant-path correction and depthscl's KDIST policy (gasset / taugas
+ * / kdistr / taucor / depthscl, taugas.f:7392-7510, 2236-2534 with the look-ups 2538-6821, 1802-1920, 7650-7692,
+ * 7550-7590) -- what the reference evaluates per wavelength between its table look-ups and DISORT's optical depths,
+ * evaluated on the device for all wavelengths of a run at once (north_star: "per-wavelength optical depths ...
+ * precomputed into coalesced HBM arrays").  The same sequence of roundings as the reference; exp / log / log10 / pow are
+ * the device math library's (a few ulps per call: tests/test_gas_device.py states the bound on the optical depths). */
+#define SBD_GAS_SLOTS 63   /* absorber-amount slots, params.f:14 (mxq) */
+typedef struct {
+    int32_t nz;            /* levels = DISORT layers (drt.f:144; with SPOWDER's extra level)                        */
+    int32_t kdist;         /* KDIST 0..3 (taugas.f:7520-7528)                                                       */
+    const double *uu;      /* [nz][SBD_GAS_SLOTS] absorber amounts above each level, levels bottom-up (absint,
+                              taugas.f:1924-2233)                                                                    */
+    const double *z;       /* [nz] level altitudes, km, bottom-up                                                  */
+    double amu0_first;     /* cosine of the solar zenith angle for the gas terms of the run's FIRST wavelength ...  */
+    double amu0_rest;      /* ... and of every later one (the same unless SZA >= 90: drt.f:433-455)                 */
+    double xo4;            /* XO4 (taugas.f:3190)                                                                   */
+    const void *tables;    /* image of sbdart_amd/data/sbdart_tables.bin (the band model's coefficient tables)      */
+    size_t tables_bytes;
+} sbd_gas_model;
 
 /* ---- lifecycle ---- */
 int  sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out);
@@ -249,6 +274,20 @@ int      sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_ba
 void     sbd_shard_range_points(int32_t nwork, const int32_t *point_of, int32_t nshard, int32_t rank, int32_t *lo, int32_t *hi);
 int      sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_batch_out *out,
                                   const double *weight, double *acc_flux, double *acc_uu);
+/* The gas terms of npoint wavelengths on the fleet's devices (points sharded by sbd_shard_range, every device keeps its
+ * points' results): wl [npoint] micrometres (wl[0] is the run's first wavelength), lay [npoint][nch][nlyr] the points'
+ XX  Returns
+ * per point nk (1 or 3 k-terms), wt [npoint][3] the terms' weights (depthscl's wt: 1 when nk = 1), and taucor's
+ * failures as SBD_ST_ERR_INPUT-free status: fail [npoint] 1 where the reference would stop ("TAUCOR: iteration did
+ * not converge"), may be NULL.  The depths stay on the devices for sbd_fleet_solve_mix_host with dtaug == NULL.
+ * dtaug_out, if not NULL: [npoint][3][nlyr] the terms' gas depths copied back (tests, IOUT-independent inspection). */
+int      sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, const double *wl, const double *lay,
+                             int32_t nch, int32_t *nk, double *wt, int32_t *fail, double *dtaug_out);
+/* The same arithmetic on the HOST (no GPU involved; the same source, sbd_gas.hpp): with the host's libm the results
+ * are bit-equal to the Fortran host's band model, hence to the reference's -- the pin of the device kernel's source. */
+int      sbd_gas_terms_host(const sbd_gas_model *g, int32_t nlyr, int32_t npoint, const double *wl, const double *lay, int32_t nch,
+                            int32_t *nk, double *wt, int32_t *fail, double *dtaug_out);
+
 /* How the devices are fed (replaces nothing in the reference: its loop is serial, drt.f:425-561): every device's
  * shard is enqueued from a host thread of its own, and when the fleet spans several devices (or SBD_PIN_INPUTS=1)
  * dtauc / ssalb / pmom are page-locked for the duration of the call, so pageable arrays of the caller do not

@@ -51,7 +51,18 @@ class MixIn(C.Structure):
     _fields_ = [("nwork", C.c_int32), ("npoint", C.c_int32), ("point_of", C.c_void_p), ("dtaug", C.c_void_p),
                 ("nterm", C.c_int32), ("family", C.c_int32 * MIX_MAX_TERMS), ("lay", C.c_void_p),
                 ("wvnmlo", C.c_void_p), ("wvnmhi", C.c_void_p), ("fbeam", C.c_void_p), ("albedo", C.c_void_p),
-                ("plank", C.c_void_p)]
+                ("plank", C.c_void_p), ("kterm", C.c_void_p)]
+
+
+class GasModel(C.Structure):
+    """sbd_gas_model: the gas part of the band model for a run."""
+    _fields_ = [("nz", C.c_int32), ("kdist", C.c_int32), ("uu", C.c_void_p), ("z", C.c_void_p),
+                ("amu0_first", C.c_double), ("amu0_rest", C.c_double), ("xo4", C.c_double),
+                ("tables", C.c_void_p), ("tables_bytes", C.c_size_t)]
+
+
+GAS_SLOTS = 63
+TABLES_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "sbdart_tables.bin")
 
 
 EXPORTS = (
@@ -63,7 +74,7 @@ EXPORTS = (
     "sbd_last_error", "sbd_engine_debug_copy", "sbd_engine_debug_pivots",
     "sbd_fleet_create", "sbd_fleet_destroy", "sbd_fleet_size", "sbd_fleet_engine", "sbd_fleet_uses_rccl",
     "sbd_shard_range", "sbd_fleet_solve_host", "sbd_fleet_last_enqueue", "sbd_host_alloc", "sbd_host_free",
-    "sbd_surface_flux_albedo", "sbd_fleet_solve_mix_host", "sbd_engine_pass_count", "sbd_shard_range_points",
+    "sbd_surface_flux_albedo", "sbd_fleet_solve_mix_host", "sbd_engine_pass_count", "sbd_shard_range_points", "sbd_fleet_gas_terms", "sbd_gas_terms_host",
 )
 
 _LIB = None
@@ -135,6 +146,10 @@ def load() -> C.CDLL:
     L.sbd_fleet_solve_mix_host.restype = C.c_int
     L.sbd_shard_range_points.argtypes = [C.c_int32, vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.sbd_shard_range_points.restype = None
+    L.sbd_fleet_gas_terms.argtypes = [vp, C.POINTER(GasModel), C.c_int32, vp, vp, C.c_int32, vp, vp, vp, vp]
+    L.sbd_fleet_gas_terms.restype = C.c_int
+    L.sbd_gas_terms_host.argtypes = [C.POINTER(GasModel), C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, vp, vp, vp]
+    L.sbd_gas_terms_host.restype = C.c_int
     L.sbd_fleet_last_enqueue.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.sbd_fleet_last_enqueue.restype = C.c_int
     L.sbd_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -32,6 +33,7 @@
 #include "sbd_layer.hpp"    // LayerLds
 #include "sbd_layer2.hpp"   // Layer2Lds
 #include "sbd_surface.hpp"  // bidirectional surfaces: surfac_kernel, host-side check of the model
+#include "sbd_gas_types.hpp" // the gas model's launch interface (its source, sbd_gas.hpp, is compiled without contraction in sbd_k_gas.hip)
 static_assert(sbd::SBD_NFLUX_ == SBD_NFLUX, "flux component count");
 
 namespace {
@@ -194,7 +196,7 @@ __device__ __forceinline__ double powi_like_fortran(double a, int b)
 struct MixFamilies { int32_t f[SBD_MIX_MAX_TERMS]; };
 // point blocks: lay[(p - pbase)][4 + 3 nterm][L]; outputs: dtauc / ssalb [item], pmom [(p - pbase)], pmom_row = p - pbase
 __global__ void __launch_bounds__(64) assemble_kernel(int w0, int nitem, int L, int nmom, int first_point_done, int pbase,
-                                                      int nterm, MixFamilies fam,
+                                                      int nterm, MixFamilies fam, const int32_t *kterm, const double *gslots, int gas_p0,
                                                       const int32_t *point_of, const double *dtaug, const double *lay,
                                                       const double *plo, const double *phi_, const double *pfb, const double *pal,
                                                       const uint8_t *ppl, double *dtauc, double *ssalb, double *pmom,
@@ -209,9 +211,11 @@ __global__ void __launch_bounds__(64) assemble_kernel(int w0, int nitem, int L, 
     const bool first = (blockIdx.x == 0) ? (first_point_done == 0) : (point_of[w - 1] - pbase != p);
     const int nch = 4 + 3 * nterm;
     const double *blk = lay + (size_t)p * nch * L;
+    // the item's gas: from the host (dtaug), or what the gas kernel left on this device for (point, k-term)
+    const double *gas = gslots ? gslots + ((size_t)(point_of[w] - gas_p0) * 3 + kterm[w]) * L : dtaug + (size_t)w * L;
     for (int l = threadIdx.x; l < L; l += blockDim.x) {
         const double dc = blk[l], da = blk[L + l], dr = blk[2 * L + l], scat = blk[3 * L + l];
-        const double dt = ((dtaug[(size_t)w * L + l] + dc) + da) + dr;                     // taugas.f:7598
+        const double dt = ((gas[l] + dc) + da) + dr;                                       // taugas.f:7598
         dtauc[(size_t)w * L + l] = dt;
         ssalb[(size_t)w * L + l] = (dt > 2.2250738585072014e-308) ? scat / dt : 0.0;      // (tiny(1.d0): taugas.f:7599)
         if (first) {
@@ -347,6 +351,9 @@ struct sbd_engine {
     bool quad = false;              // radiances at the quadrature angles (USRANG = false): CMPINT instead of TERPEV/TERPSO/USRINT
     bool corint = false;            // intensity corrections after the azimuth series (sbd_intcor.hpp)
     int32_t *d_pivdbg = nullptr;    // sbd_engine_debug_pivots: [2][chunk * nmode][L * n]
+    // the gas depths sbd_fleet_gas_terms left on this device: [gas_np][3][L] for the points gas_p0 .. gas_p0 + gas_np - 1 of that call
+    double *d_gas_slots = nullptr;
+    int32_t gas_p0 = 0, gas_np = 0;
     int64_t fallback_layers = 0;    // timing mode: (item, mode, layer) problems of the last solve left to the QR kernel
 };
 
@@ -377,6 +384,7 @@ void sbd_engine_destroy(sbd_engine *e)
     if (e->d_level) (void)hipFree(e->d_level);
     if (e->d_ws) (void)hipFree(e->d_ws);
     if (e->d_stage) (void)hipFree(e->d_stage);
+    if (e->d_gas_slots) (void)hipFree(e->d_gas_slots);
     if (e->h_pin) (void)hipHostFree(e->h_pin);
     if (e->h_hint) (void)hipHostFree(e->h_hint);
     if (e->d_partial) (void)hipFree(e->d_partial);
@@ -927,7 +935,7 @@ long long sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t
 // slice in before its kernels and its outputs back after them, on the pass's stream -- the H2D of one
 // pass then runs beside the kernels of the other instead of ahead of everything.
 struct MixStage {               // device staging of a compact batch (sbd_mix_in): its items, and the point blocks pbase .. they refer to
-    int32_t *point_of;
+    int32_t *point_of, *kterm;
     double *dtaug, *lay, *lo, *hi, *fb, *al;
     uint8_t *pl;
     int32_t pbase;              // first spectral point the call's items refer to: staged block q holds point pbase + q
@@ -1086,7 +1094,8 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             const int q0 = done ? p0 + 1 : p0, nq = p1 - q0 + 1;           // (global point indices)
             const size_t blk = (size_t)(4 + 3 * m->nterm) * L;
             HIP_TRY(hipMemcpyAsync(d.point_of + w0, m->point_of + w0, sizeof(int32_t) * ns, hipMemcpyHostToDevice, cs));
-            HIP_TRY(hipMemcpyAsync(d.dtaug + (size_t)w0 * L, m->dtaug + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, cs));
+            if (m->dtaug) HIP_TRY(hipMemcpyAsync(d.dtaug + (size_t)w0 * L, m->dtaug + (size_t)w0 * L, sizeof(double) * ns * L, hipMemcpyHostToDevice, cs));
+            else HIP_TRY(hipMemcpyAsync(d.kterm + w0, m->kterm + w0, sizeof(int32_t) * ns, hipMemcpyHostToDevice, cs));
             if (nq > 0) {
                 const int s0 = q0 - d.pbase;                               // (staged block index)
                 HIP_TRY(hipMemcpyAsync(d.lay + (size_t)s0 * blk, m->lay + (size_t)q0 * blk, sizeof(double) * nq * blk, hipMemcpyHostToDevice, cs));
@@ -1098,7 +1107,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             MixFamilies fam;
             for (int t = 0; t < SBD_MIX_MAX_TERMS; ++t) fam.f[t] = m->family[t];
             hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)ns), dim3(64), 0, cs, w0, ns, L, e->cfg.nmom, done ? 1 : 0,
-                               (int)d.pbase, (int)m->nterm, fam,
+                               (int)d.pbase, (int)m->nterm, fam, (const int32_t *)d.kterm, (const double *)(m->dtaug ? nullptr : e->d_gas_slots), (int)e->gas_p0,
                                (const int32_t *)d.point_of, (const double *)d.dtaug, (const double *)d.lay, (const double *)d.lo, (const double *)d.hi,
                                (const double *)d.fb, (const double *)d.al, (const uint8_t *)d.pl,
                                (double *)in->dtauc, (double *)in->ssalb, (double *)in->pmom, (int32_t *)in->pmom_row,
@@ -1401,8 +1410,10 @@ static int solve_mix_host_enqueue(sbd_engine *e, const sbd_mix_in *m, const sbd_
 {
     if (e->ibcnd) return fail(SBD_E_UNSUPPORTED, "compact batches: not with IBCND = 1");
     if (e->P.ibdrf == 1) return fail(SBD_E_UNSUPPORTED, "compact batches: not with the ocean surface (per-item constants)");
-    if (!m->point_of || !m->dtaug || !m->lay || !m->wvnmlo || !m->wvnmhi
+    if (!m->point_of || !m->lay || !m->wvnmlo || !m->wvnmhi
         || !m->fbeam || !m->albedo || !m->plank) return fail(SBD_E_INVALID, "compact batch: null input array");
+    if (!m->dtaug && !m->kterm) return fail(SBD_E_INVALID, "compact batch: neither dtaug nor kterm");
+    if (!m->dtaug && !e->d_gas_slots) return fail(SBD_E_INVALID, "compact batch: dtaug is NULL and no sbd_fleet_gas_terms call left gas depths on this device");
     if (m->npoint < 1) return fail(SBD_E_INVALID, "compact batch: npoint < 1");
     if (m->nterm < 0 || m->nterm > SBD_MIX_MAX_TERMS) return fail(SBD_E_INVALID, "compact batch: nterm outside 0..SBD_MIX_MAX_TERMS");
     for (int t = 0; t < m->nterm; ++t)
@@ -1416,6 +1427,12 @@ static int solve_mix_host_enqueue(sbd_engine *e, const sbd_mix_in *m, const sbd_
     }
     const int32_t pbase = m->point_of[0];
     const size_t NP = (size_t)(m->point_of[W - 1] - pbase + 1);      // the point blocks this call's items refer to
+    if (!m->dtaug) {
+        if (pbase < e->gas_p0 || m->point_of[W - 1] >= e->gas_p0 + e->gas_np)
+            return fail(SBD_E_INVALID, "compact batch: an item's point is not among the points whose gas depths this device holds");
+        for (size_t i = 0; i < W; ++i)
+            if (m->kterm[i] < 0 || m->kterm[i] > 2) return fail(SBD_E_INVALID, "compact batch: kterm outside 0..2");
+    }
     const int L = e->L, nlev = e->nlev;
     const bool rad = !e->cfg.onlyfl;
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1423,7 +1440,7 @@ static int solve_mix_host_enqueue(sbd_engine *e, const sbd_mix_in *m, const sbd_
     const size_t b_blk = sizeof(double) * NP * (size_t)(4 + 3 * m->nterm) * L, b_p = sizeof(double) * NP;
     const size_t b_flux = sizeof(double) * W * SBD_NFLUX * nlev;
     const size_t b_uu = rad ? sizeof(double) * W * e->P.nphi * nlev * e->P.numu : 0;
-    const size_t total = 3 * up(b_lay) + up(b_pm) + 5 * up(b_w) + up(W) + up(b_flux) + up(b_uu) + 3 * up(sizeof(int32_t) * W)
+    const size_t total = 3 * up(b_lay) + up(b_pm) + 5 * up(b_w) + up(W) + up(b_flux) + up(b_uu) + 4 * up(sizeof(int32_t) * W)
                          + up(b_blk) + 4 * up(b_p) + up(NP);
     int rc = ensure_stage(e, total);
     if (rc != SBD_OK) return rc;
@@ -1441,6 +1458,7 @@ static int solve_mix_host_enqueue(sbd_engine *e, const sbd_mix_in *m, const sbd_
     hs.mix = m;
     hs.ms.pbase = pbase;
     hs.ms.point_of = (int32_t *)take(sizeof(int32_t) * W);
+    hs.ms.kterm = (int32_t *)take(sizeof(int32_t) * W);
     hs.ms.dtaug = (double *)take(b_lay);
     hs.ms.lay = (double *)take(b_blk);
     hs.ms.lo = (double *)take(b_p); hs.ms.hi = (double *)take(b_p); hs.ms.fb = (double *)take(b_p); hs.ms.al = (double *)take(b_p);
@@ -1850,8 +1868,21 @@ int sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_batch
     std::vector<int> busy;
     std::vector<int32_t> slo(nd), shi(nd);
     for (int r = 0; r < nd; ++r) {
-        sbd_shard_range_points(in->nwork, in->point_of, nd, r, &slo[r], &shi[r]);
+        if (in->dtaug) {
+            sbd_shard_range_points(in->nwork, in->point_of, nd, r, &slo[r], &shi[r]);
+        } else {
+            // gas depths resident on the devices (sbd_fleet_gas_terms): an item goes where its point's depths are
+            const int32_t *b = in->point_of, *e_ = in->point_of + in->nwork;
+            slo[r] = (int32_t)(std::lower_bound(b, e_, f->eng[r]->gas_p0) - b);
+            shi[r] = (int32_t)(std::lower_bound(b, e_, f->eng[r]->gas_p0 + f->eng[r]->gas_np) - b);
+            if (!f->eng[r]->d_gas_slots) shi[r] = slo[r];
+        }
         if (shi[r] > slo[r]) busy.push_back(r);
+    }
+    if (!in->dtaug) {
+        int64_t covered = 0;
+        for (int r : busy) covered += shi[r] - slo[r];
+        if (covered != in->nwork) return fail(SBD_E_INVALID, "compact batch: dtaug is NULL and some item's point was not in the last sbd_fleet_gas_terms call");
     }
     struct PinGuard {
         std::vector<void *> p;
@@ -1882,6 +1913,7 @@ int sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_batch
             si.nwork = hi - lo;
             si.point_of = in->point_of + lo;
             si.dtaug = in->dtaug ? in->dtaug + (size_t)lo * L : nullptr;
+            si.kterm = in->kterm ? in->kterm + lo : nullptr;
             sbd_batch_out so = {out->flux ? out->flux + (size_t)lo * nel_f : nullptr,
                                 (rad && out->uu) ? out->uu + (size_t)lo * uu_item : nullptr, out->status + lo, nullptr};
             f->t_enq[2 * r] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
@@ -1903,6 +1935,96 @@ int sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_batch
             }
     }
     return fleet_finish(f, busy, weight != nullptr, acc_flux, acc_uu);
+}
+
+// The gas part of the band model for the points of a run, on the fleet's devices (sbd_gas.hpp through sbd_k_gas.hip):
+// points sharded by sbd_shard_range, every device keeps its points' gas depths for the compact-form solves that follow.
+int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, const double *wl, const double *lay,
+                        int32_t nch, int32_t *nk, double *wt, int32_t *failed, double *dtaug_out)
+{
+    if (!f || f->eng.empty() || !g || !wl || !lay || !nk || !wt) return fail(SBD_E_INVALID, "null argument");
+    if (!g->uu || !g->z || !g->tables) return fail(SBD_E_INVALID, "gas model: null array");
+    if (npoint <= 0) return npoint == 0 ? SBD_OK : fail(SBD_E_INVALID, "npoint < 0");
+    sbd_engine *e0 = f->eng[0];
+    const int L = e0->L;
+    if (g->nz != L) return fail(SBD_E_INVALID, "gas model: nz differs from the fleet's NLYR");
+    if (nch < 3) return fail(SBD_E_INVALID, "gas model: the layer blocks need the cloud, aerosol and Rayleigh channels");
+    if (g->kdist < 0 || g->kdist > 3) return fail(SBD_E_INVALID, "gas model: KDIST outside 0..3");
+    sbd::GasTablesPacked pk;
+    std::string perr;
+    if (!pk.parse(g->tables, g->tables_bytes, perr)) return fail(SBD_E_INVALID, perr);
+    const int nd = (int)f->eng.size();
+    std::vector<int> rcs(nd, SBD_OK);
+    std::vector<std::string> errs(nd);
+    auto run = [&](const int r) {
+        sbd_engine *e = f->eng[r];
+        int32_t lo, hi;
+        sbd_shard_range(npoint, nd, r, &lo, &hi);
+        const int np = hi - lo;
+        auto bad = [&](hipError_t he, const char *what) {
+            if (he == hipSuccess) return false;
+            rcs[r] = SBD_E_HIP;
+            errs[r] = std::string(what) + ": " + hipGetErrorString(he);
+            (void)hipGetLastError();
+            return true;
+        };
+        if (bad(hipSetDevice(e->cfg.device), "hipSetDevice")) return;
+        if (e->d_gas_slots) { (void)hipFree(e->d_gas_slots); e->d_gas_slots = nullptr; }
+        e->gas_p0 = lo; e->gas_np = 0;
+        if (np <= 0) return;
+        const size_t npad = ((size_t)np + 63) & ~(size_t)63;
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t b_td = up(8 * pk.d.size()), b_ti = up(4 * pk.i.size()), b_uu = up(8 * (size_t)L * SBD_GAS_SLOTS), b_z = up(8 * (size_t)L);
+        const size_t b_wl = up(8 * (size_t)np), b_lay = up(8 * (size_t)np * nch * L), b_ws = up(8 * (size_t)16 * L * npad);
+        const size_t b_nk = up(4 * (size_t)np), b_wt = up(8 * (size_t)np * 3);
+        char *tmp = nullptr;
+        if (bad(hipMalloc(&tmp, b_td + b_ti + b_uu + b_z + b_wl + b_lay + b_ws + 2 * b_nk + b_wt), "hipMalloc(gas work area)")) return;
+        if (bad(hipMalloc(&e->d_gas_slots, 8 * (size_t)np * 3 * L), "hipMalloc(gas depths)")) { (void)hipFree(tmp); return; }
+        char *q = tmp;
+        auto take = [&](size_t b) { char *x = q; q += b; return x; };
+        double *d_td = (double *)take(b_td);
+        int32_t *d_ti = (int32_t *)take(b_ti);
+        double *d_uu = (double *)take(b_uu), *d_z = (double *)take(b_z), *d_wl = (double *)take(b_wl), *d_lay = (double *)take(b_lay);
+        double *d_ws = (double *)take(b_ws);
+        int32_t *d_nk = (int32_t *)take(b_nk), *d_fail = (int32_t *)take(b_nk);
+        double *d_wt = (double *)take(b_wt);
+        hipStream_t st = e->stream;
+        bool err = false;
+        err = err || bad(hipMemcpyAsync(d_td, pk.d.data(), 8 * pk.d.size(), hipMemcpyHostToDevice, st), "H2D tables");
+        err = err || bad(hipMemcpyAsync(d_ti, pk.i.data(), 4 * pk.i.size(), hipMemcpyHostToDevice, st), "H2D tables");
+        err = err || bad(hipMemcpyAsync(d_uu, g->uu, 8 * (size_t)L * SBD_GAS_SLOTS, hipMemcpyHostToDevice, st), "H2D uu");
+        err = err || bad(hipMemcpyAsync(d_z, g->z, 8 * (size_t)L, hipMemcpyHostToDevice, st), "H2D z");
+        err = err || bad(hipMemcpyAsync(d_wl, wl + lo, 8 * (size_t)np, hipMemcpyHostToDevice, st), "H2D wl");
+        err = err || bad(hipMemcpyAsync(d_lay, lay + (size_t)lo * nch * L, 8 * (size_t)np * nch * L, hipMemcpyHostToDevice, st), "H2D lay");
+        err = err || bad(hipMemsetAsync(e->d_gas_slots, 0, 8 * (size_t)np * 3 * L, st), "memset");
+        if (!err) {
+            sbd::GasRun R;
+            std::string verr;
+            pk.view(d_td, d_ti, R.T, verr);
+            R.uu = d_uu; R.z = d_z; R.nz = L; R.kdist = g->kdist;
+            R.amu0_first = g->amu0_first; R.amu0_rest = g->amu0_rest; R.xo4 = g->xo4; R.re_earth = sbd::kReEarth;
+            sbd::launch_gas(st, R, np, lo == 0 ? 1 : 0, d_wl, d_lay, nch, d_ws, npad, d_nk, d_wt, d_fail, e->d_gas_slots);
+            err = err || bad(hipGetLastError(), "gas_kernel");
+            err = err || bad(hipMemcpyAsync(nk + lo, d_nk, 4 * (size_t)np, hipMemcpyDeviceToHost, st), "D2H nk");
+            err = err || bad(hipMemcpyAsync(wt + (size_t)lo * 3, d_wt, 8 * (size_t)np * 3, hipMemcpyDeviceToHost, st), "D2H wt");
+            if (failed) err = err || bad(hipMemcpyAsync(failed + lo, d_fail, 4 * (size_t)np, hipMemcpyDeviceToHost, st), "D2H fail");
+            if (dtaug_out) err = err || bad(hipMemcpyAsync(dtaug_out + (size_t)lo * 3 * L, e->d_gas_slots, 8 * (size_t)np * 3 * L, hipMemcpyDeviceToHost, st), "D2H depths");
+        }
+        (void)bad(hipStreamSynchronize(st), "gas_kernel (sync)");
+        (void)hipFree(tmp);
+        if (rcs[r] == SBD_OK) e->gas_np = np;
+        else if (e->d_gas_slots) { (void)hipFree(e->d_gas_slots); e->d_gas_slots = nullptr; }
+    };
+    if (nd > 1) {
+        std::vector<std::thread> th;
+        for (int r = 0; r < nd; ++r) th.emplace_back(run, r);
+        for (auto &t : th) t.join();
+    } else {
+        run(0);
+    }
+    for (int r = 0; r < nd; ++r)
+        if (rcs[r] != SBD_OK) return fail(rcs[r], errs[r]);
+    return SBD_OK;
 }
 
 // host clock around device i's enqueue in the last sbd_fleet_solve_host (seconds since that call began), and how

@@ -343,7 +343,25 @@ class DisortFleet(DisortEngine):
             return flux, uu, status
         return flux, uu, status, acc_f, acc_u
 
-    def solve_mix(self, point_of, dtaug, lay, family, wvnmlo, wvnmhi, fbeam, albedo, plank, weight=None, items=True):
+    def gas_terms(self, gas_model, wl, lay, want_depths=False):
+        """The gas part of the band model on the fleet's devices (sbd_fleet_gas_terms): gas_model a _lib.GasModel, wl
+        [npoint], lay [npoint][channels][nlyr] the points' layer blocks.  Returns (nk [npoint], wt [npoint][3], fail
+        [npoint], depths [npoint][3][nlyr] or None); the depths stay on the devices for solve_mix(dtaug=None, kterm=...)."""
+        wl, lay = _f64(wl), _f64(lay)
+        npt = wl.shape[0]
+        assert lay.shape[0] == npt and lay.shape[2] == self.nlyr
+        nk = np.zeros(npt, dtype=np.int32)
+        wt = np.zeros((npt, 3))
+        fail = np.zeros(npt, dtype=np.int32)
+        depths = np.zeros((npt, 3, self.nlyr)) if want_depths else None
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        rc = self._L.sbd_fleet_gas_terms(self._h, C.byref(gas_model), npt, vp(wl), vp(lay), lay.shape[1], vp(nk), vp(wt),
+                                         vp(fail), vp(depths))
+        if rc != _lib.OK:
+            raise SbdError(rc, "sbd_fleet_gas_terms")
+        return nk, wt, fail, depths
+
+    def solve_mix(self, point_of, dtaug, lay, family, wvnmlo, wvnmhi, fbeam, albedo, plank, weight=None, items=True, kterm=None):
         """A batch in COMPACT form (sbd_mix_in, include/sbdart_amd.h): per spectral point a block lay[point] of
         [4 + 3 nterm][nlyr] doubles (dtauc, dtaua, dtaur, tsc, then g, m1, m2 of every scattering term; `family` =
         GETMOM's iphas per term), per work item the gas of its k-term; DTAUC / SSALB / PMOM are formed on the device
@@ -352,12 +370,13 @@ class DisortFleet(DisortEngine):
         from ._lib import MIX_MAX_TERMS, MixIn
         rows = np.ascontiguousarray(point_of, dtype=np.int32)
         W = rows.shape[0]
-        dtaug = _f64(dtaug)
+        dtaug = None if dtaug is None else _f64(dtaug)          # (None: the depths gas_terms left on the devices, by kterm)
+        kt = None if kterm is None else np.ascontiguousarray(kterm, dtype=np.int32)
         lay = _f64(lay)
         family = [int(x) for x in family]
         nterm = len(family)
         NP = lay.shape[0]
-        assert dtaug.shape == (W, self.nlyr) and lay.shape == (NP, 4 + 3 * nterm, self.nlyr) and nterm <= MIX_MAX_TERMS
+        assert (dtaug is None or dtaug.shape == (W, self.nlyr)) and lay.shape == (NP, 4 + 3 * nterm, self.nlyr) and nterm <= MIX_MAX_TERMS
         lo, hi, fb, al = (_f64(np.broadcast_to(x, (NP,))) for x in (wvnmlo, wvnmhi, fbeam, albedo))
         pl = np.ascontiguousarray(np.broadcast_to(plank, (NP,)), dtype=np.uint8)
         flux = np.zeros((W, _lib.NFLUX, self.nlev)) if items else None
@@ -365,7 +384,7 @@ class DisortFleet(DisortEngine):
         status = np.zeros(W, dtype=np.int32)
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         fam = (C.c_int32 * MIX_MAX_TERMS)(*(family + [0] * (MIX_MAX_TERMS - nterm)))
-        mi = MixIn(W, NP, vp(rows), vp(dtaug), nterm, fam, vp(lay), vp(lo), vp(hi), vp(fb), vp(al), vp(pl))
+        mi = MixIn(W, NP, vp(rows), vp(dtaug), nterm, fam, vp(lay), vp(lo), vp(hi), vp(fb), vp(al), vp(pl), vp(kt))
         bo = BatchOut(vp(flux), vp(uu), vp(status))
         acc_f = acc_u = None
         if weight is not None:

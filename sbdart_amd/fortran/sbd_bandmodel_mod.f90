@@ -49,6 +49,14 @@ module sbd_bandmodel_mod
     character(len=96) :: why = ''                         ! ... or why not
     integer :: nterm = 0, family(mix_max_terms) = 0
     real(kr), allocatable :: lay(:, :, :)                 ! (nz, 4 + 3 nterm, npoint)
+    ! the run's gas model (include/sbdart_amd.h, sbd_gas_model): what gasset / depthscl take besides the wavelength
+    logical :: gas_on_device = .false.                    ! in: leave the gas terms to the engine (sbd_fleet_gas_terms):
+                                                          ! the band model then delivers no work items, only the points
+    logical :: gas_ok = .false.                           ! out: the fields below are set (not with a k-distribution file)
+    integer :: kdist = 3
+    real(kr) :: amu_gas(2) = 0, xo4 = 1                   ! cosine for the gas terms of the first / the later wavelengths
+    real(kr), allocatable :: uu(:, :), z(:)               ! (63, nz) absorber amounts, (nz) altitudes, bottom-up
+    real(kr), allocatable :: wl(:)                        ! (npoint)
   end type
 
 contains
@@ -416,6 +424,15 @@ contains
           nch = 4 + 3*mixb%nterm
           if (allocated(mixb%lay)) deallocate(mixb%lay)
           allocate(mixb%lay(nz, nch, grid%n))
+          mixb%gas_ok = .not. from_ck
+          if (mixb%gas_ok) then
+            mixb%kdist = m%kdist; mixb%xo4 = mix%xo4
+            mixb%amu_gas = amu0
+            if (m%sza >= 90.) mixb%amu_gas(2) = 1.       ! (drt.f:433-455: the cosine is reset after the first gasset)
+            mixb%uu = uu; mixb%z = atm%z
+            if (allocated(mixb%wl)) deallocate(mixb%wl)
+            allocate(mixb%wl(grid%n))
+          end if
         end if
       end if
     end if
@@ -553,6 +570,7 @@ contains
         scat(l) = dtauc(l)*wcld(l) + dtaua(l)*waer(l) + dtaur(l)
       end do
       if (compact) then
+        if (mixb%gas_ok) mixb%wl(iw) = wl
         mixb%lay(:, 1, iw) = dtauc; mixb%lay(:, 2, iw) = dtaua; mixb%lay(:, 3, iw) = dtaur; mixb%lay(:, 4, iw) = scat
         if (ncloud_term == 1) mixb%lay(:, 5:7, iw) = trm_c
         do k = 1, naer_term

@@ -242,6 +242,12 @@ subroutine run_once(phase)
         write(u11) mix%lay
         write(u11) bdtauc
         write(u11) (int(recs(i)%iwl - 1, 4), i = 1, nrec)
+        ! ... and the run's gas model with the items' k-term bookkeeping (tests of the engine's gas kernel)
+        write(u11) merge(1_4, 0_4, mix%gas_ok)
+        if (mix%gas_ok) then
+          write(u11) int(mix%kdist, 4), mix%amu_gas, mix%xo4, mix%uu, mix%z, mix%wl
+          write(u11) (int(recs(i)%kd, 4), int(recs(i)%nk, 4), recs(i)%wt, i = 1, nrec)
+        end if
       else
         write(u11) 0_4, 0_4, 0_4, 0_4, (0_4, i = 1, 6), 0_4
         write(0, '(a)') 'sbdart_amd: arrays form: '//trim(mix%why)
