@@ -638,6 +638,11 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     const size_t surf_per_ms = sizeof(double) * ((size_t)nn * (nn + 1) + nn + numu1 * (nn + 1) + numu1 + 4);
     const size_t per_slot = (per_ms + (brdf_item ? surf_per_ms : 0)) * nmode + sizeof(double) * sv_stride + sizeof(int32_t) * svi_stride;
     size_t budget = (size_t)64 << 30;   // of 288 GB: fewer, larger passes (launch tails cost ~7 % at 16k items)
+    // A caller that says how large its batches are (a run of the Fortran host: one batch, one process) gets at most 9 GB
+    // unless they are huge: the runtime hands out up to ~9 GB in 0.3 ms, but 16 GB cost 1.2 s, 47 GB 1.9 s and 64 GB
+    // 3.3 s the first time in a process (tools/microbench/malloc_time.hip, profiles/r05_malloc_time.txt) -- more than the
+    // whole run of anything below a few million solves, whose extra passes cost milliseconds.
+    if (cfg->max_batch > 0 && cfg->max_batch < 2000000) budget = (size_t)9 << 30;
     if (const char *s = getenv("SBD_WORKSPACE_MB")) budget = (size_t)atoll(s) << 20;
     // Two workspaces of `chunk` items each: consecutive passes of a batch alternate between them on two
     // streams, so that the layer kernel of one pass (latency-bound arithmetic) runs beside the band LU /

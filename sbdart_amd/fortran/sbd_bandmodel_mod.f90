@@ -19,7 +19,7 @@ module sbd_bandmodel_mod
   implicit none
   private
   public :: model_input, covered_by_band_model, build_work_items, aerosol_input, gas_depth_report, corint_history, &
-            mix_batch, mix_max_terms, assemble_item
+            mix_batch, mix_max_terms, assemble_item, expand_work_items
   integer, parameter :: maxmom_all = 299               ! params.f:10
 
   type model_input                     ! the &INPUT variables this step reads, same names
@@ -89,6 +89,29 @@ contains
         pmom(k, l) = q
       end do
     end do
+  end subroutine
+
+  ! Device-side gas terms (mix_batch%gas_on_device): the band model delivered ONE record per spectral point; with the
+  ! number of k-terms nk(point) and their weights wt(:, point) back from the engine (sbd_fleet_gas_terms) the records
+  ! become the run's work items -- a point's record once per k-term, in the order the reference's kd_loop makes them
+  subroutine expand_work_items(recs, nrec, nk, wt)
+    type(optics_t), allocatable, intent(inout) :: recs(:)
+    integer, intent(inout) :: nrec
+    integer, intent(in) :: nk(:)
+    real(kr), intent(in) :: wt(:, :)
+    type(optics_t), allocatable :: items(:)
+    integer :: i, k, n
+    allocate(items(sum(nk(1:nrec))))
+    n = 0
+    do i = 1, nrec
+      do k = 1, nk(i)
+        n = n + 1
+        items(n) = recs(i)
+        items(n)%kd = k; items(n)%nk = nk(i); items(n)%wt = wt(k, i)
+      end do
+    end do
+    call move_alloc(items, recs)
+    nrec = n
   end subroutine
 
   ! .true. when every switch of the run is inside the first slice; otherwise why not
@@ -314,7 +337,7 @@ contains
     real(kr), parameter :: dtor = 3.1415926536_kr/180.
     integer :: nz, nmom, iwl, kd, i
     integer :: nthreads, mkt
-    logical :: from_ck, compact, aer_ok
+    logical :: from_ck, compact, aer_ok, gas_dev
     integer :: ncloud_term, naer_term, aer_family(mix_max_terms), nch
 
     ! ---- once per run: profiles, rescaling, absorber amounts, clouds, aerosols, surface (drt.f:297-423) ----
@@ -393,7 +416,10 @@ contains
     end if
 
     ! ---- does the run fit the compact form?  (every scatterer one term GETMOM(family, g) x two factors) ----
-    compact = .false.
+    compact = .false.; gas_dev = .false.
+    if (present(mixb)) then
+      if (.not. mixb%want) mixb%gas_on_device = .false.
+    end if
     ncloud_term = 0; naer_term = 0; nch = 4
     call aerosol_terms(load, naer_term, aer_family, aer_ok)      ! (also sizes the term recorder of every wavelength)
     if (deck%nslot > 0 .or. lcloud%given) ncloud_term = 1
@@ -425,6 +451,8 @@ contains
           if (allocated(mixb%lay)) deallocate(mixb%lay)
           allocate(mixb%lay(nz, nch, grid%n))
           mixb%gas_ok = .not. from_ck
+          gas_dev = mixb%gas_ok .and. mixb%gas_on_device
+          mixb%gas_on_device = gas_dev
           if (mixb%gas_ok) then
             mixb%kdist = m%kdist; mixb%xo4 = mix%xo4
             mixb%amu_gas = amu0
@@ -437,6 +465,9 @@ contains
       end if
     end if
 
+    if (present(mixb)) then
+      if (.not. compact) mixb%gas_on_device = .false.
+    end if
     ! (the phase-function moments belong to the WAVELENGTH: one block per spectral point, shared by its k-terms --
     !  drt.f:476-533 computes them before the k loop -- and handed to the engine that way, sbd_batch_in%pmom_row)
     if (compact) then
@@ -444,7 +475,7 @@ contains
     else
       allocate(bpmom(0:nmom, nz, grid%n))
     end if
-    allocate(nk_of(grid%n), first(grid%n), sd(nz, mkt*grid%n), ss(nz, merge(1, mkt*grid%n, compact)), &
+    allocate(nk_of(grid%n), first(grid%n), sd(nz, merge(1, mkt*grid%n, gas_dev)), ss(nz, merge(1, mkt*grid%n, compact)), &
              swt(mkt, grid%n), swl(grid%n), slo(grid%n), shi(grid%n), sfb(grid%n), salb(grid%n), splank(grid%n), &
              sbit(4, grid%n))
     sbit = 0
@@ -462,13 +493,13 @@ contains
       first(iwl) = nrec + 1
       nrec = nrec + nk_of(iwl)
     end do
-    allocate(recs(nrec), bdtauc(nz, nrec), bssalb(nz, merge(1, nrec, compact)), btemper(0:nz))
+    allocate(recs(nrec), bdtauc(nz, merge(1, nrec, gas_dev)), bssalb(nz, merge(1, nrec, compact)), btemper(0:nz))
     btemper = temper
     !$omp parallel do schedule(static) num_threads(nthreads) private(kd, i)
     do iwl = 1, grid%n
       do kd = 1, nk_of(iwl)
         i = first(iwl) + kd - 1
-        bdtauc(:, i) = sd(:, mkt*(iwl - 1) + kd)
+        if (.not. gas_dev) bdtauc(:, i) = sd(:, mkt*(iwl - 1) + kd)
         if (.not. compact) bssalb(:, i) = ss(:, mkt*(iwl - 1) + kd)
         recs(i)%nlyr = nz; recs(i)%nstr = m%nstr; recs(i)%nmom = nmom; recs(i)%numu = size(umu); recs(i)%nphi = size(phi)
         recs(i)%flags = merge(1, 0, splank(iwl)) + merge(0, 2, m%radiance) + merge(16, 0, m%radiance .and. m%corint)
@@ -507,7 +538,10 @@ contains
         amu_sun = 1.
         if (iw > 1) amu_gas = 1.
       end if
-      if (from_ck) then                                          ! readk: weights and depths of this sub-band's k-terms
+      if (gas_dev) then                                          ! (the engine evaluates the gas terms: sbd_fleet_gas_terms)
+        nk = 1
+        gwk = 0.; gwk(1) = 1.
+      else if (from_ck) then                                     ! readk: weights and depths of this sub-band's k-terms
         nk = ck%nk(iw)
         gwk(1:nk) = ck%gwk(1:nk, iw)
         dtauk(:, 1:nk) = ck%dtauk(:, 1:nk, iw)
@@ -587,6 +621,10 @@ contains
       nk_of(iw) = nk
       swl(iw) = wl; slo(iw) = wvlo; shi(iw) = wvhi; sfb(iw) = flxin; salb(iw) = rsfc; splank(iw) = plank
       if (m%spowder) dtaur(nz) = 0.                                  ! (depthscl does this at every k-term)
+      if (gas_dev) then                                              ! one record per point for now: expand_work_items
+        swt(1, iw) = 1.
+        return
+      end if
       do k = 1, nk
         ! ---- gas depth of this k-term with the slant-path correction policy KDIST (depthscl) ----
         wt = gwk(k)

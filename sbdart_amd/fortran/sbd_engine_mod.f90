@@ -6,7 +6,7 @@ module sbd_engine_mod
   use iso_c_binding
   implicit none
   private
-  public :: sbd_run_cfg, sbd_batch_in, sbd_batch_out, sbd_mix_in
+  public :: sbd_run_cfg, sbd_batch_in, sbd_batch_out, sbd_mix_in, sbd_gas_model, sbd_fleet_gas_terms
   public :: sbd_engine_create, sbd_engine_destroy, sbd_engine_solve_host, &
             sbd_engine_solve_device, sbd_engine_accumulate_host, sbd_engine_nlevel, &
             sbd_engine_chunk, sbd_strerror_f, sbd_last_error_f, sbd_abi_version
@@ -52,6 +52,17 @@ module sbd_engine_mod
     integer(c_int32_t) :: nterm = 0
     integer(c_int32_t) :: family(SBD_MIX_MAX_TERMS) = 0
     type(c_ptr) :: lay, wvnmlo, wvnmhi, fbeam, albedo, plank
+    type(c_ptr) :: kterm = c_null_ptr    ! with dtaug = c_null_ptr: the items' k-terms (0-based); their gas depths are
+                                         ! the ones sbd_fleet_gas_terms left on the devices
+  end type
+
+  ! the gas part of the band model for a run (include/sbdart_amd.h): evaluated by the engine for all wavelengths at once
+  type, bind(C) :: sbd_gas_model
+    integer(c_int32_t) :: nz, kdist
+    type(c_ptr) :: uu, z                 ! (63, nz) absorber amounts, (nz) altitudes, levels bottom-up
+    real(c_double) :: amu0_first, amu0_rest, xo4
+    type(c_ptr) :: tables                ! image of sbdart_tables.bin
+    integer(c_size_t) :: tables_bytes
   end type
 
   interface
@@ -128,6 +139,14 @@ module sbd_engine_mod
       type(c_ptr), value :: fleet, weight, acc_flux, acc_uu
       type(sbd_mix_in), intent(in) :: min
       type(sbd_batch_out), intent(in) :: bout
+      integer(c_int) :: rc
+    end function
+    function sbd_fleet_gas_terms(fleet, gas, npoint, wl, lay, nch, nk, wt, failed, dtaug_out) &
+         bind(C, name='sbd_fleet_gas_terms') result(rc)
+      import
+      type(c_ptr), value :: fleet, wl, lay, nk, wt, failed, dtaug_out
+      type(sbd_gas_model), intent(in) :: gas
+      integer(c_int32_t), value :: npoint, nch
       integer(c_int) :: rc
     end function
     function sbd_engine_nlevel(eng) bind(C, name='sbd_engine_nlevel') result(n)

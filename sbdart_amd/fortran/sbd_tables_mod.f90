@@ -10,7 +10,7 @@ module sbd_tables_mod
   use sbd_grid_mod, only: kr
   implicit none
   private
-  public :: tables_load, tbl, tbl_int, tables_loaded
+  public :: tables_load, tbl, tbl_int, tables_loaded, tables_image
   public :: pzero, tzero, re_earth, pmo, grav, alosch, mxq
 
   integer, parameter :: mxq = 63                       ! absorber-amount slots (params.f:14)
@@ -24,6 +24,8 @@ module sbd_tables_mod
   end type
   type(entry_t), allocatable, target, save :: entries(:)
   logical, save :: tables_loaded = .false.
+  ! the file as it is, for the engine's gas kernel (include/sbdart_amd.h, sbd_gas_model%tables)
+  integer(kind=1), allocatable, target, save :: tables_image(:)
 
 contains
 
@@ -62,6 +64,12 @@ contains
       if (ios /= 0 .or. magic(1:7) /= 'SBDTBL1') then
         close(u)
         cycle
+      end if
+      inquire(unit=u, size=n)
+      if (n > 0) then
+        allocate(tables_image(n))
+        read(u, pos=1) tables_image
+        read(u, pos=13)                                    ! (back behind the header)
       end if
       allocate(entries(ntab))
       do k = 1, ntab

@@ -58,7 +58,7 @@ subroutine run_once(phase)
   use sbd_atmos_mod, only: atmosphere
   use sbd_bandmodel_mod
   use sbd_ckfile_mod, only: ck_file, read_ck_files
-  use sbd_tables_mod, only: tables_load
+  use sbd_tables_mod, only: tables_load, tables_image
   use sbd_filter_mod
   use sbd_fleet_cache_mod
   integer, intent(in) :: phase
@@ -111,12 +111,21 @@ subroutine run_once(phase)
   character(len=256) :: why
   type(ck_file) :: ck                                  ! KDIST = -1: the k-distribution file pair
   type(mix_batch), target :: mix                       ! the run's batch in compact form (sbd_mix_in), when it fits
-  logical :: use_mix
+  logical :: use_mix, gas_dev
   real(kr), allocatable :: one_dtau(:), one_ssalb(:), one_pmom(:, :)
+  ! the gas terms on the device (sbd_fleet_gas_terms): per spectral point the number of k-terms, their weights, TAUCOR's
+  ! verdict; per work item its k-term; the fleet whose devices hold the depths
+  integer(c_int32_t), allocatable, target :: gas_nk(:), gas_fail(:), kterm(:)
+  real(kr), allocatable, target :: gas_wt(:, :), gas_depths(:, :, :)
+  type(c_ptr) :: gas_fleet
+  integer(kind=8) :: tick_g0, tick_g1
+  real(kind=8) :: t_gas
+  integer(c_int) :: rc_gas
 
   call set_defaults()
   call warn_reset()
   aborted = .false.
+  use_mix = .false.; gas_dev = .false.; gas_fleet = c_null_ptr; t_gas = 0
 
   ! ---- read ./INPUT exactly like drt.f:220-231 ----
   open(newunit=u11, file='INPUT', status='old', iostat=ios)
@@ -223,6 +232,12 @@ subroutine run_once(phase)
     mix%want = phase == 0 .and. .not. (pstat == 0 .and. plen > 0) .and. ibcnd /= 1
     call get_environment_variable('SBD_NO_MIX', path, plen, pstat)
     if (pstat == 0 .and. plen > 0) mix%want = .false.
+    ! ... and the gas terms themselves on the device (sbd_fleet_gas_terms: the band model then delivers one record per
+    ! spectral point, the engine says how many k-terms each has).  SBD_HOST_GAS=1 keeps them on the host.
+    call get_environment_variable('SBD_DUMP_MIX', path, plen, pstat)
+    mix%gas_on_device = mix%want .and. .not. (pstat == 0 .and. plen > 0)
+    call get_environment_variable('SBD_HOST_GAS', path, plen, pstat)
+    if (pstat == 0 .and. plen > 0) mix%gas_on_device = .false.
     if (kdist == -1) then
       call build_work_items(model, grid, umu(1:numu), phiv(1:merge(view%nphi, 0, radcalc)), recs, nrec, atm, &
                             bdtauc, bssalb, bpmom, btemper, ck, mix)
@@ -231,6 +246,7 @@ subroutine run_once(phase)
                             bdtauc, bssalb, bpmom, btemper, mixb=mix)
     end if
     use_mix = mix%ok
+    gas_dev = use_mix .and. mix%gas_on_device
     ! SBD_DUMP_MIX=file: the run's batch in compact form, for inspection / tests (stream: int32 nz, channels, points,
     ! terms, family(6), items; then lay, the items' gas depths and their points, 0-based) -- and stop before the engine
     call get_environment_variable('SBD_DUMP_MIX', path, plen, pstat)
@@ -327,6 +343,37 @@ subroutine run_once(phase)
 
   if (.not. allocated(umu)) call viewing_cosines()
 
+  ! ---- the per-run arguments every engine of the run is created with (drt.f:330-335) ----
+  allocate(temper(0:nz))
+  if (from_model) then
+    temper = btemper
+  else
+    temper = recs(1)%temper
+  end if
+  if (btemp < 0._kr) btemp = recs(1)%btemp          ! drt.f:334-335 defaults come with the profile
+  if (ttemp < 0._kr) ttemp = recs(1)%ttemp
+
+  ! ---- the gas terms on the device: so far the band model delivered ONE record per spectral point; the engine
+  !      evaluates gasset / depthscl for all of them at once and keeps the depths, the host gets the number of
+  !      k-terms per point and their weights and makes the work items of them ----
+  if (gas_dev) then
+    call system_clock(tick_g0)
+    npart = 3*nrec                                     ! (an upper bound for the engines' batch size)
+    gas_fleet = fleet_for(nstr, .false., rc_gas)       ! (any engine of the run will do; SBD_E_RETRY_NSTR creates one too)
+    if (aborted) return
+    call gas_terms_on(gas_fleet, .false.)
+    if (aborted) return
+    if (any(gas_fail /= 0)) then
+      ! TAUCOR's iteration failed somewhere: the reference prints its operands and stops there (taugas.f:7684-7690) --
+      ! the host's own gas terms reproduce that to the letter
+      call quit('the slant-path correction did not converge at some wavelength: run with SBD_HOST_GAS=1 for the reference''s report')
+      return
+    end if
+    call expand_work_items(recs, nrec, int(gas_nk), gas_wt)
+    call system_clock(tick_g1)
+    t_gas = real(tick_g1 - tick_g0, 8)/real(tick_rate, 8)
+  end if
+
   ! ---- batch arrays (row-major by work item == Fortran's first index fastest).  Items the filter
   !      function removes (ff = 0) are not solved (drt.f:461-462); items with a beam come first so
   !      that an NSTR retry (below) re-solves one contiguous part, and among them first those whose call
@@ -353,8 +400,8 @@ subroutine run_once(phase)
     if (pass == 2) nbeam = npart
   end do
   ! (the band model's arrays are already the batch when every item is solved and all are of one kind)
-  in_place = from_model .and. npart == nrec .and. (ncorr == nrec .or. nbeam - ncorr == nrec .or. nbeam == 0)
-  allocate(wvnmlo(nrec), wvnmhi(nrec), fbeam(nrec), albedo(nrec), plank(nrec), status(nrec), weight(nrec), temper(0:nz))
+  in_place = from_model .and. npart == nrec .and. (ncorr == nrec .or. nbeam - ncorr == nrec .or. nbeam == 0) .and. .not. gas_dev
+  allocate(wvnmlo(nrec), wvnmhi(nrec), fbeam(nrec), albedo(nrec), plank(nrec), status(nrec), weight(nrec), kterm(nrec))
   allocate(bitem(4, nrec))
   allocate(pmom_row(nrec))
   if (from_model) then
@@ -367,13 +414,15 @@ subroutine run_once(phase)
   if (in_place) then
     call move_alloc(bdtauc, dtauc); call move_alloc(bssalb, ssalb)
   else
-    allocate(dtauc(nz, nrec), ssalb(nz, merge(1, nrec, use_mix)))
+    allocate(dtauc(nz, merge(1, nrec, gas_dev)), ssalb(nz, merge(1, nrec, use_mix)))      ! (gas on the device: no depths here at all)
   end if
   status = 0
   do ip = 1, npart
     i = order(ip)
     if (.not. in_place) then
-      if (from_model) then
+      if (gas_dev) then
+        continue
+      else if (from_model) then
         dtauc(:, ip) = bdtauc(:, i)
         if (.not. use_mix) ssalb(:, ip) = bssalb(:, i)
       else
@@ -387,6 +436,7 @@ subroutine run_once(phase)
     plank(ip) = int(iand(recs(i)%flags, 1), c_int8_t)
     bitem(:, ip) = recs(i)%bitem
     pmom_row(ip) = recs(i)%iwl - 1                     ! (0-based block of the item's wavelength; used when from_model)
+    kterm(ip) = recs(i)%kd - 1
     weight(ip) = recs(i)%wt*recs(i)%ff                 ! dwt of stdout1 (drt.f:964)
   end do
   if (use_mix) then                                    ! (a point's scalars: any of its items carries them)
@@ -398,14 +448,6 @@ subroutine run_once(phase)
       pt_pl(j) = int(iand(recs(i)%flags, 1), c_int8_t)
     end do
   end if
-  if (from_model) then
-    temper = btemper
-  else
-    temper = recs(1)%temper
-  end if
-  if (btemp < 0._kr) btemp = recs(1)%btemp          ! drt.f:334-335 defaults come with the profile
-  if (ttemp < 0._kr) ttemp = recs(1)%ttemp
-
   allocate(flux(nlev, SBD_NFLUX, nrec), acc_flux(nlev, SBD_NFLUX))
   if (radcalc) then
     allocate(uu(numu, nlev, view%nphi, nrec), acc_uu(numu, nlev, view%nphi))
@@ -586,10 +628,10 @@ subroutine run_once(phase)
   if (pstat == 0 .and. plen > 0 .and. phase == 0 .and. from_model .and. tick_program >= 0) then
     flush(6)
     call system_clock(tick_out)
-    write(0, '(a,i0,a,i0,a,i0,7(a,f0.4))') 'sbdart_amd: timing nwl=', grid%n, ' items=', npart, ' compact=', merge(1, 0, use_mix), &
+    write(0, '(a,i0,a,i0,a,i0,8(a,f0.4))') 'sbdart_amd: timing nwl=', grid%n, ' items=', npart, ' compact=', merge(1, 0, use_mix) + merge(1, 0, gas_dev), &
       ' setup=', real(tick_bm0 - tick_program, 8)/real(tick_rate, 8), ' band_model=', real(tick_bm1 - tick_bm0, 8)/real(tick_rate, 8), &
       ' assembly=', real(tick1 - tick0, 8)/real(tick_rate, 8) + real(tick0 - tick_bm1, 8)/real(tick_rate, 8), &
-      ' engine=', real(tick2 - tick1, 8)/real(tick_rate, 8), ' engine_create=', t_create, &
+      ' gas_device=', t_gas, ' engine=', real(tick2 - tick1, 8)/real(tick_rate, 8), ' engine_create=', t_create, &
       ' output=', real(tick_out - tick2, 8)/real(tick_rate, 8), ' total=', real(tick_out - tick_program, 8)/real(tick_rate, 8)
   end if
   call get_environment_variable('SBD_SUMS_FILE', path, plen, pstat)   ! full-precision sums for parity tests
@@ -896,7 +938,13 @@ contains
     nbad = 0
     if (ipk > 0 .and. use_mix) then                      ! the item's arguments as the device formed them
       allocate(one_dtau(nz), one_ssalb(nz), one_pmom(0:nmom, nz))
-      call assemble_item(mix, int(pmom_row(ipk)) + 1, dtauc(:, ipk), nmom, one_dtau, one_ssalb, one_pmom)
+      if (gas_dev) then                                  ! (the item's gas depths, back from the device for this report)
+        call gas_terms_on(gas_fleet, .true.)
+        call assemble_item(mix, int(pmom_row(ipk)) + 1, gas_depths(:, kterm(ipk) + 1, int(pmom_row(ipk)) + 1), nmom, &
+                           one_dtau, one_ssalb, one_pmom)
+      else
+        call assemble_item(mix, int(pmom_row(ipk)) + 1, dtauc(:, ipk), nmom, one_dtau, one_ssalb, one_pmom)
+      end if
       do lc = 1, nz
         if (one_ssalb(lc) < 0._kr .or. one_ssalb(lc) > 1._kr) then
           print *, one_ssalb(lc), ', ', lc
@@ -949,6 +997,31 @@ contains
     call release_all_fleets()
   end subroutine
 
+  ! gasset + depthscl for every spectral point of the run on the devices of `fl` (sbd_fleet_gas_terms): gas_nk, gas_wt,
+  ! gas_fail; with_depths also brings the depths back (gas_depths(layer, k-term, point))
+  subroutine gas_terms_on(fl, with_depths)
+    type(c_ptr), intent(in) :: fl
+    logical, intent(in) :: with_depths
+    type(sbd_gas_model) :: gm
+    integer(c_int) :: rcg
+    integer :: np
+    type(c_ptr) :: dptr
+    np = size(mix%lay, 3)
+    if (.not. allocated(gas_nk)) allocate(gas_nk(np), gas_fail(np), gas_wt(3, np))
+    gm%nz = int(nz, c_int32_t); gm%kdist = int(mix%kdist, c_int32_t)
+    gm%uu = c_loc(mix%uu); gm%z = c_loc(mix%z)
+    gm%amu0_first = mix%amu_gas(1); gm%amu0_rest = mix%amu_gas(2); gm%xo4 = mix%xo4
+    gm%tables = c_loc(tables_image); gm%tables_bytes = int(size(tables_image), c_size_t)
+    dptr = c_null_ptr
+    if (with_depths) then
+      if (.not. allocated(gas_depths)) allocate(gas_depths(nz, 3, np))
+      dptr = c_loc(gas_depths)
+    end if
+    rcg = sbd_fleet_gas_terms(fl, gm, int(np, c_int32_t), c_loc(mix%wl), c_loc(mix%lay), int(size(mix%lay, 2), c_int32_t), &
+                              c_loc(gas_nk), c_loc(gas_wt), c_loc(gas_fail), dptr)
+    if (rcg /= SBD_OK) call quit('sbd_fleet_gas_terms: '//sbd_strerror_f(rcg)//' '//sbd_last_error_f())
+  end subroutine
+
   ! solve batch positions p0..p1 on the run's GPUs; per-run formats also get their weighted sums
   subroutine solve_part(p0, p1, beam, corrections)
     integer, intent(in) :: p0, p1
@@ -990,7 +1063,17 @@ contains
       ! run (the engine stages the blocks the part's items refer to); per point the band edges, the incident flux, the
       ! albedo and the thermal switch (the same for the k-terms of a point)
       mxin%nwork = p1 - p0 + 1; mxin%npoint = int(size(mix%lay, 3), c_int32_t)
-      mxin%point_of = c_loc(pmom_row(p0)); mxin%dtaug = c_loc(dtauc(1, p0))
+      mxin%point_of = c_loc(pmom_row(p0))
+      if (gas_dev) then                                  ! the depths are on the devices of gas_fleet: by (point, k-term)
+        if (.not. c_associated(fleet, gas_fleet)) then   ! (another stream count after an NSTR retry: other engines)
+          call gas_terms_on(fleet, .false.)
+          if (aborted) return
+          gas_fleet = fleet
+        end if
+        mxin%dtaug = c_null_ptr; mxin%kterm = c_loc(kterm(p0))
+      else
+        mxin%dtaug = c_loc(dtauc(1, p0)); mxin%kterm = c_null_ptr
+      end if
       mxin%nterm = mix%nterm; mxin%family = 0
       mxin%family(1:mix%nterm) = mix%family(1:mix%nterm)
       mxin%lay = c_loc(mix%lay)

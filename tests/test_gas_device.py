@@ -117,7 +117,8 @@ def test_gas_kernel_against_its_host_evaluation(tmp_path, namelist, devices):
     nz, npt = d["nz"], len(d["wl"])
     with DisortFleet(nlyr=nz, nstr=4, nmom=6, temper=np.linspace(220, 290, nz + 1), umu0=0.5, onlyfl=True,
                      level_out=[0, nz], devices=devices) as fl:
-        nk, wt, fail, slots = fl.gas_terms(gas_model(d)[0], d["wl"], d["lay"], want_depths=True)
+        g, img = gas_model(d)                                   # (img: the table image g points into)
+        nk, wt, fail, slots = fl.gas_terms(g, d["wl"], d["lay"], want_depths=True)
     assert np.array_equal(nk, nk_h) and np.array_equal(fail, fail_h)
     scale = np.abs(slots_h).max(axis=2, keepdims=True) + 1e-300
     err = float((np.abs(slots - slots_h) / scale).max())
@@ -142,7 +143,8 @@ def test_solve_with_the_gas_depths_left_on_the_devices(tmp_path):
     for devices in ([0], [0, 0, 0]):
         with DisortFleet(nlyr=nz, nstr=nstr, nmom=nstr + 2, temper=temper, umu0=float(np.cos(np.deg2rad(50.0))), onlyfl=True,
                          level_out=[0, nz], devices=devices) as fl:
-            nk, wt, fail, depths = fl.gas_terms(gas_model(d)[0], d["wl"], d["lay"], want_depths=True)
+            g, img = gas_model(d)
+            nk, wt, fail, depths = fl.gas_terms(g, d["wl"], d["lay"], want_depths=True)
             po = np.repeat(np.arange(npt, dtype=np.int32), nk)
             kt = np.concatenate([np.arange(k, dtype=np.int32) for k in nk])
             w = wt[po, kt]
