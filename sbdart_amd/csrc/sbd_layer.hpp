@@ -34,34 +34,34 @@ struct LayerLds {   // per-group carve-up (doubles)
     }
 };
 
-// Stand-in for LINPACK's condition estimate.  The reference calls SGECO/SGBCO (disutil.f:567-767,
-// 1094-1353) only to test 1 + RCOND == 1 (errmsg 2/3/4: disort.f:3607-3610, 4227, 4333), i.e. "singular
-// to working precision".  The engine stores no L factor, so it looks at the pivots instead: the matrix is
-// flagged when min|pivot| <= 16 eps max|pivot| (eps = 2^-52; until round 4: 8 n eps -- the end-to-end fuzz's last two
-// differing warning-file sets were warning 4 raised at NSTR 16 and 32 for layers with 1 - SSALB ~ 1e-14, where the
-// reference's RCOND stays above eps: tools/warn_probe.py).  For DISORT's systems that is where a
-// single-scattering albedo one ulp below 1 lands (the only way into these warnings with valid input: the
-// dither of disort.f:486 keeps SSALB = 1 itself 200 ulps away, 10-20 times above the threshold), and in
-// that range LINPACK's own estimate flips between warning and not from one ulp to the next.
+// A cheap FILTER for "possibly singular to working precision" in the fast layer kernel (sbd_layer2.hpp), which keeps no
+// LU of the reference's systems: min|pivot| <= thresh max|pivot| over the pivots a group holds.  The reference raises
+// errmsg 3 / 4 iff 1 + RCOND == 1 on LINPACK's estimate (SGECO, disutil.f:1094-1353; disort.f:4227, 4333); RCOND that
+// small needs a pivot ratio orders of magnitude below thresh = 1e-10, so a layer the filter lets through cannot warn,
+// and a layer it catches is handed to layer_kernel below, which factors the reference's own matrix the reference's way
+// and decides on the reference's estimate (rcond_group) -- bit for bit.  (Rounds 1-4 raised the warnings from the filter
+// itself, 16 eps: 799 of 800 random INPUTs then wrote the reference's set of warning files, the one that did not had a
+// thermal layer with 1 - SSALB ~ 1e-14.)
 // pivot: this lane's |pivot|, or a negative number for lanes that hold none; G lanes per matrix.
 template <int G>
-SBD_DEVICE bool near_singular(double pivot, int n)
+SBD_DEVICE bool near_singular(double pivot, double thresh)
 {
     double pmin = (pivot >= 0.0) ? pivot : 1.0e300, pmax = (pivot >= 0.0) ? pivot : 0.0;
     for (int d = G / 2; d >= 1; d >>= 1) {
         pmin = fmin(pmin, __shfl_xor(pmin, d, G));
         pmax = fmax(pmax, __shfl_xor(pmax, d, G));
     }
-    (void)n;
-    return !(pmin > 16.0 * 2.220446049250313e-16 * pmax);
+    return !(pmin > thresh * pmax);
 }
 
-// LU with partial pivoting of the n x n LDS matrix a (SGEFA's pivot rule: first maximal
-// |a(i,k)|, disutil.f:2060-2072).  Lane j owns column j.  Returns non-zero when the matrix is singular
-// to working precision -- see near_singular() below.
+// LU with partial pivoting of the n x n LDS matrix a (SGEFA, disutil.f:1355-1458; pivot rule: first maximal
+// |a(i,k)|, disutil.f:2060-2072; multipliers stored negated).  Lane j owns column j.  No contraction: with the
+// reference's matrix the factors are the reference's, bit for bit (its x86-64 object code has no fused multiply-add).
+// Returns SGEFA's INFO (index of a zero pivot, 0 = none).
 template <int G>
 SBD_DEVICE int lu_factor_group(double *a, int ld, int n, int *ipvt, int g)
 {
+#pragma clang fp contract(off)
 #define A(i, j) a[((j) - 1) * ld + ((i) - 1)]
     const int me = g + 1;
     int info = 0;
@@ -99,9 +99,128 @@ SBD_DEVICE int lu_factor_group(double *a, int ld, int n, int *ipvt, int g)
     if (g == 0) ipvt[n - 1] = n;
     if (A(n, n) == 0.0) info = n;
     wave_lds_sync();
-    // the pivots are U's diagonal, left in place: lane k looks at its own
-    if (near_singular<G>((me <= n) ? fabs(A(me, me)) : -1.0, n)) info = (info != 0) ? info : n;
     return info;
+}
+
+// 1-norm of the n x n LDS matrix a (SGECO's ANORM, disutil.f:1141-1144: the largest SASUM of a column -- SASUM's
+// unrolled sum associates left to right, disutil.f:1651-1666): lane j sums column j, the group takes the maximum.
+// Call BEFORE lu_factor_group.
+template <int G>
+SBD_DEVICE double matrix_norm1_group(const double *a, int ld, int n, int g)
+{
+#pragma clang fp contract(off)
+    const int me = g + 1;
+    double sum = 0.0;
+    if (me <= n)
+        for (int i = 1; i <= n; ++i) sum = sum + fabs(A(i, me));
+    for (int d = G / 2; d >= 1; d >>= 1) sum = fmax(sum, __shfl_xor(sum, d, G));
+    return sum;
+}
+
+// LINPACK's reciprocal condition estimate RCOND (SGECO, disutil.f:1094-1353) from the factors lu_factor_group left in
+// a and the norm of the original matrix: the four triangular solves with their rescalings, statement for statement,
+// by lane 0 of the group (a serial algorithm on a matrix of at most 40 x 40 in LDS; this kernel serves the rare
+// layers the fast kernel lists).  BLAS-1 as the reference has them: SDOT / SASUM accumulate left to right
+// (disutil.f:1651-1666, 1812-1828), SAXPY / SSCAL element by element; no contraction.  z: n doubles of LDS.
+// The reference raises errmsg 3 / 4 iff 1 + RCOND == 1 (disort.f:4227, 4333) -- so does the caller, on this value.
+template <int G>
+SBD_DEVICE double rcond_group(const double *a, int ld, int n, const int *ipvt, double anorm, double *z, int g)
+{
+#pragma clang fp contract(off)
+    double rcond = 0.0;
+    wave_lds_sync();
+    if (g == 0) {
+        auto sasum = [&]() { double t = 0.0; for (int i = 1; i <= n; ++i) t = t + fabs(z[i - 1]); return t; };
+        auto sscal = [&](double sa) { for (int i = 1; i <= n; ++i) z[i - 1] = sa * z[i - 1]; };
+        double ek = 1.0;
+        for (int j = 1; j <= n; ++j) z[j - 1] = 0.0;
+        // solve trans(U) w = e, the components of e chosen to make w grow
+        for (int k = 1; k <= n; ++k) {
+            const double akk = A(k, k);
+            if (z[k - 1] != 0.0) ek = copysign(fabs(ek), -z[k - 1]);
+            if (fabs(ek - z[k - 1]) > fabs(akk)) {
+                const double sc = fabs(akk) / fabs(ek - z[k - 1]);
+                sscal(sc);
+                ek = sc * ek;
+            }
+            double wk = ek - z[k - 1], wkm = -ek - z[k - 1];
+            double sp = fabs(wk), sm = fabs(wkm);
+            if (akk != 0.0) { wk = wk / akk; wkm = wkm / akk; }
+            else { wk = 1.0; wkm = 1.0; }
+            if (k + 1 <= n) {
+                for (int j = k + 1; j <= n; ++j) {
+                    sm = sm + fabs(z[j - 1] + wkm * A(k, j));
+                    z[j - 1] = z[j - 1] + wk * A(k, j);
+                    sp = sp + fabs(z[j - 1]);
+                }
+                if (sp < sm) {
+                    const double t = wkm - wk;
+                    wk = wkm;
+                    for (int j = k + 1; j <= n; ++j) z[j - 1] = z[j - 1] + t * A(k, j);
+                }
+            }
+            z[k - 1] = wk;
+        }
+        sscal(1.0 / sasum());
+        // solve trans(L) y = w
+        for (int kb = 1; kb <= n; ++kb) {
+            const int k = n + 1 - kb;
+            if (k < n) {
+                double dot = 0.0;
+                for (int i = k + 1; i <= n; ++i) dot = dot + A(i, k) * z[i - 1];
+                z[k - 1] = z[k - 1] + dot;
+            }
+            if (fabs(z[k - 1]) > 1.0) sscal(1.0 / fabs(z[k - 1]));
+            const int l = ipvt[k - 1];
+            const double t = z[l - 1];
+            z[l - 1] = z[k - 1];
+            z[k - 1] = t;
+        }
+        sscal(1.0 / sasum());
+        double ynorm = 1.0;
+        // solve L v = y
+        for (int k = 1; k <= n; ++k) {
+            const int l = ipvt[k - 1];
+            const double t = z[l - 1];
+            z[l - 1] = z[k - 1];
+            z[k - 1] = t;
+            if (k < n && t != 0.0)
+                for (int i = k + 1; i <= n; ++i) z[i - 1] = z[i - 1] + t * A(i, k);
+            if (fabs(z[k - 1]) > 1.0) {
+                const double sc = 1.0 / fabs(z[k - 1]);
+                sscal(sc);
+                ynorm = sc * ynorm;
+            }
+        }
+        {
+            const double sc = 1.0 / sasum();
+            sscal(sc);
+            ynorm = sc * ynorm;
+        }
+        // solve U z = v
+        for (int kb = 1; kb <= n; ++kb) {
+            const int k = n + 1 - kb;
+            const double akk = A(k, k);
+            if (fabs(z[k - 1]) > fabs(akk)) {
+                const double sc = fabs(akk) / fabs(z[k - 1]);
+                sscal(sc);
+                ynorm = sc * ynorm;
+            }
+            if (akk != 0.0) z[k - 1] = z[k - 1] / akk;
+            if (akk == 0.0) z[k - 1] = 1.0;
+            const double t = -z[k - 1];
+            if (t != 0.0)
+                for (int i = 1; i <= k - 1; ++i) z[i - 1] = z[i - 1] + t * A(i, k);
+        }
+        {
+            const double sc = 1.0 / sasum();
+            sscal(sc);
+            ynorm = sc * ynorm;
+        }
+        rcond = (anorm != 0.0) ? ynorm / anorm : 0.0;
+    }
+    wave_lds_sync();
+    return __shfl(rcond, 0, G);
 }
 
 // Solve with the factors (SGESL, JOB=0).  bv = this lane's RHS element (lane i <-> b(i));
@@ -109,6 +228,7 @@ SBD_DEVICE int lu_factor_group(double *a, int ld, int n, int *ipvt, int g)
 template <int G>
 SBD_DEVICE double lu_solve_group(const double *a, int ld, int n, const int *ipvt, double bv, int g)
 {
+#pragma clang fp contract(off)
     const int me = g + 1;
     for (int k = 1; k <= n - 1; ++k) {
         const int l = ipvt[k - 1];
@@ -139,6 +259,11 @@ SBD_DEVICE double lu_solve_group(const double *a, int ld, int n, const int *ipvt
 template <int G, bool LIST = false>
 __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32_t *only_flagged)
 {
+    // No contraction in this kernel's own statements: the layers it serves are the ones whose systems are singular to
+    // working precision, where the reference's warnings and rounding follow from ITS sequence of operations -- GL, CC
+    // and the two systems' matrices are formed with one rounding per operation like the reference's object code
+    // (the eigen-solver it calls keeps its own setting: its results are good to rounding either way).
+#pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int GPB = 64 / G;
     const int lane = threadIdx.x;
@@ -199,8 +324,11 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
     const int me = g + 1;
 
     // ---- delta-M scaled Legendre coefficients GL(k) (SETDIS, disort.f:2583-2585) ----
-    const double oprim = sv[o.oprim() + lc - 1];
+    // (OPRIM again from the dithered albedo and F, one rounding per operation: disort.f:2578; the setup kernel's value
+    //  comes from a contracted 1 - F w)
     const double f = sv[o.flyr() + lc - 1];
+    const double wdith = sv[o.ssalb() + lc - 1];
+    const double oprim = wdith * (1.0 - f) / (1.0 - f * wdith);
     {
         const double *pm = P.pmom + (pmom_item(P, slot) * L + (lc - 1)) * (P.nmom + 1);
         if (g < n) {
@@ -316,7 +444,13 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
             zj = (2.0 - delm0) * fbeam * sum / (4.0 * P.pi);
         }
         wave_lds_sync();
-        if (lu_factor_group<G>(lu, ld, n, ipvt, g) != 0) status |= 0x02;
+        {   // SGECO: norm, factors, RCOND; errmsg 3 iff 1 + RCOND == 1 (disort.f:4222-4228)
+            const double anorm = matrix_norm1_group<G>(lu, ld, n, g);
+            wave_lds_sync();
+            (void)lu_factor_group<G>(lu, ld, n, ipvt, g);
+            const double rcond = rcond_group<G>(lu, ld, n, ipvt, anorm, wk, g);
+            if (1.0 + rcond == 1.0) status |= 0x02;
+        }
         zj = lu_solve_group<G>(lu, ld, n, ipvt, zj, g);
         double *zzout = P.zz + ((size_t)ms * L + (lc - 1)) * n;
         if (me <= nn) zzout[me + nn - 1] = zj;
@@ -336,7 +470,13 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
             z1 = (1.0 - oprim) * xr1;
         }
         wave_lds_sync();
-        if (lu_factor_group<G>(lu, ld, n, ipvt, g) != 0) status |= 0x04;
+        {   // SGECO; errmsg 4 iff 1 + RCOND == 1 (disort.f:4328-4334)
+            const double anorm = matrix_norm1_group<G>(lu, ld, n, g);
+            wave_lds_sync();
+            (void)lu_factor_group<G>(lu, ld, n, ipvt, g);
+            const double rcond = rcond_group<G>(lu, ld, n, ipvt, anorm, wk, g);
+            if (1.0 + rcond == 1.0) status |= 0x04;
+        }
         z1 = lu_solve_group<G>(lu, ld, n, ipvt, z1, g);
         if (me <= n) z0 = (1.0 - oprim) * xr0 + cmu[me - 1] * z1;
         z0 = lu_solve_group<G>(lu, ld, n, ipvt, z0, g);

@@ -417,9 +417,11 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
     // quantity cancelling against the homogeneous one, and only the reference's own sequence of
     // operations (SGECO/SGESL on the full NSTR x NSTR system) reproduces its rounding (5e-5 vs 3e-4 of
     // the column maximum for the Cholesky-reuse solve below).  Such layers are rare.
-    // (within 64 ulps of 1: the dithered value and the undithered neighbours of 1, for which the full I - CC
-    //  is singular to working precision and the reference-algorithm kernel raises errmsg 4 from its pivots)
-    const bool hard_thermal = plank && mazim == 0 && ssalb_lc >= 1.0 - 64.0 * 1.1102230246251565e-16;
+    // (within 1024 ulps of 1: the dithered value -- 200 ulps -- and the undithered neighbours of 1, for which the full
+    //  I - CC is singular to working precision; the reference-algorithm kernel forms the reference's matrix the
+    //  reference's way and raises errmsg 4 on LINPACK's own estimate.  Until round 5 the window was 64 ulps and the
+    //  dithered layers were served below: their thermal source came out to 5e-5 of the column maximum only)
+    const bool hard_thermal = plank && mazim == 0 && ssalb_lc >= 1.0 - 1024.0 * 1.1102230246251565e-16;
     if (!spd || P.force_fallback || hard_thermal) {
 #ifdef SBD_L2_DEBUG
         if (g == 0 && blockIdx.x < 8) printf("layer2 list: block %u group %d reason %s\n", blockIdx.x, gi, !spd ? "not SPD" : "thermal/forced");
@@ -810,11 +812,16 @@ __global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1)
     };
     const bool thermal = plank && mazim == 0;
     int status = 0;
-    // errmsg 4 (UPISOT's SGECO, disort.f:4333): the Cholesky pivots of Q+ and Q- (squares of the factors'
-    // diagonals, still in LDS) stand in for the condition estimate, see near_singular() in sbd_layer.hpp
+    // errmsg 4 (UPISOT's SGECO, disort.f:4333): the Cholesky pivots of Q+ and Q- (squares of the factors' diagonals,
+    // still in LDS) are the FILTER (near_singular() in sbd_layer.hpp): a thermal layer whose pivots span ten orders of
+    // magnitude goes to the reference-algorithm kernel, which decides on LINPACK's own estimate
     if (thermal) {
         const double dl = (me <= nn) ? QP(me, me) : 0.0, dc = (me <= nn) ? QM(me, me) : 0.0;
-        if (near_singular<G>((me <= nn) ? dl * dl : -1.0, nn) || near_singular<G>((me <= nn) ? dc * dc : -1.0, nn)) status |= 0x04;
+        const bool suspect = near_singular<G>((me <= nn) ? dl * dl : -1.0, 1.0e-10) || near_singular<G>((me <= nn) ? dc * dc : -1.0, 1.0e-10);
+        if (suspect) {
+            if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;
+            return;
+        }
         wave_lds_sync();                                 // (the pivots were read from the area that now turns scratch)
     }
     const double rme = (me <= nn) ? srr[me - 1] : 1.0, rw = (me <= nn) ? srr[me - 1] * swi[me - 1] : 0.0;

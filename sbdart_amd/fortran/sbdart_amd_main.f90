@@ -468,6 +468,11 @@ subroutine run_once(phase)
     call solve_part(1, ncorr, .true., corint)
     if (.not. aborted) call solve_part(ncorr + 1, nbeam, .true., .false.)
     if (.not. aborted) call solve_part(nbeam + 1, npart, .false., .false.)
+    ! (an item CHEKIN refused: its report below wants the item's arguments -- the gas depths come back from the
+    !  devices while their engines still exist)
+    if (gas_dev .and. .not. aborted) then
+      if (any(iand(status(1:npart), SBD_ST_ERR_INPUT) /= 0)) call gas_terms_on(gas_fleet, .true.)
+    end if
     if (phase == 0) call release_fleets()               ! (a batch keeps its fleets for the runs that follow)
     if (aborted) return
   end if
@@ -938,8 +943,7 @@ contains
     nbad = 0
     if (ipk > 0 .and. use_mix) then                      ! the item's arguments as the device formed them
       allocate(one_dtau(nz), one_ssalb(nz), one_pmom(0:nmom, nz))
-      if (gas_dev) then                                  ! (the item's gas depths, back from the device for this report)
-        call gas_terms_on(gas_fleet, .true.)
+      if (gas_dev) then                                  ! (the item's gas depths: fetched from the devices after the solves)
         call assemble_item(mix, int(pmom_row(ipk)) + 1, gas_depths(:, kterm(ipk) + 1, int(pmom_row(ipk)) + 1), nmom, &
                            one_dtau, one_ssalb, one_pmom)
       else
