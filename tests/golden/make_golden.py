@@ -112,6 +112,53 @@ def main():
          ["idatm=6 wlinf=.25 wlsup=100 wlinc=20 nstr=32 ngrid=50 iout=10 sza=30"],
          lambda r: every_nth_wl(r, 250, 7), keep_stdout=False)
 
+    # --- round 5 ("full in shape, thin in extent"): BASELINE configs[3] across its whole spectral
+    #     range -- one record per wavelength of a 26-point sub-grid of 0.25-4.0 um (the point's last k-term: the
+    #     strongest absorption), NSTR 32, 20 x 16 angles, rural aerosol; thermal source switched on by the reference
+    #     itself above 2 um --
+    def last_term_of_each_point(recs):
+        out = {}
+        for r in recs:
+            out[r.iwl] = r
+        return [out[k] for k in sorted(out)]
+    emit("cfgC_rad_nstr32_wide",
+         ["idatm=6 wlinf=.25 wlsup=4.0 wlinc=.15 iout=5 nstr=32 iaer=1 vis=23 nzen=20 uzen=0,85 nphi=16 phi=0,180 sza=30"],
+         last_term_of_each_point, keep_stdout=False)
+    #     ... and configs[4] at its finest spectral step (1 cm-1) in the thermal tail, 20-25 um: every fourth point
+    emit("cfgD_thermal_tail_1cm",
+         ["idatm=6 wlinf=20 wlsup=25 wlinc=1.0001 nstr=32 ngrid=50 iout=10 sza=30"],
+         lambda r: every_nth_wl(r, 4, 1), keep_stdout=False)
+    #     ... and the conservative-thermal class (SSALB = 1 exactly in a layer with a thermal source: DISORT dithers it
+    #     to 1 - 2.2e-14, I - CC is singular to ten digits and the particular solution cancels against the homogeneous
+    #     one) as REFERENCE records: the reference's DISORT called directly (oracle/_ref/disort_ref_cli) on synthetic
+    #     columns -- one to five layers, optical depths 0.1 to 50, NSTR 4 to 32, the conservative layer in the middle,
+    #     at the top and at the bottom, with and without a beam
+    if not only or "conservative_thermal" in only:
+        import numpy as np
+        from sbdart_amd.records import F_LAMBER, F_ONLYFL, F_PLANK, SolveRecord
+        recs = []
+        for nstr in (4, 8, 16, 24, 32):
+            k = np.arange(nstr + 3)
+            for nlyr, tau, where, fbeam in ((3, 0.1, 1, 1.0), (3, 1.0, 1, 1.0), (1, 10.0, 0, 1.0), (5, 50.0, 2, 0.0), (4, 2.0, 0, 1.0),
+                                            (4, 0.5, 3, 0.0)):
+                ss = np.full(nlyr, 0.5)
+                ss[where] = 1.0
+                recs.append(SolveRecord(nlyr=nlyr, nstr=nstr, nmom=nstr + 2, flags=F_LAMBER | F_PLANK | F_ONLYFL, wvnmlo=900.0,
+                                        wvnmhi=950.0, fbeam=fbeam, umu0=0.6, phi0=0.0, albedo=0.3, btemp=300.0, ttemp=200.0, temis=0.5,
+                                        dtauc=np.full(nlyr, tau), ssalb=ss, temper=np.linspace(220.0, 295.0, nlyr + 1),
+                                        pmom=np.full(nlyr, 0.6)[:, None] ** k[None, :], umu=np.zeros(0), phi=np.zeros(0)))
+        with tempfile.TemporaryDirectory() as d:
+            write_records(os.path.join(d, "in.sbdrec"), recs, with_out=False)
+            subprocess.run([os.path.join(ROOT, "oracle", "_ref", "disort_ref_cli"), "in.sbdrec", "out.sbdrec", "1"],
+                           cwd=d, check=True, capture_output=True)
+            out = read_records(os.path.join(d, "out.sbdrec"))
+        path = os.path.join(HERE, "conservative_thermal.sbdrec")
+        write_records(path, out, with_out=True)
+        manifest["conservative_thermal"] = {"namelists": ["(disort_ref_cli on synthetic columns with SSALB = 1 in one layer and a thermal source)"],
+                                            "records": len(out), "bytes": os.path.getsize(path),
+                                            "sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "reference_warnings": []}
+        print("conservative_thermal", len(out), "records")
+
     # --- intensity corrections (CORINT = true: 299 phase-function moments per layer), one record each:
     #     a cloud seen from below and above incl. the solar aureole (IMS term, viewing angles within 10
     #     degrees of the beam), rural aerosol, and a thermal + solar point over a bright surface
