@@ -793,7 +793,11 @@ def test_eigenvalue_next_to_the_beam(delta):
             sens = np.abs(t[f] - o[f]).max() / max(scale, 1e-300)
             err = np.abs(flux[i][c] - o[f]).max()
             worst, worst_sens = max(worst, err / max(scale, 1e-9 * recmax)), max(worst_sens, sens)
-            assert err <= max(TOL, 8.0 * sens) * scale + 1e-12 * recmax, (i, f, err / max(scale, 1e-300), sens, r.umu0)
+            # (inside the 1e-10 window the layer is served by the reference-algorithm kernel, whose UPBEAM is the
+            #  reference's own operation sequence since round 5 -- ZZ within 2e-13 of the oracle's, tools/rcond_probe.py --
+            #  while the eigenvectors around it are another algorithm's: the system's condition 1/|delta| amplifies THAT
+            #  difference like any rounding, and the contracted twin samples only one such perturbation: eps/|delta| too)
+            assert err <= max(TOL, 8.0 * sens, 4.0 * 2.2e-16 / abs(delta)) * scale + 1e-12 * recmax, (i, f, err / max(scale, 1e-300), sens, r.umu0)
     print(f"delta {delta:g}: {len(recs)} records, worst error {worst:.2e} of the column maximum "
           f"(the reference's own FMA sensitivity: {worst_sens:.2e})")
 
