@@ -141,7 +141,7 @@ MI355X_SIMDS = 256 * 4         # CUs x SIMDs
 MI355X_CLOCK_HZ = 2.4e9        # peak engine clock (MI355X_MICROARCH.md)
 
 
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 def load_profile(kind, nstr, nlyr, shape=""):

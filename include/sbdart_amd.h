@@ -279,7 +279,8 @@ int      sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_
  XX  Returns
  * per point nk (1 or 3 k-terms), wt [npoint][3] the terms' weights (depthscl's wt: 1 when nk = 1), and taucor's
  * failures as SBD_ST_ERR_INPUT-free status: fail [npoint] 1 where the reference would stop ("TAUCOR: iteration did
- * not converge"), may be NULL.  The depths stay on the devices for sbd_fleet_solve_mix_host with dtaug == NULL.
+ * not converge"), may be NULL.  The depths stay on the devices for sbd_fleet_solve_mix_host with dtaug == NULL -- and so do
+ * the layer blocks: a solve that passes the SAME lay array (unchanged in between) does not send them over PCIe again.
  * dtaug_out, if not NULL: [npoint][3][nlyr] the terms' gas depths copied back (tests, IOUT-independent inspection). */
 int      sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, const double *wl, const double *lay,
                              int32_t nch, int32_t *nk, double *wt, int32_t *fail, double *dtaug_out);

@@ -195,7 +195,7 @@ __device__ __forceinline__ double powi_like_fortran(double a, int b)
 }
 struct MixFamilies { int32_t f[SBD_MIX_MAX_TERMS]; };
 // point blocks: lay[(p - pbase)][4 + 3 nterm][L]; outputs: dtauc / ssalb [item], pmom [(p - pbase)], pmom_row = p - pbase
-__global__ void __launch_bounds__(64) assemble_kernel(int w0, int nitem, int L, int nmom, int first_point_done, int pbase,
+__global__ void __launch_bounds__(64) assemble_kernel(int w0, int nitem, int L, int nmom, int first_point_done, int pbase, int lay_base,
                                                       int nterm, MixFamilies fam, const int32_t *kterm, const double *gslots, int gas_p0,
                                                       const int32_t *point_of, const double *dtaug, const double *lay,
                                                       const double *plo, const double *phi_, const double *pfb, const double *pal,
@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(64) assemble_kernel(int w0, int nitem, int L, 
     // the point's moments: by its first item in this launch -- unless the launch before already made them
     const bool first = (blockIdx.x == 0) ? (first_point_done == 0) : (point_of[w - 1] - pbase != p);
     const int nch = 4 + 3 * nterm;
-    const double *blk = lay + (size_t)p * nch * L;
+    const double *blk = lay + (size_t)(point_of[w] - lay_base) * nch * L;       // (staged per call from pbase, or the gas call's resident copy)
     // the item's gas: from the host (dtaug), or what the gas kernel left on this device for (point, k-term)
     const double *gas = gslots ? gslots + ((size_t)(point_of[w] - gas_p0) * 3 + kterm[w]) * L : dtaug + (size_t)w * L;
     for (int l = threadIdx.x; l < L; l += blockDim.x) {
@@ -354,6 +354,9 @@ struct sbd_engine {
     // the gas depths sbd_fleet_gas_terms left on this device: [gas_np][3][L] for the points gas_p0 .. gas_p0 + gas_np - 1 of that call
     double *d_gas_slots = nullptr;
     int32_t gas_p0 = 0, gas_np = 0;
+    double *d_gas_lay = nullptr;    // ... and those points' layer blocks [gas_np][gas_nch][L], kept for the solves that follow
+    int32_t gas_nch = 0;
+    const double *gas_lay_host = nullptr;   // (the caller's array they were copied from: a solve that passes the same one need not copy again)
     int64_t fallback_layers = 0;    // timing mode: (item, mode, layer) problems of the last solve left to the QR kernel
 };
 
@@ -385,6 +388,7 @@ void sbd_engine_destroy(sbd_engine *e)
     if (e->d_ws) (void)hipFree(e->d_ws);
     if (e->d_stage) (void)hipFree(e->d_stage);
     if (e->d_gas_slots) (void)hipFree(e->d_gas_slots);
+    if (e->d_gas_lay) (void)hipFree(e->d_gas_lay);
     if (e->h_pin) (void)hipHostFree(e->h_pin);
     if (e->h_hint) (void)hipHostFree(e->h_hint);
     if (e->d_partial) (void)hipFree(e->d_partial);
@@ -944,6 +948,8 @@ struct MixStage {               // device staging of a compact batch (sbd_mix_in
     double *dtaug, *lay, *lo, *hi, *fb, *al;
     uint8_t *pl;
     int32_t pbase;              // first spectral point the call's items refer to: staged block q holds point pbase + q
+    int32_t lay_base;           // ... and the point whose layer block is block 0 of `lay` (pbase, or the gas call's first point)
+    bool lay_resident;          // the layer blocks are already on the device (sbd_fleet_gas_terms kept them)
 };
 struct HostSide {
     const sbd_batch_in *in;     // host inputs (NULL members never occur: checked by the callers)
@@ -1103,7 +1109,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             else HIP_TRY(hipMemcpyAsync(d.kterm + w0, m->kterm + w0, sizeof(int32_t) * ns, hipMemcpyHostToDevice, cs));
             if (nq > 0) {
                 const int s0 = q0 - d.pbase;                               // (staged block index)
-                HIP_TRY(hipMemcpyAsync(d.lay + (size_t)s0 * blk, m->lay + (size_t)q0 * blk, sizeof(double) * nq * blk, hipMemcpyHostToDevice, cs));
+                if (!d.lay_resident) HIP_TRY(hipMemcpyAsync(d.lay + (size_t)s0 * blk, m->lay + (size_t)q0 * blk, sizeof(double) * nq * blk, hipMemcpyHostToDevice, cs));
                 const std::pair<double *, const double *> sc[4] = {{d.lo, m->wvnmlo}, {d.hi, m->wvnmhi}, {d.fb, m->fbeam}, {d.al, m->albedo}};
                 for (const auto &a : sc)
                     HIP_TRY(hipMemcpyAsync(a.first + s0, a.second + q0, sizeof(double) * nq, hipMemcpyHostToDevice, cs));
@@ -1112,7 +1118,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             MixFamilies fam;
             for (int t = 0; t < SBD_MIX_MAX_TERMS; ++t) fam.f[t] = m->family[t];
             hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)ns), dim3(64), 0, cs, w0, ns, L, e->cfg.nmom, done ? 1 : 0,
-                               (int)d.pbase, (int)m->nterm, fam, (const int32_t *)d.kterm, (const double *)(m->dtaug ? nullptr : e->d_gas_slots), (int)e->gas_p0,
+                               (int)d.pbase, (int)d.lay_base, (int)m->nterm, fam, (const int32_t *)d.kterm, (const double *)(m->dtaug ? nullptr : e->d_gas_slots), (int)e->gas_p0,
                                (const int32_t *)d.point_of, (const double *)d.dtaug, (const double *)d.lay, (const double *)d.lo, (const double *)d.hi,
                                (const double *)d.fb, (const double *)d.al, (const uint8_t *)d.pl,
                                (double *)in->dtauc, (double *)in->ssalb, (double *)in->pmom, (int32_t *)in->pmom_row,
@@ -1466,6 +1472,13 @@ static int solve_mix_host_enqueue(sbd_engine *e, const sbd_mix_in *m, const sbd_
     hs.ms.kterm = (int32_t *)take(sizeof(int32_t) * W);
     hs.ms.dtaug = (double *)take(b_lay);
     hs.ms.lay = (double *)take(b_blk);
+    hs.ms.lay_base = pbase;
+    hs.ms.lay_resident = false;
+    if (!m->dtaug && e->d_gas_lay && e->gas_lay_host == m->lay + (size_t)e->gas_p0 * (4 + 3 * m->nterm) * L && e->gas_nch == 4 + 3 * m->nterm) {
+        hs.ms.lay = e->d_gas_lay;                   // the very blocks the gas call copied: no second trip over PCIe
+        hs.ms.lay_base = e->gas_p0;
+        hs.ms.lay_resident = true;
+    }
     hs.ms.lo = (double *)take(b_p); hs.ms.hi = (double *)take(b_p); hs.ms.fb = (double *)take(b_p); hs.ms.al = (double *)take(b_p);
     hs.ms.pl = (uint8_t *)take(NP);
     hipStream_t st = e->stream;
@@ -1975,7 +1988,8 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
         };
         if (bad(hipSetDevice(e->cfg.device), "hipSetDevice")) return;
         if (e->d_gas_slots) { (void)hipFree(e->d_gas_slots); e->d_gas_slots = nullptr; }
-        e->gas_p0 = lo; e->gas_np = 0;
+        if (e->d_gas_lay) { (void)hipFree(e->d_gas_lay); e->d_gas_lay = nullptr; }
+        e->gas_p0 = lo; e->gas_np = 0; e->gas_nch = 0; e->gas_lay_host = nullptr;
         if (np <= 0) return;
         const size_t npad = ((size_t)np + 63) & ~(size_t)63;
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1987,13 +2001,14 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
         auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count(); };
         double t_alloc = 0, t_h2d = 0, t_kernel = 0;
         char *tmp = nullptr;
-        if (bad(hipMalloc(&tmp, b_td + b_ti + b_uu + b_z + b_wl + b_lay + b_ws + 2 * b_nk + b_wt), "hipMalloc(gas work area)")) return;
+        if (bad(hipMalloc(&tmp, b_td + b_ti + b_uu + b_z + b_wl + b_ws + 2 * b_nk + b_wt), "hipMalloc(gas work area)")) return;
         if (bad(hipMalloc(&e->d_gas_slots, 8 * (size_t)np * 3 * L), "hipMalloc(gas depths)")) { (void)hipFree(tmp); return; }
+        if (bad(hipMalloc(&e->d_gas_lay, b_lay), "hipMalloc(layer blocks)")) { (void)hipFree(tmp); (void)hipFree(e->d_gas_slots); e->d_gas_slots = nullptr; return; }
         char *q = tmp;
         auto take = [&](size_t b) { char *x = q; q += b; return x; };
         double *d_td = (double *)take(b_td);
         int32_t *d_ti = (int32_t *)take(b_ti);
-        double *d_uu = (double *)take(b_uu), *d_z = (double *)take(b_z), *d_wl = (double *)take(b_wl), *d_lay = (double *)take(b_lay);
+        double *d_uu = (double *)take(b_uu), *d_z = (double *)take(b_z), *d_wl = (double *)take(b_wl), *d_lay = e->d_gas_lay;
         double *d_ws = (double *)take(b_ws);
         int32_t *d_nk = (int32_t *)take(b_nk), *d_fail = (int32_t *)take(b_nk);
         double *d_wt = (double *)take(b_wt);
@@ -2027,8 +2042,11 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
         (void)hipFree(tmp);
         if (timing) fprintf(stderr, "sbdart_amd: gas terms on device %d: %d points; alloc %.2f ms, H2D %.2f ms, gas_kernel %.2f ms, D2H %.2f ms, free %.2f ms\n",
                             e->cfg.device, np, t_alloc, t_h2d - t_alloc, t_kernel - t_h2d, t_d2h - t_kernel, since() - t_d2h);
-        if (rcs[r] == SBD_OK) e->gas_np = np;
-        else if (e->d_gas_slots) { (void)hipFree(e->d_gas_slots); e->d_gas_slots = nullptr; }
+        if (rcs[r] == SBD_OK) { e->gas_np = np; e->gas_nch = nch; e->gas_lay_host = lay + (size_t)lo * nch * L; }
+        else {
+            if (e->d_gas_slots) { (void)hipFree(e->d_gas_slots); e->d_gas_slots = nullptr; }
+            if (e->d_gas_lay) { (void)hipFree(e->d_gas_lay); e->d_gas_lay = nullptr; }
+        }
     };
     if (nd > 1) {
         std::vector<std::thread> th;

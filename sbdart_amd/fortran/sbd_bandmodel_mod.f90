@@ -496,7 +496,7 @@ contains
     ! and batch arrays, not arithmetic, set the pace beyond that)
     nthreads = max(1, min(omp_get_max_threads(), grid%n/64, 16))
     call system_clock(tk(2))
-    !$omp parallel do schedule(dynamic, 16) num_threads(nthreads) proc_bind(spread)
+    !$omp parallel do schedule(dynamic, 16) num_threads(nthreads)
     do iwl = 1, grid%n
       call one_wavelength(iwl)
     end do

@@ -75,6 +75,10 @@ int sbd_px_stdout_restore(int fd)
     return 0;
 }
 
+/* an environment variable the user has not set: the OpenMP runtime reads its own when it first starts */
+#include <stdlib.h>
+int sbd_px_setenv_default(const char *name, const char *value) { return setenv(name, value, 0); }
+
 void sbd_px_usleep(int us) { usleep((useconds_t)us); }
 
 int sbd_px_ncpu(void)

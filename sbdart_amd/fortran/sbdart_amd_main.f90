@@ -1342,11 +1342,22 @@ end subroutine
 end module sbd_run_mod
 
 program sbdart_amd
+  use iso_c_binding
   use sbd_run_mod
   implicit none
   character(len=1024) :: arg, list
   integer :: n
+  interface
+    integer(c_int) function sbd_px_setenv_default(name, value) bind(C, name='sbd_px_setenv_default')
+      use iso_c_binding
+      character(kind=c_char), intent(in) :: name(*), value(*)
+    end function
+  end interface
   call system_clock(tick_program)
+  ! The OpenMP runtime's first act is to map the machine's topology for thread affinity: 35-70 ms on the 256-core GPU
+  ! box (profiles/r05_e2e_omp_init.txt) -- ten times the band model's wavelength loop, which needs no placement.
+  ! Unless the user says otherwise, affinity is off.
+  n = sbd_px_setenv_default('KMP_AFFINITY'//c_null_char, 'disabled'//c_null_char)
   n = command_argument_count()
   if (n >= 2) then
     call get_command_argument(1, arg)

@@ -27,10 +27,14 @@ TOL_CONSERVATIVE_THERMAL = 6e-5   # measured <= 5.1e-5, see test_fuzz_all_stream
 FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "*.sbdrec")) if "albtrn" not in f)   # (IBCND = 1: its own test)
 
 
-def _check(flux, uu, st, recs, outs, tol=TOL, key=None):
-    """Absolute gate per array, then the ratchet on the worst normalised error of the whole comparison (`key`)."""
+def _check(flux, uu, st, recs, outs, tol=TOL, key=None, sens=None):
+    """Absolute gate per array, then the ratchet on the worst normalised error of the whole comparison (`key`).
+    sens[i] (optional): the reference's OWN sensitivity of record i to the rounding of its arithmetic (its FMA-contracted
+    twin against itself, pyoracle.disort(perturbed=True)); the record's gate is then max(tol, 8 sens[i])."""
     worst = 0.0
+    tol0 = tol
     for i, (r, o) in enumerate(zip(recs, outs)):
+        tol = tol0 if sens is None else max(tol0, 8.0 * sens[i])
         assert st[i] == o.get("status", 0), (i, st[i], o.get("status"))   # warnings 2/3/4/9 included
         recmax = max(max(np.abs(o[f]).max() for f in FLUX), 1e-300)
         for c, f in enumerate(FLUX):
@@ -60,7 +64,25 @@ def test_engine_matches_reference_records(path):
     flux, uu, st = solve_records(recs)
     outs = [dict(rfldir=r.rfldir, rfldn=r.rfldn, flup=r.flup, dfdt=r.dfdt, uavg=r.uavg, uu=r.uu,
                  status=0) for r in recs]
-    _check(flux, uu, st, recs, outs, key="records/" + os.path.basename(path))
+    _check(flux, uu, st, recs, outs, key="records/" + os.path.basename(path), sens=_own_sensitivity(path, recs))
+
+
+# BASELINE configs[4] at 1 cm-1 in the thermal tail (20-25 um, NSTR 32, 50 layers, top layers of optical depth 1e-14): the
+# reference's own fluxes move by up to 3.1e-6 of the column maximum when its arithmetic is contracted (8 of the 75 records
+# above 1.4e-6) -- more than this file's gate.  Such records are gated at 8 x their own sensitivity, like
+# tests/golden/illcond (test_ill_conditioned_records).
+SENSITIVE_FILES = ("cfgD_thermal_tail_1cm.sbdrec",)
+
+
+def _own_sensitivity(path, recs):
+    if os.path.basename(path) not in SENSITIVE_FILES:
+        return None
+    import pyoracle
+    out = []
+    for r in recs:
+        o, t = pyoracle.disort(r), pyoracle.disort(r, perturbed=True)
+        out.append(max(float(np.abs(t[f] - o[f]).max() / max(np.abs(o[f]).max(), 1e-300)) for f in FLUX))
+    return out
 
 
 def _edge_records():
@@ -277,18 +299,25 @@ def test_two_level_fused_path_matches_reference_records(path):
     recs = [r for r in read_records(path) if r.onlyfl]
     if not recs:
         pytest.skip("no flux-only record in this file")
-    L = recs[0].nlyr
-    flux, _, st = solve_records(recs, level_out=[0, L])
+    sens = _own_sensitivity(path, recs)
+    flux = [None] * len(recs)
+    st = [0] * len(recs)
+    for L in sorted({r.nlyr for r in recs}):                      # (a file may hold columns of several depths)
+        idx = [i for i, r in enumerate(recs) if r.nlyr == L]
+        f_, _, s_ = solve_records([recs[i] for i in idx], level_out=[0, L])
+        for k, i in enumerate(idx):
+            flux[i], st[i] = f_[k], s_[k]
     worst = 0.0
     for i, r in enumerate(recs):
         assert st[i] == 0
+        tol = TOL if sens is None else max(TOL, 8.0 * sens[i])
         recmax = max(max(np.abs(getattr(r, f)).max() for f in FLUX), 1e-300)
         for c, f in enumerate(FLUX):
             ref = getattr(r, f)
             scale = np.abs(ref).max()
             err = np.abs(flux[i][c] - ref[[0, -1]]).max()
             worst = max(worst, normalised(err, scale, recmax))
-            assert err <= TOL * scale + 1e-12 * recmax, (i, f, err, scale)
+            assert err <= tol * scale + 1e-12 * recmax, (i, f, err, scale)
     print(f"{os.path.basename(path)}: worst two-level error {worst:.2e} (normalised)")
     ratchet("two_level/" + os.path.basename(path), worst)
 
