@@ -321,6 +321,9 @@ int         sbd_engine_quadrature(const sbd_engine *e, double *cmu, double *cwt)
  * events on the stream the kernels ran on; phase: 0 setup, 1 layer, 2 band LU,
  * 3 back-substitution + fluxes, 4 intensities, -1 total.  Synchronises the stream. */
 double      sbd_engine_last_ms(sbd_engine *e, int phase);
+/* on = 1: ONE stream, a synchronisation per pass -- each kernel family alone on the chip; on = 2: the events are recorded
+ * where the passes run (two streams, a pass's kernels beside the other pass's) and read at the next sbd_engine_last_ms:
+ * the durations a kernel trace of the same call shows; 0: off */
 void        sbd_engine_enable_timing(sbd_engine *e, int on);
 /* timing mode: number of (item, mode, layer) eigenproblems of the last solve that the fast layer kernel handed
  * to the reference-algorithm kernel (not positive definite after symmetrisation, no Jacobi convergence, thermal

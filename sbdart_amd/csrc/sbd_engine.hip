@@ -325,7 +325,12 @@ struct sbd_engine {
     double *d_acc = nullptr;      // [5*nlev + nphi*nlev*numu] weighted sums of the last fleet solve
     double *d_red = nullptr;      // same size: RCCL reduce result (root)
     // timing
-    bool timing = false;
+    bool timing = false;            // per-kernel HIP events, ONE stream, a synchronisation per pass (the kernels of a pass alone on the chip)
+    bool timing_inplace = false;    // ... or the events recorded where the passes run -- two streams, a pass's kernels beside the other
+                                    // pass's -- and read afterwards: the durations rocprofv3's kernel trace of the same command shows
+    std::vector<hipEvent_t> ev_ip;  // [pass][kPhases + 1]
+    int ip_npass = 0;
+    bool ip_pending = false;
     static constexpr int kPhases = 5;   // setup, layer, band LU, back-substitution + fluxes, intensities
     hipEvent_t ev[kPhases + 1] = {};
     float ms_phase[kPhases] = {};
@@ -389,6 +394,7 @@ void sbd_engine_destroy(sbd_engine *e)
     if (e->d_stage) (void)hipFree(e->d_stage);
     if (e->d_gas_slots) (void)hipFree(e->d_gas_slots);
     if (e->d_gas_lay) (void)hipFree(e->d_gas_lay);
+    for (hipEvent_t ev : e->ev_ip) (void)hipEventDestroy(ev);
     if (e->h_pin) (void)hipHostFree(e->h_pin);
     if (e->h_hint) (void)hipHostFree(e->h_hint);
     if (e->d_partial) (void)hipFree(e->d_partial);
@@ -835,7 +841,7 @@ int32_t sbd_engine_nlevel(const sbd_engine *e) { return e ? e->nlev : 0; }
 size_t sbd_engine_workspace_bytes(const sbd_engine *e) { return e ? e->ws_bytes : 0; }
 int32_t sbd_engine_chunk(const sbd_engine *e) { return e ? e->chunk : 0; }
 void *sbd_engine_stream(sbd_engine *e) { return e ? (void *)e->stream : nullptr; }
-void sbd_engine_enable_timing(sbd_engine *e, int on) { if (e) e->timing = on != 0; }
+void sbd_engine_enable_timing(sbd_engine *e, int on) { if (e) { e->timing = on == 1; e->timing_inplace = on == 2; if (!on) e->have_times = false; } }
 
 int sbd_engine_quadrature(const sbd_engine *e, double *cmu, double *cwt)
 {
@@ -880,6 +886,23 @@ int64_t sbd_engine_last_fallback_layers(sbd_engine *e) { return (e && e->have_ti
 
 double sbd_engine_last_ms(sbd_engine *e, int phase)
 {
+    if (e && e->ip_pending) {                 // in-place events of the last solve: read them now that they are asked for
+        e->ip_pending = false;
+        (void)hipSetDevice(e->cfg.device);
+        bool ok = true;
+        for (float &m : e->ms_phase) m = 0.f;
+        for (int ip = 0; ip < e->ip_npass && ok; ++ip) {
+            ok = hipEventSynchronize(e->ev_ip[(size_t)ip * (sbd_engine::kPhases + 1) + sbd_engine::kPhases]) == hipSuccess;
+            for (int ph = 0; ph < sbd_engine::kPhases && ok; ++ph) {
+                float ms = 0.f;
+                ok = hipEventElapsedTime(&ms, e->ev_ip[(size_t)ip * (sbd_engine::kPhases + 1) + ph], e->ev_ip[(size_t)ip * (sbd_engine::kPhases + 1) + ph + 1]) == hipSuccess;
+                e->ms_phase[ph] += ms;
+            }
+        }
+        if (!ok) (void)hipGetLastError();
+        e->fallback_layers = -1;
+        e->have_times = ok;
+    }
     if (!e || !e->have_times) return -1.0;
     if (phase < 0) {
         double t = 0.0;
@@ -1042,6 +1065,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : e->stream;
     const int L = e->L, n = e->n, nmode = e->nmode, nlev = e->nlev;
     const bool timing = e->timing;
+    const bool tip = e->timing_inplace && !timing;
     const bool dbg = getenv("SBD_DEBUG_SYNC") != nullptr;
 #define SBD_DBG(tag) do { if (dbg) { hipError_t de_ = hipStreamSynchronize(st); fprintf(stderr, "[sbd] %s: %s (eigflag=%p partial=%p ws=%p..%p)\n", tag, hipGetErrorString(de_), (void*)e->d_eigflag, (void*)e->d_partial, (void*)e->d_ws, (void*)(e->d_ws + e->ws_bytes)); } } while (0)
     float acc_ms[sbd_engine::kPhases] = {};
@@ -1167,6 +1191,16 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         const int rc0 = copy_pass(0);
         if (rc0 != SBD_OK) return rc0;
     }
+    if (tip) {
+        while (e->ev_ip.size() < (size_t)npass_run * (sbd_engine::kPhases + 1)) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreate(&ev));
+            e->ev_ip.push_back(ev);
+        }
+        e->ip_npass = npass_run;
+        e->ip_pending = true;
+        e->have_times = false;
+    }
     for (int ipass = 0; ipass < npass_run; ++ipass) {
         const int w0 = pw0[ipass], ns = pw0[ipass + 1] - w0;
         const bool second = (ipass & 1) != 0;
@@ -1188,13 +1222,13 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
         P.uu = rad ? out->uu + (size_t)w0 * e->P.nphi * nlev * e->P.numu : nullptr;
         P.status = out->status + w0;
 
-        if (timing) HIP_TRY(hipEventRecord(e->ev[0], st));
+        if (timing) HIP_TRY(hipEventRecord(e->ev[0], st)); else if (tip) HIP_TRY(hipEventRecord(e->ev_ip[(size_t)ipass * (sbd_engine::kPhases + 1) + 0], st));
         sbd::launch_setup((unsigned)ns, st, P);
         if (P.ibdrf && !P.brdf_shared)      // the ocean's SURFAC tables and CHEKIN's test of them, per item and mode
             hipLaunchKernelGGL(sbd::surfac_kernel, dim3((unsigned)((size_t)ns * nmode)), dim3(256),
                                sizeof(double) * sbd::surf_lds_doubles(e->nn, e->P.numu), st, P, (int32_t *)nullptr);
         SBD_DBG("setup");
-        if (timing) HIP_TRY(hipEventRecord(e->ev[1], st));
+        if (timing) HIP_TRY(hipEventRecord(e->ev[1], st)); else if (tip) HIP_TRY(hipEventRecord(e->ev_ip[(size_t)ipass * (sbd_engine::kPhases + 1) + 1], st));
         {
             const int gpb = 64 / e->G;
             const long long groups = (long long)ns * nmode * L;
@@ -1220,7 +1254,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             sbd::launch_layer_v1(e->G, grid, e->layer_lds, st, P, flt);
         }
         SBD_DBG("layer(v1/fallback)");
-        if (timing) HIP_TRY(hipEventRecord(e->ev[2], st));
+        if (timing) HIP_TRY(hipEventRecord(e->ev[2], st)); else if (tip) HIP_TRY(hipEventRecord(e->ev_ip[(size_t)ipass * (sbd_engine::kPhases + 1) + 2], st));
         {
             const unsigned bgrid = (unsigned)((size_t)ns * nmode);
             if (e->band4 && e->d_pivdbg) {
@@ -1233,13 +1267,13 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             else sbd::launch_band_lds(e->nn, bgrid, e->band_lds, st, P);
         }
         SBD_DBG("band");
-        if (timing) HIP_TRY(hipEventRecord(e->ev[3], st));
+        if (timing) HIP_TRY(hipEventRecord(e->ev[3], st)); else if (tip) HIP_TRY(hipEventRecord(e->ev_ip[(size_t)ipass * (sbd_engine::kPhases + 1) + 3], st));
         if (e->fused) { /* the band kernel has written the fluxes */ }
         else if (e->band4) sbd::launch_backsolve4(e->nn, (unsigned)(((size_t)ns * nmode + 3) / 4), st, P);
         else if (e->band1 && !e->solve_v1) sbd::launch_backsolve1(e->nn, (unsigned)((size_t)ns * nmode), st, P);
         else sbd::launch_backsolve(e->nn, (unsigned)((size_t)ns * nmode), e->solve_lds, st, P);
         SBD_DBG("backsolve");
-        if (timing) HIP_TRY(hipEventRecord(e->ev[4], st));
+        if (timing) HIP_TRY(hipEventRecord(e->ev[4], st)); else if (tip) HIP_TRY(hipEventRecord(e->ev_ip[(size_t)ipass * (sbd_engine::kPhases + 1) + 4], st));
         if (rad) {
             if (e->quad) sbd::launch_cmpint((unsigned)((size_t)ns * nmode), st, P);
             else sbd::launch_usrint((unsigned)((size_t)ns * nmode), e->usr_lds, st, P);
@@ -1255,7 +1289,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             if (rad && hs->out->uu) HIP_TRY(hipMemcpyAsync(hs->out->uu + (size_t)w0 * nu, P.uu, sizeof(double) * ns * nu, hipMemcpyDeviceToHost, st));
             if (hs->out->status) HIP_TRY(hipMemcpyAsync(hs->out->status + w0, P.status, sizeof(int32_t) * ns, hipMemcpyDeviceToHost, st));
         }
-        if (timing) HIP_TRY(hipEventRecord(e->ev[5], st));
+        if (timing) HIP_TRY(hipEventRecord(e->ev[5], st)); else if (tip) HIP_TRY(hipEventRecord(e->ev_ip[(size_t)ipass * (sbd_engine::kPhases + 1) + 5], st));
         HIP_TRY(hipGetLastError());
         {
             const int rcn = copy_pass(ipass + 1);

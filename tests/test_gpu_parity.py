@@ -23,7 +23,6 @@ pytestmark = pytest.mark.gpu
 
 FLUX = ("rfldir", "rfldn", "flup", "dfdt", "uavg")
 TOL = 2e-6            # measured worst 9.8e-7 (cfgB); every comparison is also ratcheted (tests/ratchet.py)
-TOL_CONSERVATIVE_THERMAL = 6e-5   # measured <= 5.1e-5, see test_fuzz_all_stream_counts_and_layer_counts
 FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "*.sbdrec")) if "albtrn" not in f)   # (IBCND = 1: its own test)
 
 
@@ -440,10 +439,19 @@ def test_fuzz_all_stream_counts_and_layer_counts(seed):
     easy = [i for i, h in enumerate(hard) if not h]
     _check([flux[i] for i in easy], [uu[i] for i in easy], [st[i] for i in easy],
            [recs[i][0] for i in easy], [recs[i][1] for i in easy], key=f"fuzz/{seed}/easy")
+    # Round 5: the class has no gate of its own any more.  What was measured there (1e-8 .. 5e-5, "moving with the
+    # rounding of the record's other layers") is the REFERENCE's own sensitivity to the rounding of its arithmetic: its
+    # FMA-contracted twin moves by 4.2e-5 of the column maximum on the record where the engine is 3.4e-5 off (seed 153,
+    # NSTR 38), 1.1e-5 where it is 1.4e-5 off (seed 141, NSTR 34), 1.9e-5 / 2.4e-5 (seed 323, NSTR 26), and by 1e-8 where
+    # the engine is at 1e-8.  Every record is gated at max(TOL, 8 x its own sensitivity), like tests/golden/illcond.
     tough = [i for i, h in enumerate(hard) if h]
+    sens = []
+    for i in tough:
+        t = pyoracle.disort(recs[i][0], perturbed=True)
+        sens.append(max(float(np.abs(t[f] - recs[i][1][f]).max() / max(np.abs(recs[i][1][f]).max(), 1e-300)) for f in FLUX))
     _check([flux[i] for i in tough], [uu[i] for i in tough], [st[i] for i in tough],
-           [recs[i][0] for i in tough], [recs[i][1] for i in tough], tol=TOL_CONSERVATIVE_THERMAL,
-           key=f"fuzz/{seed}/conservative_thermal")   # (measured <= 5.1e-5)
+           [recs[i][0] for i in tough], [recs[i][1] for i in tough], sens=sens,
+           key=f"fuzz/{seed}/conservative_thermal")
 
 
 def test_result_independent_of_batch_neighbours():

@@ -14,7 +14,7 @@ for S in D C; do
   cmd="python bench.py --shape cfg$S"
   key=$([ $S = D ] && echo cfgD_nstr32_50layers_flux || echo cfgC_nstr32_radiance_20x16)
   nstr=32; nlyr=$([ $S = D ] && echo 50 || echo 33)
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $o/trace$S -- $cmd > $o/trace$S.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $o/trace$S -- $cmd --headline-only > $o/trace$S.log 2>&1   # (no serialized pass: every launch in the timed configuration)
   grep '^{"shape' $o/trace$S.log | tail -1 > $o/cfg${S}_bench_under_rocprof.json
   find $o/trace$S -name "*kernel_stats.csv" -exec cp {} $o/cfg${S}_kernel_stats.csv \;
   W=$(python -c "import json;d=json.loads(open('$o/cfg${S}_bench_under_rocprof.json').read());print(d['$key']['roofline']['solves_per_launch'])")
