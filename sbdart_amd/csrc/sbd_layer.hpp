@@ -249,6 +249,13 @@ SBD_DEVICE double lu_solve_group(const double *a, int ld, int n, const int *ipvt
 #undef A
 }
 
+// OPRIM (disort.f:2578) with one rounding per operation
+SBD_DEVICE double oprim_exact(double w, double f)
+{
+#pragma clang fp contract(off)
+    return w * (1.0 - f) / (1.0 - f * w);
+}
+
 // LIST = true: the form that walks layer_kernel2's list.  Normally the list is empty and the kernel only stands between
 // layer_kernel2 and the band kernel of its stream -- but its blocks asked for 256 VGPRs, and on a chip filled by the
 // OTHER stream's kernels (three 160-VGPR waves or two 256-VGPR waves per SIMD) such a wave waits until half a SIMD
@@ -259,11 +266,6 @@ SBD_DEVICE double lu_solve_group(const double *a, int ld, int n, const int *ipvt
 template <int G, bool LIST = false>
 __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32_t *only_flagged)
 {
-    // No contraction in this kernel's own statements: the layers it serves are the ones whose systems are singular to
-    // working precision, where the reference's warnings and rounding follow from ITS sequence of operations -- GL, CC
-    // and the two systems' matrices are formed with one rounding per operation like the reference's object code
-    // (the eigen-solver it calls keeps its own setting: its results are good to rounding either way).
-#pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int GPB = 64 / G;
     const int lane = threadIdx.x;
@@ -324,11 +326,8 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
     const int me = g + 1;
 
     // ---- delta-M scaled Legendre coefficients GL(k) (SETDIS, disort.f:2583-2585) ----
-    // (OPRIM again from the dithered albedo and F, one rounding per operation: disort.f:2578; the setup kernel's value
-    //  comes from a contracted 1 - F w)
     const double f = sv[o.flyr() + lc - 1];
-    const double wdith = sv[o.ssalb() + lc - 1];
-    const double oprim = wdith * (1.0 - f) / (1.0 - f * wdith);
+    const double oprim = sv[o.oprim() + lc - 1];
     {
         const double *pm = P.pmom + (pmom_item(P, slot) * L + (lc - 1)) * (P.nmom + 1);
         if (g < n) {
@@ -432,9 +431,48 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
     }
     wave_lds_sync();
 
+    // ---- the particular solutions' systems: the REFERENCE's matrices, bit for bit ----
+    // GL and CC once more, now with one rounding per operation like the reference's object code (no fused multiply-add
+    // there), OPRIM from the dithered albedo and F the same way (disort.f:2578; the setup kernel's value comes from a
+    // contracted 1 - F w): (1 + mu/mu0) I - CC and I - CC below are then the reference's own, SGEFA's rule factors them the
+    // reference's way and SGECO's estimate decides errmsg 3 / 4 as the reference does.  The eigenproblem above keeps the
+    // contracted CC it always had: its solver is another implementation of ASYMTX, good to rounding either way -- and
+    // fed the exactly symmetric matrix of a Rayleigh-only layer 20 ulps from conservative scattering it returned NaN
+    // eigenvectors (end-to-end fuzz, seed 5001; tests/test_gpu_parity.py::test_rayleigh_layer_next_to_conservative).
+    const bool thermal = plank && mazim == 0;
+    if (fbeam > 0.0 || thermal) {
+#pragma clang fp contract(off)
+        wave_lds_sync();
+        const double wdith = sv[o.ssalb() + lc - 1];
+        const double oprim_x = wdith * (1.0 - f) / (1.0 - f * wdith);
+        const double *pm = P.pmom + (pmom_item(P, slot) * L + (lc - 1)) * (P.nmom + 1);
+        if (g < n) {
+            const int k = g;
+            const double pk = (k == 0) ? 1.0 : ((k <= P.nmom) ? pm[k] : 0.0);
+            gl[k] = (double)(2 * k + 1) * oprim_x * (pk - f) / (1.0 - f);
+        }
+        wave_lds_sync();
+        if (me <= n) {
+            for (int iq = 1; iq <= nn; ++iq) {
+                double sum = 0.0;
+                for (int l = mazim; l <= n - 1; ++l) sum = sum + gl[l] * YLMC(l, iq) * YLMC(l, me);
+                CC(iq, me) = 0.5 * sum * cwt[me - 1];
+            }
+        }
+        wave_lds_sync();
+        if (me <= nn) {
+            for (int iq = 1; iq <= nn; ++iq) {
+                CC(iq + nn, me) = CC(iq, me + nn);
+                CC(iq + nn, me + nn) = CC(iq, me);
+            }
+        }
+        wave_lds_sync();
+    }
+
     // ---- UPBEAM (disort.f:4205-4241) ----
     double zj = 0.0;
     if (fbeam > 0.0) {
+#pragma clang fp contract(off)
         const double delm0 = (mazim == 0) ? 1.0 : 0.0;
         if (me <= n) {
             for (int iq = 1; iq <= n; ++iq) LU(iq, me) = -CC(iq, me);
@@ -461,8 +499,9 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
 
     // ---- UPISOT (disort.f:4309-4349), azimuth-independent only ----
     double z0 = 0.0, z1 = 0.0;
-    const bool thermal = plank && mazim == 0;
     if (thermal) {
+#pragma clang fp contract(off)
+        const double oprim = oprim_exact(sv[o.ssalb() + lc - 1], f);
         const double xr0 = sv[o.xr0() + lc - 1], xr1 = sv[o.xr1() + lc - 1];
         if (me <= n) {
             for (int iq = 1; iq <= n; ++iq) LU(iq, me) = -CC(iq, me);

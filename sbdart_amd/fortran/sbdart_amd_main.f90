@@ -61,6 +61,7 @@ subroutine run_once(phase)
   use sbd_tables_mod, only: tables_load, tables_image
   use sbd_filter_mod
   use sbd_fleet_cache_mod
+  use omp_lib, only: omp_get_max_threads
   integer, intent(in) :: phase
   integer, parameter :: ncldz = 5, naerz = 5, naerb = 150, maxmom = 299, ndb = 20
   ! ---- &INPUT / &DINPUT (drt.f:200-215), same names, same defaults where they matter ----
@@ -98,7 +99,7 @@ subroutine run_once(phase)
   real(kr), allocatable, target :: pt_lo(:), pt_hi(:), pt_fb(:), pt_al(:)   ! compact form: per SPECTRAL POINT
   integer(c_int8_t), allocatable, target :: pt_pl(:)
   integer(c_int32_t), allocatable, target :: status(:), level_out(:)
-  integer, allocatable :: order(:), where_solved(:)
+  integer, allocatable :: order(:), where_solved(:), part_of(:)
   real(kr), allocatable :: zlev(:), plev(:)
   integer :: stall, fatal_at, nbad
   type(model_input) :: model
@@ -111,7 +112,7 @@ subroutine run_once(phase)
   character(len=256) :: why
   type(ck_file) :: ck                                  ! KDIST = -1: the k-distribution file pair
   type(mix_batch), target :: mix                       ! the run's batch in compact form (sbd_mix_in), when it fits
-  logical :: use_mix, gas_dev
+  logical :: use_mix, gas_dev, items_wanted
   real(kr), allocatable :: one_dtau(:), one_ssalb(:), one_pmom(:, :)
   ! the gas terms on the device (sbd_fleet_gas_terms): per spectral point the number of k-terms, their weights, TAUCOR's
   ! verdict; per work item its k-term; the fleet whose devices hold the depths
@@ -381,17 +382,26 @@ subroutine run_once(phase)
   call system_clock(tick0, tick_rate)
   allocate(order(nrec), where_solved(nrec))
   where_solved = 0                                   ! batch position of record i, 0 = not solved
+  ! (the part of every record first -- 0 not solved, 1 beam with corrections, 2 beam, 3 no beam --, all records at once:
+  !  the records are hundreds of bytes apart, three serial walks over 200 000 of them cost tens of milliseconds)
+  allocate(part_of(nrec))
+  !$omp parallel do schedule(static) num_threads(max(1, min(omp_get_max_threads(), nrec/4096 + 1, 16)))
+  do i = 1, nrec
+    if (recs(i)%ff == 0._kr) then
+      part_of(i) = 0
+    else if (.not. recs(i)%fbeam > 0._kr) then
+      part_of(i) = 3
+    else if (corint .and. radcalc .and. iand(recs(i)%flags, 16) == 0) then
+      part_of(i) = 2
+    else
+      part_of(i) = 1
+    end if
+  end do
+  !$omp end parallel do
   npart = 0
   do pass = 1, 3
     do i = 1, nrec
-      if (recs(i)%ff == 0._kr) cycle
-      if (.not. recs(i)%fbeam > 0._kr) then
-        if (pass /= 3) cycle
-      else if (corint .and. radcalc .and. iand(recs(i)%flags, 16) == 0) then
-        if (pass /= 2) cycle
-      else
-        if (pass /= 1) cycle
-      end if
+      if (part_of(i) /= pass) cycle
       npart = npart + 1
       order(npart) = i
       where_solved(i) = npart
@@ -417,6 +427,7 @@ subroutine run_once(phase)
     allocate(dtauc(nz, merge(1, nrec, gas_dev)), ssalb(nz, merge(1, nrec, use_mix)))      ! (gas on the device: no depths here at all)
   end if
   status = 0
+  !$omp parallel do schedule(static) private(i) num_threads(max(1, min(omp_get_max_threads(), npart/4096 + 1, 16)))
   do ip = 1, npart
     i = order(ip)
     if (.not. in_place) then
@@ -439,14 +450,18 @@ subroutine run_once(phase)
     kterm(ip) = recs(i)%kd - 1
     weight(ip) = recs(i)%wt*recs(i)%ff                 ! dwt of stdout1 (drt.f:964)
   end do
+  !$omp end parallel do
   if (use_mix) then                                    ! (a point's scalars: any of its items carries them)
     allocate(pt_lo(grid%n), pt_hi(grid%n), pt_fb(grid%n), pt_al(grid%n), pt_pl(grid%n))
     pt_lo = 0; pt_hi = 0; pt_fb = 0; pt_al = 0; pt_pl = 0
+    !$omp parallel do schedule(static) private(j) num_threads(max(1, min(omp_get_max_threads(), nrec/4096 + 1, 16)))
     do i = 1, nrec
+      if (recs(i)%kd /= 1) cycle                         ! (a point's first k-term speaks for the point)
       j = recs(i)%iwl
       pt_lo(j) = recs(i)%wvnmlo; pt_hi(j) = recs(i)%wvnmhi; pt_fb(j) = recs(i)%fbeam; pt_al(j) = recs(i)%albedo
       pt_pl(j) = int(iand(recs(i)%flags, 1), c_int8_t)
     end do
+    !$omp end parallel do
   end if
   allocate(flux(nlev, SBD_NFLUX, nrec), acc_flux(nlev, SBD_NFLUX))
   if (radcalc) then
@@ -464,6 +479,8 @@ subroutine run_once(phase)
   !  transmissivity in two arguments SBDART never looks at and leaves every flux and intensity at zero
   !  (disort.f:545-556) -- the run prints zeros; so does this one, without a solve.  The engine offers the
   !  mode itself through sbd_run_cfg::ibcnd.)
+  call get_environment_variable('SBD_ORDERED_SUMS', path, plen, pstat)
+  items_wanted = fmt%per_point .or. (pstat == 0 .and. plen > 0 .and. path(1:1) /= '0')
   if (ibcnd /= 1) then
     call solve_part(1, ncorr, .true., corint)
     if (.not. aborted) call solve_part(ncorr + 1, nbeam, .true., .false.)
@@ -1061,6 +1078,11 @@ contains
     if (.not. fmt%per_point) then
       wptr = c_loc(weight(p0)); aptr = c_loc(acc_flux)
       if (radcalc) uptr = c_loc(acc_uu)
+      ! (a per-run format reads the engine's sums, not the items: their fluxes and intensities stay on the device --
+      !  16 MB per 200 000 items that would cross PCIe for nobody.  SBD_ORDERED_SUMS=1 adds the items on the host.)
+      if (.not. items_wanted) then
+        bout%flux = c_null_ptr; bout%uu = c_null_ptr
+      end if
     end if
     if (use_mix) then
       ! compact form: the part's items with the gas of their k-term, the spectral points' blocks by their index in the
