@@ -344,6 +344,7 @@ struct sbd_engine {
     bool band_reg = false;
     bool band4 = false;             // four systems per wave, block form (sbd_band4.hpp), NSTR <= 16
     bool band1 = false;             // one system per wave, block form in registers (sbd_band1.hpp), 16 < NSTR <= 32
+    bool band_rows = false;         // one system per wave, a row per lane (sbd_bandr.hpp), NSTR 34..40
     int32_t *d_surf_flag = nullptr; // shared surface tables: CHEKIN's verdict on the model (sbd_surface.hpp)
     double *d_surf = nullptr;       // shared surface tables (Hapke / Ross-Li: one set per run)
     bool brdf_bad = false;          // ... the model's flux albedo leaves [0,1]: every item gets SBD_ST_ERR_INPUT
@@ -633,7 +634,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     // (band4: the band kernel reads GC and scales it itself, no ga/gb blocks -- a third of the workspace)
     bool band4 = nn <= 8;
     bool band1 = nn >= 9 && nn <= 16;
-    if (const char *s = getenv("SBD_BAND_V1")) { band4 = band4 && atoi(s) == 0; band1 = band1 && atoi(s) == 0; }
+    bool band_rows = sbd::has_band_rows(nn);
+    if (const char *s = getenv("SBD_BAND_V1")) { band4 = band4 && atoi(s) == 0; band1 = band1 && atoi(s) == 0; band_rows = band_rows && atoi(s) == 0; }
     // fluxes at the top of the first layer and at the surface only (IOUT 1 / 10 with the default ZOUT): fused band kernel
     bool fused = (band4 || band1) && nn >= 3 && cfg->onlyfl && cfg->nlevel_out == 2 && cfg->level_out[0] == 0 && cfg->level_out[1] == L;
     if (const char *s = getenv("SBD_NO_FUSE")) fused = fused && atoi(s) == 0;
@@ -762,10 +764,11 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     e->band_reg = false;                          // (round 1's register-window LU is gone: LDS window, sbd_band.hpp)
     e->band4 = band4;
     e->band1 = band1;
+    e->band_rows = band_rows;
     e->fused = fused;
     e->corint = rad && cfg->corint != 0;
     e->quad = quad;
-    e->P.ublock = band4 ? 1 : 0;
+    e->P.ublock = (band4 || band_rows) ? 1 : 0;
     e->P.gconly = (band4 || band1) ? 1 : 0;
     const sbd::BandLds bl(n, nn, e->band_reg);
     e->band_lds = (int)sizeof(double) * bl.total;
@@ -1264,6 +1267,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             } else if (e->band4 && e->pivot_exact) sbd::launch_band4_exact(e->nn, (bgrid + 3) / 4, st, P, e->fused, false);
             else if (e->band4) sbd::launch_band4(e->nn, (bgrid + 3) / 4, st, P, e->fused);
             else if (e->band1) sbd::launch_band1(e->nn, bgrid, st, P, e->fused);
+            else if (e->band_rows) sbd::launch_band_rows(e->nn, bgrid, st, P);
             else sbd::launch_band_lds(e->nn, bgrid, e->band_lds, st, P);
         }
         SBD_DBG("band");

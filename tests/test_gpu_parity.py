@@ -283,11 +283,11 @@ def test_level_selection_and_accumulate():
         assert np.allclose(acc, ref, rtol=1e-13, atol=0)
 
 
-@pytest.mark.parametrize("nstr", [8, 16, 20, 24, 32])
+@pytest.mark.parametrize("nstr", [8, 16, 20, 24, 32, 36, 40])
 def test_level_selection_for_every_band_kernel(nstr):
     """Two output levels (TOA, surface: what IOUT 1/10 ask for) instead of all of them, through every band
-    LU variant (four-per-wave NSTR <= 16, one-per-wave up to 32; the level pair takes their fused forms -- no stored
-    factor --, all levels the stored-factor ones): GC is then only kept for the layers that need it, and the answers
+    LU variant (four-per-wave NSTR <= 16, one-per-wave up to 32, a row per lane for 34-40; the level pair takes the
+    fused forms of the first two -- no stored factor --, all levels the stored-factor ones): GC is then only kept for the layers that need it, and the answers
     must not change beyond the gate.  (NSTR > 20 used to build its first
     window rows from GC of layers that had not been kept.)"""
     import pyoracle
