@@ -183,8 +183,9 @@ struct BandRows {      // the wave's registers
     int lrow;                // the row's index in LINPACK's order (moves with the interchanges)
     int k;                   // column being eliminated (wave-uniform)
     int myk, myJ;            // retired lanes: the row of U they hold, its first column inside the layer
+    double mypiv;            // ... and its pivot
     bool live, retired;
-    double pv_min, pv_max;
+    double pv_min, pv_max;   // smallest / largest |pivot| among the rows this lane retired
     bool pv_nan;
 };
 
@@ -195,7 +196,7 @@ template <int NN>
 SBD_DEVICE void band_rows_pivot(BandRows<NN> &s, const double akJ, const int J)
 {
     const int lane = threadIdx.x;
-    const double ak = s.live ? akJ : 0.0;
+    const double ak = akJ;               // (lanes without a live row: whatever their registers hold -- never candidates)
     // -1/a for every candidate while the max-scan runs (v_rcp_f64 + two Newton steps, as sbd_band.hpp)
     double rk = __builtin_amdgcn_rcp(ak);
     rk = rk * (2.0 - ak * rk);
@@ -224,14 +225,13 @@ SBD_DEVICE void band_rows_pivot(BandRows<NN> &s, const double akJ, const int J)
     const int Pl = hit ? __ffsll((long long)hit) - 1 : 0;
     s.P = Pl;
     const double piv = pick_lane(ak, Pl), tsel = pick_lane(rk, Pl);
-    { const double ap = fabs(piv); s.pv_nan = s.pv_nan || (ap != ap); s.pv_min = fmin(s.pv_min, ap); s.pv_max = fmax(s.pv_max, ap); }
     const double tinv = (piv != 0.0) ? tsel : 0.0;
     // the interchange: the row that sat at position k takes the pivot row's place in the order
     const int lP = __builtin_amdgcn_readlane(s.lrow, Pl);
     if (s.live && s.lrow == s.k) s.lrow = lP;
     const bool other = s.live && lane != Pl;
     s.m = other ? ak * tinv : 0.0;
-    if (lane == Pl && s.live) { s.live = false; s.retired = true; s.myJ = J; s.myk = s.k; }
+    if (lane == Pl && s.live) { s.live = false; s.retired = true; s.myJ = J; s.myk = s.k; s.mypiv = ak; }
 }
 
 template <int NN>
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
 
     BandRows<NN> s;
     static_for<n>([&](auto cc) { s.cur[decltype(cc)::value] = 0.0; s.nxt[decltype(cc)::value] = 0.0; });
-    s.b = 0.0; s.m = 0.0; s.P = 0; s.lrow = 0; s.k = 1; s.myk = 0; s.myJ = 0; s.live = false; s.retired = false;
+    s.b = 0.0; s.m = 0.0; s.P = 0; s.lrow = 0; s.k = 1; s.myk = 0; s.myJ = 0; s.mypiv = 0.0; s.live = false; s.retired = false;
     s.pv_min = 1.0e300; s.pv_max = 0.0; s.pv_nan = false;
 
     // nb boundary rows r0, r0+1, .. (columns c0+1 .. c0+n) to the free lanes of rank rank0.. through the LDS stage
@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
             double akJ;
             BandRowsStep<NN>::pick(s.cur, __builtin_amdgcn_readfirstlane(J), akJ);
             band_rows_pivot<NN>(s, akJ, J);
-            BandRowsStep<NN>::run(s.cur, s.nxt, s.b, s.m, __builtin_amdgcn_readfirstlane(s.P), __builtin_amdgcn_readfirstlane(J), __builtin_amdgcn_readfirstlane(lc == ncut ? 1 : 0));
+            BandRowsStep<NN>::run(s.cur, s.nxt, s.b, s.m, 1ull << __builtin_amdgcn_readfirstlane(s.P), __builtin_amdgcn_readfirstlane(J), __builtin_amdgcn_readfirstlane(lc == ncut ? 1 : 0));
             s.k = s.k + 1;
         }
         // ---- the retired rows leave: U(k, .) by layer block (register c <-> column c of [x_lc, x_lc+1]), B(k) ----
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
             double *urow = ufac + (size_t)(s.myk - 1) * UW;
             static_for<NN>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                if (2 * c + 1 >= s.myJ) *(double2 *)(urow + 2 * c) = make_double2(s.cur[2 * c], s.cur[2 * c + 1]);
+                *(double2 *)(urow + 2 * c) = make_double2(s.cur[2 * c], s.cur[2 * c + 1]);   // (left of the diagonal: never read)
             });
             if (lc < ncut) {
                 static_for<NN>([&](auto cc) {
@@ -336,6 +336,7 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
                 });
             }
             yv[s.myk - 1] = s.b;
+            { const double ap = fabs(s.mypiv); s.pv_nan = s.pv_nan || (ap != ap); s.pv_min = fmin(s.pv_min, ap); s.pv_max = fmax(s.pv_max, ap); }
             s.retired = false;
         }
         // ---- the survivors' x_lc+1 becomes x_lc ----
@@ -343,7 +344,13 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
     }
     // 1 + min|pivot| / max|pivot| == 1 (a zero pivot included), silent on NaN like the reference's 1 + RCOND == 1
     // (the pivot ratio stands in for RCOND as in band1 / band4, sbd_band1.hpp)
-    if (!s.pv_nan && s.pv_min <= 1.1102230246251565e-16 * s.pv_max && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], 0x01);
+    double pmin = s.pv_min, pmax = s.pv_max;
+    for (int d = 32; d >= 1; d >>= 1) {
+        pmin = fmin(pmin, __shfl_xor(pmin, d));
+        pmax = fmax(pmax, __shfl_xor(pmax, d));
+    }
+    const bool any_nan = __ballot(s.pv_nan) != 0ull;
+    if (!any_nan && pmin <= 1.1102230246251565e-16 * pmax && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], 0x01);
 }
 
 }  // namespace sbd

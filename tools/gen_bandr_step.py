@@ -18,9 +18,8 @@ Run:  python tools/gen_bandr_step.py   (make runs it; the output is not kept in 
 import os
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sbdart_amd", "csrc", "sbd_bandr_step.inc")
-PAIR = ("s[92:93]", "s[94:95]")
-PLO = ("s92", "s94")
-PHI = ("s93", "s95")
+G = 16           # columns per group: the pivot lane's elements of a group are fetched with EXEC narrowed to that lane
+SBASE = 60       # ... into s[SBASE : SBASE + 2 G)
 VBASE = 64       # cur[c] lives in v[VBASE+2c : +1], nxt[c] behind cur, then b: fixed registers, because AMDGPU inline asm
                  # cannot name the halves of a 64-bit operand (v_readlane_b32 needs them) -- "+{v[a:b]}" constraints
 
@@ -33,11 +32,22 @@ def emit(nn):
     n = 2 * nn
     name = [f"v[{vreg(i)}:{vreg(i) + 1}]" for i in range(2 * n + 1)]     # cur, nxt, b
     B = 2 * n
-    m, P, J, last = "%[m]", "%[P]", "%[J]", "%[last]"
+    m, J, last, mask = "%[m]", "%[J]", "%[last]", "%[mask]"
 
-    def rl(i, pair):
-        return [f"v_readlane_b32 {PLO[pair]}, v{vreg(i)}, {P}", f"v_readlane_b32 {PHI[pair]}, v{vreg(i) + 1}, {P}"]
+    def pair(i):                                   # SGPR pair of the i-th column of a group
+        return f"s[{SBASE + 2 * i}:{SBASE + 2 * i + 1}]"
 
+    def fetch(cols):                               # the pivot lane's elements of these columns, into the group's pairs
+        out = [f"s_mov_b64 exec, {mask}"]
+        for c in cols:
+            i = c2i[c]
+            out += [f"v_readfirstlane_b32 s{SBASE + 2 * i}, v{vreg(c)}", f"v_readfirstlane_b32 s{SBASE + 2 * i + 1}, v{vreg(c) + 1}"]
+        out.append("s_mov_b64 exec, -1")
+        return out
+
+    # groups of G columns: x_lc's columns 1..n-1, then x_lc+1's n..2n-1
+    groups = [list(range(g, min(g + G, n))) for g in range(1, n, G)] + [list(range(g, min(g + G, 2 * n))) for g in range(n, 2 * n, G)]
+    c2i = {c: k for grp in groups for k, c in enumerate(grp)}
     L = [f"s_lshl_b32 s96, {J}, 2",
          "s_add_i32 s96, s96, 12",                 # bytes from the getpc result to the table
          "s_getpc_b64 s[98:99]",
@@ -46,35 +56,36 @@ def emit(nn):
          "s_setpc_b64 s[98:99]"]
     for j in range(n):                             # sub-step j starts at column j+1
         L.append(f"s_branch .Lbr_p{j + 1}_%=" if j + 1 < n else "s_branch .Lbr_bound_%=")
-    for c in range(1, n):                          # x_lc
-        L.append(f".Lbr_b{c}_%=:")
-        if c + 1 < n:
-            L += rl(c + 1, (c + 1) & 1)
-        else:
-            L.append("s_nop 0")                    # (no v_readlane left to fill the second wait state)
-        L.append(f"v_fmac_f64_e32 {name[c]}, {PAIR[c & 1]}, {m}")
-    L.append(".Lbr_bound_%=:")
-    L += [f"s_cmp_lg_u32 {last}, 0", "s_cbranch_scc1 .Lbr_rhs_%="]
-    L += rl(n, n & 1)
-    for c in range(n, 2 * n):                      # x_lc+1
-        if c + 1 < 2 * n:
-            L += rl(c + 1, (c + 1) & 1)
-        else:
-            L.append("s_nop 0")
-        L.append(f"v_fmac_f64_e32 {name[c]}, {PAIR[c & 1]}, {m}")
+    for grp in groups:
+        if grp[0] == n:
+            L.append(".Lbr_bound_%=:")
+            L += [f"s_cmp_lg_u32 {last}, 0", "s_cbranch_scc1 .Lbr_rhs_%="]
+        elif grp[0] < n:
+            L.append(f".Lbr_p{grp[0]}_%=:")       # (entering at the first column of a group needs no stub)
+        L += fetch(grp)
+        if len(grp) == 1:
+            L.append("s_nop 1")
+        for c in grp:
+            if c < n:
+                L.append(f".Lbr_b{c}_%=:")
+            L.append(f"v_fmac_f64_e32 {name[c]}, {pair(c2i[c])}, {m}")
     L.append(".Lbr_rhs_%=:")
-    L += rl(B, 0) + ["s_nop 1", f"v_fmac_f64_e32 {name[B]}, {PAIR[0]}, {m}", "s_branch .Lbr_end_%="]
-    for c in range(1, n):                          # entries: the first column's element, then into the sequence
-        L.append(f".Lbr_p{c}_%=:")
-        L += rl(c, c & 1)
-        L += ["s_nop 1", f"s_branch .Lbr_b{c}_%="]
+    L += [f"s_mov_b64 exec, {mask}", f"v_readfirstlane_b32 s{SBASE}, v{vreg(B)}", f"v_readfirstlane_b32 s{SBASE + 1}, v{vreg(B) + 1}",
+          "s_mov_b64 exec, -1", "s_nop 1", f"v_fmac_f64_e32 {name[B]}, {pair(0)}, {m}", "s_branch .Lbr_end_%="]
+    for grp in groups:                             # entries inside a group: the rest of the group's elements, then into the sequence
+        if grp[0] >= n:
+            break
+        for c in grp[1:]:
+            L.append(f".Lbr_p{c}_%=:")
+            L += fetch([x for x in grp if x >= c])
+            L += ["s_nop 1", f"s_branch .Lbr_b{c}_%="]
     L.append(".Lbr_end_%=:")
     text = "".join(f'        "{x}\\n"\n' for x in L)
     io = [f'"+{{{name[c]}}}"(cur[{c}])' for c in range(n)] + [f'"+{{{name[n + c]}}}"(nxt[{c}])' for c in range(n)] + [f'"+{{{name[B]}}}"(b)']
-    run = (f"    SBD_DEVICE static void run(double (&cur)[{n}], double (&nxt)[{n}], double &b, double m, int P, int J, int last)\n    {{\n"
+    run = (f"    SBD_DEVICE static void run(double (&cur)[{n}], double (&nxt)[{n}], double &b, double m, unsigned long long mask, int J, int last)\n    {{\n"
            f"        asm volatile(\n{text}"
-           f"        : {', '.join(io)}\n        : [m] \"v\"(m), [P] \"s\"(P), [J] \"s\"(J), [last] \"s\"(last)\n"
-           f"        : \"s92\", \"s93\", \"s94\", \"s95\", \"s96\", \"s98\", \"s99\", \"scc\");\n    }}\n")
+           f"        : {', '.join(io)}\n        : [m] \"v\"(m), [mask] \"s\"(mask), [J] \"s\"(J), [last] \"s\"(last)\n"
+           f"        : {', '.join(chr(34) + 's' + str(SBASE + q) + chr(34) for q in range(2 * G))}, \"s96\", \"s98\", \"s99\", \"scc\");\n    }}\n")
     # ak = cur[J]
     K = [f"s_lshl_b32 s96, {'%1'}, 3", "s_add_i32 s96, s96, 12", "s_getpc_b64 s[98:99]", "s_add_u32 s98, s98, s96",
          "s_addc_u32 s99, s99, 0", "s_setpc_b64 s[98:99]"]
