@@ -12,7 +12,8 @@
 //   pivot search over the live lanes' cur[J] (DPP max scan + ballot; ties to the first row in LINPACK's order, which a
 //   per-lane logical row index keeps through the interchanges -- the interchange itself moves no data),
 //   multipliers -a/pivot per lane (the pivot's reciprocal by v_rcp_f64 + two Newton steps),
-//   for every column right of J: the pivot row's element through two v_readlane, one FMA per lane.
+//   for every column right of J: the pivot row's element through an SGPR pair (two v_readfirstlane with EXEC narrowed
+//   to the pivot lane, 16 columns a group), one FMA per lane.
 // The columns right of J are a suffix of one fixed sequence "columns 1 .. 2*NSTR-1, right-hand side": the sequence is
 // written once, in place on fixed registers, and sub-step J jumps into it (generated inline asm, sbd_bandr_step.inc;
 // in C++ the compiler's PHI copies and out-of-place FMAs cost a third of the time and twice the registers).  A retired pivot row stays in its lane until the layer is

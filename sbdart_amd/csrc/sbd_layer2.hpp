@@ -153,7 +153,10 @@ template <int NN, int G, bool RAD>
 #define SBD_RAD_WAVES 2      // waves per SIMD of the intensity variant at NN > 12: a 256-register cap, ~170 spills -- and the NSTR 32
                              // radiance layer kernel 33.6 -> 26.5 ms per 768 points (same-box A/B, round 4; 1: 340 registers, no spill)
 #endif
-__global__ void __launch_bounds__(64, (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1) layer_kernel2(Params P, int32_t *eigflag)
+#ifndef SBD_BIG_WAVES
+#define SBD_BIG_WAVES 2      // ... and of the flux variant at NN > 16 (groups of 32 lanes)
+#endif
+__global__ void __launch_bounds__(64, (NN > 16 && !RAD) ? SBD_BIG_WAVES : (NN > 12) ? (RAD ? SBD_RAD_WAVES : 2) : 1) layer_kernel2(Params P, int32_t *eigflag)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int n = 2 * NN, nn = NN, GPB = 64 / G;

@@ -4,16 +4,21 @@ inline asm, one pair of blocks per NSTR/2 = 17..20.
 
 The kernel keeps a matrix row per lane: cur[n] (columns of x_lc) and nxt[n] (columns of x_lc+1) in registers.  Sub-step
 J of a layer adds m * (pivot row's element) to every column right of J: columns J+1..n-1 of cur, all of nxt, and the
-right-hand side -- a SUFFIX of one fixed sequence "column 1, 2, .., 2n-1, b".  So the sequence is written once and
-sub-step J jumps into it (s_getpc/s_setpc into a table of branches): 3 instructions per column (two v_readlane of the
-pivot lane's element, one v_fmac_f64 in place), the two v_readlane of column c+1 issued before the FMA of column c on
-alternating SGPR pairs, so that the two wait states between a VALU write of an SGPR and its VALU read are filled with
-work.  Written in C++ (J through a tree of scalar branches, static register indices) the compiler's PHI copies cost 40
-v_mov_b64 per sub-step and out-of-place FMAs a second set of 80 registers (2 waves per SIMD need <= 256); same cure
-as tools/gen_band1_take.py.
+right-hand side -- a SUFFIX of one fixed sequence "column 1, 2, .., 2n-1, b".  So the sequence is written once, in
+place on fixed registers, and sub-step J jumps into it (s_getpc/s_setpc into a table of branches).  A column costs
+three instructions: two v_readfirstlane_b32 of the pivot lane's element into an SGPR pair, one v_fmac_f64 with that
+pair as an operand.  The elements of G = 16 columns are fetched together with EXEC narrowed to the pivot lane
+(v_readfirstlane then reads that lane): measured on gfx950 (tools/microbench/valu_rates.hip, two waves per SIMD), a
+v_readlane_b32 with an SGPR lane select takes 1.7 issue slots of 4 cycles, v_readfirstlane_b32 -- like a constant or M0
+lane select -- one, an FMA one; fetching a group ahead also keeps the two wait states between a VALU write of an SGPR
+and its VALU read filled.  A sub-step that starts inside a group enters through a stub that fetches the rest of the
+group.  Written in C++ (J through a tree of scalar branches, static register indices) the compiler's PHI copies cost
+40 v_mov_b64 per sub-step and out-of-place FMAs a second set of 80 registers (2 waves per SIMD need <= 256); same
+cure as tools/gen_band1_take.py.
 
 BandRowsStep<NN>::pick(cur, J, ak): ak = cur[J], J wave-uniform.
-BandRowsStep<NN>::run(cur, nxt, b, m, P, J, last): the updates; P = pivot lane, last != 0: no x_lc+1 (last layer).
+BandRowsStep<NN>::run(cur, nxt, b, m, mask, J, last): the updates; mask = 1 << pivot lane, last != 0: no x_lc+1 (the
+last layer).  EXEC must be all ones on entry (the kernel's sub-step loop is wave-uniform) and is on exit.
 Run:  python tools/gen_bandr_step.py   (make runs it; the output is not kept in the repository)."""
 import os
 
@@ -21,7 +26,7 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sbdart_amd
 G = 16           # columns per group: the pivot lane's elements of a group are fetched with EXEC narrowed to that lane
 SBASE = 60       # ... into s[SBASE : SBASE + 2 G)
 VBASE = 64       # cur[c] lives in v[VBASE+2c : +1], nxt[c] behind cur, then b: fixed registers, because AMDGPU inline asm
-                 # cannot name the halves of a 64-bit operand (v_readlane_b32 needs them) -- "+{v[a:b]}" constraints
+                 # cannot name the halves of a 64-bit operand (v_readfirstlane_b32 needs them) -- "+{v[a:b]}" constraints
 
 
 def vreg(i):
