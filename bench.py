@@ -185,7 +185,7 @@ def shape_roofline(names, phase_ms, nlaunch, pass_size, W, nstr, nlyr, nlev, sha
     traffic = None
     tp, src = load_profile("traffic", nstr, nlyr, shape)
     if tp is not None and tp.get("solves_per_launch") == pass_size:
-        key = {"layer_kernel": "layer_kernel2", "band_kernel": ("band4_kernel", "band1_kernel", "band_kernel")}.get(names[dom], names[dom])
+        key = {"layer_kernel": "layer_kernel2", "band_kernel": ("band4_kernel", "band1_kernel", "band_rows_kernel", "band_kernel")}.get(names[dom], names[dom])
         keys = key if isinstance(key, tuple) else (key,)
         for kname, kd in tp["kernels"].items():
             if any(k in kname for k in keys):
@@ -296,15 +296,17 @@ def e2e_input_to_stdout(device):
 
 def other_shapes(dev, only=None, serialized_pass=True):
     """One-step lines for the other BASELINE shapes (parity-test cases, not the headline): configs[4]'s
-    NSTR 32 x 50 layers in flux mode and configs[3]'s radiance shape (NSTR 32, 20 x 16 angles, 32 azimuth modes).
-    `only` = "cfgC" | "cfgD": that shape alone (bench.py --shape: the command the shape's counters are recorded with)."""
+    NSTR 32 x 50 layers in flux mode, configs[3]'s radiance shape (NSTR 32, 20 x 16 angles, 32 azimuth modes), and the
+    reference's largest stream count (NSTR 40, params.f:9-11) on the headline's 33 layers.
+    `only` = "cfgC" | "cfgD" | "nstr40": that shape alone (bench.py --shape: the command the shape's counters are recorded with)."""
     import torch
     from sbdart_amd.engine import DisortEngine
     from sbdart_amd.workload import sw_sweep
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     out = {}
     for name, kw, nwl in (("cfgD_nstr32_50layers_flux", dict(nstr=32, nlyr=50), 6144),
-                          ("cfgC_nstr32_radiance_20x16", dict(nstr=32, nlyr=33, thermal_above_um=99.0), 384)):
+                          ("cfgC_nstr32_radiance_20x16", dict(nstr=32, nlyr=33, thermal_above_um=99.0), 384),
+                          ("nstr40_33layers_flux", dict(nstr=40, nlyr=33), 4096)):     # params.f's largest stream count
         if only and not name.startswith(only):
             continue
         try:
@@ -338,7 +340,7 @@ def other_shapes(dev, only=None, serialized_pass=True):
             finite = bool(torch.isfinite(flux).all().item()) and (uu is None or bool(torch.isfinite(uu).all().item()))
             names = ["setup_kernel", "layer_kernel", "band_kernel", "backsolve_kernel", "usrint+azimuth"]
             nl = eng.pass_count(sw.nwork)
-            shape = "cfgC" if rad else "cfgD"
+            shape = "cfgC" if rad else ("nstr40" if name.startswith("nstr40") else "cfgD")
             out[name] = {"value": sw.nwl / dt if finite else None, "unit": "spectral-points/s", "ms_per_step": 1e3 * dt,
                          "nwl": sw.nwl, "solves": sw.nwork, "nstr": sw.nstr, "nlyr": sw.nlyr,
                          "kernel_ms": dict(zip(["setup", "layer", "band", "backsolve", "usrint+azimuth"], map(float, kms))),
@@ -531,7 +533,7 @@ def main():
                     help="the timed steps and the per-kernel timing pass only: no host-entry-point legs (whose passes have other "
                          "sizes) -- the command profiles/<tag>_kernel_stats.csv is recorded with, so that its averages are "
                          "bench-size launches")
-    ap.add_argument("--shape", choices=["cfgC", "cfgD"], default=None,
+    ap.add_argument("--shape", choices=["cfgC", "cfgD", "nstr40"], default=None,
                     help="print the one-step line of another BASELINE shape (other_shapes) and nothing else: the command its "
                          "counters in profiles/ are recorded with")
     ap.add_argument("--rendezvous-only", choices=["nccl", "gloo"], default=None,
