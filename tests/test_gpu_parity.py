@@ -519,6 +519,37 @@ def test_lds_window_variant_matches():
     ratchet("alt/band_v1", max(errs))
 
 
+_ROWS_CODE = ("import numpy as np,sys,json;sys.path.insert(0,'.');"
+              "from sbdart_amd.engine import solve_records;from sbdart_amd.workload import sw_sweep,sweep_to_records;"
+              "out=[];"
+              "\nfor nstr in (34,36,38,40):"
+              "\n    sw=sw_sweep(nwl=24,nstr=nstr,nlyr=33,seed=777+nstr);r=sweep_to_records(sw,range(0,sw.nwork,5));"
+              "\n    f,u,s=solve_records(r);out.append([np.asarray(x).tolist() for x in f]+[list(map(int,s))])"
+              "\nprint(json.dumps(out))")
+
+
+def test_row_per_lane_band_kernel_against_the_lds_window_kernel():
+    """NSTR 34-40: band_rows_kernel (a matrix row per lane, sbd_bandr.hpp) against round 1's LDS-window band_kernel
+    (SBD_BAND_V1=1) on the same systems.  Both follow LINPACK's pivot order and update a(i,j) + t*m(i) as one FMA, so
+    the factors can only differ where the two kernels build a boundary row's element from differently contracted
+    products: measured, the fluxes are bit-identical (gate: 1e-13 of the column maximum), the status words equal."""
+    import subprocess, sys, json
+    from conftest import ROOT
+    run = lambda **env: json.loads(subprocess.check_output([sys.executable, "-c", _ROWS_CODE], cwd=ROOT,
+                                                           env=dict(os.environ, **env), text=True).strip().splitlines()[-1])
+    a, b = run(), run(SBD_BAND_V1="1")
+    worst = 0.0
+    for ra, rb in zip(a, b):
+        assert ra[-1] == rb[-1]
+        for fa, fb in zip(ra[:-1], rb[:-1]):
+            fa, fb = np.array(fa), np.array(fb)
+            for c in range(fa.shape[0]):
+                worst = max(worst, float(np.abs(fa[c] - fb[c]).max() / max(np.abs(fb[c]).max(), 1e-300)))
+    print(f"row-per-lane vs LDS-window band LU, NSTR 34-40: worst flux difference {worst:.2e} of the column maximum")
+    assert worst < 1e-13, worst
+    ratchet("alt/band_rows_vs_v1", worst)
+
+
 def test_small_passes_match():
     """SBD_CHUNK=5 cuts the batch into passes of five work items (workspace reuse, list reset and
     output offsets between passes): same answers."""
