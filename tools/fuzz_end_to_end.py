@@ -81,7 +81,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
         p.append("iout=%d nstr=%d nzen=%d uzen=%s nphi=%d phi=0,%d"%(pick(5,6,20,21,22,23),pick(4,8,16,16,20,24),pick(2,5),pick("0,80","100,175","10,170"),pick(2,3),pick(90,180)))
         if random.random()<.4: p.append("corint=t")
     else:
-        p.append("iout=%d nstr=%d"%(pick(1,7,10,11),pick(4,8,16,16,18,24,32,36)))       # (round 4: also the NSTR > 16 kernels)
+        p.append("iout=%d nstr=%d"%(pick(1,7,10,11),pick(4,8,16,16,18,24,32,36,40)))    # (round 4: also the NSTR > 16 kernels; round 5: 36 and 40 run band_rows_kernel)
     if random.random()<.15: p.append("isat=%d"%pick(1,4,9,13,17,22,26))
     nl=" ".join(p)
     if random.random()<.3 and "iout=7" not in nl: nl += " zout=%g,%g"%(pick(0,1,3),pick(10,30,100))
