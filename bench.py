@@ -139,6 +139,8 @@ def cpu_baseline(sw, seconds_target=10.0):
 
 MI355X_SIMDS = 256 * 4         # CUs x SIMDs
 MI355X_CLOCK_HZ = 2.4e9        # peak engine clock (MI355X_MICROARCH.md)
+VALU_SLOT_NS_MEASURED = 2.05   # one wave64 issue slot (4 cycles) as the chip sustains it under fp64 load: 1.95 GHz
+                               # (tools/microbench/valu_rates.hip, profiles/r05_valu_rates.txt)
 
 
 PROFILE_TAG = "r05"
@@ -173,7 +175,9 @@ def valu_issue(W, step_s, nstr, nlyr, shape=""):
     per_solve = sum(k["valu_wave_insts_per_solve"] for k in vp["kernels"].values())
     frac = per_solve * W * 4.0 / (MI355X_SIMDS * MI355X_CLOCK_HZ * step_s)
     return {"valu_wave_insts_per_solve": per_solve, "issue_cycles_per_inst": 4,
-            "frac_of_step": frac, "source": src + " (SQ_INSTS_VALU, separate PMC pass)",
+            "frac_of_step": frac,
+            "frac_of_step_at_sustained_clock": per_solve * W * VALU_SLOT_NS_MEASURED * 1e-9 / (MI355X_SIMDS * step_s),
+            "sustained_slot_ns": VALU_SLOT_NS_MEASURED, "source": src + " (SQ_INSTS_VALU, separate PMC pass)",
             "per_kernel": {k: v["valu_wave_insts_per_solve"] for k, v in vp["kernels"].items()}}
 
 
