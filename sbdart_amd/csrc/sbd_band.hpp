@@ -24,6 +24,7 @@
 #pragma once
 #include "sbd_common.hpp"
 #include "sbd_surface.hpp"
+#include "sbd_bandsys.hpp"
 
 namespace sbd {
 
@@ -53,7 +54,6 @@ struct SolveLds {   // per-wave carve-up of the back-substitution + flux kernel 
     int stage, x, total;
     __host__ __device__ SolveLds(int n, int nn, int L)
     {
-        const int ncd = 3 * nn - 1;
         const int fluxsz = 2 * 16 * n + 64;                         // E / U0C staging, 16 levels at a time
         const int stagesz = (2 * n - 1 + kBackBlock + 1) * (kBackBlock + 1);   // U block (2n-1 super-diagonals) + a zero row
         stage = 0;
@@ -242,7 +242,6 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     const int L = P.L;
     int32_t *svi = P.svi + (size_t)slot * P.svi_stride;
     const int st0 = svi[SBD_SVI_STATUS];
-    const double fbeam = P.fbeam[slot];
     const bool dead = (st0 & (0x20 | 0x10 | 0x08)) != 0;
     if (mazim > 0 && (mazim > svi[SBD_SVI_NAZ] || dead)) return;
     const int nlev = P.nlev;
@@ -251,18 +250,6 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         for (int i = lane; i < SBD_NFLUX_ * nlev; i += 64) flux[i] = 0.0;
         return;
     }
-    const int ncut = svi[SBD_SVI_NCUT];
-    const bool lyrcut = svi[SBD_SVI_LYRCUT] != 0;
-    const bool plank = P.plank[slot] != 0;
-    const SV o(L);
-    const double *sv = P.sv + (size_t)slot * P.sv_stride;
-    const double *taucpr = sv + o.taucpr();
-    const double *expbea = sv + o.expbea();
-    const double albedo = P.albedo[slot];
-    const double delm0 = (mazim == 0) ? 1.0 : 0.0;
-    const double umu0 = P.umu0;
-    const double *cmu = P.t.cmu, *cwt = P.t.cwt;
-
     const BandLds lds(n, nn, REG);
     // window width: LINPACK's 2*NCD+1 columns for the register variant (a column per lane), the
     // structural 2*NSTR (u_width) for the LDS variant, which is fed by columns as well as by rows
@@ -270,134 +257,24 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
     double *win = smem + lds.win;
     double *bw = smem + lds.bw;                       // RHS entries of the window rows (LU phase)
     double *yv = P.yv + (size_t)ms * L * n;           // RHS / forward-eliminated RHS in HBM
-    double *sbot = smem + lds.misc + 4;               // [n] surface-reflection sums (bottom BC)
-
-    const double *gc = P.gc + (size_t)ms * L * n * n;
-    const double *kk = P.kk + (size_t)ms * L * n;
-    const double *ek = P.ek + (size_t)ms * L * nn;
-    const double *zz = P.zz + (size_t)ms * L * n;
-    // thermal particular solutions exist for mode 0 only
-    const double *zp0 = P.zp0 + (size_t)(ms - mazim) * L * n;
-    const double *zp1 = P.zp1 + (size_t)(ms - mazim) * L * n;
+    // the system: right-hand side B (SOLVE0, disort.f:3434-3599; unknown index = (lc-1)*n + iq), the boundary rows
+    // (SETMTX, disort.f:2844-2990) and the interface rows from the matrix-ready blocks ga / gb (sbd_bandsys.hpp)
+    BandSystem<NN> S;
+    S.init(P, slot, mazim, ms, svi, smem + lds.misc + 4);     // [n] surface-reflection sums (bottom BC)
+    const int ncut = S.ncut;
     constexpr int UW = u_width(n);
     double *ufac = P.ufac + (size_t)ms * (size_t)(L * n) * UW;
     const int N = ncut * n;
-#define GC(i, j, lc) gc[((size_t)((lc) - 1) * n + ((i) - 1)) * n + ((j) - 1)]
-#define KK(i, lc) kk[((lc) - 1) * n + ((i) - 1)]
-#define EK(i, lc) ek[((lc) - 1) * nn + ((i) - 1)]
-#define ZZ(i, lc) zz[((lc) - 1) * n + ((i) - 1)]
-#define ZP0(i, lc) zp0[((lc) - 1) * n + ((i) - 1)]
-#define ZP1(i, lc) zp1[((lc) - 1) * n + ((i) - 1)]
 #define WIN(s, j) win[(s) * CWP + ((j) % CW)]
-
-    // the surface: Lambertian (couples only for m = 0, disort.f:2925) or bidirectional (SURFAC's tables of this mode)
-    const bool brdf = P.ibdrf != 0;
-    const size_t sidx = surf_index(P, slot, mazim);
-    const double *bdrt = brdf ? surf_bdr(P, sidx) : nullptr, *bemt = brdf ? surf_bem(P, sidx) : nullptr;
-    const bool refl = !lyrcut && (brdf || delm0 != 0.0);
-    // ---- bottom-boundary reflection sums: S(IQ) = sum_k CWT(k) CMU(k) BDR GC(nn+1-k, IQ, ncut),
-    //      Lambertian BDR = albedo for every pair (SURFAC, disort.f:3746-3763) ----
-    if (lane < n) {
-        double s = 0.0;
-        if (refl && !brdf)
-            for (int k = 1; k <= nn; ++k) s = s + cwt[k - 1] * cmu[k - 1] * albedo * GC(nn + 1 - k, lane + 1, ncut);
-        sbot[lane] = s;
-    }
-    // ---- right-hand side B (SOLVE0, disort.f:3434-3599), unknown index = (lc-1)*n + iq ----
-    const double bplank = sv[o.bplank()], tplank = sv[o.tplank()];
-    const bool beam = fbeam > 0.0;
+    S.fill_sbot(lane);
     for (int it = lane + 1; it <= N; it += 64) {
-        double v;
-        if (it <= nn) {   // top boundary
-            const int iq = it;
-            v = 0.0;
-            if (mazim == 0) {
-                if (beam) v = -ZZ(nn + 1 - iq, 1) - ZP0(nn + 1 - iq, 1) + P.fisot + tplank;
-                else v = -ZP0(nn + 1 - iq, 1) + P.fisot + tplank;
-            } else {
-                v = -ZZ(nn + 1 - iq, 1);
-            }
-        } else if (it > N - nn) {   // bottom boundary
-            const int iq = it - (N - nn);
-            if (lyrcut) {                                  // nothing comes back from below the cut (disort.f:3441-3452)
-                if (mazim > 0) v = -ZZ(iq + nn, ncut) * expbea[ncut];
-                else if (beam) v = -ZZ(iq + nn, ncut) * expbea[ncut] - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
-                else v = -ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
-            } else {
-                v = surf_bottom_rhs(iq, mazim, beam, fbeam, umu0, P.pi, albedo, bdrt, bemt, nn, cwt, cmu,
-                                    zz + (ncut - 1) * n, zp0 + (ncut - 1) * n, zp1 + (ncut - 1) * n,
-                                    expbea[ncut], taucpr[ncut], bplank);
-            }
-        } else {   // interface lc | lc+1
-            const int q = it - nn - 1;
-            const int lc = q / n + 1, iq = q % n + 1;
-            if (mazim > 0) {
-                v = (ZZ(iq, lc + 1) - ZZ(iq, lc)) * expbea[lc];
-            } else if (beam) {
-                v = (ZZ(iq, lc + 1) - ZZ(iq, lc)) * expbea[lc] + ZP0(iq, lc + 1) - ZP0(iq, lc)
-                    + (ZP1(iq, lc + 1) - ZP1(iq, lc)) * taucpr[lc];
-            } else {
-                v = ZP0(iq, lc + 1) - ZP0(iq, lc) + (ZP1(iq, lc + 1) - ZP1(iq, lc)) * taucpr[lc];
-            }
-        }
+        const double v = S.rhs(it);
         yv[it - 1] = v;
         if (!REG && it <= RW) bw[it - 1] = v;
     }
     __threadfence_block();   // RHS in HBM is re-read by this wave (row prefetch)
     wave_lds_sync();
-
-    // ---- matrix entry generator (SETMTX, disort.f:2844-2990): element (r, col) of the
-    //      coefficient matrix as a product g*f of one GC element and one STWJ factor ----
-    auto entry = [&](int r, int col, double &g, double &f) {
-        g = 0.0;
-        f = 1.0;
-        if (col < 1 || col > N) return;
-        if (r <= nn) {                       // top boundary: GC(nn+1-r, j, 1) * exp(KK(j,1)*TAUCPR(1))
-            if (col <= n) {
-                g = GC(nn + 1 - r, col, 1);
-                if (col <= nn) f = exp(KK(col, 1) * taucpr[1]);
-            }
-        } else if (r > N - nn) {             // bottom boundary, Lambertian reflection folded in
-            const int iq = col - (N - n);
-            if (iq >= 1) {
-                g = GC(nn + (r - (N - nn)), iq, ncut);
-                if (refl && brdf) {                        // row r - (N - nn) of BDR meets the downward streams (disort.f:2946-2952)
-                    double sr = 0.0;
-                    for (int k = 1; k <= nn; ++k)
-                        sr = sr + cwt[k - 1] * cmu[k - 1] * SBD_BDR(bdrt, r - (N - nn), k) * GC(nn + 1 - k, iq, ncut);
-                    g = g - (1.0 + delm0) * sr;
-                } else if (refl) g = g - (1.0 + delm0) * sbot[iq - 1];
-                if (iq > nn) f = EK(n + 1 - iq, ncut);
-            }
-        } else {                             // continuity between layers lc and lc+1
-            const int q = r - nn - 1;
-            const int lc = q / n + 1, jq = q - (lc - 1) * n + 1;
-            const int d = col - (lc - 1) * n;
-            if (d >= 1 && d <= n) {
-                g = GC(jq, d, lc);
-                if (d > nn) f = EK(n + 1 - d, lc);
-            } else if (d > n && d <= 2 * n) {
-                g = -GC(jq, d - n, lc + 1);
-                if (d - n <= nn) f = EK(d - n, lc + 1);
-            }
-        }
-    };
-
-    const double *ga_ms = P.ga + (size_t)ms * L * n * n;
-    const double *gb_ms = P.gb + (size_t)ms * L * n * n + (size_t)n * n;    // block of layer lc+1
-    auto row_elem = [&](int r, int col) -> double {      // element (r, col) of an entering row
-        if (col > N) return 0.0;
-        if (r > nn && r <= N - nn) {         // interface row: matrix-ready blocks, unit stride
-            const int qq = r - nn - 1;                   // row jq = qq % n of interface lc = qq / n + 1
-            const int d = col - (qq / n) * n;            // 1..2n inside the row's support
-            if (d >= 1 && d <= n) return ga_ms[(size_t)qq * n + d - 1];
-            if (d > n && d <= 2 * n) return gb_ms[(size_t)qq * n + d - n - 1];
-            return 0.0;
-        }
-        double g, f;                         // boundary rows
-        entry(r, col, g, f);
-        return g * f;
-    };
+    auto row_elem = [&](int r, int col) -> double { return S.row_elem(r, col); };
 
     // logical row k+i lives in physical row kq+i (kq = k - kbase < MARGIN, re-based every
     // MARGIN steps); column j sits at ring position j % CW, tracked by a wrap-around counter
@@ -570,12 +447,6 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         if (lane == 0) { ufac[(size_t)(N - 1) * UW] = d; yv[N - 1] = bw[kq]; }
     }
     if (status && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], status);
-#undef GC
-#undef KK
-#undef EK
-#undef ZZ
-#undef ZP0
-#undef ZP1
 #undef WIN
 }
 

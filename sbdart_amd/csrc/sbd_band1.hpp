@@ -193,7 +193,6 @@ __global__ void __launch_bounds__(64, SBD_B1_WAVES) band1_kernel(Params P)
     double *ufac = FUSED ? nullptr : P.ufac + (size_t)ms * (size_t)(L * n) * UW;
     double *bcb = P.bcb + (size_t)ms * 2 * n * n;                  // bottom-boundary rows + a block of zeros (below)
     double *mcol = smem;                                           // [RW] pivot column, for the right-hand side
-    const int N = ncut * n;
 #define GC(i, j, lc) gc[((size_t)((lc) - 1) * n + ((i) - 1)) * n + ((j) - 1)]
 #define KK(i, lc) kk[((lc) - 1) * n + ((i) - 1)]
 #define EK(i, lc) ek[((lc) - 1) * nn + ((i) - 1)]

@@ -26,6 +26,7 @@
 #include "sbd_common.hpp"
 #include "sbd_surface.hpp"
 #include "sbd_band.hpp"
+#include "sbd_bandsys.hpp"
 
 namespace sbd {
 
@@ -45,135 +46,6 @@ SBD_DEVICE double pick_lane(double x, int src)       // lane `src` (wave-uniform
                             __builtin_amdgcn_readlane(__double2loint(x), src));
 }
 
-// The boundary-value system of one (item, mode): right-hand side and matrix rows (SOLVE0 / SETMTX)
-template <int NN>
-struct BandSystem {
-    static constexpr int n = 2 * NN, nn = NN;
-    int N, ncut, mazim;
-    bool lyrcut, beam, brdf, refl;
-    double fbeam, albedo, delm0, umu0, pi, fisot, tplank, bplank;
-    const double *gc, *kk, *ek, *zz, *zp0, *zp1, *ga, *gb, *taucpr, *expbea, *cmu, *cwt, *bdrt, *bemt;
-    double *sbot;
-
-    SBD_DEVICE double GC(int i, int j, int lc) const { return gc[((size_t)(lc - 1) * n + (i - 1)) * n + (j - 1)]; }
-    SBD_DEVICE double KK(int i, int lc) const { return kk[(lc - 1) * n + (i - 1)]; }
-    SBD_DEVICE double EK(int i, int lc) const { return ek[(lc - 1) * nn + (i - 1)]; }
-    SBD_DEVICE double ZZ(int i, int lc) const { return zz[(lc - 1) * n + (i - 1)]; }
-    SBD_DEVICE double ZP0(int i, int lc) const { return zp0[(lc - 1) * n + (i - 1)]; }
-    SBD_DEVICE double ZP1(int i, int lc) const { return zp1[(lc - 1) * n + (i - 1)]; }
-
-    SBD_DEVICE void init(const Params &P, int slot, int mazim_, long long ms, const int32_t *svi, double *sbot_)
-    {
-        const int L = P.L;
-        mazim = mazim_;
-        ncut = svi[SBD_SVI_NCUT];
-        lyrcut = svi[SBD_SVI_LYRCUT] != 0;
-        N = ncut * n;
-        const SV o(L);
-        const double *sv = P.sv + (size_t)slot * P.sv_stride;
-        taucpr = sv + o.taucpr();
-        expbea = sv + o.expbea();
-        bplank = sv[o.bplank()];
-        tplank = sv[o.tplank()];
-        fbeam = P.fbeam[slot];
-        beam = fbeam > 0.0;
-        albedo = P.albedo[slot];
-        delm0 = (mazim == 0) ? 1.0 : 0.0;
-        umu0 = P.umu0; pi = P.pi; fisot = P.fisot;
-        cmu = P.t.cmu; cwt = P.t.cwt;
-        gc = P.gc + (size_t)ms * L * n * n;
-        kk = P.kk + (size_t)ms * L * n;
-        ek = P.ek + (size_t)ms * L * nn;
-        zz = P.zz + (size_t)ms * L * n;
-        zp0 = P.zp0 + (size_t)(ms - mazim) * L * n;   // thermal particular solutions exist for mode 0 only
-        zp1 = P.zp1 + (size_t)(ms - mazim) * L * n;
-        ga = P.ga + (size_t)ms * L * n * n;
-        gb = P.gb + (size_t)ms * L * n * n + (size_t)n * n;    // block of layer lc+1
-        // the surface: Lambertian (couples only for m = 0, disort.f:2925) or bidirectional (SURFAC's tables of this mode)
-        brdf = P.ibdrf != 0;
-        const size_t sidx = surf_index(P, slot, mazim);
-        bdrt = brdf ? surf_bdr(P, sidx) : nullptr;
-        bemt = brdf ? surf_bem(P, sidx) : nullptr;
-        refl = !lyrcut && (brdf || delm0 != 0.0);
-        sbot = sbot_;
-    }
-    // bottom-boundary reflection sums: S(IQ) = sum_k CWT(k) CMU(k) BDR GC(nn+1-k, IQ, ncut), Lambertian BDR = albedo
-    // for every pair (SURFAC, disort.f:3746-3763); lane < n
-    SBD_DEVICE void fill_sbot(int lane) const
-    {
-        if (lane < n) {
-            double s = 0.0;
-            if (refl && !brdf)
-#pragma nounroll
-                for (int k = 1; k <= nn; ++k) s = s + cwt[k - 1] * cmu[k - 1] * albedo * GC(nn + 1 - k, lane + 1, ncut);
-            sbot[lane] = s;
-        }
-    }
-    // right-hand side B (SOLVE0, disort.f:3434-3599), unknown index = (lc-1)*n + iq
-    SBD_DEVICE double rhs(int it) const
-    {
-        double v;
-        if (it <= nn) {   // top boundary
-            const int iq = it;
-            if (mazim == 0) {
-                if (beam) v = -ZZ(nn + 1 - iq, 1) - ZP0(nn + 1 - iq, 1) + fisot + tplank;
-                else v = -ZP0(nn + 1 - iq, 1) + fisot + tplank;
-            } else {
-                v = -ZZ(nn + 1 - iq, 1);
-            }
-        } else if (it > N - nn) {   // bottom boundary
-            const int iq = it - (N - nn);
-            if (lyrcut) {                                  // nothing comes back from below the cut (disort.f:3441-3452)
-                if (mazim > 0) v = -ZZ(iq + nn, ncut) * expbea[ncut];
-                else if (beam) v = -ZZ(iq + nn, ncut) * expbea[ncut] - ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
-                else v = -ZP0(iq + nn, ncut) - ZP1(iq + nn, ncut) * taucpr[ncut];
-            } else {
-                v = surf_bottom_rhs(iq, mazim, beam, fbeam, umu0, pi, albedo, bdrt, bemt, nn, cwt, cmu,
-                                    zz + (ncut - 1) * n, zp0 + (ncut - 1) * n, zp1 + (ncut - 1) * n,
-                                    expbea[ncut], taucpr[ncut], bplank);
-            }
-        } else {   // interface lc | lc+1
-            const int q = it - nn - 1;
-            const int lc = q / n + 1, iq = q % n + 1;
-            if (mazim > 0) {
-                v = (ZZ(iq, lc + 1) - ZZ(iq, lc)) * expbea[lc];
-            } else if (beam) {
-                v = (ZZ(iq, lc + 1) - ZZ(iq, lc)) * expbea[lc] + ZP0(iq, lc + 1) - ZP0(iq, lc)
-                    + (ZP1(iq, lc + 1) - ZP1(iq, lc)) * taucpr[lc];
-            } else {
-                v = ZP0(iq, lc + 1) - ZP0(iq, lc) + (ZP1(iq, lc + 1) - ZP1(iq, lc)) * taucpr[lc];
-            }
-        }
-        return v;
-    }
-    // element (r, col) of a boundary row (SETMTX, disort.f:2844-2990): a GC element times its STWJ factor
-    SBD_DEVICE double boundary_elem(int r, int col) const
-    {
-        if (col < 1 || col > N) return 0.0;
-        double g = 0.0, f = 1.0;
-        if (r <= nn) {                       // top boundary: GC(nn+1-r, j, 1) * exp(KK(j,1)*TAUCPR(1))
-            if (col <= n) {
-                g = GC(nn + 1 - r, col, 1);
-                if (col <= nn) f = exp(KK(col, 1) * taucpr[1]);
-            }
-        } else {                             // bottom boundary, the surface's reflection folded in
-            const int iq = col - (N - n);
-            if (iq >= 1) {
-                g = GC(nn + (r - (N - nn)), iq, ncut);
-                if (refl && brdf) {                        // row r - (N - nn) of BDR meets the downward streams (disort.f:2946-2952)
-                    double sr = 0.0;
-#pragma nounroll
-                    for (int k = 1; k <= nn; ++k)
-                        sr = sr + cwt[k - 1] * cmu[k - 1] * SBD_BDR(bdrt, r - (N - nn), k) * GC(nn + 1 - k, iq, ncut);
-                    g = g - (1.0 + delm0) * sr;
-                } else if (refl) g = g - (1.0 + delm0) * sbot[iq - 1];
-                if (iq > nn) f = EK(n + 1 - iq, ncut);
-            }
-        }
-        return g * f;
-    }
-};
-
 template <int NN>
 struct BandRows {      // the wave's registers
     static constexpr int n = 2 * NN;
@@ -186,6 +58,8 @@ struct BandRows {      // the wave's registers
     int myk, myJ;            // retired lanes: the row of U they hold, its first column inside the layer
     double mypiv;            // ... and its pivot
     bool live, retired;
+    bool func;               // FUSED: the lane holds a row of FLUXES' functionals -- eliminated like a live row, never a pivot
+    int fk;                  // ... which: 0..2 the top level's (mean intensity, down, up), 3..5 the surface level's
     double pv_min, pv_max;   // smallest / largest |pivot| among the rows this lane retired
     bool pv_nan;
 };
@@ -230,12 +104,24 @@ SBD_DEVICE void band_rows_pivot(BandRows<NN> &s, const double akJ, const int J)
     // the interchange: the row that sat at position k takes the pivot row's place in the order
     const int lP = __builtin_amdgcn_readlane(s.lrow, Pl);
     if (s.live && s.lrow == s.k) s.lrow = lP;
-    const bool other = s.live && lane != Pl;
+    const bool other = (s.live || s.func) && lane != Pl;
     s.m = other ? ak * tinv : 0.0;
     if (lane == Pl && s.live) { s.live = false; s.retired = true; s.myJ = J; s.myk = s.k; s.mypiv = ak; }
 }
 
-template <int NN>
+SBD_DEVICE double wave_sum(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 64);
+    return v;
+}
+
+// FUSED (flux-only run, output levels = top of layer 1 and the surface; sbd_band1.hpp / sbd_band4.hpp have the long
+// version): FLUXES' three angular sums at a level are linear functionals c^T x of the solution; each rides through the
+// elimination as one more row of [A b; c^T 0] that never takes part in the pivot search, so that after the last step
+// its right-hand side is -c^T x.  A row is a lane here, and 3 NSTR/2 + 3 <= 63: the top level's three rows take lanes
+// that would idle, the surface level's three join for the last layer.  No U, no B, no back-substitution kernel.
+template <int NN, bool FUSED>
 __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -255,6 +141,7 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
     if (dead) {   // DISORT returned before computing anything: outputs stay zero (ZEROAL)
         double *flux = P.flux + (size_t)slot * SBD_NFLUX_ * P.nlev;
         for (int i = lane; i < SBD_NFLUX_ * P.nlev; i += 64) flux[i] = 0.0;
+        if constexpr (FUSED) { if (lane == 0) P.status[slot] = st0; }     // (the last kernel of a fused pass: no finish_kernel)
         return;
     }
     const BandRowsLds lds(n, nn);
@@ -265,11 +152,13 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
     wave_lds_sync();
     const int ncut = __builtin_amdgcn_readfirstlane(S.ncut), N = ncut * n;   // (wave-uniform, and known to be)
     double *yv = P.yv + (size_t)ms * L * n;
-    double *ufac = P.ufac + (size_t)ms * (size_t)(L * n) * UW;
+    double *ufac = FUSED ? nullptr : P.ufac + (size_t)ms * (size_t)(L * n) * UW;
+    const SV o(L);
+    const double *sv = P.sv + (size_t)slot * P.sv_stride;
 
     BandRows<NN> s;
     static_for<n>([&](auto cc) { s.cur[decltype(cc)::value] = 0.0; s.nxt[decltype(cc)::value] = 0.0; });
-    s.b = 0.0; s.m = 0.0; s.P = 0; s.lrow = 0; s.k = 1; s.myk = 0; s.myJ = 0; s.mypiv = 0.0; s.live = false; s.retired = false;
+    s.b = 0.0; s.m = 0.0; s.P = 0; s.lrow = 0; s.k = 1; s.myk = 0; s.myJ = 0; s.mypiv = 0.0; s.live = false; s.retired = false; s.func = false; s.fk = 0;
     s.pv_min = 1.0e300; s.pv_max = 0.0; s.pv_nan = false;
 
     // nb boundary rows r0, r0+1, .. (columns c0+1 .. c0+n) to the free lanes of rank rank0.. through the LDS stage
@@ -290,9 +179,45 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
         }
     };
 
+    // FUSED: the three functional rows of output level `lev`, which lies in layer lcf (the layer whose columns are x_lc
+    // now), to the free lanes of rank rank0..: c_k(j) = sum_i w_i GC(i, j, lcf) * exp(-KK(j, lcf) (utau' - reference depth
+    // of column j's scaling)), k = mean intensity / downward / upward weights (sbd_band1.hpp)
+    auto enter_functionals = [&](int lcf, int lev, bool valid, int fk0, bool isfree, int rank, int rank0) {
+        wave_lds_sync();
+        if (lane < n) {
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+            if (valid) {
+                const int jq = lane + 1;
+                const double up = sv[o.utaupr() + lev];
+                const double ref = (lane < nn) ? S.taucpr[lcf] : S.taucpr[lcf - 1];
+                const double e = exp(-S.KK(jq, lcf) * (up - ref));
+                double sa = 0.0, sd = 0.0, su = 0.0;
+#pragma nounroll
+                for (int i = 0; i < n; ++i) {
+                    const int iw = (i < nn) ? nn - 1 - i : i - nn;
+                    const double g = S.GC(i + 1, jq, lcf), w = S.cwt[iw];
+                    sa = sa + w * g;
+                    if (i < nn) sd = sd + (w * S.cmu[iw]) * g;
+                    else su = su + (w * S.cmu[iw]) * g;
+                }
+                c0 = sa * e; c1 = sd * e; c2 = su * e;
+            }
+            stage[0 * SP + lane] = c0; stage[1 * SP + lane] = c1; stage[2 * SP + lane] = c2;
+        }
+        wave_lds_sync();
+        if (isfree && rank >= rank0 && rank < rank0 + 3) {
+            const int i = rank - rank0;
+            const double *row = stage + i * SP;
+            static_for<n>([&](auto cc) { constexpr int c = decltype(cc)::value; s.cur[c] = row[c]; s.nxt[c] = 0.0; });
+            s.b = 0.0;
+            s.func = true;
+            s.fk = fk0 + i;
+        }
+    };
+
     for (int lc = 1; lc <= ncut; ++lc) {
         // ---- the rows that enter for this layer take the lanes free since the last one ----
-        const bool isfree = !s.live;
+        const bool isfree = !s.live && !s.func;
         const unsigned long long fmask = __ballot(isfree);
         const int rank = __popcll(fmask & ((1ull << lane) - 1ull));
         int taken = 0;
@@ -311,8 +236,18 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
                 s.b = S.rhs(nn + qq + 1);
                 s.live = true;
             }
+            taken += n;
         } else {
             enter_boundary(N - nn + 1, N - n, nn, isfree, rank, taken);
+            taken += nn;
+        }
+        if constexpr (FUSED) {
+            if (lc == 1) { enter_functionals(1, P.t.level_out[0], true, 0, isfree, rank, taken); taken += 3; }
+            if (lc == ncut) {      // (only a level inside layer ncut has any: below a cut-off layer the fluxes stay zero)
+                const int levb = P.t.level_out[1];
+                enter_functionals(ncut, levb, svi[SBD_SVI_LAYRU + levb] == ncut, 3, isfree, rank, taken);
+                taken += 3;
+            }
         }
         // ---- the layer's NSTR columns ----
 #pragma nounroll
@@ -325,6 +260,7 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
         }
         // ---- the retired rows leave: U(k, .) by layer block (register c <-> column c of [x_lc, x_lc+1]), B(k) ----
         if (s.retired) {
+          if constexpr (!FUSED) {
             double *urow = ufac + (size_t)(s.myk - 1) * UW;
             static_for<NN>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
@@ -337,6 +273,7 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
                 });
             }
             yv[s.myk - 1] = s.b;
+          }
             { const double ap = fabs(s.mypiv); s.pv_nan = s.pv_nan || (ap != ap); s.pv_min = fmin(s.pv_min, ap); s.pv_max = fmax(s.pv_max, ap); }
             s.retired = false;
         }
@@ -351,7 +288,65 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
         pmax = fmax(pmax, __shfl_xor(pmax, d));
     }
     const bool any_nan = __ballot(s.pv_nan) != 0ull;
-    if (!any_nan && pmin <= 1.1102230246251565e-16 * pmax && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], 0x01);
+    const int status = (!any_nan && pmin <= 1.1102230246251565e-16 * pmax) ? 0x01 : 0;
+    if (status && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], status);
+    if constexpr (FUSED) {
+        if (lane == 0) P.status[slot] = st0 | status;       // (the last kernel of a fused pass: no finish_kernel)
+        // ---- FLUXES (disort.f:1780-2042) at the two levels from the functionals' right-hand sides ----
+        double fs[2][3];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const unsigned long long w = __ballot(s.func && s.fk == k);
+            fs[k / 3][k % 3] = w ? -pick_lane(s.b, __ffsll((long long)w) - 1) : 0.0;
+        }
+        const bool mycol = lane < n;
+        const int qc = mycol ? lane : 0;
+        const int iqw = (qc < nn) ? nn - 1 - qc : qc - nn;
+        const double wq = mycol ? S.cwt[iqw] : 0.0, wmq = mycol ? S.cwt[iqw] * S.cmu[iqw] : 0.0;
+        const double pi = P.pi, umu0 = P.umu0, fbeam = S.fbeam;
+        const bool beam = S.beam;
+        const int32_t *layru = svi + SBD_SVI_LAYRU;
+        const double *utau = sv + o.utau(), *utaupr = sv + o.utaupr(), *ssalbv = sv + o.ssalb();
+        const double *xr0 = sv + o.xr0(), *xr1 = sv + o.xr1();
+        const int nlev = P.nlev;
+        double *flux = P.flux + (size_t)slot * SBD_NFLUX_ * nlev;
+#pragma unroll
+        for (int ol = 0; ol < 2; ++ol) {
+            const int lev = P.t.level_out[ol];
+            const int lc = layru[lev];
+            double rfldir = 0.0, rfldn = 0.0, flup = 0.0, dfdt = 0.0, uavg = 0.0;
+            if (lc <= ncut) {       // (levels below a cut-off layer stay zero, disort.f:1907-1916)
+                const double up = utaupr[lev];
+                // particular solutions' share of U0C(iq): ZZ e^{-tau'/mu0} + ZPLK0 + ZPLK1 tau' (disort.f:1945-1960)
+                double part = S.zp0[(lc - 1) * n + qc] + S.zp1[(lc - 1) * n + qc] * up;
+                if (beam) part = S.zz[(lc - 1) * n + qc] * exp(-up / umu0) + part;
+                const double uavg_s = fs[ol][0] + wave_sum(wq * part);
+                const double fldn_s = fs[ol][1] + wave_sum((qc < nn) ? wmq * part : 0.0);
+                const double flup_s = fs[ol][2] + wave_sum((qc >= nn) ? wmq * part : 0.0);
+                double dirint = 0.0, fldir = 0.0;
+                if (beam) {
+                    const double fact = exp(-up / umu0);
+                    dirint = fbeam * fact;
+                    fldir = umu0 * (fbeam * fact);
+                    rfldir = umu0 * fbeam * exp(-utau[lev] / umu0);
+                }
+                flup = 2.0 * pi * flup_s;
+                const double fldn = 2.0 * pi * fldn_s;
+                const double fdntot = fldn + fldir;
+                rfldn = fdntot - rfldir;
+                uavg = (2.0 * pi * uavg_s + dirint) / (4.0 * pi);
+                const double plsorc = xr0[lc - 1] + xr1[lc - 1] * up;
+                dfdt = (1.0 - ssalbv[lc - 1]) * 4.0 * pi * (uavg - plsorc);
+            }
+            if (lane == 0) {
+                flux[0 * nlev + ol] = rfldir;
+                flux[1 * nlev + ol] = rfldn;
+                flux[2 * nlev + ol] = flup;
+                flux[3 * nlev + ol] = dfdt;
+                flux[4 * nlev + ol] = uavg;
+            }
+        }
+    }
 }
 
 }  // namespace sbd

@@ -637,7 +637,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     bool band_rows = sbd::has_band_rows(nn);
     if (const char *s = getenv("SBD_BAND_V1")) { band4 = band4 && atoi(s) == 0; band1 = band1 && atoi(s) == 0; band_rows = band_rows && atoi(s) == 0; }
     // fluxes at the top of the first layer and at the surface only (IOUT 1 / 10 with the default ZOUT): fused band kernel
-    bool fused = (band4 || band1) && nn >= 3 && cfg->onlyfl && cfg->nlevel_out == 2 && cfg->level_out[0] == 0 && cfg->level_out[1] == L;
+    bool fused = (band4 || band1 || band_rows) && nn >= 3 && cfg->onlyfl && cfg->nlevel_out == 2 && cfg->level_out[0] == 0 && cfg->level_out[1] == L;
     if (const char *s = getenv("SBD_NO_FUSE")) fused = fused && atoi(s) == 0;
     e->pivot_exact = cfg->pivot_exact != 0;
     if (const char *s = getenv("SBD_EXACT_PIVOT")) e->pivot_exact = e->pivot_exact || atoi(s) != 0;
@@ -1267,7 +1267,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             } else if (e->band4 && e->pivot_exact) sbd::launch_band4_exact(e->nn, (bgrid + 3) / 4, st, P, e->fused, false);
             else if (e->band4) sbd::launch_band4(e->nn, (bgrid + 3) / 4, st, P, e->fused);
             else if (e->band1) sbd::launch_band1(e->nn, bgrid, st, P, e->fused);
-            else if (e->band_rows) sbd::launch_band_rows(e->nn, bgrid, st, P);
+            else if (e->band_rows) sbd::launch_band_rows(e->nn, bgrid, st, P, e->fused);
             else sbd::launch_band_lds(e->nn, bgrid, e->band_lds, st, P);
         }
         SBD_DBG("band");
@@ -1815,7 +1815,7 @@ int sbd_fleet_solve_host(sbd_fleet *f, const sbd_batch_in *in, const sbd_batch_o
     if (e0->ibcnd) weight = nullptr;                 // (albedo / transmissivity of the medium: nothing to integrate)
     const int L = e0->L, nlev = e0->nlev, nmom1 = e0->cfg.nmom + 1;
     const bool rad = !e0->cfg.onlyfl;
-    const size_t nel_f = (size_t)SBD_NFLUX * nlev, nel_u = rad ? (size_t)e0->P.nphi * nlev * e0->P.numu : 0, nel = nel_f + nel_u;
+    const size_t nel_f = (size_t)SBD_NFLUX * nlev;
     const size_t uu_item = rad ? (size_t)e0->P.nphi * nlev * e0->P.numu : 0;
     std::vector<int> busy;
     for (int r = 0; r < nd; ++r) {

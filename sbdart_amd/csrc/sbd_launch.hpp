@@ -36,7 +36,7 @@ hipError_t prepare_band_lds(int nn, int lds);
 void launch_band_lds(int nn, unsigned grid, int lds, hipStream_t st, const Params &P);
 bool has_band_rows(int nn);
 int band_rows_lds_bytes(int nn);
-void launch_band_rows(int nn, unsigned grid, hipStream_t st, const Params &P);
+void launch_band_rows(int nn, unsigned grid, hipStream_t st, const Params &P, bool fused);
 void launch_band4(int nn, unsigned grid, hipStream_t st, const Params &P, bool fused);
 void launch_band4_pivdbg(int nn, unsigned grid, hipStream_t st, const Params &P);
 void launch_band4_exact(int nn, unsigned grid, hipStream_t st, const Params &P, bool fused, bool pivdbg);

@@ -327,7 +327,13 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
 
     // ---- delta-M scaled Legendre coefficients GL(k) (SETDIS, disort.f:2583-2585) ----
     const double f = sv[o.flyr() + lc - 1];
-    const double oprim = sv[o.oprim() + lc - 1];
+    double w_lay = sv[o.ssalb() + lc - 1];       // the layer's single-scattering albedo as the setup kernel left it (dithered if 1)
+    double oprim = sv[o.oprim() + lc - 1];
+    int status = 0;
+    double *kkout = P.kk + ((size_t)ms * L + (lc - 1)) * n;
+    double *ekout = P.ek + ((size_t)ms * L + (lc - 1)) * nn;
+    // (a second attempt only when an eigenvalue comes out EXACTLY zero, below)
+    for (int attempt = 0;; ++attempt) {
     {
         const double *pm = P.pmom + (pmom_item(P, slot) * L + (lc - 1)) * (P.nmom + 1);
         if (g < n) {
@@ -368,13 +374,10 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
         }
     }
     wave_lds_sync();
-    int status = 0;
     {
         const int ier = eig_group(arr, ldh, ev, ld, eval, nn, wk, xs, g);
         if (ier != 0) status |= 0x08;
     }
-    double *kkout = P.kk + ((size_t)ms * L + (lc - 1)) * n;
-    double *ekout = P.ek + ((size_t)ms * L + (lc - 1)) * nn;
     if (me <= nn) {   // disort.f:3264-3269
         const double kq = sqrt(fabs(eval[me - 1]));
         eval[me - 1] = kq;
@@ -384,6 +387,22 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
         ekout[nn + 1 - me - 1] = exp(-kq * sv[o.dtaucp() + lc - 1]);
     }
     wave_lds_sync();
+    // A layer a few ulps from conservative scattering (SSALB = 1 - 3e-16: molecular scattering with a trace of absorption;
+    // DISORT dithers SSALB = 1 only) has an eigenvalue k^2 of a few units of the last place of ARRAY's entries: what comes
+    // out is rounding -- the reference gets 2^-48 or 3 x 2^-48 there -- and here, with other contractions, it can cancel to
+    // exactly zero, which the division by k below turns into NaN eigenvectors (end-to-end fuzz, seed 5003: NSTR 40).  Such
+    // a layer IS conservative to working precision: it gets the reference's own remedy for that, the dithered albedo
+    // (disort.f:486), and one more pass.  The fluxes do not depend on which tiny k stands there (the oracle's FMA twin
+    // moves them by 3e-9).
+    {
+        bool zero_k = false;
+        for (int q = 0; q < nn; ++q) zero_k = zero_k || (eval[q] == 0.0);
+        if (!zero_k || attempt == 1) break;
+        wave_lds_sync();
+        w_lay = 1.0 - P.dither;
+        oprim = w_lay * (1.0 - f) / (1.0 - f * w_lay);
+    }
+    }
     if (me <= nn) {   // (G+)+(G-) = AMB * evec / k  (disort.f:3273-3286), column me, into APB
         for (int iq = 1; iq <= nn; ++iq) {
             double sum = 0.0;
@@ -443,7 +462,7 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
     if (fbeam > 0.0 || thermal) {
 #pragma clang fp contract(off)
         wave_lds_sync();
-        const double wdith = sv[o.ssalb() + lc - 1];
+        const double wdith = w_lay;
         const double oprim_x = wdith * (1.0 - f) / (1.0 - f * wdith);
         const double *pm = P.pmom + (pmom_item(P, slot) * L + (lc - 1)) * (P.nmom + 1);
         if (g < n) {
@@ -501,7 +520,7 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
     double z0 = 0.0, z1 = 0.0;
     if (thermal) {
 #pragma clang fp contract(off)
-        const double oprim = oprim_exact(sv[o.ssalb() + lc - 1], f);
+        const double oprim = oprim_exact(w_lay, f);
         const double xr0 = sv[o.xr0() + lc - 1], xr1 = sv[o.xr1() + lc - 1];
         if (me <= n) {
             for (int iq = 1; iq <= n; ++iq) LU(iq, me) = -CC(iq, me);

@@ -400,7 +400,6 @@ __global__ void __launch_bounds__(256) azimuth_kernel(Params P, int naz_run)
     if (tid >= per * P.nslot) return;
     const int slot = (int)(tid / per);
     const int rem = (int)(tid % per);   // li*numu + iu
-    const double fbeam = P.fbeam[slot];
     const int nazi = P.svi[(size_t)slot * P.svi_stride + SBD_SVI_NAZ];
     const int naz = (nazi < naz_run) ? nazi : naz_run;   // disort.f:577-586 (0 without a beam) and the item's last mode with a moment
     const double *uum = P.uum + (size_t)slot * nmode * per + rem;

@@ -28,10 +28,13 @@ from sbdart_amd.records import read_records, write_records  # noqa: E402
 CAPTURE = os.path.join(ROOT, "oracle", "_ref", "sbdart_capture")
 
 
-def run_case(namelist: str):
+def run_case(namelist: str, files=None):
     with tempfile.TemporaryDirectory() as d:
         with open(os.path.join(d, "INPUT"), "w") as f:
             f.write("\n &INPUT\n" + namelist + "\n /\n")
+        for name, text in (files or {}).items():        # the user's data files (atms.dat, usrcld.dat, filter.dat, ...)
+            with open(os.path.join(d, name), "w") as f:
+                f.write(text)
         env = dict(os.environ, SBD_CAPTURE_FILE=os.path.join(d, "cap.sbdrec"))
         out = subprocess.run([CAPTURE], cwd=d, env=env, capture_output=True, text=True, check=True).stdout
         recs = read_records(os.path.join(d, "cap.sbdrec"))
@@ -50,12 +53,12 @@ def main():
     if only and os.path.exists(os.path.join(HERE, "MANIFEST.json")):
         manifest.update(json.load(open(os.path.join(HERE, "MANIFEST.json"))))
 
-    def emit(name, namelists, pick, keep_stdout=True, full_inputs=False):
+    def emit(name, namelists, pick, keep_stdout=True, full_inputs=False, files=None):
         if only and name not in only:
             return None
         allrec, stdout, allw = [], "", []
         for nl in namelists:
-            out, recs, warns = run_case(nl)
+            out, recs, warns = run_case(nl, files)
             stdout += out
             allrec += pick(recs)
             allw += warns
@@ -245,6 +248,27 @@ def main():
          ["idatm=4 wlinf=8 wlsup=9.6 wlinc=4.16667 iday=200 time=0 alat=35 alon=-120 nf=2 uo3=0.35 ngrid=65 "
           "zgrid1=2 zgrid2=10 iout=1 nstr=16"],
          lambda r: [x for x in r if x.kd == 3][::9][:6], keep_stdout=False)
+
+    # --- layers a few ulps from conservative scattering (molecular scattering with a trace of absorption: SSALB = 1 - 1e-16
+    #     .. 1 - 2e-15, which DISORT does not dither): two runs of the end-to-end fuzz of round 5 whose items came back NaN
+    #     from the engine (tests/test_gpu_parity.py::test_rayleigh_layer_next_to_conservative).  The user's data files are
+    #     the ones tests/test_band_model.py writes.
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_band_model import USER_FILES  # noqa: E402
+
+    def near_conservative(recs, n_near, with_exact_one):
+        near = [r for r in recs if 0 < 1 - r.ssalb.max() < 1e-13][:n_near]
+        one = [r for r in recs if r.ssalb.max() == 1.0][:1] if with_exact_one else []
+        plain = [r for r in recs if 1 - r.ssalb.max() > 1e-6][:1]
+        return near + one + plain
+    emit("illcond/rayleigh_next_to_conservative",
+         ["idatm=3 csza=0.5 uw=2 sclh2o=2.5 uw=1.5 zpres=0.5 isalb=9 sc=0.2,0.01,0.002,1.0,2.0 ngrid=65 zgrid1=1 zgrid2=30 "
+          "nothrm=1 iout=6 nstr=16 nzen=5 uzen=0,80 nphi=2 phi=0,180 zout=0,100 wlinc=.01 isat=-1"],
+         lambda r: near_conservative(r, 3, True), keep_stdout=False, files=USER_FILES)
+    emit("illcond/nstr40_next_to_conservative",
+         ["idatm=5 wlinf=0.3 wlsup=0.45 wlinc=0 csza=0.2 uo3=0.2 xo4=0 xn2o=0.1 iout=7 nstr=40 nre=0"],
+         lambda r: [x for x in r if x.iwl in (16, 17, 22)][:3] + [x for x in r if x.iwl == 1][:1], keep_stdout=False,
+         files=USER_FILES)
 
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

@@ -16,7 +16,7 @@ from sbdart_amd.records import read_records
 
 from conftest import GOLDEN
 
-FILES = sorted(glob.glob(os.path.join(GOLDEN, "*.sbdrec")))
+FILES = sorted(glob.glob(os.path.join(GOLDEN, "*.sbdrec")) + glob.glob(os.path.join(GOLDEN, "illcond", "*.sbdrec")))
 FLUX = ("rfldir", "rfldn", "flup", "dfdt", "uavg")
 TOL = 1e-12
 

@@ -10,7 +10,8 @@ if len(sys.argv) > 2:
     from test_band_model import USER_FILES
     files = USER_FILES
 for name, env in (("default", {}), ("SBD_HOST_GAS=1", {"SBD_HOST_GAS": "1"}), ("SBD_NO_MIX=1", {"SBD_NO_MIX": "1"}),
-                  ("SBD_FORCE_EIG_FALLBACK=1", {"SBD_FORCE_EIG_FALLBACK": "1"})):
+                  ("SBD_FORCE_EIG_FALLBACK=1", {"SBD_FORCE_EIG_FALLBACK": "1"}), ("SBD_BAND_V1=1", {"SBD_BAND_V1": "1"}),
+                  ("SBD_LAYER_V1=1", {"SBD_LAYER_V1": "1"})):
     with tempfile.TemporaryDirectory() as d:
         try:
             ref, got, cap = run_reference_and_host(nl, d, from_input=True, files=files, host_env=env)

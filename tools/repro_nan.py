@@ -16,6 +16,9 @@ with tempfile.TemporaryDirectory() as d:
     out = os.path.join(d, "items.sbdrec")
     subprocess.run([os.path.join(ROOT, "sbdart_amd", "bin", "sbdart_amd")], cwd=d, env=dict(os.environ, SBD_DUMP_OPTICS=out, SBD_OPTICS=os.path.join(d, "none")), capture_output=True)
     recs = [r for r in read_records(out) if r.ff != 0.0]
+for r in recs:                       # (the dump of the host's band model does not carry the LAMBER bit)
+    if getattr(r, "ibdrf", 0) == 0:
+        r.flags |= 4
 print(len(recs), "items; nstr", recs[0].nstr, "nlyr", recs[0].nlyr, "onlyfl", recs[0].onlyfl, "ibdrf", getattr(recs[0], "ibdrf", 0))
 for lev in (None, [0, recs[0].nlyr]):
     flux, uu, st = solve_records(recs, level_out=lev)
