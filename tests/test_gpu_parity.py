@@ -320,6 +320,30 @@ def test_level_selection_for_every_band_kernel(nstr):
             assert np.abs(ft[c] - fa[c][[0, -1]]).max() <= 1e-8 * recmax, (nstr, name, "two levels vs all")
 
 
+@pytest.mark.parametrize("nstr", [8, 16, 24, 32, 34, 40])
+def test_fused_level_pair_on_one_to_three_layers(nstr):
+    """The fused band kernels (no stored factor: FLUXES' functionals ride through the elimination) on atmospheres of one,
+    two and three layers, where the first layer step is the last or next to it -- the top level's functional rows and the
+    surface level's then enter together (band4 / band1: tags in the x_lc+1 half; band_rows: six lanes at once).  Thermal
+    items included (the sweep's long-wave end); against the oracle and against the stored-factor path."""
+    import pyoracle
+    from sbdart_amd.engine import solve_records
+    from sbdart_amd.workload import sw_sweep, sweep_to_records
+    for nlyr in (1, 2, 3):
+        sw = sw_sweep(nwl=16, nstr=nstr, nlyr=nlyr, seed=900 + nlyr, thermal_above_um=3.0)
+        recs = sweep_to_records(sw, range(0, sw.nwork, 3))
+        outs = [pyoracle.disort(r) for r in recs]
+        f_all, _, st_all = solve_records(recs)
+        f_two, _, st_two = solve_records(recs, level_out=[0, nlyr])
+        assert st_all == st_two == [o["status"] for o in outs], (nstr, nlyr)
+        for fa, ft, o in zip(f_all, f_two, outs):
+            recmax = max(np.abs(o[name]).max() for name in FLUX)
+            for c, name in enumerate(FLUX):
+                sc = max(np.abs(o[name]).max(), 1e-300)
+                assert np.abs(ft[c] - o[name][[0, -1]]).max() <= TOL * sc + 1e-12 * recmax, (nstr, nlyr, name, "two levels")
+                assert np.abs(ft[c] - fa[c][[0, -1]]).max() <= 1e-8 * recmax, (nstr, nlyr, name, "two levels vs all")
+
+
 @pytest.mark.parametrize("path", [f for f in FILES if "rad" not in f and "corint" not in f and "sbchk5" not in f and "quadangles" not in f],
                          ids=lambda f: os.path.basename(f))
 def test_two_level_fused_path_matches_reference_records(path):
