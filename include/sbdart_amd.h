@@ -75,7 +75,8 @@ extern "C" {
 #define SBD_ST_ERR_EIGEN     0x08  /* eigen-solve did not converge (fatal, disort.f:3254-3261) */
 #define SBD_ST_RETRY_NSTR    0x10  /* disort.f:2645-2650 */
 #define SBD_ST_ERR_INPUT     0x20  /* CHEKIN fatal for this item (disort.f:5140) */
-#define SBD_ST_WARN_PLKAVG   0x40  /* errmsg 9 / 10 (disort.f:5597, 5657) */
+#define SBD_ST_WARN_PLKAVG   0x40  /* errmsg 10: PLKAVG returns zero, possible underflow (disort.f:5657) */
+#define SBD_ST_WARN_PLKCONV  0x80  /* errmsg 9: PLKAVG's Simpson rule did not converge (disort.f:5597); until round 5 it shared 0x40 */
 
 /* flux components per output level, in this order (DISORT's output arguments) */
 #define SBD_NFLUX 5

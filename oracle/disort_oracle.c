@@ -2040,7 +2040,8 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
         tplank = in->temis * sbdo_plkavg(in->wvnmlo, in->wvnmhi, in->ttemp, &pw);
         bplank = sbdo_plkavg(in->wvnmlo, in->wvnmhi, in->btemp, &pw);
         for (int lev = 0; lev <= L; ++lev) w->pkag[lev] = sbdo_plkavg(in->wvnmlo, in->wvnmhi, in->temper[lev], &pw);
-        if (pw) status |= SBDO_WARN_PLKAVG;
+        if (pw & 2) status |= SBDO_WARN_PLKAVG;
+        if (pw & 1) status |= SBDO_WARN_PLKCONV;
     }
 
     /* ---- azimuth loop (disort.f:577-829) ---- */

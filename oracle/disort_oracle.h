@@ -26,7 +26,8 @@ extern "C" {
 #define SBDO_ERR_ASYMTX        0x08   /* fatal      disort.f:3254-3261 */
 #define SBDO_RETRY_NSTR        0x10   /* nstr=-abs(nstr) disort.f:2645-2650 */
 #define SBDO_ERR_INPUT         0x20   /* CHEKIN fatal, disort.f:5140 */
-#define SBDO_WARN_PLKAVG       0x40   /* errmsg(9)/(10) disort.f:5597,5657 */
+#define SBDO_WARN_PLKAVG       0x40   /* errmsg(10) disort.f:5657 */
+#define SBDO_WARN_PLKCONV      0x80   /* errmsg(9) disort.f:5597 */
 
 typedef struct {
     int nlyr, nstr, nmom;       /* PMOM row stride is nmom+1 */

@@ -17,7 +17,7 @@ _LIB: Optional[C.CDLL] = None
 _LIB_FMA: Optional[C.CDLL] = None
 
 WARN_SOLVE0_RCOND, WARN_UPBEAM_RCOND, WARN_UPISOT_RCOND = 1, 2, 4
-ERR_ASYMTX, RETRY_NSTR, ERR_INPUT, WARN_PLKAVG = 8, 16, 32, 64
+ERR_ASYMTX, RETRY_NSTR, ERR_INPUT, WARN_PLKAVG, WARN_PLKCONV = 8, 16, 32, 64, 128
 
 _dp = C.POINTER(C.c_double)
 

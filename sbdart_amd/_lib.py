@@ -15,7 +15,7 @@ RFLDIR, RFLDN, FLUP, DFDT, UAVG = range(5)
 
 OK, E_INVALID, E_RETRY_NSTR, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_NOMEM = 0, -1, -2, -3, -4, -5, -6
 ST_WARN_SOLVE0, ST_WARN_UPBEAM, ST_WARN_UPISOT, ST_ERR_EIGEN = 0x01, 0x02, 0x04, 0x08
-ST_RETRY_NSTR, ST_ERR_INPUT, ST_WARN_PLKAVG = 0x10, 0x20, 0x40
+ST_RETRY_NSTR, ST_ERR_INPUT, ST_WARN_PLKAVG, ST_WARN_PLKCONV = 0x10, 0x20, 0x40, 0x80
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

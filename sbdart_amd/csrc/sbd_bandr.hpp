@@ -72,11 +72,6 @@ SBD_DEVICE void band_rows_pivot(BandRows<NN> &s, const double akJ, const int J)
 {
     const int lane = threadIdx.x;
     const double ak = akJ;               // (lanes without a live row: whatever their registers hold -- never candidates)
-    // -1/a for every candidate while the max-scan runs (v_rcp_f64 + two Newton steps, as sbd_band.hpp)
-    double rk = __builtin_amdgcn_rcp(ak);
-    rk = rk * (2.0 - ak * rk);
-    rk = rk * (2.0 - ak * rk);
-    rk = -rk;
     // ISAMAX over the live rows: largest |a|, first in LINPACK's row order among equals
     const unsigned hi = s.live ? ((unsigned)__double2hiint(ak) & 0x7fffffffu) : 0u;
     const unsigned mhi = wave_umax<true>(hi);
@@ -99,10 +94,20 @@ SBD_DEVICE void band_rows_pivot(BandRows<NN> &s, const double akJ, const int J)
     }
     const int Pl = hit ? __ffsll((long long)hit) - 1 : 0;
     s.P = Pl;
-    const double piv = pick_lane(ak, Pl), tsel = pick_lane(rk, Pl);
-    const double tinv = (piv != 0.0) ? tsel : 0.0;
+    // the pivot and its row's place in the order, from the pivot lane: v_readfirstlane with EXEC narrowed to that lane
+    // (one issue slot each; v_readlane with an SGPR lane select costs 1.7, profiles/r05_valu_rates.txt)
+    int plo, phi, lP;
+    asm volatile("s_mov_b64 exec, %3\n\tv_readfirstlane_b32 %0, %4\n\tv_readfirstlane_b32 %1, %5\n\tv_readfirstlane_b32 %2, %6\n\t"
+                 "s_mov_b64 exec, -1\n\ts_nop 1"
+                 : "=s"(plo), "=s"(phi), "=s"(lP)
+                 : "s"(1ull << Pl), "v"(__double2loint(ak)), "v"(__double2hiint(ak)), "v"(s.lrow));
+    const double piv = __hiloint2double(phi, plo);
+    // -1/pivot (v_rcp_f64 + two Newton steps, as sbd_band.hpp forms it lane by lane: the same bits)
+    double rk = __builtin_amdgcn_rcp(piv);
+    rk = rk * (2.0 - piv * rk);
+    rk = rk * (2.0 - piv * rk);
+    const double tinv = (piv != 0.0) ? -rk : 0.0;
     // the interchange: the row that sat at position k takes the pivot row's place in the order
-    const int lP = __builtin_amdgcn_readlane(s.lrow, Pl);
     if (s.live && s.lrow == s.k) s.lrow = lP;
     const bool other = (s.live || s.func) && lane != Pl;
     s.m = other ? ak * tinv : 0.0;

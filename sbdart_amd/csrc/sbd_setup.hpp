@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
             sv[o.bplank()] = P.ibcnd ? (((P.slot_base + slot) & 1) ? 1.0 : 0.0) : pk;
         }
     }
-    if (pw) atomicOr(&s_pw, 1);
+    if (pw) atomicOr(&s_pw, pw);
     __syncthreads();
     // ---- thermal source slopes (disort.f:659-666) ----
     for (int lc = lane; lc < L; lc += 64) {
@@ -287,7 +287,8 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
     if (lane == 0) {
         int st = 0;
         if (s_err) st |= 0x20;   // SBD_ST_ERR_INPUT
-        if (s_pw) st |= 0x40;    // SBD_ST_WARN_PLKAVG
+        if (s_pw & 2) st |= 0x40;    // SBD_ST_WARN_PLKAVG  (errmsg 10: returns zero)
+        if (s_pw & 1) st |= 0x80;    // SBD_ST_WARN_PLKCONV (errmsg 9: Simpson's rule did not converge)
         // beam angle == quadrature angle (disort.f:2643-2650)
         if (fbeam > 0.0) {
             for (int iq = 0; iq < P.nn; ++iq)

@@ -14,11 +14,11 @@ module sbd_engine_mod
             sbd_fleet_solve_host, sbd_fleet_solve_mix_host
   public :: SBD_OK, SBD_E_RETRY_NSTR, SBD_NFLUX, SBD_ABI_VER, SBD_MIX_MAX_TERMS
   public :: SBD_ST_WARN_SOLVE0, SBD_ST_WARN_UPBEAM, SBD_ST_WARN_UPISOT, SBD_ST_ERR_EIGEN, &
-            SBD_ST_RETRY_NSTR, SBD_ST_ERR_INPUT, SBD_ST_WARN_PLKAVG
+            SBD_ST_RETRY_NSTR, SBD_ST_ERR_INPUT, SBD_ST_WARN_PLKAVG, SBD_ST_WARN_PLKCONV
 
   integer(c_int), parameter :: SBD_ABI_VER = 6, SBD_OK = 0, SBD_E_RETRY_NSTR = -2, SBD_NFLUX = 5
   integer(c_int), parameter :: SBD_ST_WARN_SOLVE0 = 1, SBD_ST_WARN_UPBEAM = 2, SBD_ST_WARN_UPISOT = 4, &
-       SBD_ST_ERR_EIGEN = 8, SBD_ST_RETRY_NSTR = 16, SBD_ST_ERR_INPUT = 32, SBD_ST_WARN_PLKAVG = 64
+       SBD_ST_ERR_EIGEN = 8, SBD_ST_RETRY_NSTR = 16, SBD_ST_ERR_INPUT = 32, SBD_ST_WARN_PLKAVG = 64, SBD_ST_WARN_PLKCONV = 128
 
   type, bind(C) :: sbd_run_cfg
     integer(c_int32_t) :: abi_version, nlyr, nstr, nmom, onlyfl, lamber, usrang, numu, nphi, &

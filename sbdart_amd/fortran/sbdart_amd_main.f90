@@ -540,6 +540,7 @@ subroutine run_once(phase)
   if (iand(stall, SBD_ST_WARN_SOLVE0) /= 0) call warn_file(2, 'SOLVE0--SGBCO says matrix near singular')
   if (iand(stall, SBD_ST_WARN_UPBEAM) /= 0) call warn_file(3, 'UPBEAM--SGECO says matrix near singular')
   if (iand(stall, SBD_ST_WARN_UPISOT) /= 0) call warn_file(4, 'UPISOT--SGECO says matrix near singular')
+  if (iand(stall, SBD_ST_WARN_PLKCONV) /= 0) call warn_file(9, 'PLKAVG--Simpson rule didnt converge')
   if (iand(stall, SBD_ST_WARN_PLKAVG) /= 0) call warn_file(10, 'PLKAVG--returns zero; possible underflow')
   if (any(plank(1:npart) /= 0)) then                ! CHEKIN warning 6 (disort.f:5145-5152)
     do i = 1, nz

@@ -124,6 +124,10 @@ def _edge_records():
     out.append(rec(6, 8, [0.4] * 6, [0.6] * 6, [0.5] * 6, plank=True, fbeam=1.5, wl=(2400.0, 2600.0)))
     out.append(rec(6, 16, [1.5] * 6, [0.95] * 6, [0.85] * 6, plank=True, fbeam=0.0, wl=(100.0, 3000.0)))
     out.append(rec(6, 8, [0.4] * 6, [0.6] * 6, [0.5] * 6, plank=True, fbeam=0.0, wl=(999.0, 1000.0)))
+    # ... and an ultraviolet band a percent wide with the thermal source left on (NOTHRM = 0): Simpson's rule works on values
+    # around e^-250 and does not converge -- errmsg 9, its own status bit since round 5 (end-to-end fuzz, seed 6004: the host
+    # wrote SBDART_WARNING.10 where the reference writes .09)
+    out.append(rec(6, 8, [0.4] * 6, [0.6] * 6, [0.5] * 6, plank=True, fbeam=1.5, wl=(39400.0, 39790.0)))
     # overhead sun (NAZ = 0) and radiance mode with beam + thermal
     out.append(rec(5, 8, [0.3] * 5, [0.8] * 5, [0.6] * 5, umu0=1.0))
     out.append(rec(5, 8, [0.3] * 5, [0.8] * 5, [0.6] * 5, rad=True))
