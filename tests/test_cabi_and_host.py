@@ -147,3 +147,27 @@ def test_flux_albedo_of_the_surface_models_on_the_host():
         assert L.sbd_surface_flux_albedo(ibdrf, bp, bi, 1.5, C.byref(out)) != _lib.OK        # DREF--input argument error(s)
     assert L.sbd_surface_flux_albedo(1, (C.c_double * 8)(*models[0][1]), None, 0.5, C.byref(C.c_double())) != _lib.OK
     print("worst relative difference from the oracle's DREF: %.2e" % worst)
+
+
+def test_status_bits_agree_across_the_header_the_bindings_and_the_oracle():
+    """SBD_ST_* of include/sbdart_amd.h, the Python and Fortran bindings' copies, and the oracle's status bits (the
+    parity tests compare status WORDS between engine and oracle): one table, five places."""
+    import re
+    from conftest import ROOT
+    from sbdart_amd import _lib
+    hdr = dict((m.group(1), int(m.group(2), 16)) for m in
+               re.finditer(r"#define\s+SBD_ST_(\w+)\s+(0x[0-9a-fA-F]+)", open(os.path.join(ROOT, "include", "sbdart_amd.h")).read()))
+    assert hdr == {"WARN_SOLVE0": 1, "WARN_UPBEAM": 2, "WARN_UPISOT": 4, "ERR_EIGEN": 8, "RETRY_NSTR": 16, "ERR_INPUT": 32,
+                   "WARN_PLKAVG": 64, "WARN_PLKCONV": 128}
+    for name, val in hdr.items():
+        assert getattr(_lib, "ST_" + name) == val, name
+    f90 = open(os.path.join(ROOT, "sbdart_amd", "fortran", "sbd_engine_mod.f90")).read()
+    for name, val in hdr.items():
+        assert re.search(r"SBD_ST_%s\s*=\s*%d\b" % (name, val), f90), name
+    ohdr = dict((m.group(1), int(m.group(2), 16)) for m in
+                re.finditer(r"#define\s+SBDO_(\w+)\s+(0x[0-9a-fA-F]+)", open(os.path.join(ROOT, "oracle", "disort_oracle.h")).read()))
+    same = {"WARN_SOLVE0": "WARN_SOLVE0_RCOND", "WARN_UPBEAM": "WARN_UPBEAM_RCOND", "WARN_UPISOT": "WARN_UPISOT_RCOND",
+            "ERR_EIGEN": "ERR_ASYMTX", "RETRY_NSTR": "RETRY_NSTR", "ERR_INPUT": "ERR_INPUT", "WARN_PLKAVG": "WARN_PLKAVG",
+            "WARN_PLKCONV": "WARN_PLKCONV"}
+    for name, oname in same.items():
+        assert ohdr[oname] == hdr[name], name
