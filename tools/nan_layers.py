@@ -1,3 +1,7 @@
+"""GPU box: which LAYER of a work item goes wrong -- the items of one INPUT (Fortran host, SBD_DUMP_OPTICS, the user data
+files of tests/test_band_model.py in the run directory), item ITEM (default 15) through the engine with every level kept:
+per layer the non-finite entries of GC and the smallest |k| against the oracle's.  The item is left in
+gpurun_out/nan_item.sbdrec.   usage: python tools/nan_layers.py "namelist text" [ITEM]"""
 import os, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests"); sys.path.insert(0, ROOT + "/oracle")
@@ -16,7 +20,7 @@ with tempfile.TemporaryDirectory() as d:
     recs = [r for r in read_records(out) if r.ff != 0.0]
 for r in recs:
     if getattr(r, "ibdrf", 0) == 0: r.flags |= 4
-r = recs[15]
+r = recs[int(sys.argv[2]) if len(sys.argv) > 2 else 15]
 os.makedirs(ROOT + "/gpurun_out", exist_ok=True)
 write_records(ROOT + "/gpurun_out/nan_item.sbdrec", [r])
 o = pyoracle.disort(r, debug_mode=0)
