@@ -8,10 +8,11 @@
 
 namespace sbd {
 
-// (NN, G) table of the fast layer kernel: G lanes per layer
+// (NN, G) table of the fast layer kernel: G lanes per layer (a power of two up to NSTR 32: the exchanges ride on the DPP
+// network; 20 for NSTR 34-40, whose groups talk through ds_bpermute anyway -- three layers per wave instead of two)
 #define SBD_L2_CASES(M)                                                                        \
     M(2, 4) M(3, 4) M(4, 4) M(5, 8) M(6, 8) M(7, 8) M(8, 8) M(9, 16) M(10, 16) M(11, 16)   \
-    M(12, 16) M(13, 16) M(14, 16) M(15, 16) M(16, 16) M(17, 32) M(18, 32) M(19, 32) M(20, 32)
+    M(12, 16) M(13, 16) M(14, 16) M(15, 16) M(16, 16) M(17, 20) M(18, 20) M(19, 20) M(20, 20)
 inline int l2_group(int nn)
 {
 #define SBD_L2_G(NNv, Gv) if (nn == NNv) return Gv;

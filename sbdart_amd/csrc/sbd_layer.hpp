@@ -47,9 +47,18 @@ template <int G>
 SBD_DEVICE bool near_singular(double pivot, double thresh)
 {
     double pmin = (pivot >= 0.0) ? pivot : 1.0e300, pmax = (pivot >= 0.0) ? pivot : 0.0;
-    for (int d = G / 2; d >= 1; d >>= 1) {
-        pmin = fmin(pmin, __shfl_xor(pmin, d, G));
-        pmax = fmax(pmax, __shfl_xor(pmax, d, G));
+    if constexpr ((G & (G - 1)) == 0) {
+        for (int d = G / 2; d >= 1; d >>= 1) {
+            pmin = fmin(pmin, __shfl_xor(pmin, d, G));
+            pmax = fmax(pmax, __shfl_xor(pmax, d, G));
+        }
+    } else {                                     // (groups of 20 lanes, NSTR 34-40: every lane visits the group's lanes)
+        const int base = ((int)threadIdx.x / G) * G;
+        const double own_min = pmin, own_max = pmax;
+        for (int t = 0; t < G; ++t) {
+            pmin = fmin(pmin, __shfl(own_min, base + t));
+            pmax = fmax(pmax, __shfl(own_max, base + t));
+        }
     }
     return !(pmin > thresh * pmax);
 }

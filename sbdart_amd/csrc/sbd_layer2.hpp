@@ -148,6 +148,15 @@ SBD_DEVICE double group_bcast(double x)
     return __hiloint2double(hi, lo);
 }
 
+// x of lane `src` of this lane's group: a sub-wave shuffle for the power-of-two groups, an absolute lane for the groups
+// of 20 (NSTR 34-40) -- the same ds_bpermute_b32 either way
+template <int G>
+SBD_DEVICE double group_shfl(double x, int src)
+{
+    if constexpr ((G & (G - 1)) == 0) return __shfl(x, src, G);
+    else return __shfl(x, ((int)threadIdx.x / G) * G + src);
+}
+
 template <int NN, int G, bool RAD>
 #ifndef SBD_RAD_WAVES
 #define SBD_RAD_WAVES 2      // waves per SIMD of the intensity variant at NN > 12: a 256-register cap, ~170 spills -- and the NSTR 32
@@ -169,7 +178,7 @@ __global__ void __launch_bounds__(64, (NN > 16 && !RAD) ? SBD_BIG_WAVES : (NN > 
     const unsigned bpmode = (unsigned)((per_mode + GPB - 1) / GPB);
     const int mazim = (int)(blockIdx.x / bpmode);
     const long long fid = (long long)(blockIdx.x % bpmode) * GPB + gi;
-    const bool live = fid < per_mode;                       // (the mode's last block may be partial)
+    const bool live = gi < GPB && fid < per_mode;            // (the mode's last block may be partial; groups of 20 lanes leave four)
     const int slot = live ? (int)(fid / L) : 0;
     const int lc = live ? (int)(fid % L) + 1 : L + 1;
     const long long ms = (long long)slot * nmode + mazim;
@@ -397,7 +406,7 @@ __global__ void __launch_bounds__(64, (NN > 16 && !RAD) ? SBD_BIG_WAVES : (NN > 
         wave_lds_sync();
 #pragma unroll
         for (int k = 1; k <= nn; ++k) {
-            const double dp = __shfl(rp[k - 1], k - 1, G), dm = __shfl(rm[k - 1], k - 1, G);
+            const double dp = group_shfl<G>(rp[k - 1], k - 1), dm = group_shfl<G>(rm[k - 1], k - 1);
             if (!(dp > 0.0) || !(dm > 0.0)) spd = false;
             const double rdp = rsqrt_nr(dp), rdm = rsqrt_nr(dm);
             if (me == k) { rp[k - 1] = dp * rdp; rm[k - 1] = dm * rdm; }
@@ -552,8 +561,8 @@ __global__ void __launch_bounds__(64, (NN > 16 && !RAD) ? SBD_BIG_WAVES : (NN > 
                     const int src = (j < NP) ? partner : j;
                     double ob[nn];
 #pragma unroll
-                    for (int i = 0; i < nn; ++i) ob[i] = __shfl(bcol[i], src, G);
-                    meet(partner, (j < nn) && (partner < nn) && (j < NP), ob, __shfl(nrm, src, G), __shfl(wsc, src, G));
+                    for (int i = 0; i < nn; ++i) ob[i] = group_shfl<G>(bcol[i], src);
+                    meet(partner, (j < nn) && (partner < nn) && (j < NP), ob, group_shfl<G>(nrm, src), group_shfl<G>(wsc, src));
                 }
             }
             // quadratic convergence: a sweep that started below 3e-7 ends below 1e-13 (eigenvalues to
