@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SBD_ABI_VERSION 6
+#define SBD_ABI_VERSION 7
 
 /* limits of the reference (params.f:9-15) */
 #define SBD_MAX_NLYR 65   /* mxly   */
@@ -62,13 +62,20 @@ extern "C" {
 #define SBD_E_NOMEM         -6
 
 /* ---- per-work-item status bits ---- */
-/* warnings 2/3/4: the reference raises them from LINPACK's RCOND estimate (1 + RCOND == 1), which needs the L
- * factor this engine never stores.  The band system (warning 2) is tested the same way with the pivot ratio in RCOND's
- * place -- 1 + min|pivot| / max|pivot| == 1, a zero pivot included, and like the reference's test silent when the
- * system is full of NaN; the two dense systems (warnings 3, 4) with min|pivot| <= 16 eps max|pivot|.  The same regimes,
- * not the same ulp: on 800 random INPUTs the host writes the reference's set of warning files in 799
- * (profiles/r04_warning_files_fuzz.json;
- * tests/test_gpu_parity.py::test_near_singular_systems_raise_the_reference_warnings). */
+/* warnings 2/3/4: the reference raises them from LINPACK's condition estimate, 1 + RCOND == 1 (SGBCO for the band system,
+ * disort.f:3607-3610; SGECO for the two dense systems, disort.f:4225-4228, 4331-4334).
+ *   3, 4 (dense): LINPACK's OWN estimate.  The fast layer kernel's pivot ratio is only a filter (min/max <= 1e-10, or an
+ *      eigenvalue within 1e-10 of 1/umu0, or SSALB within 1 024 ulps of 1 with a thermal source); a layer it flags goes to
+ *      the reference-algorithm layer kernel, which forms the reference's matrices with one rounding per operation, factors
+ *      them by SGEFA's rule and runs SGECO's estimate statement for statement (rcond_group, csrc/sbd_layer.hpp): equal status
+ *      words for every ulp offset (tests/test_gpu_parity.py::test_near_singular_systems_raise_the_reference_warnings,
+ *      ::test_eigenvalue_next_to_the_beam -- the latter on records for which the REFERENCE wrote SBDART_WARNING.03,
+ *      tests/golden/illcond/beam_at_eigenvalue.*).
+ *   2 (band): the band kernels' pivot ratio is a filter as well (1 + min|pivot|/max|pivot| == 1 or <= SBD_RCOND_FILTER); a
+ *      system it flags is re-run in the reference's own formulation -- ASYMTX's eigenvectors in ASYMTX's column order
+ *      (reference-algorithm layer kernel), SETMTX's matrix in LINPACK band storage, SGBFA by ISAMAX's rule and SGBCO's
+ *      estimate statement for statement (band_rcond_kernel, csrc/sbd_bandco.hpp) -- and the bit is set iff 1 + RCOND == 1,
+ *      a system full of NaN raising nothing, like the reference's test. */
 #define SBD_ST_WARN_SOLVE0   0x01  /* band matrix singular pivot        (errmsg 2, disort.f:3609) */
 #define SBD_ST_WARN_UPBEAM   0x02  /* beam-source system singular pivot (errmsg 3, disort.f:4227) */
 #define SBD_ST_WARN_UPISOT   0x04  /* thermal-source system singular    (errmsg 4, disort.f:4333) */
@@ -161,7 +168,7 @@ typedef struct {
                           (usrang) or nstr/2 output cosines; flux comes back zero like DISORT's (ZEROAL) */
 } sbd_batch_out;
 
-/* The same batch in COMPACT form (ABI v6): per SPECTRAL POINT what scatters there, per WORK ITEM only the gas of its
+/* The same batch in COMPACT form (ABI v6; lay_token ABI v7): per SPECTRAL POINT what scatters there, per WORK ITEM only the gas of its
  * k-term -- the operands of the statements with which the reference turns its band model's output into DISORT's
  * arguments, which the engine then executes on the device (assemble_kernel) instead of receiving their results over
  * PCIe.  The statements, in the reference's own association (one rounding per operation, no contraction):
@@ -199,6 +206,11 @@ typedef struct {
                                  the one sbd_fleet_gas_terms left ON THE DEVICE for (point_of, kterm): the gas never
                                  crosses PCIe.  point_of then counts the points of that gas call, and a fleet of several
                                  devices hands every item to the device that holds its point */
+    int64_t lay_token;        /* (ABI v7) 0: the layer blocks are staged from `lay`.  Non-zero: the generation number
+                                 sbd_fleet_gas_terms returned for the blocks it left ON THE DEVICES (with dtaug == NULL
+                                 only): the solve reads those, `lay` is not touched; a number that is not the fleet's
+                                 current one is SBD_E_INVALID.  Residency is the caller's explicit statement, never
+                                 inferred from pointer values */
 } sbd_mix_in;
 
 /* The gas part of the band model for a run (ABI v6): LOWTRAN7's band model and continua along a vertical and a slant
@@ -277,14 +289,18 @@ int      sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_
                                   const double *weight, double *acc_flux, double *acc_uu);
 /* The gas terms of npoint wavelengths on the fleet's devices (points sharded by sbd_shard_range, every device keeps its
  * points' results): wl [npoint] micrometres (wl[0] is the run's first wavelength), lay [npoint][nch][nlyr] the points'
- XX  Returns
- * per point nk (1 or 3 k-terms), wt [npoint][3] the terms' weights (depthscl's wt: 1 when nk = 1), and taucor's
- * failures as SBD_ST_ERR_INPUT-free status: fail [npoint] 1 where the reference would stop ("TAUCOR: iteration did
- * not converge"), may be NULL.  The depths stay on the devices for sbd_fleet_solve_mix_host with dtaug == NULL -- and so do
- * the layer blocks: a solve that passes the SAME lay array (unchanged in between) does not send them over PCIe again.
+ * layer blocks in sbd_mix_in's layout -- the gas model reads channels 0..2 only (dtauc, dtaua, dtaur: depthscl's
+ * roll-off of the k-terms looks at the scatterers' depth above a level, taugas.f:7550-7590), so nch >= 3; a caller that
+ * will solve from the same blocks passes nch = 4 + 3 nterm.  Returns per point nk (1 or 3 k-terms), wt [npoint][3] the
+ * terms' weights (depthscl's wt: 1 when nk = 1), and taucor's failures: fail [npoint] 1 where the reference would stop
+ * ("TAUCOR: iteration did not converge"), may be NULL.  The depths stay on the devices for sbd_fleet_solve_mix_host with
+ * dtaug == NULL.  So do the layer blocks, and the call says so explicitly: *lay_token (may be NULL) receives a non-zero
+ * generation number naming the device copy of `lay`; a later sbd_mix_in with lay_token set to that number solves from the
+ * resident blocks (its `lay` pointer is not read), with lay_token = 0 the blocks are staged from `lay` again.  A token is
+ * valid until the next sbd_fleet_gas_terms call on the fleet; a stale one is SBD_E_INVALID, never silently stale data.
  * dtaug_out, if not NULL: [npoint][3][nlyr] the terms' gas depths copied back (tests, IOUT-independent inspection). */
 int      sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, const double *wl, const double *lay,
-                             int32_t nch, int32_t *nk, double *wt, int32_t *fail, double *dtaug_out);
+                             int32_t nch, int32_t *nk, double *wt, int32_t *fail, double *dtaug_out, int64_t *lay_token);
 /* The same arithmetic on the HOST (no GPU involved; the same source, sbd_gas.hpp): with the host's libm the results
  * are bit-equal to the Fortran host's band model, hence to the reference's -- the pin of the device kernel's source. */
 int      sbd_gas_terms_host(const sbd_gas_model *g, int32_t nlyr, int32_t npoint, const double *wl, const double *lay, int32_t nch,

@@ -1122,6 +1122,12 @@ static int soleig(work_t *w, int lc, int mazim, double *amb, double *apb, double
 }
 
 /* UPBEAM (disort.f:4130-4245): zj returned in CMU order, ZZ(.,lc) reordered */
+/* search aid for the ill-conditioned fixtures (tests/golden/illcond): the smallest condition estimates of the most
+   recent sbdo_disort call on this thread -- 0 band system (SOLVE0), 1 UPBEAM, 2 UPISOT; +inf when never formed */
+static __thread double g_rcond_min[3];
+double sbdo_last_rcond(int which) { return (which >= 0 && which < 3) ? g_rcond_min[which] : -1.0; }
+static inline void note_rcond(int which, double r) { if (r < g_rcond_min[which]) g_rcond_min[which] = r; }
+
 static int upbeam(work_t *w, int lc, int mazim, double delm0, double fbeam, double pi,
                   double umu0, const double *cc, double *array, int *ipvt, double *wk, double *zj)
 {
@@ -1135,6 +1141,7 @@ static int upbeam(work_t *w, int lc, int mazim, double delm0, double fbeam, doub
         zj[iq - 1] = (2.0 - delm0) * fbeam * sum / (4.0 * pi);
     }
     double rcond = sbdo_sgeco(array, n, n, ipvt, wk);
+    note_rcond(1, rcond);
     int warn = (1.0 + rcond == 1.0);
     sbdo_sgesl(array, n, n, ipvt, zj);
     for (int iq = 1; iq <= nn; ++iq) {
@@ -1156,6 +1163,7 @@ static int upisot(work_t *w, int lc, const double *cc, double *array, int *ipvt,
         z1[iq - 1] = (1.0 - oprim) * xr1;
     }
     double rcond = sbdo_sgeco(array, n, n, ipvt, wk);
+    note_rcond(2, rcond);
     int warn = (1.0 + rcond == 1.0);
     sbdo_sgesl(array, n, n, ipvt, z1);
     for (int iq = 1; iq <= n; ++iq) z0[iq - 1] = (1.0 - oprim) * xr0 + CMU(iq) * z1[iq - 1];
@@ -1402,6 +1410,7 @@ static int solve0(work_t *w, double *b, double *cband, int lda, int ncol, int ma
     }
     int ncd = 3 * nn - 1;
     double rcond = sbdo_sgbco(cband, lda, ncol, ncd, ncd, ipvt, z);
+    note_rcond(0, rcond);
     int warn = (1.0 + rcond == 1.0);
     sbdo_sgbsl(cband, lda, ncol, ncd, ncd, ipvt, b);
     for (int lc = 1; lc <= ncut; ++lc) {
@@ -1707,6 +1716,7 @@ int sbdo_disort(const sbdo_in *in, sbdo_out *out)
     const double rpd = pi / 180.0;
     int status = 0;
 
+    g_rcond_min[0] = g_rcond_min[1] = g_rcond_min[2] = HUGE_VAL;
     out->status = 0;
     out->nstr_out = n0;
     /* ---- CHEKIN subset (disort.f:4864-5176): fatal input errors ---- */

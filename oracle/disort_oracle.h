@@ -71,6 +71,10 @@ typedef struct {
 } sbdo_out;
 
 int  sbdo_disort(const sbdo_in *in, sbdo_out *out);
+/* smallest LINPACK condition estimate of the most recent sbdo_disort call on this thread: which = 0 band system
+   (SGBCO, disort.f:3607), 1 UPBEAM's, 2 UPISOT's (SGECO, disort.f:4225, 4331); +inf when none was formed.
+   A search aid for fixtures in which the reference's 1 + RCOND == 1 fires. */
+double sbdo_last_rcond(int which);
 
 /* building blocks, exported for unit tests */
 void   sbdo_qgausn(int m, double *gmu, double *gwt);                 /* disort.f:5984 */

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SBDART_AMD_LIB points at another build of the same library (kernel experiments)
 LIB_PATH = os.environ.get("SBDART_AMD_LIB") or os.path.join(_HERE, "lib", "libsbdart_amd.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 NFLUX = 5
 RFLDIR, RFLDN, FLUP, DFDT, UAVG = range(5)
 
@@ -46,12 +46,12 @@ MIX_MAX_TERMS = 6
 
 
 class MixIn(C.Structure):
-    """sbd_mix_in (ABI v6): a batch in compact form -- per spectral point a block [4 + 3 nterm][nlyr] (dtauc, dtaua, dtaur,
+    """sbd_mix_in (ABI v6; lay_token v7): a batch in compact form -- per spectral point a block [4 + 3 nterm][nlyr] (dtauc, dtaua, dtaur,
     tsc, then g, m1, m2 of every scattering term), per work item the gas of its k-term."""
     _fields_ = [("nwork", C.c_int32), ("npoint", C.c_int32), ("point_of", C.c_void_p), ("dtaug", C.c_void_p),
                 ("nterm", C.c_int32), ("family", C.c_int32 * MIX_MAX_TERMS), ("lay", C.c_void_p),
                 ("wvnmlo", C.c_void_p), ("wvnmhi", C.c_void_p), ("fbeam", C.c_void_p), ("albedo", C.c_void_p),
-                ("plank", C.c_void_p), ("kterm", C.c_void_p)]
+                ("plank", C.c_void_p), ("kterm", C.c_void_p), ("lay_token", C.c_int64)]
 
 
 class GasModel(C.Structure):
@@ -146,7 +146,7 @@ def load() -> C.CDLL:
     L.sbd_fleet_solve_mix_host.restype = C.c_int
     L.sbd_shard_range_points.argtypes = [C.c_int32, vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.sbd_shard_range_points.restype = None
-    L.sbd_fleet_gas_terms.argtypes = [vp, C.POINTER(GasModel), C.c_int32, vp, vp, C.c_int32, vp, vp, vp, vp]
+    L.sbd_fleet_gas_terms.argtypes = [vp, C.POINTER(GasModel), C.c_int32, vp, vp, C.c_int32, vp, vp, vp, vp, C.POINTER(C.c_int64)]
     L.sbd_fleet_gas_terms.restype = C.c_int
     L.sbd_gas_terms_host.argtypes = [C.POINTER(GasModel), C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, vp, vp, vp]
     L.sbd_gas_terms_host.restype = C.c_int

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -362,7 +363,9 @@ struct sbd_engine {
     int32_t gas_p0 = 0, gas_np = 0;
     double *d_gas_lay = nullptr;    // ... and those points' layer blocks [gas_np][gas_nch][L], kept for the solves that follow
     int32_t gas_nch = 0;
-    const double *gas_lay_host = nullptr;   // (the caller's array they were copied from: a solve that passes the same one need not copy again)
+    int64_t gas_token = 0;          // generation number of d_gas_lay (sbd_fleet_gas_terms hands it to the caller; a solve names it
+                                    // in sbd_mix_in::lay_token to read the resident blocks -- never inferred from pointers)
+    std::vector<int32_t> gas_nk;    // [gas_np] number of k-terms of those points (a solve's kterm is checked against it)
     int64_t fallback_layers = 0;    // timing mode: (item, mode, layer) problems of the last solve left to the QR kernel
 };
 
@@ -1459,7 +1462,7 @@ static int solve_mix_host_enqueue(sbd_engine *e, const sbd_mix_in *m, const sbd_
 {
     if (e->ibcnd) return fail(SBD_E_UNSUPPORTED, "compact batches: not with IBCND = 1");
     if (e->P.ibdrf == 1) return fail(SBD_E_UNSUPPORTED, "compact batches: not with the ocean surface (per-item constants)");
-    if (!m->point_of || !m->lay || !m->wvnmlo || !m->wvnmhi
+    if (!m->point_of || (!m->lay && m->lay_token == 0) || !m->wvnmlo || !m->wvnmhi
         || !m->fbeam || !m->albedo || !m->plank) return fail(SBD_E_INVALID, "compact batch: null input array");
     if (!m->dtaug && !m->kterm) return fail(SBD_E_INVALID, "compact batch: neither dtaug nor kterm");
     if (!m->dtaug && !e->d_gas_slots) return fail(SBD_E_INVALID, "compact batch: dtaug is NULL and no sbd_fleet_gas_terms call left gas depths on this device");
@@ -1480,7 +1483,8 @@ static int solve_mix_host_enqueue(sbd_engine *e, const sbd_mix_in *m, const sbd_
         if (pbase < e->gas_p0 || m->point_of[W - 1] >= e->gas_p0 + e->gas_np)
             return fail(SBD_E_INVALID, "compact batch: an item's point is not among the points whose gas depths this device holds");
         for (size_t i = 0; i < W; ++i)
-            if (m->kterm[i] < 0 || m->kterm[i] > 2) return fail(SBD_E_INVALID, "compact batch: kterm outside 0..2");
+            if (m->kterm[i] < 0 || m->kterm[i] >= e->gas_nk[(size_t)(m->point_of[i] - e->gas_p0)])
+                return fail(SBD_E_INVALID, "compact batch: kterm outside 0..nk-1 of its point (nk as sbd_fleet_gas_terms returned it)");
     }
     const int L = e->L, nlev = e->nlev;
     const bool rad = !e->cfg.onlyfl;
@@ -1512,10 +1516,18 @@ static int solve_mix_host_enqueue(sbd_engine *e, const sbd_mix_in *m, const sbd_
     hs.ms.lay = (double *)take(b_blk);
     hs.ms.lay_base = pbase;
     hs.ms.lay_resident = false;
-    if (!m->dtaug && e->d_gas_lay && e->gas_lay_host == m->lay + (size_t)e->gas_p0 * (4 + 3 * m->nterm) * L && e->gas_nch == 4 + 3 * m->nterm) {
+    if (m->lay_token != 0) {
+        // the caller names the device copy sbd_fleet_gas_terms left (explicit residency, ABI v7)
+        if (m->dtaug) return fail(SBD_E_INVALID, "compact batch: lay_token goes with dtaug == NULL (the gas call's points)");
+        if (!e->d_gas_lay || m->lay_token != e->gas_token)
+            return fail(SBD_E_INVALID, "compact batch: lay_token is not the one the last sbd_fleet_gas_terms call returned");
+        if (e->gas_nch != 4 + 3 * m->nterm)
+            return fail(SBD_E_INVALID, "compact batch: the resident layer blocks have another channel count than 4 + 3 nterm");
         hs.ms.lay = e->d_gas_lay;                   // the very blocks the gas call copied: no second trip over PCIe
         hs.ms.lay_base = e->gas_p0;
         hs.ms.lay_resident = true;
+    } else if (!m->lay) {
+        return fail(SBD_E_INVALID, "compact batch: lay is NULL and lay_token is 0");
     }
     hs.ms.lo = (double *)take(b_p); hs.ms.hi = (double *)take(b_p); hs.ms.fb = (double *)take(b_p); hs.ms.al = (double *)take(b_p);
     hs.ms.pl = (uint8_t *)take(NP);
@@ -1996,8 +2008,10 @@ int sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_batch
 // The gas part of the band model for the points of a run, on the fleet's devices (sbd_gas.hpp through sbd_k_gas.hip):
 // points sharded by sbd_shard_range, every device keeps its points' gas depths for the compact-form solves that follow.
 int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, const double *wl, const double *lay,
-                        int32_t nch, int32_t *nk, double *wt, int32_t *failed, double *dtaug_out)
+                        int32_t nch, int32_t *nk, double *wt, int32_t *failed, double *dtaug_out, int64_t *lay_token)
 {
+    static std::atomic<int64_t> generation{0};
+    if (lay_token) *lay_token = 0;
     if (!f || f->eng.empty() || !g || !wl || !lay || !nk || !wt) return fail(SBD_E_INVALID, "null argument");
     if (!g->uu || !g->z || !g->tables) return fail(SBD_E_INVALID, "gas model: null array");
     if (npoint <= 0) return npoint == 0 ? SBD_OK : fail(SBD_E_INVALID, "npoint < 0");
@@ -2027,7 +2041,7 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
         if (bad(hipSetDevice(e->cfg.device), "hipSetDevice")) return;
         if (e->d_gas_slots) { (void)hipFree(e->d_gas_slots); e->d_gas_slots = nullptr; }
         if (e->d_gas_lay) { (void)hipFree(e->d_gas_lay); e->d_gas_lay = nullptr; }
-        e->gas_p0 = lo; e->gas_np = 0; e->gas_nch = 0; e->gas_lay_host = nullptr;
+        e->gas_p0 = lo; e->gas_np = 0; e->gas_nch = 0; e->gas_token = 0; e->gas_nk.clear();
         if (np <= 0) return;
         const size_t npad = ((size_t)np + 63) & ~(size_t)63;
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -2063,7 +2077,7 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
         if (!err) {
             sbd::GasRun R;
             std::string verr;
-            pk.view(d_td, d_ti, R.T, verr);
+            if (!pk.view(d_td, d_ti, R.T, verr)) { rcs[r] = SBD_E_INVALID; errs[r] = "gas tables: " + verr; err = true; }
             R.uu = d_uu; R.z = d_z; R.nz = L; R.kdist = g->kdist;
             R.amu0_first = g->amu0_first; R.amu0_rest = g->amu0_rest; R.xo4 = g->xo4; R.re_earth = sbd::kReEarth;
             if (timing) { (void)hipStreamSynchronize(st); t_h2d = since(); }
@@ -2080,7 +2094,7 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
         (void)hipFree(tmp);
         if (timing) fprintf(stderr, "sbdart_amd: gas terms on device %d: %d points; alloc %.2f ms, H2D %.2f ms, gas_kernel %.2f ms, D2H %.2f ms, free %.2f ms\n",
                             e->cfg.device, np, t_alloc, t_h2d - t_alloc, t_kernel - t_h2d, t_d2h - t_kernel, since() - t_d2h);
-        if (rcs[r] == SBD_OK) { e->gas_np = np; e->gas_nch = nch; e->gas_lay_host = lay + (size_t)lo * nch * L; }
+        if (rcs[r] == SBD_OK) { e->gas_np = np; e->gas_nch = nch; e->gas_nk.assign(nk + lo, nk + lo + np); }
         else {
             if (e->d_gas_slots) { (void)hipFree(e->d_gas_slots); e->d_gas_slots = nullptr; }
             if (e->d_gas_lay) { (void)hipFree(e->d_gas_lay); e->d_gas_lay = nullptr; }
@@ -2095,6 +2109,9 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
     }
     for (int r = 0; r < nd; ++r)
         if (rcs[r] != SBD_OK) return fail(rcs[r], errs[r]);
+    const int64_t token = ++generation;               // (never 0; unique in the process: a token of another fleet cannot match)
+    for (int r = 0; r < nd; ++r) f->eng[r]->gas_token = token;
+    if (lay_token) *lay_token = token;
     return SBD_OK;
 }
 

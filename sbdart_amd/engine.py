@@ -346,7 +346,11 @@ class DisortFleet(DisortEngine):
     def gas_terms(self, gas_model, wl, lay, want_depths=False):
         """The gas part of the band model on the fleet's devices (sbd_fleet_gas_terms): gas_model a _lib.GasModel, wl
         [npoint], lay [npoint][channels][nlyr] the points' layer blocks.  Returns (nk [npoint], wt [npoint][3], fail
-        [npoint], depths [npoint][3][nlyr] or None); the depths stay on the devices for solve_mix(dtaug=None, kterm=...)."""
+        [npoint], depths [npoint][3][nlyr] or None); the depths stay on the devices for solve_mix(dtaug=None, kterm=...).
+        The layer blocks stay there too: `self.lay_token` is the generation number the library returned for them, and
+        solve_mix(..., lay_token=self.lay_token) reads the device copy instead of sending `lay` again.  Residency is that
+        explicit statement only -- a solve_mix without the token always stages the `lay` it is given (the
+        library used to recognise the caller's array by its address, which a temporary array can share with a freed one)."""
         wl, lay = _f64(wl), _f64(lay)
         npt = wl.shape[0]
         assert lay.shape[0] == npt and lay.shape[2] == self.nlyr
@@ -355,13 +359,17 @@ class DisortFleet(DisortEngine):
         fail = np.zeros(npt, dtype=np.int32)
         depths = np.zeros((npt, 3, self.nlyr)) if want_depths else None
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        token = C.c_int64(0)
+        self.lay_token = 0
         rc = self._L.sbd_fleet_gas_terms(self._h, C.byref(gas_model), npt, vp(wl), vp(lay), lay.shape[1], vp(nk), vp(wt),
-                                         vp(fail), vp(depths))
+                                         vp(fail), vp(depths), C.byref(token))
         if rc != _lib.OK:
             raise SbdError(rc, "sbd_fleet_gas_terms")
+        self.lay_token = int(token.value)
         return nk, wt, fail, depths
 
-    def solve_mix(self, point_of, dtaug, lay, family, wvnmlo, wvnmhi, fbeam, albedo, plank, weight=None, items=True, kterm=None):
+    def solve_mix(self, point_of, dtaug, lay, family, wvnmlo, wvnmhi, fbeam, albedo, plank, weight=None, items=True, kterm=None,
+                  lay_token=0):
         """A batch in COMPACT form (sbd_mix_in, include/sbdart_amd.h): per spectral point a block lay[point] of
         [4 + 3 nterm][nlyr] doubles (dtauc, dtaua, dtaur, tsc, then g, m1, m2 of every scattering term; `family` =
         GETMOM's iphas per term), per work item the gas of its k-term; DTAUC / SSALB / PMOM are formed on the device
@@ -384,7 +392,7 @@ class DisortFleet(DisortEngine):
         status = np.zeros(W, dtype=np.int32)
         vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
         fam = (C.c_int32 * MIX_MAX_TERMS)(*(family + [0] * (MIX_MAX_TERMS - nterm)))
-        mi = MixIn(W, NP, vp(rows), vp(dtaug), nterm, fam, vp(lay), vp(lo), vp(hi), vp(fb), vp(al), vp(pl), vp(kt))
+        mi = MixIn(W, NP, vp(rows), vp(dtaug), nterm, fam, vp(lay), vp(lo), vp(hi), vp(fb), vp(al), vp(pl), vp(kt), int(lay_token))
         bo = BatchOut(vp(flux), vp(uu), vp(status))
         acc_f = acc_u = None
         if weight is not None:

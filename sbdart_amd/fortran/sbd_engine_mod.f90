@@ -16,7 +16,7 @@ module sbd_engine_mod
   public :: SBD_ST_WARN_SOLVE0, SBD_ST_WARN_UPBEAM, SBD_ST_WARN_UPISOT, SBD_ST_ERR_EIGEN, &
             SBD_ST_RETRY_NSTR, SBD_ST_ERR_INPUT, SBD_ST_WARN_PLKAVG, SBD_ST_WARN_PLKCONV
 
-  integer(c_int), parameter :: SBD_ABI_VER = 6, SBD_OK = 0, SBD_E_RETRY_NSTR = -2, SBD_NFLUX = 5
+  integer(c_int), parameter :: SBD_ABI_VER = 7, SBD_OK = 0, SBD_E_RETRY_NSTR = -2, SBD_NFLUX = 5
   integer(c_int), parameter :: SBD_ST_WARN_SOLVE0 = 1, SBD_ST_WARN_UPBEAM = 2, SBD_ST_WARN_UPISOT = 4, &
        SBD_ST_ERR_EIGEN = 8, SBD_ST_RETRY_NSTR = 16, SBD_ST_ERR_INPUT = 32, SBD_ST_WARN_PLKAVG = 64, SBD_ST_WARN_PLKCONV = 128
 
@@ -54,6 +54,8 @@ module sbd_engine_mod
     type(c_ptr) :: lay, wvnmlo, wvnmhi, fbeam, albedo, plank
     type(c_ptr) :: kterm = c_null_ptr    ! with dtaug = c_null_ptr: the items' k-terms (0-based); their gas depths are
                                          ! the ones sbd_fleet_gas_terms left on the devices
+    integer(c_int64_t) :: lay_token = 0  ! (ABI v7) the number sbd_fleet_gas_terms returned for the layer blocks it left
+                                         ! on the devices: the solve reads those; 0 = stage them from `lay`
   end type
 
   ! the gas part of the band model for a run (include/sbdart_amd.h): evaluated by the engine for all wavelengths at once
@@ -141,10 +143,11 @@ module sbd_engine_mod
       type(sbd_batch_out), intent(in) :: bout
       integer(c_int) :: rc
     end function
-    function sbd_fleet_gas_terms(fleet, gas, npoint, wl, lay, nch, nk, wt, failed, dtaug_out) &
+    function sbd_fleet_gas_terms(fleet, gas, npoint, wl, lay, nch, nk, wt, failed, dtaug_out, lay_token) &
          bind(C, name='sbd_fleet_gas_terms') result(rc)
       import
       type(c_ptr), value :: fleet, wl, lay, nk, wt, failed, dtaug_out
+      integer(c_int64_t), intent(out) :: lay_token
       type(sbd_gas_model), intent(in) :: gas
       integer(c_int32_t), value :: npoint, nch
       integer(c_int) :: rc

@@ -119,6 +119,7 @@ subroutine run_once(phase)
   integer(c_int32_t), allocatable, target :: gas_nk(:), gas_fail(:), kterm(:)
   real(kr), allocatable, target :: gas_wt(:, :), gas_depths(:, :, :)
   type(c_ptr) :: gas_fleet
+  integer(c_int64_t) :: gas_lay_token = 0               ! names the layer blocks sbd_fleet_gas_terms left on gas_fleet's devices
   integer(kind=8) :: tick_g0, tick_g1
   real(kind=8) :: t_gas
   integer(c_int) :: rc_gas
@@ -1048,7 +1049,7 @@ contains
       dptr = c_loc(gas_depths)
     end if
     rcg = sbd_fleet_gas_terms(fl, gm, int(np, c_int32_t), c_loc(mix%wl), c_loc(mix%lay), int(size(mix%lay, 2), c_int32_t), &
-                              c_loc(gas_nk), c_loc(gas_wt), c_loc(gas_fail), dptr)
+                              c_loc(gas_nk), c_loc(gas_wt), c_loc(gas_fail), dptr, gas_lay_token)
     if (rcg /= SBD_OK) call quit('sbd_fleet_gas_terms: '//sbd_strerror_f(rcg)//' '//sbd_last_error_f())
   end subroutine
 
@@ -1106,6 +1107,7 @@ contains
           gas_fleet = fleet
         end if
         mxin%dtaug = c_null_ptr; mxin%kterm = c_loc(kterm(p0))
+        mxin%lay_token = gas_lay_token                   ! the layer blocks that call left on the devices (mix%lay unchanged since)
       else
         mxin%dtaug = c_loc(dtauc(1, p0)); mxin%kterm = c_null_ptr
       end if

@@ -150,6 +150,34 @@ def test_solve_with_the_gas_depths_left_on_the_devices(tmp_path):
             w = wt[po, kt]
             a = fl.solve_mix(po, None, d["lay"], d["family"], lo, hi, 1.0, 0.2, 0, weight=w, kterm=kt)
             b = fl.solve_mix(po, depths[po, kt], d["lay"], d["family"], lo, hi, 1.0, 0.2, 0, weight=w)
+            # ABI v7: residency of the layer blocks is the caller's explicit statement (the token), never inferred
+            token = fl.lay_token
+            assert token != 0
+            c = fl.solve_mix(po, None, d["lay"], d["family"], lo, hi, 1.0, 0.2, 0, weight=w, kterm=kt, lay_token=token)
+            assert np.array_equal(a[0], c[0]) and np.array_equal(a[2], c[2])
+            # the hazard ADVICE r05 names: the caller edits `lay` in place between the gas call and a solve.  Without a
+            # token the edited blocks are staged (results change); with the token the device copy answers (unchanged).
+            lay2 = d["lay"].copy()
+            lay2[:, 2, :] *= 3.0                                   # three times the Rayleigh depth
+            lay2[:, 3, :] = lay2[:, 0, :] * 0 + d["lay"][:, 3, :] + 2.0 * d["lay"][:, 2, :]
+            e_ = fl.solve_mix(po, None, lay2, d["family"], lo, hi, 1.0, 0.2, 0, weight=w, kterm=kt)
+            assert not np.array_equal(a[0], e_[0])
+            f_ = fl.solve_mix(po, None, lay2, d["family"], lo, hi, 1.0, 0.2, 0, weight=w, kterm=kt, lay_token=token)
+            assert np.array_equal(a[0], f_[0])
+            from sbdart_amd.engine import SbdError
+            with pytest.raises(SbdError):                         # a token that is not the fleet's current one
+                fl.solve_mix(po, None, d["lay"], d["family"], lo, hi, 1.0, 0.2, 0, weight=w, kterm=kt, lay_token=token + 12345)
+            with pytest.raises(SbdError):                         # a token beside explicit gas depths
+                fl.solve_mix(po, depths[po, kt], d["lay"], d["family"], lo, hi, 1.0, 0.2, 0, weight=w, lay_token=token)
+            if (nk == 1).any():                                    # a k-term the point does not have
+                bad = kt.copy()
+                bad[np.flatnonzero(nk[po] == 1)[0]] = 1
+                with pytest.raises(SbdError):
+                    fl.solve_mix(po, None, d["lay"], d["family"], lo, hi, 1.0, 0.2, 0, weight=w, kterm=bad)
+            fl.gas_terms(g, d["wl"], d["lay"])                     # a new gas call: the old token is stale
+            assert fl.lay_token not in (0, token)
+            with pytest.raises(SbdError):
+                fl.solve_mix(po, None, d["lay"], d["family"], lo, hi, 1.0, 0.2, 0, weight=w, kterm=kt, lay_token=token)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and (a[2] == 0).all()
         assert np.allclose(a[3], b[3], rtol=1e-13, atol=0)
         assert np.isfinite(a[0]).all() and np.abs(a[0]).max() > 0
