@@ -143,7 +143,7 @@ VALU_SLOT_NS_MEASURED = 2.05   # one wave64 issue slot (4 cycles) as the chip su
                                # (tools/microbench/valu_rates.hip, profiles/r05_valu_rates.txt)
 
 
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 
 def load_profile(kind, nstr, nlyr, shape=""):
@@ -181,7 +181,35 @@ def valu_issue(W, step_s, nstr, nlyr, shape=""):
             "per_kernel": {k: v["valu_wave_insts_per_solve"] for k, v in vp["kernels"].items()}}
 
 
-def shape_roofline(names, phase_ms, nlaunch, pass_size, W, nstr, nlyr, nlev, shape="", extra_out_bytes=0):
+def rocprof_kernel_name(phase, nstr, fused, rad=False):
+    """The name a rocprofv3 kernel trace prints for the kernel family of timing phase `phase` at this stream count (the
+    template arguments are the ones sbd_launch.hpp instantiates): so that `roofline.frac` can be recomputed from
+    profiles/<tag>_kernel_stats.csv mechanically (VERDICT r05 weak #11)."""
+    nn = nstr // 2
+    g = 1
+    while g < nn:
+        g *= 2
+    if nn > 16:
+        g = nn                                   # NSTR 34-40: groups of nn lanes (sbd_layer2.hpp)
+    b = "true" if fused else "false"
+    if phase == "setup_kernel":
+        return "sbd::setup_kernel(sbd::Params)"
+    if phase == "layer_kernel":
+        return f"void sbd::layer_kernel2<{nn}, {g}, {'true' if rad else 'false'}>(sbd::Params, int*)"
+    if phase == "band_kernel":
+        if nstr <= 16:
+            return f"void sbd::band4_kernel<{nn}, {b}, false, false>(sbd::Params)"
+        if nstr <= 32:
+            return f"void sbd::band1_kernel<{nn}, {b}>(sbd::Params)"
+        return f"void sbd::band_rows_kernel<{nn}, {b}>(sbd::Params)"
+    if phase == "backsolve_kernel":
+        if nstr <= 16:
+            return f"void sbd::backsolve4_kernel<{nn}>(sbd::Params)"
+        return f"void sbd::backsolve1_kernel<{nn}>(sbd::Params)" if nstr <= 32 else f"void sbd::backsolve_kernel<{nn}>(sbd::Params)"
+    return "sbd::usrint_kernel(sbd::Params) + sbd::azimuth_kernel(sbd::Params, int)"
+
+
+def shape_roofline(names, phase_ms, nlaunch, pass_size, W, nstr, nlyr, nlev, shape="", extra_out_bytes=0, fused=True, rad=False):
     """The `roofline` object for the kernel that takes the most time: algorithmic bytes (SURVEY 8d) over its time."""
     dom = int(np.argmax(phase_ms))
     abytes = algorithmic_bytes_per_solve(nlyr, nstr, nlev) + extra_out_bytes
@@ -196,7 +224,7 @@ def shape_roofline(names, phase_ms, nlaunch, pass_size, W, nstr, nlyr, nlev, sha
                 traffic = (traffic or 0.0) + kd["bytes_per_launch"]
     elif tp is not None:
         src = f"{src}: recorded at {tp.get('solves_per_launch')} solves per launch, this run has {pass_size}"
-    return {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": rocprof_kernel_name(names[dom], nstr, fused, rad), "kernel_family": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_unit": f"HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE; {src})",
             "algorithmic_bytes_per_solve": abytes, "solves_per_launch": pass_size, "launches": nlaunch,
@@ -351,7 +379,7 @@ def other_shapes(dev, only=None, serialized_pass=True):
                          "nonzero_status": int((st != 0).sum().item()), "fallback_layers": int(fb), "finite": finite,
                          "kernel_ms_in_timed_step": dict(zip(["setup", "layer", "band", "backsolve", "usrint+azimuth"], map(float, kms_ip))),
                          "roofline": shape_roofline(names, kms_ip if (kms_ip > 0).all() else np.array(kms), nl, (sw.nwork + nl - 1) // nl, sw.nwork, sw.nstr,
-                                                    sw.nlyr, 2, shape, extra_out_bytes=8 * 20 * 16 if rad else 0),
+                                                    sw.nlyr, 2, shape, extra_out_bytes=8 * 20 * 16 if rad else 0, fused=not rad, rad=rad),
                          "valu_issue": valu_issue(sw.nwork, dt, sw.nstr, sw.nlyr, shape)}
             eng.close()
         except Exception as ex:   # a side line must not take the headline down
@@ -359,7 +387,7 @@ def other_shapes(dev, only=None, serialized_pass=True):
     return out
 
 
-def host_entry_legs(args, sw, eng, d_in, d_w, acc, flux, status, stream, dev, local_rank, rank, world, level_out, barrier, strong):
+def host_entry_legs(args, sw, eng, d_in, d_w, acc, flux, status, stream, dev, local_rank, rank, world, level_out, barrier, strong, coll):
     """The step through the HOST entry points (never `value`): DISORT's arguments as arrays, the moments once per spectral
     point, and the compact form of SURVEY 8(d)'s engine phase (`value_8d`).  Returns the fields of the bench line."""
     import ctypes as C
@@ -464,26 +492,17 @@ def host_entry_legs(args, sw, eng, d_in, d_w, acc, flux, status, stream, dev, lo
     mix_agree = bool(np.allclose(acc_m, acc_r.cpu().numpy(), rtol=1e-12, atol=0))
     bad_mix = int((status_r != 0).sum().item())
     del r_in, r_row, r_w, flux_r, status_r
-    if world > 1:
-        tt = torch.tensor([elapsed_m, elapsed_r], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed_m, elapsed_r = float(tt[0].item()), float(tt[1].item())
+    elapsed_m, elapsed_r = coll.all_max(elapsed_m, elapsed_r)
     h2d_bytes = int(sum(a.nbytes for a in h_in) + h_w.nbytes)
     h2d_bytes_shared = int(h2d_bytes - h_in[2].nbytes + h_pm_pt.nbytes + h_rows.nbytes)
-    if world > 1:
-        tt = torch.tensor([elapsed_h], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed_h = float(tt.item())
+    elapsed_h, elapsed_hs = coll.all_max(elapsed_h, elapsed_hs)
 
     assert np.allclose(acc_h, acc.cpu().numpy(), rtol=1e-12, atol=0) or world > 1, "host entry point disagrees with the device one"
     nwl_total = args.nwl if strong else sw.nwl * world
     med_m = float(np.median(mix_steps))
-    if world > 1:
-        # (every rank's own median, the slowest rank's is the node's pace -- and the same statistic on both
-        #  sides of the resident ratio)
-        tt = torch.tensor([med_m], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        med_m = float(tt.item())
+    # (every rank's own median, the slowest rank's is the node's pace -- and the same statistic on both
+    #  sides of the resident ratio)
+    med_m = coll.all_max(med_m)
     med_r = 1e3 * elapsed_r / nh
     return {
         "value_incl_h2d": nwl_total * nh / elapsed_h, "ms_per_step_incl_h2d": 1e3 * elapsed_h / nh,
@@ -520,15 +539,79 @@ DEV_SWITCHES = ("SBD_CHUNK", "SBD_WORKSPACE_MB", "SBD_BAND_V1", "SBD_LAYER_V1",
                 "SBD_FORCE_EIG_FALLBACK", "SBD_DEBUG_SYNC", "SBD_DBG_FLAGS", "SBD_NO_FUSE", "SBD_SOLVE_V1", "SBD_NO_HINT", "SBD_EXACT_PIVOT")
 
 
+def default_nwl(scaling, gpus):
+    """--nwl when it is not given: 49 152 spectral points per GPU -- per rank with weak scaling, and with strong scaling ONE
+    sweep of 49 152 x gpus points, so that every rank's shard is still a bench-size batch (2^17 solves: >= 64 work items
+    per CU, SURVEY 8d) and a strong-scaling run measures kernels, not launch latency (VERDICT r05 weak #10)."""
+    return 49152 * (gpus if scaling == "strong" else 1)
+
+
+class Coll:
+    """The collectives of the bench line.  world > 1 on distinct GPUs: RCCL on device tensors (backend "nccl").
+    --share-device rehearsal: the same calls on host copies over gloo (several ranks on one GPU cannot form an RCCL
+    communicator)."""
+    def __init__(self, world, dev, host):
+        self.world, self.dev, self.host = world, dev, host
+
+    def _all(self, vals, op):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return [float(v) for v in vals]
+        tt = torch.tensor([float(v) for v in vals], dtype=torch.float64, device="cpu" if self.host else self.dev)
+        dist.all_reduce(tt, op=op)
+        return [float(x) for x in tt.tolist()]
+
+    def all_max(self, *vals):
+        import torch.distributed as dist
+        r = self._all(vals, dist.ReduceOp.MAX)
+        return r[0] if len(r) == 1 else r
+
+    def all_sum(self, *vals):
+        import torch.distributed as dist
+        r = self._all(vals, dist.ReduceOp.SUM)
+        return r[0] if len(r) == 1 else r
+
+    def gather(self, rank, vals):
+        """[world][len(vals)] of every rank's numbers (an all-reduce of a one-hot block: no object collectives)."""
+        import torch.distributed as dist
+        k = len(vals)
+        v = [0.0] * (k * self.world)
+        v[rank * k:(rank + 1) * k] = [float(x) for x in vals]
+        r = self._all(v, dist.ReduceOp.SUM) if self.world > 1 else v
+        return [r[i * k:(i + 1) * k] for i in range(self.world)]
+
+    def reduce_sum_(self, acc):
+        """acc (device tensor) := sum over the ranks, on rank 0 -- the ONE collective of the path."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return
+        if self.host:
+            h = acc.cpu()
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+            acc.copy_(h)
+        else:
+            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)
+
+    def barrier(self):
+        import torch.distributed as dist
+        if self.world > 1:
+            dist.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nwl", type=int, default=49152, help="spectral points per GPU (W = 2.67x)")
+    ap.add_argument("--nwl", type=int, default=None,
+                    help="spectral points: per GPU with --scaling weak (default 49152; W = 2.67x), of the ONE sweep with "
+                         "--scaling strong (default 49152 x --gpus, so that every rank's shard is a bench-size batch and a "
+                         "strong-scaling run measures kernels, not launches)")
     ap.add_argument("--nstr", type=int, default=16)
     ap.add_argument("--nlyr", type=int, default=33)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0, help="CPU work of the 1-core cpu_baseline leg (bounded sample)")
     ap.add_argument("--no-side-lines", action="store_true", help="skip the latency case and the other BASELINE shapes")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --nwl spectral points PER GPU (the default; each rank its own PRNG stream); strong: ONE sweep of "
@@ -540,9 +623,19 @@ def main():
     ap.add_argument("--shape", choices=["cfgC", "cfgD", "nstr40"], default=None,
                     help="print the one-step line of another BASELINE shape (other_shapes) and nothing else: the command its "
                          "counters in profiles/ are recorded with")
+    ap.add_argument("--share-device", action="store_true",
+                    help="DEVELOPER / TEST ONLY (refused unless SBD_BENCH_SHARE_DEVICE_TEST=1 is in the environment): all "
+                         "--gpus ranks run on cuda:0 and meet over gloo -- a rehearsal of the N > 1 line on a one-GPU box "
+                         "(tests/test_bench_rehearsal.py); the line it prints carries \"rehearsal\": true and is NOT a "
+                         "multi-GPU measurement")
     ap.add_argument("--rendezvous-only", choices=["nccl", "gloo"], default=None,
                     help="launcher check: bring up --gpus ranks on this backend, count them, print that, exit (no bench line)")
     args = ap.parse_args()
+    if args.share_device and os.environ.get("SBD_BENCH_SHARE_DEVICE_TEST") != "1":
+        sys.exit("bench.py: --share-device is a test rehearsal (several ranks on ONE GPU); refused without "
+                 "SBD_BENCH_SHARE_DEVICE_TEST=1 -- it never produces a multi-GPU measurement")
+    if args.nwl is None:
+        args.nwl = default_nwl(args.scaling, args.gpus)
     on = [k for k in DEV_SWITCHES if os.environ.get(k)]
     if on:   # the headline number is the default path only
         sys.exit(f"bench.py: developer switch(es) {on} set in the environment -- refusing to produce a bench line")
@@ -553,12 +646,15 @@ def main():
     if args.gpus > 1 and launched_world() is None:
         # `python bench.py --gpus N` on its own: this process becomes the launcher of N ranks (one per GPU) and
         # passes their exit code on -- it never prints a bench line itself (a 1-GPU line labelled N would be a lie)
-        backend = "gloo" if args.rendezvous_only == "gloo" else "nccl"
+        backend = "gloo" if (args.rendezvous_only == "gloo" or args.share_device) else "nccl"
         if backend == "nccl" and torch.cuda.device_count() < args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s): "
                      f"refusing to print a line for fewer devices than asked for")
         sys.exit(relaunch_one_rank_per_gpu(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
-    rank, local_rank, world = rendezvous(args.gpus, backend="gloo" if args.rendezvous_only == "gloo" else "nccl")
+    rank, local_rank, world = rendezvous(args.gpus, backend="gloo" if (args.rendezvous_only == "gloo" or args.share_device) else "nccl")
+    share = bool(args.share_device)
+    if share:
+        local_rank = 0                     # (rehearsal: every rank on cuda:0; collectives on host tensors over gloo)
     if args.rendezvous_only:
         # launcher path only (CPU test of `--gpus N`): the ranks met, counted each other, rank 0 says so -- no metric
         if rank == 0:
@@ -569,6 +665,7 @@ def main():
         return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll = Coll(world, dev, host=share)
 
     from sbdart_amd.engine import DisortEngine
     from sbdart_amd.workload import sw_sweep
@@ -581,6 +678,7 @@ def main():
             dist.destroy_process_group()
         return
     strong = args.scaling == "strong"
+    p_lo, p_hi = 0, args.nwl
     if strong:
         # ONE sweep of --nwl spectral points, the same on every rank (same PRNG stream); rank r takes the points
         # sbd_shard_range gives it -- shards cut between spectral points, total work fixed as N grows
@@ -614,20 +712,21 @@ def main():
         rc = L.sbd_engine_accumulate_device(eng._h, W, d_w.data_ptr(), flux.data_ptr(), None,
                                             acc.data_ptr(), None, C.c_void_p(stream))
         assert rc == 0, rc
-        if world > 1:
-            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)   # the one RCCL collective of the path
+        coll.reduce_sum_(acc)                               # the one RCCL collective of the path
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        coll.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    barrier()
     # HIP events around every kernel family of every pass, recorded on the streams the kernels are launched on (the
-    # engine's two pass streams) DURING the timed steps and read after them: what the roofline object is computed from
+    # engine's two pass streams) DURING the timed steps and read after them: what the roofline object is computed from.
+    # The mode is switched on and the events are CREATED here, in one more untimed step, so that no hipEventCreate falls
+    # inside the timed region
     L.sbd_engine_enable_timing(eng._h, 2)
+    step()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -635,15 +734,12 @@ def main():
     elapsed = time.perf_counter() - t0
     inplace_ms = np.array([eng.last_ms(p) for p in range(5)])       # (the last timed step's launches)
     L.sbd_engine_enable_timing(eng._h, 0)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    W_all = W
-    if world > 1:
-        tt = torch.tensor([float(W)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        W_all = int(tt.item())
+    elapsed_rank = elapsed
+    elapsed = coll.all_max(elapsed)                        # the slowest rank's clock
+    W_all = int(round(coll.all_sum(float(W))))
+    # every rank's shard and clock, for the line: [first point, one past the last (strong: of the ONE sweep; weak: of the
+    # rank's own sweep), solves, seconds of the timed steps]
+    shards = coll.gather(rank, [p_lo, p_hi, W, elapsed_rank])
     bad = int((status != 0).sum().item())
     if not bool(torch.isfinite(flux).all().item()):
         sys.exit("bench.py: non-finite fluxes -- refusing to report a rate for wrong answers")
@@ -667,7 +763,7 @@ def main():
 
     # ---- the same step through the HOST entry points (what the Fortran host calls), outside the timed region; never `value` ----
     hl = None if args.headline_only else host_entry_legs(args, sw, eng, d_in, d_w, acc, flux, status, stream, dev, local_rank,
-                                                         rank, world, level_out, barrier, strong)
+                                                         rank, world, level_out, barrier, strong, coll)
 
     if rank == 0:
         nwl_total = args.nwl if strong else sw.nwl * world
@@ -681,7 +777,8 @@ def main():
         pass_size = (W + nlaunch - 1) // nlaunch
         # the dominant kernel's launches as they ran in the timed region (two streams: a pass's band LU beside the other
         # pass's layer kernel); `kernel_ms` below is the serialized pass (each kernel family alone on the chip)
-        roof = shape_roofline(names, inplace_ms if (inplace_ms > 0).all() else phase_ms, nlaunch, pass_size, W, sw.nstr, sw.nlyr, eng.nlev)
+        roof = shape_roofline(names, inplace_ms if (inplace_ms > 0).all() else phase_ms, nlaunch, pass_size, W, sw.nstr, sw.nlyr, eng.nlev,
+                              fused=True)
         roof["timed_with"] = "HIP events on the engine's pass streams during the last timed step (sbd_engine_enable_timing 2)"
         roof["note"] = ("latency/issue bound by construction (SURVEY 8d): ~5 KB of inputs per 2.5 MFLOP of pivoted fp64; the "
                         "binding figures are roofline_fp64 (algorithmic flops against the fp64 vector peak) and valu_issue "
@@ -698,9 +795,13 @@ def main():
                                       f"(sbd_shard_range; rank 0: {sw.nwl} points, {W} solves), {W_total} DISORT solves, "
                                       if strong else
                                       f"{sw.nwl} spectral points/GPU, {W} DISORT solves/GPU (avg nk {W / sw.nwl:.2f}), ")
-                                   + "flux at TOA+surface, seed 12345",
+                                   + "flux at TOA+surface, seed 12345; `value` = rate with the inputs RESIDENT in HBM when the timed "
+                                     "region starts (north_star: optical depths precomputed into HBM arrays), `value_8d` beside it = "
+                                     "SURVEY 8(d)'s engine phase incl. H2D of the compact inputs and D2H of the sums",
                        "nstr": sw.nstr, "nlyr": sw.nlyr, "nwl_per_gpu": sw.nwl, "solves_per_gpu": W,
                        "nwl_total": nwl_total, "solves_total": W_total,
+                       "shards": [{"rank": r_, "points": [int(a_), int(b_)], "solves": int(w_), "timed_s": t_}
+                                  for r_, (a_, b_, w_, t_) in enumerate(shards)],
                        "parallelism": f"spectral shard x{world}, 1 RCCL reduce of {5 * eng.nlev} doubles/step; per GPU {nlaunch} passes alternating on 2 streams",
                        "chunk": eng.chunk, "workspace_bytes": eng.workspace_bytes},
             "solves_per_s": W_total * args.steps / elapsed,
@@ -718,6 +819,10 @@ def main():
         }
         out["valu_issue"] = valu_issue(W, elapsed / args.steps, sw.nstr, sw.nlyr)
         flux_h = flux.cpu().numpy()
+        if share:
+            out["rehearsal"] = True
+            out["rehearsal_note"] = (f"--share-device: {world} ranks on ONE GPU over gloo -- exercises the N > 1 bookkeeping of this "
+                                     "line (shards, MAX-reduced clock, sum over ranks); NOT a multi-GPU measurement")
         if world == 1 and not args.no_side_lines:
             eng.close()
             del d_in, flux, status
@@ -725,8 +830,12 @@ def main():
             out["latency_case"] = latency_case(local_rank)
             out["other_shapes"] = other_shapes(dev)
             out["e2e_input_to_stdout"] = e2e_input_to_stdout(local_rank)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"], allc, idx, ref = cpu_baseline(sw)
+        if not args.no_cpu_baseline:
+            # rank 0's host cores, rank 0's shard (N > 1: the same bounded sample of the same workload -- a per-core
+            # figure does not depend on how many GPUs the sweep is cut over; `flux_rmse_vs_cpu` then checks rank 0's items)
+            out["cpu_baseline"], allc, idx, ref = cpu_baseline(sw, seconds_target=args.cpu_baseline_seconds)
+            if world > 1:
+                out["cpu_baseline"]["sample"] = str(out["cpu_baseline"].get("sample", "")) + f" (rank 0's shard of {world})"
             if allc is not None:
                 out["cpu_baseline_allcore"] = allc
             if ref is not None:
@@ -748,8 +857,6 @@ def main():
                     "thermal_solves": int(np.count_nonzero(np.asarray(sw.plank)[idx])),
                     "units": "fluxes per unit FBEAM (synthetic sweep has FBEAM = 1; thermal items in W/m2 per band); "
                              "north_star gate 1e-4 W/m2 on integrated fluxes"}
-        elif not args.no_cpu_baseline:
-            out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
