@@ -306,6 +306,17 @@ int      sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoin
 int      sbd_gas_terms_host(const sbd_gas_model *g, int32_t nlyr, int32_t npoint, const double *wl, const double *lay, int32_t nch,
                             int32_t *nk, double *wt, int32_t *fail, double *dtaug_out);
 
+/* errmsg 2 on the HOST (no GPU involved): LINPACK's reciprocal condition estimate (SGBCO, disutil.f:426-769) of the
+ * boundary-value system of azimuth mode `mazim` of ONE work item over a Lambertian surface, as SOLVE0 forms and tests it
+ * (disort.f:3602-3610) -- the reference's own formulation restated (csrc/sbd_refband.hpp: SETDIS's scaling, SOLEIG on ASYMTX,
+ * SETMTX in LINPACK band storage, SGBFA / SGBCO), the SAME source band_rcond_kernel runs on the device for the systems the
+ * band kernels' filter flags.  With the host's exp the value is the reference's bit for bit (tests/test_refband_host.py
+ * against the oracle, which is pinned on the reference executable's SBDART_WARNING.02 files): the pin of that kernel's
+ * source.  dtauc / ssalb [nlyr], pmom [nlyr][nmom+1] as in sbd_batch_in; plank only decides LYRCUT (disort.f:2602).
+ * SBD_E_UNSUPPORTED when ASYMTX does not converge (the reference stops there). */
+int      sbd_band_rcond_host(int32_t nlyr, int32_t nstr, int32_t nmom, int32_t mazim, int32_t plank, double albedo,
+                             const double *dtauc, const double *ssalb, const double *pmom, double *rcond);
+
 /* How the devices are fed (replaces nothing in the reference: its loop is serial, drt.f:425-561): every device's
  * shard is enqueued from a host thread of its own, and when the fleet spans several devices (or SBD_PIN_INPUTS=1)
  * dtauc / ssalb / pmom are page-locked for the duration of the call, so pageable arrays of the caller do not
@@ -347,7 +358,8 @@ void        sbd_engine_enable_timing(sbd_engine *e, int on);
  * source in a conservative layer); -1 without timing */
 int64_t     sbd_engine_last_fallback_layers(sbd_engine *e);
 /* Test hook: copy one workspace array of the LAST chunk solved to the host.
- * which: 0 gc, 1 kk, 2 ek, 3 zz, 4 zp0, 5 zp1, 6 ll, 7 sv, 8 svi(int32).  Returns bytes copied
+ * which: 0 gc, 1 kk, 2 ek, 3 zz, 4 zp0, 5 zp1, 6 ll, 7 sv, 8 svi(int32), 16 band_rcond_kernel's estimates [item x mode]
+ * (NaN where no system was served), 17 its list (int32: count, then item x mode indices).  Returns bytes copied
  * (<= nbytes) or a negative error. */
 long long   sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t nbytes);
 /* Test hook (NSTR <= 16, all output levels): on != 0 makes the band LU record, per system and elimination

@@ -74,7 +74,7 @@ EXPORTS = (
     "sbd_last_error", "sbd_engine_debug_copy", "sbd_engine_debug_pivots",
     "sbd_fleet_create", "sbd_fleet_destroy", "sbd_fleet_size", "sbd_fleet_engine", "sbd_fleet_uses_rccl",
     "sbd_shard_range", "sbd_fleet_solve_host", "sbd_fleet_last_enqueue", "sbd_host_alloc", "sbd_host_free",
-    "sbd_surface_flux_albedo", "sbd_fleet_solve_mix_host", "sbd_engine_pass_count", "sbd_shard_range_points", "sbd_fleet_gas_terms", "sbd_gas_terms_host",
+    "sbd_surface_flux_albedo", "sbd_fleet_solve_mix_host", "sbd_engine_pass_count", "sbd_shard_range_points", "sbd_band_rcond_host", "sbd_fleet_gas_terms", "sbd_gas_terms_host",
 )
 
 _LIB = None
@@ -150,6 +150,8 @@ def load() -> C.CDLL:
     L.sbd_fleet_gas_terms.restype = C.c_int
     L.sbd_gas_terms_host.argtypes = [C.POINTER(GasModel), C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, vp, vp, vp]
     L.sbd_gas_terms_host.restype = C.c_int
+    L.sbd_band_rcond_host.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, vp, vp, vp, C.POINTER(C.c_double)]
+    L.sbd_band_rcond_host.restype = C.c_int
     L.sbd_fleet_last_enqueue.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.sbd_fleet_last_enqueue.restype = C.c_int
     L.sbd_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]

@@ -572,7 +572,9 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         // (pm <= ..., not !(pm > ...): a system full of NaN -- conservative scattering at NSTR 4 makes them in the reference
         //  as well -- has RCOND = NaN there, and 1 + NaN == 1 is false: no warning.  The fuzz's last ten differing
         //  SBDART_WARNING sets of round 4 were all of this kind, tools/warn_probe.py)
-        if (q == 0 && pm <= 1.1102230246251565e-16 * am) status |= 0x01;
+        // (round 6: a FILTER, <= 1e-10 -- the system is listed for band_rcond_kernel, which forms the reference's own band
+        //  matrix and raises errmsg 2 on LINPACK's own estimate, sbd_refband.hpp)
+        if (q == 0 && pm <= 1.0e-10 * am) rcond_candidate(P, ms);
     }
     if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
     if constexpr (FUSED) {

@@ -34,10 +34,14 @@
 #include "sbd_layer.hpp"    // LayerLds
 #include "sbd_layer2.hpp"   // Layer2Lds
 #include "sbd_surface.hpp"  // bidirectional surfaces: surfac_kernel, host-side check of the model
+#include "sbd_hosttables.hpp" // QGAUSN / LEPOLY on the host (also behind sbd_band_rcond_host)
 #include "sbd_gas_types.hpp" // the gas model's launch interface (its source, sbd_gas.hpp, is compiled without contraction in sbd_k_gas.hip)
 static_assert(sbd::SBD_NFLUX_ == SBD_NFLUX, "flux component count");
 
 namespace {
+using sbd::hosttab::gauss01;
+using sbd::hosttab::legendre_norm;
+using sbd::hosttab::ref_pi;
 
 thread_local std::string g_last_error;
 
@@ -53,74 +57,6 @@ int fail(int code, const std::string &msg)
         if (e_ != hipSuccess)                                                               \
             return fail(SBD_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
     } while (0)
-
-// ---- per-run tables on the host (fp64, the reference's fp32-widened constants) ----
-inline double ref_pi() { return (double)(2.0f * asinf(1.0f)); }              // disort.f:441
-inline double ref_sqt(int k) { return (double)sqrtf((float)k); }             // disort.f:452-454
-
-// Gauss-Legendre rule on (0,1), Newton with cubic correction (QGAUSN, disort.f:5984-6157)
-void gauss01(int m, double *gmu, double *gwt)
-{
-    const double pi = ref_pi(), tol = 10.0 * 2.220446049250313e-16;
-    if (m == 1) { gmu[0] = 0.5; gwt[0] = 1.0; return; }
-    const double en = m, nnp1 = (double)(m * (m + 1));
-    const double cona = (double)((float)(m - 1) / (float)(8 * m * m * m));
-    const int lim = m / 2;
-    for (int k = 1; k <= lim; ++k) {
-        const double t = (double)(4 * k - 1) * pi / (double)(4 * m + 2);
-        double x = cos(t + cona / tan(t)), p = 0, pm1, pm2, tmp, ppr;
-        for (;;) {
-            pm2 = 1.0;
-            pm1 = x;
-            for (int nn = 2; nn <= m; ++nn) {
-                p = ((double)(2 * nn - 1) * x * pm1 - (double)(nn - 1) * pm2) / (double)nn;
-                pm2 = pm1;
-                pm1 = p;
-            }
-            tmp = 1.0 / (1.0 - x * x);
-            ppr = en * (pm2 - x * p) * tmp;
-            const double p2pri = (2.0 * x * ppr - nnp1 * p) * tmp;
-            const double xi = x - (p / ppr) * (1.0 + (p / ppr) * p2pri / (2.0 * ppr));
-            if (fabs(xi - x) > tol) { x = xi; continue; }
-            break;
-        }
-        const double ep = en * pm2;
-        gmu[k - 1] = -x;
-        gwt[k - 1] = 2.0 / (tmp * (ep * ep));
-        gmu[m - k] = x;
-        gwt[m - k] = gwt[k - 1];
-    }
-    if (m % 2) {
-        gmu[lim] = 0.0;
-        double prod = 1.0;
-        for (int k = 3; k <= m; k += 2) prod = prod * (double)k / (double)(k - 1);
-        gwt[lim] = 2.0 / (prod * prod);
-    }
-    for (int k = 0; k < m; ++k) { gmu[k] = 0.5 * gmu[k] + 0.5; gwt[k] = 0.5 * gwt[k]; }
-}
-
-// normalised associated Legendre functions, degree recurrence per order m (LEPOLY,
-// disort.f:5286-5408); ylm[i*(maxl+1)+l]; needs order m-1 in place for m > 0.
-void legendre_norm(int nmu, int m, int maxl, int twonm1, const double *mu, double *ylm)
-{
-    auto Y = [&](int l, int i) -> double & { return ylm[(size_t)i * (maxl + 1) + l]; };
-    if (m == 0) {
-        for (int i = 0; i < nmu; ++i) { Y(0, i) = 1.0; Y(1, i) = mu[i]; }
-        for (int l = 2; l <= twonm1; ++l)
-            for (int i = 0; i < nmu; ++i)
-                Y(l, i) = ((double)(2 * l - 1) * mu[i] * Y(l - 1, i) - (double)(l - 1) * Y(l - 2, i)) / (double)l;
-    } else {
-        for (int i = 0; i < nmu; ++i) {
-            Y(m, i) = -ref_sqt(2 * m - 1) / ref_sqt(2 * m) * sqrt(1.0 - mu[i] * mu[i]) * Y(m - 1, i);
-            Y(m + 1, i) = ref_sqt(2 * m + 1) * mu[i] * Y(m, i);
-        }
-        for (int l = m + 2; l <= twonm1; ++l) {
-            const double t1 = ref_sqt(l - m) * ref_sqt(l + m), t2 = ref_sqt(l - m - 1) * ref_sqt(l + m - 1);
-            for (int i = 0; i < nmu; ++i)
-                Y(l, i) = ((double)(2 * l - 1) * mu[i] * Y(l - 1, i) - t2 * Y(l - 2, i)) / t1;
-        }
-    }
-}
 
 __global__ void finish_kernel(sbd::Params P)
 {
@@ -363,6 +299,11 @@ struct sbd_engine {
     int32_t gas_p0 = 0, gas_np = 0;
     double *d_gas_lay = nullptr;    // ... and those points' layer blocks [gas_np][gas_nch][L], kept for the solves that follow
     int32_t gas_nch = 0;
+    // errmsg 2 on LINPACK's own estimate (sbd_refband.hpp): scratch of band_rcond_kernel, kRcBlocks blocks per workspace
+    static constexpr int kRcBlocks = 32;
+    double *d_rb = nullptr;
+    size_t rb_stride = 0;           // doubles per block
+    double *d_rcdbg = nullptr;      // [2][chunk * nmode] the estimates of the systems served (tests; NaN where none)
     int64_t gas_token = 0;          // generation number of d_gas_lay (sbd_fleet_gas_terms hands it to the caller; a solve names it
                                     // in sbd_mix_in::lay_token to read the resident blocks -- never inferred from pointers)
     std::vector<int32_t> gas_nk;    // [gas_np] number of k-terms of those points (a solve's kterm is checked against it)
@@ -398,6 +339,8 @@ void sbd_engine_destroy(sbd_engine *e)
     if (e->d_stage) (void)hipFree(e->d_stage);
     if (e->d_gas_slots) (void)hipFree(e->d_gas_slots);
     if (e->d_gas_lay) (void)hipFree(e->d_gas_lay);
+    if (e->d_rb) (void)hipFree(e->d_rb);
+    if (e->d_rcdbg) (void)hipFree(e->d_rcdbg);
     for (hipEvent_t ev : e->ev_ip) (void)hipEventDestroy(ev);
     if (e->h_pin) (void)hipHostFree(e->h_pin);
     if (e->h_hint) (void)hipHostFree(e->h_hint);
@@ -673,7 +616,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     size_t flag_bytes = 0;
     for (;;) {   // a GPU that cannot spare the budget right now gets smaller passes instead of an error
         flag_bytes = sizeof(int32_t) * ((size_t)chunk * nmode * L + 4);   // count + entries
-        e->ws_bytes = 2 * (((size_t)chunk * per_slot + flag_bytes + 8192 + 255) & ~(size_t)255);
+        const size_t rc_bytes = sizeof(int32_t) * (2 * (size_t)chunk * nmode + 4) + 512;   // rclist (count + entries) and rcflag
+        e->ws_bytes = 2 * (((size_t)chunk * per_slot + flag_bytes + rc_bytes + 8192 + 255) & ~(size_t)255);
         const hipError_t me_ = hipMalloc(&e->d_ws, e->ws_bytes);
         if (me_ == hipSuccess) break;
         e->d_ws = nullptr;
@@ -694,6 +638,13 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         e->d_eigflag = (int32_t *)take(flag_bytes);
         P.eiglist = e->d_eigflag;
         P.eighint = e->h_hint;
+        P.rclist = (int32_t *)take(sizeof(int32_t) * (nms + 4));
+        P.rcflag = (int32_t *)take(sizeof(int32_t) * nms);
+        {   // the layer kernels' net for band_rcond_kernel: an eigenvalue k <= 1e-6 / (smallest quadrature cosine)
+            double mumin = 1.0;
+            for (int i = 0; i < nn; ++i) mumin = std::min(mumin, e->h_cmu[i]);
+            P.rc_kmin = 1.0e-6 / mumin;
+        }
         P.sv = (double *)take(sizeof(double) * (size_t)chunk * sv_stride);
         P.svi = (int32_t *)take(sizeof(int32_t) * (size_t)chunk * svi_stride);
         P.gc = (double *)take(sizeof(double) * nms * L * n * n);
@@ -796,15 +747,23 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         if (e->use_layer2) CREATE_TRY(sbd::prepare_layer2(nn, rad_user, e->layer2_lds));
     }
     for (auto &x : e->ev) CREATE_TRY(hipEventCreate(&x));
+    {   // band_rcond_kernel's scratch (both workspaces) and its report
+        e->rb_stride = sbd::band_rcond_scratch_doubles(n, L);
+        CREATE_TRY(hipMalloc(&e->d_rb, sizeof(double) * 2 * sbd_engine::kRcBlocks * e->rb_stride));
+        CREATE_TRY(hipMalloc(&e->d_rcdbg, sizeof(double) * 2 * (size_t)e->chunk * e->nmode));
+        CREATE_TRY(hipMemset(e->d_rcdbg, 0xFF, sizeof(double) * 2 * (size_t)e->chunk * e->nmode));
+        CREATE_TRY(hipMemset(e->P.rclist, 0, sizeof(int32_t) * 4));
+    }
     {   // second workspace (every field of P is final here): each workspace pointer moved by half the allocation
         e->P2 = e->P;
         const size_t half = e->ws_bytes / 2;
         auto mv = [&](auto *&ptr) { if (ptr) ptr = (std::remove_reference_t<decltype(ptr)>)((char *)ptr + half); };
         sbd::Params &Q = e->P2;
-        mv(Q.eiglist); mv(Q.sv); mv(Q.svi); mv(Q.gc); mv(Q.ga); mv(Q.gb); mv(Q.bcb); mv(Q.gcc); mv(Q.kk); mv(Q.ek); mv(Q.zz); mv(Q.zp0);
+        mv(Q.eiglist); mv(Q.rclist); mv(Q.rcflag); mv(Q.sv); mv(Q.svi); mv(Q.gc); mv(Q.ga); mv(Q.gb); mv(Q.bcb); mv(Q.gcc); mv(Q.kk); mv(Q.ek); mv(Q.zz); mv(Q.zp0);
         mv(Q.zp1); mv(Q.ll); mv(Q.yv); mv(Q.ufac); mv(Q.gu); mv(Q.zb); mv(Q.z0u); mv(Q.z1u); mv(Q.uum);
         if (brdf_item) { mv(Q.bdr); mv(Q.bem); mv(Q.rmu); mv(Q.emu); }
         CREATE_TRY(hipMemset(Q.eiglist, 0, sizeof(int32_t) * ((size_t)e->chunk * e->nmode * e->L + 4)));
+        CREATE_TRY(hipMemset(Q.rclist, 0, sizeof(int32_t) * 4));
         Q.eighint = e->h_hint ? e->h_hint + 1 : nullptr;
     }
     if (brdf && !brdf_item) {
@@ -960,6 +919,8 @@ long long sbd_engine_debug_copy(sbd_engine *e, int which, void *host_buf, size_t
     case 13: src = e->P.eiglist; bytes = 4 * 64; break;     // count + first entries of the fallback list (first workspace)
     case 14: src = e->P2.eiglist; bytes = 4 * 64; break;    // ... second workspace
     case 15: src = e->d_pivdbg; bytes = e->d_pivdbg ? 4 * nms * L * n : 0; break;   // pivot register indices (first workspace)
+    case 16: src = e->d_rcdbg; bytes = 8 * nms; break;        // band_rcond_kernel's estimates [item x mode] (first workspace; NaN: not served)
+    case 17: src = e->P.rclist; bytes = 4 * (nms + 1); break; // its list: count, then the ms indices
     default: return SBD_E_INVALID;
     }
     if (bytes > nbytes) bytes = nbytes;
@@ -1288,8 +1249,12 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             sbd::launch_azimuth((unsigned)((items + 255) / 256), st, P, e->naz_run);
             if (e->corint) sbd::launch_intcor((unsigned)ns, st, P, e->naz_run);
         }
-        if (!e->fused)      // (the fused band kernel writes the status words itself: nothing runs after it)
+        if (!e->fused)      // (the fused band kernel writes the status words itself)
             hipLaunchKernelGGL(finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, P);
+        // errmsg 2: the systems this pass's layer / band kernels listed, on the reference's own band matrix and LINPACK's own
+        // estimate (normally none: every block reads the count and leaves)
+        sbd::launch_band_rcond(sbd_engine::kRcBlocks, st, P, e->d_rb + (second ? (size_t)sbd_engine::kRcBlocks * e->rb_stride : 0), e->rb_stride,
+                               e->d_rcdbg + (second ? (size_t)e->chunk * nmode : 0));
         if (hs) {   // this pass's outputs, staging -> host
             const size_t nf = (size_t)SBD_NFLUX * nlev, nu = rad ? (size_t)e->P.nphi * nlev * e->P.numu : 0;
             if (hs->out->flux) HIP_TRY(hipMemcpyAsync(hs->out->flux + (size_t)w0 * nf, P.flux, sizeof(double) * ns * nf, hipMemcpyDeviceToHost, st));

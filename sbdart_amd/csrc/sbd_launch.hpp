@@ -50,5 +50,9 @@ void launch_usrint(unsigned grid, int lds, hipStream_t st, const Params &P);
 void launch_cmpint(unsigned grid, hipStream_t st, const Params &P);
 void launch_azimuth(unsigned grid, hipStream_t st, const Params &P, int naz_run);
 void launch_intcor(unsigned grid, hipStream_t st, const Params &P, int naz_run);
+// errmsg 2 on LINPACK's own estimate (sbd_refband.hpp, sbd_k_refband.hip): doubles of scratch per block; the kernel that
+// serves the pass's list of flagged systems (Params::rclist)
+size_t band_rcond_scratch_doubles(int n, int L);
+void launch_band_rcond(unsigned grid, hipStream_t st, const Params &P, double *scratch, size_t stride, double *rcond_dbg);
 
 }  // namespace sbd

@@ -81,7 +81,8 @@ __global__ void __launch_bounds__(64) setup_kernel(Params P)
     const int slot = blockIdx.x;
     if (slot >= P.nslot) return;
     const int lane = threadIdx.x;
-    if (slot == 0 && lane == 0) P.eiglist[0] = 0;      // empty list for this pass's layer kernels
+    if (slot == 0 && lane == 0) { P.eiglist[0] = 0; P.rclist[0] = 0; }      // empty lists for this pass's layer kernels / band_rcond_kernel
+    for (int m = lane; m < P.nmode; m += 64) P.rcflag[(size_t)slot * P.nmode + m] = 0;
     const int L = P.L, n = P.n, nmom = P.nmom;
     const SV o(L);
     double *sv = P.sv + (size_t)slot * P.sv_stride;

@@ -2,6 +2,7 @@
 /* Process plumbing of the Fortran host's batch mode (sbdart_amd --batch LIST): what ISO_C_BINDING cannot reach in
  * libc without calling variadic functions.  Linked into the executable only -- not part of the engine's C ABI. */
 #include <fcntl.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 #include <sched.h>
@@ -89,3 +90,135 @@ int sbd_px_ncpu(void)
 }
 
 int sbd_px_getcwd(char *buf, int len) { return getcwd(buf, (size_t)len) ? (int)strlen(buf) : -1; }
+
+/* ---- sbdart_amd --serve: a resident process that owns the GPU and its engines, and the `sbdart` client that stands in
+ *      for the reference's executable under RunRT / TestRuns (RunRT.py:2021-2044 Popens `sbdart` in the run's directory
+ *      and reads its stdout).  The client hands over its working directory and its OWN file descriptors 1 and 2
+ *      (SCM_RIGHTS): the server's run writes straight into them.  Message: int32 length, the directory; reply: int32 exit
+ *      code.  The same framing serves the server's private channel to its fork helper (sbd_sv_send_job / recv_job). ---- */
+#include <errno.h>
+#include <poll.h>
+#include <sys/socket.h>
+#include <sys/uio.h>
+#include <sys/un.h>
+
+int sbd_px_dup(int fd) { return dup(fd); }
+int sbd_px_dup2(int from, int to) { fflush(stdout); fflush(stderr); return dup2(from, to) < 0 ? -1 : 0; }
+int sbd_px_close(int fd) { return close(fd); }
+int sbd_px_getpid(void) { return (int)getpid(); }
+
+int sbd_sv_socketpair(int *sv) { return socketpair(AF_UNIX, SOCK_STREAM, 0, sv); }
+
+int sbd_sv_listen(const char *path)
+{
+    struct sockaddr_un a;
+    if (strlen(path) >= sizeof(a.sun_path)) return -1;
+    const int fd = socket(AF_UNIX, SOCK_STREAM, 0);
+    if (fd < 0) return -1;
+    memset(&a, 0, sizeof(a));
+    a.sun_family = AF_UNIX;
+    strcpy(a.sun_path, path);
+    /* a socket file nobody listens on is a dead server's: replace it; a live one means another server owns the path */
+    const int probe = socket(AF_UNIX, SOCK_STREAM, 0);
+    if (probe >= 0) {
+        if (connect(probe, (struct sockaddr *)&a, sizeof(a)) == 0) { close(probe); close(fd); errno = EADDRINUSE; return -2; }
+        close(probe);
+    }
+    unlink(path);
+    const mode_t old = umask(0177);
+    const int rc = bind(fd, (struct sockaddr *)&a, sizeof(a));
+    umask(old);
+    if (rc < 0 || listen(fd, 64) < 0) { close(fd); return -1; }
+    return fd;
+}
+
+static int send_all(int fd, const void *p, size_t n)
+{
+    const char *c = (const char *)p;
+    while (n > 0) {
+        const ssize_t k = send(fd, c, n, MSG_NOSIGNAL);
+        if (k < 0) { if (errno == EINTR) continue; return -1; }
+        c += k; n -= (size_t)k;
+    }
+    return 0;
+}
+static int recv_all(int fd, void *p, size_t n)
+{
+    char *c = (char *)p;
+    while (n > 0) {
+        const ssize_t k = recv(fd, c, n, 0);
+        if (k == 0) return 1;                       /* peer closed */
+        if (k < 0) { if (errno == EINTR) continue; return -1; }
+        c += k; n -= (size_t)k;
+    }
+    return 0;
+}
+
+/* a directory and two file descriptors over a Unix socket */
+int sbd_sv_send_job(int sock, const char *dir, int fd1, int fd2)
+{
+    int32_t len = (int32_t)strlen(dir);
+    struct iovec io = { &len, sizeof(len) };
+    union { struct cmsghdr h; char buf[CMSG_SPACE(2 * sizeof(int))]; } u;
+    struct msghdr m;
+    memset(&m, 0, sizeof(m));
+    memset(&u, 0, sizeof(u));
+    m.msg_iov = &io; m.msg_iovlen = 1;
+    m.msg_control = u.buf; m.msg_controllen = sizeof(u.buf);
+    struct cmsghdr *c = CMSG_FIRSTHDR(&m);
+    c->cmsg_level = SOL_SOCKET; c->cmsg_type = SCM_RIGHTS; c->cmsg_len = CMSG_LEN(2 * sizeof(int));
+    int fds[2] = { fd1, fd2 };
+    memcpy(CMSG_DATA(c), fds, sizeof(fds));
+    for (;;) {
+        const ssize_t k = sendmsg(sock, &m, MSG_NOSIGNAL);
+        if (k == (ssize_t)sizeof(len)) break;
+        if (k < 0 && errno == EINTR) continue;
+        return -1;
+    }
+    return send_all(sock, dir, (size_t)len);
+}
+
+/* 0: a job (dir NUL-terminated, *fd1 / *fd2 the sender's descriptors, ours to close); 1: the peer closed; -1: error */
+int sbd_sv_recv_job(int sock, char *dir, int dirlen, int *fd1, int *fd2)
+{
+    int32_t len = 0;
+    struct iovec io = { &len, sizeof(len) };
+    union { struct cmsghdr h; char buf[CMSG_SPACE(2 * sizeof(int))]; } u;
+    struct msghdr m;
+    memset(&m, 0, sizeof(m));
+    m.msg_iov = &io; m.msg_iovlen = 1;
+    m.msg_control = u.buf; m.msg_controllen = sizeof(u.buf);
+    ssize_t k;
+    do { k = recvmsg(sock, &m, 0); } while (k < 0 && errno == EINTR);
+    if (k == 0) return 1;
+    if (k != (ssize_t)sizeof(len)) return -1;
+    *fd1 = *fd2 = -1;
+    for (struct cmsghdr *c = CMSG_FIRSTHDR(&m); c; c = CMSG_NXTHDR(&m, c))
+        if (c->cmsg_level == SOL_SOCKET && c->cmsg_type == SCM_RIGHTS && c->cmsg_len >= CMSG_LEN(2 * sizeof(int))) {
+            int fds[2];
+            memcpy(fds, CMSG_DATA(c), sizeof(fds));
+            *fd1 = fds[0]; *fd2 = fds[1];
+        }
+    if (len < 0 || len >= dirlen || *fd1 < 0 || *fd2 < 0) return -1;
+    if (recv_all(sock, dir, (size_t)len) != 0) return -1;
+    dir[len] = 0;
+    return 0;
+}
+
+int sbd_sv_send_code(int sock, int code) { int32_t c = code; return send_all(sock, &c, sizeof(c)); }
+int sbd_sv_recv_code(int sock, int *code) { int32_t c = 0; const int r = recv_all(sock, &c, sizeof(c)); *code = c; return r; }
+
+/* the next client of the listening socket: its connection (>= 0) with its job, -2 after idle_ms without one, -1 on error */
+int sbd_sv_accept(int lfd, int idle_ms, char *dir, int dirlen, int *fd1, int *fd2)
+{
+    for (;;) {
+        struct pollfd p = { lfd, POLLIN, 0 };
+        const int r = poll(&p, 1, idle_ms);
+        if (r == 0) return -2;
+        if (r < 0) { if (errno == EINTR) continue; return -1; }
+        const int c = accept(lfd, NULL, NULL);
+        if (c < 0) { if (errno == EINTR || errno == ECONNABORTED) continue; return -1; }
+        if (sbd_sv_recv_job(c, dir, dirlen, fd1, fd2) == 0) return c;
+        close(c);                                   /* a client that said nothing useful: next */
+    }
+}

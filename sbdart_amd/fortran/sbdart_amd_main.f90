@@ -45,10 +45,17 @@ module sbd_run_mod
   real(kind=8), save :: t_engine = 0, t_wait = 0, t_phase2 = 0        ! batch mode's time account (SBD_TIMING)
   integer(kind=8), save :: tick_program = -1                          ! system_clock at the program's first statement
   real(kind=8), save :: t_create = 0                                  ! sbd_fleet_create calls of the run (SBD_TIMING)
+  ! sbdart_amd --serve: serve_mode = this process (or the run's forked first phase) works for a client of the resident
+  ! server -- messages go to file descriptor 2, which is the CLIENT's; serve_big = the estimate of the run's work items (bytes)
+  ! above which the forked first phase hands the run back to be made whole in the server (exit code 77)
+  logical, save :: serve_mode = .false.
+  real(kind=8), save :: serve_big = 64.0d6
   character(len=*), parameter :: items_tmp = '.sbd_items.part', items_file = '.sbd_items', stdout_file = 'SBDART.stdout', stderr_file = 'SBDART.stderr', phase1_mark = '.sbd_phase1'
 contains
 
-! phase 0: the whole run, as the reference's executable; 1: up to the work items (written to items_file); 2: from there
+! phase 0: the whole run, as the reference's executable; 1: up to the work items (written to items_file); 2: from there;
+! 3: the whole run inside a process that serves further runs (sbdart_amd --serve, runs too large for a file of work
+!    items): like 0 -- compact form, gas terms on the device -- but an error ends the run, not the process, like 2
 subroutine run_once(phase)
   use iso_c_binding
   use sbd_engine_mod
@@ -63,6 +70,11 @@ subroutine run_once(phase)
   use sbd_fleet_cache_mod
   use omp_lib, only: omp_get_max_threads
   integer, intent(in) :: phase
+  interface
+    subroutine sbd_px_exit_now(code) bind(C, name='sbd_px_exit_now')
+      import; integer(c_int), value :: code
+    end subroutine
+  end interface
   integer, parameter :: ncldz = 5, naerz = 5, naerb = 150, maxmom = 299, ndb = 20
   ! ---- &INPUT / &DINPUT (drt.f:200-215), same names, same defaults where they matter ----
   integer :: idatm, isat, nf, iday, isalb, krhclr, jaer(naerz), iaer, nothrm, nosct, kdist, ngrid, idb(ndb), iout, nstr, &
@@ -226,12 +238,22 @@ subroutine run_once(phase)
     if (.not. ok) call quit('band-model tables not found; tried'//trim(why))
     if (aborted) return
     call viewing_cosines()
+    if (phase == 1 .and. serve_mode) then
+      ! a forked first phase of the resident server: a run whose work items would fill a file of more than serve_big bytes
+      ! (DISORT's arguments per item: 5 KB at NSTR 16 x 33 layers) is handed back (exit code 77) -- the server makes it
+      ! whole, compact form and gas terms on the device, like a process of its own would (phase 3)
+      if (8.0d0*real(grid%n, 8)*3.0d0*real(max(33, abs(ngrid)), 8) &
+          *real(merge(302, min(max(nstr, 4) + 2, 40) + 4, corint), 8) > serve_big) then
+        flush(6)
+        call sbd_px_exit_now(77_c_int)
+      end if
+    end if
     call system_clock(tick0, tick_rate)
     ! the batch in compact form (the scatterers per spectral point, the gas per work item; DISORT's arguments are formed
     ! on the device) whenever the run's output is the engine's: not when the work items themselves are asked for
     ! (SBD_DUMP_OPTICS, phase 1 of a batch) and not for IBCND = 1 (no solve at all).  SBD_NO_MIX=1 keeps the arrays form.
     call get_environment_variable('SBD_DUMP_OPTICS', path, plen, pstat)
-    mix%want = phase == 0 .and. .not. (pstat == 0 .and. plen > 0) .and. ibcnd /= 1
+    mix%want = (phase == 0 .or. phase == 3) .and. .not. (pstat == 0 .and. plen > 0) .and. ibcnd /= 1
     call get_environment_variable('SBD_NO_MIX', path, plen, pstat)
     if (pstat == 0 .and. plen > 0) mix%want = .false.
     ! ... and the gas terms themselves on the device (sbd_fleet_gas_terms: the band model then delivers one record per
@@ -689,9 +711,10 @@ contains
   subroutine quit(msg)
     character(len=*), intent(in) :: msg
     integer :: ue, ios2
-    if (phase /= 2) call fatal(msg)
+    if (phase == 0 .or. phase == 1) call fatal(msg)
     aborted = .true.
-    open(newunit=ue, file=stderr_file, position='append', action='write', iostat=ios2)
+    ios2 = 1
+    if (.not. serve_mode) open(newunit=ue, file=stderr_file, position='append', action='write', iostat=ios2)
     if (ios2 == 0) then
       write(ue, '(a)') 'sbdart_amd: '//msg
       close(ue)
@@ -1372,6 +1395,212 @@ contains
   end subroutine
 end subroutine
 
+! sbdart_amd --serve SOCKET: a resident process that owns the GPU, the HIP runtime and the engines of the configurations it
+! has met, serving `sbdart` clients (sbdart_client.c) one run at a time: the harnesses launch `sbdart` once per run in the
+! run's directory and read its stdout (RunRT.py:2021-2044, TestRuns/test_runs:31-145) -- unchanged.  A client hands over its
+! working directory and its own file descriptors 1 and 2; the run writes straight into them.
+!   * the run's first phase (INPUT -> screening -> band model -> work items) in a CHILD, forked by a helper process that was
+!     itself forked before this process touched the GPU: the reference's process-per-run isolation, STOPs of the model code
+!     included, for a fork (as `--batch`);
+!   * its second phase (work items -> engine -> text) here, on the engines kept from earlier runs;
+!   * a run too large for a file of work items (the child says so: exit code 77) is made whole here (phase 3: compact form,
+!     gas terms on the device);
+!   * after SBDART_AMD_IDLE_S seconds (default 300) without a client the server leaves and removes its socket.
+subroutine run_server(sockpath)
+  use iso_c_binding
+  use sbd_tables_mod, only: tables_load
+  use omp_lib
+  character(len=*), intent(in) :: sockpath
+  interface
+    integer(c_int) function sbd_px_chdir(path) bind(C, name='sbd_px_chdir')
+      import; character(kind=c_char), intent(in) :: path(*)
+    end function
+    integer(c_int) function sbd_px_fork() bind(C, name='sbd_px_fork')
+      import
+    end function
+    integer(c_int) function sbd_px_wait(pid) bind(C, name='sbd_px_wait')
+      import; integer(c_int), value :: pid
+    end function
+    subroutine sbd_px_exit_now(code) bind(C, name='sbd_px_exit_now')
+      import; integer(c_int), value :: code
+    end subroutine
+    integer(c_int) function sbd_px_exists(path) bind(C, name='sbd_px_exists')
+      import; character(kind=c_char), intent(in) :: path(*)
+    end function
+    integer(c_int) function sbd_px_remove(path) bind(C, name='sbd_px_remove')
+      import; character(kind=c_char), intent(in) :: path(*)
+    end function
+    integer(c_int) function sbd_px_rename(from, to) bind(C, name='sbd_px_rename')
+      import; character(kind=c_char), intent(in) :: from(*), to(*)
+    end function
+    integer(c_int) function sbd_px_dup(fd) bind(C, name='sbd_px_dup')
+      import; integer(c_int), value :: fd
+    end function
+    integer(c_int) function sbd_px_dup2(from, to) bind(C, name='sbd_px_dup2')
+      import; integer(c_int), value :: from, to
+    end function
+    integer(c_int) function sbd_px_close(fd) bind(C, name='sbd_px_close')
+      import; integer(c_int), value :: fd
+    end function
+    integer(c_int) function sbd_sv_socketpair(sv) bind(C, name='sbd_sv_socketpair')
+      import; integer(c_int) :: sv(2)
+    end function
+    integer(c_int) function sbd_sv_listen(path) bind(C, name='sbd_sv_listen')
+      import; character(kind=c_char), intent(in) :: path(*)
+    end function
+    integer(c_int) function sbd_sv_accept(lfd, idle_ms, dir, dirlen, fd1, fd2) bind(C, name='sbd_sv_accept')
+      import; integer(c_int), value :: lfd, idle_ms, dirlen; character(kind=c_char) :: dir(*); integer(c_int) :: fd1, fd2
+    end function
+    integer(c_int) function sbd_sv_send_job(sock, dir, fd1, fd2) bind(C, name='sbd_sv_send_job')
+      import; integer(c_int), value :: sock, fd1, fd2; character(kind=c_char), intent(in) :: dir(*)
+    end function
+    integer(c_int) function sbd_sv_recv_job(sock, dir, dirlen, fd1, fd2) bind(C, name='sbd_sv_recv_job')
+      import; integer(c_int), value :: sock, dirlen; character(kind=c_char) :: dir(*); integer(c_int) :: fd1, fd2
+    end function
+    integer(c_int) function sbd_sv_send_code(sock, code) bind(C, name='sbd_sv_send_code')
+      import; integer(c_int), value :: sock, code
+    end function
+    integer(c_int) function sbd_sv_recv_code(sock, code) bind(C, name='sbd_sv_recv_code')
+      import; integer(c_int), value :: sock; integer(c_int) :: code
+    end function
+  end interface
+  character(kind=c_char, len=1024), target :: dir
+  character(len=16) :: txt
+  integer :: tlen, tstat, ios, idle_s, nserved, dlen
+  integer(c_int) :: sv(2), helper, lfd, cfd, fd1, fd2, code, rc, keep1, keep2
+  integer(kind=8) :: c0, c1, crate
+  real(kind=8) :: t_first, t_second
+  logical :: ok, timing
+  character(len=256) :: why
+
+  serve_mode = .true.
+  idle_s = 300
+  call get_environment_variable('SBDART_AMD_IDLE_S', txt, tlen, tstat)
+  if (tstat == 0 .and. tlen > 0) read(txt(1:tlen), *, iostat=ios) idle_s
+  call get_environment_variable('SBDART_AMD_BIG_MB', txt, tlen, tstat)
+  if (tstat == 0 .and. tlen > 0) then
+    read(txt(1:tlen), *, iostat=ios) serve_big
+    serve_big = serve_big*1.0d6
+  end if
+  call get_environment_variable('SBD_TIMING', txt, tlen, tstat)
+  timing = tstat == 0 .and. tlen > 0
+  call tables_load(ok, why)                             ! once: the helper and its children inherit the tables
+  if (sbd_sv_socketpair(sv) /= 0) stop 'sbdart_amd --serve: socketpair failed'
+  flush(6)
+  helper = sbd_px_fork()                                ! BEFORE this process touches the GPU (a HIP context does not survive a fork)
+  if (helper < 0) stop 'sbdart_amd --serve: fork failed'
+  if (helper == 0) then
+    rc = sbd_px_close(sv(1))
+    call helper_loop(sv(2))
+    call sbd_px_exit_now(0_c_int)
+  end if
+  rc = sbd_px_close(sv(2))
+  lfd = sbd_sv_listen(trim(sockpath)//c_null_char)
+  if (lfd < 0) then
+    rc = sbd_px_close(sv(1))
+    rc = sbd_px_wait(helper)
+    if (lfd == -2) then
+      write(0, '(a)') 'sbdart_amd --serve: another server is listening on this socket'
+      call sbd_px_exit_now(4_c_int)
+    end if
+    write(0, '(a)') 'sbdart_amd --serve: cannot listen on the socket path'
+    call sbd_px_exit_now(5_c_int)
+  end if
+  nserved = 0; t_first = 0; t_second = 0
+  call system_clock(c0, crate)
+  do
+    cfd = sbd_sv_accept(lfd, int(min(idle_s, 2000000)*1000, c_int), dir, int(len(dir), c_int), fd1, fd2)
+    if (cfd < 0) exit                                   ! idle (or the socket broke): leave
+    dlen = index(dir, c_null_char) - 1
+    call serve_one(dir(1:dlen))
+    rc = sbd_px_close(fd1); rc = sbd_px_close(fd2)
+    rc = sbd_sv_send_code(cfd, code)
+    rc = sbd_px_close(cfd)
+    nserved = nserved + 1
+  end do
+  rc = sbd_px_close(lfd)
+  rc = sbd_px_remove(trim(sockpath)//c_null_char)
+  rc = sbd_px_close(sv(1))                              ! (the helper sees the end of its channel and leaves)
+  rc = sbd_px_wait(helper)
+  if (timing) write(0, '(a,i0,a,f9.3,a,f9.3,a,f9.3,a,i0,a)') 'sbdart_amd --serve: ', nserved, ' runs; first phases ', t_first, &
+    ' s, second phases ', t_second, ' s of which engine calls ', t_engine, ' s; ', nslot_now(), ' fleets kept'
+  call release_all_fleets()
+
+contains
+
+  ! the fork helper: a child per run, in the run's directory, writing into the client's descriptors
+  subroutine helper_loop(sock)
+    integer(c_int), intent(in) :: sock
+    character(kind=c_char, len=1024), target :: d
+    integer(c_int) :: a, b, child, cd, r
+    integer :: n
+    do
+      if (sbd_sv_recv_job(sock, d, int(len(d), c_int), a, b) /= 0) exit
+      n = index(d, c_null_char) - 1
+      child = sbd_px_fork()
+      if (child == 0) then
+        r = sbd_px_close(sock)
+        if (sbd_px_chdir(d(1:n)//c_null_char) /= 0) call sbd_px_exit_now(3_c_int)
+        if (sbd_px_dup2(a, 1_c_int) /= 0 .or. sbd_px_dup2(b, 2_c_int) /= 0) call sbd_px_exit_now(3_c_int)
+        r = sbd_px_close(a); r = sbd_px_close(b)
+        call omp_set_num_threads(min(8, max(1, omp_get_num_procs())))
+        call run_once(1)
+        flush(6)
+        call sbd_px_exit_now(0_c_int)
+      end if
+      r = sbd_px_close(a); r = sbd_px_close(b)
+      cd = -1
+      if (child > 0) cd = sbd_px_wait(child)
+      ! (the work items become visible only COMPLETE, as in a batch: the child wrote them under a temporary name)
+      if (sbd_px_exists(d(1:n)//'/'//items_tmp//c_null_char) /= 0) then
+        if (cd == 0) then
+          if (sbd_px_rename(d(1:n)//'/'//items_tmp//c_null_char, d(1:n)//'/'//items_file//c_null_char) /= 0) cd = -2
+        else
+          r = sbd_px_remove(d(1:n)//'/'//items_tmp//c_null_char)
+        end if
+      end if
+      if (sbd_sv_send_code(sock, cd) /= 0) exit
+    end do
+  end subroutine
+
+  ! one client's run; sets `code`, the client's exit code
+  subroutine serve_one(d)
+    character(len=*), intent(in) :: d
+    integer(c_int) :: r, c1st
+    integer(kind=8) :: t0, t1, t2
+    r = sbd_px_remove(d//'/'//items_file//c_null_char)      ! (left-overs of a run that was killed)
+    r = sbd_px_remove(d//'/'//items_tmp//c_null_char)
+    call system_clock(t0)
+    code = 1
+    if (sbd_sv_send_job(sv(1), d//c_null_char, fd1, fd2) /= 0) return
+    if (sbd_sv_recv_code(sv(1), c1st) /= 0) return
+    call system_clock(t1)
+    t_first = t_first + real(t1 - t0, 8)/real(crate, 8)
+    code = c1st
+    if (c1st == 77 .or. (c1st == 0 .and. sbd_px_exists(d//'/'//items_file//c_null_char) /= 0)) then
+      if (sbd_px_chdir(d//c_null_char) /= 0) then
+        code = 3; return
+      end if
+      flush(6); flush(0)
+      keep1 = sbd_px_dup(1_c_int); keep2 = sbd_px_dup(2_c_int)
+      if (sbd_px_dup2(fd1, 1_c_int) == 0 .and. sbd_px_dup2(fd2, 2_c_int) == 0) then
+        call run_once(merge(3, 2, c1st == 77))
+        flush(6); flush(0)
+        code = 0
+      else
+        code = 3
+      end if
+      r = sbd_px_dup2(keep1, 1_c_int); r = sbd_px_dup2(keep2, 2_c_int)
+      r = sbd_px_close(keep1); r = sbd_px_close(keep2)
+      r = sbd_px_remove(items_file//c_null_char)
+      r = sbd_px_remove(items_file//'.atm'//c_null_char)
+      r = sbd_px_chdir('/'//c_null_char)
+    end if
+    call system_clock(t2)
+    t_second = t_second + real(t2 - t1, 8)/real(crate, 8)
+  end subroutine
+end subroutine
+
 end module sbd_run_mod
 
 program sbdart_amd
@@ -1399,10 +1628,16 @@ program sbdart_amd
       call run_batch(trim(list))
       stop
     end if
+    if (trim(arg) == '--serve') then
+      call get_command_argument(2, list)
+      call run_server(trim(list))
+      stop
+    end if
   end if
   if (n >= 1) then
     write(0, '(a)') 'usage: sbdart_amd            (one run: ./INPUT -> stdout, as the reference)'
     write(0, '(a)') '       sbdart_amd --batch LIST   (LIST: run directories, one per line; text -> <dir>/SBDART.stdout)'
+    write(0, '(a)') '       sbdart_amd --serve SOCKET (resident server of the `sbdart` client beside this file: RunRT / TestRuns unchanged)'
     stop 2
   end if
   call run_once(0)

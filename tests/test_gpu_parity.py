@@ -932,6 +932,101 @@ def test_eigenvalue_next_to_the_beam(delta):
           f"(the reference's own FMA sensitivity: {worst_sens:.2e})")
 
 
+def test_beam_on_an_eigenvalue_raises_errmsg_3():
+    """The positive half of test_eigenvalue_next_to_the_beam (that test never asserted a warning): UMU0 stepped
+    ulp by ulp through 1/k of a layer.  LINPACK's estimate of UPBEAM's system falls below eps within a few ulps of the
+    crossing -- the REFERENCE EXECUTABLE wrote SBDART_WARNING.03 for these records and not for their neighbours
+    (tests/golden/illcond/reference_warnings.*, tests/golden/make_illcond_warnings.py): equal status words, record by
+    record, and at least twenty of them raised."""
+    import json
+    from sbdart_amd.engine import solve_records
+    from sbdart_amd.records import read_records
+    recs = read_records(os.path.join(GOLDEN, "illcond", "reference_warnings.sbdrec"))
+    meta = json.load(open(os.path.join(GOLDEN, "illcond", "reference_warnings.json")))["records"]
+    pick = [i for i, m in enumerate(meta) if m["family"].startswith("beam")]
+    assert len(pick) >= 100
+    _, _, st = solve_records([recs[i] for i in pick])
+    raised = 0
+    for k, i in enumerate(pick):
+        want = (0x02 if 3 in meta[i]["reference_warnings"] else 0)
+        assert (int(st[k]) & 0x07) == want, (meta[i], int(st[k]))
+        raised += want != 0
+    assert raised >= 20, raised
+
+
+@pytest.mark.parametrize("levels", ["all", "pair"])
+def test_reference_warning_fixtures(levels):
+    """errmsg 2 on LINPACK's OWN estimate (round 6).  212 records for which the reference executable itself wrote -- or
+    narrowly did not write -- SBDART_WARNING.02 / .03 (tests/golden/make_illcond_warnings.py; the band family: a layer a few
+    ulps from conservative scattering next to layers of ordinary scale, RCOND 1e-20 .. 3e-16 against the threshold 1.1e-16).
+    The band kernels' pivot ratio and the layer kernels' smallest eigenvalue only LIST a system; band_rcond_kernel then
+    forms the reference's own band matrix from the raw inputs (SETDIS's scaling, SOLEIG on ASYMTX, SETMTX) and runs SGBCO's
+    estimate statement for statement (sbd_refband.hpp -- the source sbd_band_rcond_host pins bit for bit on the host).
+    Status bits 0x01 / 0x02 / 0x04 must equal the reference's warning files 02 / 03 / 04 for every record, with the
+    factor stored (every level) and through the fused band kernel (the level pair); the device's estimate itself must be
+    the oracle's to 1e-6 (exp() is the device library's: a few ulps in SETMTX's entries)."""
+    import ctypes as C
+    import json
+    import pyoracle
+    from sbdart_amd.engine import engine_for_record, run_key
+    from sbdart_amd.records import read_records
+    recs = read_records(os.path.join(GOLDEN, "illcond", "reference_warnings.sbdrec"))
+    meta = json.load(open(os.path.join(GOLDEN, "illcond", "reference_warnings.json")))["records"]
+    lib = pyoracle.lib()
+    lib.sbdo_last_rcond.restype = C.c_double
+    lib.sbdo_last_rcond.argtypes = [C.c_int]
+    groups = {}
+    for i, r in enumerate(recs):
+        groups.setdefault(run_key(r), []).append(i)
+    npos = {1: 0, 2: 0, 4: 0}
+    listed = worst = 0
+    for idx in groups.values():
+        r0 = recs[idx[0]]
+        with engine_for_record(r0, level_out=None if levels == "all" else [0, r0.nlyr], max_batch=len(idx)) as eng:
+            _, _, st = eng.solve(np.stack([recs[i].dtauc for i in idx]), np.stack([recs[i].ssalb for i in idx]),
+                                 np.stack([recs[i].pmom for i in idx]), [recs[i].wvnmlo for i in idx], [recs[i].wvnmhi for i in idx],
+                                 [recs[i].fbeam for i in idx], [recs[i].albedo for i in idx], [recs[i].plank for i in idx])
+            rc_dev = eng.debug_array(16, np.float64, len(idx))            # (flux-only records: one mode per item)
+        for k, i in enumerate(idx):
+            w = meta[i]["reference_warnings"]
+            want = (1 if 2 in w else 0) | (2 if 3 in w else 0) | (4 if 4 in w else 0)
+            assert (int(st[k]) & 0x07) == want, (levels, meta[i], int(st[k]), float(rc_dev[k]))
+            for b in (1, 2, 4):
+                npos[b] += bool(want & b)
+            if meta[i]["family"].startswith("band"):
+                assert np.isfinite(rc_dev[k]), (meta[i], "not listed for band_rcond_kernel")   # the filter caught it
+                pyoracle.disort(recs[i])
+                rc = lib.sbdo_last_rcond(0)
+                listed += 1
+                worst = max(worst, abs(rc_dev[k] - rc) / rc)
+    assert npos[1] >= 30 and npos[2] >= 60, npos
+    assert listed >= 40 and worst < 1e-6, (listed, worst)
+    print(f"{levels}: errmsg 2 raised in {npos[1]} records, errmsg 3 in {npos[2]}, errmsg 4 in {npos[4]}; "
+          f"{listed} band systems served by band_rcond_kernel, estimate within {worst:.1e} of the oracle's")
+
+
+def test_the_rcond_list_is_empty_on_ordinary_records():
+    """The filter's price: band_rcond_kernel serves ONE wave per listed system, serially -- on ordinary atmospheres nothing may
+    be listed (the reference's golden records of the BASELINE shapes: 0 systems), and the dithered conservative layers of
+    real runs (windows without gas absorption) are listed but never warn, like the reference."""
+    from sbdart_amd.engine import engine_for_record
+    from sbdart_amd.records import read_records
+    for name, expect_none in (("cfgB_sw_nstr16", True), ("sbchk1", True), ("cfgD_nstr32_50ly", False), ("conservative_thermal", False)):
+        recs = [r for r in read_records(os.path.join(GOLDEN, name + ".sbdrec")) if r.lamber and not r.ibcnd]
+        r0 = recs[0]
+        recs = [r for r in recs if r.nlyr == r0.nlyr and r.nstr == r0.nstr and r.nmom == r0.nmom and np.array_equal(r.temper, r0.temper)
+                and r.umu0 == r0.umu0 and (r.flags & ~1) == (r0.flags & ~1)][:40]
+        with engine_for_record(r0, level_out=[0, r0.nlyr] if r0.onlyfl else None, max_batch=len(recs)) as eng:
+            _, _, st = eng.solve(np.stack([r.dtauc for r in recs]), np.stack([r.ssalb for r in recs]), np.stack([r.pmom for r in recs]),
+                                 [r.wvnmlo for r in recs], [r.wvnmhi for r in recs], [r.fbeam for r in recs], [r.albedo for r in recs],
+                                 [r.plank for r in recs])
+            lst = eng.debug_array(17, np.int32, 1 << 16)
+        assert not any(int(x) & 0x01 for x in st), name              # the reference wrote no SBDART_WARNING.02 for any of them
+        if expect_none:
+            assert int(lst[0]) == 0, (name, int(lst[0]))
+        print(f"{name}: {len(recs)} records, {int(lst[0])} systems listed for band_rcond_kernel")
+
+
 def test_ill_conditioned_records():
     """Records whose answer the reference itself only holds to ~1e-5: a 65-level regridded atmosphere in the
     thermal window (dozens of layers of optical depth ~1e-6).  The C restatement reproduces the reference
