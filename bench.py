@@ -323,6 +323,78 @@ def e2e_input_to_stdout(device):
                 out[name] = rec
         except Exception as ex:   # a side line must not take the headline down
             out[name] = {"error": repr(ex)}
+    try:
+        out["served"] = served_runs(device, cases)
+    except Exception as ex:
+        out["served"] = {"error": repr(ex)}
+    return out
+
+
+def served_runs(device, cases):
+    """The same INPUTs as a caller of `sbdart` sees them when `sbdart` is the CLIENT of a resident `sbdart_amd --serve`
+    (sbdart_amd/fortran/sbdart_client.c; the harnesses of the reference launch one `sbdart` per run, RunRT.py:2021-2044):
+    wall time of the client process, median of 5 after one discarded run, the text compared with the one-shot process's.
+    `testruns_180`: TestRuns' five examples, 180 runs launched one client process per run, sequentially, as
+    TestRuns/test_runs launches the reference (which needs ~0.8 s for them on this box's host, `reference_s`)."""
+    import gzip
+    bindir = os.path.join(ROOT, "sbdart_amd", "bin")
+    host, client = os.path.join(bindir, "sbdart_amd"), os.path.join(bindir, "sbdart")
+    if not os.path.exists(client):
+        return None
+    out = {}
+    with tempfile.TemporaryDirectory() as top:
+        sock = os.path.join(top, "sock")
+        senv = dict(os.environ, SBD_OPTICS="/nonexistent", SBD_DEVICES=str(device), SBDART_AMD_IDLE_S="120")
+        srv = subprocess.Popen([host, "--serve", sock], env=senv, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        try:
+            for _ in range(6000):
+                if os.path.exists(sock) or srv.poll() is not None:
+                    break
+                time.sleep(0.01)
+            cenv = dict(os.environ, SBDART_AMD_SOCKET=sock, SBDART_AMD_NO_AUTOSTART="1")
+            for k, (name, nml) in enumerate(cases):
+                d = os.path.join(top, f"case{k}")
+                os.makedirs(d)
+                with open(os.path.join(d, "INPUT"), "w") as f:
+                    f.write(f"\n &INPUT\n {nml}\n /\n")
+                alone = subprocess.run([host], cwd=d, env=senv, capture_output=True, text=True, timeout=600).stdout
+                walls, same = [], True
+                for rep in range(6):
+                    t0 = time.perf_counter()
+                    r = subprocess.run([client], cwd=d, env=cenv, capture_output=True, text=True, timeout=600)
+                    w = time.perf_counter() - t0
+                    same = same and r.returncode == 0 and r.stdout == alone
+                    if rep:
+                        walls.append(w)
+                walls.sort()
+                out[name] = {"wall_s_median": walls[len(walls) // 2], "wall_s_min": walls[0], "wall_s_max": walls[-1],
+                             "text_equals_one_shot": bool(same)}
+            # TestRuns' 180 runs, one client process per run
+            from sbdart_amd.sweep import Sweep
+            shipped = os.path.join(ROOT, "tests", "golden", "shipped")
+            nrun, secs = 0, 0.0
+            for k in range(1, 6):
+                block = gzip.open(os.path.join(shipped, f"sbchk{k}.sbd.gz"), "rt").read().split("_DATA_", 1)[0]
+                sw = Sweep(block)
+                t0 = time.perf_counter()
+                outs = sw.run(client, os.path.join(top, f"tr{k}"), env=cenv)
+                secs += time.perf_counter() - t0
+                nrun += len(outs)
+            out["testruns_180"] = {"runs": nrun, "seconds": secs, "ms_per_run": 1e3 * secs / max(1, nrun),
+                                   "how": "one `sbdart` client process per run, sequentially (subprocess.run per run, INPUT written before it)"}
+            ref = os.path.join(ROOT, "oracle", "_ref", "sbdart_ref")
+            if os.path.exists(ref):
+                t0 = time.perf_counter()
+                for k in range(1, 6):
+                    block = gzip.open(os.path.join(shipped, f"sbchk{k}.sbd.gz"), "rt").read().split("_DATA_", 1)[0]
+                    Sweep(block).run(ref, os.path.join(top, f"rr{k}"))
+                out["testruns_180"]["reference_s"] = time.perf_counter() - t0
+        finally:
+            srv.terminate()
+            try:
+                srv.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                srv.kill()
     return out
 
 
@@ -536,7 +608,7 @@ def host_entry_legs(args, sw, eng, d_in, d_w, acc, flux, status, stream, dev, lo
 
 
 DEV_SWITCHES = ("SBD_CHUNK", "SBD_WORKSPACE_MB", "SBD_BAND_V1", "SBD_LAYER_V1",
-                "SBD_FORCE_EIG_FALLBACK", "SBD_DEBUG_SYNC", "SBD_DBG_FLAGS", "SBD_NO_FUSE", "SBD_SOLVE_V1", "SBD_NO_HINT", "SBD_EXACT_PIVOT")
+                "SBD_FORCE_EIG_FALLBACK", "SBD_DEBUG_SYNC", "SBD_DBG_FLAGS", "SBD_NO_FUSE", "SBD_SOLVE_V1", "SBD_NO_HINT", "SBD_EXACT_PIVOT", "SBD_RCOND_SERIAL")
 
 
 def default_nwl(scaling, gpus):

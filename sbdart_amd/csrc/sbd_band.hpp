@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(64) band_kernel(Params P)
         { const double ap = fabs(d); pv_nan = pv_nan || (ap != ap); pv_min = fmin(pv_min, ap); pv_max = fmax(pv_max, ap); }
         // 1 + min|pivot| / max|pivot| == 1 (a zero pivot included), silent on NaN like the reference's 1 + RCOND == 1
         // (round 6: a FILTER -- the system is listed for band_rcond_kernel, sbd_refband.hpp)
-        if (lane == 0 && !pv_nan && pv_min <= 1.0e-10 * pv_max) rcond_candidate(P, ms);
+        if (lane == 0 && ((!pv_nan && pv_min <= 1.0e-10 * pv_max) || P.rcflag[ms] == 2)) rcond_candidate(P, ms);
         if (lane == 0) { ufac[(size_t)(N - 1) * UW] = d; yv[N - 1] = bw[kq]; }
     }
     if (status && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], status);

@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(64, SBD_B1_WAVES) band1_kernel(Params P)
         const bool ynan = __builtin_amdgcn_ballot_w64(y != y) != 0ull;
         // (round 6: a FILTER, <= 1e-10 -- the system is listed for band_rcond_kernel, which forms the reference's own band
         //  matrix and raises errmsg 2 on LINPACK's own estimate, sbd_refband.hpp)
-        if (lane == 0 && !ynan && __hiloint2double((int)pmin_hi, 0) <= 1.0e-10 * __hiloint2double((int)pmax_hi, 0)) rcond_candidate(P, ms);
+        if (lane == 0 && ((!ynan && __hiloint2double((int)pmin_hi, 0) <= 1.0e-10 * __hiloint2double((int)pmax_hi, 0)) || P.rcflag[ms] == 2)) rcond_candidate(P, ms);
     }
     if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
     if constexpr (FUSED) {

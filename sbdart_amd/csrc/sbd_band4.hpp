@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(64, 2) band4_kernel(Params P)
         //  SBDART_WARNING sets of round 4 were all of this kind, tools/warn_probe.py)
         // (round 6: a FILTER, <= 1e-10 -- the system is listed for band_rcond_kernel, which forms the reference's own band
         //  matrix and raises errmsg 2 on LINPACK's own estimate, sbd_refband.hpp)
-        if (q == 0 && pm <= 1.0e-10 * am) rcond_candidate(P, ms);
+        if (q == 0 && (pm <= 1.0e-10 * am || P.rcflag[ms] == 2)) rcond_candidate(P, ms);
     }
     if (status) atomicOr(&svi[SBD_SVI_STATUS], status);
     if constexpr (FUSED) {

@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(64, 2) band_rows_kernel(Params P)
     const bool any_nan = __ballot(s.pv_nan) != 0ull;
     // (round 6: a FILTER, <= 1e-10 -- the system is listed for band_rcond_kernel, which forms the reference's own band matrix
     //  and raises errmsg 2 on LINPACK's own estimate, sbd_refband.hpp)
-    if (lane == 0 && !any_nan && pmin <= 1.0e-10 * pmax) rcond_candidate(P, ms);
+    if (lane == 0 && ((!any_nan && pmin <= 1.0e-10 * pmax) || P.rcflag[ms] == 2)) rcond_candidate(P, ms);
     const int status = 0;
     if (status && lane == 0) atomicOr(&svi[SBD_SVI_STATUS], status);
     if constexpr (FUSED) {

@@ -57,10 +57,10 @@ struct Params {
     int32_t *eighint;        // host-visible word: the list's length as the list-walking layer kernel last found it (this workspace)
     int32_t *eiglist;        // [1 + nslot*nmode*L] count + (item, mode, layer) indices left to the QR kernel
     // errmsg 2 on LINPACK's own estimate (sbd_refband.hpp): the systems (item x mode) of this pass that a cheap filter flagged
-    // -- a layer with an eigenvalue k <= 1e-6 / min(mu) (layer kernels) or a pivot ratio <= 1e-10 (band kernels) -- wait
-    // in rclist (count, then ms indices; rcflag[ms] says "listed") for band_rcond_kernel at the end of the pass
+    // -- an item with a layer within 1e-12 of conservative scattering, SSALB = 1 included (setup_kernel marks its systems:
+    // rcflag = 2), or a pivot ratio <= 1e-10 in the band LU -- are listed by the band kernels in rclist (count, then ms
+    // indices; rcflag[ms] = 1: listed) for band_rcond_kernel at the end of the pass
     int32_t *rclist, *rcflag;
-    double rc_kmin;          // the layer kernels' threshold on an eigenvalue k: 1e-6 / (smallest quadrature cosine)
     int32_t nslot;          // work items in this chunk
     int32_t sv_stride, svi_stride;
     int32_t cw, ncd;        // band: CW = 2*ncd+1 columns kept per U row, ncd = 3nn-1
@@ -101,7 +101,7 @@ struct Params {
 // list system ms = slot * nmode + mazim for band_rcond_kernel (once: rcflag dedupes); any lane of any kernel of the pass
 SBD_DEVICE void rcond_candidate(const Params &P, long long ms)
 {
-    if (atomicExch(&P.rcflag[ms], 1) == 0) P.rclist[1 + atomicAdd(&P.rclist[0], 1)] = (int32_t)ms;
+    if (atomicExch(&P.rcflag[ms], 1) != 1) P.rclist[1 + atomicAdd(&P.rclist[0], 1)] = (int32_t)ms;
 }
 
 // index of the [L][nmom+1] block of moments that belongs to work item `slot` of the pass

@@ -300,7 +300,7 @@ struct sbd_engine {
     double *d_gas_lay = nullptr;    // ... and those points' layer blocks [gas_np][gas_nch][L], kept for the solves that follow
     int32_t gas_nch = 0;
     // errmsg 2 on LINPACK's own estimate (sbd_refband.hpp): scratch of band_rcond_kernel, kRcBlocks blocks per workspace
-    static constexpr int kRcBlocks = 32;
+    int rc_blocks = 8;              // blocks of band_rcond_kernel per workspace (scratch: <= 1 GB per workspace)
     double *d_rb = nullptr;
     size_t rb_stride = 0;           // doubles per block
     double *d_rcdbg = nullptr;      // [2][chunk * nmode] the estimates of the systems served (tests; NaN where none)
@@ -445,7 +445,19 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     }
 
     int ndev = 0;
+    // SBD_TIMING: where the creation's time goes (ms since its first statement, to stderr) -- the runtime's bring-up is the
+    // first HIP call of a process, the kernels' code objects are loaded by the first hipFuncSetAttribute / launch of a family
+    const bool t_on = getenv("SBD_TIMING") != nullptr && getenv("SBD_TIMING_CREATE") != nullptr;
+    const auto t_c0 = std::chrono::steady_clock::now();
+    std::string t_log;
+    auto t_mark = [&](const char *what) {
+        if (!t_on) return;
+        char b[96];
+        snprintf(b, sizeof(b), " %s %.1f", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_c0).count());
+        t_log += b;
+    };
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SBD_E_NO_DEVICE, "hipGetDeviceCount");
+    t_mark("hipGetDeviceCount");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(SBD_E_NO_DEVICE, "device ordinal out of range");
     HIP_TRY(hipSetDevice(cfg->device));
 
@@ -546,7 +558,9 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
                         std::string(#expr) + ": " + hipGetErrorString(e_));                 \
         }                                                                                   \
     } while (0)
+    t_mark("host-tables");
     CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    t_mark("first-stream");
     CREATE_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&e->copy, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -557,6 +571,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     for (int i = 0; i < e->nlev; ++i) hlev[i] = cfg->nlevel_out > 0 ? cfg->level_out[i] : i;
     CREATE_TRY(hipMalloc(&e->d_level, sizeof(int32_t) * e->nlev));
     CREATE_TRY(hipMemcpy(e->d_level, hlev.data(), sizeof(int32_t) * e->nlev, hipMemcpyHostToDevice));
+    t_mark("tables-up");
     e->tab.cmu = e->d_tab + o_cmu;
     e->tab.cwt = e->d_tab + o_cwt;
     e->tab.ylmc = e->d_tab + o_ylmc;
@@ -626,6 +641,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         chunk /= 2;
     }
     e->chunk = chunk;
+    t_mark("workspace");
     // the list-walking layer kernel tells the host how long it found the list (a word of pinned host memory per workspace,
     // written by the kernel itself: no copy command in the stream)
     if (hipHostMalloc((void **)&e->h_hint, 2 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess) { e->h_hint[0] = -1; e->h_hint[1] = -1; }
@@ -640,11 +656,6 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         P.eighint = e->h_hint;
         P.rclist = (int32_t *)take(sizeof(int32_t) * (nms + 4));
         P.rcflag = (int32_t *)take(sizeof(int32_t) * nms);
-        {   // the layer kernels' net for band_rcond_kernel: an eigenvalue k <= 1e-6 / (smallest quadrature cosine)
-            double mumin = 1.0;
-            for (int i = 0; i < nn; ++i) mumin = std::min(mumin, e->h_cmu[i]);
-            P.rc_kmin = 1.0e-6 / mumin;
-        }
         P.sv = (double *)take(sizeof(double) * (size_t)chunk * sv_stride);
         P.svi = (int32_t *)take(sizeof(int32_t) * (size_t)chunk * svi_stride);
         P.gc = (double *)take(sizeof(double) * nms * L * n * n);
@@ -733,7 +744,9 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         sbd_engine_destroy(e);
         return fail(SBD_E_UNSUPPORTED, "LDS footprint exceeds 160 KiB for this NSTR/NLYR");
     }
+    t_mark("carve");
     CREATE_TRY(sbd::prepare_layer_v1(G, e->layer_lds));
+    t_mark("prepare-layer-v1");
     CREATE_TRY(sbd::prepare_band_lds(nn, e->band_lds));
     CREATE_TRY(sbd::prepare_backsolve(nn, e->solve_lds));
     {
@@ -746,10 +759,15 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
         CREATE_TRY(hipMemset(e->d_eigflag, 0, flag_bytes));
         if (e->use_layer2) CREATE_TRY(sbd::prepare_layer2(nn, rad_user, e->layer2_lds));
     }
+    t_mark("prepare-kernels");
     for (auto &x : e->ev) CREATE_TRY(hipEventCreate(&x));
     {   // band_rcond_kernel's scratch (both workspaces) and its report
         e->rb_stride = sbd::band_rcond_scratch_doubles(n, L);
-        CREATE_TRY(hipMalloc(&e->d_rb, sizeof(double) * 2 * sbd_engine::kRcBlocks * e->rb_stride));
+        // one wave per listed system, serial in its band part: the concurrency is the number of blocks -- as many as 1 GB of
+        // scratch per workspace holds, 8 .. 512 (1 MB per block at NSTR 16 x 33 layers, 6.5 MB at NSTR 40 x 65)
+        e->rc_blocks = (int)std::max<size_t>(8, std::min<size_t>(512, ((size_t)1 << 30) / (sizeof(double) * e->rb_stride)));
+        if (cfg->max_batch > 0) e->rc_blocks = (int)std::min<size_t>((size_t)e->rc_blocks, std::max<size_t>(8, (size_t)cfg->max_batch * e->nmode));
+        CREATE_TRY(hipMalloc(&e->d_rb, sizeof(double) * 2 * (size_t)e->rc_blocks * e->rb_stride));
         CREATE_TRY(hipMalloc(&e->d_rcdbg, sizeof(double) * 2 * (size_t)e->chunk * e->nmode));
         CREATE_TRY(hipMemset(e->d_rcdbg, 0xFF, sizeof(double) * 2 * (size_t)e->chunk * e->nmode));
         CREATE_TRY(hipMemset(e->P.rclist, 0, sizeof(int32_t) * 4));
@@ -794,6 +812,8 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
 
     // beam angle == quadrature angle (disort.f:2643-2650): whole-run property when a beam
     // is present; reported here so the host can pick NSTR-2 / NSTR+2 as drt.f:536-555 does.
+    t_mark("end");
+    if (t_on) fprintf(stderr, "sbdart_amd: engine create on device %d (ms since entry):%s\n", cfg->device, t_log.c_str());
     *out = e;
     if (cfg->umu0 > 0.0)
         for (int iq = 0; iq < nn; ++iq)
@@ -1253,7 +1273,7 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             hipLaunchKernelGGL(finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, P);
         // errmsg 2: the systems this pass's layer / band kernels listed, on the reference's own band matrix and LINPACK's own
         // estimate (normally none: every block reads the count and leaves)
-        sbd::launch_band_rcond(sbd_engine::kRcBlocks, st, P, e->d_rb + (second ? (size_t)sbd_engine::kRcBlocks * e->rb_stride : 0), e->rb_stride,
+        sbd::launch_band_rcond((unsigned)e->rc_blocks, st, P, e->d_rb + (second ? (size_t)e->rc_blocks * e->rb_stride : 0), e->rb_stride,
                                e->d_rcdbg + (second ? (size_t)e->chunk * nmode : 0));
         if (hs) {   // this pass's outputs, staging -> host
             const size_t nf = (size_t)SBD_NFLUX * nlev, nu = rad ? (size_t)e->P.nphi * nlev * e->P.numu : 0;

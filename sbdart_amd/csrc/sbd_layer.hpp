@@ -412,13 +412,6 @@ __global__ void __launch_bounds__(64, LIST ? 3 : 1) layer_kernel(Params P, int32
         oprim = w_lay * (1.0 - f) / (1.0 - f * w_lay);
     }
     }
-    // errmsg 2 (sbd_refband.hpp): a layer whose smallest eigenvalue is rounding noise lists its system for band_rcond_kernel
-    // (the same net as the fast layer kernel's, sbd_layer2.hpp)
-    if (g == 0) {
-        bool tiny = false;
-        for (int q = 0; q < nn; ++q) tiny = tiny || (eval[q] <= P.rc_kmin);
-        if (tiny) rcond_candidate(P, ms);
-    }
     if (me <= nn) {   // (G+)+(G-) = AMB * evec / k  (disort.f:3273-3286), column me, into APB
         for (int iq = 1; iq <= nn; ++iq) {
             double sum = 0.0;

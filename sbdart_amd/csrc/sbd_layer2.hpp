@@ -626,10 +626,6 @@ __global__ void __launch_bounds__(64, (NN > 16 && !RAD) ? SBD_BIG_WAVES : (NN > 
             if (g == 0) eigflag[1 + atomicAdd(&eigflag[0], 1)] = (int32_t)lidx;
             return;
         }
-        // errmsg 2 (sbd_refband.hpp): the reference's band system can only be singular to working precision next to a layer
-        // whose smallest eigenvalue is rounding noise (k <= 1e-6 / min mu is a generous net: measured k/kmax < 1e-8 for every
-        // RCOND < 1e-15) -- such a system is listed for band_rcond_kernel at the end of the pass
-        if ((__ballot((me <= nn) && lam <= P.rc_kmin * P.rc_kmin) & gmask) != 0ull && g == 0) rcond_candidate(P, (long long)ms);
     }
     if (me <= nn) {
         const double rkq = rsqrt_nr(fabs(lam));           // (lam > 0 here; k to an ulp or two, like the factors)

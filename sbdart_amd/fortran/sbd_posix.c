@@ -222,3 +222,36 @@ int sbd_sv_accept(int lfd, int idle_ms, char *dir, int dirlen, int *fd1, int *fd
         close(c);                                   /* a client that said nothing useful: next */
     }
 }
+
+/* SBD_DEVICES names the HIP devices of the run ("0", "0,2,3"; "all" = every visible one; unset = "0").  The runtime
+ * brings up EVERY agent it can see at its first call -- eight on an 8-GPU node for a run that uses one (VERDICT r05 #3b).
+ * Unless the user restricts the runtime himself (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES), the
+ * others are hidden here: ROCR_VISIBLE_DEVICES = the list and, since the ordinals then count from 0, SBD_DEVICES = 0..k-1.
+ * Must run before the process's first HIP call (the host program's first statement).  Returns 1 when it changed the
+ * environment.  SBD_SHOW_DEVICES=1: say on stderr what the runtime will see. */
+int sbd_px_restrict_devices(void)
+{
+    const char *want = getenv("SBD_DEVICES");
+    int changed = 0;
+    if (!getenv("ROCR_VISIBLE_DEVICES") && !getenv("HIP_VISIBLE_DEVICES") && !getenv("CUDA_VISIBLE_DEVICES")
+        && !(want && strcmp(want, "all") == 0)) {
+        const char *list = (want && *want) ? want : "0";
+        int k = 0, ok = 1;
+        for (const char *c = list; *c; ++c) {
+            if (*c == ',') ++k;
+            else if (*c < '0' || *c > '9') ok = 0;
+        }
+        if (ok && list[0] != ',' && list[strlen(list) - 1] != ',') {
+            char remap[256];
+            size_t o = 0;
+            for (int i = 0; i <= k && o + 8 < sizeof(remap); ++i) o += (size_t)snprintf(remap + o, sizeof(remap) - o, i ? ",%d" : "%d", i);
+            setenv("ROCR_VISIBLE_DEVICES", list, 1);
+            setenv("SBD_DEVICES", remap, 1);
+            changed = 1;
+        }
+    }
+    if (getenv("SBD_SHOW_DEVICES"))
+        fprintf(stderr, "sbdart_amd: devices: ROCR_VISIBLE_DEVICES=%s SBD_DEVICES=%s\n",
+                getenv("ROCR_VISIBLE_DEVICES") ? getenv("ROCR_VISIBLE_DEVICES") : "(unset)", getenv("SBD_DEVICES") ? getenv("SBD_DEVICES") : "(unset)");
+    return changed;
+}

@@ -48,6 +48,7 @@ module sbd_run_mod
   ! sbdart_amd --serve: serve_mode = this process (or the run's forked first phase) works for a client of the resident
   ! server -- messages go to file descriptor 2, which is the CLIENT's; serve_big = the estimate of the run's work items (bytes)
   ! above which the forked first phase hands the run back to be made whole in the server (exit code 77)
+  integer, parameter :: gas_device_min = 8000       ! spectral points from which a run's gas terms are evaluated on the device
   logical, save :: serve_mode = .false.
   real(kind=8), save :: serve_big = 64.0d6
   character(len=*), parameter :: items_tmp = '.sbd_items.part', items_file = '.sbd_items', stdout_file = 'SBDART.stdout', stderr_file = 'SBDART.stderr', phase1_mark = '.sbd_phase1'
@@ -260,6 +261,14 @@ subroutine run_once(phase)
     ! spectral point, the engine says how many k-terms each has).  SBD_HOST_GAS=1 keeps them on the host.
     call get_environment_variable('SBD_DUMP_MIX', path, plen, pstat)
     mix%gas_on_device = mix%want .and. .not. (pstat == 0 .and. plen > 0)
+    ! ... for runs large enough to pay for it: below gas_device_min spectral points the host's gas terms cost a few
+    ! milliseconds, while the device's put the runtime's bring-up and one more kernel family's code object ahead of
+    ! everything else (profiles/r05_e2e_input_to_stdout.txt: 751 wavelengths 0.125 s with the gas on the host, 0.21-0.29 s
+    ! on the device; 39 897 and 75 001 wavelengths: the device ahead or level).  SBD_HOST_GAS=1 / SBD_DEVICE_GAS=1 decide
+    ! for any size.
+    if (grid%n < gas_device_min) mix%gas_on_device = .false.
+    call get_environment_variable('SBD_DEVICE_GAS', path, plen, pstat)
+    if (pstat == 0 .and. plen > 0) mix%gas_on_device = mix%want
     call get_environment_variable('SBD_HOST_GAS', path, plen, pstat)
     if (pstat == 0 .and. plen > 0) mix%gas_on_device = .false.
     if (kdist == -1) then
@@ -1614,12 +1623,17 @@ program sbdart_amd
       use iso_c_binding
       character(kind=c_char), intent(in) :: name(*), value(*)
     end function
+    integer(c_int) function sbd_px_restrict_devices() bind(C, name='sbd_px_restrict_devices')
+      use iso_c_binding
+    end function
   end interface
   call system_clock(tick_program)
   ! The OpenMP runtime's first act is to map the machine's topology for thread affinity: 35-70 ms on the 256-core GPU
   ! box (profiles/r05_e2e_omp_init.txt) -- ten times the band model's wavelength loop, which needs no placement.
   ! Unless the user says otherwise, affinity is off.
   n = sbd_px_setenv_default('KMP_AFFINITY'//c_null_char, 'disabled'//c_null_char)
+  ! The HIP runtime brings up every GPU it can see at its first call: the run's devices only (sbd_posix.c)
+  n = sbd_px_restrict_devices()
   n = command_argument_count()
   if (n >= 2) then
     call get_command_argument(1, arg)

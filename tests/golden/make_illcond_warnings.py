@@ -161,7 +161,8 @@ def main():
                            "20 000 stacks of random moments and 5 184 conservative stacks up to tau 1e15 never took the oracle's band "
                            "RCOND below 1.1e-12; a hill climb on log tau / log(1 - SSALB) / g per layer reached 1e-17..1e-20 in "
                            "3 000-6 000 steps (four seeds), every end point confirmed by the reference executable.  In 6 000 "
-                           "perturbations of those end points RCOND < 1e-15 implied a layer with kmin/kmax < 1e-8."}
+                           "perturbations of those end points RCOND < 1e-15 implied a layer with kmin/kmax < 1e-8."
+                           "  Round 6's filter: hill climbs in which every layer is at least 1e-12 away from conservative scattering (SSALB <= 1 - 1e-12; three seeds, NSTR 4-16, 2 000-3 000 steps) ended at RCOND 1.1e-14 .. 2.3e-14, a hundred times the threshold; with exactly conservative layers (SSALB = 1, which DISORT dithers to 1 - 2.2e-14) beside layers at least 1e-6 away, eight seeds (NSTR 4-32, up to 12 000 steps) ended at 1.1e-15 .. 1.1e-14 -- ten times the threshold: the engine lists every item with a layer within 1e-12 of 1, SSALB = 1 included (setup_kernel), beside the band LU's pivot ratio <= 1e-10."}
     with open(os.path.join(HERE, "illcond", "reference_warnings.json"), "w") as f:
         json.dump(doc, f, indent=1)
     print(len(kept), "records", os.path.getsize(path), "bytes")

@@ -369,6 +369,10 @@ def test_aerosol_file_from_input_alone(tmp_path, namelist, wls, nmom):
 
 DIVERSE = [
     "idatm=6 wlinf=.5 wlsup=.9 wlinc=.2 iout=5 nstr=32 iaer=1 vis=23 nzen=20 uzen=0,85 nphi=16 phi=0,180 sza=30",   # BASELINE configs[3]
+    # ... configs[3] outside the visible: one ultraviolet point (ozone's Hartley-Huggins bands under
+    # Rayleigh scattering) and one at 3.7 um (solar + thermal sources together, three k-terms), the same 20 x 16 angles
+    "idatm=6 wlinf=.3 wlsup=.3 iout=5 nstr=32 iaer=1 vis=23 nzen=20 uzen=0,85 nphi=16 phi=0,180 sza=30",
+    "idatm=6 wlinf=3.7 wlsup=3.7 iout=5 nstr=32 iaer=1 vis=23 nzen=20 uzen=0,85 nphi=16 phi=0,180 sza=30",
     "idatm=6 wlinf=.25 wlsup=100 wlinc=20 nstr=32 ngrid=50 iout=10 sza=30",                                          # BASELINE configs[4]
     "idatm=4 isat=6 sza=30 iout=10 isalb=6",
     "idatm=2 wlinf=8 wlsup=13 wlinc=.25 sza=95 iout=11 tcloud=2 zcloud=6 nre=-40 rhcld=1",
@@ -390,7 +394,13 @@ def test_diverse_inputs_from_input_alone(tmp_path, namelist):
     _build()
     ref, got, _ = run_reference_and_host(namelist, str(tmp_path), from_input=True)
     off = _compare_stdout(got, ref)
-    print(f"{len(ref.split())} tokens, {off} one unit off in the last printed digit", file=sys.stderr)
+    # ... and with the gas terms of the run evaluated on the device (sbd_fleet_gas_terms: the default from 8 000 spectral
+    # points on, round 6; forced here): the same text by the same rule
+    env = dict(os.environ, SBD_OPTICS=str(tmp_path / "no-optics-file"), SBD_ATMOS=str(tmp_path / "no-atm-file"), SBD_DEVICE_GAS="1")
+    p = subprocess.run([HOST], cwd=str(tmp_path), env=env, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    off_dev = _compare_stdout(p.stdout, ref)
+    print(f"{len(ref.split())} tokens, {off} / {off_dev} (gas on the host / on the device) one unit off in the last printed digit", file=sys.stderr)
 
 
 @pytest.mark.gpu

@@ -182,3 +182,23 @@ def test_a_large_run_is_made_whole_in_the_server(tmp_path):
         assert not os.path.exists(os.path.join(d, ".sbd_items"))
     finally:
         srv.stop()
+
+
+def test_the_runtime_sees_only_the_devices_of_the_run(tmp_path):
+    """SBD_DEVICES -> ROCR_VISIBLE_DEVICES before the first HIP call (VERDICT r05 #3b: on an 8-GPU node the runtime brings up
+    eight agents for a run that uses one), the ordinals renumbered; the user's own restriction of the runtime is respected."""
+    _build()
+    d = _mkrun(str(tmp_path / "a"), GAS_REPORT)
+    base = {k: v for k, v in os.environ.items() if k not in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "SBD_DEVICES")}
+
+    def seen(**extra):
+        p = subprocess.run([HOST], cwd=d, env=dict(base, SBD_SHOW_DEVICES="1", **extra), capture_output=True, text=True)
+        line = [ln for ln in p.stderr.splitlines() if ln.startswith("sbdart_amd: devices:")][0]
+        return line.split("devices: ")[1]
+
+    assert seen() == "ROCR_VISIBLE_DEVICES=0 SBD_DEVICES=0"
+    assert seen(SBD_DEVICES="2") == "ROCR_VISIBLE_DEVICES=2 SBD_DEVICES=0"
+    assert seen(SBD_DEVICES="1,3,6") == "ROCR_VISIBLE_DEVICES=1,3,6 SBD_DEVICES=0,1,2"
+    assert seen(SBD_DEVICES="all") == "ROCR_VISIBLE_DEVICES=(unset) SBD_DEVICES=all"
+    assert seen(SBD_DEVICES="2", ROCR_VISIBLE_DEVICES="4,5,6") == "ROCR_VISIBLE_DEVICES=4,5,6 SBD_DEVICES=2"
+    assert seen(SBD_DEVICES="1", HIP_VISIBLE_DEVICES="3,4") == "ROCR_VISIBLE_DEVICES=(unset) SBD_DEVICES=1"
