@@ -71,7 +71,11 @@ SBD_DEVICE double sgbco(double *abd, int lda, int n, int ml, int mu, int32_t *ip
         for (int i = 0; i < l; ++i) sj = sj + fabs(ABD(is + i, j));
         if (sj > anorm) anorm = sj;
     }
-    for (int r = 0; r < 64; ++r) { const double o = lane_val(anorm, r); if (r == 0) anorm = o; else if (o > anorm) anorm = o; }
+    {
+        const double mine = anorm;                                    // (this lane's columns)
+        anorm = lane_val(mine, 0);
+        for (int r = 1; r < 64; ++r) { const double o = lane_val(mine, r); if (o > anorm) anorm = o; }
+    }
     // (the serial code takes the columns in order with `if (s > anorm)`: a maximum that skips NaN, like this one)
 
     // ---- SGBFA ----

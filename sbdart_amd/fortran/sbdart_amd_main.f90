@@ -50,7 +50,7 @@ module sbd_run_mod
   ! above which the forked first phase hands the run back to be made whole in the server (exit code 77)
   integer, parameter :: gas_device_min = 8000       ! spectral points from which a run's gas terms are evaluated on the device
   logical, save :: serve_mode = .false.
-  real(kind=8), save :: serve_big = 64.0d6
+  real(kind=8), save :: serve_big = 64.0d6, serve_mid = 1.0d6
   character(len=*), parameter :: items_tmp = '.sbd_items.part', items_file = '.sbd_items', stdout_file = 'SBDART.stdout', stderr_file = 'SBDART.stderr', phase1_mark = '.sbd_phase1'
 contains
 
@@ -321,6 +321,16 @@ subroutine run_once(phase)
   end if
   nmom = maxval(recs(1:nrec)%nmom)
   call get_environment_variable('SBD_DUMP_OPTICS', path, plen, pstat)      ! the work items, for inspection / tests
+  if (phase == 1 .and. serve_mode .and. from_model .and. ibcnd /= 1) then
+    ! a forked first phase of the resident server whose work items would fill more than serve_mid bytes (a 751-wavelength
+    ! run at NSTR 16: 10 MB written here and read back there) was a REHEARSAL: screening and band model came through
+    ! without a STOP -- the server now makes the run whole itself (exit code 78 -> phase 3, compact form; what stopped
+    ! nothing here stops nothing there: same INPUT, same files, same code)
+    if (8.0d0*real(nrec, 8)*real(nz, 8)*real(nmom + 4, 8) > serve_mid) then
+      flush(6)
+      call sbd_px_exit_now(78_c_int)
+    end if
+  end if
   if (phase == 1) then                                  ! batch mode: hand the work items to the process that solves
     path = items_tmp; plen = len(items_tmp); pstat = 0    ! (renamed to items_file by the worker once this child has exited with code 0)
     if (have_atm) call write_atmosphere(items_file//'.atm', nz, zlev, plev)
@@ -1412,8 +1422,10 @@ end subroutine
 !     itself forked before this process touched the GPU: the reference's process-per-run isolation, STOPs of the model code
 !     included, for a fork (as `--batch`);
 !   * its second phase (work items -> engine -> text) here, on the engines kept from earlier runs;
-!   * a run too large for a file of work items (the child says so: exit code 77) is made whole here (phase 3: compact form,
-!     gas terms on the device);
+!   * a run too large for a file of work items (the child says so before its band model: exit code 77) is made whole here
+!     (phase 3: compact form, gas terms on the device); a run of middle size (more than SBDART_AMD_MID_MB = 1 MB of work
+!     items) is REHEARSED in the child -- screening and band model without a STOP, exit code 78 -- and then made whole here
+!     as well: no file of work items is written and read back;
 !   * after SBDART_AMD_IDLE_S seconds (default 300) without a client the server leaves and removes its socket.
 subroutine run_server(sockpath)
   use iso_c_binding
@@ -1490,6 +1502,11 @@ subroutine run_server(sockpath)
   if (tstat == 0 .and. tlen > 0) then
     read(txt(1:tlen), *, iostat=ios) serve_big
     serve_big = serve_big*1.0d6
+  end if
+  call get_environment_variable('SBDART_AMD_MID_MB', txt, tlen, tstat)
+  if (tstat == 0 .and. tlen > 0) then
+    read(txt(1:tlen), *, iostat=ios) serve_mid
+    serve_mid = serve_mid*1.0d6
   end if
   call get_environment_variable('SBD_TIMING', txt, tlen, tstat)
   timing = tstat == 0 .and. tlen > 0
@@ -1586,14 +1603,14 @@ contains
     call system_clock(t1)
     t_first = t_first + real(t1 - t0, 8)/real(crate, 8)
     code = c1st
-    if (c1st == 77 .or. (c1st == 0 .and. sbd_px_exists(d//'/'//items_file//c_null_char) /= 0)) then
+    if (c1st == 77 .or. c1st == 78 .or. (c1st == 0 .and. sbd_px_exists(d//'/'//items_file//c_null_char) /= 0)) then
       if (sbd_px_chdir(d//c_null_char) /= 0) then
         code = 3; return
       end if
       flush(6); flush(0)
       keep1 = sbd_px_dup(1_c_int); keep2 = sbd_px_dup(2_c_int)
       if (sbd_px_dup2(fd1, 1_c_int) == 0 .and. sbd_px_dup2(fd2, 2_c_int) == 0) then
-        call run_once(merge(3, 2, c1st == 77))
+        call run_once(merge(3, 2, c1st == 77 .or. c1st == 78))
         flush(6); flush(0)
         code = 0
       else

@@ -170,13 +170,16 @@ def test_a_large_run_is_made_whole_in_the_server(tmp_path):
     _build()
     sock = str(tmp_path / "sock")
     d = _mkrun(str(tmp_path / "big"), "idatm=6 isat=0 wlinf=.25 wlsup=4.0 wlinc=.0005 nstr=16 iout=10")
+    # ... a run of middle size (751 wavelengths: 10 MB of work items) is REHEARSED in the forked child -- exit code 78 -- and
+    # made whole in the server too; a single wavelength goes through the file of work items
+    mid = _mkrun(str(tmp_path / "mid"), "idatm=6 isat=0 wlinf=.25 wlsup=4.0 wlinc=.005 nstr=16 iout=10")
     small = _mkrun(str(tmp_path / "small"), "idatm=4 wlinf=.55 wlsup=.55 iout=10 sza=30")
-    want = [subprocess.run([HOST], cwd=x, capture_output=True, text=True) for x in (d, small)]
+    want = [subprocess.run([HOST], cwd=x, capture_output=True, text=True) for x in (d, mid, small)]
     assert all(w.returncode == 0 for w in want)
-    srv = Server(sock, env={"SBDART_AMD_BIG_MB": "1"})
+    srv = Server(sock, env={"SBDART_AMD_BIG_MB": "20"})
     try:
         env = dict(os.environ, SBDART_AMD_SOCKET=sock, SBDART_AMD_NO_AUTOSTART="1")
-        for x, w in list(zip((d, small), want)) * 2:
+        for x, w in list(zip((d, mid, small), want)) * 2:
             p = subprocess.run([CLIENT], cwd=x, env=env, capture_output=True, text=True)
             assert p.returncode == 0 and p.stdout == w.stdout, (x, p.stderr[-500:])
         assert not os.path.exists(os.path.join(d, ".sbd_items"))
