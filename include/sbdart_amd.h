@@ -234,6 +234,34 @@ typedef struct {
     size_t tables_bytes;
 } sbd_gas_model;
 
+/* The scatterers' part of the band model for a run (ABI v7, round 6): Rayleigh depths, the cloud deck (Mie look-up) and the
+ * boundary-layer / stratospheric aerosols (rayleigh spectra.f:179-247; taucloud.f:10-140, 6726-6768; tauaero.f:1175-1359) --
+ * what the reference evaluates per wavelength to fill the operands sbd_mix_in::lay holds, evaluated on the device for all
+ * wavelengths of a run at once (sbd_fleet_point_terms): the layer blocks are BORN in HBM and never cross PCIe.  Covered: what
+ * the compact form covers (one cloud per layer from ZCLOUD / TCLOUD / LWP / NRE with IMOMC 1..3; IAER 1..5 with IMOMA 1..3;
+ * stratospheric layers JAER / TAERST); usrcld.dat, aerosol.dat, user moments and SPOWDER keep the host's blocks.  The same
+ * sequence of roundings as the reference (csrc/sbd_scat.hpp, pinned bit for bit on the host by sbd_scatter_blocks_host). */
+#define SBD_SCAT_SLOTS 5   /* ncldz = naerz = 5 (params.f:12) */
+typedef struct {
+    int32_t nz;                  /* levels = layers (drt.f:144)                                                          */
+    const double *z, *p, *t;     /* [nz] level altitude (km), pressure (mb), temperature (K), bottom-up (atms)           */
+    double xrsc;                 /* XRSC: multiplier of the Rayleigh depths (drt.f:470)                                  */
+    int32_t cloud_term;          /* 1: the run has a cloud deck -- it is the FIRST scattering term of every block        */
+    int32_t cld_nslot;           /* cloud slots in use; per slot: layer (1 = top; negative: "the cloud extends up to"),  */
+    int32_t cld_layer[SBD_SCAT_SLOTS];                     /* TCLOUD, LWP, NRE (taucloud.f:40-100)                        */
+    double cld_tcloud[SBD_SCAT_SLOTS], cld_lwp[SBD_SCAT_SLOTS], cld_nre[SBD_SCAT_SLOTS];
+    int32_t iaer, nosct;         /* IAER (0 none, else the boundary-layer spectrum below), NOSCT                         */
+    int32_t aer_nwl;             /* boundary-layer spectrum: wavelengths, extinction, absorption, asymmetry factor       */
+    const double *aer_wl, *aer_ext, *aer_absb, *aer_asym;   /* [aer_nwl] (tauaero.f:1240-1290)                            */
+    double abaer;                /* ABAER: Angstrom exponent outside the spectrum                                         */
+    const double *aer_column;    /* [nz] layers top-down: boundary-layer depth at 0.55 um / extinction(0.55)             */
+    int32_t nstrat;              /* stratospheric layers: model JAER, layer (1 = top), depth at 0.55 um TAERST           */
+    int32_t jaer[SBD_SCAT_SLOTS], strat_layer[SBD_SCAT_SLOTS];
+    double taerst[SBD_SCAT_SLOTS];
+    const void *tables;          /* image of sbdart_amd/data/sbdart_tables.bin (Mie and stratospheric tables)            */
+    size_t tables_bytes;
+} sbd_scat_model;
+
 /* ---- lifecycle ---- */
 int  sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out);
 void sbd_engine_destroy(sbd_engine *e);
@@ -301,6 +329,17 @@ int      sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_
  * dtaug_out, if not NULL: [npoint][3][nlyr] the terms' gas depths copied back (tests, IOUT-independent inspection). */
 int      sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, const double *wl, const double *lay,
                              int32_t nch, int32_t *nk, double *wt, int32_t *fail, double *dtaug_out, int64_t *lay_token);
+/* sbd_fleet_gas_terms with the layer blocks made ON THE DEVICES from the scatterers' model (sbd_scat_model above) instead
+ * of coming from the host: per point of `wl` the block [nch][nlyr] (nch = 4 + 3 x the model's terms: cloud, boundary-layer
+ * aerosol, one per active stratospheric layer -- sbd_mix_in's layout) is computed where the gas kernel and the solves read
+ * it.  Everything else as sbd_fleet_gas_terms; lay_out, if not NULL: [npoint][nch][nlyr] the blocks copied back (tests, and
+ * the host's report on an item CHEKIN refuses). */
+int      sbd_fleet_point_terms(sbd_fleet *f, const sbd_gas_model *g, const sbd_scat_model *sm, int32_t npoint, const double *wl,
+                               int32_t nch, int32_t *nk, double *wt, int32_t *fail, double *dtaug_out, double *lay_out,
+                               int64_t *lay_token);
+/* The scatterers' blocks on the HOST (no GPU; the same source, csrc/sbd_scat.hpp): bit-equal to the Fortran host's band model,
+ * hence to the reference's operands -- the pin of the device kernel's source.  lay_out [npoint][nch][nz]. */
+int      sbd_scatter_blocks_host(const sbd_scat_model *sm, int32_t npoint, const double *wl, int32_t nch, double *lay_out);
 /* The same arithmetic on the HOST (no GPU involved; the same source, sbd_gas.hpp): with the host's libm the results
  * are bit-equal to the Fortran host's band model, hence to the reference's -- the pin of the device kernel's source. */
 int      sbd_gas_terms_host(const sbd_gas_model *g, int32_t nlyr, int32_t npoint, const double *wl, const double *lay, int32_t nch,

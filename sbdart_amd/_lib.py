@@ -61,6 +61,18 @@ class GasModel(C.Structure):
                 ("tables", C.c_void_p), ("tables_bytes", C.c_size_t)]
 
 
+class ScatModel(C.Structure):
+    """sbd_scat_model: the scatterers' part of the band model for a run (Rayleigh, cloud deck, aerosols)."""
+    _fields_ = [("nz", C.c_int32), ("z", C.c_void_p), ("p", C.c_void_p), ("t", C.c_void_p), ("xrsc", C.c_double),
+                ("cloud_term", C.c_int32), ("cld_nslot", C.c_int32), ("cld_layer", C.c_int32 * 5),
+                ("cld_tcloud", C.c_double * 5), ("cld_lwp", C.c_double * 5), ("cld_nre", C.c_double * 5),
+                ("iaer", C.c_int32), ("nosct", C.c_int32), ("aer_nwl", C.c_int32),
+                ("aer_wl", C.c_void_p), ("aer_ext", C.c_void_p), ("aer_absb", C.c_void_p), ("aer_asym", C.c_void_p),
+                ("abaer", C.c_double), ("aer_column", C.c_void_p),
+                ("nstrat", C.c_int32), ("jaer", C.c_int32 * 5), ("strat_layer", C.c_int32 * 5), ("taerst", C.c_double * 5),
+                ("tables", C.c_void_p), ("tables_bytes", C.c_size_t)]
+
+
 GAS_SLOTS = 63
 TABLES_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "sbdart_tables.bin")
 
@@ -74,7 +86,7 @@ EXPORTS = (
     "sbd_last_error", "sbd_engine_debug_copy", "sbd_engine_debug_pivots",
     "sbd_fleet_create", "sbd_fleet_destroy", "sbd_fleet_size", "sbd_fleet_engine", "sbd_fleet_uses_rccl",
     "sbd_shard_range", "sbd_fleet_solve_host", "sbd_fleet_last_enqueue", "sbd_host_alloc", "sbd_host_free",
-    "sbd_surface_flux_albedo", "sbd_fleet_solve_mix_host", "sbd_engine_pass_count", "sbd_shard_range_points", "sbd_band_rcond_host", "sbd_fleet_gas_terms", "sbd_gas_terms_host",
+    "sbd_surface_flux_albedo", "sbd_fleet_solve_mix_host", "sbd_engine_pass_count", "sbd_shard_range_points", "sbd_band_rcond_host", "sbd_fleet_gas_terms", "sbd_gas_terms_host", "sbd_fleet_point_terms", "sbd_scatter_blocks_host",
 )
 
 _LIB = None
@@ -150,6 +162,11 @@ def load() -> C.CDLL:
     L.sbd_fleet_gas_terms.restype = C.c_int
     L.sbd_gas_terms_host.argtypes = [C.POINTER(GasModel), C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, vp, vp, vp]
     L.sbd_gas_terms_host.restype = C.c_int
+    L.sbd_fleet_point_terms.argtypes = [vp, C.POINTER(GasModel), C.POINTER(ScatModel), C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp,
+                                        C.POINTER(C.c_int64)]
+    L.sbd_fleet_point_terms.restype = C.c_int
+    L.sbd_scatter_blocks_host.argtypes = [C.POINTER(ScatModel), C.c_int32, vp, C.c_int32, vp]
+    L.sbd_scatter_blocks_host.restype = C.c_int
     L.sbd_band_rcond_host.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, vp, vp, vp, C.POINTER(C.c_double)]
     L.sbd_band_rcond_host.restype = C.c_int
     L.sbd_fleet_last_enqueue.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]

@@ -61,6 +61,7 @@ struct Params {
     // rcflag = 2), or a pivot ratio <= 1e-10 in the band LU -- are listed by the band kernels in rclist (count, then ms
     // indices; rcflag[ms] = 1: listed) for band_rcond_kernel at the end of the pass
     int32_t *rclist, *rcflag;
+    int32_t *rchint;         // host-visible word: the list's length as band_rcond_kernel last found it (this workspace)
     int32_t nslot;          // work items in this chunk
     int32_t sv_stride, svi_stride;
     int32_t cw, ncd;        // band: CW = 2*ncd+1 columns kept per U row, ncd = 3nn-1

@@ -35,6 +35,7 @@
 #include "sbd_layer2.hpp"   // Layer2Lds
 #include "sbd_surface.hpp"  // bidirectional surfaces: surfac_kernel, host-side check of the model
 #include "sbd_hosttables.hpp" // QGAUSN / LEPOLY on the host (also behind sbd_band_rcond_host)
+#include "sbd_scat_types.hpp" // the scatterers' kernel (sbd_k_scat.hip on sbd_scat.hpp)
 #include "sbd_gas_types.hpp" // the gas model's launch interface (its source, sbd_gas.hpp, is compiled without contraction in sbd_k_gas.hip)
 static_assert(sbd::SBD_NFLUX_ == SBD_NFLUX, "flux component count");
 
@@ -275,7 +276,8 @@ struct sbd_engine {
     int layer_lds = 0, band_lds = 0, solve_lds = 0, usr_lds = 0, layer2_lds = 0;
     bool solve_v1 = false;
     bool pivot_exact = false;       // sbd_run_cfg::pivot_exact / SBD_EXACT_PIVOT: ISAMAX's rule in band4_kernel
-    int32_t *h_hint = nullptr;      // [2] pinned, device-visible: length of the fallback list of the workspace's last pass (-1: not known yet)
+    int32_t *h_hint = nullptr;      // [4] pinned, device-visible: length of the fallback list of the workspace's last pass (-1: not known yet),
+                                    // then [2..3] the same for band_rcond_kernel's list
     int32_t *d_eigflag = nullptr;
     bool use_layer2 = true;
     bool band_reg = false;
@@ -644,7 +646,7 @@ int sbd_engine_create(const sbd_run_cfg *cfg, sbd_engine **out)
     t_mark("workspace");
     // the list-walking layer kernel tells the host how long it found the list (a word of pinned host memory per workspace,
     // written by the kernel itself: no copy command in the stream)
-    if (hipHostMalloc((void **)&e->h_hint, 2 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess) { e->h_hint[0] = -1; e->h_hint[1] = -1; }
+    if (hipHostMalloc((void **)&e->h_hint, 4 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess) { e->h_hint[0] = -1; e->h_hint[1] = -1; e->h_hint[2] = -1; e->h_hint[3] = -1; }
     else { (void)hipGetLastError(); e->h_hint = nullptr; }
     {
         char *p = e->d_ws;
@@ -1236,7 +1238,8 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             //  2 048 wait for room behind the other stream's kernels; should the list be long after all, they walk it, slower)
             if (flt && e->h_hint && !getenv("SBD_NO_HINT")) {
                 const int32_t hint = ((volatile int32_t *)e->h_hint)[second ? 1 : 0];
-                if (hint == 0 && grid > 64u) grid = 64u;
+                static const unsigned hint_grid = getenv("SBD_HINT_GRID") ? (unsigned)atoi(getenv("SBD_HINT_GRID")) : 8u;   // (A/B: 64 until round 6)
+                if (hint == 0 && grid > hint_grid) grid = hint_grid;
             }
             sbd::launch_layer_v1(e->G, grid, e->layer_lds, st, P, flt);
         }
@@ -1273,7 +1276,13 @@ static int solve_device_impl(sbd_engine *e, const sbd_batch_in *in, const sbd_ba
             hipLaunchKernelGGL(finish_kernel, dim3((ns + 255) / 256), dim3(256), 0, st, P);
         // errmsg 2: the systems this pass's layer / band kernels listed, on the reference's own band matrix and LINPACK's own
         // estimate (normally none: every block reads the count and leaves)
-        sbd::launch_band_rcond((unsigned)e->rc_blocks, st, P, e->d_rb + (second ? (size_t)e->rc_blocks * e->rb_stride : 0), e->rb_stride,
+        // (an empty list the last time this workspace ran -- the kernel's own report, h_hint[2..3] -- : two blocks instead of
+        //  up to 512 have to find a free slot behind the other stream's kernels; should the list be long after all they walk
+        //  it, slower, and the next pass knows)
+        unsigned rc_grid = (unsigned)e->rc_blocks;
+        if (e->h_hint && !getenv("SBD_NO_HINT") && ((volatile int32_t *)e->h_hint)[2 + (second ? 1 : 0)] == 0) rc_grid = getenv("SBD_HINT_GRID_RC") ? (unsigned)atoi(getenv("SBD_HINT_GRID_RC")) : 2u;
+        P.rchint = e->h_hint ? e->h_hint + 2 + (second ? 1 : 0) : nullptr;
+        sbd::launch_band_rcond(rc_grid, st, P, e->d_rb + (second ? (size_t)e->rc_blocks * e->rb_stride : 0), e->rb_stride,
                                e->d_rcdbg + (second ? (size_t)e->chunk * nmode : 0));
         if (hs) {   // this pass's outputs, staging -> host
             const size_t nf = (size_t)SBD_NFLUX * nlev, nu = rad ? (size_t)e->P.nphi * nlev * e->P.numu : 0;
@@ -1992,12 +2001,14 @@ int sbd_fleet_solve_mix_host(sbd_fleet *f, const sbd_mix_in *in, const sbd_batch
 
 // The gas part of the band model for the points of a run, on the fleet's devices (sbd_gas.hpp through sbd_k_gas.hip):
 // points sharded by sbd_shard_range, every device keeps its points' gas depths for the compact-form solves that follow.
-int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, const double *wl, const double *lay,
-                        int32_t nch, int32_t *nk, double *wt, int32_t *failed, double *dtaug_out, int64_t *lay_token)
+static int fleet_point_terms_impl(sbd_fleet *f, const sbd_gas_model *g, const sbd_scat_model *sm, int32_t npoint, const double *wl,
+                                  const double *lay, int32_t nch, int32_t *nk, double *wt, int32_t *failed, double *dtaug_out,
+                                  double *lay_out, int64_t *lay_token)
 {
     static std::atomic<int64_t> generation{0};
     if (lay_token) *lay_token = 0;
-    if (!f || f->eng.empty() || !g || !wl || !lay || !nk || !wt) return fail(SBD_E_INVALID, "null argument");
+    if (!f || f->eng.empty() || !g || !wl || (!lay && !sm) || !nk || !wt) return fail(SBD_E_INVALID, "null argument");
+    if (sm && (!sm->z || !sm->p || !sm->t || sm->nz != f->eng[0]->L)) return fail(SBD_E_INVALID, "scatter model: null profile, or nz differs from the fleet's NLYR");
     if (!g->uu || !g->z || !g->tables) return fail(SBD_E_INVALID, "gas model: null array");
     if (npoint <= 0) return npoint == 0 ? SBD_OK : fail(SBD_E_INVALID, "npoint < 0");
     sbd_engine *e0 = f->eng[0];
@@ -2033,12 +2044,14 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
         const size_t b_td = up(8 * pk.d.size()), b_ti = up(4 * pk.i.size()), b_uu = up(8 * (size_t)L * SBD_GAS_SLOTS), b_z = up(8 * (size_t)L);
         const size_t b_wl = up(8 * (size_t)np), b_lay = up(8 * (size_t)np * nch * L), b_ws = up(8 * (size_t)16 * L * npad);
         const size_t b_nk = up(4 * (size_t)np), b_wt = up(8 * (size_t)np * 3);
+        const size_t naw = (sm && sm->iaer != 0) ? (size_t)sm->aer_nwl : 0;
+        const size_t b_sm = sm ? up(8 * (4 * (size_t)L + 4 * naw)) : 0;      // z, p, t, column, the boundary-layer spectrum
         const bool timing = getenv("SBD_TIMING") != nullptr;
         const auto t_0 = std::chrono::steady_clock::now();
         auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count(); };
         double t_alloc = 0, t_h2d = 0, t_kernel = 0;
         char *tmp = nullptr;
-        if (bad(hipMalloc(&tmp, b_td + b_ti + b_uu + b_z + b_wl + b_ws + 2 * b_nk + b_wt), "hipMalloc(gas work area)")) return;
+        if (bad(hipMalloc(&tmp, b_td + b_ti + b_uu + b_z + b_wl + b_ws + 2 * b_nk + b_wt + b_sm), "hipMalloc(gas work area)")) return;
         if (bad(hipMalloc(&e->d_gas_slots, 8 * (size_t)np * 3 * L), "hipMalloc(gas depths)")) { (void)hipFree(tmp); return; }
         if (bad(hipMalloc(&e->d_gas_lay, b_lay), "hipMalloc(layer blocks)")) { (void)hipFree(tmp); (void)hipFree(e->d_gas_slots); e->d_gas_slots = nullptr; return; }
         char *q = tmp;
@@ -2049,6 +2062,7 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
         double *d_ws = (double *)take(b_ws);
         int32_t *d_nk = (int32_t *)take(b_nk), *d_fail = (int32_t *)take(b_nk);
         double *d_wt = (double *)take(b_wt);
+        double *d_sm = sm ? (double *)take(b_sm) : nullptr;
         hipStream_t st = e->stream;
         bool err = false;
         t_alloc = since();
@@ -2057,7 +2071,7 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
         err = err || bad(hipMemcpyAsync(d_uu, g->uu, 8 * (size_t)L * SBD_GAS_SLOTS, hipMemcpyHostToDevice, st), "H2D uu");
         err = err || bad(hipMemcpyAsync(d_z, g->z, 8 * (size_t)L, hipMemcpyHostToDevice, st), "H2D z");
         err = err || bad(hipMemcpyAsync(d_wl, wl + lo, 8 * (size_t)np, hipMemcpyHostToDevice, st), "H2D wl");
-        err = err || bad(hipMemcpyAsync(d_lay, lay + (size_t)lo * nch * L, 8 * (size_t)np * nch * L, hipMemcpyHostToDevice, st), "H2D lay");
+        if (!sm) err = err || bad(hipMemcpyAsync(d_lay, lay + (size_t)lo * nch * L, 8 * (size_t)np * nch * L, hipMemcpyHostToDevice, st), "H2D lay");
         err = err || bad(hipMemsetAsync(e->d_gas_slots, 0, 8 * (size_t)np * 3 * L, st), "memset");
         if (!err) {
             sbd::GasRun R;
@@ -2065,8 +2079,27 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
             if (!pk.view(d_td, d_ti, R.T, verr)) { rcs[r] = SBD_E_INVALID; errs[r] = "gas tables: " + verr; err = true; }
             R.uu = d_uu; R.z = d_z; R.nz = L; R.kdist = g->kdist;
             R.amu0_first = g->amu0_first; R.amu0_rest = g->amu0_rest; R.xo4 = g->xo4; R.re_earth = sbd::kReEarth;
+            if (sm && !err) {
+                // the layer blocks are MADE here (scatter_kernel on sbd_scat.hpp): the model's small arrays go over, the
+                // blocks are born where the gas kernel and the solves read them
+                sbd_scat_model dsm = *sm;
+                double *q2 = d_sm;
+                auto put = [&](const double *src, size_t cnt) -> const double * {
+                    double *dst = q2;
+                    q2 += cnt;
+                    if (cnt) err = err || bad(hipMemcpyAsync(dst, src, 8 * cnt, hipMemcpyHostToDevice, st), "H2D scatter model");
+                    return dst;
+                };
+                dsm.z = put(sm->z, L); dsm.p = put(sm->p, L); dsm.t = put(sm->t, L);
+                dsm.aer_column = (sm->iaer != 0) ? put(sm->aer_column, L) : nullptr;
+                if (naw) { dsm.aer_wl = put(sm->aer_wl, naw); dsm.aer_ext = put(sm->aer_ext, naw); dsm.aer_absb = put(sm->aer_absb, naw); dsm.aer_asym = put(sm->aer_asym, naw); }
+                std::string serr;
+                if (!err && !sbd::launch_scatter_abi(st, &dsm, pk, d_td, np, d_wl, d_lay, nch, serr)) { rcs[r] = SBD_E_INVALID; errs[r] = serr; err = true; }
+                err = err || bad(hipGetLastError(), "scatter_kernel");
+                if (lay_out && !err) err = err || bad(hipMemcpyAsync(lay_out + (size_t)lo * nch * L, d_lay, 8 * (size_t)np * nch * L, hipMemcpyDeviceToHost, st), "D2H layer blocks");
+            }
             if (timing) { (void)hipStreamSynchronize(st); t_h2d = since(); }
-            sbd::launch_gas(st, R, np, lo == 0 ? 1 : 0, d_wl, d_lay, nch, d_ws, npad, d_nk, d_wt, d_fail, e->d_gas_slots);
+            if (!err) sbd::launch_gas(st, R, np, lo == 0 ? 1 : 0, d_wl, d_lay, nch, d_ws, npad, d_nk, d_wt, d_fail, e->d_gas_slots);
             err = err || bad(hipGetLastError(), "gas_kernel");
             if (timing) { (void)hipStreamSynchronize(st); t_kernel = since(); }
             err = err || bad(hipMemcpyAsync(nk + lo, d_nk, 4 * (size_t)np, hipMemcpyDeviceToHost, st), "D2H nk");
@@ -2098,6 +2131,20 @@ int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, co
     for (int r = 0; r < nd; ++r) f->eng[r]->gas_token = token;
     if (lay_token) *lay_token = token;
     return SBD_OK;
+}
+
+int sbd_fleet_gas_terms(sbd_fleet *f, const sbd_gas_model *g, int32_t npoint, const double *wl, const double *lay,
+                        int32_t nch, int32_t *nk, double *wt, int32_t *failed, double *dtaug_out, int64_t *lay_token)
+{
+    if (!lay) return fail(SBD_E_INVALID, "null argument");
+    return fleet_point_terms_impl(f, g, nullptr, npoint, wl, lay, nch, nk, wt, failed, dtaug_out, nullptr, lay_token);
+}
+
+int sbd_fleet_point_terms(sbd_fleet *f, const sbd_gas_model *g, const sbd_scat_model *sm, int32_t npoint, const double *wl,
+                          int32_t nch, int32_t *nk, double *wt, int32_t *failed, double *dtaug_out, double *lay_out, int64_t *lay_token)
+{
+    if (!sm) return fail(SBD_E_INVALID, "null scatter model");
+    return fleet_point_terms_impl(f, g, sm, npoint, wl, nullptr, nch, nk, wt, failed, dtaug_out, lay_out, lay_token);
 }
 
 // host clock around device i's enqueue in the last sbd_fleet_solve_host (seconds since that call began), and how

@@ -266,12 +266,13 @@ SBD_DEVICE double sgbco(double *abd, int lda, int n, int ml, int mu, int32_t *ip
 // grid: any number of single-wave blocks; block b serves list entries b, b + gridDim.x, ...  scratch: per block
 // refband::SystemScratch(n, L).total + 64 * refband::layer_work_doubles(n) doubles.
 // rcond_dbg (tests; may be NULL): [nslot * nmode] the estimate of every system served (untouched otherwise).
-__global__ void __launch_bounds__(64) band_rcond_kernel(Params P, double *scratch, size_t stride, double *rcond_dbg, int serial)
+__global__ void __launch_bounds__(64, 4) band_rcond_kernel(Params P, double *scratch, size_t stride, double *rcond_dbg, int serial)
 {
     extern __shared__ __attribute__((aligned(16))) double zlds[];      // SGBCO's z of the wave form: n NLYR doubles
     const int lane = threadIdx.x;
     const int L = P.L, n = P.n, nmode = P.nmode, nmom = P.nmom;
     const int count = P.rclist[0];
+    if (P.rchint && blockIdx.x == 0 && lane == 0) *P.rchint = count;     // (the host sizes the next pass's grid by it)
     const refband::SystemScratch o(n, L);
     const size_t lw = refband::layer_work_doubles(n);
     double *s = scratch + (size_t)blockIdx.x * stride;

@@ -368,6 +368,27 @@ class DisortFleet(DisortEngine):
         self.lay_token = int(token.value)
         return nk, wt, fail, depths
 
+    def point_terms(self, gas_model, scat_model, wl, nch, want_depths=False, want_blocks=False):
+        """gas_terms with the layer blocks MADE on the devices from the scatterers' model (sbd_fleet_point_terms; scat_model a
+        _lib.ScatModel, nch = 4 + 3 x its terms).  Returns (nk, wt, fail, depths or None, blocks [npoint][nch][nlyr] or None);
+        `self.lay_token` names the blocks for solve_mix(lay=None, lay_token=...)."""
+        wl = _f64(wl)
+        npt = wl.shape[0]
+        nk = np.zeros(npt, dtype=np.int32)
+        wt = np.zeros((npt, 3))
+        fail = np.zeros(npt, dtype=np.int32)
+        depths = np.zeros((npt, 3, self.nlyr)) if want_depths else None
+        blocks = np.zeros((npt, int(nch), self.nlyr)) if want_blocks else None
+        vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+        token = C.c_int64(0)
+        self.lay_token = 0
+        rc = self._L.sbd_fleet_point_terms(self._h, C.byref(gas_model), C.byref(scat_model), npt, vp(wl), int(nch), vp(nk), vp(wt),
+                                           vp(fail), vp(depths), vp(blocks), C.byref(token))
+        if rc != _lib.OK:
+            raise SbdError(rc, "sbd_fleet_point_terms")
+        self.lay_token = int(token.value)
+        return nk, wt, fail, depths, blocks
+
     def solve_mix(self, point_of, dtaug, lay, family, wvnmlo, wvnmhi, fbeam, albedo, plank, weight=None, items=True, kterm=None,
                   lay_token=0):
         """A batch in COMPACT form (sbd_mix_in, include/sbdart_amd.h): per spectral point a block lay[point] of
@@ -380,11 +401,16 @@ class DisortFleet(DisortEngine):
         W = rows.shape[0]
         dtaug = None if dtaug is None else _f64(dtaug)          # (None: the depths gas_terms left on the devices, by kterm)
         kt = None if kterm is None else np.ascontiguousarray(kterm, dtype=np.int32)
-        lay = _f64(lay)
         family = [int(x) for x in family]
         nterm = len(family)
-        NP = lay.shape[0]
-        assert (dtaug is None or dtaug.shape == (W, self.nlyr)) and lay.shape == (NP, 4 + 3 * nterm, self.nlyr) and nterm <= MIX_MAX_TERMS
+        if lay is None:                                         # (the blocks point_terms made on the devices: lay_token)
+            assert lay_token != 0
+            NP = int(np.shape(wvnmlo)[0])
+        else:
+            lay = _f64(lay)
+            NP = lay.shape[0]
+            assert lay.shape == (NP, 4 + 3 * nterm, self.nlyr)
+        assert (dtaug is None or dtaug.shape == (W, self.nlyr)) and nterm <= MIX_MAX_TERMS
         lo, hi, fb, al = (_f64(np.broadcast_to(x, (NP,))) for x in (wvnmlo, wvnmhi, fbeam, albedo))
         pl = np.ascontiguousarray(np.broadcast_to(plank, (NP,)), dtype=np.uint8)
         flux = np.zeros((W, _lib.NFLUX, self.nlev)) if items else None

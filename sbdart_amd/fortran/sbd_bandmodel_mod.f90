@@ -57,6 +57,17 @@ module sbd_bandmodel_mod
     real(kr) :: amu_gas(2) = 0, xo4 = 1                   ! cosine for the gas terms of the first / the later wavelengths
     real(kr), allocatable :: uu(:, :), z(:)               ! (63, nz) absorber amounts, (nz) altitudes, bottom-up
     real(kr), allocatable :: wl(:)                        ! (npoint)
+    ! the scatterers' part on the device as well (include/sbdart_amd.h, sbd_scat_model; sbd_fleet_point_terms): the layer
+    ! blocks are then made where the engine reads them and `lay` holds no point (npoint, nch say what it would hold)
+    logical :: scat_on_device = .false.                   ! in: the caller wants that (only with gas_on_device)
+    logical :: scat_ok = .false.                          ! out: the model below is the run's (sbd_scat.hpp covers the run)
+    logical :: scat_dev = .false.                         ! out: ... and the blocks are left to the devices
+    integer :: npoint = 0, nch = 0
+    type(atmosphere) :: atm                               ! levels bottom-up (Rayleigh)
+    type(cloud_deck) :: deck
+    type(aerosol_load) :: load
+    real(kr) :: xrsc = 1
+    integer :: ncloud_term = 0
   end type
 
 contains
@@ -345,7 +356,7 @@ contains
     real(kr), parameter :: dtor = 3.1415926536_kr/180.
     integer :: nz, nmom, iwl, kd, i
     integer :: nthreads, mkt
-    logical :: from_ck, compact, aer_ok, gas_dev
+    logical :: from_ck, compact, aer_ok, gas_dev, scat_dev
     integer :: ncloud_term, naer_term, aer_family(mix_max_terms), nch
     integer(kind=8) :: tk(4), tkrate
     character(len=8) :: tenv
@@ -428,9 +439,10 @@ contains
     end if
 
     ! ---- does the run fit the compact form?  (every scatterer one term GETMOM(family, g) x two factors) ----
-    compact = .false.; gas_dev = .false.
+    compact = .false.; gas_dev = .false.; scat_dev = .false.
     if (present(mixb)) then
       if (.not. mixb%want) mixb%gas_on_device = .false.
+      mixb%scat_dev = .false.
     end if
     ncloud_term = 0; naer_term = 0; nch = 4
     call aerosol_terms(load, naer_term, aer_family, aer_ok)      ! (also sizes the term recorder of every wavelength)
@@ -460,11 +472,19 @@ contains
           if (ncloud_term == 1) mixb%family(1) = m%imomc
           mixb%family(ncloud_term + 1:ncloud_term + naer_term) = aer_family(1:naer_term)
           nch = 4 + 3*mixb%nterm
-          if (allocated(mixb%lay)) deallocate(mixb%lay)
-          allocate(mixb%lay(nz, nch, grid%n))
           mixb%gas_ok = .not. from_ck
           gas_dev = mixb%gas_ok .and. mixb%gas_on_device
           mixb%gas_on_device = gas_dev
+          ! the scatterers on the device too: what sbd_scat.hpp covers -- a cloud deck (not usrcld.dat), IAER 1..5
+          mixb%scat_ok = .not. lcloud%given .and. load%iaer /= -1
+          if (mixb%scat_ok) then
+            mixb%atm = atm; mixb%deck = deck; mixb%load = load; mixb%xrsc = m%xrsc; mixb%ncloud_term = ncloud_term
+          end if
+          scat_dev = gas_dev .and. mixb%scat_on_device .and. mixb%scat_ok
+          mixb%scat_dev = scat_dev
+          mixb%npoint = grid%n; mixb%nch = nch
+          if (allocated(mixb%lay)) deallocate(mixb%lay)
+          allocate(mixb%lay(nz, nch, merge(0, grid%n, scat_dev)))
           if (mixb%gas_ok) then
             mixb%kdist = m%kdist; mixb%xo4 = mix%xo4
             mixb%amu_gas = amu0
@@ -602,6 +622,13 @@ contains
         !$omp end critical (sbd_surface_warning)
       else
         rsfc = max(0._kr, min(surface_albedo(wlalb, alb, wl), 1._kr))
+      end if
+      if (scat_dev) then                                         ! (the engine makes the layer blocks: sbd_fleet_point_terms)
+        if (mixb%gas_ok) mixb%wl(iw) = wl
+        nk_of(iw) = nk
+        swl(iw) = wl; slo(iw) = wvlo; shi(iw) = wvhi; sfb(iw) = flxin; salb(iw) = rsfc; splank(iw) = plank
+        swt(1, iw) = 1.
+        return
       end if
       call rayleigh_depths(wl, atm, dtaur)
       if (m%xrsc /= 1._kr) dtaur = m%xrsc*dtaur

@@ -6,7 +6,8 @@ module sbd_engine_mod
   use iso_c_binding
   implicit none
   private
-  public :: sbd_run_cfg, sbd_batch_in, sbd_batch_out, sbd_mix_in, sbd_gas_model, sbd_fleet_gas_terms
+  public :: sbd_run_cfg, sbd_batch_in, sbd_batch_out, sbd_mix_in, sbd_gas_model, sbd_fleet_gas_terms, &
+            sbd_scat_model, sbd_fleet_point_terms, sbd_scatter_blocks_host
   public :: sbd_engine_create, sbd_engine_destroy, sbd_engine_solve_host, &
             sbd_engine_solve_device, sbd_engine_accumulate_host, sbd_engine_nlevel, &
             sbd_engine_chunk, sbd_strerror_f, sbd_last_error_f, sbd_abi_version
@@ -64,6 +65,23 @@ module sbd_engine_mod
     type(c_ptr) :: uu, z                 ! (63, nz) absorber amounts, (nz) altitudes, levels bottom-up
     real(c_double) :: amu0_first, amu0_rest, xo4
     type(c_ptr) :: tables                ! image of sbdart_tables.bin
+    integer(c_size_t) :: tables_bytes
+  end type
+
+  ! the scatterers' part of the band model for a run (include/sbdart_amd.h): the layer blocks made on the devices
+  type, bind(C) :: sbd_scat_model
+    integer(c_int32_t) :: nz
+    type(c_ptr) :: z, p, t               ! (nz) levels bottom-up
+    real(c_double) :: xrsc
+    integer(c_int32_t) :: cloud_term, cld_nslot, cld_layer(5)
+    real(c_double) :: cld_tcloud(5), cld_lwp(5), cld_nre(5)
+    integer(c_int32_t) :: iaer, nosct, aer_nwl
+    type(c_ptr) :: aer_wl, aer_ext, aer_absb, aer_asym
+    real(c_double) :: abaer
+    type(c_ptr) :: aer_column            ! (nz) layers top-down
+    integer(c_int32_t) :: nstrat, jaer(5), strat_layer(5)
+    real(c_double) :: taerst(5)
+    type(c_ptr) :: tables
     integer(c_size_t) :: tables_bytes
   end type
 
@@ -149,6 +167,23 @@ module sbd_engine_mod
       type(c_ptr), value :: fleet, wl, lay, nk, wt, failed, dtaug_out
       integer(c_int64_t), intent(out) :: lay_token
       type(sbd_gas_model), intent(in) :: gas
+      integer(c_int32_t), value :: npoint, nch
+      integer(c_int) :: rc
+    end function
+    function sbd_fleet_point_terms(fleet, gas, scat, npoint, wl, nch, nk, wt, failed, dtaug_out, lay_out, lay_token) &
+         bind(C, name='sbd_fleet_point_terms') result(rc)
+      import
+      type(c_ptr), value :: fleet, wl, nk, wt, failed, dtaug_out, lay_out
+      integer(c_int64_t), intent(out) :: lay_token
+      type(sbd_gas_model), intent(in) :: gas
+      type(sbd_scat_model), intent(in) :: scat
+      integer(c_int32_t), value :: npoint, nch
+      integer(c_int) :: rc
+    end function
+    function sbd_scatter_blocks_host(scat, npoint, wl, nch, lay_out) bind(C, name='sbd_scatter_blocks_host') result(rc)
+      import
+      type(sbd_scat_model), intent(in) :: scat
+      type(c_ptr), value :: wl, lay_out
       integer(c_int32_t), value :: npoint, nch
       integer(c_int) :: rc
     end function

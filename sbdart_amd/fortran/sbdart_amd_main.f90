@@ -125,7 +125,7 @@ subroutine run_once(phase)
   character(len=256) :: why
   type(ck_file) :: ck                                  ! KDIST = -1: the k-distribution file pair
   type(mix_batch), target :: mix                       ! the run's batch in compact form (sbd_mix_in), when it fits
-  logical :: use_mix, gas_dev, items_wanted
+  logical :: use_mix, gas_dev, scat_dev, items_wanted
   real(kr), allocatable :: one_dtau(:), one_ssalb(:), one_pmom(:, :)
   ! the gas terms on the device (sbd_fleet_gas_terms): per spectral point the number of k-terms, their weights, TAUCOR's
   ! verdict; per work item its k-term; the fleet whose devices hold the depths
@@ -271,6 +271,10 @@ subroutine run_once(phase)
     if (pstat == 0 .and. plen > 0) mix%gas_on_device = mix%want
     call get_environment_variable('SBD_HOST_GAS', path, plen, pstat)
     if (pstat == 0 .and. plen > 0) mix%gas_on_device = .false.
+    ! ... and with them the scatterers' part (sbd_fleet_point_terms: Rayleigh, the cloud deck, the aerosols -- the layer
+    ! blocks are made on the devices and never exist on the host).  SBD_HOST_SCAT=1 keeps that part on the host.
+    call get_environment_variable('SBD_HOST_SCAT', path, plen, pstat)
+    mix%scat_on_device = mix%gas_on_device .and. .not. (pstat == 0 .and. plen > 0)
     if (kdist == -1) then
       call build_work_items(model, grid, umu(1:numu), phiv(1:merge(view%nphi, 0, radcalc)), recs, nrec, atm, &
                             bdtauc, bssalb, bpmom, btemper, ck, mix)
@@ -280,6 +284,7 @@ subroutine run_once(phase)
     end if
     use_mix = mix%ok
     gas_dev = use_mix .and. mix%gas_on_device
+    scat_dev = gas_dev .and. mix%scat_dev
     ! SBD_DUMP_MIX=file: the run's batch in compact form, for inspection / tests (stream: int32 nz, channels, points,
     ! terms, family(6), items; then lay, the items' gas depths and their points, 0-based) -- and stop before the engine
     call get_environment_variable('SBD_DUMP_MIX', path, plen, pstat)
@@ -296,6 +301,17 @@ subroutine run_once(phase)
         if (mix%gas_ok) then
           write(u11) int(mix%kdist, 4), mix%amu_gas, mix%xo4, mix%uu, mix%z, mix%wl
           write(u11) (int(recs(i)%kd, 4), int(recs(i)%nk, 4), recs(i)%wt, i = 1, nrec)
+        end if
+        ! ... and the run's scatterers as sbd_scat_model takes them (tests of sbd_scat.hpp: `lay` above is what they give)
+        write(u11) merge(1_4, 0_4, mix%scat_ok)
+        if (mix%scat_ok) then
+          write(u11) mix%atm%z, mix%atm%p, mix%atm%t, mix%xrsc
+          write(u11) int(mix%ncloud_term, 4), int(mix%deck%nslot, 4), int(mix%deck%layer, 4), mix%deck%tcloud, &
+                     mix%deck%lwp, mix%deck%nre
+          write(u11) int(mix%load%iaer, 4), int(mix%load%nosct, 4), int(mix%load%nwl, 4), mix%load%abaer
+          if (mix%load%iaer /= 0) write(u11) mix%load%wl(1:mix%load%nwl), mix%load%ext(1:mix%load%nwl), &
+                                             mix%load%absb(1:mix%load%nwl), mix%load%asym(1:mix%load%nwl), mix%load%column(1:atm%nz)
+          write(u11) int(mix%load%nstrat, 4), int(mix%load%jaer, 4), int(mix%load%strat_layer, 4), mix%load%taerst
         end if
       else
         write(u11) 0_4, 0_4, 0_4, 0_4, (0_4, i = 1, 6), 0_4
@@ -612,7 +628,11 @@ subroutine run_once(phase)
   if (radcalc .and. nbeam > 0 .and. (.not. corint .or. nbeam > ncorr)) then
     do ip = merge(ncorr + 1, 1, corint), nbeam
       if (use_mix) then                                  ! (SSALB = tsc / DTAUC where DTAUC > tiny: positive iff tsc is)
-        known = any(mix%lay(:, 4, int(pmom_row(ip)) + 1) > tiny(1._kr))
+        if (scat_dev .and. size(mix%lay, 3) == 0) then   ! (the blocks are on the devices: this point's, from the same source)
+          known = any(host_block_of(int(pmom_row(ip)) + 1) > tiny(1._kr))
+        else
+          known = any(mix%lay(:, 4, int(pmom_row(ip)) + 1) > tiny(1._kr))
+        end if
       else
         known = sum(ssalb(:, ip)) > 0._kr
       end if
@@ -694,14 +714,15 @@ subroutine run_once(phase)
     end do
     call write_run_record(sums, fmt, sensor%wlmin, sensor%wlmax, zlev, plev, view%phi, view%uzen)   ! (wl1, wl2 of setfilt)
   end if
-  ! SBD_TIMING: the run's account in one line (seconds inside the process, counted from the program's first statement):
+  ! SBD_TIMING: the run's account in one line (seconds inside the process, counted from the program's first statement;
+  ! compact = 1 compact form, 2 with the gas terms on the device, 3 with the layer blocks made there as well):
   ! setup = namelist, screening, tables, grid; band_model; assembly = batch arrays; engine = fleet create (of which
   ! engine_create) + H2D + kernels + D2H / reduce; output = warnings and writers; total = first statement -> here
   call get_environment_variable('SBD_TIMING', path, plen, pstat)
   if (pstat == 0 .and. plen > 0 .and. phase == 0 .and. from_model .and. tick_program >= 0) then
     flush(6)
     call system_clock(tick_out)
-    write(0, '(a,i0,a,i0,a,i0,8(a,f0.4))') 'sbdart_amd: timing nwl=', grid%n, ' items=', npart, ' compact=', merge(1, 0, use_mix) + merge(1, 0, gas_dev), &
+    write(0, '(a,i0,a,i0,a,i0,8(a,f0.4))') 'sbdart_amd: timing nwl=', grid%n, ' items=', npart, ' compact=', merge(1, 0, use_mix) + merge(1, 0, gas_dev) + merge(1, 0, scat_dev), &
       ' setup=', real(tick_bm0 - tick_program, 8)/real(tick_rate, 8), ' band_model=', real(tick_bm1 - tick_bm0, 8)/real(tick_rate, 8), &
       ' assembly=', real(tick1 - tick0, 8)/real(tick_rate, 8) + real(tick0 - tick_bm1, 8)/real(tick_rate, 8), &
       ' gas_device=', t_gas, ' engine=', real(tick2 - tick1, 8)/real(tick_rate, 8), ' engine_create=', t_create, &
@@ -1078,8 +1099,9 @@ contains
     type(sbd_gas_model) :: gm
     integer(c_int) :: rcg
     integer :: np
-    type(c_ptr) :: dptr
-    np = size(mix%lay, 3)
+    type(c_ptr) :: dptr, lptr
+    type(sbd_scat_model) :: sm
+    np = mix%npoint
     if (.not. allocated(gas_nk)) allocate(gas_nk(np), gas_fail(np), gas_wt(3, np))
     gm%nz = int(nz, c_int32_t); gm%kdist = int(mix%kdist, c_int32_t)
     gm%uu = c_loc(mix%uu); gm%z = c_loc(mix%z)
@@ -1090,10 +1112,62 @@ contains
       if (.not. allocated(gas_depths)) allocate(gas_depths(nz, 3, np))
       dptr = c_loc(gas_depths)
     end if
-    rcg = sbd_fleet_gas_terms(fl, gm, int(np, c_int32_t), c_loc(mix%wl), c_loc(mix%lay), int(size(mix%lay, 2), c_int32_t), &
+    if (scat_dev) then                                   ! the layer blocks are made on the devices too
+      call scat_model_of(sm)
+      lptr = c_null_ptr
+      if (with_depths) then                              ! (CHEKIN's report on a refused item needs its block)
+        deallocate(mix%lay)
+        allocate(mix%lay(nz, mix%nch, np))
+        lptr = c_loc(mix%lay)
+      end if
+      rcg = sbd_fleet_point_terms(fl, gm, sm, int(np, c_int32_t), c_loc(mix%wl), int(mix%nch, c_int32_t), &
+                                  c_loc(gas_nk), c_loc(gas_wt), c_loc(gas_fail), dptr, lptr, gas_lay_token)
+      if (rcg /= SBD_OK) call quit('sbd_fleet_point_terms: '//sbd_strerror_f(rcg)//' '//sbd_last_error_f())
+      return
+    end if
+    rcg = sbd_fleet_gas_terms(fl, gm, int(np, c_int32_t), c_loc(mix%wl), c_loc(mix%lay), int(mix%nch, c_int32_t), &
                               c_loc(gas_nk), c_loc(gas_wt), c_loc(gas_fail), dptr, gas_lay_token)
     if (rcg /= SBD_OK) call quit('sbd_fleet_gas_terms: '//sbd_strerror_f(rcg)//' '//sbd_last_error_f())
   end subroutine
+
+  ! the run's scatterers as the C ABI's model (pointers into `mix`, which outlives every call)
+  subroutine scat_model_of(sm)
+    type(sbd_scat_model), intent(out) :: sm
+    sm%nz = int(nz, c_int32_t)
+    sm%z = c_loc(mix%atm%z); sm%p = c_loc(mix%atm%p); sm%t = c_loc(mix%atm%t)
+    sm%xrsc = mix%xrsc
+    sm%cloud_term = int(mix%ncloud_term, c_int32_t)
+    sm%cld_nslot = int(mix%deck%nslot, c_int32_t); sm%cld_layer = int(mix%deck%layer, c_int32_t)
+    sm%cld_tcloud = mix%deck%tcloud; sm%cld_lwp = mix%deck%lwp; sm%cld_nre = mix%deck%nre
+    sm%iaer = int(mix%load%iaer, c_int32_t); sm%nosct = int(mix%load%nosct, c_int32_t)
+    sm%aer_nwl = int(mix%load%nwl, c_int32_t)
+    sm%aer_wl = c_null_ptr; sm%aer_ext = c_null_ptr; sm%aer_absb = c_null_ptr; sm%aer_asym = c_null_ptr
+    sm%aer_column = c_null_ptr
+    if (mix%load%iaer /= 0) then
+      sm%aer_wl = c_loc(mix%load%wl); sm%aer_ext = c_loc(mix%load%ext); sm%aer_absb = c_loc(mix%load%absb)
+      sm%aer_asym = c_loc(mix%load%asym); sm%aer_column = c_loc(mix%load%column)
+    end if
+    sm%abaer = mix%load%abaer
+    sm%nstrat = int(mix%load%nstrat, c_int32_t); sm%jaer = int(mix%load%jaer, c_int32_t)
+    sm%strat_layer = int(mix%load%strat_layer, c_int32_t); sm%taerst = mix%load%taerst
+    sm%tables = c_loc(tables_image); sm%tables_bytes = int(size(tables_image), c_size_t)
+  end subroutine
+
+  ! one point's scattering depths (channel 4 of its block) on the host, from the source the devices run
+  function host_block_of(ipt) result(sc)
+    integer, intent(in) :: ipt
+    real(kr) :: sc(nz)
+    real(kr), allocatable, target :: blk(:, :)
+    real(kr), target :: w1(1)
+    type(sbd_scat_model) :: sm
+    integer(c_int) :: rcb
+    allocate(blk(nz, mix%nch))
+    call scat_model_of(sm)
+    w1(1) = mix%wl(ipt)
+    rcb = sbd_scatter_blocks_host(sm, 1_c_int32_t, c_loc(w1), int(mix%nch, c_int32_t), c_loc(blk))
+    if (rcb /= SBD_OK) call quit('sbd_scatter_blocks_host: '//sbd_strerror_f(rcb))
+    sc = blk(:, 4)
+  end function
 
   ! solve batch positions p0..p1 on the run's GPUs; per-run formats also get their weighted sums
   subroutine solve_part(p0, p1, beam, corrections)
@@ -1140,7 +1214,7 @@ contains
       ! compact form: the part's items with the gas of their k-term, the spectral points' blocks by their index in the
       ! run (the engine stages the blocks the part's items refer to); per point the band edges, the incident flux, the
       ! albedo and the thermal switch (the same for the k-terms of a point)
-      mxin%nwork = p1 - p0 + 1; mxin%npoint = int(size(mix%lay, 3), c_int32_t)
+      mxin%nwork = p1 - p0 + 1; mxin%npoint = int(mix%npoint, c_int32_t)
       mxin%point_of = c_loc(pmom_row(p0))
       if (gas_dev) then                                  ! the depths are on the devices of gas_fleet: by (point, k-term)
         if (.not. c_associated(fleet, gas_fleet)) then   ! (another stream count after an NSTR retry: other engines)
@@ -1155,7 +1229,8 @@ contains
       end if
       mxin%nterm = mix%nterm; mxin%family = 0
       mxin%family(1:mix%nterm) = mix%family(1:mix%nterm)
-      mxin%lay = c_loc(mix%lay)
+      mxin%lay = c_null_ptr                              ! (made on the devices: lay_token names them)
+      if (size(mix%lay, 3) > 0) mxin%lay = c_loc(mix%lay)
       mxin%wvnmlo = c_loc(pt_lo); mxin%wvnmhi = c_loc(pt_hi); mxin%fbeam = c_loc(pt_fb); mxin%albedo = c_loc(pt_al)
       mxin%plank = c_loc(pt_pl)
       rc = sbd_fleet_solve_mix_host(fleet, mxin, bout, wptr, aptr, uptr)
