@@ -8,10 +8,16 @@ module sbd_io_mod
   public :: optics_t, read_optics, write_optics, read_atmosphere, write_atmosphere, warn_file, warn_reset, fatal
   logical, save :: issued(0:20) = .false.              ! warning numbers written by this run (errmsg writes each once)
 
+  ! the layer arrays of a work item read from an optics FILE (SBD_OPTICS); the band model's items keep theirs in its batch
+  ! arrays, and their records carry ONE unallocated component instead of six array descriptors (75 001 records of the
+  ! six-descriptor type cost the band model 7 of its 10.5 ms, round 6)
+  type optics_arrays
+    real(kr), allocatable :: dtauc(:), ssalb(:), temper(:), pmom(:,:), umu(:), phi(:)
+  end type
   type optics_t      ! one (wavelength, k-term) work item as handed to DISORT (drt.f:541-546)
     integer :: nlyr, nstr, nmom, numu, nphi, flags, kd, nk, iwl
     real(kr) :: wl, wt, ff, wvnmlo, wvnmhi, fbeam, umu0, phi0, albedo, btemp, ttemp, temis, fisot
-    real(kr), allocatable :: dtauc(:), ssalb(:), temper(:), pmom(:,:), umu(:), phi(:)
+    type(optics_arrays), allocatable :: a
     ! bidirectional surface (LAMBER flag off): model 1 ocean, 2 Hapke, 3 Ross-Li, its run parameters, and the
     ! ocean's per-wavelength constants nr, ni, rsw (records.py: the block behind PHI when hdr(11) /= 0)
     integer :: ibdrf = 0
@@ -58,10 +64,11 @@ contains
       r%wl = sc(1); r%wt = sc(2); r%ff = sc(3); r%wvnmlo = sc(4); r%wvnmhi = sc(5); r%fbeam = sc(6)
       r%umu0 = sc(7); r%phi0 = sc(8); r%albedo = sc(9); r%btemp = sc(10); r%ttemp = sc(11)
       r%temis = sc(12); r%fisot = sc(13)
-      if (allocated(r%dtauc)) deallocate(r%dtauc, r%ssalb, r%temper, r%pmom, r%umu, r%phi)
-      allocate(r%dtauc(r%nlyr), r%ssalb(r%nlyr), r%temper(0:r%nlyr), r%pmom(0:r%nmom, r%nlyr), &
-               r%umu(r%numu), r%phi(r%nphi))
-      read(u) r%dtauc, r%ssalb, r%temper, r%pmom, r%umu, r%phi
+      if (allocated(r%a)) deallocate(r%a)
+      allocate(r%a)
+      allocate(r%a%dtauc(r%nlyr), r%a%ssalb(r%nlyr), r%a%temper(0:r%nlyr), r%a%pmom(0:r%nmom, r%nlyr), &
+               r%a%umu(r%numu), r%a%phi(r%nphi))
+      read(u) r%a%dtauc, r%a%ssalb, r%a%temper, r%a%pmom, r%a%umu, r%a%phi
       r%ibdrf = hdr(11); r%bpar = 0; r%bitem = 0
       r%ib = 1; r%nb = 1
       if (hdr(12) /= 0) then
@@ -114,7 +121,7 @@ contains
       if (present(bdtauc)) then
         write(u) bdtauc(:, i), bssalb(:, i), btemper, bpmom(:recs(i)%nmom + lbound(bpmom, 1), :, recs(i)%iwl), umu, phi
       else
-        write(u) recs(i)%dtauc, recs(i)%ssalb, recs(i)%temper, recs(i)%pmom, recs(i)%umu, recs(i)%phi
+        write(u) recs(i)%a%dtauc, recs(i)%a%ssalb, recs(i)%a%temper, recs(i)%a%pmom, recs(i)%a%umu, recs(i)%a%phi
       end if
       if (recs(i)%ibdrf /= 0) write(u) recs(i)%bpar, recs(i)%bitem
     end do

@@ -407,7 +407,7 @@ subroutine run_once(phase)
   if (from_model) then
     temper = btemper
   else
-    temper = recs(1)%temper
+    temper = recs(1)%a%temper
   end if
   if (btemp < 0._kr) btemp = recs(1)%btemp          ! drt.f:334-335 defaults come with the profile
   if (ttemp < 0._kr) ttemp = recs(1)%ttemp
@@ -495,9 +495,9 @@ subroutine run_once(phase)
         dtauc(:, ip) = bdtauc(:, i)
         if (.not. use_mix) ssalb(:, ip) = bssalb(:, i)
       else
-        dtauc(:, ip) = recs(i)%dtauc; ssalb(:, ip) = recs(i)%ssalb
+        dtauc(:, ip) = recs(i)%a%dtauc; ssalb(:, ip) = recs(i)%a%ssalb
         pmom(:, :, ip) = 0                             ! (a run whose CORINT went off holds shorter moment arrays later)
-        pmom(0:recs(i)%nmom, :, ip) = recs(i)%pmom
+        pmom(0:recs(i)%nmom, :, ip) = recs(i)%a%pmom
       end if
     end if
     wvnmlo(ip) = recs(i)%wvnmlo; wvnmhi(ip) = recs(i)%wvnmhi
