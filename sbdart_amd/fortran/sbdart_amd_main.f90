@@ -424,7 +424,9 @@ subroutine run_once(phase)
     if (aborted) return
     if (any(gas_fail /= 0)) then
       ! TAUCOR's iteration failed somewhere: the reference prints its operands and stops there (taugas.f:7684-7690) --
-      ! the host's own gas terms reproduce that to the letter
+      ! the host's own gas terms reproduce that to the letter.  (Not by starting this executable again in place: an
+      ! exec of a process that holds a GPU context, followed by the new image opening the device under the same PID,
+      ! took the GPU box down twice in round 6.)
       call quit('the slant-path correction did not converge at some wavelength: run with SBD_HOST_GAS=1 for the reference''s report')
       return
     end if
