@@ -674,8 +674,8 @@ class Coll:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nwl", type=int, default=None,
                     help="spectral points: per GPU with --scaling weak (default 49152; W = 2.67x), of the ONE sweep with "
                          "--scaling strong (default 49152 x --gpus, so that every rank's shard is a bench-size batch and a "
