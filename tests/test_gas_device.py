@@ -183,3 +183,44 @@ def test_solve_with_the_gas_depths_left_on_the_devices(tmp_path):
         assert np.isfinite(a[0]).all() and np.abs(a[0]).max() > 0
         res[len(devices)] = a
     assert np.array_equal(res[1][0], res[3][0]) and np.array_equal(res[1][2], res[3][2])
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_gas_source_on_the_host_bit_for_bit_on_random_runs(tmp_path, seed):
+    """The pin above over seeded random atmospheres, absorber amounts, KDIST policies, zenith angles and grids (12 runs per
+    seed; a run the band model's input checks stop is skipped)."""
+    import random
+    if not os.access(HOST, os.X_OK):
+        pytest.skip("Fortran host not built")
+    rnd = random.Random(seed)
+    pick = lambda *a: rnd.choice(a)
+    compared = 0
+    for it in range(12):
+        lo = pick(.2, .25, .3, .4, .55, 1., 2., 3.5, 5., 8., 15.)
+        hi = min(lo * pick(1.1, 1.5, 2., 4.), 95.)
+        p = ["idatm=%d" % pick(1, 2, 3, 4, 5, 6), "wlinf=%g wlsup=%g wlinc=%g" % (lo, hi, pick(.01 * lo, -.01, -.003, .02 * lo)),
+             "sza=%g" % pick(0, 30, 60, 80, 88, 95), "nstr=4 iout=10", "kdist=%d" % pick(0, 1, 2, 3, 3, 3)]
+        if rnd.random() < .3: p.append("uw=%g" % pick(.1, .5, 2, 4, 8))
+        if rnd.random() < .3: p.append("uo3=%g" % pick(.1, .2, .35, .5))
+        if rnd.random() < .3: p.append("xco2=%g xch4=%g" % (pick(0, 280, 420, 800, 5000), pick(0, .8, 1.8, 3)))
+        if rnd.random() < .3: p.append("xo4=%g xn2o=%g" % (pick(0, 1, 2), pick(0, .1, .4)))
+        if rnd.random() < .2: p.append("xco=%g xno2=%g xso2=%g" % (pick(0, .5, 5), pick(0, 1e-4, 1e-2), pick(0, 1e-3, .1)))
+        if rnd.random() < .2: p.append("sclh2o=%g" % pick(1., 2.5))
+        if rnd.random() < .2: p.append("pbar=%g" % pick(800, 900, 1030))
+        if rnd.random() < .3: p.append("tcloud=%g zcloud=%g" % (pick(1, 20, 80), pick(1, 4, 9)))
+        if rnd.random() < .3: p.append("iaer=%d vis=%g" % (pick(1, 2, 3, 4), pick(5, 23)))
+        if rnd.random() < .25: p.append("ngrid=%d zgrid1=%g zgrid2=%g" % (pick(20, 40, 65), pick(.5, 1, 2), pick(10, 30)))
+        sub = tmp_path / f"r{it}"
+        sub.mkdir()
+        try:
+            d = dump(sub, " ".join(p))
+        except (FileNotFoundError, AssertionError):
+            continue
+        nk, wt, fail, slots = host_gas_terms(d)
+        npt = len(d["wl"])
+        assert not fail.any(), " ".join(p)
+        assert np.array_equal(np.bincount(d["point_of"], minlength=npt), nk), " ".join(p)
+        assert np.array_equal(slots[d["point_of"], d["kd"] - 1], d["dtaug"]), " ".join(p)
+        assert np.array_equal(wt[d["point_of"], d["kd"] - 1], d["wt"]), " ".join(p)
+        compared += 1
+    assert compared >= 8, compared
