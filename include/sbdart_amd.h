@@ -207,8 +207,9 @@ typedef struct {
                                  crosses PCIe.  point_of then counts the points of that gas call, and a fleet of several
                                  devices hands every item to the device that holds its point */
     int64_t lay_token;        /* (ABI v7) 0: the layer blocks are staged from `lay`.  Non-zero: the generation number
-                                 sbd_fleet_gas_terms returned for the blocks it left ON THE DEVICES (with dtaug == NULL
-                                 only): the solve reads those, `lay` is not touched; a number that is not the fleet's
+                                 sbd_fleet_gas_terms / sbd_fleet_point_terms returned for the blocks it left (or made) ON
+                                 THE DEVICES (with dtaug == NULL only): the solve reads those, `lay` is not touched and
+                                 may be NULL; a number that is not the fleet's
                                  current one is SBD_E_INVALID.  Residency is the caller's explicit statement, never
                                  inferred from pointer values */
 } sbd_mix_in;
