@@ -21,8 +21,9 @@
 // as plain serial code that compiles for the host and for the device.  On the device one wave serves one flagged system
 // (band_rcond_kernel, sbd_k_refband.hip): a lane per layer for the eigenproblems, then the band matrix.  On the host the
 // same source stands behind sbd_band_rcond_host (no GPU): with the host's exp it returns the oracle's RCOND bit for bit
-// (tests/test_refband_host.py) -- the pin of the kernel's source, like sbd_gas.hpp's.  Only systems the cheap filter flags
-// come here (a layer with kmin <= 1e-6 kmax, or a pivot ratio <= 1e-10 in the band LU): none on the headline sweep.
+// (tests/test_refband_host.py) -- the pin of the kernel's source, like sbd_gas.hpp's.  Only systems the cheap filter lists
+// come here (an item with a layer within 1e-12 of conservative scattering -- setup_kernel's mark, sbd_setup.hpp -- or a pivot
+// ratio <= 1e-10 in the band LU): none on the headline sweep.
 #pragma once
 #include <math.h>
 #include <stddef.h>
