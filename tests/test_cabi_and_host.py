@@ -171,3 +171,25 @@ def test_status_bits_agree_across_the_header_the_bindings_and_the_oracle():
             "WARN_PLKCONV": "WARN_PLKCONV"}
     for name, oname in same.items():
         assert ohdr[oname] == hdr[name], name
+
+
+@pytest.mark.parametrize("namelist", [
+    "idatm=4 wlinf=.5 wlsup=.7 wlinc=.01 nstr=8 iout=10 tcloud=5 zcloud=2 iaer=1 vis=20",
+    "idatm=2 wlinf=3.5 wlsup=12 wlinc=-.01 nstr=16 iout=20 nzen=3 uzen=0,40,80 nphi=2 phi=0,90 isalb=8 sc=.6,.2,.1,.06",
+])
+def test_work_item_files_survive_a_round_trip_through_the_host(tmp_path, namelist):
+    """The work-item file a first phase writes (`sbdart_amd --serve` / `--batch`: the band model's items, layer arrays from its
+    batch arrays) read back by the host and written again from the records' own arrays: byte for byte the same file.  No GPU:
+    SBD_DUMP_OPTICS stops before the engine."""
+    import subprocess
+    host = os.path.join(ROOT, "sbdart_amd", "bin", "sbdart_amd")
+    if not os.access(host, os.X_OK):
+        pytest.skip("Fortran host not built")
+    d = str(tmp_path)
+    with open(os.path.join(d, "INPUT"), "w") as f:
+        f.write(f"\n &INPUT\n {namelist}\n /\n")
+    a, b = os.path.join(d, "a.sbdrec"), os.path.join(d, "b.sbdrec")
+    subprocess.run([host], cwd=d, env=dict(os.environ, SBD_OPTICS=os.path.join(d, "none"), SBD_DUMP_OPTICS=a), capture_output=True)
+    subprocess.run([host], cwd=d, env=dict(os.environ, SBD_OPTICS=a, SBD_DUMP_OPTICS=b), capture_output=True)
+    assert os.path.getsize(a) > 1000
+    assert open(a, "rb").read() == open(b, "rb").read()
